@@ -1,0 +1,379 @@
+"""CPU oracle: a plain-torch fp32 restatement of pygda's A2GNN-style GDA training path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+Nothing under ``pygda_amd/`` imports it, and the product path raises if the HIP
+library is missing instead of falling back to this file.
+
+Every function cites the reference ``file:line`` (relative to the reference
+checkout of pygda-team/pygda v1.2.1) whose arithmetic it restates, op for op and
+in the same evaluation order, so that on CPU the results are bit-identical to the
+reference running on PyG's non-fused path (``index_select`` -> multiply ->
+scatter-add in edge order).
+
+Pinning status (see ``tests/golden/make_golden.py`` and DESIGN.md §3):
+  * ``guassian_kernel`` / ``get_MMD`` / ``MMD`` / ``GradReverse`` / ``Attention``:
+    PINNED -- checked against the reference's own files imported by path.
+  * ``gcn_norm`` / ``PropGCNConv`` / ``CachedGCNConv`` / ``A2GNNBase`` /
+    ``A2GNN.forward_model`` / GRADE / UDAGCN / AdaGCN restatements: checked against the
+    reference's own files executed on a build-authored stand-in for the PyG calls they
+    make (PyG, torch_scatter, torch_sparse are absent from the reference checkout and
+    cannot be installed here; pinned versions: torch_geometric>=2.4.0,
+    torch_scatter>=2.1.0, torch_sparse>=0.6.15, README.md:56-59).  The reference
+    holds no tests or golden vectors at that boundary, so for these symbols parity is
+    **UNPINNED at the PyG boundary**: the PyG semantics are restated from its
+    published algorithm (listed in ``tests/golden/_pyg_stub.py``).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+
+# ----------------------------------------------------------------------------
+# graph normalisation  (a1)
+# ----------------------------------------------------------------------------
+def add_remaining_self_loops(edge_index: Tensor, edge_weight: Tensor,
+                             fill_value: float, num_nodes: int
+                             ) -> Tuple[Tensor, Tensor]:
+    """PyG ``add_remaining_self_loops`` as called from prop_gcn_conv.py:72 and
+    cached_gcn_conv.py:95: existing loops are dropped from the edge list, one
+    loop per node is appended LAST in node order; a node that already had a loop
+    keeps that loop's weight (last writer in edge order wins)."""
+    row, col = edge_index[0], edge_index[1]
+    mask = row != col
+    loop_w = torch.full((num_nodes,), float(fill_value), dtype=edge_weight.dtype)
+    inv = ~mask
+    # sequential last-writer-wins, as CPU index_put does
+    loop_w[row[inv]] = edge_weight[inv]
+    loop_idx = torch.arange(num_nodes, dtype=torch.long)
+    ei = torch.cat([edge_index[:, mask], torch.stack([loop_idx, loop_idx])], dim=1)
+    ew = torch.cat([edge_weight[mask], loop_w])
+    return ei, ew
+
+
+def gcn_norm(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
+             improved: bool = False, add_self_loops: bool = True,
+             degree_side: str = "col") -> Tuple[Tensor, Tensor]:
+    """prop_gcn_conv.py:64-81 (degree over ``col``, the destination) and
+    cached_gcn_conv.py:88-103 (``degree_side='row'``, the source)."""
+    fill = 2.0 if improved else 1.0
+    if edge_weight is None:
+        edge_weight = torch.ones(edge_index.size(1), dtype=torch.float32)
+    if add_self_loops:
+        edge_index, edge_weight = add_remaining_self_loops(
+            edge_index, edge_weight, fill, num_nodes)
+    row, col = edge_index[0], edge_index[1]
+    idx = col if degree_side == "col" else row
+    deg = torch.zeros(num_nodes, dtype=edge_weight.dtype).index_add_(0, idx, edge_weight)
+    dis = deg.pow(-0.5)
+    dis[dis == float("inf")] = 0
+    return edge_index, dis[row] * edge_weight * dis[col]
+
+
+def propagate(edge_index: Tensor, edge_weight: Tensor, x: Tensor) -> Tensor:
+    """PyG ``MessagePassing.propagate`` with aggr='add', flow source->target, as
+    used at prop_gcn_conv.py:209 (+ message :238) and cached_gcn_conv.py:138,156:
+    ``out[i] = sum_{e: col[e]==i} w[e] * x[row[e]]`` accumulated in edge order."""
+    msg = edge_weight.view(-1, 1) * x.index_select(0, edge_index[0])
+    return torch.zeros(x.size(0), x.size(1), dtype=x.dtype).index_add_(0, edge_index[1], msg)
+
+
+def glorot_(t: Tensor) -> Tensor:
+    """PyG ``inits.glorot``: U(-a, a), a = sqrt(6 / (size(-2) + size(-1)))."""
+    a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+    with torch.no_grad():
+        t.uniform_(-a, a)
+    return t
+
+
+# ----------------------------------------------------------------------------
+# operators  (a2, a8, a10, a12)
+# ----------------------------------------------------------------------------
+class _Lin(nn.Module):
+    """PyG ``Linear(in, out, bias=False, weight_initializer='glorot')``: weight
+    ``[out, in]``, one glorot draw at construction (no torch kaiming draw)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels))
+        glorot_(self.weight)
+
+
+class PropGCNConv(nn.Module):
+    """prop_gcn_conv.py:84-215.  ``lin`` has no bias and weight ``[out, in]``; the
+    glorot draw happens twice (PyG ``Linear.__init__`` and then
+    ``PropGCNConv.reset_parameters`` :144-147), which matters only for RNG-stream
+    parity of freshly initialised models."""
+
+    def __init__(self, in_channels: int, out_channels: int, improved: bool = False,
+                 add_self_loops: bool = True, normalize: bool = True, bias: bool = True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.improved, self.add_self_loops, self.normalize = improved, add_self_loops, normalize
+        self.lin = _Lin(in_channels, out_channels)   # PyG Linear.__init__ draws glorot once
+        glorot_(self.lin.weight)          # PropGCNConv.reset_parameters
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+
+    def forward(self, x, edge_index, prop_nums=1, edge_weight=None):
+        if self.normalize:                                   # :182-192 (cached=False)
+            edge_index, edge_weight = gcn_norm(edge_index, edge_weight, x.size(0),
+                                               self.improved, self.add_self_loops, "col")
+        elif edge_weight is None:
+            edge_weight = torch.ones(edge_index.size(1), dtype=x.dtype)
+        out = F.linear(x, self.lin.weight)                   # :205
+        for _ in range(prop_nums):                           # :208-210
+            out = propagate(edge_index, edge_weight, out)
+        if self.bias is not None:                            # :212-213
+            out = out + self.bias
+        return out
+
+
+class GCNConv(PropGCNConv):
+    """PyG ``GCNConv`` as used by grade_base.py:58-61, adagcn_base.py:49-52,
+    gnn_base.py:65-71: lin (glorot, no bias) -> gcn_norm(col) -> 1 propagate -> + bias."""
+
+    def forward(self, x, edge_index, edge_weight=None):       # noqa: D102
+        return super().forward(x, edge_index, 1, edge_weight)
+
+
+class CachedGCNConv(nn.Module):
+    """cached_gcn_conv.py:35-174: ``x @ W`` (W ``[in, out]``), source-side degree
+    norm cached per ``cache_name``, one propagate, bias added in ``update``."""
+
+    def __init__(self, in_channels, out_channels, weight=None, bias=None,
+                 improved=False, use_bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.improved = in_channels, out_channels, improved
+        self.cache_dict = {}
+        if weight is None:
+            self.weight = nn.Parameter(torch.empty(in_channels, out_channels))
+            glorot_(self.weight)
+        else:
+            self.weight = weight
+        if bias is None:
+            self.bias = nn.Parameter(torch.zeros(out_channels)) if use_bias else None
+        else:
+            self.bias = bias
+
+    def forward(self, x, edge_index, cache_name="default_cache", edge_weight=None):
+        x = torch.matmul(x, self.weight)                                    # :130
+        if cache_name not in self.cache_dict:                               # :132-136
+            self.cache_dict[cache_name] = gcn_norm(edge_index, edge_weight, x.size(0),
+                                                   self.improved, True, "row")
+        ei, norm = self.cache_dict[cache_name]
+        out = propagate(ei, norm, x)                                        # :138,156
+        if self.bias is not None:                                           # :172-174
+            out = out + self.bias
+        return out
+
+
+class _GradReverse(torch.autograd.Function):
+    """reverse_layer.py:4-66: identity forward, ``-alpha * g`` backward."""
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        ctx.alpha = alpha
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.neg() * ctx.alpha, None
+
+
+def grad_reverse(x: Tensor, alpha: float) -> Tensor:
+    return _GradReverse.apply(x, alpha)
+
+
+class Attention(nn.Module):
+    """attention.py:6-55: softmax(Linear(h,1)) over K stacked views, weighted sum.
+    (The Dropout(0.1) the reference constructs at :26 is never applied.)"""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.dense_weight = nn.Linear(in_channels, 1)
+
+    def forward(self, inputs: List[Tensor]) -> Tensor:
+        stacked = torch.stack(inputs, dim=1)
+        weights = F.softmax(self.dense_weight(stacked), dim=1)
+        return torch.sum(stacked * weights, dim=1)
+
+
+# ----------------------------------------------------------------------------
+# MMD  (a7)
+# ----------------------------------------------------------------------------
+def guassian_kernel(source, target, kernel_mul=2.0, kernel_num=5, fix_sigma=None,
+                    chunk_rows: Optional[int] = None):
+    """mmd.py:4-55.  ``chunk_rows`` only bounds the size of the ``[n,n,d]``
+    temporary (the per-element arithmetic and its order are unchanged); ``None``
+    materialises it whole exactly as the reference does."""
+    n = int(source.size(0)) + int(target.size(0))
+    total = torch.cat([source, target], dim=0)
+    if chunk_rows is None:
+        t0 = total.unsqueeze(0).expand(n, n, total.size(1))
+        t1 = total.unsqueeze(1).expand(n, n, total.size(1))
+        L2 = ((t0 - t1) ** 2).sum(2)                                        # :43-46
+    else:
+        rows = []
+        for s in range(0, n, chunk_rows):
+            blk = total[s:s + chunk_rows]
+            rows.append(((total.unsqueeze(0) - blk.unsqueeze(1)) ** 2).sum(2))
+        L2 = torch.cat(rows, dim=0)
+    if fix_sigma:
+        bandwidth = fix_sigma
+    else:
+        bandwidth = (torch.sum(L2.data) + 1e-6) / (n ** 2 - n)              # :50
+    bandwidth = bandwidth / (kernel_mul ** (kernel_num // 2))               # :51
+    bw_list = [bandwidth * (kernel_mul ** i) for i in range(kernel_num)]    # :52
+    return sum(torch.exp(-L2 / bw) for bw in bw_list)                       # :53-55
+
+
+def get_MMD(source_feat, target_feat, kernel_mul=2.0, kernel_num=5, fix_sigma=None,
+            chunk_rows: Optional[int] = None):
+    """mmd.py:57-107."""
+    k = guassian_kernel(source_feat, target_feat, kernel_mul, kernel_num, fix_sigma, chunk_rows)
+    b = min(int(source_feat.size(0)), int(target_feat.size(0)))
+    return torch.mean(k[:b, :b] + k[b:, b:] - k[:b, b:] - k[b:, :b])        # :100-106
+
+
+def MMD(source_feat, target_feat, sampling_num=1000, times=5,
+        chunk_rows: Optional[int] = None, samples=None):
+    """mmd.py:109-159.  Row indices come from the CPU default generator
+    (``torch.randint`` without a device, :148-149) unless ``samples`` (a pair of
+    ``[times, sampling_num]`` int64 tensors) is supplied."""
+    if samples is None:
+        s_idx = torch.randint(source_feat.size(0), (times, sampling_num))
+        t_idx = torch.randint(target_feat.size(0), (times, sampling_num))
+    else:
+        s_idx, t_idx = samples
+    mmd = 0
+    for i in range(times):
+        mmd = mmd + get_MMD(source_feat[s_idx[i]], target_feat[t_idx[i]], chunk_rows=chunk_rows)
+    return mmd / times
+
+
+# ----------------------------------------------------------------------------
+# backbones and forward_model restatements  (a3, a4, a9, a13, a14)
+# ----------------------------------------------------------------------------
+class Graph:
+    """The reference's data contract: ``.x``, ``.edge_index``, ``.y``."""
+
+    def __init__(self, x, edge_index, y=None):
+        self.x, self.edge_index, self.y = x, edge_index, y
+
+
+class A2GNNBase(nn.Module):
+    """a2gnn_base.py:11-203 (node mode)."""
+
+    def __init__(self, in_dim, hid_dim, num_classes, num_layers=1, adv=False,
+                 dropout=0.1, act=F.relu):
+        super().__init__()
+        self.dropout, self.act, self.adv = dropout, act, adv
+        self.convs = nn.ModuleList([PropGCNConv(in_dim, hid_dim)])
+        for _ in range(num_layers - 1):
+            self.convs.append(PropGCNConv(hid_dim, hid_dim))
+        self.cls = PropGCNConv(hid_dim, num_classes)
+        if adv:
+            self.domain_discriminator = nn.Linear(hid_dim, 2)
+
+    def feat_bottleneck(self, x, edge_index, batch=None, prop_nums=30):      # :106-143
+        for conv in self.convs:
+            x = conv(x, edge_index, prop_nums)
+            x = self.act(x)
+            x = F.dropout(x, p=self.dropout, training=self.training)
+        return x
+
+    def feat_classifier(self, x, edge_index, batch=None, prop_nums=1):       # :145-176
+        return self.cls(x, edge_index, prop_nums)
+
+    def domain_classifier(self, x, alpha):                                   # :178-203
+        return self.domain_discriminator(grad_reverse(x, alpha))
+
+    def forward(self, data, prop_nums):                                      # :72-104
+        x = self.feat_bottleneck(data.x, data.edge_index, None, prop_nums)
+        return self.feat_classifier(x, data.edge_index, None, 1)
+
+
+def a2gnn_forward_model(net: A2GNNBase, src: Graph, tgt: Graph, alpha: float,
+                        s_pnums: int, t_pnums: int, adv: bool, weight: float,
+                        mmd_chunk_rows: Optional[int] = None, mmd_samples=None):
+    """a2gnn.py:146-213: CE(source) + weight * (MMD | GRL domain CE); the second
+    target forward (:211) is returned but not part of the loss."""
+    source_logits = net(src, s_pnums)                                        # :181
+    loss = F.nll_loss(F.log_softmax(source_logits, dim=1), src.y)            # :182
+    sf = net.feat_bottleneck(src.x, src.edge_index, None, s_pnums)           # :192
+    tf = net.feat_bottleneck(tgt.x, tgt.edge_index, None, t_pnums)           # :193
+    if adv:                                                                  # :196-205
+        sd = net.domain_classifier(sf, alpha)
+        td = net.domain_classifier(tf, alpha)
+        lab = torch.tensor([0] * src.x.shape[0] + [1] * tgt.x.shape[0])
+        loss = loss + weight * F.cross_entropy(torch.cat([sd, td], 0), lab)
+    else:                                                                    # :206-209
+        loss = loss + MMD(sf, tf, chunk_rows=mmd_chunk_rows, samples=mmd_samples) * weight
+    target_logits = net(tgt, t_pnums)                                        # :211
+    return loss, source_logits, target_logits
+
+
+class GRADEBase(nn.Module):
+    """grade_base.py:9-202 (node mode)."""
+
+    def __init__(self, in_dim, hid_dim, num_classes, num_layers=1, dropout=0.1,
+                 act=F.relu, disc="JS"):
+        super().__init__()
+        self.dropout, self.act, self.num_classes = dropout, act, num_classes
+        self.convs = nn.ModuleList([GCNConv(in_dim, hid_dim)])
+        for _ in range(num_layers - 1):
+            self.convs.append(GCNConv(hid_dim, hid_dim))
+        self.cls = nn.Linear(hid_dim, num_classes)
+        width = hid_dim * num_layers + num_classes * (1 if disc == "JS" else 2)
+        self.discriminator = nn.Sequential(nn.Linear(width, 2))
+
+    def forward(self, data):                                                 # :78-115
+        x, feats = data.x, []
+        for conv in self.convs:
+            x = conv(x, data.edge_index)
+            x = self.act(x)
+            x = F.dropout(x, p=self.dropout, training=self.training)
+            feats.append(x)
+        x = self.cls(x)
+        feats.append(x)
+        return x, torch.cat(feats, dim=1)
+
+
+def grade_forward_model(net: GRADEBase, src: Graph, tgt: Graph, alpha: float,
+                        disc: str, weight: float, mmd_chunk_rows=None, mmd_samples=None):
+    """grade.py:129-197 for disc in {'JS', 'MMD'}."""
+    s_logits, s_feats = net(src)
+    t_logits, t_feats = net(tgt)
+    loss = F.nll_loss(F.log_softmax(s_logits, dim=1), src.y)
+    if disc == "JS":                                                         # :169-176
+        preds = net.discriminator(grad_reverse(torch.cat([s_feats, t_feats], 0), alpha))
+        lab = torch.tensor([0] * src.x.size(0) + [1] * tgt.x.size(0))
+        dom = F.cross_entropy(preds, lab)
+    elif disc == "MMD":                                                      # :177-182
+        m = min(src.x.size(0), tgt.x.size(0))
+        dom = MMD(s_feats[:m], t_feats[:m], chunk_rows=mmd_chunk_rows, samples=mmd_samples)
+    else:
+        raise NotImplementedError(disc)
+    return loss + dom * weight, s_logits, t_logits
+
+
+# ----------------------------------------------------------------------------
+# the CPU baseline step (bench.py cpu_baseline, kind="port")
+# ----------------------------------------------------------------------------
+def a2gnn_train_step(net: A2GNNBase, opt: torch.optim.Optimizer, src: Graph, tgt: Graph,
+                     alpha: float, s_pnums: int, t_pnums: int, adv: bool, weight: float,
+                     mmd_chunk_rows: Optional[int] = None):
+    """One iteration of the step loop a2gnn.py:308-319."""
+    net.train()
+    loss, s_logits, _ = a2gnn_forward_model(net, src, tgt, alpha, s_pnums, t_pnums, adv,
+                                            weight, mmd_chunk_rows)
+    val = loss.item()
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return val, s_logits

@@ -1,0 +1,249 @@
+"""Build-authored, test-only stand-in for the third-party modules the reference's
+hot-path files import (torch_geometric, torch_scatter, torch_sparse), used ONLY by
+``make_golden.py`` in the build container to execute the reference's own files
+(loaded by path from the reference checkout) and record golden vectors.
+
+None of those wheels is vendored in the reference or installable here, and the
+reference has no tests pinning results at this boundary, so the semantics below are
+restated from PyG's published behaviour (>=2.4).  Each numbered item is an
+ASSUMPTION; goldens produced through this stub are "parity unpinned at the PyG
+boundary" (the MMD / GradReverse / Attention goldens do not go through it).
+
+ 1. ``MessagePassing.propagate(edge_index, **kw)``, aggr='add', flow
+    source->target: gather ``x_j = x[edge_index[0]]``, call ``message`` with the
+    kwargs its signature names, scatter-add into ``edge_index[1]`` sequentially in
+    edge order, then ``update``.
+ 2. ``add_remaining_self_loops``: drop existing loops, append one loop per node LAST
+    in node order, loop weight = existing loop's weight else ``fill_value``.
+ 3. ``scatter_add(src, index, dim=0, dim_size=N)`` = zeros(N).index_add_(0, index, src).
+ 4. ``Linear(in, out, bias=False, weight_initializer='glorot')``: weight ``[out,in]``
+    ~ U(-a, a), a = sqrt(6/(in+out)), drawn once in ``__init__``;
+    ``reset_parameters()`` draws again.  ``inits.glorot/zeros`` likewise.
+ 5. ``GCNConv`` = lin(no bias, glorot) -> gcn_norm(destination degree, self loops)
+    -> one propagate -> + bias(zeros); its ``__init__`` also calls reset_parameters().
+ 6. ``NeighborLoader(data, [-1]*L, batch_size=N)``: one batch = the whole graph,
+    nodes and edges in input order.
+"""
+import inspect
+import math
+import sys
+import types
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+
+def _mod(name):
+    m = types.ModuleType(name)
+    m.__path__ = []          # allow sub-imports
+    sys.modules[name] = m
+    return m
+
+
+def maybe_num_nodes(edge_index, num_nodes=None):
+    if num_nodes is not None:
+        return num_nodes
+    return int(edge_index.max()) + 1 if edge_index.numel() > 0 else 0
+
+
+def scatter_add(src, index, dim=0, out=None, dim_size=None):
+    assert dim == 0
+    n = dim_size if dim_size is not None else int(index.max()) + 1
+    shape = (n,) + tuple(src.shape[1:])
+    return torch.zeros(shape, dtype=src.dtype, device=src.device).index_add_(0, index, src)
+
+
+def add_remaining_self_loops(edge_index, edge_attr=None, fill_value=None, num_nodes=None):
+    N = maybe_num_nodes(edge_index, num_nodes)
+    mask = edge_index[0] != edge_index[1]
+    loop_index = torch.arange(0, N, dtype=torch.long, device=edge_index.device)
+    loop_index = loop_index.unsqueeze(0).repeat(2, 1)
+    if edge_attr is not None:
+        loop_attr = edge_attr.new_full((N,) + tuple(edge_attr.shape[1:]), fill_value)
+        inv_mask = ~mask
+        loop_attr[edge_index[0][inv_mask]] = edge_attr[inv_mask]
+        edge_attr = torch.cat([edge_attr[mask], loop_attr], dim=0)
+    edge_index = torch.cat([edge_index[:, mask], loop_index], dim=1)
+    return edge_index, edge_attr
+
+
+def glorot(t):
+    if t is not None:
+        a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+        t.data.uniform_(-a, a)
+
+
+def zeros(t):
+    if t is not None:
+        t.data.fill_(0)
+
+
+class Linear(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, bias=True, weight_initializer=None,
+                 bias_initializer=None):
+        super().__init__()
+        assert weight_initializer == 'glorot' and not bias
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = torch.nn.Parameter(torch.empty(out_channels, in_channels))
+        self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        glorot(self.weight)
+
+    def forward(self, x):
+        return torch.nn.functional.linear(x, self.weight, self.bias)
+
+
+class MessagePassing(torch.nn.Module):
+    def __init__(self, aggr='add', flow='source_to_target', node_dim=-2, **kwargs):
+        super().__init__()
+        assert aggr == 'add' and flow == 'source_to_target'
+        self.aggr, self.flow, self.node_dim = aggr, flow, node_dim
+
+    def propagate(self, edge_index, size=None, **kwargs):
+        x = kwargs['x']
+        n = x.size(0)
+        params = inspect.signature(self.message).parameters
+        margs = {}
+        for name in params:
+            if name == 'x_j':
+                margs[name] = x.index_select(0, edge_index[0])
+            elif name == 'x_i':
+                margs[name] = x.index_select(0, edge_index[1])
+            else:
+                margs[name] = kwargs.get(name)
+        msg = self.message(**margs)
+        out = torch.zeros((n,) + tuple(msg.shape[1:]), dtype=msg.dtype).index_add_(0, edge_index[1], msg)
+        return self.update(out)
+
+    def message(self, x_j):
+        return x_j
+
+    def update(self, aggr_out):
+        return aggr_out
+
+
+def _gcn_norm(edge_index, edge_weight, num_nodes, improved=False, add_self_loops=True):
+    fill = 2. if improved else 1.
+    if edge_weight is None:
+        edge_weight = torch.ones((edge_index.size(1),), dtype=torch.float32)
+    if add_self_loops:
+        edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, fill, num_nodes)
+    row, col = edge_index[0], edge_index[1]
+    deg = scatter_add(edge_weight, col, dim=0, dim_size=num_nodes)
+    dis = deg.pow_(-0.5)
+    dis.masked_fill_(dis == float('inf'), 0)
+    return edge_index, dis[row] * edge_weight * dis[col]
+
+
+class GCNConv(MessagePassing):
+    def __init__(self, in_channels, out_channels, improved=False, cached=False,
+                 add_self_loops=True, normalize=True, bias=True, **kwargs):
+        super().__init__(aggr='add')
+        self.improved = improved
+        self.lin = Linear(in_channels, out_channels, bias=False, weight_initializer='glorot')
+        self.bias = torch.nn.Parameter(torch.empty(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin.reset_parameters()
+        zeros(self.bias)
+
+    def forward(self, x, edge_index, edge_weight=None):
+        edge_index, edge_weight = _gcn_norm(edge_index, edge_weight, x.size(0), self.improved)
+        x = self.lin(x)
+        out = self.propagate(edge_index, x=x, edge_weight=edge_weight)
+        return out + self.bias
+
+    def message(self, x_j, edge_weight):
+        return edge_weight.view(-1, 1) * x_j
+
+
+def global_mean_pool(x, batch, size=None):
+    n = int(batch.max()) + 1 if size is None else size
+    s = torch.zeros(n, x.size(1), dtype=x.dtype).index_add_(0, batch, x)
+    c = torch.zeros(n, dtype=x.dtype).index_add_(0, batch, torch.ones_like(batch, dtype=x.dtype))
+    return s / c.clamp(min=1).view(-1, 1)
+
+
+class Data:
+    def __init__(self, x=None, edge_index=None, y=None, **kw):
+        self.x, self.edge_index, self.y = x, edge_index, y
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def to(self, device):
+        return self
+
+    @property
+    def num_nodes(self):
+        return self.x.size(0)
+
+
+class NeighborLoader:
+    """Full-batch only (assumption 6)."""
+
+    def __init__(self, data, num_neighbors, batch_size=1, **kw):
+        assert all(k == -1 for k in num_neighbors) and batch_size >= data.x.size(0)
+        self.data = data
+
+    def __iter__(self):
+        yield self.data
+
+    def __len__(self):
+        return 1
+
+
+class DataLoader:
+    def __init__(self, *a, **k):
+        raise NotImplementedError('graph mode is out of scope')
+
+
+def install():
+    """Register the stand-ins in ``sys.modules`` (idempotent)."""
+    if 'torch_geometric' in sys.modules and getattr(sys.modules['torch_geometric'], '_gda_stub', False):
+        return
+    tg = _mod('torch_geometric')
+    tg._gda_stub = True
+    typing_m = _mod('torch_geometric.typing')
+    typing_m.Adj = Tensor
+    typing_m.OptTensor = Optional[Tensor]
+    typing_m.PairTensor = Tuple[Tensor, Tensor]
+    typing_m.OptPairTensor = Tuple[Tensor, Optional[Tensor]]
+    typing_m.Size = Optional[Tuple[int, int]]
+    typing_m.NoneType = type(None)
+    nn_m = _mod('torch_geometric.nn')
+    nn_m.global_mean_pool = global_mean_pool
+    nn_m.GCNConv = GCNConv
+    nn_m.MessagePassing = MessagePassing
+    for missing in ('SAGEConv', 'GATConv', 'GINConv'):
+        setattr(nn_m, missing, None)
+    inits = _mod('torch_geometric.nn.inits')
+    inits.glorot, inits.zeros = glorot, zeros
+    dense = _mod('torch_geometric.nn.dense')
+    lin = _mod('torch_geometric.nn.dense.linear')
+    lin.Linear = Linear
+    dense.Linear = Linear
+    conv = _mod('torch_geometric.nn.conv')
+    conv.MessagePassing = MessagePassing
+    conv.GCNConv = GCNConv
+    utils = _mod('torch_geometric.utils')
+    utils.add_remaining_self_loops = add_remaining_self_loops
+    nn_utils = _mod('torch_geometric.utils.num_nodes')
+    nn_utils.maybe_num_nodes = maybe_num_nodes
+    loader = _mod('torch_geometric.loader')
+    loader.NeighborLoader, loader.DataLoader = NeighborLoader, DataLoader
+    data = _mod('torch_geometric.data')
+    data.Data = Data
+    ts = _mod('torch_scatter')
+    ts.scatter_add = scatter_add
+    tsp = _mod('torch_sparse')
+
+    class SparseTensor:      # never instantiated: pygda callers pass edge_index tensors
+        pass
+
+    tsp.SparseTensor = SparseTensor
+    for name in ('matmul', 'fill_diag', 'sum', 'mul'):
+        setattr(tsp, name, None)

@@ -1,0 +1,268 @@
+"""Regenerate the golden fixtures in this directory by RUNNING THE REFERENCE.
+
+Build-container only (needs the reference checkout, default /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python -m tests.golden.make_golden [name ...]
+
+Each fixture is a small ``.npz`` of inputs, weights and the outputs / gradients the
+reference's own code produced for them.  MMD / GradReverse / Attention fixtures come
+from the reference files imported directly (true oracle).  Everything that touches
+message passing runs the reference's files on ``_pyg_stub`` (see its header for the
+assumptions; "parity unpinned at the PyG boundary").
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from ._ref_loader import load_reference
+from . import _pyg_stub
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(8)
+
+
+# ---------------------------------------------------------------- helpers --
+def make_graph(n, e, seed, undirected=True, self_loops=0, dups=0, isolated=True):
+    """Random edge list with the edge cases gcn_norm must handle."""
+    g = torch.Generator().manual_seed(seed)
+    hi = n - 1 if isolated else n            # node n-1 stays isolated
+    src = torch.randint(0, hi, (e,), generator=g)
+    dst = torch.randint(0, hi, (e,), generator=g)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    if undirected:
+        src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+    if dups:
+        src = torch.cat([src, src[:dups]])
+        dst = torch.cat([dst, dst[:dups]])
+    if self_loops:
+        l = torch.randint(0, hi, (self_loops,), generator=g)
+        src, dst = torch.cat([src, l]), torch.cat([dst, l])
+    perm = torch.randperm(src.numel(), generator=g)
+    return torch.stack([src[perm], dst[perm]]).long()
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def sd_arrays(module, prefix="param/"):
+    return {prefix + k: np_(v) for k, v in module.state_dict().items()}
+
+
+def grads(module, prefix="grad/"):
+    return {prefix + k: np_(p.grad) for k, p in module.named_parameters() if p.grad is not None}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ---------------------------------------------------------------- fixtures --
+def fx_mmd(ref):
+    """True oracle: mmd.py imported directly."""
+    for tag, (ns, nt, d, seed) in {"small": (50, 70, 8, 1), "mid": (300, 200, 32, 2),
+                                   "a2gnn": (1200, 900, 128, 3)}.items():
+        g = torch.Generator().manual_seed(seed)
+        s = torch.randn(ns, d, generator=g).relu_().requires_grad_()
+        t = (torch.randn(nt, d, generator=g) * 1.3 + 0.2).relu_().requires_grad_()
+        torch.manual_seed(100 + seed)
+        loss = ref.MMD(s, t)
+        loss.backward()
+        torch.manual_seed(100 + seed)                   # replay the CPU randint stream
+        si = torch.randint(ns, (5, 1000)); ti = torch.randint(nt, (5, 1000))
+        save(f"mmd_{tag}", src=np_(s), tgt=np_(t), seed=np.int64(100 + seed),
+             src_idx=np_(si), tgt_idx=np_(ti), loss=np_(loss), gsrc=np_(s.grad), gtgt=np_(t.grad))
+    # get_MMD on explicit rows, equal and small n, incl. gradient
+    g = torch.Generator().manual_seed(7)
+    s = torch.randn(96, 24, generator=g).requires_grad_()
+    t = (torch.randn(96, 24, generator=g) + 0.5).requires_grad_()
+    k = ref.guassian_kernel(s, t)
+    loss = ref.get_MMD(s, t)
+    loss.backward()
+    save("get_mmd_96", src=np_(s), tgt=np_(t), kernel=np_(k), loss=np_(loss),
+         gsrc=np_(s.grad), gtgt=np_(t.grad))
+
+
+def fx_grl_attention(ref):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(17, 6, generator=g).requires_grad_()
+    w = torch.randn(17, 6, generator=g)
+    y = ref.GradReverse.apply(x, 0.37)
+    (y * w).sum().backward()
+    torch.manual_seed(12)
+    att = ref.Attention(6)
+    a, b = torch.randn(17, 6, generator=g), torch.randn(17, 6, generator=g)
+    out = att([a, b])
+    save("grl_attention", x=np_(x), w=np_(w), alpha=np.float64(0.37), y=np_(y), gx=np_(x.grad),
+         a=np_(a), b=np_(b), att_out=np_(out), **sd_arrays(att))
+
+
+GRAPHS = {
+    # name: (n, e, seed, undirected, self_loops, dups)
+    "g7": (7, 9, 21, False, 2, 2),
+    "g64": (64, 150, 22, True, 3, 5),
+    "g300d": (300, 1200, 23, False, 6, 10),
+    "g300u": (300, 700, 24, True, 0, 0),
+}
+
+
+def fx_gcn_norm(ref):
+    out = {}
+    for name, (n, e, seed, und, sl, dp) in GRAPHS.items():
+        ei = make_graph(n, e, seed, und, sl, dp)
+        g = torch.Generator().manual_seed(seed + 100)
+        w = torch.rand(ei.size(1), generator=g) + 0.1
+        out[f"{name}/edge_index"] = np_(ei)
+        out[f"{name}/n"] = np.int64(n)
+        out[f"{name}/w"] = np_(w)
+        for tag, ew, improved in (("plain", None, False), ("improved", None, True), ("weighted", w, False)):
+            ei2, w2 = ref.gcn_norm(ei, ew, n, improved, True)
+            out[f"{name}/{tag}/col/edge_index"], out[f"{name}/{tag}/col/weight"] = np_(ei2), np_(w2)
+            ei3, w3 = ref.CachedGCNConv.norm(ei, n, ew, improved, torch.float32)
+            out[f"{name}/{tag}/row/edge_index"], out[f"{name}/{tag}/row/weight"] = np_(ei3), np_(w3)
+    save("gcn_norm", **out)
+
+
+def fx_prop_gcn_conv(ref):
+    out = {}
+    for name, fin, fout in (("g7", 5, 3), ("g64", 16, 8), ("g300d", 32, 128), ("g300u", 24, 5)):
+        n, e, seed, und, sl, dp = GRAPHS[name]
+        ei = make_graph(n, e, seed, und, sl, dp)
+        torch.manual_seed(seed)
+        conv = ref.PropGCNConv(fin, fout)
+        with torch.no_grad():
+            conv.bias.uniform_(-0.1, 0.1)
+        g = torch.Generator().manual_seed(seed + 7)
+        x0 = torch.randn(n, fin, generator=g)
+        gy = torch.randn(n, fout, generator=g)
+        out[f"{name}/edge_index"], out[f"{name}/x"], out[f"{name}/gy"] = np_(ei), np_(x0), np_(gy)
+        out.update({f"{name}/{k}": v for k, v in sd_arrays(conv).items()})
+        for k in (0, 1, 3, 10):
+            x = x0.clone().requires_grad_()
+            conv.zero_grad()
+            y = conv(x, ei, k)
+            (y * gy).sum().backward()
+            out[f"{name}/k{k}/y"], out[f"{name}/k{k}/gx"] = np_(y), np_(x.grad)
+            out[f"{name}/k{k}/gW"], out[f"{name}/k{k}/gb"] = np_(conv.lin.weight.grad), np_(conv.bias.grad)
+    save("prop_gcn_conv", **out)
+
+
+def fx_cached_gcn_conv(ref):
+    out = {}
+    for name, fin, fout in (("g7", 5, 3), ("g300d", 32, 16)):
+        n, e, seed, und, sl, dp = GRAPHS[name]
+        ei = make_graph(n, e, seed, und, sl, dp)
+        torch.manual_seed(seed)
+        conv = ref.CachedGCNConv(fin, fout)
+        with torch.no_grad():
+            conv.bias.uniform_(-0.1, 0.1)
+        g = torch.Generator().manual_seed(seed + 9)
+        x = torch.randn(n, fin, generator=g).requires_grad_()
+        gy = torch.randn(n, fout, generator=g)
+        y = conv(x, ei, "k1")
+        (y * gy).sum().backward()
+        # cache reuse: a different edge_index under the same key is ignored (:132-136)
+        y_again = conv(x.detach(), ei[:, : ei.size(1) // 2], "k1")
+        out.update({f"{name}/edge_index": np_(ei), f"{name}/x": np_(x), f"{name}/gy": np_(gy),
+                    f"{name}/y": np_(y), f"{name}/y_cached": np_(y_again), f"{name}/gx": np_(x.grad),
+                    f"{name}/gW": np_(conv.weight.grad), f"{name}/gb": np_(conv.bias.grad)})
+        out.update({f"{name}/{k}": v for k, v in sd_arrays(conv).items()})
+    save("cached_gcn_conv", **out)
+
+
+def _domain_pair(seed, ns=300, nt=200, f=24, c=5):
+    es = make_graph(ns, 700, seed, True, 2, 3)
+    et = make_graph(nt, 420, seed + 1, True, 1, 0)
+    g = torch.Generator().manual_seed(seed + 2)
+    xs = (torch.rand(ns, f, generator=g) < 0.15).float()
+    xt = (torch.rand(nt, f, generator=g) < 0.2).float()
+    ys = torch.randint(0, c, (ns,), generator=g)
+    yt = torch.randint(0, c, (nt,), generator=g)
+    return _pyg_stub.Data(x=xs, edge_index=es, y=ys), _pyg_stub.Data(x=xt, edge_index=et, y=yt)
+
+
+def _pair_arrays(s, t):
+    return dict(src_x=np_(s.x), src_ei=np_(s.edge_index), src_y=np_(s.y),
+                tgt_x=np_(t.x), tgt_ei=np_(t.edge_index), tgt_y=np_(t.y))
+
+
+def fx_a2gnn(ref):
+    """A2GNNBase logits; A2GNN.forward_model loss + grads (dropout=0), MMD and adv;
+    a 3-epoch fit() trajectory from a fixed seed (init weights, MMD samples and all)."""
+    s, t = _domain_pair(31)
+    for adv in (False, True):
+        m = ref.A2GNN(24, 16, 5, num_layers=2, dropout=0.0, s_pnums=0, t_pnums=10, adv=adv,
+                      weight=10, device="cpu", epoch=3, verbose=0)
+        torch.manual_seed(41)
+        m.a2gnn = m.init_model()
+        m.a2gnn.train()
+        torch.manual_seed(42)
+        loss, sl, tl = m.forward_model(s, t, 0.6)
+        loss.backward()
+        arrs = dict(_pair_arrays(s, t), loss=np_(loss), src_logits=np_(sl), tgt_logits=np_(tl),
+                    alpha=np.float64(0.6), mmd_seed=np.int64(42), init_seed=np.int64(41))
+        arrs.update(sd_arrays(m.a2gnn)); arrs.update(grads(m.a2gnn))
+        m.a2gnn.eval()
+        with torch.no_grad():
+            arrs["eval_tgt_logits"] = np_(m.a2gnn(t, 10))
+            arrs["eval_src_logits"] = np_(m.a2gnn(s, 0))
+        save("a2gnn_forward_adv" if adv else "a2gnn_forward_mmd", **arrs)
+
+    # fit trajectory
+    import pygda.models.a2gnn as a2mod
+    losses, accs = [], []
+    orig = a2mod.logger
+    a2mod.logger = lambda **kw: (losses.append(kw["loss"]), accs.append(kw["source_train_acc"]))
+    try:
+        for adv in (False, True):
+            losses.clear(); accs.clear()
+            m = ref.A2GNN(24, 16, 5, num_layers=2, dropout=0.0, s_pnums=0, t_pnums=10, adv=adv,
+                          weight=10, lr=0.01, weight_decay=0.005, device="cpu", epoch=3, verbose=0)
+            torch.manual_seed(51)
+            m.fit(s, t)
+            logits, labels = m.predict(t)
+            slogits, _ = m.predict(s, source=True)
+            arrs = dict(_pair_arrays(s, t), seed=np.int64(51), losses=np.array(losses, dtype=np.float64),
+                        accs=np.array(accs, dtype=np.float64), tgt_logits=np_(logits), tgt_labels=np_(labels),
+                        src_logits=np_(slogits))
+            arrs.update(sd_arrays(m.a2gnn, "final/"))
+            save("a2gnn_fit3_adv" if adv else "a2gnn_fit3_mmd", **arrs)
+    finally:
+        a2mod.logger = orig
+
+
+def fx_grade(ref):
+    s, t = _domain_pair(61)
+    for disc in ("JS", "MMD"):
+        m = ref.GRADE(24, 8, 5, num_layers=3, dropout=0.0, disc=disc, weight=0.01, device="cpu",
+                      epoch=3, verbose=0)
+        torch.manual_seed(71)
+        m.grade = m.init_model()
+        m.grade.train()
+        torch.manual_seed(72)
+        loss, sl, tl = m.forward_model(s, t, 0.45)
+        loss.backward()
+        arrs = dict(_pair_arrays(s, t), loss=np_(loss), src_logits=np_(sl), tgt_logits=np_(tl),
+                    alpha=np.float64(0.45), mmd_seed=np.int64(72), init_seed=np.int64(71))
+        arrs.update(sd_arrays(m.grade)); arrs.update(grads(m.grade))
+        save(f"grade_forward_{disc.lower()}", **arrs)
+
+
+FIXTURES = {"mmd": fx_mmd, "grl_attention": fx_grl_attention, "gcn_norm": fx_gcn_norm,
+            "prop_gcn_conv": fx_prop_gcn_conv, "cached_gcn_conv": fx_cached_gcn_conv,
+            "a2gnn": fx_a2gnn, "grade": fx_grade}
+
+
+def main(argv):
+    ref = load_reference()
+    for name in (argv or list(FIXTURES)):
+        FIXTURES[name](ref)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

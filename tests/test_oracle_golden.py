@@ -1,0 +1,147 @@
+"""CPU: the oracle (oracle/pygda_cpu.py) against the golden vectors recorded from the
+reference (tests/golden/make_golden.py).  Same ops in the same order -> bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pygda_cpu as O
+from tests.conftest import T, load_golden, sub
+
+
+def eq(a, b, tol=0.0):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    if tol == 0.0:
+        np.testing.assert_array_equal(a, b)
+    else:
+        np.testing.assert_allclose(a, b, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("tag", ["small", "mid", "a2gnn"])
+def test_mmd_true_oracle(tag):
+    g = load_golden(f"mmd_{tag}")
+    s, t = T(g["src"]).requires_grad_(), T(g["tgt"]).requires_grad_()
+    torch.manual_seed(int(g["seed"]))
+    loss = O.MMD(s, t)                       # draws its own indices from the CPU generator
+    loss.backward()
+    eq(loss, g["loss"]); eq(s.grad, g["gsrc"]); eq(t.grad, g["gtgt"])
+    # explicit-sample entry point + row chunking leave the arithmetic unchanged
+    s2, t2 = T(g["src"]).requires_grad_(), T(g["tgt"]).requires_grad_()
+    loss2 = O.MMD(s2, t2, chunk_rows=256, samples=(T(g["src_idx"]), T(g["tgt_idx"])))
+    eq(loss2, g["loss"], 1e-6)
+
+
+def test_get_mmd_and_kernel():
+    g = load_golden("get_mmd_96")
+    s, t = T(g["src"]).requires_grad_(), T(g["tgt"]).requires_grad_()
+    eq(O.guassian_kernel(s, t), g["kernel"])
+    loss = O.get_MMD(s, t)
+    loss.backward()
+    eq(loss, g["loss"]); eq(s.grad, g["gsrc"]); eq(t.grad, g["gtgt"])
+
+
+def test_grl_attention():
+    g = load_golden("grl_attention")
+    x = T(g["x"]).requires_grad_()
+    y = O.grad_reverse(x, float(g["alpha"]))
+    (y * T(g["w"])).sum().backward()
+    eq(y, g["y"]); eq(x.grad, g["gx"])
+    att = O.Attention(6)
+    att.load_state_dict({k: T(v) for k, v in sub(g, "param/").items()})
+    eq(att([T(g["a"]), T(g["b"])]), g["att_out"])
+
+
+@pytest.mark.parametrize("name", ["g7", "g64", "g300d", "g300u"])
+def test_gcn_norm(name):
+    g = sub(load_golden("gcn_norm"), name + "/")
+    ei, n, w = T(g["edge_index"]), int(g["n"]), T(g["w"])
+    for tag, ew, improved in (("plain", None, False), ("improved", None, True), ("weighted", w, False)):
+        for side in ("col", "row"):
+            ei2, w2 = O.gcn_norm(ei, ew, n, improved, True, side)
+            eq(ei2, g[f"{tag}/{side}/edge_index"]); eq(w2, g[f"{tag}/{side}/weight"])
+
+
+@pytest.mark.parametrize("name,fin,fout", [("g7", 5, 3), ("g64", 16, 8), ("g300d", 32, 128), ("g300u", 24, 5)])
+def test_prop_gcn_conv(name, fin, fout):
+    g = sub(load_golden("prop_gcn_conv"), name + "/")
+    conv = O.PropGCNConv(fin, fout)
+    conv.load_state_dict({k: T(v) for k, v in sub(g, "param/").items()})
+    for k in (0, 1, 3, 10):
+        x = T(g["x"]).requires_grad_()
+        conv.zero_grad()
+        y = conv(x, T(g["edge_index"]), k)
+        (y * T(g["gy"])).sum().backward()
+        eq(y, g[f"k{k}/y"]); eq(x.grad, g[f"k{k}/gx"])
+        eq(conv.lin.weight.grad, g[f"k{k}/gW"]); eq(conv.bias.grad, g[f"k{k}/gb"])
+
+
+@pytest.mark.parametrize("name,fin,fout", [("g7", 5, 3), ("g300d", 32, 16)])
+def test_cached_gcn_conv(name, fin, fout):
+    g = sub(load_golden("cached_gcn_conv"), name + "/")
+    conv = O.CachedGCNConv(fin, fout)
+    conv.load_state_dict({k: T(v) for k, v in sub(g, "param/").items()})
+    x = T(g["x"]).requires_grad_()
+    y = conv(x, T(g["edge_index"]), "k1")
+    (y * T(g["gy"])).sum().backward()
+    eq(y, g["y"]); eq(x.grad, g["gx"]); eq(conv.weight.grad, g["gW"]); eq(conv.bias.grad, g["gb"])
+    ei = T(g["edge_index"])
+    eq(conv(x.detach(), ei[:, : ei.size(1) // 2], "k1"), g["y_cached"])
+
+
+@pytest.mark.parametrize("adv", [False, True])
+def test_a2gnn_forward_model(adv):
+    g = load_golden("a2gnn_forward_adv" if adv else "a2gnn_forward_mmd")
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    # RNG-stream parity of the initialisation (double glorot draw per conv)
+    torch.manual_seed(int(g["init_seed"]))
+    net = O.A2GNNBase(24, 16, 5, num_layers=2, adv=adv, dropout=0.0)
+    for k, v in sub(g, "param/").items():
+        eq(net.state_dict()[k], v)
+    net.train()
+    torch.manual_seed(int(g["mmd_seed"]))
+    loss, sl, tl = O.a2gnn_forward_model(net, src, tgt, float(g["alpha"]), 0, 10, adv, 10)
+    loss.backward()
+    eq(loss, g["loss"]); eq(sl, g["src_logits"]); eq(tl, g["tgt_logits"])
+    for k, v in sub(g, "grad/").items():
+        eq(dict(net.named_parameters())[k].grad, v)
+    net.eval()
+    with torch.no_grad():
+        eq(net(tgt, 10), g["eval_tgt_logits"]); eq(net(src, 0), g["eval_src_logits"])
+
+
+@pytest.mark.parametrize("adv", [False, True])
+def test_a2gnn_fit_trajectory(adv):
+    """Three epochs of the a2gnn.py:300-336 loop from a fixed seed."""
+    g = load_golden("a2gnn_fit3_adv" if adv else "a2gnn_fit3_mmd")
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    torch.manual_seed(int(g["seed"]))
+    net = O.A2GNNBase(24, 16, 5, num_layers=2, adv=adv, dropout=0.0)
+    opt = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=0.005)
+    losses = []
+    for epoch in range(3):
+        alpha = 2. / (1. + np.exp(-10. * float(epoch) / 3)) - 1
+        val, _ = O.a2gnn_train_step(net, opt, src, tgt, alpha, 0, 10, adv, 10)
+        losses.append(val)
+    eq(np.array(losses), g["losses"])
+    net.eval()
+    with torch.no_grad():
+        eq(net(tgt, 10), g["tgt_logits"]); eq(net(src, 0), g["src_logits"])
+
+
+@pytest.mark.parametrize("disc", ["JS", "MMD"])
+def test_grade_forward_model(disc):
+    g = load_golden(f"grade_forward_{disc.lower()}")
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    torch.manual_seed(int(g["init_seed"]))
+    net = O.GRADEBase(24, 8, 5, num_layers=3, dropout=0.0, disc=disc)
+    for k, v in sub(g, "param/").items():
+        eq(net.state_dict()[k], v)
+    net.train()
+    torch.manual_seed(int(g["mmd_seed"]))
+    loss, sl, tl = O.grade_forward_model(net, src, tgt, float(g["alpha"]), disc, 0.01)
+    loss.backward()
+    eq(loss, g["loss"]); eq(sl, g["src_logits"]); eq(tl, g["tgt_logits"])
+    for k, v in sub(g, "grad/").items():
+        eq(dict(net.named_parameters())[k].grad, v)
