@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""Headline benchmark: A2GNN training-step throughput on ACMv9->DBLPv7 shapes.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one iteration of the reference's training loop (pygda/models/a2gnn.py:308-319
+plus the per-epoch metric :328-329) -- with full-batch loading that is one epoch.  Work unit
+(SURVEY.md §8d): edges aggregated = sum over every executed aggregation (forward and
+backward) of nnz(A_hat) incl. self loops = nnz_s*(4*L*s_pnums+2) + nnz_t*(3*L*t_pnums+1).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+``roofline`` (dominant kernel family, timed live with HIP events on the launch stream) and
+``cpu_baseline`` (the CPU oracle's training step on the same workload, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+FP32_MFMA_PEAK_TF = 157.3      # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def make_cfg_a(seed=200, ns=9360, es=15556, nt=5484, et=8117, feat=6775, classes=5, density=0.01):
+    """Shape-identical stand-in for CitationDataset ACMv9 -> DBLPv7 (the files are not in the
+    reference checkout, data/README.md links Google Drive only): E distinct undirected pairs
+    symmetrised, x ~ Bernoulli(0.01) float32 [N, 6775], y uniform in {0..4}; seed 200 is the
+    benchmark scripts' (unused) default seed (benchmark/node/a2gnn.py:23)."""
+    from pygda_amd.data import Data
+    g = torch.Generator().manual_seed(seed)
+
+    def graph(n, e):
+        keys = torch.empty(0, dtype=torch.int64)
+        while keys.numel() < e:
+            a = torch.randint(0, n, (2 * e,), generator=g)
+            b = torch.randint(0, n, (2 * e,), generator=g)
+            lo, hi = torch.minimum(a, b), torch.maximum(a, b)
+            k = (lo * n + hi)[lo != hi]
+            keys = torch.unique(torch.cat([keys, k]))
+        keys = keys[torch.randperm(keys.numel(), generator=g)[:e]]
+        lo, hi = keys // n, keys % n
+        ei = torch.stack([torch.cat([lo, hi]), torch.cat([hi, lo])])
+        x = (torch.rand(n, feat, generator=g) < density).float()
+        y = torch.randint(0, classes, (n,), generator=g)
+        return Data(x=x, edge_index=ei, y=y)
+
+    return graph(ns, es), graph(nt, et)
+
+
+def edges_per_step(nnz_s, nnz_t, L, s_p, t_p):
+    return nnz_s * (4 * L * s_p + 2) + nnz_t * (3 * L * t_p + 1)
+
+
+def cpu_baseline(src, tgt, hp, edges):
+    """The CPU oracle (oracle/pygda_cpu.py, kind='port') on the same workload: one training
+    step (forward + backward + Adam), the reference's own op sequence incl. the [2000,2000,128]
+    MMD temporaries.  ~10-25 s of CPU work on 8+ cores."""
+    import psutil
+    from oracle import pygda_cpu as O
+    threads = torch.get_num_threads()
+    torch.manual_seed(1)
+    net = O.A2GNNBase(src.x.size(1), hp["hid"], hp["classes"], num_layers=hp["L"], dropout=hp["dropout"])
+    opt = torch.optim.Adam(net.parameters(), lr=hp["lr"], weight_decay=hp["wd"])
+    s, t = O.Graph(src.x, src.edge_index, src.y), O.Graph(tgt.x, tgt.edge_index, tgt.y)
+    chunk = None if psutil.virtual_memory().available > 48 * 2 ** 30 else 128
+    t0 = time.perf_counter()
+    O.a2gnn_train_step(net, opt, s, t, 0.0, hp["s_pnums"], hp["t_pnums"], False, hp["weight"], chunk)
+    dt = time.perf_counter() - t0
+    return {"value": edges / dt, "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": "1 full-batch A2GNN training step (fwd+bwd+Adam) of the same cfg-A workload, "
+                      f"{dt:.1f} s" + ("" if chunk is None else ", MMD temporaries row-chunked"),
+            "epochs_per_sec": 1.0 / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--adv", action="store_true", help="adversarial branch instead of MMD")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    import pygda_amd
+    from pygda_amd import profiler
+    from pygda_amd.models import A2GNN
+
+    # hyper-parameters of benchmark/node/run_citation.sh:92 (A2GNN, ACMv9 -> DBLPv7)
+    hp = dict(hid=128, classes=5, L=2, lr=0.01, wd=0.005, dropout=0.5, s_pnums=0, t_pnums=10, weight=10)
+    src, tgt = make_cfg_a(seed=200)
+    total_epochs = args.warmup + args.steps
+    model = A2GNN(src.x.size(1), hp["hid"], hp["classes"], num_layers=hp["L"], lr=hp["lr"],
+                  weight_decay=hp["wd"], epoch=total_epochs, dropout=hp["dropout"], s_pnums=hp["s_pnums"],
+                  t_pnums=hp["t_pnums"], weight=hp["weight"], adv=args.adv, device=dev, verbose=0)
+    torch.manual_seed(1234 + rank)
+    state = model._prepare(src, tgt)
+    src_d, tgt_d = src.to(dev), tgt.to(dev)          # inputs resident in HBM before the timed region
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    model._train_epochs(*state, epochs=range(args.warmup))
+    from pygda_amd.graph import as_graph
+    nnz_s = as_graph(src_d.edge_index, src_d.num_nodes).nnz
+    nnz_t = as_graph(tgt_d.edge_index, tgt_d.num_nodes).nnz
+    edges = edges_per_step(nnz_s, nnz_t, hp["L"], hp["s_pnums"], hp["t_pnums"])
+
+    sync()
+    profiler.start()
+    t0 = time.perf_counter()
+    model._train_epochs(*state, epochs=range(args.warmup, total_epochs))
+    sync()
+    dt = time.perf_counter() - t0
+    profiler.stop()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    prof = profiler.summary()
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+
+        def roof(name):
+            r = prof[name]
+            secs = r["ms"] * 1e-3
+            if name.startswith("spmm"):
+                ach = r["bytes"] / secs / 1e9
+                return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": r["launches"],
+                        "avg_launch_us": r["avg_us"], "algorithmic_bytes_per_launch": r["bytes"] / r["launches"]}
+            ach = r["flops"] / secs / 1e12
+            return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None, "launches": r["launches"],
+                    "avg_launch_us": r["avg_us"]}
+
+        cands = [k for k in prof if k.startswith("spmm") or k.startswith("dense")]
+        dominant = max(cands, key=lambda k: prof[k]["ms"])
+        agg = max((k for k in prof if k.startswith("spmm")), key=lambda k: prof[k]["ms"])
+        out = {
+            "metric": "edges_aggregated_per_sec", "value": world * edges * args.steps / dt, "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "cfg-A: A2GNN ACMv9->DBLPv7 (shape-identical stand-in graphs, "
+                                   "Ns=9360/Es=15556, Nt=5484/Et=8117, F=6775), nhid=128, L=2, s_pnums=0, "
+                                   "t_pnums=10, weight=10, dropout=0.5, full batch, "
+                                   + ("adversarial" if args.adv else "MMD") + " domain loss",
+                       "edges_aggregated_per_step": edges, "nnz_source": nnz_s, "nnz_target": nnz_t,
+                       "parallelism": "single GPU" if world == 1 else f"{world} data-parallel replicas, "
+                                      "flat RCCL gradient all-reduce per step"},
+            "epochs_per_sec": world * args.steps / dt,
+            "roofline": roof(dominant),
+            "roofline_aggregation": roof(agg),
+            "kernel_time_ms_per_step": {k: v["ms"] / args.steps for k, v in sorted(prof.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(src, tgt, hp, edges)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,173 @@
+/*
+ * gda_hip.h -- C ABI of libgda_hip.so: the MI355X (gfx950) kernels behind pygda's
+ * message-passing / domain-adaptation-loss hot path.
+ *
+ * The reference (pygda-team/pygda v1.2.1) is pure Python and has no FFI of its own;
+ * the arithmetic on this path lives in third-party wheels it calls (PyG
+ * MessagePassing.propagate, torch_scatter.scatter_add, add_remaining_self_loops) and
+ * in torch elementwise chains (pygda/utils/mmd.py).  Each entry point below names the
+ * reference call site(s) whose work it replaces.  pygda_amd/ binds these with ctypes
+ * (INTEGRATION.md shows the stub a pygda maintainer would add).
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = invalid argument (GDA_E_*),
+ *     >0 = hipError_t of the failing runtime call.  Nothing throws across the ABI.
+ *   - all pointers are caller-owned DEVICE pointers unless the name ends in _host;
+ *     kernels never allocate: scratch is passed in (size from gda_*_workspace_bytes).
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); all
+ *     work is enqueued asynchronously on it; the library keeps no mutable state, so
+ *     calls are re-entrant and hipGraph-capturable.
+ *   - indices inside the library are int32 (N, nnz < 2^31); features are fp32,
+ *     row-major with an explicit leading dimension in elements.
+ */
+#ifndef GDA_HIP_H
+#define GDA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDA_OK 0
+#define GDA_E_NULL (-1)      /* required pointer is NULL */
+#define GDA_E_SIZE (-2)      /* negative / overflowing / inconsistent size */
+#define GDA_E_WORKSPACE (-3) /* workspace too small */
+#define GDA_E_UNSUPPORTED (-4)
+#define GDA_E_ALIAS (-5)     /* output aliases an input that must stay intact */
+
+typedef void* gda_stream_t;
+
+int gda_abi_version(void);
+/* Human-readable text for a status returned by any function here. */
+const char* gda_status_string(int status);
+
+/* ------------------------------------------------------------------------------
+ * Graph ingestion: COO edge list -> self-loop merge -> symmetric normalisation ->
+ * CSR by destination (forward) + CSR by source (transpose, for the backward pass).
+ *
+ * Replaces gcn_norm (pygda/nn/prop_gcn_conv.py:64-81: add_remaining_self_loops :72,
+ * scatter_add degree over col :78, deg^-1/2 with inf->0 :79-80, w' = dis[row]*w*dis[col]
+ * :81) and CachedGCNConv.norm (pygda/nn/cached_gcn_conv.py:88-103, degree over row),
+ * plus the edge ordering PyG's propagate scatter relies on.  Both CSRs keep the
+ * edges of a row in their original edge order (stable sort), so a sequential row
+ * sum reproduces the CPU scatter-add order.
+ *
+ *   src,dst   [E] int64  edge_index[0], edge_index[1]  (message flows src -> dst)
+ *   w         [E] fp32 or NULL (all ones)
+ *   fill_value     self-loop weight for nodes without one (1, or 2 for improved)
+ *   add_self_loops 0/1; normalize 0/1 (0: values are the raw weights)
+ *   degree_side    0 = over dst/col (PropGCNConv, GCNConv), 1 = over src/row (CachedGCNConv)
+ *   rowptr  [N+1], colidx/val [E+N]  : by-destination CSR, colidx = source node
+ *   t_rowptr[N+1], t_colidx/t_val [E+N] : by-source CSR, t_colidx = destination node
+ * nnz (= kept edges + N) is rowptr[N].
+ * ---------------------------------------------------------------------------- */
+size_t gda_graph_workspace_bytes(int64_t E, int64_t N);
+int gda_build_csr_norm(const int64_t* src, const int64_t* dst, const float* w,
+                       int64_t E, int64_t N, float fill_value, int add_self_loops,
+                       int normalize, int degree_side,
+                       int32_t* rowptr, int32_t* colidx, float* val,
+                       int32_t* t_rowptr, int32_t* t_colidx, float* t_val,
+                       void* workspace, size_t workspace_bytes, gda_stream_t stream);
+
+/* Expand a CSR back to the COO edge_index the reference returns from gcn_norm, in
+ * CSR order; nnz_cap >= rowptr[N] bounds the launch (entries past rowptr[N] untouched). */
+int gda_csr_to_coo(const int32_t* rowptr, const int32_t* colidx, int64_t N, int64_t nnz_cap,
+                   int64_t* src_out, int64_t* dst_out, gda_stream_t stream);
+
+/* ------------------------------------------------------------------------------
+ * Neighbour aggregation  y = A_hat * x  (CSR SpMM, fp32).
+ *
+ * Replaces MessagePassing.propagate + message + scatter-add aggregate
+ * (pygda/nn/prop_gcn_conv.py:208-210,238; pygda/nn/cached_gcn_conv.py:138,156):
+ *   y[i,:] = sum_{k in rowptr[i]..rowptr[i+1]} val[k] * x[colidx[k],:]   (+ bias)
+ * accumulated in CSR (= edge) order with separately rounded multiply and add, i.e.
+ * the CPU result bit for bit for rows processed by one lane group.
+ * `bias` ([d], may be NULL) is added once to the final output (prop_gcn_conv.py:212-213,
+ * cached_gcn_conv.py:172-174).  y must not alias x.
+ *
+ * gda_spmm_csr_kstep_f32 applies the operator K>=1 times (the prop_nums loop
+ * prop_gcn_conv.py:208-210) ping-ponging between y and tmp ([n_rows, ldy], needed
+ * when K>1); x is left intact.  The backward of K steps is the same call on the
+ * by-source CSR with the incoming gradient.
+ * ---------------------------------------------------------------------------- */
+int gda_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                     int64_t n_rows, int64_t d, const float* x, int64_t ldx,
+                     float* y, int64_t ldy, const float* bias, gda_stream_t stream);
+int gda_spmm_csr_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                           int64_t n_rows, int64_t d, int K, const float* x, int64_t ldx,
+                           float* y, int64_t ldy, float* tmp, const float* bias,
+                           gda_stream_t stream);
+
+/* ------------------------------------------------------------------------------
+ * Multi-kernel Gaussian MMD over sampled rows, forward and backward, with no
+ * [n,n,d] temporary.
+ *
+ * Replaces MMD / get_MMD / guassian_kernel (pygda/utils/mmd.py:4-159) as called from
+ * A2GNN.forward_model (pygda/models/a2gnn.py:208) and GRADE (pygda/models/grade.py:182).
+ * For each of `times` resamples t: rows r<n of `total` are src[src_idx[t,r]], rows
+ * n<=r<2n are tgt[tgt_idx[t,r-n]] (idx NULL = identity, i.e. get_MMD on the rows as
+ * given; then times must be 1).  L2[i,j] = sum_k (total[j,k]-total[i,k])^2 (direct
+ * difference form, mmd.py:43-46); bandwidth = (sum L2 + 1e-6)/(m^2-m) / kernel_mul^(kernel_num/2),
+ * m = 2n (mmd.py:50-51; fix_sigma>0 overrides the data-dependent value); K = sum_q
+ * exp(-L2/(bandwidth*kernel_mul^q)) (mmd.py:52-55); loss_t = mean(XX+YY-XY-YX) over the
+ * n x n blocks (mmd.py:100-106); loss = (sum_t loss_t)/times (mmd.py:152-157).
+ * The reference's block arithmetic needs equally many source and target rows; so does this.
+ *
+ *   loss        [1] fp32 (device)
+ *   bandwidth   [times] fp32 (device, saved for backward; gradient does not flow
+ *               through it -- mmd.py:50 uses .data)
+ *   l2_saved    [times, 2n, 2n] fp32 (device; produced by fwd, consumed by bwd)
+ * Backward: grad_rows [times, 2n, d] = d loss / d total rows, scaled by *grad_loss.
+ * The caller scatters them onto feature rows (a CSR SpMM with the selection matrix).
+ * ---------------------------------------------------------------------------- */
+size_t gda_mmd_workspace_bytes(int times, int64_t n, int64_t d);
+int gda_mmd_fwd_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
+                    int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
+                    int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
+                    float* loss, float* bandwidth, float* l2_saved,
+                    void* workspace, size_t workspace_bytes, gda_stream_t stream);
+int gda_mmd_bwd_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
+                    int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
+                    int times, int64_t n, float kernel_mul, int kernel_num,
+                    const float* bandwidth, const float* l2_saved, const float* grad_loss,
+                    float* grad_rows, gda_stream_t stream);
+
+/* ------------------------------------------------------------------------------
+ * Gradient-reversal + linear domain discriminator + softmax cross-entropy, fused.
+ *
+ * Replaces GradReverse.apply (pygda/nn/reverse_layer.py:39,65-66) -> Linear(h, C) ->
+ * F.cross_entropy over cat(source, target) rows (pygda/models/a2gnn.py:197-205,
+ * pygda/models/grade.py:170-176).  Rows [0, n_src) of `feat_src` carry label 0,
+ * rows of `feat_tgt` label 1 (C = 2 in the reference; C <= 8 supported, labels may
+ * instead be given per row with `labels` != NULL over the concatenation).
+ *   forward : loss[0] = mean_r ( logsumexp(z_r) - z_r[label_r] ),  z = f W^T + b
+ *             also writes probs [n_src+n_tgt, C] (softmax, saved for backward)
+ *   backward: dz = (probs - onehot)/n * grad_loss ; gW [C,h] = dz^T f ; gb [C] = sum dz ;
+ *             gfeat = -alpha * dz W   (the reversal), written for both domains.
+ * ---------------------------------------------------------------------------- */
+int gda_grl_disc_ce_fwd_f32(const float* feat_src, int64_t ld_src, int64_t n_src,
+                            const float* feat_tgt, int64_t ld_tgt, int64_t n_tgt,
+                            int64_t h, int C, const float* W, const float* b,
+                            const int64_t* labels, float* probs, float* loss,
+                            void* workspace, size_t workspace_bytes, gda_stream_t stream);
+int gda_grl_disc_ce_bwd_f32(const float* feat_src, int64_t ld_src, int64_t n_src,
+                            const float* feat_tgt, int64_t ld_tgt, int64_t n_tgt,
+                            int64_t h, int C, const float* W, const int64_t* labels,
+                            const float* probs, const float* grad_loss, float alpha,
+                            float* gfeat_src, float* gfeat_tgt, float* gW, float* gb,
+                            void* workspace, size_t workspace_bytes, gda_stream_t stream);
+size_t gda_grl_disc_workspace_bytes(int64_t n_rows, int64_t h, int C);
+
+/* ------------------------------------------------------------------------------
+ * Feature-row gather  out[r,:] = x[idx[r],:]  (mini-batch assembly: the x[n_id]
+ * slice PyG's NeighborLoader performs, pygda/models/a2gnn.py:260-277).
+ * ---------------------------------------------------------------------------- */
+int gda_gather_rows_f32(const float* x, int64_t ldx, int64_t d, const int64_t* idx,
+                        int64_t n_out, float* out, int64_t ldo, gda_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDA_HIP_H */

@@ -1,0 +1,97 @@
+"""ctypes binding of libgda_hip.so (the C ABI declared in include/gda_hip.h).
+
+The product path has no fallback: if the library is missing or a call fails this module
+raises.  Tensors cross the boundary as raw device pointers (``tensor.data_ptr()``), the
+stream as ``torch.cuda.current_stream().cuda_stream``.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgda_hip.so")
+
+_P = c_void_p
+_SIGNATURES = {
+    "gda_abi_version": (c_int, []),
+    "gda_status_string": (c_char_p, [c_int]),
+    "gda_graph_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "gda_build_csr_norm": (c_int, [_P, _P, _P, c_int64, c_int64, c_float, c_int, c_int, c_int,
+                                   _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gda_csr_to_coo": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P]),
+    "gda_spmm_csr_f32": (c_int, [_P, _P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P]),
+    "gda_spmm_csr_kstep_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P, c_int64,
+                                       _P, _P, _P]),
+    "gda_mmd_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64]),
+    "gda_mmd_fwd_f32": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, _P, c_int, c_int64, c_float,
+                                c_int, c_float, _P, _P, _P, _P, c_size_t, _P]),
+    "gda_mmd_bwd_f32": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, _P, c_int, c_int64, c_float,
+                                c_int, _P, _P, _P, _P, _P]),
+    "gda_grl_disc_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "gda_grl_disc_ce_fwd_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int,
+                                        _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gda_grl_disc_ce_bwd_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int,
+                                        _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gda_gather_rows_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class GdaError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GdaError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(pygda_amd has no CPU / eager fallback)")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().gda_status_string(int(status)).decode()
+        raise GdaError(f"{what} failed with status {status}: {msg}")
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu_tensor(t, name, dtype=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise GdaError(f"{name} must be a tensor on the MI355X device (got {getattr(t, 'device', type(t))}); "
+                       "pygda_amd has no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise GdaError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    return t
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag):
+    """A reusable byte scratch buffer per (device, tag, stream): kernels never allocate."""
+    key = (str(device), tag, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

@@ -1,0 +1,60 @@
+// ABI version, status strings, and the feature-row gather used for mini-batch assembly.
+#include "gda_common.h"
+
+namespace {
+
+constexpr int TB = 256;
+
+// out[r, :] = x[idx[r], :]  -- the x[n_id] slice PyG's NeighborLoader performs
+// (pygda/models/a2gnn.py:260-277).  A lane group of G lanes moves one row with 16-byte
+// accesses: fully coalesced reads of whole feature rows, HBM bound (2*n_out*d*4 bytes).
+template <int VEC>
+__global__ void __launch_bounds__(TB)
+k_gather(const float* __restrict__ x, int64_t ldx, int d, const int64_t* __restrict__ idx,
+         int64_t n_out, float* __restrict__ out, int64_t ldo) {
+    const int per_row = (d + VEC - 1) / VEC;                 // vector slots per row
+    const int64_t total = n_out * per_row;
+    for (int64_t s = (int64_t)blockIdx.x * TB + threadIdx.x; s < total; s += (int64_t)gridDim.x * TB) {
+        const int64_t r = s / per_row;
+        const int c = (int)(s % per_row) * VEC;
+        const float* p = x + idx[r] * ldx + c;
+        float* q = out + r * ldo + c;
+        if constexpr (VEC == 4) *reinterpret_cast<float4*>(q) = *reinterpret_cast<const float4*>(p);
+        else *q = *p;
+    }
+}
+
+}  // namespace
+
+extern "C" int gda_abi_version(void) { return 1; }
+
+extern "C" const char* gda_status_string(int status) {
+    switch (status) {
+        case GDA_OK: return "ok";
+        case GDA_E_NULL: return "gda: required pointer is NULL";
+        case GDA_E_SIZE: return "gda: negative, overflowing or inconsistent size";
+        case GDA_E_WORKSPACE: return "gda: workspace too small";
+        case GDA_E_UNSUPPORTED: return "gda: unsupported configuration";
+        case GDA_E_ALIAS: return "gda: output aliases an input";
+        default: break;
+    }
+    if (status > 0) return hipGetErrorString((hipError_t)status);
+    return "gda: unknown status";
+}
+
+extern "C" int gda_gather_rows_f32(const float* x, int64_t ldx, int64_t d, const int64_t* idx,
+                                   int64_t n_out, float* out, int64_t ldo, gda_stream_t stream_) {
+    if (n_out < 0 || d < 0 || d >= INT32_MAX || ldx < d || ldo < d) return GDA_E_SIZE;
+    if (n_out == 0 || d == 0) return GDA_OK;
+    if (!x || !idx || !out) return GDA_E_NULL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool v4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) &&
+                    ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    const int64_t slots = n_out * (v4 ? d / 4 : d);
+    int64_t grid = gda_cdiv(slots, TB);
+    if (grid > 256 * 16) grid = 256 * 16;                     // grid-stride beyond 16 workgroups per CU
+    if (v4) k_gather<4><<<(unsigned)grid, TB, 0, stream>>>(x, ldx, (int)d, idx, n_out, out, ldo);
+    else k_gather<1><<<(unsigned)grid, TB, 0, stream>>>(x, ldx, (int)d, idx, n_out, out, ldo);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}

@@ -1,0 +1,200 @@
+// Neighbour aggregation y = A_hat * x as a CSR SpMM for gfx950 (fp32).
+//
+// Replaces PyG MessagePassing.propagate + message + scatter-add aggregate as pygda
+// calls it (pygda/nn/prop_gcn_conv.py:208-210,238; pygda/nn/cached_gcn_conv.py:138,156).
+//
+// Mapping.  A wavefront (64 lanes) is cut into lane groups of G lanes; one group owns
+// one destination row and walks its neighbour list sequentially, so the per-element
+// accumulation order is the CSR (= original edge) order and multiply and add are
+// rounded separately -- the CPU gather/scale/scatter-add result bit for bit.  Each
+// lane owns VEC consecutive feature columns (16-byte loads when the width allows),
+// so a group reads one neighbour's feature row as one fully coalesced
+// G*VEC*4-byte segment (512 B for the hid=128 layers: G=32, VEC=4 -> two rows per wave).
+// Neighbour (col, val) pairs are fetched G at a time, one pair per lane (coalesced),
+// and broadcast inside the group with DPP/bpermute shuffles; the gather loads of four
+// neighbours are issued back to back before the dependent adds so four 512 B
+// requests per group are in flight.
+// HBM bound: algorithmic bytes per call = nnz*8 + (N+1)*4 + 2*N*d*4.
+#include "gda_common.h"
+
+namespace {
+
+constexpr int TB = 256;           // 4 wavefronts per workgroup
+constexpr int UNROLL = 4;
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = float4; };
+
+template <int VEC>
+__device__ __forceinline__ void vload(float (&r)[VEC], const float* __restrict__ p) {
+    using V = typename VecT<VEC>::type;
+    const V v = *reinterpret_cast<const V*>(p);
+    if constexpr (VEC == 1) { r[0] = v; }
+    if constexpr (VEC == 2) { r[0] = v.x; r[1] = v.y; }
+    if constexpr (VEC == 4) { r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
+}
+
+template <int VEC>
+__device__ __forceinline__ void vstore(float* __restrict__ p, const float (&r)[VEC]) {
+    using V = typename VecT<VEC>::type;
+    V v;
+    if constexpr (VEC == 1) { v = r[0]; }
+    if constexpr (VEC == 2) { v.x = r[0]; v.y = r[1]; }
+    if constexpr (VEC == 4) { v.x = r[0]; v.y = r[1]; v.z = r[2]; v.w = r[3]; }
+    *reinterpret_cast<V*>(p) = v;
+}
+
+// G lanes per row, VEC columns per lane.  Columns beyond G*VEC are covered by an outer
+// chunk loop (re-walking the neighbour list), so any d works with any (G, VEC) whose
+// alignment holds.
+template <int G, int VEC>
+__global__ void __launch_bounds__(TB)
+k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+       const float* __restrict__ val, int64_t n_rows, int d,
+       const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
+       const float* __restrict__ bias) {
+    constexpr int ROWS_PER_BLOCK = TB / G;
+    const int lane_in_group = threadIdx.x % G;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + threadIdx.x / G;
+    const bool live = row < n_rows;
+    // keep whole groups together for the shuffles; dead groups just run empty loops
+    const int32_t start = live ? rowptr[row] : 0;
+    const int32_t end = live ? rowptr[row + 1] : 0;
+
+    for (int c0 = 0; c0 < d; c0 += G * VEC) {
+        const int c = c0 + lane_in_group * VEC;
+        const bool col_ok = c < d;                    // d % VEC == 0 is guaranteed by dispatch
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
+
+        for (int32_t base = start; base < end; base += G) {
+            // one (col, val) pair per lane: a coalesced G*8-byte tile of the neighbour list
+            const int32_t k = base + lane_in_group;
+            const int32_t my_col = k < end ? colidx[k] : 0;
+            const float my_val = k < end ? val[k] : 0.0f;
+            const int cnt = min((int32_t)G, end - base);
+            int e = 0;
+            for (; e + UNROLL <= cnt; e += UNROLL) {
+                float xv[UNROLL][VEC];
+                float w[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int32_t cu = __shfl(my_col, e + u, G);
+                    w[u] = __shfl(my_val, e + u, G);
+                    if (col_ok) vload<VEC>(xv[u], x + (int64_t)cu * ldx + c);
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        acc[v] = __fadd_rn(acc[v], __fmul_rn(w[u], col_ok ? xv[u][v] : 0.0f));
+            }
+            for (; e < cnt; ++e) {
+                const int32_t cu = __shfl(my_col, e, G);
+                const float w = __shfl(my_val, e, G);
+                float xv[VEC];
+                if (col_ok) {
+                    vload<VEC>(xv, x + (int64_t)cu * ldx + c);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] = __fadd_rn(acc[v], __fmul_rn(w, xv[v]));
+                }
+            }
+        }
+        if (live && col_ok) {
+            if (bias) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = __fadd_rn(acc[v], bias[c + v]);
+            }
+            vstore<VEC>(y + row * ldy + c, acc);
+        }
+    }
+}
+
+template <int G, int VEC>
+int launch(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n_rows, int d,
+           const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias, hipStream_t s) {
+    constexpr int ROWS_PER_BLOCK = TB / G;
+    const int64_t grid = gda_cdiv(n_rows, ROWS_PER_BLOCK);
+    if (grid > INT32_MAX) return GDA_E_SIZE;
+    k_spmm<G, VEC><<<(unsigned)grid, TB, 0, s>>>(rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, bias);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+int dispatch(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n_rows, int64_t d,
+             const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias, hipStream_t s) {
+    // vector width: widest that keeps every row start and column offset aligned
+    const bool a16 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
+                     ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+    const bool a8 = (d % 2 == 0) && (ldx % 2 == 0) && (ldy % 2 == 0) &&
+                    ((uintptr_t)x % 8 == 0) && ((uintptr_t)y % 8 == 0);
+    const int di = (int)d;
+#define GO(G, V) return launch<G, V>(rowptr, colidx, val, n_rows, di, x, ldx, y, ldy, bias, s)
+    if (a16) {
+        const int64_t lanes = d / 4;
+        if (lanes >= 64) GO(64, 4);
+        if (lanes > 16) GO(32, 4);
+        if (lanes > 8) GO(16, 4);
+        if (lanes > 4) GO(8, 4);
+        GO(4, 4);
+    }
+    if (a8) {
+        const int64_t lanes = d / 2;
+        if (lanes > 32) GO(64, 2);
+        if (lanes > 16) GO(32, 2);
+        if (lanes > 8) GO(16, 2);
+        if (lanes > 4) GO(8, 2);
+        GO(4, 2);
+    }
+    if (d > 32) GO(64, 1);
+    if (d > 16) GO(32, 1);
+    if (d > 8) GO(16, 1);
+    if (d > 4) GO(8, 1);
+    GO(4, 1);
+#undef GO
+}
+
+int check(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n_rows, int64_t d,
+          const float* x, int64_t ldx, float* y, int64_t ldy) {
+    if (n_rows < 0 || d < 0 || n_rows >= INT32_MAX || d >= INT32_MAX || ldx < d || ldy < d) return GDA_E_SIZE;
+    if (n_rows == 0 || d == 0) return GDA_OK;
+    if (!rowptr || !x || !y) return GDA_E_NULL;
+    (void)colidx; (void)val;   // may be NULL only when nnz == 0, which the host cannot see here
+    if ((const float*)y == x) return GDA_E_ALIAS;
+    return GDA_OK;
+}
+
+}  // namespace
+
+extern "C" int gda_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                                int64_t n_rows, int64_t d, const float* x, int64_t ldx,
+                                float* y, int64_t ldy, const float* bias, gda_stream_t stream) {
+    const int st = check(rowptr, colidx, val, n_rows, d, x, ldx, y, ldy);
+    if (st != GDA_OK || n_rows == 0 || d == 0) return st;
+    return dispatch(rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, bias, (hipStream_t)stream);
+}
+
+extern "C" int gda_spmm_csr_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                                      int64_t n_rows, int64_t d, int K, const float* x, int64_t ldx,
+                                      float* y, int64_t ldy, float* tmp, const float* bias,
+                                      gda_stream_t stream) {
+    if (K < 1) return GDA_E_SIZE;
+    const int st = check(rowptr, colidx, val, n_rows, d, x, ldx, y, ldy);
+    if (st != GDA_OK || n_rows == 0 || d == 0) return st;
+    if (K > 1 && !tmp) return GDA_E_NULL;
+    if (K > 1 && (tmp == y || (const float*)tmp == x)) return GDA_E_ALIAS;
+    const float* in = x;
+    int64_t ld_in = ldx;
+    for (int j = 1; j <= K; ++j) {                   // step j writes y when K-j is even
+        float* out = ((K - j) % 2 == 0) ? y : tmp;
+        const int r = dispatch(rowptr, colidx, val, n_rows, d, in, ld_in, out, ldy,
+                               j == K ? bias : nullptr, (hipStream_t)stream);
+        if (r != GDA_OK) return r;
+        in = out;
+        ld_in = ldy;
+    }
+    return GDA_OK;
+}

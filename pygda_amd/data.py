@@ -1,0 +1,132 @@
+"""Minimal graph container and loaders with the PyG names pygda's trainers use
+(``Data``; ``NeighborLoader(data, num_neighbors, batch_size=...)``;
+pygda/models/a2gnn.py:254-286).  Full-batch loading hands out the graph itself (cached on
+the device after the first ``.to``); fan-out sampling is done by the native host sampler
+(pygda_amd/sampler.py)."""
+import torch
+
+
+class Data:
+    """Any object with ``x [N,F] fp32``, ``edge_index [2,E] int64`` (row 0 = source, row 1 =
+    destination), ``y [N] int64`` and ``.to(device)`` satisfies the trainers; this is one."""
+
+    def __init__(self, x=None, edge_index=None, y=None, **kwargs):
+        self.x, self.edge_index, self.y = x, edge_index, y
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+        self._device_copies = {}
+
+    # -- container protocol -------------------------------------------------------
+    def keys(self):
+        return [k for k, v in self.__dict__.items() if not k.startswith("_") and v is not None]
+
+    def __contains__(self, key):
+        return key in self.keys()
+
+    def __getitem__(self, key):
+        return getattr(self, key)
+
+    @property
+    def num_nodes(self):
+        if self.x is not None:
+            return self.x.size(0)
+        return int(self.edge_index.max()) + 1 if self.edge_index is not None and self.edge_index.numel() else 0
+
+    @property
+    def num_edges(self):
+        return 0 if self.edge_index is None else self.edge_index.size(1)
+
+    @property
+    def num_node_features(self):
+        return 0 if self.x is None else self.x.size(1)
+
+    def is_undirected(self):
+        ei = self.edge_index
+        n = self.num_nodes
+        a = torch.unique(ei[0] * n + ei[1])
+        b = torch.unique(ei[1] * n + ei[0])
+        return a.numel() == b.numel() and bool((a == b).all())
+
+    def to(self, device, non_blocking=False):
+        """Device copy, made once per device and then reused -- so per-step
+        ``batch.to(device)`` (a2gnn.py:311-312) costs nothing after the first call and the
+        graph cache sees the same edge tensor every step."""
+        device = torch.device(device)
+        probe = self.x if self.x is not None else self.edge_index
+        if probe is not None and probe.device == device:
+            return self
+        key = str(device)
+        hit = self._device_copies.get(key)
+        if hit is None:
+            hit = Data(**{k: (v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v)
+                          for k, v in self.__dict__.items() if not k.startswith("_")})
+            self._device_copies[key] = hit
+        return hit
+
+    def cpu(self):
+        return self.to("cpu")
+
+    def __repr__(self):
+        info = ", ".join(f"{k}={list(v.shape) if torch.is_tensor(v) else v}" for k, v in self.__dict__.items()
+                         if not k.startswith("_") and v is not None)
+        return f"Data({info})"
+
+
+def to_undirected(edge_index, num_nodes=None):
+    """Symmetrise and de-duplicate an edge list (what benchmark/node/a2gnn.py:92-97 applies)."""
+    n = int(edge_index.max()) + 1 if num_nodes is None else num_nodes
+    both = torch.cat([edge_index, edge_index.flip(0)], dim=1)
+    key = torch.unique(both[0] * n + both[1])
+    return torch.stack([key // n, key % n])
+
+
+class NeighborLoader:
+    """``NeighborLoader(data, num_neighbors, batch_size)`` as the trainers build it.
+
+    ``num_neighbors`` all -1 with ``batch_size >= N``: one batch, the whole graph (every
+    benchmark setting of the reference).  Otherwise seeds are taken ``batch_size`` at a time
+    (in order unless ``shuffle``) and each batch is the union of their sampled L-hop
+    in-neighbourhoods, seeds first, exactly ``batch.batch_size`` of them."""
+
+    def __init__(self, data, num_neighbors, batch_size=1, shuffle=False, input_nodes=None,
+                 rank=0, world_size=1, seed=0, **kwargs):
+        self.data, self.num_neighbors = data, list(num_neighbors)
+        self.batch_size, self.shuffle = int(batch_size), shuffle
+        self.rank, self.world_size, self.seed = rank, world_size, seed
+        n = data.num_nodes
+        self.input_nodes = torch.arange(n) if input_nodes is None else torch.as_tensor(input_nodes).long().cpu()
+        self.full_batch = (all(k == -1 for k in self.num_neighbors) and self.batch_size >= n
+                           and input_nodes is None and world_size == 1)
+        self._sampler = None
+        self._epoch = 0
+
+    def _batches(self):
+        seeds = self.input_nodes
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self._epoch)
+            seeds = seeds[torch.randperm(seeds.numel(), generator=g)]
+        chunks = list(torch.split(seeds, self.batch_size))
+        return chunks[self.rank::self.world_size]      # data-parallel shard of the seed batches
+
+    def __len__(self):
+        return 1 if self.full_batch else len(self._batches())
+
+    def __iter__(self):
+        if self.full_batch:
+            yield self.data
+            return
+        from .sampler import NeighborSampler
+        if self._sampler is None:
+            self._sampler = NeighborSampler(self.data.edge_index, self.data.num_nodes)
+        for b, seeds in enumerate(self._batches()):
+            yield self._sampler.sample_batch(self.data, seeds, self.num_neighbors,
+                                             seed=hash((self.seed, self._epoch, b, self.rank)) & 0x7FFFFFFF)
+        self._epoch += 1
+
+
+class DataLoader:
+    """Graph-level mini-batching (``mode='graph'``) is outside this build's scope."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("graph-classification mode (mode='graph') is out of scope; "
+                                  "see DESIGN.md, section 'Out of scope'")

@@ -1,0 +1,132 @@
+"""Device-resident normalised adjacency (CSR by destination + CSR by source).
+
+The reference recomputes ``gcn_norm`` on every conv call (``cached=False``,
+pygda/nn/prop_gcn_conv.py:182-192 -- 10x per A2GNN step) and lets PyG scatter over a COO
+edge list.  Here the edge list is ingested once per graph / mini-batch by
+``gda_build_csr_norm`` into the layout the SpMM kernel wants, and looked up again through
+a small identity-keyed cache, so the ``forward(x, edge_index, ...)`` operator surface
+stays unchanged.
+"""
+import weakref
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+
+
+class CSRGraph:
+    """``rowptr/colidx/val``: rows = destination nodes (forward aggregation);
+    ``t_rowptr/t_colidx/t_val``: rows = source nodes (the transpose, backward)."""
+
+    __slots__ = ("num_nodes", "nnz_cap", "rowptr", "colidx", "val", "t_rowptr", "t_colidx",
+                 "t_val", "_nnz", "device")
+
+    def __init__(self, num_nodes, nnz_cap, rowptr, colidx, val, t_rowptr, t_colidx, t_val):
+        self.num_nodes, self.nnz_cap = num_nodes, nnz_cap
+        self.rowptr, self.colidx, self.val = rowptr, colidx, val
+        self.t_rowptr, self.t_colidx, self.t_val = t_rowptr, t_colidx, t_val
+        self._nnz = None
+        self.device = rowptr.device
+
+    @property
+    def nnz(self):
+        """Number of stored entries incl. self loops (one host sync, then cached)."""
+        if self._nnz is None:
+            self._nnz = int(self.rowptr[self.num_nodes].item())
+        return self._nnz
+
+    def transposed(self):
+        return CSRGraph(self.num_nodes, self.nnz_cap, self.t_rowptr, self.t_colidx, self.t_val,
+                        self.rowptr, self.colidx, self.val)
+
+    def to_coo(self):
+        """(edge_index [2, nnz], weight [nnz]) in CSR order -- what gcn_norm returns."""
+        nnz = self.nnz
+        src = torch.empty(max(nnz, 1), dtype=torch.int64, device=self.device)
+        dst = torch.empty(max(nnz, 1), dtype=torch.int64, device=self.device)
+        L = _lib.lib()
+        _lib.check(L.gda_csr_to_coo(_lib.ptr(self.rowptr), _lib.ptr(self.colidx), self.num_nodes, nnz,
+                                    _lib.ptr(src), _lib.ptr(dst), _lib.stream()), "gda_csr_to_coo")
+        return torch.stack([src[:nnz], dst[:nnz]]), self.val[:nnz]
+
+
+def build_csr(edge_index, num_nodes, edge_weight=None, improved=False, add_self_loops=True,
+              normalize=True, degree_side="col", validate=True):
+    """COO ``edge_index`` (row 0 = source, row 1 = destination) -> :class:`CSRGraph`.
+
+    Semantics of gcn_norm (prop_gcn_conv.py:64-81; ``degree_side='col'``) and
+    CachedGCNConv.norm (cached_gcn_conv.py:88-103; ``degree_side='row'``).
+    """
+    _lib.require_gpu_tensor(edge_index, "edge_index", torch.int64)
+    if edge_index.dim() != 2 or edge_index.size(0) != 2:
+        raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
+    E, N = int(edge_index.size(1)), int(num_nodes)
+    if validate and E > 0:
+        lo, hi = int(edge_index.min()), int(edge_index.max())
+        if lo < 0 or hi >= N:
+            raise IndexError(f"edge_index values must lie in [0, {N}), found [{lo}, {hi}]")
+    dev = edge_index.device
+    src = edge_index[0].contiguous()
+    dst = edge_index[1].contiguous()
+    w = None
+    if edge_weight is not None:
+        _lib.require_gpu_tensor(edge_weight, "edge_weight")
+        if edge_weight.numel() != E:
+            raise ValueError("edge_weight must have one entry per edge")
+        w = edge_weight.detach().to(torch.float32).contiguous()
+    cap = E + N
+    i32 = dict(dtype=torch.int32, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    rowptr, t_rowptr = torch.empty(N + 1, **i32), torch.empty(N + 1, **i32)
+    colidx, t_colidx = torch.empty(max(cap, 1), **i32), torch.empty(max(cap, 1), **i32)
+    val, t_val = torch.empty(max(cap, 1), **f32), torch.empty(max(cap, 1), **f32)
+    L = _lib.lib()
+    nbytes = L.gda_graph_workspace_bytes(E, N)
+    ws = _lib.workspace(nbytes, dev, "graph")
+    _lib.check(L.gda_build_csr_norm(
+        _lib.ptr(src), _lib.ptr(dst), _lib.ptr(w), E, N, 2.0 if improved else 1.0,
+        int(bool(add_self_loops)), int(bool(normalize)), 0 if degree_side == "col" else 1,
+        _lib.ptr(rowptr), _lib.ptr(colidx), _lib.ptr(val),
+        _lib.ptr(t_rowptr), _lib.ptr(t_colidx), _lib.ptr(t_val),
+        _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_build_csr_norm")
+    return CSRGraph(N, cap, rowptr, colidx, val, t_rowptr, t_colidx, t_val)
+
+
+class _GraphCache:
+    """LRU of built graphs keyed by the identity (and in-place version) of the edge tensors."""
+
+    def __init__(self, capacity=32):
+        self.capacity = capacity
+        self._d = OrderedDict()
+
+    def get(self, edge_index, num_nodes, edge_weight, improved, add_self_loops, normalize, degree_side):
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes),
+               None if edge_weight is None else (edge_weight.data_ptr(), edge_weight._version),
+               bool(improved), bool(add_self_loops), bool(normalize), degree_side)
+        hit = self._d.get(key)
+        if hit is not None:
+            ref_ei, ref_w, g = hit
+            if ref_ei() is edge_index and (edge_weight is None or ref_w() is edge_weight):
+                self._d.move_to_end(key)
+                return g
+        g = build_csr(edge_index, num_nodes, edge_weight, improved, add_self_loops, normalize, degree_side)
+        self._d[key] = (weakref.ref(edge_index), None if edge_weight is None else weakref.ref(edge_weight), g)
+        while len(self._d) > self.capacity:
+            self._d.popitem(last=False)
+        return g
+
+    def clear(self):
+        self._d.clear()
+
+
+graph_cache = _GraphCache()
+
+
+def as_graph(edge_index, num_nodes, edge_weight=None, improved=False, add_self_loops=True,
+             normalize=True, degree_side="col"):
+    """``edge_index`` may already be a :class:`CSRGraph` (then it is used as is)."""
+    if isinstance(edge_index, CSRGraph):
+        return edge_index
+    return graph_cache.get(edge_index, num_nodes, edge_weight, improved, add_self_loops, normalize,
+                           degree_side)

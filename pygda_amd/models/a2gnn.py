@@ -1,0 +1,80 @@
+"""``A2GNN`` trainer (pygda/models/a2gnn.py:17-411) on the MI355X kernels: source
+cross-entropy + weight * (sampled multi-kernel MMD | gradient-reversed domain CE) with
+asymmetric propagation depths ``s_pnums`` / ``t_pnums``."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ..nn import A2GNNBase
+from ..ops import grl_disc_ce
+from ..utils import MMD
+from .base import BaseGDA
+
+
+class A2GNN(BaseGDA):
+    def __init__(self, in_dim, hid_dim, num_classes, mode='node', num_layers=3, dropout=0.,
+                 act=F.relu, s_pnums=0, t_pnums=30, adv=False, weight=5, weight_decay=0., lr=4e-3,
+                 epoch=200, device='cuda:0', batch_size=0, num_neigh=-1, verbose=2, **kwargs):
+        super().__init__(in_dim=in_dim, hid_dim=hid_dim, num_classes=num_classes, num_layers=num_layers,
+                         dropout=dropout, act=act, weight_decay=weight_decay, lr=lr, epoch=epoch,
+                         device=device, batch_size=batch_size, num_neigh=num_neigh, verbose=verbose,
+                         **kwargs)
+        self.s_pnums, self.t_pnums, self.adv, self.weight, self.mode = s_pnums, t_pnums, adv, weight, mode
+        # the reference also runs a second full target forward per step whose logits it returns
+        # and never uses (a2gnn.py:211); kept by default so a step does the reference's work
+        self.compute_target_logits = True
+
+    def init_model(self, **kwargs):
+        return A2GNNBase(in_dim=self.in_dim, hid_dim=self.hid_dim, num_classes=self.num_classes,
+                         num_layers=self.num_layers, adv=self.adv, dropout=self.dropout, act=self.act,
+                         mode=self.mode, **kwargs).to(self.device)
+
+    def forward_model(self, source_data, target_data, alpha):
+        net = self.a2gnn
+        source_logits = net(source_data, self.s_pnums)                                   # :181
+        loss = F.nll_loss(F.log_softmax(source_logits, dim=1), source_data.y)            # :182
+        sb = tb = None
+        if self.mode != 'node':
+            sb, tb = source_data.batch, target_data.batch
+        source_features = net.feat_bottleneck(source_data.x, source_data.edge_index, sb, self.s_pnums)
+        target_features = net.feat_bottleneck(target_data.x, target_data.edge_index, tb, self.t_pnums)
+        if self.adv:                                                                     # :196-205, fused
+            disc = net.domain_discriminator
+            loss = loss + self.weight * grl_disc_ce(source_features, target_features, disc.weight,
+                                                    disc.bias, alpha)
+        else:                                                                            # :206-209
+            loss = loss + MMD(source_features, target_features) * self.weight
+        if self.compute_target_logits:
+            target_logits = net(target_data, self.t_pnums)                               # :211
+        else:
+            target_logits = None
+        return loss, source_logits, target_logits
+
+    def _prepare(self, source_data, target_data):
+        """Everything fit() does before its epoch loop (a2gnn.py:254-296)."""
+        if self.mode != 'node':
+            raise NotImplementedError("mode='graph' is out of scope (DESIGN.md)")
+        self._node_loaders(source_data, target_data)
+        self.a2gnn = self.init_model(**self.kwargs)
+        optimizer = torch.optim.Adam(self.a2gnn.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+
+        def step(src, tgt, alpha, epoch):
+            loss, source_logits, _ = self.forward_model(src, tgt, alpha)
+            return loss, source_logits
+
+        def alpha(e):                                                                    # :305-306
+            return 2. / (1. + np.exp(-10. * float(e) / self.epoch)) - 1
+
+        return self.a2gnn, optimizer, step, alpha
+
+    def fit(self, source_data, target_data):
+        self._train_epochs(*self._prepare(source_data, target_data))
+
+    def process_graph(self, data):
+        pass
+
+    def predict(self, data, source=False):
+        """``data`` is ignored, as in the reference: the loaders stored by fit() are replayed."""
+        self.a2gnn.eval()
+        loader, k = (self.source_loader, self.s_pnums) if source else (self.target_loader, self.t_pnums)
+        return self._predict_loader(loader, lambda batch: self.a2gnn(batch, k))

@@ -1,0 +1,139 @@
+"""``BaseGDA`` (pygda/models/base.py:13-162): hyper-parameter container and the abstract
+trainer API, plus the step loop every trainer of the reference re-implements by hand
+(loaders -> zip -> forward_model -> Adam step -> per-epoch micro-F1 + log line)."""
+import time
+from abc import ABC, abstractmethod
+
+import torch
+import torch.nn.functional as F
+
+from ..data import NeighborLoader
+from ..metrics import eval_micro_f1
+from ..utils import logger
+
+
+class BaseGDA(ABC):
+    def __init__(self, in_dim, hid_dim, num_classes, num_layers=2, dropout=0., weight_decay=0.,
+                 act=F.relu, lr=4e-3, epoch=100, device='cuda:0', batch_size=0, num_neigh=-1,
+                 verbose=2, **kwargs):
+        self.in_dim, self.hid_dim, self.num_classes = in_dim, hid_dim, num_classes
+        self.num_layers, self.dropout, self.weight_decay = num_layers, dropout, weight_decay
+        self.act, self.verbose, self.kwargs = act, verbose, kwargs
+        self.lr, self.epoch, self.device, self.batch_size = lr, epoch, device, batch_size
+        if type(num_neigh) is int:                                   # base.py:86-95
+            self.num_neigh = [num_neigh] * self.num_layers
+        elif type(num_neigh) is list:
+            if len(num_neigh) != self.num_layers:
+                raise ValueError('Number of neighbors should have the '
+                                 'same length as hidden layers dimension or'
+                                 'the number of layers.')
+            self.num_neigh = num_neigh
+        else:
+            raise ValueError('Number of neighbors must be int or list of int')
+        self.model = None
+        self.epoch_hook = None        # optional callable(epoch, loss, acc, seconds): bench / tests
+
+    # -- API of the reference -------------------------------------------------------
+    def fit(self, data, **kwargs):
+        """Subclasses override (base.py:99-111)."""
+
+    def predict(self, data, **kwargs):
+        """Subclasses override (base.py:113-125)."""
+
+    @abstractmethod
+    def init_model(self, **kwargs):
+        ...
+
+    @abstractmethod
+    def process_graph(self, data, **kwargs):
+        ...
+
+    @abstractmethod
+    def forward_model(self, data, **kwargs):
+        ...
+
+    # -- shared machinery -------------------------------------------------------------
+    def _node_loaders(self, source_data, target_data):
+        """a2gnn.py:254-277 (same block in every trainer): full batch when batch_size == 0."""
+        self.num_source_nodes, self.num_target_nodes = source_data.x.shape[0], target_data.x.shape[0]
+        dist = _dist_info()
+        if self.batch_size == 0:
+            self.source_batch_size, self.target_batch_size = self.num_source_nodes, self.num_target_nodes
+            sb, tb = self.source_batch_size, self.target_batch_size
+        else:
+            sb = tb = self.batch_size
+        full = self.batch_size == 0
+        kw = {} if full else dist
+        self.source_loader = NeighborLoader(source_data, self.num_neigh, batch_size=sb, **kw)
+        self.target_loader = NeighborLoader(target_data, self.num_neigh, batch_size=tb, **kw)
+
+    def _train_epochs(self, net, optimizer, step_fn, alpha_fn, before_step=None, epochs=None):
+        """The epoch loop of a2gnn.py:298-336: ``step_fn(src, tgt, alpha, epoch)`` returns
+        ``(loss, source_logits)``; the optimiser step happens here.  ``epochs`` (default
+        ``range(self.epoch)``) lets a harness run the same loop in slices."""
+        start = time.time()
+        for epoch in (range(self.epoch) if epochs is None else epochs):
+            epoch_loss, logits, labels = 0.0, [], []
+            alpha = alpha_fn(epoch)
+            for src, tgt in zip(self.source_loader, self.target_loader):
+                if before_step is not None:
+                    before_step()
+                else:
+                    net.train()
+                src, tgt = src.to(self.device), tgt.to(self.device)
+                loss, source_logits = step_fn(src, tgt, alpha, epoch)
+                optimizer.zero_grad()
+                loss.backward()
+                _allreduce_grads(optimizer)
+                optimizer.step()
+                epoch_loss += loss.item()
+                logits.append(source_logits.detach())
+                labels.append(src.y)
+            preds = torch.cat(logits).argmax(dim=1)
+            acc = eval_micro_f1(torch.cat(labels), preds)
+            secs = time.time() - start
+            logger(epoch=epoch, loss=epoch_loss, source_train_acc=acc, time=secs,
+                   verbose=self.verbose, train=True)
+            if self.epoch_hook is not None:
+                self.epoch_hook(epoch, epoch_loss, acc, secs)
+
+    def _predict_loader(self, loader, forward):
+        """predict() of the reference (a2gnn.py:384-411) keeps only the last batch when the
+        loader has several (:402-409 overwrite ``logits`` before concatenating it with itself);
+        here every batch's rows are returned, in loader order.  Identical for one batch."""
+        outs, labs = [], []
+        with torch.no_grad():
+            for batch in loader:
+                batch = batch.to(self.device)
+                out = forward(batch)
+                k = getattr(batch, "batch_size", None)
+                outs.append(out if k is None else out[:k])
+                labs.append(batch.y if k is None else batch.y[:k])
+        return torch.cat(outs), torch.cat(labs)
+
+
+def _dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dict(rank=dist.get_rank(), world_size=dist.get_world_size())
+    return dict(rank=0, world_size=1)
+
+
+def _allreduce_grads(optimizer):
+    """Data-parallel step: ONE flat all-reduce (RCCL over xGMI when the backend is nccl) of
+    all gradients, averaged over ranks.  No-op in single-process runs."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    params = [p for g in optimizer.param_groups for p in g["params"]]
+    for p in params:                      # a rank whose batch never touched p still joins
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p))
+        off += n

@@ -1,0 +1,48 @@
+"""``A2GNNBase`` (pygda/nn/a2gnn_base.py:11-203): L asymmetric-propagation conv layers
+(act + dropout after each), a conv classifier with one propagation step, optional linear
+domain discriminator behind gradient reversal."""
+import torch.nn.functional as F
+from torch import nn
+
+from .prop_gcn_conv import PropGCNConv
+from .reverse_layer import GradReverse
+
+
+def global_mean_pool(x, batch, size=None):
+    """Per-graph mean of node rows (graph mode only; plain torch, off the hot path)."""
+    import torch
+    n = int(batch.max()) + 1 if size is None else size
+    out = torch.zeros(n, x.size(1), dtype=x.dtype, device=x.device).index_add_(0, batch, x)
+    cnt = torch.zeros(n, dtype=x.dtype, device=x.device).index_add_(0, batch, torch.ones_like(batch, dtype=x.dtype))
+    return out / cnt.clamp(min=1).unsqueeze(1)
+
+
+class A2GNNBase(nn.Module):
+    def __init__(self, in_dim, hid_dim, num_classes, num_layers=1, adv=False, dropout=0.1,
+                 act=F.relu, mode="node", **kwargs):
+        super().__init__()
+        self.in_dim, self.hid_dim, self.num_classes = in_dim, hid_dim, num_classes
+        self.num_layers, self.adv, self.dropout, self.act, self.mode = num_layers, adv, dropout, act, mode
+        widths = [in_dim] + [hid_dim] * num_layers
+        self.convs = nn.ModuleList(PropGCNConv(a, b) for a, b in zip(widths[:-1], widths[1:]))
+        self.cls = PropGCNConv(hid_dim, num_classes) if mode == "node" else nn.Linear(hid_dim, num_classes)
+        if adv:
+            self.domain_discriminator = nn.Linear(hid_dim, 2)
+
+    def forward(self, data, prop_nums):
+        batch = None if self.mode == "node" else data.batch
+        h = self.feat_bottleneck(data.x, data.edge_index, batch, prop_nums=prop_nums)
+        return self.feat_classifier(h, data.edge_index, batch, prop_nums=1)
+
+    def feat_bottleneck(self, x, edge_index, batch, prop_nums=30):
+        for conv in self.convs:
+            x = F.dropout(self.act(conv(x, edge_index, prop_nums)), p=self.dropout, training=self.training)
+        if self.mode == "graph":
+            x = global_mean_pool(x, batch)
+        return x
+
+    def feat_classifier(self, x, edge_index, batch, prop_nums=1):
+        return self.cls(x, edge_index, prop_nums) if self.mode == "node" else self.cls(x)
+
+    def domain_classifier(self, x, alpha):
+        return self.domain_discriminator(GradReverse.apply(x, alpha))

@@ -1,0 +1,17 @@
+"""View attention (pygda/nn/attention.py:6-55): softmax over K stacked views of a learned
+per-view score, weighted sum.  K = 2 (GCN view, PPMI view) in UDAGCN."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class Attention(nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        self.dense_weight = nn.Linear(in_channels, 1)
+        self.dropout = nn.Dropout(0.1)     # constructed, never applied -- as in the reference (:26)
+
+    def forward(self, inputs):
+        stacked = torch.stack(inputs, dim=1)
+        weights = F.softmax(self.dense_weight(stacked), dim=1)
+        return torch.sum(stacked * weights, dim=1)

@@ -1,0 +1,51 @@
+"""``CachedGCNConv`` (pygda/nn/cached_gcn_conv.py:10-177) on the MI355X kernels:
+``x @ W`` (W ``[in, out]``), source-degree normalisation cached per ``cache_name``,
+one aggregation, bias added afterwards."""
+import torch
+from torch import nn
+
+from ..graph import CSRGraph, build_csr
+from ..ops import propagate
+from .linear import glorot, zeros
+
+
+class CachedGCNConv(nn.Module):
+    def __init__(self, in_channels, out_channels, weight=None, bias=None, improved=False,
+                 use_bias=True, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels, self.improved = in_channels, out_channels, improved
+        self.cache_dict = {}
+        if weight is None:
+            self.weight = nn.Parameter(torch.empty(in_channels, out_channels, dtype=torch.float32))
+            glorot(self.weight)
+        else:
+            self.weight = weight          # shared Parameter (UDAGCN ties the PPMI stack to the GCN stack)
+        if bias is None:
+            if use_bias:
+                self.bias = nn.Parameter(torch.empty(out_channels, dtype=torch.float32))
+                zeros(self.bias)
+            else:
+                self.register_parameter("bias", None)
+        else:
+            self.bias = bias
+
+    @staticmethod
+    def norm(edge_index, num_nodes, edge_weight=None, improved=False, dtype=None):
+        """(edge_index, weight) with ``deg`` taken over the SOURCE node (:88-103), by destination."""
+        return build_csr(edge_index, num_nodes, edge_weight, improved, True, True, "row").to_coo()
+
+    def _graph(self, x, edge_index, cache_name, edge_weight):
+        if isinstance(edge_index, CSRGraph):
+            return edge_index
+        g = self.cache_dict.get(cache_name)
+        if g is None:                     # :132-136 -- never invalidated, exactly like the reference
+            g = build_csr(edge_index, x.size(0), edge_weight, self.improved, True, True, "row")
+            self.cache_dict[cache_name] = g
+        return g
+
+    def forward(self, x, edge_index, cache_name="default_cache", edge_weight=None):
+        x = torch.matmul(x, self.weight)                                        # :130
+        return propagate(x, self._graph(x, edge_index, cache_name, edge_weight), 1, self.bias)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"

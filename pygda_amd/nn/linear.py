@@ -1,0 +1,56 @@
+"""PyG-style ``Linear`` (weight ``[out, in]``, glorot) used inside the conv layers.
+
+The dense hidden x weight contraction is a plain fp32 GEMM: it goes to the ROCm BLAS
+(hipBLASLt / rocBLAS fp32 MFMA kernels) through ``F.linear``; everything sparse or fused
+around it is ours.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import profiler
+
+
+def glorot(t):
+    """U(-a, a), a = sqrt(6 / (fan_in + fan_out)) -- PyG ``inits.glorot``."""
+    if t is not None:
+        a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+        with torch.no_grad():
+            t.uniform_(-a, a)
+
+
+def zeros(t):
+    if t is not None:
+        with torch.no_grad():
+            t.fill_(0)
+
+
+class Linear(nn.Module):
+    def __init__(self, in_channels, out_channels, bias=True, weight_initializer="glorot"):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight_initializer = weight_initializer
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if self.weight_initializer == "glorot":
+            glorot(self.weight)
+        else:
+            nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        zeros(self.bias)
+
+    def forward(self, x):
+        if profiler.enabled:
+            n = x.numel() // x.size(-1)
+            with profiler.region(f"dense_projection[{self.in_channels}x{self.out_channels}]", 1,
+                                 4 * (x.numel() + self.weight.numel() + n * self.out_channels),
+                                 2 * n * self.in_channels * self.out_channels):
+                return F.linear(x, self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, bias={self.bias is not None})"

@@ -1,0 +1,71 @@
+"""``PropGCNConv`` / ``gcn_norm`` on the MI355X aggregation kernels.
+
+Operator surface of pygda/nn/prop_gcn_conv.py:24-264 (same constructor, ``forward(x,
+edge_index, prop_nums=1, edge_weight=None)``, ``.lin.weight [out, in]``, ``.bias``); the
+body is ours: one cached CSR ingestion per graph instead of a ``gcn_norm`` per call, one
+K-step SpMM launch sequence instead of ``prop_nums`` PyG propagates, and a backward that
+re-runs the same kernel on the transposed CSR instead of saving K intermediates.
+"""
+import torch
+from torch import nn
+
+from ..graph import CSRGraph, as_graph, build_csr
+from ..ops import propagate
+from .linear import Linear, zeros
+
+
+def gcn_norm(edge_index, edge_weight=None, num_nodes=None, improved=False, add_self_loops=True,
+             dtype=None):
+    """Symmetric normalisation with self loops (prop_gcn_conv.py:24-81, tensor branch).
+
+    Returns ``(edge_index, edge_weight)`` like the reference, listed by destination node
+    (stable in the original edge order inside a destination) rather than in input order --
+    the multiset of weighted edges is identical.
+    """
+    if num_nodes is None:
+        num_nodes = int(edge_index.max()) + 1 if edge_index.numel() else 0
+    g = build_csr(edge_index, num_nodes, edge_weight, improved, add_self_loops, True, "col")
+    return g.to_coo()
+
+
+class PropGCNConv(nn.Module):
+    def __init__(self, in_channels, out_channels, improved=False, cached=False,
+                 add_self_loops=True, normalize=True, bias=True, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.improved, self.cached = improved, cached
+        self.add_self_loops, self.normalize = add_self_loops, normalize
+        self._cached_graph = None
+        self.lin = Linear(in_channels, out_channels, bias=False, weight_initializer="glorot")
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()          # second glorot draw, as in the reference (:144-147)
+
+    def reset_parameters(self):
+        self.lin.reset_parameters()
+        zeros(self.bias)
+        self._cached_graph = None
+
+    def _graph(self, x, edge_index, edge_weight):
+        if isinstance(edge_index, CSRGraph):
+            return edge_index
+        if self.cached and self._cached_graph is not None:
+            return self._cached_graph
+        g = as_graph(edge_index, x.size(0), edge_weight, self.improved,
+                     self.add_self_loops and self.normalize, self.normalize, "col")
+        if self.cached:
+            self._cached_graph = g
+        return g
+
+    def forward(self, x, edge_index, prop_nums=1, edge_weight=None):
+        out = self.lin(x)                                        # :205
+        if prop_nums > 0:                                        # :208-213, bias fused in the last step
+            return propagate(out, self._graph(x, edge_index, edge_weight), prop_nums, self.bias)
+        if self.bias is not None:
+            out = out + self.bias
+        return out
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"

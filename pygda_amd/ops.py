@@ -1,0 +1,210 @@
+"""torch.autograd wrappers over the C ABI (include/gda_hip.h).  PyTorch supplies device
+memory, the stream and autograd plumbing; every numeric kernel named here is ours."""
+import torch
+
+from . import _lib, profiler
+from .graph import CSRGraph, build_csr
+
+
+def _f32c(t, name):
+    _lib.require_gpu_tensor(t, name)
+    if t.dtype != torch.float32:
+        raise _lib.GdaError(f"{name}: the aggregation path computes in fp32, got {t.dtype}")
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------- SpMM --
+def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
+    """``A_hat^K @ x (+ bias)`` without autograd (K launches, ping-pong buffers)."""
+    x = _f32c(x, "x")
+    if x.dim() != 2 or x.size(0) != graph.num_nodes:
+        raise ValueError(f"x must be [num_nodes={graph.num_nodes}, d], got {tuple(x.shape)}")
+    rp, ci, va = (graph.t_rowptr, graph.t_colidx, graph.t_val) if transposed else \
+                 (graph.rowptr, graph.colidx, graph.val)
+    n, d = x.shape
+    y = torch.empty_like(x)
+    tmp = torch.empty_like(x) if K > 1 else None
+    b = None if bias is None else _f32c(bias, "bias")
+    L = _lib.lib()
+    if profiler.enabled:      # algorithmic bytes per launch: nnz*(4+4) + (N+1)*4 + 2*N*d*4
+        nbytes = K * (graph.nnz * 8 + (n + 1) * 4 + 2 * n * d * 4)
+        ctx = profiler.region(f"spmm_csr_f32[d={d}]", K, nbytes, K * 2 * graph.nnz * d)
+    else:
+        ctx = profiler.region("", 0)
+    with ctx:
+        _lib.check(L.gda_spmm_csr_kstep_f32(_lib.ptr(rp), _lib.ptr(ci), _lib.ptr(va), n, d, int(K),
+                                            _lib.ptr(x), d, _lib.ptr(y), d, _lib.ptr(tmp), _lib.ptr(b),
+                                            _lib.stream()), "gda_spmm_csr_kstep_f32")
+    return y
+
+
+class _Propagate(torch.autograd.Function):
+    """K-step neighbour aggregation.  Linear in x, so nothing but the graph is saved:
+    backward is the same K-step kernel on the by-source CSR (A_hat^T)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, graph, K):
+        ctx.graph, ctx.K, ctx.has_bias = graph, K, bias is not None
+        return spmm_kstep(graph, x, K, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        gx = spmm_kstep(ctx.graph, gy.contiguous(), ctx.K, None, transposed=True) \
+            if ctx.needs_input_grad[0] else None
+        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[1] else None
+        return gx, gb, None, None
+
+
+def propagate(x, graph: CSRGraph, K=1, bias=None):
+    """``out = A_hat^K x + bias`` with autograd (prop_gcn_conv.py:208-213)."""
+    if K < 1:
+        raise ValueError("K must be >= 1")
+    return _Propagate.apply(x, bias, graph, int(K))
+
+
+# ---------------------------------------------------------------------------- MMD --
+class _MMD(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, tgt, src_idx, tgt_idx, times, n, kernel_mul, kernel_num, fix_sigma):
+        src, tgt = _f32c(src, "source_feat"), _f32c(tgt, "target_feat")
+        d = src.size(1)
+        if tgt.size(1) != d:
+            raise ValueError("source and target features must have the same width")
+        dev = src.device
+        m = 2 * n
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        bw = torch.empty(times, dtype=torch.float32, device=dev)
+        l2 = torch.empty(times, m, m, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        ws = _lib.workspace(L.gda_mmd_workspace_bytes(times, n, d), dev, "mmd")
+        with profiler.region("mmd_fwd", 3, 0, times * (3 * m * m * d + 12 * m * m)):
+            _lib.check(L.gda_mmd_fwd_f32(
+                _lib.ptr(src), src.size(1), _lib.ptr(tgt), tgt.size(1), d, _lib.ptr(src_idx),
+                _lib.ptr(tgt_idx), times, n, float(kernel_mul), int(kernel_num),
+                float(fix_sigma) if fix_sigma else 0.0, _lib.ptr(loss), _lib.ptr(bw), _lib.ptr(l2),
+                _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_mmd_fwd_f32")
+        ctx.save_for_backward(src, tgt, src_idx, tgt_idx, bw, l2)
+        ctx.cfg = (times, n, float(kernel_mul), int(kernel_num))
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        src, tgt, src_idx, tgt_idx, bw, l2 = ctx.saved_tensors
+        times, n, kernel_mul, kernel_num = ctx.cfg
+        d, dev, m = src.size(1), src.device, 2 * n
+        grad_rows = torch.empty(times, m, d, dtype=torch.float32, device=dev)
+        gl = gl.reshape(1).to(torch.float32).contiguous()
+        L = _lib.lib()
+        with profiler.region("mmd_bwd", 1, 0, times * (3 * m * m * d + 12 * m * m)):
+            _lib.check(L.gda_mmd_bwd_f32(
+                _lib.ptr(src), src.size(1), _lib.ptr(tgt), tgt.size(1), d, _lib.ptr(src_idx),
+                _lib.ptr(tgt_idx), times, n, kernel_mul, kernel_num, _lib.ptr(bw), _lib.ptr(l2),
+                _lib.ptr(gl), _lib.ptr(grad_rows), _lib.stream()), "gda_mmd_bwd_f32")
+        if src_idx is None:                       # get_MMD on the rows as given
+            gs, gt = grad_rows[0, :n], grad_rows[0, n:]
+        else:
+            gs = _scatter_rows(grad_rows, src_idx, 0, n, src.size(0))
+            gt = _scatter_rows(grad_rows, tgt_idx, n, n, tgt.size(0))
+        return (gs if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None,
+                None, None, None, None, None, None, None)
+
+
+def _scatter_rows(grad_rows, idx, offset, n, num_feat_rows):
+    """Sum the per-sample row gradients back onto the sampled feature rows (duplicates
+    included) deterministically: a CSR SpMM with the 0/1 selection matrix, built on device
+    by the same ingestion kernel (no self loops, no normalisation)."""
+    times, m, d = grad_rows.shape
+    dev = grad_rows.device
+    pos = (torch.arange(times, device=dev).view(-1, 1) * m + offset +
+           torch.arange(n, device=dev).view(1, -1)).reshape(-1)
+    n_nodes = max(num_feat_rows, times * m)
+    g = build_csr(torch.stack([pos, idx.reshape(-1)]), n_nodes, None, add_self_loops=False,
+                  normalize=False, validate=False)
+    flat = grad_rows.view(times * m, d)
+    if n_nodes > times * m:                       # SpMM gathers rows < n_nodes only via colidx: fine
+        pass
+    out = torch.empty(num_feat_rows, d, dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    _lib.check(L.gda_spmm_csr_f32(_lib.ptr(g.rowptr), _lib.ptr(g.colidx), _lib.ptr(g.val),
+                                  num_feat_rows, d, _lib.ptr(flat), d, _lib.ptr(out), d, None,
+                                  _lib.stream()), "gda_spmm_csr_f32")
+    return out
+
+
+def mmd_loss(source_feat, target_feat, src_idx=None, tgt_idx=None, kernel_mul=2.0, kernel_num=5,
+             fix_sigma=None):
+    """Sampled multi-kernel MMD (mmd.py:57-159).  ``src_idx/tgt_idx``: ``[times, n]`` int64
+    device tensors of row samples, or both ``None`` for get_MMD on the rows as given."""
+    if (src_idx is None) != (tgt_idx is None):
+        raise ValueError("give both index tensors or neither")
+    if src_idx is None:
+        if source_feat.size(0) != target_feat.size(0):
+            # the reference's XX + YY - XY - YX broadcast fails the same way (mmd.py:100-106)
+            raise RuntimeError("get_MMD needs equally many source and target rows, got "
+                               f"{source_feat.size(0)} and {target_feat.size(0)}")
+        times, n = 1, source_feat.size(0)
+    else:
+        _lib.require_gpu_tensor(src_idx, "src_idx", torch.int64)
+        _lib.require_gpu_tensor(tgt_idx, "tgt_idx", torch.int64)
+        if src_idx.shape != tgt_idx.shape or src_idx.dim() != 2:
+            raise RuntimeError("source and target samples must both be [times, sampling_num]")
+        times, n = src_idx.shape
+        src_idx, tgt_idx = src_idx.contiguous(), tgt_idx.contiguous()
+    return _MMD.apply(source_feat, target_feat, src_idx, tgt_idx, int(times), int(n), kernel_mul,
+                      kernel_num, fix_sigma)
+
+
+# ------------------------------------------------- GRL + discriminator + CE (fused) --
+class _GrlDiscCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fs, ft, W, b, alpha, labels):
+        fs, ft, W, b = _f32c(fs, "source_feat"), _f32c(ft, "target_feat"), _f32c(W, "weight"), _f32c(b, "bias")
+        ns, nt, h, C = fs.size(0), ft.size(0), fs.size(1), W.size(0)
+        dev = fs.device
+        probs = torch.empty(ns + nt, C, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        ws = _lib.workspace(L.gda_grl_disc_workspace_bytes(ns + nt, h, C), dev, "disc")
+        _lib.check(L.gda_grl_disc_ce_fwd_f32(
+            _lib.ptr(fs), h, ns, _lib.ptr(ft), h, nt, h, C, _lib.ptr(W), _lib.ptr(b), _lib.ptr(labels),
+            _lib.ptr(probs), _lib.ptr(loss), _lib.ptr(ws), ws.numel(), _lib.stream()),
+            "gda_grl_disc_ce_fwd_f32")
+        ctx.save_for_backward(fs, ft, W, probs, labels)
+        ctx.alpha = float(alpha)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        fs, ft, W, probs, labels = ctx.saved_tensors
+        ns, nt, h, C = fs.size(0), ft.size(0), fs.size(1), W.size(0)
+        dev = fs.device
+        gfs = torch.empty_like(fs) if ctx.needs_input_grad[0] else None
+        gft = torch.empty_like(ft) if ctx.needs_input_grad[1] else None
+        gW, gb = torch.empty_like(W), torch.empty(C, dtype=torch.float32, device=dev)
+        gl = gl.reshape(1).to(torch.float32).contiguous()
+        L = _lib.lib()
+        ws = _lib.workspace(L.gda_grl_disc_workspace_bytes(ns + nt, h, C), dev, "disc")
+        _lib.check(L.gda_grl_disc_ce_bwd_f32(
+            _lib.ptr(fs), h, ns, _lib.ptr(ft), h, nt, h, C, _lib.ptr(W), _lib.ptr(labels),
+            _lib.ptr(probs), _lib.ptr(gl), ctx.alpha, _lib.ptr(gfs), _lib.ptr(gft), _lib.ptr(gW),
+            _lib.ptr(gb), _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_grl_disc_ce_bwd_f32")
+        return gfs, gft, gW, gb, None, None
+
+
+def grl_disc_ce(source_feat, target_feat, weight, bias, alpha, labels=None):
+    """``F.cross_entropy(Linear(GradReverse(cat(source, target))), domain_labels)`` fused
+    (a2gnn.py:197-205 / grade.py:170-176).  Default labels: 0 for source rows, 1 for target."""
+    return _GrlDiscCE.apply(source_feat, target_feat, weight, bias, alpha, labels)
+
+
+# -------------------------------------------------------------------------- gather --
+def gather_rows(x, idx):
+    """``x[idx]`` for a ``[N, d]`` fp32 feature matrix (mini-batch assembly)."""
+    x = _f32c(x, "x")
+    _lib.require_gpu_tensor(idx, "idx", torch.int64)
+    idx = idx.contiguous()
+    out = torch.empty(idx.numel(), x.size(1), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    _lib.check(L.gda_gather_rows_f32(_lib.ptr(x), x.size(1), x.size(1), _lib.ptr(idx), idx.numel(),
+                                     _lib.ptr(out), x.size(1), _lib.stream()), "gda_gather_rows_f32")
+    return out

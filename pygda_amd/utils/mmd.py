@@ -1,0 +1,36 @@
+"""``MMD`` / ``get_MMD`` / ``guassian_kernel`` (pygda/utils/mmd.py:4-159) on the fused
+MI355X kernels (:func:`pygda_amd.ops.mmd_loss`): no ``[n, n, d]`` temporary, recompute in
+the backward pass."""
+import torch
+
+from ..ops import mmd_loss
+
+
+def guassian_kernel(source, target, kernel_mul=2.0, kernel_num=5, fix_sigma=None):
+    """The ``[m, m]`` multi-bandwidth kernel matrix itself (mmd.py:4-55), for callers that
+    want it.  Off the training path (the trainers never materialise it): evaluated with
+    device tensor ops in row blocks, same arithmetic as the reference."""
+    total = torch.cat([source, target], dim=0)
+    m = total.size(0)
+    rows = [((total.unsqueeze(0) - total[s:s + 256].unsqueeze(1)) ** 2).sum(2) for s in range(0, m, 256)]
+    L2 = torch.cat(rows, dim=0)
+    bandwidth = fix_sigma if fix_sigma else (torch.sum(L2.data) + 1e-6) / (m ** 2 - m)
+    bandwidth = bandwidth / (kernel_mul ** (kernel_num // 2))
+    return sum(torch.exp(-L2 / (bandwidth * (kernel_mul ** i))) for i in range(kernel_num))
+
+
+def get_MMD(source_feat, target_feat, kernel_mul=2.0, kernel_num=5, fix_sigma=None):
+    """mean(XX + YY - XY - YX) over the given rows (mmd.py:57-107)."""
+    return mmd_loss(source_feat, target_feat, None, None, kernel_mul, kernel_num, fix_sigma)
+
+
+def MMD(source_feat, target_feat, sampling_num=1000, times=5):
+    """Average of ``times`` MMDs over ``sampling_num`` rows drawn with replacement per
+    domain (mmd.py:109-159).  The draws come from the CPU default generator exactly as in
+    the reference (``torch.randint`` without a device, :148-149), so a seeded run samples
+    the same rows; only the 2 x times x sampling_num indices cross PCIe."""
+    source_sample = torch.randint(source_feat.size(0), (times, sampling_num))
+    target_sample = torch.randint(target_feat.size(0), (times, sampling_num))
+    dev = source_feat.device
+    return mmd_loss(source_feat, target_feat, source_sample.to(dev, non_blocking=True),
+                    target_sample.to(dev, non_blocking=True))

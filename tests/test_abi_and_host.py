@@ -1,0 +1,146 @@
+"""CPU: the C-ABI library loads and exports every symbol include/gda_hip.h declares; the
+host-side mirror of the reference interface (ctor validation, Data, loaders, metrics,
+logger) behaves like the reference.  No kernels are launched here."""
+import io
+import os
+import re
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import pygda_amd
+from pygda_amd import _lib
+from pygda_amd.data import Data, NeighborLoader, to_undirected
+from pygda_amd.metrics import eval_macro_f1, eval_micro_f1
+from pygda_amd.models import A2GNN, GRADE, BaseGDA
+from pygda_amd.utils import logger
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "gda_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(gda_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in gda_hip.h but not exported"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert L.gda_abi_version() == 1
+    assert L.gda_status_string(0) == b"ok"
+    assert b"workspace" in L.gda_status_string(-3)
+    assert L.gda_mmd_workspace_bytes(5, 1000, 128) > 0
+    assert L.gda_graph_workspace_bytes(1000, 100) > 0
+
+
+def test_argument_validation_without_gpu():
+    """Status codes for bad arguments come back before anything touches a device."""
+    L = _lib.lib()
+    assert L.gda_spmm_csr_f32(None, None, None, 10, 4, None, 4, None, 4, None, None) == -1     # NULL
+    assert L.gda_spmm_csr_f32(None, None, None, -1, 4, None, 4, None, 4, None, None) == -2     # size
+    assert L.gda_spmm_csr_kstep_f32(None, None, None, 10, 4, 0, None, 4, None, 4, None, None, None) == -2
+    assert L.gda_build_csr_norm(None, None, None, 5, 3, 1.0, 1, 1, 0, None, None, None, None, None, None,
+                                None, 0, None) == -1
+    assert L.gda_mmd_fwd_f32(None, 4, None, 4, 4, None, None, 1, 8, 2.0, 5, 0.0, None, None, None, None, 0,
+                             None) == -1
+    assert L.gda_gather_rows_f32(None, 4, 8, None, 3, None, 8, None) == -2                    # ldx < d
+
+
+def test_product_path_has_no_cpu_fallback():
+    x = torch.randn(4, 8)
+    ei = torch.tensor([[0, 1], [1, 0]])
+    conv = pygda_amd.nn.PropGCNConv(8, 4)
+    with pytest.raises(_lib.GdaError):
+        conv(x, ei, 2)
+    with pytest.raises(_lib.GdaError):
+        pygda_amd.utils.get_MMD(torch.randn(4, 3), torch.randn(4, 3))
+
+
+def test_basegda_num_neigh_validation():
+    m = A2GNN(8, 4, 3, num_layers=2, num_neigh=[15, 10], device="cpu")
+    assert m.num_neigh == [15, 10]
+    assert A2GNN(8, 4, 3, num_layers=3, device="cpu").num_neigh == [-1, -1, -1]
+    with pytest.raises(ValueError):
+        A2GNN(8, 4, 3, num_layers=2, num_neigh=[15], device="cpu")
+    with pytest.raises(ValueError):
+        GRADE(8, 4, 3, num_layers=2, num_neigh="all", device="cpu")
+    with pytest.raises(TypeError):
+        BaseGDA(8, 4, 3)          # abstract
+
+
+def test_reference_signatures_and_defaults():
+    import inspect
+    sig = inspect.signature(A2GNN.__init__).parameters
+    want = dict(mode='node', num_layers=3, dropout=0., s_pnums=0, t_pnums=30, adv=False, weight=5,
+                weight_decay=0., lr=4e-3, epoch=200, device='cuda:0', batch_size=0, num_neigh=-1, verbose=2)
+    for k, v in want.items():
+        assert sig[k].default == v, k
+    assert sig['act'].default is F.relu
+    g = inspect.signature(GRADE.__init__).parameters
+    assert (g['disc'].default, g['weight'].default, g['weight_decay'].default, g['lr'].default) == ('JS', 0.01, 0.01, 0.001)
+    p = inspect.signature(pygda_amd.nn.PropGCNConv.forward).parameters
+    assert list(p)[1:] == ['x', 'edge_index', 'prop_nums', 'edge_weight'] and p['prop_nums'].default == 1
+    c = inspect.signature(pygda_amd.nn.CachedGCNConv.forward).parameters
+    assert c['cache_name'].default == "default_cache"
+    mm = inspect.signature(pygda_amd.utils.MMD).parameters
+    assert (mm['sampling_num'].default, mm['times'].default) == (1000, 5)
+
+
+def test_init_rng_stream_matches_reference_golden():
+    """Same seed -> same initial weights as the reference's A2GNNBase (double glorot draw
+    per conv, torch default init for the discriminator)."""
+    from tests.conftest import load_golden, sub
+    for adv in (False, True):
+        g = load_golden("a2gnn_forward_adv" if adv else "a2gnn_forward_mmd")
+        torch.manual_seed(int(g["init_seed"]))
+        net = pygda_amd.nn.A2GNNBase(24, 16, 5, num_layers=2, adv=adv, dropout=0.0)
+        sd = net.state_dict()
+        assert set(sd) == set(sub(g, "param/"))
+        for k, v in sub(g, "param/").items():
+            np.testing.assert_array_equal(sd[k].numpy(), v)
+    g = load_golden("grade_forward_js")
+    torch.manual_seed(int(g["init_seed"]))
+    net = pygda_amd.nn.GRADEBase(24, 8, 5, num_layers=3, dropout=0.0, disc="JS")
+    for k, v in sub(g, "param/").items():
+        np.testing.assert_array_equal(net.state_dict()[k].numpy(), v)
+
+
+def test_data_and_full_batch_loader():
+    x = torch.randn(6, 3)
+    ei = torch.tensor([[0, 1, 2, 2], [1, 0, 3, 3]])
+    d = Data(x=x, edge_index=ei, y=torch.arange(6))
+    assert d.num_nodes == 6 and d.num_edges == 4 and d.num_node_features == 3
+    assert d.to("cpu") is d
+    loader = NeighborLoader(d, [-1, -1], batch_size=6)
+    assert len(loader) == 1 and next(iter(loader)) is d
+    und = to_undirected(ei, 6)
+    assert und.size(1) == 4      # (0,1),(1,0),(2,3),(3,2); the duplicate is merged
+    assert Data(x=x, edge_index=und).is_undirected() and not d.is_undirected()
+
+
+def test_metrics_match_sklearn():
+    from sklearn.metrics import f1_score
+    g = torch.Generator().manual_seed(0)
+    for c in (2, 5, 9):
+        y = torch.randint(0, c, (500,), generator=g)
+        p = torch.randint(0, c, (500,), generator=g)
+        assert abs(eval_micro_f1(y, p) - f1_score(y.numpy(), p.numpy(), average="micro")) < 1e-12
+        assert abs(eval_macro_f1(y, p) - f1_score(y.numpy(), p.numpy(), average="macro")) < 1e-12
+    # a class that is predicted but absent from the labels still counts (sklearn semantics)
+    y, p = torch.tensor([0, 0, 1, 1]), torch.tensor([0, 2, 1, 1])
+    assert abs(eval_macro_f1(y, p) - f1_score(y.numpy(), p.numpy(), average="macro")) < 1e-12
+
+
+def test_logger_format():
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        logger(epoch=3, loss=1.23456, source_train_acc=0.5, time=2.0, verbose=2, train=True)
+        logger(epoch=3, loss=1.0, verbose=0)
+        logger(epoch=4, loss=(1.0, 2.0), verbose=1)
+    lines = buf.getvalue().splitlines()
+    assert lines[0] == "Epoch 0003: loss 1.2346, source acc 0.5000, time 2.00"
+    assert lines[1] == "Epoch 0004: Loss I 1.0000 | Loss O 2.0000 | "

@@ -1,0 +1,328 @@
+"""GPU: the HIP path (through the C ABI) against the golden vectors recorded from the
+reference and against the CPU oracle on the same seeded inputs.
+
+Tolerances (stated once): integer / index work and the normalisation weights are bit-exact;
+a single aggregation is bit-exact against the oracle (same edge order, separately rounded
+multiply and add); anything downstream of the dense projection (a BLAS GEMM whose summation
+order differs from the CPU's) is compared at 1e-4 absolute on logits / 1e-4 relative on
+losses and gradients -- the bound BASELINE.json's north_star states -- with predicted
+labels identical.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import pygda_amd
+from pygda_amd import ops
+from pygda_amd.data import Data
+from pygda_amd.graph import build_csr
+from pygda_amd.nn import A2GNNBase, CachedGCNConv, GRADEBase, PropGCNConv
+from oracle import pygda_cpu as O
+from tests.conftest import T, load_golden, sub
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LOGIT_ATOL = 1e-4
+REL = 1e-4
+
+
+def close(a, b, rtol=REL, atol=1e-6):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def exact(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_array_equal(a, b)
+
+
+def by_destination(ei, w):
+    """The reference lists normalised edges in input order, the CSR by destination (stable)."""
+    order = np.argsort(ei[1], kind="stable")
+    return ei[:, order], w[order]
+
+
+# ------------------------------------------------------------------ graph ingestion --
+@pytest.mark.parametrize("name", ["g7", "g64", "g300d", "g300u"])
+def test_gcn_norm_bit_exact(name):
+    g = sub(load_golden("gcn_norm"), name + "/")
+    ei, n, w = T(g["edge_index"], DEV), int(g["n"]), T(g["w"], DEV)
+    for tag, ew, improved in (("plain", None, False), ("improved", None, True), ("weighted", w, False)):
+        for side in ("col", "row"):
+            G = build_csr(ei, n, ew, improved, True, True, side)
+            got_ei, got_w = G.to_coo()
+            want_ei, want_w = by_destination(g[f"{tag}/{side}/edge_index"], g[f"{tag}/{side}/weight"])
+            exact(got_ei, want_ei)
+            exact(got_w, want_w)
+            # the transpose CSR holds the same weighted edges, listed by source
+            Gt = G.transposed()
+            t_ei, t_w = Gt.to_coo()                     # rows of Gt are sources: (dst, src) swapped
+            order = np.argsort(g[f"{tag}/{side}/edge_index"][0], kind="stable")
+            exact(t_ei[0], g[f"{tag}/{side}/edge_index"][1][order])
+            exact(t_ei[1], g[f"{tag}/{side}/edge_index"][0][order])
+            exact(t_w, g[f"{tag}/{side}/weight"][order])
+
+
+def test_graph_edge_cases():
+    # empty edge list: only the appended loops remain, each with weight 1
+    G = build_csr(torch.zeros(2, 0, dtype=torch.int64, device=DEV), 5)
+    exact(G.rowptr, np.arange(6)); exact(G.val[:5], np.ones(5, np.float32))
+    # no self loops + isolated node: degree 0 -> inf -> 0 weight, empty row
+    ei = torch.tensor([[0, 1], [1, 0]], device=DEV)
+    G = build_csr(ei, 3, None, False, False, True)
+    exact(G.rowptr, [0, 1, 2, 2]); exact(G.val[:2], [1.0, 1.0])
+    with pytest.raises(IndexError):
+        build_csr(torch.tensor([[0, 7], [1, 0]], device=DEV), 3)
+
+
+# ----------------------------------------------------------------- aggregation --
+@pytest.mark.parametrize("name,d", [("g7", 3), ("g64", 8), ("g300d", 128), ("g300u", 5), ("g300d", 6),
+                                    ("g300u", 64), ("g64", 260)])
+@pytest.mark.parametrize("K", [1, 3, 10])
+def test_spmm_bit_exact_vs_oracle(name, d, K):
+    g = sub(load_golden("gcn_norm"), name + "/")
+    ei, n = T(g["edge_index"]), int(g["n"])
+    gen = torch.Generator().manual_seed(d * 31 + K)
+    x = torch.randn(n, d, generator=gen)
+    bias = torch.randn(d, generator=gen)
+    nei, nw = O.gcn_norm(ei, None, n)
+    want = x
+    for _ in range(K):
+        want = O.propagate(nei, nw, want)
+    want = want + bias
+    G = build_csr(ei.to(DEV), n)
+    got = ops.spmm_kstep(G, x.to(DEV), K, bias.to(DEV))
+    exact(got, want)
+    # backward operator: the transpose, also in edge order
+    gy = torch.randn(n, d, generator=gen)
+    xg = x.clone().requires_grad_()
+    out = xg
+    for _ in range(K):
+        out = O.propagate(nei, nw, out)
+    out.backward(gy)
+    got_gx = ops.spmm_kstep(G, gy.to(DEV), K, None, transposed=True)
+    exact(got_gx, xg.grad)
+
+
+@pytest.mark.parametrize("name,fin,fout", [("g7", 5, 3), ("g64", 16, 8), ("g300d", 32, 128), ("g300u", 24, 5)])
+def test_prop_gcn_conv_golden(name, fin, fout):
+    g = sub(load_golden("prop_gcn_conv"), name + "/")
+    conv = PropGCNConv(fin, fout).to(DEV)
+    conv.load_state_dict({k: T(v) for k, v in sub(g, "param/").items()})
+    ei = T(g["edge_index"], DEV)
+    for k in (0, 1, 3, 10):
+        x = T(g["x"], DEV).requires_grad_()
+        conv.zero_grad()
+        y = conv(x, ei, k)
+        (y * T(g["gy"], DEV)).sum().backward()
+        close(y, g[f"k{k}/y"], atol=1e-5); close(x.grad, g[f"k{k}/gx"], atol=1e-5)
+        close(conv.lin.weight.grad, g[f"k{k}/gW"], atol=1e-4); close(conv.bias.grad, g[f"k{k}/gb"], atol=1e-4)
+
+
+@pytest.mark.parametrize("name,fin,fout", [("g7", 5, 3), ("g300d", 32, 16)])
+def test_cached_gcn_conv_golden(name, fin, fout):
+    g = sub(load_golden("cached_gcn_conv"), name + "/")
+    conv = CachedGCNConv(fin, fout).to(DEV)
+    conv.load_state_dict({k: T(v) for k, v in sub(g, "param/").items()})
+    x = T(g["x"], DEV).requires_grad_()
+    ei = T(g["edge_index"], DEV)
+    y = conv(x, ei, "k1")
+    (y * T(g["gy"], DEV)).sum().backward()
+    close(y, g["y"], atol=1e-5); close(x.grad, g["gx"], atol=1e-5)
+    close(conv.weight.grad, g["gW"], atol=1e-4); close(conv.bias.grad, g["gb"], atol=1e-4)
+    # the per-name cache is never invalidated (cached_gcn_conv.py:132-136)
+    close(conv(x.detach(), ei[:, : ei.size(1) // 2], "k1"), g["y_cached"], atol=1e-5)
+
+
+def test_spmm_properties_large():
+    """Size-independent checks at a size the CPU oracle would not enjoy: adjoint identity
+    <A x, y> == <x, A^T y>, linearity, and K steps == K single steps (bit-exact)."""
+    n, e, d = 200_000, 2_000_000, 128
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    ei = torch.randint(0, n, (2, e), generator=gen, device=DEV)
+    G = build_csr(ei, n)
+    assert G.nnz <= e + n
+    x = torch.randn(n, d, generator=gen, device=DEV)
+    y = torch.randn(n, d, generator=gen, device=DEV)
+    Ax = ops.spmm_kstep(G, x, 1)
+    Aty = ops.spmm_kstep(G, y, 1, transposed=True)
+    lhs, rhs = (Ax.double() * y.double()).sum(), (x.double() * Aty.double()).sum()
+    assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs), 1.0) * 1e3
+    close(ops.spmm_kstep(G, 2.0 * x + y, 1), 2.0 * Ax + ops.spmm_kstep(G, y, 1), rtol=1e-5, atol=1e-5)
+    step = x
+    for _ in range(3):
+        step = ops.spmm_kstep(G, step, 1)
+    exact(ops.spmm_kstep(G, x, 3), step)
+    # row sums of A_hat against the dense definition on a random row subset
+    ones = torch.ones(n, 4, device=DEV)
+    rs = ops.spmm_kstep(G, ones, 1)[:, 0]
+    rp = G.rowptr.long()
+    seg = torch.zeros(n, device=DEV, dtype=torch.float64).index_add_(
+        0, torch.repeat_interleave(torch.arange(n, device=DEV), rp[1:] - rp[:-1]), G.val[: G.nnz].double())
+    close(rs, seg, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------ MMD --
+@pytest.mark.parametrize("tag", ["small", "mid", "a2gnn"])
+def test_mmd_golden(tag):
+    g = load_golden(f"mmd_{tag}")
+    s, t = T(g["src"], DEV).requires_grad_(), T(g["tgt"], DEV).requires_grad_()
+    torch.manual_seed(int(g["seed"]))
+    loss = pygda_amd.utils.MMD(s, t)          # draws the same rows from the CPU generator
+    loss.backward()
+    close(loss, g["loss"], rtol=REL, atol=1e-6)
+    scale = np.abs(g["gsrc"]).max()
+    close(s.grad, g["gsrc"], rtol=1e-3, atol=1e-4 * scale)
+    close(t.grad, g["gtgt"], rtol=1e-3, atol=1e-4 * np.abs(g["gtgt"]).max())
+
+
+def test_get_mmd_golden():
+    g = load_golden("get_mmd_96")
+    s, t = T(g["src"], DEV).requires_grad_(), T(g["tgt"], DEV).requires_grad_()
+    close(pygda_amd.utils.guassian_kernel(s, t), g["kernel"], rtol=1e-5, atol=1e-6)
+    loss = pygda_amd.utils.get_MMD(s, t)
+    loss.backward()
+    close(loss, g["loss"], rtol=REL, atol=1e-6)
+    close(s.grad, g["gsrc"], rtol=1e-3, atol=1e-4 * np.abs(g["gsrc"]).max())
+    close(t.grad, g["gtgt"], rtol=1e-3, atol=1e-4 * np.abs(g["gtgt"]).max())
+    with pytest.raises(RuntimeError):          # unequal row counts fail, as the reference's broadcast does
+        pygda_amd.utils.get_MMD(s[:10], t[:20])
+
+
+def test_mmd_properties():
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    a = torch.randn(512, 645, generator=gen, device=DEV)         # GRADE width hid*L + C, not a multiple of 4
+    close(pygda_amd.utils.get_MMD(a, a.clone()), 0.0, atol=1e-6)  # identical domains
+    b = torch.randn(512, 645, generator=gen, device=DEV) + 0.3
+    ab, ba = pygda_amd.utils.get_MMD(a, b), pygda_amd.utils.get_MMD(b, a)
+    close(ab, ba, rtol=1e-5)                                      # symmetric in the domains
+    assert ab.item() > 1e-3
+    torch.manual_seed(3)
+    l1 = pygda_amd.utils.MMD(a, b, sampling_num=300, times=3)
+    torch.manual_seed(3)
+    l2 = pygda_amd.utils.MMD(a, b, sampling_num=300, times=3)
+    exact(l1, l2)                                                 # deterministic reductions
+
+
+# --------------------------------------------------- GRL + discriminator + CE --
+@pytest.mark.parametrize("ns,nt,h,C", [(300, 200, 16, 2), (1000, 777, 128, 2), (50, 60, 645, 2), (40, 30, 20, 3)])
+def test_grl_disc_ce_vs_torch(ns, nt, h, C):
+    gen = torch.Generator().manual_seed(ns + h)
+    fs, ft = torch.randn(ns, h, generator=gen), torch.randn(nt, h, generator=gen)
+    W, b = torch.randn(C, h, generator=gen) * 0.1, torch.randn(C, generator=gen) * 0.1
+    lab = torch.cat([torch.zeros(ns, dtype=torch.long), torch.ones(nt, dtype=torch.long)])
+    if C > 2:
+        lab = torch.randint(0, C, (ns + nt,), generator=gen)
+    alpha = 0.7
+    ref_in = [v.clone().requires_grad_() for v in (fs, ft, W, b)]
+    z = F.linear(O.grad_reverse(torch.cat([ref_in[0], ref_in[1]]), alpha), ref_in[2], ref_in[3])
+    want = F.cross_entropy(z, lab)
+    (want * 1.7).backward()
+    got_in = [v.clone().to(DEV).requires_grad_() for v in (fs, ft, W, b)]
+    got = ops.grl_disc_ce(*got_in, alpha, labels=lab.to(DEV) if C > 2 else None)
+    (got * 1.7).backward()
+    close(got, want, rtol=1e-5)
+    for a_, b_ in zip(got_in, ref_in):
+        close(a_.grad, b_.grad, rtol=1e-4, atol=1e-7)
+
+
+def test_gather_rows():
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    for d in (256, 5):
+        x = torch.randn(1000, d, generator=gen, device=DEV)
+        idx = torch.randint(0, 1000, (4096,), generator=gen, device=DEV)
+        exact(ops.gather_rows(x, idx), x[idx])
+
+
+# ------------------------------------------------------------ trainers vs golden --
+def _pair(g):
+    s = Data(x=T(g["src_x"]), edge_index=T(g["src_ei"]), y=T(g["src_y"]))
+    t = Data(x=T(g["tgt_x"]), edge_index=T(g["tgt_ei"]), y=T(g["tgt_y"]))
+    return s, t
+
+
+@pytest.mark.parametrize("adv", [False, True])
+def test_a2gnn_forward_model_golden(adv):
+    g = load_golden("a2gnn_forward_adv" if adv else "a2gnn_forward_mmd")
+    s, t = _pair(g)
+    m = pygda_amd.models.A2GNN(24, 16, 5, num_layers=2, dropout=0.0, s_pnums=0, t_pnums=10, adv=adv,
+                               weight=10, device=DEV, epoch=3, verbose=0)
+    torch.manual_seed(int(g["init_seed"]))
+    m.a2gnn = m.init_model()
+    m.a2gnn.train()
+    torch.manual_seed(int(g["mmd_seed"]))
+    loss, sl, tl = m.forward_model(s.to(DEV), t.to(DEV), float(g["alpha"]))
+    loss.backward()
+    close(loss, g["loss"], rtol=REL)
+    close(sl, g["src_logits"], rtol=0, atol=LOGIT_ATOL); close(tl, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    params = dict(m.a2gnn.named_parameters())
+    for k, v in sub(g, "grad/").items():
+        close(params[k].grad, v, rtol=1e-3, atol=1e-4 * max(np.abs(v).max(), 1e-3))
+    m.a2gnn.eval()
+    with torch.no_grad():
+        close(m.a2gnn(t.to(DEV), 10), g["eval_tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+        close(m.a2gnn(s.to(DEV), 0), g["eval_src_logits"], rtol=0, atol=LOGIT_ATOL)
+
+
+@pytest.mark.parametrize("adv", [False, True])
+def test_a2gnn_fit_predict_golden(adv):
+    """fit() for three epochs from the reference's seed, then predict(): per-epoch loss and
+    source accuracy, final logits within 1e-4, predicted labels identical."""
+    g = load_golden("a2gnn_fit3_adv" if adv else "a2gnn_fit3_mmd")
+    s, t = _pair(g)
+    m = pygda_amd.models.A2GNN(24, 16, 5, num_layers=2, dropout=0.0, s_pnums=0, t_pnums=10, adv=adv,
+                               weight=10, lr=0.01, weight_decay=0.005, device=DEV, epoch=3, verbose=0)
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+    torch.manual_seed(int(g["seed"]))
+    m.fit(s, t)
+    close([x[0] for x in seen], g["losses"], rtol=REL)
+    close([x[1] for x in seen], g["accs"], rtol=0, atol=1e-12)
+    logits, labels = m.predict(t)
+    close(logits, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    exact(labels, g["tgt_labels"])
+    exact(logits.argmax(1), g["tgt_logits"].argmax(1))
+    slogits, _ = m.predict(s, source=True)
+    close(slogits, g["src_logits"], rtol=0, atol=LOGIT_ATOL)
+
+
+@pytest.mark.parametrize("disc", ["JS", "MMD"])
+def test_grade_forward_model_golden(disc):
+    g = load_golden(f"grade_forward_{disc.lower()}")
+    s, t = _pair(g)
+    m = pygda_amd.models.GRADE(24, 8, 5, num_layers=3, dropout=0.0, disc=disc, weight=0.01, device=DEV,
+                               epoch=3, verbose=0)
+    torch.manual_seed(int(g["init_seed"]))
+    m.grade = m.init_model()
+    m.grade.train()
+    torch.manual_seed(int(g["mmd_seed"]))
+    loss, sl, tl = m.forward_model(s.to(DEV), t.to(DEV), float(g["alpha"]))
+    loss.backward()
+    close(loss, g["loss"], rtol=REL)
+    close(sl, g["src_logits"], rtol=0, atol=LOGIT_ATOL); close(tl, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    params = dict(m.grade.named_parameters())
+    for k, v in sub(g, "grad/").items():
+        close(params[k].grad, v, rtol=1e-3, atol=1e-4 * max(np.abs(v).max(), 1e-3))
+
+
+# ------------------------------------------- full BASELINE size vs the CPU oracle --
+def test_cfg_a_full_size_logits_vs_oracle():
+    """configs[1]: A2GNN at ACMv9->DBLPv7 shapes (stand-in data, see bench.py), nhid=128,
+    L=2, t_pnums=10, dropout off: target logits within 1e-4 of the CPU oracle, labels identical."""
+    from bench import make_cfg_a
+    src, tgt = make_cfg_a(seed=200)
+    torch.manual_seed(0)
+    net = A2GNNBase(src.x.size(1), 128, 5, num_layers=2, dropout=0.0)
+    ora = O.A2GNNBase(src.x.size(1), 128, 5, num_layers=2, dropout=0.0)
+    ora.load_state_dict(net.state_dict())
+    ora.eval()
+    with torch.no_grad():
+        want = ora(O.Graph(tgt.x, tgt.edge_index), 10)
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        got = net(tgt.to(DEV), 10)
+    close(got, want, rtol=0, atol=LOGIT_ATOL)
+    exact(got.argmax(1), want.argmax(1))
