@@ -148,7 +148,7 @@ __global__ void k_degree(const int32_t* __restrict__ rowptr, const float* __rest
     float s = 0.0f;
     for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) s = __fadd_rn(s, val[k]);
     deg[i] = s;
-    float r = __fdiv_rn(1.0f, __fsqrt_rn(s));         // pow(-0.5) == 1/sqrt on the CPU path
+    float r = 1.0f / sqrtf(s);   // pow(-0.5) == IEEE 1/sqrt on the CPU path (sqrtf and / are correctly rounded; __fsqrt_rn is not)
     if (isinf(r)) r = 0.0f;
     dis[i] = r;
 }
