@@ -1,0 +1,100 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 output (gpurun_out/, scratch) into the small tracked summaries under
+profiles/: per-kernel time table from --kernel-trace --stats, and per-kernel HBM traffic from
+the two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; MI355X_MICROARCH.md: counters are in
+KiB, and on gfx950 FETCH_SIZE reports half the bytes of a wide 16 B/lane coalesced read, so
+the read side is doubled for kernels whose loads are 16 B/lane).
+
+    python tools/summarize_rocprof.py --tag r1 --stats gpurun_out/prof_r1 \\
+        --fetch gpurun_out/pmc_fetch_r1 --write gpurun_out/pmc_write_r1 [--bench gpurun_out/x.json]
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+
+
+def find(d, suffix):
+    hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name[:100]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--stats")
+    ap.add_argument("--fetch")
+    ap.add_argument("--write")
+    ap.add_argument("--bench")
+    ap.add_argument("--out", default="profiles")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    lines = [f"# rocprofv3 summary `{a.tag}`", ""]
+    result = {"tag": a.tag}
+    if a.bench and os.path.exists(a.bench):
+        txt = [l for l in open(a.bench).read().splitlines() if l.startswith("{")]
+        if txt:
+            b = json.loads(txt[-1])
+            result["bench"] = b
+            lines += ["Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
+                      f"--steps {b['steps']} --warmup {b['warmup']} --no-cpu-baseline`", "",
+                      f"bench line under the profiler: {b['ms_per_step']:.3f} ms/step, "
+                      f"{b['value']:.4g} {b['unit']}", ""]
+    if a.stats:
+        f = find(a.stats, "kernel_stats.csv")
+        rows = list(csv.DictReader(open(f)))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        lines += ["## Kernel time (`--kernel-trace --stats`)", "",
+                  "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
+        ks = []
+        for r in rows[:40]:
+            ks.append(dict(name=short(r["Name"]), calls=int(r["Calls"]), total_ms=float(r["TotalDurationNs"]) / 1e6,
+                           avg_us=float(r["AverageNs"]) / 1e3, pct=float(r["Percentage"])))
+            lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | "
+                         f"{float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | "
+                         f"{float(r['MaxNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |")
+        lines += ["", f"total kernel time {tot/1e6:.2f} ms over {len(rows)} distinct kernels", ""]
+        result["kernels"] = ks
+    pmc = {}
+    for counter, d in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
+        if not d:
+            continue
+        f = find(d, "counter_collection.csv")
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            pmc.setdefault(k, {})[counter] = dict(launches=len(v), avg_kib=sum(v) / len(v))
+    if pmc:
+        lines += ["## HBM-side traffic per launch (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes)", "",
+                  "FETCH_SIZE/WRITE_SIZE are KiB at the L2's fabric side (Infinity-Cache hits included). "
+                  "`traffic` = 2 x FETCH + WRITE for kernels with 16 B/lane loads (gfx950 correction), "
+                  "FETCH + WRITE otherwise.", "",
+                  "| kernel | launches | FETCH KiB | WRITE KiB | traffic MB/launch |", "|---|---|---|---|---|"]
+        ours = {}
+        for k, v in sorted(pmc.items(), key=lambda kv: -(kv[1].get("FETCH_SIZE", {}).get("avg_kib", 0) *
+                                                         kv[1].get("FETCH_SIZE", {}).get("launches", 0)))[:25]:
+            fe, wr = v.get("FETCH_SIZE", {}).get("avg_kib", 0.0), v.get("WRITE_SIZE", {}).get("avg_kib", 0.0)
+            wide = k.startswith("k_spmm<") and k.split(",")[1].strip().startswith("4")
+            traffic = ((2 if wide else 1) * fe + wr) * 1024
+            n = v.get("FETCH_SIZE", v.get("WRITE_SIZE"))["launches"]
+            lines.append(f"| `{k}` | {n} | {fe:.1f} | {wr:.1f} | {traffic/1e6:.3f} |")
+            if k.startswith("k_"):
+                ours[k] = dict(fetch_kib=fe, write_kib=wr, traffic_bytes=traffic, wide_correction=wide)
+        result["pmc"] = ours
+        lines.append("")
+    open(os.path.join(a.out, f"{a.tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
+    json.dump(result, open(os.path.join(a.out, f"{a.tag}_rocprof_summary.json"), "w"), indent=1)
+    print("\n".join(lines[:60]))
+
+
+if __name__ == "__main__":
+    main()
