@@ -132,7 +132,7 @@ int gda_mmd_bwd_f32(const float* src, int64_t ld_src, const float* tgt, int64_t 
                     int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
                     int times, int64_t n, float kernel_mul, int kernel_num,
                     const float* bandwidth, const float* l2_saved, const float* grad_loss,
-                    float* grad_rows, gda_stream_t stream);
+                    float* grad_rows, void* workspace, size_t workspace_bytes, gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
  * Gradient-reversal + linear domain discriminator + softmax cross-entropy, fused.

@@ -56,6 +56,8 @@ __device__ __forceinline__ float4 load4(const float* __restrict__ p, int64_t k, 
     return v;
 }
 
+__device__ __forceinline__ int64_t gda_cdiv_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
 __device__ __forceinline__ double block_sum(double v, double* sh) {
     // fixed-order tree: wave shuffle, then 4 wave leaders through LDS
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -177,10 +179,10 @@ k_ksum(const float* __restrict__ l2, const double* __restrict__ partial, int til
     const int t = blockIdx.z;
     const float bw0 = bandwidth_of(partial, tiles_per_t, t, m, kp, red);
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) bandwidth[t] = bw0;
-    float bw[MAXQ];
+    float nib[MAXQ];                                   // -1 / (bandwidth * kernel_mul^q), mmd.py:52
     {
         float f = 1.f;
-        for (int q = 0; q < kp.kernel_num; ++q) { bw[q] = bw0 * f; f *= kp.kernel_mul; }   // mmd.py:52
+        for (int q = 0; q < kp.kernel_num; ++q) { nib[q] = -1.f / (bw0 * f); f *= kp.kernel_mul; }
     }
     const int64_t i0 = (int64_t)blockIdx.y * TILE, j0 = (int64_t)blockIdx.x * TILE;
     const float* L = l2 + (int64_t)t * m * m;
@@ -190,7 +192,7 @@ k_ksum(const float* __restrict__ l2, const double* __restrict__ partial, int til
         if (i >= m || j >= m) continue;
         const float dist = L[i * m + j];
         float kv = 0.f;
-        for (int q = 0; q < kp.kernel_num; ++q) kv += expf(-dist / bw[q]);              // mmd.py:53-55
+        for (int q = 0; q < kp.kernel_num; ++q) kv += expf(dist * nib[q]);              // mmd.py:53-55
         local += ((i < n) == (j < n)) ? kv : -kv;                                       // XX+YY-XY-YX
     }
     const double s = block_sum((double)local, red);
@@ -213,96 +215,117 @@ k_finalize(const double* __restrict__ kpartial, int tiles_per_t, int times, int6
 }
 
 // --------------------------------------------------------------- backward --
+// Work decomposition: 32 rows x 128 feature columns per workgroup, the j range cut into
+// NSEG segments -> (m/32) * NSEG * times workgroups (1260 at m=2000, times=5) so that every
+// CU holds several workgroups; per-segment partial sums are combined in a fixed order by
+// k_bwd_reduce (deterministic, no atomics).
+constexpr int BI = 32;        // rows i per workgroup
+constexpr int BJ = 64;        // rows j per LDS tile
+constexpr int LDG = BI + 4;   // padded leading dimension of the G tile (16-byte aligned rows)
+
 __global__ void __launch_bounds__(TB)
 k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* __restrict__ bandwidth,
-      KParams kp, const float* __restrict__ grad_loss, int times, float* __restrict__ grad_rows) {
-    __shared__ __attribute__((aligned(16))) float Gs[TILE][LDT];   // Gs[j][i] = G[i][j] (G symmetric)
-    __shared__ __attribute__((aligned(16))) float Ts[TILE][DC];    // rows j of total, this column chunk
+      KParams kp, const float* __restrict__ grad_loss, int times, int nseg,
+      float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float Gs[BJ][LDG];     // Gs[j][i] = G[i][j] (G symmetric)
+    __shared__ __attribute__((aligned(16))) float Ts[BJ][DC];      // rows j of total, this column chunk
     const int t = blockIdx.z;
-    const int64_t i0 = (int64_t)blockIdx.x * TILE;
-    const int64_t c0 = (int64_t)blockIdx.y * DC;
-    const int tid = threadIdx.x, ty = tid / 16, tx = tid % 16;
+    const int seg = blockIdx.y % nseg;
+    const int64_t c0 = (int64_t)(blockIdx.y / nseg) * DC;
+    const int64_t i0 = (int64_t)blockIdx.x * BI;
+    const int tid = threadIdx.x, ty = tid / 32, tx = tid % 32;
     const int64_t n = R.n;
 
-    float bw[MAXQ], nib[MAXQ];
+    float nib[MAXQ];                                                // -1 / bw_q
     {
         float f = 1.f;
         const float b0 = bandwidth[t];
-        for (int q = 0; q < kp.kernel_num; ++q) { bw[q] = b0 * f; nib[q] = -1.f / bw[q]; f *= kp.kernel_mul; }
+        for (int q = 0; q < kp.kernel_num; ++q) { nib[q] = -1.f / (b0 * f); f *= kp.kernel_mul; }
     }
     // d loss / d K[i,j] = +-1 / (n^2 * times) * upstream
     const float coef = grad_loss[0] / ((float)n * (float)n) / (float)times;
 
-    // this thread's 4 rows x (4+4) columns of total[i,:]
-    float ti[4][8], acc[4][8];
+    float ti[4][4], acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int64_t i = i0 + ty * 4 + a;
         const float* p = i < m ? row_ptr(R, t, i) : nullptr;
-        const float4 lo = load4(p, c0 + tx * 4, d, R.vec4);
-        const float4 hi = load4(p, c0 + 64 + tx * 4, d, R.vec4);
-        ti[a][0] = lo.x; ti[a][1] = lo.y; ti[a][2] = lo.z; ti[a][3] = lo.w;
-        ti[a][4] = hi.x; ti[a][5] = hi.y; ti[a][6] = hi.z; ti[a][7] = hi.w;
+        const float4 v = load4(p, c0 + tx * 4, d, R.vec4);
+        ti[a][0] = v.x; ti[a][1] = v.y; ti[a][2] = v.z; ti[a][3] = v.w;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[a][c] = 0.f;
+        for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
     }
 
+    // this segment's j tiles: tiles seg, seg + nseg, ...
     const float* L = l2 + (int64_t)t * m * m;
-    for (int64_t j0 = 0; j0 < m; j0 += TILE) {
+    const int64_t ntiles = gda_cdiv_dev(m, BJ);
+    for (int64_t jt = seg; jt < ntiles; jt += nseg) {
+        const int64_t j0 = jt * BJ;
         __syncthreads();
-        // G tile, read as L2[j][i] (== L2[i][j]) so that the LDS store is row-contiguous
-        for (int f = tid; f < TILE * TILE; f += TB) {
-            const int jj = f / TILE, ii = f % TILE;
+        // G tile, read as L2[j][i] (== L2[i][j]): coalesced along i, stored row-contiguous
+        for (int f = tid; f < BJ * BI; f += TB) {
+            const int jj = f / BI, ii = f % BI;
             const int64_t j = j0 + jj, i = i0 + ii;
             float g = 0.f;
             if (i < m && j < m) {
                 const float dist = L[j * m + i];
                 float dk = 0.f;
-                for (int q = 0; q < kp.kernel_num; ++q) dk += expf(-dist / bw[q]) * nib[q];
+                for (int q = 0; q < kp.kernel_num; ++q) dk = fmaf(expf(dist * nib[q]), nib[q], dk);
                 g = (((i < n) == (j < n)) ? coef : -coef) * dk;
             }
             Gs[jj][ii] = g;
         }
-        // rows j of total for this column chunk
-        for (int f = tid; f < TILE * (DC / 4); f += TB) {
+        for (int f = tid; f < BJ * (DC / 4); f += TB) {
             const int jj = f / (DC / 4), c4 = (f % (DC / 4)) * 4;
             const int64_t j = j0 + jj;
             const float* p = j < m ? row_ptr(R, t, j) : nullptr;
             *reinterpret_cast<float4*>(&Ts[jj][c4]) = load4(p, c0 + c4, d, R.vec4);
         }
         __syncthreads();
-#pragma unroll 4
-        for (int jj = 0; jj < TILE; ++jj) {
+#pragma unroll 8
+        for (int jj = 0; jj < BJ; ++jj) {
             const float4 g4 = *reinterpret_cast<const float4*>(&Gs[jj][ty * 4]);
-            const float4 lo = *reinterpret_cast<const float4*>(&Ts[jj][tx * 4]);
-            const float4 hi = *reinterpret_cast<const float4*>(&Ts[jj][64 + tx * 4]);
+            const float4 t4 = *reinterpret_cast<const float4*>(&Ts[jj][tx * 4]);
             const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-            const float tj[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const float tj[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc[a][c] = fmaf(gv[a], ti[a][c] - tj[c], acc[a][c]);
+                for (int c = 0; c < 4; ++c) acc[a][c] = fmaf(gv[a], ti[a][c] - tj[c], acc[a][c]);
         }
     }
 
-    float* out = grad_rows + (int64_t)t * m * d;
+    // partial sums of this segment: part[t][seg][i][c]  (seg-major so the reduce streams)
+    float* out = part + (((int64_t)t * nseg + seg) * m) * d;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int64_t i = i0 + ty * 4 + a;
         if (i >= m) continue;
+        const int64_t c = c0 + tx * 4;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t c = c0 + 64 * h + tx * 4;
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-                if (c + v < d) out[i * d + c + v] = 4.f * acc[a][4 * h + v];
-        }
+        for (int v = 0; v < 4; ++v)
+            if (c + v < d) out[i * d + c + v] = acc[a][v];
     }
 }
 
-struct MmdWs { double* partial; double* kpartial; size_t total; };
+// grad_rows = 4 * sum over segments (fixed order)
+__global__ void __launch_bounds__(TB)
+k_bwd_reduce(const float* __restrict__ part, int64_t per_t, int nseg, int times,
+             float* __restrict__ grad_rows) {
+    const int64_t total = per_t * times;
+    for (int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x; k < total; k += (int64_t)gridDim.x * TB) {
+        const int64_t t = k / per_t, r = k % per_t;
+        float s = 0.f;
+        for (int g = 0; g < nseg; ++g) s += part[(t * nseg + g) * per_t + r];
+        grad_rows[k] = 4.f * s;
+    }
+}
 
-MmdWs carve(void* base, int times, int64_t n) {
+constexpr int BWD_NSEG = 4;
+
+struct MmdWs { double* partial; double* kpartial; float* bwd_part; size_t total; };
+
+MmdWs carve(void* base, int times, int64_t n, int64_t d) {
     const int64_t m = 2 * n, nt = gda_cdiv(m, TILE);
     MmdWs w{};
     size_t off = 0;
@@ -313,6 +336,7 @@ MmdWs carve(void* base, int times, int64_t n) {
     };
     w.partial = (double*)take(sizeof(double) * times * nt * nt);
     w.kpartial = (double*)take(sizeof(double) * times * nt * nt);
+    w.bwd_part = (float*)take(sizeof(float) * times * BWD_NSEG * m * (d > 0 ? d : 1));
     w.total = off;
     return w;
 }
@@ -338,9 +362,8 @@ Rows make_rows(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tg
 }  // namespace
 
 extern "C" size_t gda_mmd_workspace_bytes(int times, int64_t n, int64_t d) {
-    (void)d;
-    if (times <= 0 || n <= 0) return 0;
-    return carve(nullptr, times, n).total;
+    if (times <= 0 || n <= 0 || d <= 0) return 0;
+    return carve(nullptr, times, n, d).total;
 }
 
 extern "C" int gda_mmd_fwd_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
@@ -351,7 +374,7 @@ extern "C" int gda_mmd_fwd_f32(const float* src, int64_t ld_src, const float* tg
     int st = check_common(src, ld_src, tgt, ld_tgt, d, src_idx, tgt_idx, times, n, kernel_num);
     if (st != GDA_OK) return st;
     if (!loss || !bandwidth || !l2_saved || !workspace) return GDA_E_NULL;
-    MmdWs ws = carve(workspace, times, n);
+    MmdWs ws = carve(workspace, times, n, d);
     if (workspace_bytes < ws.total) return GDA_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t m = 2 * n;
@@ -372,16 +395,26 @@ extern "C" int gda_mmd_bwd_f32(const float* src, int64_t ld_src, const float* tg
                                int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
                                int times, int64_t n, float kernel_mul, int kernel_num,
                                const float* bandwidth, const float* l2_saved, const float* grad_loss,
-                               float* grad_rows, gda_stream_t stream_) {
+                               float* grad_rows, void* workspace, size_t workspace_bytes,
+                               gda_stream_t stream_) {
     int st = check_common(src, ld_src, tgt, ld_tgt, d, src_idx, tgt_idx, times, n, kernel_num);
     if (st != GDA_OK) return st;
-    if (!bandwidth || !l2_saved || !grad_loss || !grad_rows) return GDA_E_NULL;
+    if (!bandwidth || !l2_saved || !grad_loss || !grad_rows || !workspace) return GDA_E_NULL;
+    MmdWs ws = carve(workspace, times, n, d);
+    if (workspace_bytes < ws.total) return GDA_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t m = 2 * n;
     const Rows R = make_rows(src, ld_src, tgt, ld_tgt, src_idx, tgt_idx, n);
     const KParams kp{kernel_mul, kernel_num, 0.f};
-    const dim3 grid((unsigned)gda_cdiv(m, TILE), (unsigned)gda_cdiv(d, DC), (unsigned)times);
-    k_bwd<<<grid, TB, 0, stream>>>(R, d, m, l2_saved, bandwidth, kp, grad_loss, times, grad_rows);
+    const int64_t ntiles = gda_cdiv(m, BJ);
+    const int nseg = (int)(ntiles < BWD_NSEG ? ntiles : BWD_NSEG);
+    const dim3 grid((unsigned)gda_cdiv(m, BI), (unsigned)(gda_cdiv(d, DC) * nseg), (unsigned)times);
+    k_bwd<<<grid, TB, 0, stream>>>(R, d, m, l2_saved, bandwidth, kp, grad_loss, times, nseg, ws.bwd_part);
+    GDA_LAUNCH_CHECK();
+    const int64_t total = (int64_t)times * m * d;
+    int64_t rg = gda_cdiv(total, TB);
+    if (rg > 4096) rg = 4096;
+    k_bwd_reduce<<<(unsigned)rg, TB, 0, stream>>>(ws.bwd_part, m * d, nseg, times, grad_rows);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }

@@ -95,11 +95,13 @@ class _MMD(torch.autograd.Function):
         grad_rows = torch.empty(times, m, d, dtype=torch.float32, device=dev)
         gl = gl.reshape(1).to(torch.float32).contiguous()
         L = _lib.lib()
-        with profiler.region("mmd_bwd", 1, 0, times * (3 * m * m * d + 12 * m * m)):
+        ws = _lib.workspace(L.gda_mmd_workspace_bytes(times, n, d), dev, "mmd")
+        with profiler.region("mmd_bwd", 2, 0, times * (3 * m * m * d + 12 * m * m)):
             _lib.check(L.gda_mmd_bwd_f32(
                 _lib.ptr(src), src.size(1), _lib.ptr(tgt), tgt.size(1), d, _lib.ptr(src_idx),
                 _lib.ptr(tgt_idx), times, n, kernel_mul, kernel_num, _lib.ptr(bw), _lib.ptr(l2),
-                _lib.ptr(gl), _lib.ptr(grad_rows), _lib.stream()), "gda_mmd_bwd_f32")
+                _lib.ptr(gl), _lib.ptr(grad_rows), _lib.ptr(ws), ws.numel(), _lib.stream()),
+                "gda_mmd_bwd_f32")
         if src_idx is None:                       # get_MMD on the rows as given
             gs, gt = grad_rows[0, :n], grad_rows[0, n:]
         else:
