@@ -171,8 +171,10 @@ def main():
                                    "t_pnums=10, weight=10, dropout=0.5, full batch, "
                                    + ("adversarial" if args.adv else "MMD") + " domain loss",
                        "edges_aggregated_per_step": edges, "nnz_source": nnz_s, "nnz_target": nnz_t,
-                       "parallelism": "single GPU" if world == 1 else f"{world} data-parallel replicas, "
-                                      "flat RCCL gradient all-reduce per step"},
+                       "parallelism": "single GPU" if world == 1 else
+                       f"dp{world}: one full-batch replica per GPU (cfg-A has one batch per epoch), "
+                       "independent dropout draws, global-batch MMD over all-gathered sample rows, "
+                       "one flat RCCL gradient all-reduce per step"},
             "epochs_per_sec": world * args.steps / dt,
             "roofline": roof(dominant),
             "roofline_aggregation": roof(agg),

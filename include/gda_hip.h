@@ -107,8 +107,8 @@ int gda_spmm_csr_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const f
  * Replaces MMD / get_MMD / guassian_kernel (pygda/utils/mmd.py:4-159) as called from
  * A2GNN.forward_model (pygda/models/a2gnn.py:208) and GRADE (pygda/models/grade.py:182).
  * For each of `times` resamples t: rows r<n of `total` are src[src_idx[t,r]], rows
- * n<=r<2n are tgt[tgt_idx[t,r-n]] (idx NULL = identity, i.e. get_MMD on the rows as
- * given; then times must be 1).  L2[i,j] = sum_k (total[j,k]-total[i,k])^2 (direct
+ * n<=r<2n are tgt[tgt_idx[t,r-n]] (idx NULL = the rows as given, stacked [times, n, d] per
+ * domain; times = 1 is get_MMD).  L2[i,j] = sum_k (total[j,k]-total[i,k])^2 (direct
  * difference form, mmd.py:43-46); bandwidth = (sum L2 + 1e-6)/(m^2-m) / kernel_mul^(kernel_num/2),
  * m = 2n (mmd.py:50-51; fix_sigma>0 overrides the data-dependent value); K = sum_q
  * exp(-L2/(bandwidth*kernel_mul^q)) (mmd.py:52-55); loss_t = mean(XX+YY-XY-YX) over the
@@ -166,6 +166,27 @@ size_t gda_grl_disc_workspace_bytes(int64_t n_rows, int64_t h, int C);
  * ---------------------------------------------------------------------------- */
 int gda_gather_rows_f32(const float* x, int64_t ldx, int64_t d, const int64_t* idx,
                         int64_t n_out, float* out, int64_t ldo, gda_stream_t stream);
+
+/* ------------------------------------------------------------------------------
+ * Host neighbour sampler (mini-batch assembly; HOST pointers throughout).
+ *
+ * Replaces the C++ sampler behind PyG's NeighborLoader as pygda's trainers construct it
+ * (pygda/models/a2gnn.py:260-277; grade.py, udagcn.py, adagcn.py likewise): L-hop in-neighbour
+ * sampling without replacement from seed nodes, fan-out list `fanouts` (-1 = all), seeds first
+ * then newly reached nodes in discovery order, sampled edges relabelled to local ids.
+ * A handle is not thread-safe; one per loader.  gda_sampler_sample keeps the batch inside the
+ * handle and reports its sizes; gda_sampler_fetch copies it out into caller buffers of those
+ * sizes (nodes: global ids [n_nodes]; esrc/edst: local ids [n_edges], message esrc -> edst).
+ * ---------------------------------------------------------------------------- */
+typedef struct gda_sampler gda_sampler;
+int gda_sampler_create(const int64_t* src_host, const int64_t* dst_host, int64_t E, int64_t N,
+                       gda_sampler** out);
+void gda_sampler_destroy(gda_sampler* s);
+int gda_sampler_sample(gda_sampler* s, const int64_t* seeds_host, int64_t n_seeds,
+                       const int32_t* fanouts, int L, uint64_t rng_seed,
+                       int64_t* n_nodes_out, int64_t* n_edges_out);
+int gda_sampler_fetch(const gda_sampler* s, int64_t* nodes_out, int64_t* esrc_out,
+                      int64_t* edst_out);
 
 #ifdef __cplusplus
 }

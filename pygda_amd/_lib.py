@@ -35,6 +35,11 @@ _SIGNATURES = {
     "gda_grl_disc_ce_bwd_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int,
                                         _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gda_gather_rows_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P]),
+    "gda_sampler_create": (c_int, [_P, _P, c_int64, c_int64, ctypes.POINTER(c_void_p)]),
+    "gda_sampler_destroy": (None, [_P]),
+    "gda_sampler_sample": (c_int, [_P, _P, c_int64, _P, c_int, ctypes.c_uint64,
+                                   ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
+    "gda_sampler_fetch": (c_int, [_P, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -29,18 +29,18 @@ constexpr int MAXQ = 8;       // kernel_num upper bound
 struct Rows {
     const float* src; int64_t ld_src;
     const float* tgt; int64_t ld_tgt;
-    const int64_t* src_idx; const int64_t* tgt_idx;   // [times, n] or NULL (identity)
+    const int64_t* src_idx; const int64_t* tgt_idx;   // [times, n] or NULL (rows stacked [times, n, d])
     int64_t n;                                         // rows per domain
     bool vec4;                                         // 16-byte loads legal
 };
 
 __device__ __forceinline__ const float* row_ptr(const Rows& R, int t, int64_t r) {
     if (r < R.n) {
-        const int64_t g = R.src_idx ? R.src_idx[(int64_t)t * R.n + r] : r;
+        const int64_t g = R.src_idx ? R.src_idx[(int64_t)t * R.n + r] : (int64_t)t * R.n + r;
         return R.src + g * R.ld_src;
     }
     const int64_t q = r - R.n;
-    const int64_t g = R.tgt_idx ? R.tgt_idx[(int64_t)t * R.n + q] : q;
+    const int64_t g = R.tgt_idx ? R.tgt_idx[(int64_t)t * R.n + q] : (int64_t)t * R.n + q;
     return R.tgt + g * R.ld_tgt;
 }
 
@@ -348,7 +348,6 @@ int check_common(const float* src, int64_t ld_src, const float* tgt, int64_t ld_
     if (2 * n >= 46340 * 2) return GDA_E_SIZE;                 // m*m*times must stay well inside int64 / fp32 counts
     if (kernel_num < 1 || kernel_num > MAXQ) return GDA_E_UNSUPPORTED;
     if ((src_idx == nullptr) != (tgt_idx == nullptr)) return GDA_E_NULL;
-    if (!src_idx && times != 1) return GDA_E_SIZE;
     return GDA_OK;
 }
 

@@ -1,0 +1,130 @@
+// Native host neighbour sampler (mini-batch assembly for the data-parallel path).
+//
+// Replaces the C++ sampler behind PyG's NeighborLoader (pyg-lib / torch-sparse), which
+// pygda's trainers construct at pygda/models/a2gnn.py:260-277 (same block in every trainer):
+// for a batch of seed nodes and fan-outs [k_1..k_L], hop l samples, for every node first
+// reached in hop l-1, up to k_l of its in-neighbours WITHOUT replacement (k = -1: all) and
+// keeps the sampled edges (neighbour -> node).  Output nodes are the seeds first, then newly
+// reached nodes in discovery order; edges are relabelled to that local numbering, grouped
+// by destination in frontier order.  PyG's RNG stream cannot be matched (SURVEY §7 "sampler
+// fidelity"); parity is structural + exact for fan-out -1.
+//
+// The per-node draws come from a counter-based generator keyed on (seed, hop, node), so a
+// batch is reproducible and independent of traversal order.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/gda_hip.h"
+
+namespace {
+
+struct SplitMix {
+    uint64_t s;
+    explicit SplitMix(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    // unbiased enough for sampling: 64-bit multiply-shift
+    uint64_t below(uint64_t n) { return (uint64_t)(((unsigned __int128)next() * n) >> 64); }
+};
+
+}  // namespace
+
+struct gda_sampler {
+    int64_t N = 0;
+    std::vector<int64_t> in_ptr;      // [N+1]  in-neighbour lists (sources of edges into v), edge order
+    std::vector<int64_t> in_src;      // [E]
+    std::vector<int32_t> local;       // [N] global -> local id of the batch being built, -1 if absent
+    // last sampled batch
+    std::vector<int64_t> nodes, esrc, edst;
+    std::vector<int64_t> scratch;
+};
+
+extern "C" int gda_sampler_create(const int64_t* src_host, const int64_t* dst_host, int64_t E,
+                                  int64_t N, gda_sampler** out) {
+    if (!out || (E > 0 && (!src_host || !dst_host))) return GDA_E_NULL;
+    if (E < 0 || N < 0) return GDA_E_SIZE;
+    gda_sampler* s = new (std::nothrow) gda_sampler();
+    if (!s) return GDA_E_SIZE;
+    s->N = N;
+    s->in_ptr.assign(N + 1, 0);
+    for (int64_t e = 0; e < E; ++e) {
+        if (src_host[e] < 0 || src_host[e] >= N || dst_host[e] < 0 || dst_host[e] >= N) { delete s; return GDA_E_SIZE; }
+        ++s->in_ptr[dst_host[e] + 1];
+    }
+    for (int64_t v = 0; v < N; ++v) s->in_ptr[v + 1] += s->in_ptr[v];
+    s->in_src.resize(E);
+    std::vector<int64_t> cur(s->in_ptr.begin(), s->in_ptr.end() - 1);
+    for (int64_t e = 0; e < E; ++e) s->in_src[cur[dst_host[e]]++] = src_host[e];   // stable: edge order kept
+    s->local.assign(N, -1);
+    *out = s;
+    return GDA_OK;
+}
+
+extern "C" void gda_sampler_destroy(gda_sampler* s) { delete s; }
+
+extern "C" int gda_sampler_sample(gda_sampler* s, const int64_t* seeds_host, int64_t n_seeds,
+                                  const int32_t* fanouts, int L, uint64_t rng_seed,
+                                  int64_t* n_nodes_out, int64_t* n_edges_out) {
+    if (!s || !n_nodes_out || !n_edges_out || (n_seeds > 0 && !seeds_host) || (L > 0 && !fanouts)) return GDA_E_NULL;
+    if (n_seeds < 0 || L < 0) return GDA_E_SIZE;
+    for (int64_t v : s->nodes) s->local[v] = -1;          // reset only what the last batch touched
+    s->nodes.clear(); s->esrc.clear(); s->edst.clear();
+    for (int64_t i = 0; i < n_seeds; ++i) {
+        const int64_t v = seeds_host[i];
+        if (v < 0 || v >= s->N) return GDA_E_SIZE;
+        if (s->local[v] < 0) { s->local[v] = (int32_t)s->nodes.size(); s->nodes.push_back(v); }
+    }
+    int64_t frontier_begin = 0;
+    for (int hop = 0; hop < L; ++hop) {
+        const int64_t frontier_end = (int64_t)s->nodes.size();
+        const int32_t k = fanouts[hop];
+        for (int64_t f = frontier_begin; f < frontier_end; ++f) {
+            const int64_t v = s->nodes[f];
+            const int64_t b = s->in_ptr[v], deg = s->in_ptr[v + 1] - b;
+            const int32_t lv = s->local[v];
+            auto take = [&](int64_t u) {
+                if (s->local[u] < 0) { s->local[u] = (int32_t)s->nodes.size(); s->nodes.push_back(u); }
+                s->esrc.push_back(s->local[u]);
+                s->edst.push_back(lv);
+            };
+            if (k < 0 || deg <= k) {
+                for (int64_t j = 0; j < deg; ++j) take(s->in_src[b + j]);
+            } else {
+                // k distinct positions out of deg: partial Fisher-Yates on an index scratch,
+                // then restore list order so the kept edges stay in original edge order
+                SplitMix rng(rng_seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(hop + 1)) ^ (0x9E3779B97F4A7C15ull * (uint64_t)(v + 1)));
+                s->scratch.resize(deg);
+                for (int64_t j = 0; j < deg; ++j) s->scratch[j] = j;
+                for (int32_t j = 0; j < k; ++j) {
+                    const int64_t r = j + (int64_t)rng.below((uint64_t)(deg - j));
+                    std::swap(s->scratch[j], s->scratch[r]);
+                }
+                std::sort(s->scratch.begin(), s->scratch.begin() + k);
+                for (int32_t j = 0; j < k; ++j) take(s->in_src[b + s->scratch[j]]);
+            }
+        }
+        frontier_begin = frontier_end;
+    }
+    *n_nodes_out = (int64_t)s->nodes.size();
+    *n_edges_out = (int64_t)s->esrc.size();
+    return GDA_OK;
+}
+
+extern "C" int gda_sampler_fetch(const gda_sampler* s, int64_t* nodes_out, int64_t* esrc_out,
+                                 int64_t* edst_out) {
+    if (!s) return GDA_E_NULL;
+    if (!s->nodes.empty()) { if (!nodes_out) return GDA_E_NULL; std::memcpy(nodes_out, s->nodes.data(), s->nodes.size() * sizeof(int64_t)); }
+    if (!s->esrc.empty()) {
+        if (!esrc_out || !edst_out) return GDA_E_NULL;
+        std::memcpy(esrc_out, s->esrc.data(), s->esrc.size() * sizeof(int64_t));
+        std::memcpy(edst_out, s->edst.data(), s->edst.size() * sizeof(int64_t));
+    }
+    return GDA_OK;
+}

@@ -89,11 +89,16 @@ class NeighborLoader:
     in-neighbourhoods, seeds first, exactly ``batch.batch_size`` of them."""
 
     def __init__(self, data, num_neighbors, batch_size=1, shuffle=False, input_nodes=None,
-                 rank=0, world_size=1, seed=0, **kwargs):
-        self.data, self.num_neighbors = data, list(num_neighbors)
+                 rank=0, world_size=1, seed=0, device=None, **kwargs):
+        self.num_neighbors = list(num_neighbors)
         self.batch_size, self.shuffle = int(batch_size), shuffle
         self.rank, self.world_size, self.seed = rank, world_size, seed
         n = data.num_nodes
+        full = (all(k == -1 for k in self.num_neighbors) and self.batch_size >= n
+                and input_nodes is None and world_size == 1)
+        # sampled mode keeps the feature matrix resident on the training device: batches are
+        # assembled there by the row-gather kernel, only node / edge ids cross PCIe
+        self.data = data.to(device) if (device is not None and not full) else data
         self.input_nodes = torch.arange(n) if input_nodes is None else torch.as_tensor(input_nodes).long().cpu()
         self.full_batch = (all(k == -1 for k in self.num_neighbors) and self.batch_size >= n
                            and input_nodes is None and world_size == 1)
@@ -106,7 +111,10 @@ class NeighborLoader:
             g = torch.Generator().manual_seed(self.seed + self._epoch)
             seeds = seeds[torch.randperm(seeds.numel(), generator=g)]
         chunks = list(torch.split(seeds, self.batch_size))
-        return chunks[self.rank::self.world_size]      # data-parallel shard of the seed batches
+        # data-parallel shard of the seed batches; every rank gets the same count (short ranks
+        # wrap around) so that the per-step gradient all-reduce never waits for a missing peer
+        per_rank = -(-len(chunks) // self.world_size)
+        return [chunks[(self.rank + i * self.world_size) % len(chunks)] for i in range(per_rank)]
 
     def __len__(self):
         return 1 if self.full_batch else len(self._batches())

@@ -63,7 +63,7 @@ class BaseGDA(ABC):
         else:
             sb = tb = self.batch_size
         full = self.batch_size == 0
-        kw = {} if full else dist
+        kw = {} if full else dict(dist, device=self.device)
         self.source_loader = NeighborLoader(source_data, self.num_neigh, batch_size=sb, **kw)
         self.target_loader = NeighborLoader(target_data, self.num_neigh, batch_size=tb, **kw)
 
@@ -113,27 +113,12 @@ class BaseGDA(ABC):
 
 
 def _dist_info():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        return dict(rank=dist.get_rank(), world_size=dist.get_world_size())
-    return dict(rank=0, world_size=1)
+    from ..distributed import info
+    return info()
 
 
 def _allreduce_grads(optimizer):
     """Data-parallel step: ONE flat all-reduce (RCCL over xGMI when the backend is nccl) of
     all gradients, averaged over ranks.  No-op in single-process runs."""
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return
-    params = [p for g in optimizer.param_groups for p in g["params"]]
-    for p in params:                      # a rank whose batch never touched p still joins
-        if p.grad is None:
-            p.grad = torch.zeros_like(p)
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat.div_(dist.get_world_size())
-    off = 0
-    for p in params:
-        n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p))
-        off += n
+    from ..distributed import allreduce_grads
+    allreduce_grads(p for g in optimizer.param_groups for p in g["params"])

@@ -102,8 +102,8 @@ class _MMD(torch.autograd.Function):
                 _lib.ptr(tgt_idx), times, n, kernel_mul, kernel_num, _lib.ptr(bw), _lib.ptr(l2),
                 _lib.ptr(gl), _lib.ptr(grad_rows), _lib.ptr(ws), ws.numel(), _lib.stream()),
                 "gda_mmd_bwd_f32")
-        if src_idx is None:                       # get_MMD on the rows as given
-            gs, gt = grad_rows[0, :n], grad_rows[0, n:]
+        if src_idx is None:                       # rows as given, stacked [times, n, d]
+            gs, gt = grad_rows[:, :n].reshape(times * n, d), grad_rows[:, n:].reshape(times * n, d)
         else:
             gs = _scatter_rows(grad_rows, src_idx, 0, n, src.size(0))
             gt = _scatter_rows(grad_rows, tgt_idx, n, n, tgt.size(0))
@@ -131,6 +131,37 @@ def _scatter_rows(grad_rows, idx, offset, n, num_feat_rows):
                                   num_feat_rows, d, _lib.ptr(flat), d, _lib.ptr(out), d, None,
                                   _lib.stream()), "gda_spmm_csr_f32")
     return out
+
+
+class _SampleRows(torch.autograd.Function):
+    """``feat[idx]`` for ``idx [times, n]`` -> ``[times, n, d]``: gather kernel forward,
+    deterministic selection-matrix SpMM backward (duplicates summed in a fixed order)."""
+
+    @staticmethod
+    def forward(ctx, feat, idx):
+        ctx.save_for_backward(idx)
+        ctx.rows = feat.size(0)
+        return gather_rows(feat, idx.reshape(-1)).view(idx.size(0), idx.size(1), feat.size(1))
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        times, n, d = g.shape
+        return _scatter_rows(g.contiguous().view(times, n, d), idx, 0, n, ctx.rows), None
+
+
+def sample_rows(feat, idx):
+    return _SampleRows.apply(_f32c(feat, "feat"), idx)
+
+
+def mmd_loss_rows(source_rows, target_rows, kernel_mul=2.0, kernel_num=5, fix_sigma=None):
+    """MMD over explicit row sets ``[times, n, d]`` per domain (the data-parallel path, where
+    the rows are an all-gather of every rank's samples)."""
+    if source_rows.shape != target_rows.shape or source_rows.dim() != 3:
+        raise RuntimeError("row sets must both be [times, n, d]")
+    times, n, d = source_rows.shape
+    return _MMD.apply(source_rows.reshape(times * n, d), target_rows.reshape(times * n, d), None, None,
+                      int(times), int(n), kernel_mul, kernel_num, fix_sigma)
 
 
 def mmd_loss(source_feat, target_feat, src_idx=None, tgt_idx=None, kernel_mul=2.0, kernel_num=5,

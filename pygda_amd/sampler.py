@@ -1,0 +1,58 @@
+"""Python face of the native host neighbour sampler (csrc/gda_sampler.cpp) and the
+mini-batch assembly around it: sample on the host, gather the feature rows on the device
+(``gda_gather_rows_f32``) when the features live there."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .data import Data
+
+
+class NeighborSampler:
+    def __init__(self, edge_index, num_nodes):
+        ei = edge_index.detach().cpu().contiguous()
+        self.num_nodes = int(num_nodes)
+        self._src = np.ascontiguousarray(ei[0].numpy(), dtype=np.int64)
+        self._dst = np.ascontiguousarray(ei[1].numpy(), dtype=np.int64)
+        self._h = ctypes.c_void_p()
+        L = _lib.lib()
+        _lib.check(L.gda_sampler_create(self._src.ctypes.data, self._dst.ctypes.data, self._src.size,
+                                        self.num_nodes, ctypes.byref(self._h)), "gda_sampler_create")
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().gda_sampler_destroy(h)
+            self._h = None
+
+    def sample(self, seeds, fanouts, seed=0):
+        """-> (n_id [n_nodes] global ids, seeds first; edge_index [2, n_edges] local ids)."""
+        seeds = np.ascontiguousarray(torch.as_tensor(seeds).cpu().numpy(), dtype=np.int64)
+        fan = np.ascontiguousarray(np.asarray(fanouts, dtype=np.int32))
+        nn_, ne_ = ctypes.c_int64(), ctypes.c_int64()
+        L = _lib.lib()
+        _lib.check(L.gda_sampler_sample(self._h, seeds.ctypes.data, seeds.size, fan.ctypes.data, fan.size,
+                                        ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), ctypes.byref(nn_),
+                                        ctypes.byref(ne_)), "gda_sampler_sample")
+        nodes = np.empty(nn_.value, dtype=np.int64)
+        ei = np.empty((2, ne_.value), dtype=np.int64)
+        _lib.check(L.gda_sampler_fetch(self._h, nodes.ctypes.data, ei[0].ctypes.data if ne_.value else None,
+                                       ei[1].ctypes.data if ne_.value else None), "gda_sampler_fetch")
+        return torch.from_numpy(nodes), torch.from_numpy(ei)
+
+    def sample_batch(self, data, seeds, fanouts, seed=0):
+        """A ``Data`` batch like PyG's: ``x``/``y`` sliced to the sampled nodes (seeds are the
+        first ``batch_size`` rows), local ``edge_index``, ``n_id``, ``batch_size``."""
+        n_id, ei = self.sample(seeds, fanouts, seed)
+        dev = data.x.device
+        if dev.type == "cuda":
+            from .ops import gather_rows
+            n_dev = n_id.to(dev, non_blocking=True)
+            x = gather_rows(data.x, n_dev)
+            y = None if data.y is None else data.y[n_dev]
+            return Data(x=x, edge_index=ei.to(dev, non_blocking=True), y=y, n_id=n_dev,
+                        batch_size=int(torch.as_tensor(seeds).numel()))
+        return Data(x=data.x[n_id], edge_index=ei, y=None if data.y is None else data.y[n_id], n_id=n_id,
+                    batch_size=int(torch.as_tensor(seeds).numel()))

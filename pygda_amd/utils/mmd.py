@@ -3,7 +3,8 @@ MI355X kernels (:func:`pygda_amd.ops.mmd_loss`): no ``[n, n, d]`` temporary, rec
 the backward pass."""
 import torch
 
-from ..ops import mmd_loss
+from .. import distributed
+from ..ops import mmd_loss, mmd_loss_rows, sample_rows
 
 
 def guassian_kernel(source, target, kernel_mul=2.0, kernel_num=5, fix_sigma=None):
@@ -29,8 +30,22 @@ def MMD(source_feat, target_feat, sampling_num=1000, times=5):
     domain (mmd.py:109-159).  The draws come from the CPU default generator exactly as in
     the reference (``torch.randint`` without a device, :148-149), so a seeded run samples
     the same rows; only the 2 x times x sampling_num indices cross PCIe."""
+    dev = source_feat.device
+    if distributed.active():
+        # data-parallel: each rank draws its 1/W share of every resample from ITS mini-batch,
+        # the rows are all-gathered (2 x times x sampling_num x d floats) and every rank
+        # evaluates the same global-batch MMD; gradients return to the rows a rank owns.
+        w = distributed.info()["world_size"]
+        per = -(-sampling_num // w)
+        s_idx = torch.randint(source_feat.size(0), (times, per)).to(dev, non_blocking=True)
+        t_idx = torch.randint(target_feat.size(0), (times, per)).to(dev, non_blocking=True)
+        s_rows = distributed.all_gather_rows(sample_rows(source_feat, s_idx))     # [W, times, per, d]
+        t_rows = distributed.all_gather_rows(sample_rows(target_feat, t_idx))
+        d = source_feat.size(1)
+        s_rows = s_rows.permute(1, 0, 2, 3).reshape(times, w * per, d)
+        t_rows = t_rows.permute(1, 0, 2, 3).reshape(times, w * per, d)
+        return mmd_loss_rows(s_rows, t_rows)
     source_sample = torch.randint(source_feat.size(0), (times, sampling_num))
     target_sample = torch.randint(target_feat.size(0), (times, sampling_num))
-    dev = source_feat.device
     return mmd_loss(source_feat, target_feat, source_sample.to(dev, non_blocking=True),
                     target_sample.to(dev, non_blocking=True))

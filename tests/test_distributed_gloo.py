@@ -1,0 +1,105 @@
+"""CPU, world_size 2 over gloo: the data-parallel exchange steps of pygda_amd/distributed.py
+(flat gradient all-reduce; all-gather of MMD sample rows with the slice-and-scale backward)
+and the rank sharding of the loaders.  The kernels themselves need a GPU; the collective
+logic is backend-independent and is what runs over RCCL on the GPU box."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _pair_loss(rows_s, rows_t):
+    """A differentiable stand-in for the global-batch pairwise statistic (same structure as
+    MMD: every row interacts with every other row of both domains)."""
+    tot = torch.cat([rows_s, rows_t], dim=1)                   # [times, 2n, d]
+    d2 = ((tot.unsqueeze(1) - tot.unsqueeze(2)) ** 2).sum(-1)
+    return torch.exp(-d2 / 4.0).mean()
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pygda_amd import distributed as D
+        from pygda_amd.data import Data, NeighborLoader
+        assert D.active() and D.info() == dict(rank=rank, world_size=world)
+
+        # ---- 1. flat gradient all-reduce == mean of the per-rank gradients -----------------
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.ReLU(), torch.nn.Linear(4, 3))
+        unused = torch.nn.Parameter(torch.zeros(2))            # a parameter no rank touches
+        g = torch.Generator().manual_seed(100 + rank)
+        x, y = torch.randn(8, 6, generator=g), torch.randint(0, 3, (8,), generator=g)
+        torch.nn.functional.cross_entropy(net(x), y).backward()
+        local = [p.grad.clone() for p in net.parameters()]
+        D.allreduce_grads(list(net.parameters()) + [unused])
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
+        for i, p in enumerate(net.parameters()):
+            want = sum(gr[i] for gr in gathered) / world
+            assert torch.allclose(p.grad, want, atol=1e-7)
+        assert unused.grad is not None and torch.equal(unused.grad, torch.zeros(2))
+
+        # ---- 2. all-gather of sample rows: global loss, per-rank gradient slices ------------
+        g = torch.Generator().manual_seed(7 + rank)
+        rs = torch.randn(3, 5, 4, generator=g, requires_grad=True)      # [times, per, d] of this rank
+        rt = torch.randn(3, 5, 4, generator=g, requires_grad=True)
+        S = D.all_gather_rows(rs).permute(1, 0, 2, 3).reshape(3, world * 5, 4)
+        Tt = D.all_gather_rows(rt).permute(1, 0, 2, 3).reshape(3, world * 5, 4)
+        loss = _pair_loss(S, Tt)
+        loss.backward()
+        both = [None] * world
+        dist.all_gather_object(both, (rs.detach(), rt.detach(), rs.grad, rt.grad, loss.item()))
+        # single-process reference on the concatenated rows
+        RS = torch.stack([b[0] for b in both]).permute(1, 0, 2, 3).reshape(3, world * 5, 4).requires_grad_()
+        RT = torch.stack([b[1] for b in both]).permute(1, 0, 2, 3).reshape(3, world * 5, 4).requires_grad_()
+        ref = _pair_loss(RS, RT)
+        ref.backward()
+        assert abs(ref.item() - loss.item()) < 1e-7 and all(abs(b[4] - loss.item()) < 1e-7 for b in both)
+        want_s = RS.grad.view(3, world, 5, 4)[:, rank] * world         # scaled: allreduce_grads divides by W
+        want_t = RT.grad.view(3, world, 5, 4)[:, rank] * world
+        assert torch.allclose(rs.grad, want_s, atol=1e-7) and torch.allclose(rt.grad, want_t, atol=1e-7)
+
+        # ---- 3. loaders: disjoint seed shards, equal step counts -----------------------------
+        n = 100
+        gg = torch.Generator().manual_seed(3)
+        d = Data(x=torch.randn(n, 3, generator=gg), edge_index=torch.randint(0, n, (2, 400), generator=gg),
+                 y=torch.zeros(n, dtype=torch.long))
+        loader = NeighborLoader(d, [3, 3], batch_size=16, **D.info())
+        seeds = [b.n_id[:b.batch_size].tolist() for b in loader]
+        allseeds = [None] * world
+        dist.all_gather_object(allseeds, seeds)
+        assert len({len(s) for s in allseeds}) == 1                      # same number of steps
+        flat = [tuple(s) for r in allseeds for s in r]
+        assert set(v for s in flat for v in s) == set(range(n))          # union covers every seed
+        q.put((rank, "ok"))
+    except Exception as e:      # surface the failure in the parent
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
