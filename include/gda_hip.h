@@ -188,6 +188,25 @@ int gda_sampler_sample(gda_sampler* s, const int64_t* seeds_host, int64_t n_seed
 int gda_sampler_fetch(const gda_sampler* s, int64_t* nodes_out, int64_t* esrc_out,
                       int64_t* edst_out);
 
+/* ------------------------------------------------------------------------------
+ * Host construction of the PPMI graph (HOST pointers).
+ *
+ * Replaces the Python random-walk loop of PPMIConv.norm (pygda/nn/ppmi_conv.py:98-172):
+ * `passes` walks (40 in the reference) of length ~U{1..path_len} from every node over the
+ * symmetrised neighbour sets, row-normalised visit counts, PPMI weights
+ * max(log(p / colsum * |targets| / path_len), 0).  Own counter-based generator (`seed`):
+ * statistical, not bit-wise, parity with the reference's np.random stream.  The weighted edge
+ * list (sorted by (src, dst), zero weights kept, no self loops added) is held by the returned
+ * handle; fetch it into buffers of gda_edge_list_size() entries, then feed it to
+ * gda_build_csr_norm(add_self_loops=1, normalize=1, degree_side=1) (ppmi_conv.py:174-184).
+ * ---------------------------------------------------------------------------- */
+typedef struct gda_edge_list gda_edge_list;
+int gda_ppmi_build_host(const int64_t* src_host, const int64_t* dst_host, int64_t E, int64_t N,
+                        int path_len, int passes, uint64_t seed, gda_edge_list** out);
+int64_t gda_edge_list_size(const gda_edge_list* l);
+int gda_edge_list_fetch(const gda_edge_list* l, int64_t* src_out, int64_t* dst_out, float* w_out);
+void gda_edge_list_destroy(gda_edge_list* l);
+
 #ifdef __cplusplus
 }
 #endif

@@ -377,3 +377,213 @@ def a2gnn_train_step(net: A2GNNBase, opt: torch.optim.Optimizer, src: Graph, tgt
     loss.backward()
     opt.step()
     return val, s_logits
+
+
+# ----------------------------------------------------------------------------
+# PPMI graph construction, UDAGCN, AdaGCN  (a11, a13, a14)
+# ----------------------------------------------------------------------------
+def ppmi_raw_edges(edge_index: Tensor, path_len: int = 5, passes: int = 40):
+    """ppmi_conv.py:56-169: ``passes`` (40 in the reference) rounds of random walks (length ~
+    U{1..path_len}) from every node over the symmetrised neighbour sets, ``np.random`` stream,
+    row-normalised visit counts -> PPMI = max(log(p / sum_a p * |targets| / path_len), 0) ->
+    weighted edge list (float64).  Python containers are used exactly as in the reference
+    because their iteration order is part of the result."""
+    import numpy as np
+    from collections import Counter
+    adj = {}
+    for a, b in edge_index.t().numpy():
+        a, b = int(a), int(b)
+        adj.setdefault(a, set()).add(b)
+        adj.setdefault(b, set()).add(a)
+    adj = {a: list(nb) for a, nb in adj.items()}
+    walks = {}
+    for _ in range(passes):                                                  # :119
+        for a in adj:
+            cur = a
+            steps = np.random.randint(1, path_len + 1)                       # :122
+            for _ in range(steps):
+                nb = adj[cur]
+                b = nb[np.random.randint(0, len(nb))]                        # :104-107
+                walks.setdefault(a, Counter())[b] += 1
+                cur = b
+    normed = {}
+    for a, c in walks.items():                                               # :109-117,150
+        s = sum(c.values())
+        normed[a] = {b: cnt / s for b, cnt in c.items()}
+    prob_sums = Counter()
+    for a, c in normed.items():                                              # :152-155
+        for b, p in c.items():
+            prob_sums[b] += p
+    ei, ew = [], []
+    for a, c in normed.items():                                              # :157-169
+        for b, p in c.items():
+            ei.append([a, b])
+            ew.append(max(np.log(p / prob_sums[b] * len(prob_sums) / path_len), 0))
+    return torch.tensor(ei).t(), torch.tensor(ew)                            # float64, like the reference
+
+
+def ppmi_norm(edge_index: Tensor, num_nodes: int, path_len: int = 5, improved: bool = False):
+    """ppmi_conv.py:171-184: the PPMI edge list + self loops + SOURCE-degree symmetric
+    normalisation, evaluated in float64 and cast to float32 at the end."""
+    edge_index, edge_weight = ppmi_raw_edges(edge_index, path_len)
+    edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight,
+                                                       2 if improved else 1, num_nodes)
+    row, col = edge_index
+    deg = torch.zeros(num_nodes, dtype=edge_weight.dtype).index_add_(0, row, edge_weight)
+    dis = deg.pow(-0.5)
+    dis[dis == float("inf")] = 0
+    return edge_index, (dis[row] * edge_weight * dis[col]).type(torch.float32)  # :176-184
+
+
+class PPMIConv(CachedGCNConv):
+    """ppmi_conv.py:10-184: a CachedGCNConv whose cached graph is the PPMI graph."""
+
+    def __init__(self, in_channels, out_channels, weight=None, bias=None, improved=False,
+                 use_bias=True, path_len=5):
+        super().__init__(in_channels, out_channels, weight, bias, improved, use_bias)
+        self.path_len = path_len
+
+    def forward(self, x, edge_index, cache_name="default_cache", edge_weight=None):
+        x = torch.matmul(x, self.weight)
+        if cache_name not in self.cache_dict:
+            self.cache_dict[cache_name] = ppmi_norm(edge_index, x.size(0), self.path_len, self.improved)
+        ei, norm = self.cache_dict[cache_name]
+        out = propagate(ei, norm, x)
+        return out + self.bias if self.bias is not None else out
+
+
+class _UDAGNN(nn.Module):
+    """udagcn_base.py:9-89: conv stack; the Dropout(0.1) modules sit in a plain list (never
+    registered, never switched to eval) and the ctor's dropout argument is ignored."""
+
+    def __init__(self, in_dim, hid_dim, gnn_type="gcn", num_layers=3, base_model=None, act=F.relu,
+                 dropout_p=0.1, **kw):
+        super().__init__()
+        ws = [None] * num_layers if base_model is None else [c.weight for c in base_model.conv_layers]
+        bs = [None] * num_layers if base_model is None else [c.bias for c in base_model.conv_layers]
+        self.dropout_layers = [nn.Dropout(dropout_p) for _ in ws]
+        self.act = act
+        cls = PPMIConv if gnn_type == "ppmi" else CachedGCNConv
+        dims = [in_dim] + [hid_dim] * num_layers
+        self.conv_layers = nn.ModuleList(cls(dims[i], dims[i + 1], weight=ws[i], bias=bs[i], **kw)
+                                         for i in range(num_layers))
+
+    def forward(self, x, edge_index, cache_name):
+        for i, conv in enumerate(self.conv_layers):
+            x = conv(x, edge_index, cache_name)
+            if i < len(self.conv_layers) - 1:
+                x = self.dropout_layers[i](self.act(x))
+        return x
+
+
+class UDAGCNBase(nn.Module):
+    """udagcn_base.py:92-267."""
+
+    def __init__(self, in_dim, hid_dim, num_classes, num_layers=3, act=F.relu, ppmi=True, adv_dim=40,
+                 dropout_p=0.1):
+        super().__init__()
+        self.ppmi = ppmi
+        self.encoder = _UDAGNN(in_dim, hid_dim, "gcn", num_layers, act=act, dropout_p=dropout_p)
+        if ppmi:
+            self.ppmi_encoder = _UDAGNN(in_dim, hid_dim, "ppmi", num_layers, base_model=self.encoder,
+                                        act=act, dropout_p=dropout_p, path_len=10)
+        self.cls_model = nn.Sequential(nn.Linear(hid_dim, num_classes))
+        self.domain_model = nn.Sequential(nn.Linear(hid_dim, adv_dim), nn.ReLU(), nn.Dropout(dropout_p),
+                                          nn.Linear(adv_dim, 2))
+        self.att_model = Attention(hid_dim)
+        self.loss_func = nn.CrossEntropyLoss()
+
+    def encode(self, data, cache_name):
+        g = self.encoder(data.x, data.edge_index, cache_name)
+        if not self.ppmi:
+            return g
+        p = self.ppmi_encoder(data.x, data.edge_index, cache_name)
+        return self.att_model([g, p])
+
+
+def udagcn_forward_model(net: UDAGCNBase, src: Graph, tgt: Graph, alpha: float, epoch: int,
+                         epochs: int):
+    """udagcn.py:131-201."""
+    es, et = net.encode(src, "source"), net.encode(tgt, "target")
+    s_logits = net.cls_model(es)
+    loss = net.loss_func(s_logits, src.y)                                            # :172
+    sd = net.domain_model(grad_reverse(es, alpha))
+    td = net.domain_model(grad_reverse(et, alpha))
+    loss = loss + net.loss_func(sd, torch.zeros(sd.size(0), dtype=torch.long)) \
+                + net.loss_func(td, torch.ones(td.size(0), dtype=torch.long))        # :177-190
+    t_logits = net.cls_model(et)
+    p = torch.clamp(F.softmax(t_logits, dim=-1), min=1e-9, max=1.0)
+    ent = torch.mean(torch.sum(-p * torch.log(p), dim=-1))                           # :193-197
+    return loss + ent * (epoch / epochs * 0.01), s_logits, t_logits                  # :199
+
+
+class _AdaGNN(nn.Module):
+    """adagcn_base.py:11-97 (gnn_type='gcn'): L GCNConv, act + Dropout between layers."""
+
+    def __init__(self, in_dim, hid_dim, num_layers, act, dropout_p):
+        super().__init__()
+        self.act = act
+        dims = [in_dim] + [hid_dim] * num_layers
+        self.conv_layers = nn.ModuleList(GCNConv(dims[i], dims[i + 1]) for i in range(num_layers))
+        self.dropout = nn.Dropout(dropout_p)
+
+    def forward(self, x, edge_index):
+        for i, conv in enumerate(self.conv_layers):
+            x = conv(x, edge_index)
+            if i < len(self.conv_layers) - 1:
+                x = self.dropout(self.act(x))
+        return x
+
+
+class AdaGCNBase(nn.Module):
+    """adagcn_base.py:99-181 (node mode).  The ctor's ``dropout`` never reaches the stack
+    (:145 builds GNN without it, so its default 0.1 at :39 always applies)."""
+
+    def __init__(self, in_dim, hid_dim, num_classes, num_layers=3, act=F.relu, dropout_p=0.1):
+        super().__init__()
+        self.encoder = _AdaGNN(in_dim, hid_dim, num_layers, act, dropout_p)
+        self.cls_model = nn.Sequential(nn.Linear(hid_dim, num_classes))
+        self.loss_func = nn.CrossEntropyLoss()
+
+    def forward(self, data):
+        return self.encoder(data.x, data.edge_index)
+
+
+def adagcn_gradient_penalty(disc: nn.Module, es: Tensor, et: Tensor) -> Tensor:
+    """adagcn.py:387-454: WGAN-GP over cat(source, target, interpolates); the interpolation
+    weights come from the CPU generator (``torch.rand`` then ``.to(device)``)."""
+    ns, nt = es.shape[0], et.shape[0]
+    if ns < nt:
+        hs = torch.cat((es, es), 0)
+        ht = torch.cat((et[0:ns], et[-ns:]), 0)
+        a = torch.rand((2 * ns, 1))
+    elif ns > nt:
+        hs = torch.cat((es[0:nt], es[-nt:]), 0)
+        ht = torch.cat((et, et), 0)
+        a = torch.rand((2 * nt, 1))
+    else:
+        hs, ht = es, et
+        a = torch.rand((nt, 1))
+    inter = ht + a * (hs - ht)
+    inputs = torch.cat((es, et, inter), 0)
+    scores = disc(inputs)
+    grad = torch.autograd.grad(inputs=inputs, outputs=scores, grad_outputs=torch.ones_like(scores),
+                               create_graph=True, retain_graph=True, only_inputs=True)[0]
+    return torch.mean((grad.view(grad.shape[0], -1).norm(2, dim=1) - 1) ** 2)
+
+
+def adagcn_forward_model(net: AdaGCNBase, disc: nn.Module, c_opt, src: Graph, tgt: Graph,
+                         gp_weight: float, domain_weight: float, critic_steps: int = 10):
+    """adagcn.py:138-198: ``critic_steps`` Wasserstein-critic updates, then the encoder loss."""
+    for _ in range(critic_steps):
+        es, et = net(src), net(tgt)
+        gp = adagcn_gradient_penalty(disc, es, et)
+        dis = -torch.abs(torch.mean(disc(es).reshape(-1)) - torch.mean(disc(et).reshape(-1)))
+        c_opt.zero_grad()
+        (dis + gp_weight * gp).backward()
+        c_opt.step()
+    es, et = net(src), net(tgt)
+    s_logits = net.cls_model(es)
+    loss = net.loss_func(s_logits, src.y)
+    dis = torch.abs(torch.mean(disc(es).reshape(-1)) - torch.mean(disc(et).reshape(-1)))
+    return loss + dis * domain_weight, s_logits, net.cls_model(et)

@@ -40,6 +40,11 @@ _SIGNATURES = {
     "gda_sampler_sample": (c_int, [_P, _P, c_int64, _P, c_int, ctypes.c_uint64,
                                    ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
     "gda_sampler_fetch": (c_int, [_P, _P, _P, _P]),
+    "gda_ppmi_build_host": (c_int, [_P, _P, c_int64, c_int64, c_int, c_int, ctypes.c_uint64,
+                                    ctypes.POINTER(c_void_p)]),
+    "gda_edge_list_size": (c_int64, [_P]),
+    "gda_edge_list_fetch": (c_int, [_P, _P, _P, _P]),
+    "gda_edge_list_destroy": (None, [_P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -1,5 +1,7 @@
 from .base import BaseGDA
 from .a2gnn import A2GNN
 from .grade import GRADE
+from .udagcn import UDAGCN
+from .adagcn import AdaGCN
 
-__all__ = ["BaseGDA", "A2GNN", "GRADE"]
+__all__ = ["BaseGDA", "A2GNN", "GRADE", "UDAGCN", "AdaGCN"]

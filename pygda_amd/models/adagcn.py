@@ -1,0 +1,108 @@
+"""``AdaGCN`` trainer (pygda/models/adagcn.py:18-454): Wasserstein critic with gradient
+penalty (10 critic updates per encoder update), then source CE + domain_weight * |E D(s) -
+E D(t)|.  The encoder runs on the MI355X aggregation kernels; the critic is a 3-layer MLP
+whose double backward (gradient penalty) stays in torch autograd.
+
+One saving over the reference with identical results: inside the critic loop the encoder
+outputs are detached.  The reference back-propagates the critic loss into the encoder ten
+times per step and then discards those gradients (``optimizer.zero_grad()`` at :292 precedes
+the only encoder step), i.e. 10 x L wasted backward aggregations per domain."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..nn import AdaGCNBase
+from .base import BaseGDA
+
+
+class AdaGCN(BaseGDA):
+    def __init__(self, in_dim, hid_dim, num_classes, mode='node', num_layers=3, dropout=0., act=F.relu,
+                 gnn_type='gcn', adv_dim=40, gp_weight=5, domain_weight=1, weight_decay=0., lr=4e-3,
+                 epoch=100, device='cuda:0', batch_size=0, num_neigh=-1, verbose=2, **kwargs):
+        super().__init__(in_dim=in_dim, hid_dim=hid_dim, num_classes=num_classes, num_layers=num_layers,
+                         dropout=dropout, act=act, weight_decay=weight_decay, lr=lr, epoch=epoch,
+                         device=device, batch_size=batch_size, num_neigh=num_neigh, verbose=verbose,
+                         **kwargs)
+        self.gnn_type, self.adv_dim, self.gp_weight = gnn_type, adv_dim, gp_weight
+        self.domain_weight, self.mode = domain_weight, mode
+        self.critic_steps = 10                                                        # :169
+
+    def init_model(self, **kwargs):
+        return AdaGCNBase(in_dim=self.in_dim, hid_dim=self.hid_dim, num_classes=self.num_classes,
+                          num_layers=self.num_layers, dropout=self.dropout, act=self.act,
+                          gnn_type=self.gnn_type, mode=self.mode, **kwargs).to(self.device)
+
+    def _critic_gap(self, es, et):
+        return torch.mean(self.discriminator(es).reshape(-1)) - torch.mean(self.discriminator(et).reshape(-1))
+
+    def forward_model(self, source_data, target_data):
+        for _ in range(self.critic_steps):                                            # :169-183
+            with torch.no_grad():
+                encoded_source = self.adagcn(source_data)
+                encoded_target = self.adagcn(target_data)
+            gp_loss = self.gradient_penalty(encoded_source, encoded_target)
+            loss = -torch.abs(self._critic_gap(encoded_source, encoded_target)) + self.gp_weight * gp_loss
+            self.c_optimizer.zero_grad()
+            loss.backward()
+            self.c_optimizer.step()
+        encoded_source = self.adagcn(source_data)                                     # :186-196
+        encoded_target = self.adagcn(target_data)
+        source_logits = self.adagcn.cls_model(encoded_source)
+        cls_loss = self.adagcn.loss_func(source_logits, source_data.y)
+        dis_loss = torch.abs(self._critic_gap(encoded_source, encoded_target))
+        target_logits = self.adagcn.cls_model(encoded_target)
+        return cls_loss + dis_loss * self.domain_weight, source_logits, target_logits
+
+    def _prepare(self, source_data, target_data):
+        if self.mode != 'node':
+            raise NotImplementedError("mode='graph' is out of scope (DESIGN.md)")
+        self._node_loaders(source_data, target_data)
+        self.adagcn = self.init_model(**self.kwargs)
+        optimizer = torch.optim.Adam(self.adagcn.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        self.discriminator = nn.Sequential(nn.Linear(self.hid_dim, self.adv_dim), nn.ReLU(), nn.Dropout(0.1),
+                                           nn.Linear(self.adv_dim, 1), nn.Sigmoid()).to(self.device)   # :264-270
+        self.c_optimizer = torch.optim.Adam(self.discriminator.parameters(), lr=self.lr,
+                                            weight_decay=self.weight_decay)
+
+        def step(src, tgt, alpha, epoch):
+            loss, source_logits, _ = self.forward_model(src, tgt)
+            return loss, source_logits
+
+        return self.adagcn, optimizer, step, lambda e: 0.0
+
+    def fit(self, source_data, target_data):
+        self._train_epochs(*self._prepare(source_data, target_data))
+
+    def process_graph(self, data):
+        pass
+
+    def predict(self, data, source=False):
+        self.adagcn.eval()
+        loader = self.source_loader if source else self.target_loader
+        return self._predict_loader(loader, lambda b: self.adagcn.cls_model(self.adagcn(b)))
+
+    def gradient_penalty(self, encoded_source, encoded_target):
+        """WGAN-GP over cat(source, target, interpolates) (:387-454); interpolation weights from
+        the CPU generator, as in the reference (``torch.rand(...).to(device)``)."""
+        num_s, num_t = encoded_source.shape[0], encoded_target.shape[0]
+        dev = encoded_source.device
+        if num_s < num_t:
+            hidden_s = torch.cat((encoded_source, encoded_source), dim=0)
+            hidden_t = torch.cat((encoded_target[0:num_s], encoded_target[-num_s:]), dim=0)
+            alpha = torch.rand((2 * num_s, 1)).to(dev)
+        elif num_s > num_t:
+            hidden_s = torch.cat((encoded_source[0:num_t], encoded_source[-num_t:]), dim=0)
+            hidden_t = torch.cat((encoded_target, encoded_target), dim=0)
+            alpha = torch.rand((2 * num_t, 1)).to(dev)
+        else:
+            hidden_s, hidden_t = encoded_source, encoded_target
+            alpha = torch.rand((num_t, 1)).to(dev)
+        interpolates = hidden_t + alpha * (hidden_s - hidden_t)
+        inputs = torch.cat((encoded_source, encoded_target, interpolates), dim=0)
+        if not inputs.requires_grad:
+            inputs.requires_grad_(True)
+        scores = self.discriminator(inputs)
+        gradient = torch.autograd.grad(inputs=inputs, outputs=scores, grad_outputs=torch.ones_like(scores),
+                                       create_graph=True, retain_graph=True, only_inputs=True)[0]
+        gradient_norm = gradient.view(gradient.shape[0], -1).norm(2, dim=1)
+        return torch.mean((gradient_norm - 1) ** 2)

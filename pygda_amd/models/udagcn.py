@@ -1,0 +1,83 @@
+"""``UDAGCN`` trainer (pygda/models/udagcn.py:19-360): source CE + gradient-reversed domain
+CE per domain (MLP discriminator) + annealed target entropy, over the dual-view encoder.
+
+The reference's per-name adjacency cache is never invalidated (cached_gcn_conv.py:132-136),
+so with ``batch_size > 0`` it would silently reuse batch #1's edges for every later batch.
+Here mini-batches key the cache per batch (SURVEY §3.4 hazard); full-batch runs use the
+reference's keys "source"/"target" unchanged."""
+import itertools
+
+import torch
+import torch.nn.functional as F
+
+from ..nn import GradReverse, UDAGCNBase
+from .base import BaseGDA
+
+
+class UDAGCN(BaseGDA):
+    def __init__(self, in_dim, hid_dim, num_classes, mode='node', num_layers=2, dropout=0., act=F.relu,
+                 ppmi=True, adv_dim=40, weight_decay=3e-3, lr=4e-3, epoch=300, device='cuda:0',
+                 batch_size=0, num_neigh=-1, verbose=2, **kwargs):
+        super().__init__(in_dim=in_dim, hid_dim=hid_dim, num_classes=num_classes, num_layers=num_layers,
+                         dropout=dropout, act=act, weight_decay=weight_decay, lr=lr, epoch=epoch,
+                         device=device, batch_size=batch_size, num_neigh=num_neigh, verbose=verbose,
+                         **kwargs)
+        self.ppmi, self.adv_dim, self.mode = ppmi, adv_dim, mode
+
+    def init_model(self, **kwargs):
+        return UDAGCNBase(in_dim=self.in_dim, hid_dim=self.hid_dim, num_classes=self.num_classes,
+                          num_layers=self.num_layers, dropout=self.dropout, act=self.act, ppmi=self.ppmi,
+                          adv_dim=self.adv_dim, **kwargs).to(self.device)
+
+    def _cache_key(self, data, name):
+        n_id = getattr(data, "n_id", None)          # sampled mini-batch: one cache entry per batch
+        return name if n_id is None else f"{name}:{int(n_id[0])}:{n_id.numel()}:{data.edge_index.size(1)}"
+
+    def forward_model(self, source_data, target_data, alpha, epoch):
+        net = self.udagcn
+        encoded_source = net.encode(source_data, self._cache_key(source_data, "source"))
+        encoded_target = net.encode(target_data, self._cache_key(target_data, "target"))
+        source_logits = net.cls_model(encoded_source)
+        loss = net.loss_func(source_logits, source_data.y)                                   # :172
+        dev = encoded_source.device
+        source_domain_preds = net.domain_model(GradReverse.apply(encoded_source, alpha))
+        target_domain_preds = net.domain_model(GradReverse.apply(encoded_target, alpha))
+        loss = loss + net.loss_func(source_domain_preds,
+                                    torch.zeros(source_domain_preds.size(0), dtype=torch.long, device=dev)) \
+                    + net.loss_func(target_domain_preds,
+                                    torch.ones(target_domain_preds.size(0), dtype=torch.long, device=dev))
+        target_logits = net.cls_model(encoded_target)
+        target_probs = torch.clamp(F.softmax(target_logits, dim=-1), min=1e-9, max=1.0)
+        loss_entropy = torch.mean(torch.sum(-target_probs * torch.log(target_probs), dim=-1))  # :193-197
+        return loss + loss_entropy * (epoch / self.epoch * 0.01), source_logits, target_logits
+
+    def _prepare(self, source_data, target_data):
+        if self.mode != 'node':
+            raise NotImplementedError("mode='graph' is out of scope (DESIGN.md)")
+        self._node_loaders(source_data, target_data)
+        self.udagcn = self.init_model(**self.kwargs)
+        params = itertools.chain(*[m.parameters() for m in self.udagcn.models])            # :262-268
+        optimizer = torch.optim.Adam(params, lr=self.lr, weight_decay=self.weight_decay)
+
+        def step(src, tgt, alpha, epoch):
+            loss, source_logits, _ = self.forward_model(src, tgt, alpha, epoch)
+            return loss, source_logits
+
+        def before_step():
+            for m in self.udagcn.models:
+                m.train()
+
+        return self.udagcn, optimizer, step, lambda e: min((e + 1) / self.epoch, 0.05), before_step
+
+    def fit(self, source_data, target_data):
+        self._train_epochs(*self._prepare(source_data, target_data))
+
+    def process_graph(self, data):
+        pass
+
+    def predict(self, data, source=False):
+        for m in self.udagcn.models:
+            m.eval()
+        loader, name = (self.source_loader, 'source') if source else (self.target_loader, 'target')
+        return self._predict_loader(
+            loader, lambda b: self.udagcn.cls_model(self.udagcn.encode(b, self._cache_key(b, name))))

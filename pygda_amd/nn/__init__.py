@@ -2,10 +2,14 @@ from .linear import Linear, glorot, zeros
 from .prop_gcn_conv import PropGCNConv, gcn_norm
 from .gcn_conv import GCNConv
 from .cached_gcn_conv import CachedGCNConv
+from .ppmi_conv import PPMIConv, ppmi_edges
 from .reverse_layer import GradReverse
 from .attention import Attention
 from .a2gnn_base import A2GNNBase, global_mean_pool
 from .grade_base import GRADEBase
+from .udagcn_base import UDAGCNBase
+from .adagcn_base import AdaGCNBase
 
-__all__ = ["Linear", "glorot", "zeros", "PropGCNConv", "gcn_norm", "GCNConv", "CachedGCNConv",
-           "GradReverse", "Attention", "A2GNNBase", "GRADEBase", "global_mean_pool"]
+__all__ = ["Linear", "glorot", "zeros", "PropGCNConv", "gcn_norm", "GCNConv", "CachedGCNConv", "PPMIConv",
+           "ppmi_edges", "GradReverse", "Attention", "A2GNNBase", "GRADEBase", "UDAGCNBase", "AdaGCNBase",
+           "global_mean_pool"]

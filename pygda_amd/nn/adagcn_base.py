@@ -1,0 +1,42 @@
+"""``AdaGCNBase`` (pygda/nn/adagcn_base.py:11-181): GCNConv (or PPMIConv) stack with act +
+``Dropout(0.1)`` between layers and a linear classifier.  As in the reference, the
+``dropout`` given to ``AdaGCNBase`` never reaches the stack (:145 builds ``GNN`` without it,
+so the helper's default 0.1 at :39 always applies)."""
+import torch.nn.functional as F
+from torch import nn
+
+from .a2gnn_base import global_mean_pool
+from .gcn_conv import GCNConv
+from .ppmi_conv import PPMIConv
+
+
+class GNN(nn.Module):
+    def __init__(self, in_dim, hid_dim, gnn_type='gcn', num_layers=3, act=F.relu, dropout=0.1, **kwargs):
+        super().__init__()
+        self.gnn_type, self.act, self.num_layers = gnn_type, act, num_layers
+        conv = GCNConv if gnn_type == 'gcn' else PPMIConv
+        dims = [in_dim] + [hid_dim] * num_layers
+        self.conv_layers = nn.ModuleList(conv(dims[i], dims[i + 1]) for i in range(num_layers))
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x, edge_index, batch, mode='node'):
+        last = len(self.conv_layers) - 1
+        for i, conv in enumerate(self.conv_layers):
+            x = conv(x, edge_index)
+            if i < last:
+                x = self.dropout(self.act(x))
+        return global_mean_pool(x, batch) if mode == 'graph' else x
+
+
+class AdaGCNBase(nn.Module):
+    def __init__(self, in_dim, hid_dim, num_classes, num_layers=3, dropout=0.1, act=F.relu, gnn_type='gcn',
+                 mode='node', **kwargs):
+        super().__init__()
+        self.encoder = GNN(in_dim=in_dim, hid_dim=hid_dim, gnn_type=gnn_type, act=act, num_layers=num_layers)
+        self.cls_model = nn.Sequential(nn.Linear(hid_dim, num_classes))
+        self.mode = mode
+        self.loss_func = nn.CrossEntropyLoss()
+
+    def forward(self, data):
+        batch = None if self.mode == 'node' else data.batch
+        return self.encoder(data.x, data.edge_index, batch, mode=self.mode)

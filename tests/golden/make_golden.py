@@ -45,7 +45,7 @@ def make_graph(n, e, seed, undirected=True, self_loops=0, dups=0, isolated=True)
 
 
 def np_(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()      # copy: later in-place optimiser steps must not leak in
 
 
 def sd_arrays(module, prefix="param/"):
@@ -253,9 +253,67 @@ def fx_grade(ref):
         save(f"grade_forward_{disc.lower()}", **arrs)
 
 
+def _zero_dropout(module):
+    """Device dropout masks cannot be replayed on another backend: parity fixtures switch every
+    Dropout off (incl. UDAGCN's unregistered ones, udagcn_base.py:47)."""
+    for m in module.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        for d in getattr(m, "dropout_layers", []):
+            d.p = 0.0
+
+
+def fx_udagcn(ref):
+    """UDAGCN.forward_model with the PPMI view (np.random-seeded walks) and without."""
+    s, t = _domain_pair(81, ns=60, nt=50, f=12, c=3)
+    for ppmi in (True, False):
+        m = ref.UDAGCN(12, 8, 3, num_layers=2, ppmi=ppmi, adv_dim=6, device="cpu", epoch=10, verbose=0)
+        torch.manual_seed(91)
+        m.udagcn = m.init_model()
+        _zero_dropout(m.udagcn)
+        np.random.seed(92)
+        loss, sl, tl = m.forward_model(s, t, 0.05, 3)
+        loss.backward()
+        arrs = dict(_pair_arrays(s, t), loss=np_(loss), src_logits=np_(sl), tgt_logits=np_(tl),
+                    alpha=np.float64(0.05), epoch=np.int64(3), epochs=np.int64(10), init_seed=np.int64(91),
+                    np_seed=np.int64(92))
+        arrs.update(sd_arrays(m.udagcn))
+        arrs.update({"grad/" + k: np_(p.grad) for k, p in m.udagcn.named_parameters() if p.grad is not None})
+        if ppmi:      # the PPMI graphs the reference built (its cache), so a different walker can be bypassed
+            for name in ("source", "target"):      # every PPMIConv layer walks its own graph (own cache_dict)
+                for li, conv in enumerate(m.udagcn.ppmi_encoder.conv_layers):
+                    ei, w = conv.cache_dict[name]
+                    arrs[f"ppmi/{name}/{li}/edge_index"], arrs[f"ppmi/{name}/{li}/weight"] = np_(ei), np_(w)
+        save("udagcn_forward_ppmi" if ppmi else "udagcn_forward_gcn", **arrs)
+
+
+def fx_adagcn(ref):
+    """AdaGCN.forward_model: 10 critic updates (gradient penalty, CPU torch.rand) + encoder loss."""
+    s, t = _domain_pair(101, ns=70, nt=55, f=12, c=3)
+    m = ref.AdaGCN(12, 8, 3, num_layers=2, adv_dim=6, gp_weight=5, domain_weight=1, lr=0.01,
+                   weight_decay=0.01, device="cpu", epoch=2, verbose=0)
+    torch.manual_seed(111)
+    m.adagcn = m.init_model()
+    m.discriminator = torch.nn.Sequential(torch.nn.Linear(8, 6), torch.nn.ReLU(), torch.nn.Dropout(0.1),
+                                          torch.nn.Linear(6, 1), torch.nn.Sigmoid())
+    _zero_dropout(m.adagcn); _zero_dropout(m.discriminator)
+    disc0 = sd_arrays(m.discriminator, "disc0/")
+    m.c_optimizer = torch.optim.Adam(m.discriminator.parameters(), lr=0.01, weight_decay=0.01)
+    m.adagcn.train()
+    torch.manual_seed(112)
+    loss, sl, tl = m.forward_model(s, t)
+    m.adagcn.zero_grad()
+    loss.backward()
+    arrs = dict(_pair_arrays(s, t), loss=np_(loss), src_logits=np_(sl), tgt_logits=np_(tl),
+                init_seed=np.int64(111), rand_seed=np.int64(112))
+    arrs.update(sd_arrays(m.adagcn)); arrs.update(grads(m.adagcn)); arrs.update(disc0)
+    arrs.update(sd_arrays(m.discriminator, "disc10/"))
+    save("adagcn_forward", **arrs)
+
+
 FIXTURES = {"mmd": fx_mmd, "grl_attention": fx_grl_attention, "gcn_norm": fx_gcn_norm,
             "prop_gcn_conv": fx_prop_gcn_conv, "cached_gcn_conv": fx_cached_gcn_conv,
-            "a2gnn": fx_a2gnn, "grade": fx_grade}
+            "a2gnn": fx_a2gnn, "grade": fx_grade, "udagcn": fx_udagcn, "adagcn": fx_adagcn}
 
 
 def main(argv):

@@ -144,3 +144,25 @@ def test_logger_format():
     lines = buf.getvalue().splitlines()
     assert lines[0] == "Epoch 0003: loss 1.2346, source acc 0.5000, time 2.00"
     assert lines[1] == "Epoch 0004: Loss I 1.0000 | Loss O 2.0000 | "
+
+
+def test_citation_dataset_reader(tmp_path):
+    """The three-text-file format of pygda/datasets/citation.py:153-173, CRLF labels included."""
+    from pygda_amd.datasets import CitationDataset
+    raw = tmp_path / "raw"
+    raw.mkdir()
+    (raw / "toy_edgelist.txt").write_text("0,1\n1,2\n2,0\n3,3\n")
+    (raw / "toy_docs.txt").write_text("0,1,0.5\n1,0,0\n0,0,1\n1,1,1\n")
+    (raw / "toy_labels.txt").write_bytes(b"0\r\n2\r\n1\r\n2\r\n")
+    ds = CitationDataset(str(tmp_path), "toy")
+    d = ds[0]
+    assert d.edge_index.dtype == torch.int64 and d.edge_index.tolist() == [[0, 1, 2, 3], [1, 2, 0, 3]]
+    assert d.x.dtype == torch.float32 and d.x.tolist() == [[0, 1, 0.5], [1, 0, 0], [0, 0, 1], [1, 1, 1]]
+    assert d.y.dtype == torch.int64 and d.y.tolist() == [0, 2, 1, 2]
+    assert ds.num_classes == 3 and ds.num_node_features == 3 and len(ds) == 1
+    m = d.train_mask.int() + d.val_mask.int() + d.test_mask.int()
+    assert m.tolist() == [1, 1, 1, 1] and int(d.train_mask.sum()) == 3
+    again = CitationDataset(str(tmp_path), "toy")[0]                 # served from the binary cache
+    assert torch.equal(again.train_mask, d.train_mask) and torch.equal(again.x, d.x)
+    with pytest.raises(FileNotFoundError):
+        CitationDataset(str(tmp_path / "nope"), "toy")

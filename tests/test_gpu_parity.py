@@ -377,3 +377,103 @@ def test_a2gnn_minibatch_training_runs():
     assert len(seen) == 3 and all(np.isfinite(v) for v in seen)
     logits, labels = m.predict(t)
     assert logits.shape == (t.num_nodes, 5) and torch.equal(labels.cpu(), t.y)
+
+
+# ----------------------------------------------------------- UDAGCN / AdaGCN --
+def _no_dropout(module):
+    for m in module.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        for d in getattr(m, "dropout_layers", []):
+            d.p = 0.0
+
+
+@pytest.mark.parametrize("ppmi", [True, False])
+def test_udagcn_forward_model_golden(ppmi):
+    """Dual-view encoder (shared weights), attention fusion, GRL domain CEs, entropy term.
+    The PPMI graphs are the ones the reference built (its np.random stream cannot be replayed
+    by the native walker): they are loaded into the layer caches, everything else is computed."""
+    g = load_golden("udagcn_forward_ppmi" if ppmi else "udagcn_forward_gcn")
+    s, t = _pair(g)
+    m = pygda_amd.models.UDAGCN(12, 8, 3, num_layers=2, ppmi=ppmi, adv_dim=6, device=DEV, epoch=10, verbose=0)
+    torch.manual_seed(int(g["init_seed"]))
+    m.udagcn = m.init_model()
+    sd = m.udagcn.state_dict()
+    assert set(sd) == set(sub(g, "param/"))
+    for k, v in sub(g, "param/").items():
+        exact(sd[k], v)                                   # init RNG stream incl. the shared parameters
+    _no_dropout(m.udagcn)
+    if ppmi:
+        for name, data in (("source", s), ("target", t)):
+            for li, conv in enumerate(m.udagcn.ppmi_encoder.conv_layers):   # each layer walked its own graph
+                ei, w = T(g[f"ppmi/{name}/{li}/edge_index"], DEV), T(g[f"ppmi/{name}/{li}/weight"], DEV)
+                conv.cache_dict[name] = build_csr(ei, data.num_nodes, w, add_self_loops=False, normalize=False)
+    loss, sl, tl = m.forward_model(s.to(DEV), t.to(DEV), float(g["alpha"]), int(g["epoch"]))
+    loss.backward()
+    close(loss, g["loss"], rtol=REL)
+    close(sl, g["src_logits"], rtol=0, atol=LOGIT_ATOL); close(tl, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    named = dict(m.udagcn.named_parameters())
+    for k, v in sub(g, "grad/").items():
+        if k in named:
+            close(named[k].grad, v, rtol=1e-3, atol=1e-4 * max(np.abs(v).max(), 1e-3))
+
+
+def test_ppmi_conv_native_graph_is_well_formed():
+    g = load_golden("udagcn_forward_ppmi")
+    s, _ = _pair(g)
+    conv = pygda_amd.nn.PPMIConv(12, 8, path_len=10).to(DEV)
+    np.random.seed(0)
+    ei, w = conv.norm(s.edge_index.to(DEV), s.num_nodes)
+    assert ei.shape[0] == 2 and w.shape[0] == ei.shape[1] and bool((w >= 0).all()) and bool(torch.isfinite(w).all())
+    loops = ei[0] == ei[1]
+    assert int(loops.sum()) == s.num_nodes                 # exactly one loop per node after the merge
+    y = conv(s.x.to(DEV), s.edge_index.to(DEV), "k")
+    assert y.shape == (s.num_nodes, 8) and bool(torch.isfinite(y).all())
+    # same support size as the graph the reference built on the same input (on this small dense
+    # graph nearly every PPMI weight is clipped to 0, so weight statistics are left to the
+    # convergence test in tests/test_sampler_host.py)
+    ref_w = g["ppmi/source/0/weight"]
+    assert abs(w.numel() - ref_w.size) < 0.1 * ref_w.size
+
+
+def test_adagcn_forward_model_golden():
+    """Ten critic updates (gradient penalty: double backward through the MLP critic, CPU-drawn
+    interpolation weights) and the encoder loss; critic weights after the ten Adam steps too."""
+    g = load_golden("adagcn_forward")
+    s, t = _pair(g)
+    m = pygda_amd.models.AdaGCN(12, 8, 3, num_layers=2, adv_dim=6, gp_weight=5, domain_weight=1, lr=0.01,
+                                weight_decay=0.01, device=DEV, epoch=2, verbose=0)
+    m.adagcn = m.init_model()
+    m.adagcn.load_state_dict({k: T(v) for k, v in sub(g, "param/").items()})
+    m.discriminator = torch.nn.Sequential(torch.nn.Linear(8, 6), torch.nn.ReLU(), torch.nn.Dropout(0.0),
+                                          torch.nn.Linear(6, 1), torch.nn.Sigmoid()).to(DEV)
+    m.discriminator.load_state_dict({k: T(v) for k, v in sub(g, "disc0/").items()})
+    _no_dropout(m.adagcn)
+    m.c_optimizer = torch.optim.Adam(m.discriminator.parameters(), lr=0.01, weight_decay=0.01)
+    m.adagcn.train()
+    torch.manual_seed(int(g["rand_seed"]))
+    loss, sl, tl = m.forward_model(s.to(DEV), t.to(DEV))
+    m.adagcn.zero_grad()
+    loss.backward()
+    close(loss, g["loss"], rtol=REL)
+    close(sl, g["src_logits"], rtol=0, atol=LOGIT_ATOL); close(tl, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    for k, v in sub(g, "disc10/").items():
+        close(m.discriminator.state_dict()[k], v, rtol=1e-3, atol=1e-5)
+    named = dict(m.adagcn.named_parameters())
+    for k, v in sub(g, "grad/").items():
+        close(named[k].grad, v, rtol=1e-3, atol=1e-4 * max(np.abs(v).max(), 1e-3))
+
+
+@pytest.mark.parametrize("cls", ["UDAGCN", "AdaGCN"])
+def test_udagcn_adagcn_fit_predict_run(cls):
+    g = load_golden("udagcn_forward_gcn")
+    s, t = _pair(g)
+    kw = dict(ppmi=True, adv_dim=6) if cls == "UDAGCN" else dict(adv_dim=6)
+    m = getattr(pygda_amd.models, cls)(12, 8, 3, num_layers=2, device=DEV, epoch=2, verbose=0, **kw)
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append(loss)
+    torch.manual_seed(0); np.random.seed(0)
+    m.fit(s, t)
+    logits, labels = m.predict(t)
+    assert len(seen) == 2 and all(np.isfinite(v) for v in seen)
+    assert logits.shape == (t.num_nodes, 3) and torch.equal(labels.cpu(), t.y)

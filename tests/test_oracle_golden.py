@@ -145,3 +145,51 @@ def test_grade_forward_model(disc):
     eq(loss, g["loss"]); eq(sl, g["src_logits"]); eq(tl, g["tgt_logits"])
     for k, v in sub(g, "grad/").items():
         eq(dict(net.named_parameters())[k].grad, v)
+
+
+@pytest.mark.parametrize("ppmi", [True, False])
+def test_udagcn_forward_model(ppmi):
+    """Includes the PPMI random-walk construction replayed from the np.random seed."""
+    g = load_golden("udagcn_forward_ppmi" if ppmi else "udagcn_forward_gcn")
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    torch.manual_seed(int(g["init_seed"]))
+    net = O.UDAGCNBase(12, 8, 3, num_layers=2, ppmi=ppmi, adv_dim=6, dropout_p=0.0)
+    sd = net.state_dict()
+    for k, v in sub(g, "param/").items():
+        eq(sd[k], v)
+    np.random.seed(int(g["np_seed"]))
+    loss, sl, tl = O.udagcn_forward_model(net, src, tgt, float(g["alpha"]), int(g["epoch"]), int(g["epochs"]))
+    loss.backward()
+    eq(loss, g["loss"]); eq(sl, g["src_logits"]); eq(tl, g["tgt_logits"])
+    if ppmi:
+        for name in ("source", "target"):
+            for li, conv in enumerate(net.ppmi_encoder.conv_layers):
+                ei, w = conv.cache_dict[name]
+                eq(ei, g[f"ppmi/{name}/{li}/edge_index"]); eq(w, g[f"ppmi/{name}/{li}/weight"])
+    named = dict(net.named_parameters())
+    for k, v in sub(g, "grad/").items():
+        if k in named:          # shared parameters are listed once by named_parameters()
+            eq(named[k].grad, v)
+
+
+def test_adagcn_forward_model():
+    g = load_golden("adagcn_forward")
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    net = O.AdaGCNBase(12, 8, 3, num_layers=2, dropout_p=0.0)
+    net.load_state_dict({k: T(v) for k, v in sub(g, "param/").items()})
+    disc = torch.nn.Sequential(torch.nn.Linear(8, 6), torch.nn.ReLU(), torch.nn.Dropout(0.0),
+                               torch.nn.Linear(6, 1), torch.nn.Sigmoid())
+    disc.load_state_dict({k: T(v) for k, v in sub(g, "disc0/").items()})
+    c_opt = torch.optim.Adam(disc.parameters(), lr=0.01, weight_decay=0.01)
+    net.train()
+    torch.manual_seed(int(g["rand_seed"]))
+    loss, sl, tl = O.adagcn_forward_model(net, disc, c_opt, src, tgt, 5, 1)
+    net.zero_grad()
+    loss.backward()
+    eq(loss, g["loss"]); eq(sl, g["src_logits"]); eq(tl, g["tgt_logits"])
+    for k, v in sub(g, "disc10/").items():
+        eq(disc.state_dict()[k], v)
+    for k, v in sub(g, "grad/").items():
+        eq(dict(net.named_parameters())[k].grad, v)

@@ -99,3 +99,48 @@ def test_bad_seed_rejected():
     S = NeighborSampler(rand_graph(10, 20, 4), 10)
     with pytest.raises(Exception):
         S.sample(torch.tensor([11]), [2])
+
+
+def test_native_ppmi_builder_matches_oracle_statistically():
+    """csrc/gda_ppmi.cpp against the oracle's replay of ppmi_conv.py:98-169.  The generators
+    differ, so parity is statistical: with many passes both estimators converge to the same
+    PPMI weights; with the reference's 40 passes the summary statistics agree."""
+    import numpy as np
+    from oracle import pygda_cpu as O
+    from pygda_amd.nn.ppmi_conv import ppmi_edges
+    g = torch.Generator().manual_seed(5)
+    n = 120
+    ei = torch.randint(0, n - 1, (2, 260), generator=g)          # node n-1 isolated
+    ei = ei[:, ei[0] != ei[1]]
+
+    def as_dict(e, w):
+        return {(int(a), int(b)): float(x) for (a, b), x in zip(e.t().tolist(), w.tolist())}
+
+    def agreement(x, y):
+        common = [k for k in x if k in y and (x[k] > 0 or y[k] > 0)]
+        a, b = np.array([x[k] for k in common]), np.array([y[k] for k in common])
+        return np.corrcoef(a, b)[0, 1], len(common), a.mean(), b.mean()
+
+    np.random.seed(0)
+    ref = as_dict(*O.ppmi_raw_edges(ei, path_len=5, passes=600))
+    np.random.seed(7)
+    ref2 = as_dict(*O.ppmi_raw_edges(ei, path_len=5, passes=600))
+    mine = as_dict(*ppmi_edges(ei, n, path_len=5, passes=600, seed=1))
+    ceiling, _, _, _ = agreement(ref, ref2)            # two runs of the reference algorithm itself
+    corr, n_common, ma_, mb_ = agreement(ref, mine)
+    assert n_common > 200 and ceiling > 0.95
+    assert corr > ceiling - 0.02                        # as close to the reference as it is to itself
+    assert abs(ma_ - mb_) < 0.03 * ma_
+    # the reference setting: 40 passes
+    np.random.seed(1)
+    r40 = as_dict(*O.ppmi_raw_edges(ei, path_len=5))
+    m40 = as_dict(*ppmi_edges(ei, n, path_len=5, seed=2))
+    ra, ma = np.array(list(r40.values())), np.array(list(m40.values()))
+    assert abs(len(r40) - len(m40)) < 0.05 * len(r40)                       # same support size
+    assert abs((ra > 0).mean() - (ma > 0).mean()) < 0.05
+    assert abs(ra[ra > 0].mean() - ma[ma > 0].mean()) < 0.08 * ra[ra > 0].mean()
+    assert all(a != n - 1 and b != n - 1 for a, b in m40)                  # isolated node: no walks
+    # reproducible, and governed by np.random.seed when no explicit seed is given
+    np.random.seed(3); e1, w1 = ppmi_edges(ei, n, 5)
+    np.random.seed(3); e2, w2 = ppmi_edges(ei, n, 5)
+    assert torch.equal(e1, e2) and torch.equal(w1, w2)
