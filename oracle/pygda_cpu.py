@@ -587,3 +587,144 @@ def adagcn_forward_model(net: AdaGCNBase, disc: nn.Module, c_opt, src: Graph, tg
     loss = net.loss_func(s_logits, src.y)
     dis = torch.abs(torch.mean(disc(es).reshape(-1)) - torch.mean(disc(et).reshape(-1)))
     return loss + dis * domain_weight, s_logits, net.cls_model(et)
+
+
+# ----------------------------------------------------------------------------
+# GNNBase backbones, GNN and DANE trainers  (a15)
+# ----------------------------------------------------------------------------
+def _sum_aggregate(x: Tensor, edge_index: Tensor) -> Tensor:
+    return torch.zeros_like(x).index_add_(0, edge_index[1], x.index_select(0, edge_index[0]))
+
+
+class SAGEConv(nn.Module):
+    """PyG ``SAGEConv`` defaults as gnn_base.py:73-79 uses it (aggr='mean', root_weight=True):
+    ``lin_l(mean_{j->i} x_j) + lin_r(x_i)``; no self loops; lin_l carries the bias.  No
+    runnable PyG here: restated from the GraphSAGE definition -- parity unpinned."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+
+    def forward(self, x, edge_index, edge_weight=None):
+        cnt = torch.zeros(x.size(0), dtype=x.dtype).index_add_(
+            0, edge_index[1], torch.ones(edge_index.size(1), dtype=x.dtype))
+        mean = _sum_aggregate(x, edge_index) / cnt.clamp(min=1).unsqueeze(1)
+        return self.lin_l(mean) + self.lin_r(x)
+
+
+class GINConv(nn.Module):
+    """PyG ``GINConv(nn, train_eps=True)`` (gnn_base.py:89-95): ``nn((1+eps) x_i + sum_j x_j)``,
+    eps initialised to 0.  Parity unpinned (definition-level restatement)."""
+
+    def __init__(self, net: nn.Module):
+        super().__init__()
+        self.nn = net
+        self.eps = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x, edge_index, edge_weight=None):
+        return self.nn(_sum_aggregate(x, edge_index) + (1 + self.eps) * x)
+
+
+class GATConv(nn.Module):
+    """PyG ``GATConv(heads=1, concat=False)`` (gnn_base.py:81-87): x' = W x; self loops
+    (existing removed, one added per node); e_ij = LeakyReLU_0.2(a_src.x'_j + a_dst.x'_i);
+    alpha = softmax over the incoming edges of i; out_i = sum_j alpha_ij x'_j + bias.
+    Parity unpinned (definition-level restatement)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.lin = _Lin(in_channels, out_channels)
+        self.att_src = nn.Parameter(torch.empty(1, 1, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, 1, out_channels))
+        glorot_(self.att_src); glorot_(self.att_dst)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+
+    def forward(self, x, edge_index, edge_attr=None):
+        n = x.size(0)
+        keep = edge_index[0] != edge_index[1]
+        loops = torch.arange(n)
+        ei = torch.cat([edge_index[:, keep], torch.stack([loops, loops])], dim=1)
+        h = F.linear(x, self.lin.weight)
+        a_s = (h * self.att_src.view(1, -1)).sum(-1)
+        a_d = (h * self.att_dst.view(1, -1)).sum(-1)
+        e = F.leaky_relu(a_s[ei[0]] + a_d[ei[1]], 0.2)
+        m = torch.full((n,), float("-inf")).scatter_reduce(0, ei[1], e, reduce="amax")
+        p = torch.exp(e - m[ei[1]])
+        z = torch.zeros(n).index_add_(0, ei[1], p)
+        alpha = p / z[ei[1]]
+        out = torch.zeros_like(h).index_add_(0, ei[1], alpha.unsqueeze(1) * h[ei[0]])
+        return out + self.bias
+
+
+class GNNBase(nn.Module):
+    """gnn_base.py:11-203 (node mode)."""
+
+    def __init__(self, in_dim, hid_dim, num_classes, num_layers=1, dropout=0.1, act=F.relu, gnn="gcn"):
+        super().__init__()
+        self.dropout, self.act = dropout, act
+        mk = {"gcn": GCNConv, "sage": SAGEConv, "gat": GATConv,
+              "gin": lambda a, b: GINConv(nn.Sequential(nn.Linear(a, b)))}[gnn]
+        dims = [in_dim] + [hid_dim] * num_layers
+        self.convs = nn.ModuleList(mk(dims[i], dims[i + 1]) for i in range(num_layers))
+        self.cls = mk(hid_dim, num_classes)
+
+    def feat_bottleneck(self, x, edge_index, edge_weight=None):                 # :139-171
+        for i, conv in enumerate(self.convs):
+            x = conv(x, edge_index, edge_weight)
+            if i < len(self.convs) - 1:
+                x = F.dropout(self.act(x), p=self.dropout, training=self.training)
+        return x
+
+    def feat_classifier(self, x, edge_index, edge_weight=None):                 # :173-203
+        return self.cls(x, edge_index, edge_weight)
+
+    def forward(self, x, edge_index, edge_weight=None):                          # :97-137
+        x = self.feat_bottleneck(x, edge_index, edge_weight)
+        return F.log_softmax(self.feat_classifier(x, edge_index, edge_weight), dim=1)
+
+
+def dane_l_gcn(embedding, nodes_weight, idx_u, idx_v, k, sample_size):
+    """dane.py:357-389: skip-gram edge loss with degree^0.75 negative sampling.  (The negative
+    indices address POSITIONS of the unique-source list, as the reference does.)"""
+    eu, ev = embedding[idx_u], embedding[idx_v]
+    neg = [embedding[torch.multinomial(nodes_weight, sample_size, replacement=False)] for _ in range(k)]
+    loss = -torch.sum(F.logsigmoid(torch.sum(eu * ev, dim=1)))
+    for i in range(k):
+        loss = loss - torch.sum(F.logsigmoid(torch.sum(eu * neg[i] * (-1), dim=1)))
+    return loss
+
+
+def dane_forward_model(gnn: GNNBase, disc: nn.Module, g_opt, d_opt, src: Graph, tgt: Graph, k: int,
+                       sample_size: int):
+    """dane.py:145-180 + train_d :301-355 + train_g :426-516 (node mode, train_mode='unsup')."""
+    d_loss = 0.0
+    for _ in range(5):
+        gnn.eval()
+        es = gnn.feat_bottleneck(src.x, src.edge_index)
+        et = gnn.feat_bottleneck(tgt.x, tgt.edge_index)
+        i_s = torch.multinomial(torch.ones(es.shape[0]), 8 * sample_size, replacement=True)
+        i_t = torch.multinomial(torch.ones(et.shape[0]), 8 * sample_size, replacement=True)
+        d_opt.zero_grad()
+        loss = (disc(es[i_s]) ** 2).mean() + ((disc(et[i_t]) - 1) ** 2).mean()
+        loss.backward()
+        d_opt.step()
+        d_loss = loss.item()
+    gnn.train()
+    es = gnn.feat_bottleneck(src.x, src.edge_index)
+    out_s = gnn.feat_classifier(es, src.edge_index)
+    et = gnn.feat_bottleneck(tgt.x, tgt.edge_index)
+    i_s = torch.multinomial(torch.ones(es.shape[0]), 8 * sample_size, replacement=True)
+    i_t = torch.multinomial(torch.ones(et.shape[0]), 8 * sample_size, replacement=True)
+    l_adv = (disc(et[i_t]) ** 2).mean() + ((disc(es[i_s]) - 1) ** 2).mean()
+    e_s = torch.multinomial(torch.ones(src.edge_index.shape[1]), sample_size, replacement=False)
+    e_t = torch.multinomial(torch.ones(tgt.edge_index.shape[1]), sample_size, replacement=False)
+    w_s = torch.pow(torch.unique(src.edge_index[0], return_counts=True)[1], 0.75)
+    w_t = torch.pow(torch.unique(tgt.edge_index[0], return_counts=True)[1], 0.75)
+    l_gcn = dane_l_gcn(es, w_s, src.edge_index[0][e_s], src.edge_index[1][e_s], k, sample_size) + \
+        dane_l_gcn(et, w_t, tgt.edge_index[0][e_t], tgt.edge_index[1][e_t], k, sample_size)
+    loss = l_gcn + F.cross_entropy(out_s, src.y) + l_adv * 0.1
+    g_opt.zero_grad()
+    loss.backward()
+    g_opt.step()
+    return d_loss + loss.item(), gnn(src.x, src.edge_index), gnn(tgt.x, tgt.edge_index)

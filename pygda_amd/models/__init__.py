@@ -3,5 +3,7 @@ from .a2gnn import A2GNN
 from .grade import GRADE
 from .udagcn import UDAGCN
 from .adagcn import AdaGCN
+from .gnn import GNN
+from .dane import DANE
 
-__all__ = ["BaseGDA", "A2GNN", "GRADE", "UDAGCN", "AdaGCN"]
+__all__ = ["BaseGDA", "A2GNN", "GRADE", "UDAGCN", "AdaGCN", "GNN", "DANE"]

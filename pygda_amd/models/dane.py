@@ -1,0 +1,153 @@
+"""``DANE`` trainer (pygda/models/dane.py:21-621), node mode: shared GNN encoder trained as an
+LSGAN generator (5 discriminator updates per generator update) with a skip-gram edge loss
+(degree^0.75 negative sampling) and source cross-entropy.
+
+Every random draw is made on the host generator.  The reference draws some of them on
+whatever device the tensors live on (``torch.multinomial`` of device weights, :382), which on
+its CPU path is the CPU generator -- so a seeded run here reproduces the reference's CPU run.
+As in AdaGCN, the encoder outputs are detached inside the discriminator loop: the reference
+back-propagates into the encoder there and discards the result (``g_optimizer.zero_grad()``
+at :511 precedes the only generator step)."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..data import to_undirected
+from ..nn import GNNBase
+from .base import BaseGDA
+
+
+class DANE(BaseGDA):
+    def __init__(self, in_dim, hid_dim, num_classes, num_layers, mode='node', dropout=0., gnn='gcn', k=5,
+                 train_mode='unsup', tgt_rate=0.05, act=F.relu, weight_decay=1e-5, lr=0.001, epoch=200,
+                 device='cuda:0', batch_size=0, num_neigh=-1, verbose=2, **kwargs):
+        super().__init__(in_dim=in_dim, hid_dim=hid_dim, num_classes=num_classes, num_layers=num_layers,
+                         dropout=dropout, act=act, weight_decay=weight_decay, lr=lr, epoch=epoch,
+                         device=device, batch_size=batch_size, num_neigh=num_neigh, verbose=verbose,
+                         **kwargs)
+        assert train_mode in ['semi', 'unsup'], 'unsupport training mode'
+        self.gnn_arc, self.k, self.train_mode, self.tgt_rate, self.mode = gnn, k, train_mode, tgt_rate, mode
+
+    def init_model(self, **kwargs):
+        return GNNBase(in_dim=self.in_dim, hid_dim=self.hid_dim, num_classes=self.num_classes,
+                       num_layers=self.num_layers, dropout=self.dropout, gnn=self.gnn_arc, mode=self.mode,
+                       **kwargs).to(self.device)
+
+    # -- host-side draws (CPU generator), moved to the device as index tensors -----------
+    def _draw(self, n, count, replacement):
+        return torch.multinomial(torch.ones(n), count, replacement=replacement).to(self.device)
+
+    def _lsgan_rows(self, es, et):
+        i_s = self._draw(es.shape[0], 8 * self.sample_size, True)
+        i_t = self._draw(et.shape[0], 8 * self.sample_size, True)
+        return self.domain_discriminator(es[i_s]), self.domain_discriminator(et[i_t])
+
+    def forward_model(self, source_data, target_data):
+        for _ in range(5):
+            discriminator_loss = self.train_d(source_data, target_data)
+        generator_loss = self.train_g(source_data, target_data)
+        source_logits = self.gnn(source_data.x, source_data.edge_index)
+        target_logits = self.gnn(target_data.x, target_data.edge_index)
+        return discriminator_loss + generator_loss, source_logits, target_logits
+
+    def train_d(self, source_data, target_data):                                        # :301-355
+        self.gnn.eval()
+        with torch.no_grad():
+            es = self.gnn.feat_bottleneck(source_data.x, source_data.edge_index)
+            et = self.gnn.feat_bottleneck(target_data.x, target_data.edge_index)
+        pre_s, pre_t = self._lsgan_rows(es, et)
+        self.d_optimizer.zero_grad()
+        loss = (pre_s ** 2).mean() + ((pre_t - 1) ** 2).mean()
+        loss.backward()
+        self.d_optimizer.step()
+        return loss.item()
+
+    def L_GCN(self, embedding, nodes_weight, idx_u, idx_v, k):                          # :357-389
+        eu, ev = embedding[idx_u], embedding[idx_v]
+        neg = [embedding[torch.multinomial(nodes_weight, self.sample_size, replacement=False).to(embedding.device)]
+               for _ in range(k)]
+        loss = -torch.sum(F.logsigmoid(torch.sum(eu * ev, dim=1)))
+        for i in range(k):
+            loss = loss - torch.sum(F.logsigmoid(torch.sum(eu * neg[i] * (-1), dim=1)))
+        return loss
+
+    def L_cluster(self, labelsA, embA, labelsB, embB):                                  # :391-424
+        loss = 0.0
+        for i in range(self.num_classes):
+            a, b = labelsA == i, labelsB == i
+            if bool(a.any()) and bool(b.any()):
+                loss = loss + torch.sum((embA[a].mean(0) - embB[b].mean(0)) ** 2)
+        return loss / self.num_classes
+
+    def _pick_edges(self, data):
+        """sample_size positive edges + the degree^0.75 negative-sampling weights (host draws)."""
+        ei_cpu = data.edge_index.cpu()
+        pick = torch.multinomial(torch.ones(ei_cpu.shape[1]), self.sample_size, replacement=False)
+        w = torch.pow(torch.unique(ei_cpu[0], return_counts=True)[1], 0.75)                 # host: see header
+        return w, ei_cpu[0][pick].to(self.device), ei_cpu[1][pick].to(self.device)
+
+    def train_g(self, source_data, target_data):                                        # :426-516
+        self.gnn.train()
+        es = self.gnn.feat_bottleneck(source_data.x, source_data.edge_index)
+        out_s = self.gnn.feat_classifier(es, source_data.edge_index)
+        et = self.gnn.feat_bottleneck(target_data.x, target_data.edge_index)
+        out_t = self.gnn.feat_classifier(et, target_data.edge_index)
+        pre_s, pre_t = self._lsgan_rows(es, et)
+        l_adv = (pre_t ** 2).mean() + ((pre_s - 1) ** 2).mean()
+        edges_s, edges_t = self._pick_edges(source_data), self._pick_edges(target_data)   # draw order of :480-487
+        l_gcn = self.L_GCN(es, *edges_s, self.k) + self.L_GCN(et, *edges_t, self.k)
+        l_ce = F.cross_entropy(out_s, source_data.y)
+        if self.train_mode == 'semi':
+            n_t = et.shape[0]
+            lab = self._draw(n_t, int(self.tgt_rate * n_t), False)
+            l_ce = l_ce + F.cross_entropy(out_t[lab], target_data.y[lab])
+            loss = l_gcn + l_adv * 0.1 + l_ce + self.L_cluster(source_data.y, es, target_data.y[lab], et[lab])
+        else:
+            loss = l_gcn + l_ce + l_adv * 0.1
+        self.g_optimizer.zero_grad()
+        loss.backward()
+        from .base import _allreduce_grads
+        _allreduce_grads(self.g_optimizer)
+        self.g_optimizer.step()
+        return loss.item()
+
+    def fit(self, source_data, target_data):
+        import time
+        from ..metrics import eval_micro_f1
+        from ..utils import logger
+        if self.mode != 'node':
+            raise NotImplementedError("mode='graph' is out of scope (DESIGN.md)")
+        for d in (source_data, target_data):                                            # :192-196
+            if not d.is_undirected():
+                d.edge_index = to_undirected(d.edge_index, d.num_nodes)
+        self.sample_size = min(source_data.x.shape[0], target_data.x.shape[0])
+        self._node_loaders(source_data, target_data)
+        self.gnn = self.init_model(**self.kwargs)
+        self.domain_discriminator = nn.Sequential(nn.Linear(self.hid_dim, self.hid_dim), nn.ReLU(),
+                                                  nn.Linear(self.hid_dim, 1)).to(self.device)
+        self.g_optimizer = torch.optim.Adam(self.gnn.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        self.d_optimizer = torch.optim.Adam(self.domain_discriminator.parameters(), lr=self.lr,
+                                            weight_decay=self.weight_decay)
+        start = time.time()
+        for epoch in range(self.epoch):
+            epoch_loss, logits, labels = 0, [], []
+            for src, tgt in zip(self.source_loader, self.target_loader):
+                self.gnn.train()
+                src, tgt = src.to(self.device), tgt.to(self.device)
+                loss, source_logits, _ = self.forward_model(src, tgt)
+                epoch_loss += loss
+                logits.append(source_logits.detach()); labels.append(src.y)
+            acc = eval_micro_f1(torch.cat(labels), torch.cat(logits).argmax(dim=1))
+            secs = time.time() - start
+            logger(epoch=epoch, loss=epoch_loss, source_train_acc=acc, time=secs, verbose=self.verbose, train=True)
+            if self.epoch_hook is not None:
+                self.epoch_hook(epoch, epoch_loss, acc, secs)
+
+    def process_graph(self, data):
+        pass
+
+    def predict(self, data, source=False):
+        self.gnn.eval()
+        loader = self.source_loader if source else self.target_loader
+        return self._predict_loader(loader, lambda b: self.gnn(b.x, b.edge_index))

@@ -9,7 +9,9 @@ from .a2gnn_base import A2GNNBase, global_mean_pool
 from .grade_base import GRADEBase
 from .udagcn_base import UDAGCNBase
 from .adagcn_base import AdaGCNBase
+from .sage_gin_conv import SAGEConv, GINConv
+from .gnn_base import GNNBase
 
 __all__ = ["Linear", "glorot", "zeros", "PropGCNConv", "gcn_norm", "GCNConv", "CachedGCNConv", "PPMIConv",
-           "ppmi_edges", "GradReverse", "Attention", "A2GNNBase", "GRADEBase", "UDAGCNBase", "AdaGCNBase",
+           "ppmi_edges", "GradReverse", "Attention", "A2GNNBase", "GRADEBase", "UDAGCNBase", "AdaGCNBase", "SAGEConv", "GINConv", "GNNBase",
            "global_mean_pool"]

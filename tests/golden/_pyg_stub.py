@@ -23,6 +23,7 @@ boundary" (the MMD / GradReverse / Attention goldens do not go through it).
     -> one propagate -> + bias(zeros); its ``__init__`` also calls reset_parameters().
  6. ``NeighborLoader(data, [-1]*L, batch_size=N)``: one batch = the whole graph,
     nodes and edges in input order.
+ 7. ``to_undirected`` = both directions, duplicates merged, sorted by (row, col).
 """
 import inspect
 import math
@@ -66,6 +67,21 @@ def add_remaining_self_loops(edge_index, edge_attr=None, fill_value=None, num_no
         edge_attr = torch.cat([edge_attr[mask], loop_attr], dim=0)
     edge_index = torch.cat([edge_index[:, mask], loop_index], dim=1)
     return edge_index, edge_attr
+
+
+def to_undirected(edge_index, num_nodes=None):
+    """Assumption 7: both directions, duplicates merged, sorted by (row, col) (PyG coalesce)."""
+    n = maybe_num_nodes(edge_index, num_nodes)
+    both = torch.cat([edge_index, edge_index.flip(0)], dim=1)
+    key = torch.unique(both[0] * n + both[1])
+    return torch.stack([key // n, key % n])
+
+
+def is_undirected(edge_index, num_nodes=None):
+    n = maybe_num_nodes(edge_index, num_nodes)
+    a = torch.unique(edge_index[0] * n + edge_index[1])
+    b = torch.unique(edge_index[1] * n + edge_index[0])
+    return a.numel() == b.numel() and bool((a == b).all())
 
 
 def glorot(t):
@@ -231,6 +247,7 @@ def install():
     conv.GCNConv = GCNConv
     utils = _mod('torch_geometric.utils')
     utils.add_remaining_self_loops = add_remaining_self_loops
+    utils.is_undirected, utils.to_undirected = is_undirected, to_undirected
     nn_utils = _mod('torch_geometric.utils.num_nodes')
     nn_utils.maybe_num_nodes = maybe_num_nodes
     loader = _mod('torch_geometric.loader')

@@ -72,6 +72,9 @@ def load_reference(with_pyg_stub=True):
     grb = _load("pygda.nn.grade_base", "pygda/nn/grade_base.py")
     udb = _load("pygda.nn.udagcn_base", "pygda/nn/udagcn_base.py")
     adb = _load("pygda.nn.adagcn_base", "pygda/nn/adagcn_base.py")
+    gnb = _load("pygda.nn.gnn_base", "pygda/nn/gnn_base.py")
+    NN.GNNBase = gnb.GNNBase
+    ns.GNNBase = gnb.GNNBase
     NN.PropGCNConv, NN.CachedGCNConv, NN.PPMIConv = prop.PropGCNConv, cached.CachedGCNConv, ppmi.PPMIConv
     NN.A2GNNBase, NN.GRADEBase, NN.UDAGCNBase, NN.AdaGCNBase = a2b.A2GNNBase, grb.GRADEBase, udb.UDAGCNBase, adb.AdaGCNBase
     base = _load("pygda.models.base", "pygda/models/base.py")
@@ -80,6 +83,9 @@ def load_reference(with_pyg_stub=True):
     gr = _load("pygda.models.grade", "pygda/models/grade.py")
     ud = _load("pygda.models.udagcn", "pygda/models/udagcn.py")
     ad = _load("pygda.models.adagcn", "pygda/models/adagcn.py")
+    gn = _load("pygda.models.gnn", "pygda/models/gnn.py")
+    da = _load("pygda.models.dane", "pygda/models/dane.py")
+    ns.GNN, ns.DANE = gn.GNN, da.DANE
     ns.gcn_norm, ns.PropGCNConv = prop.gcn_norm, prop.PropGCNConv
     ns.CachedGCNConv, ns.PPMIConv = cached.CachedGCNConv, ppmi.PPMIConv
     ns.A2GNNBase, ns.GRADEBase, ns.UDAGCNBase, ns.AdaGCNBase = a2b.A2GNNBase, grb.GRADEBase, udb.UDAGCNBase, adb.AdaGCNBase

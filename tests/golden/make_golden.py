@@ -311,9 +311,58 @@ def fx_adagcn(ref):
     save("adagcn_forward", **arrs)
 
 
+def _connected_pair(seed, ns=80, nt=60, f=12, c=3):
+    """Every node has an edge (DANE's negative sampling needs >= sample_size distinct sources)."""
+    s, t = _domain_pair(seed, ns=ns, nt=nt, f=f, c=c)
+    for d, n in ((s, ns), (t, nt)):
+        ring = torch.stack([torch.arange(n), (torch.arange(n) + 1) % n])
+        d.edge_index = _pyg_stub.to_undirected(torch.cat([d.edge_index, ring], dim=1), n)
+    return s, t
+
+
+def fx_gnn_dane(ref):
+    """GNNBase('gcn') logits, one GNN training step, and DANE.forward_model (5 LSGAN critic
+    steps + generator step with skip-gram negative sampling, all draws on the CPU generator)."""
+    s, t = _connected_pair(121)
+    m = ref.DANE(12, 8, 3, num_layers=2, dropout=0.0, gnn="gcn", k=5, lr=0.01, weight_decay=1e-5,
+                 device="cpu", epoch=2, verbose=0)
+    torch.manual_seed(131)
+    m.gnn = m.init_model()
+    m.domain_discriminator = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))
+    m.sample_size = min(s.x.shape[0], t.x.shape[0])
+    arrs = dict(_pair_arrays(s, t), init_seed=np.int64(131), rand_seed=np.int64(132))
+    arrs.update(sd_arrays(m.gnn, "param0/")); arrs.update(sd_arrays(m.domain_discriminator, "disc0/"))
+    m.gnn.eval()
+    with torch.no_grad():
+        arrs["logp_tgt0"] = np_(m.gnn(t.x, t.edge_index))
+    m.g_optimizer = torch.optim.Adam(m.gnn.parameters(), lr=0.01, weight_decay=1e-5)
+    m.d_optimizer = torch.optim.Adam(m.domain_discriminator.parameters(), lr=0.01, weight_decay=1e-5)
+    torch.manual_seed(132)
+    loss, sl, tl = m.forward_model(s, t)
+    arrs.update(loss=np.float64(loss), src_logits=np_(sl), tgt_logits=np_(tl))
+    arrs.update(sd_arrays(m.gnn, "param1/")); arrs.update(sd_arrays(m.domain_discriminator, "disc1/"))
+    save("dane_forward", **arrs)
+    # plain GNN trainer: two epochs from a seed
+    import pygda.models.gnn as gmod
+    losses = []
+    orig = gmod.logger
+    gmod.logger = lambda **kw: losses.append(kw["loss"])
+    try:
+        g = ref.GNN(12, 8, 3, num_layers=2, dropout=0.0, gnn="gcn", lr=0.05, weight_decay=1e-4, device="cpu",
+                    epoch=2, verbose=0)
+        torch.manual_seed(141)
+        g.fit(s, t)
+        logits, labels = g.predict(t)
+        save("gnn_fit2", **dict(_pair_arrays(s, t), seed=np.int64(141), losses=np.array(losses),
+                                tgt_logits=np_(logits), **sd_arrays(g.gnn, "final/")))
+    finally:
+        gmod.logger = orig
+
+
 FIXTURES = {"mmd": fx_mmd, "grl_attention": fx_grl_attention, "gcn_norm": fx_gcn_norm,
             "prop_gcn_conv": fx_prop_gcn_conv, "cached_gcn_conv": fx_cached_gcn_conv,
-            "a2gnn": fx_a2gnn, "grade": fx_grade, "udagcn": fx_udagcn, "adagcn": fx_adagcn}
+            "a2gnn": fx_a2gnn, "grade": fx_grade, "udagcn": fx_udagcn, "adagcn": fx_adagcn,
+            "gnn_dane": fx_gnn_dane}
 
 
 def main(argv):

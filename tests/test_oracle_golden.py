@@ -10,6 +10,7 @@ from tests.conftest import T, load_golden, sub
 
 def eq(a, b, tol=0.0):
     a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().numpy() if isinstance(b, torch.Tensor) else b
     if tol == 0.0:
         np.testing.assert_array_equal(a, b)
     else:
@@ -193,3 +194,73 @@ def test_adagcn_forward_model():
         eq(disc.state_dict()[k], v)
     for k, v in sub(g, "grad/").items():
         eq(dict(net.named_parameters())[k].grad, v)
+
+
+def test_dane_forward_model_and_gnn_base():
+    g = load_golden("dane_forward")
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    torch.manual_seed(int(g["init_seed"]))
+    net = O.GNNBase(12, 8, 3, num_layers=2, dropout=0.0, gnn="gcn")
+    for k, v in sub(g, "param0/").items():
+        eq(net.state_dict()[k], v)
+    net.eval()
+    with torch.no_grad():
+        eq(net(tgt.x, tgt.edge_index), g["logp_tgt0"])
+    disc = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))
+    disc.load_state_dict({k: T(v) for k, v in sub(g, "disc0/").items()})
+    g_opt = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=1e-5)
+    d_opt = torch.optim.Adam(disc.parameters(), lr=0.01, weight_decay=1e-5)
+    torch.manual_seed(int(g["rand_seed"]))
+    loss, sl, tl = O.dane_forward_model(net, disc, g_opt, d_opt, src, tgt, 5, min(src.x.shape[0], tgt.x.shape[0]))
+    eq(np.float64(loss), g["loss"]); eq(sl, g["src_logits"]); eq(tl, g["tgt_logits"])
+    for k, v in sub(g, "param1/").items():
+        eq(net.state_dict()[k], v)
+    for k, v in sub(g, "disc1/").items():
+        eq(disc.state_dict()[k], v)
+
+
+def test_gnn_fit_trajectory():
+    """gnn.py:151-212: CE on source only, double log_softmax, two epochs from a seed."""
+    g = load_golden("gnn_fit2")
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    torch.manual_seed(int(g["seed"]))
+    net = O.GNNBase(12, 8, 3, num_layers=2, dropout=0.0, gnn="gcn")
+    opt = torch.optim.Adam(net.parameters(), lr=0.05, weight_decay=1e-4)
+    losses = []
+    for _ in range(2):
+        net.train()
+        out = net(src.x, src.edge_index)
+        net(tgt.x, tgt.edge_index)
+        loss = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(out, dim=1), src.y)
+        losses.append(loss.item())
+        opt.zero_grad(); loss.backward(); opt.step()
+    eq(np.array(losses), g["losses"])
+    net.eval()
+    with torch.no_grad():
+        eq(net(tgt.x, tgt.edge_index), g["tgt_logits"])
+
+
+def test_oracle_sage_gin_gat_against_dense_math():
+    """No PyG to run here: the definition-level restatements are checked against dense algebra."""
+    gen = torch.Generator().manual_seed(3)
+    n, f, h = 40, 6, 5
+    ei = torch.randint(0, n, (2, 150), generator=gen)
+    x = torch.randn(n, f, generator=gen)
+    A = torch.zeros(n, n).index_put_((ei[1], ei[0]), torch.ones(ei.size(1)), accumulate=True)   # A[i,j] = #edges j->i
+    sage = O.SAGEConv(f, h)
+    mean = (A @ x) / A.sum(1).clamp(min=1).unsqueeze(1)
+    eq(sage(x, ei), sage.lin_l(mean) + sage.lin_r(x), 1e-5)
+    gin = O.GINConv(torch.nn.Sequential(torch.nn.Linear(f, h)))
+    with torch.no_grad():
+        gin.eps.fill_(0.3)
+    eq(gin(x, ei), gin.nn(A @ x + 1.3 * x), 1e-5)
+    gat = O.GATConv(f, h)
+    hh = x @ gat.lin.weight.t()
+    As = A.clone(); As.fill_diagonal_(0); As = As + torch.eye(n)          # loops replaced by exactly one
+    e = torch.nn.functional.leaky_relu((hh * gat.att_dst.view(1, -1)).sum(-1).unsqueeze(1) +
+                                       (hh * gat.att_src.view(1, -1)).sum(-1).unsqueeze(0), 0.2)
+    w = torch.exp(e - e.max()) * As                                         # multiplicity-weighted softmax
+    alpha = w / w.sum(1, keepdim=True)
+    eq(gat(x, ei), alpha @ hh + gat.bias, 1e-5)
