@@ -200,6 +200,13 @@ int gda_sampler_fetch(const gda_sampler* s, int64_t* nodes_out, int64_t* esrc_ou
  * handle; fetch it into buffers of gda_edge_list_size() entries, then feed it to
  * gda_build_csr_norm(add_self_loops=1, normalize=1, degree_side=1) (ppmi_conv.py:174-184).
  * ---------------------------------------------------------------------------- */
+/* Host helper for the MMD backward: CSR (rowptr [num_rows+1], colidx [times*n], int32) of the
+ * 0/1 selection matrix that sums the per-sample row gradients back onto the sampled feature
+ * rows; idx_host [times, n] are the row samples torch.randint drew on the host
+ * (pygda/utils/mmd.py:148-149); column ids are t*m + offset + r into the [times, m, d] buffer. */
+int gda_selection_csr_host(const int64_t* idx_host, int times, int64_t n, int64_t num_rows,
+                           int64_t offset, int64_t m, int32_t* rowptr_out, int32_t* colidx_out);
+
 typedef struct gda_edge_list gda_edge_list;
 int gda_ppmi_build_host(const int64_t* src_host, const int64_t* dst_host, int64_t E, int64_t N,
                         int path_len, int passes, uint64_t seed, gda_edge_list** out);

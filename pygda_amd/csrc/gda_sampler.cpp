@@ -128,3 +128,28 @@ extern "C" int gda_sampler_fetch(const gda_sampler* s, int64_t* nodes_out, int64
     }
     return GDA_OK;
 }
+
+
+// Host side of the MMD sample-gradient scatter (pygda/utils/mmd.py:148-153 draws the row samples
+// on the host): CSR of the 0/1 selection matrix for idx [times, n] -- rows = feature rows,
+// columns = positions t*m + offset + r of the [times, m, d] sample-gradient buffer, stable in
+// sample order.  A counting sort: O(times*n + num_rows), microseconds.
+extern "C" int gda_selection_csr_host(const int64_t* idx_host, int times, int64_t n, int64_t num_rows,
+                                      int64_t offset, int64_t m, int32_t* rowptr_out,
+                                      int32_t* colidx_out) {
+    if (!idx_host || !rowptr_out || (times * n > 0 && !colidx_out)) return GDA_E_NULL;
+    if (times < 0 || n < 0 || num_rows < 0 || (int64_t)times * m >= INT32_MAX) return GDA_E_SIZE;
+    const int64_t total = (int64_t)times * n;
+    std::memset(rowptr_out, 0, sizeof(int32_t) * (size_t)(num_rows + 1));
+    for (int64_t p = 0; p < total; ++p) {
+        const int64_t r = idx_host[p];
+        if (r < 0 || r >= num_rows) return GDA_E_SIZE;
+        ++rowptr_out[r + 1];
+    }
+    for (int64_t r = 0; r < num_rows; ++r) rowptr_out[r + 1] += rowptr_out[r];
+    std::vector<int32_t> cur(rowptr_out, rowptr_out + num_rows);
+    for (int t = 0; t < times; ++t)
+        for (int64_t r = 0; r < n; ++r)
+            colidx_out[cur[idx_host[t * n + r]]++] = (int32_t)(t * m + offset + r);
+    return GDA_OK;
+}

@@ -61,6 +61,9 @@ class Data:
             hit = Data(**{k: (v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v)
                           for k, v in self.__dict__.items() if not k.startswith("_")})
             self._device_copies[key] = hit
+            if device.type == "cuda" and hit.x is not None:
+                from . import sparse_features          # bag-of-words inputs: CSR once, SpMM projection
+                sparse_features.maybe_register(hit.x)
         return hit
 
     def cpu(self):

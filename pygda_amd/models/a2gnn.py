@@ -23,14 +23,34 @@ class A2GNN(BaseGDA):
         # the reference also runs a second full target forward per step whose logits it returns
         # and never uses (a2gnn.py:211); kept by default so a step does the reference's work
         self.compute_target_logits = True
+        import os
+        self.overlap_streams = os.environ.get("PYGDA_AMD_OVERLAP", "1") == "1"
 
     def init_model(self, **kwargs):
         return A2GNNBase(in_dim=self.in_dim, hid_dim=self.hid_dim, num_classes=self.num_classes,
                          num_layers=self.num_layers, adv=self.adv, dropout=self.dropout, act=self.act,
                          mode=self.mode, **kwargs).to(self.device)
 
+    def _target_logits_async(self, net, target_data):
+        """The reference's second target forward (:211) is not part of the loss.  It is issued on
+        a side HIP stream (fork/join, no autograd tape) so that its ~21 small aggregation
+        launches overlap the loss branch instead of queueing behind it; under hipGraph capture
+        the fork becomes a parallel branch of the graph."""
+        main = torch.cuda.current_stream()
+        side = getattr(self, "_side_stream", None)
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            out = net(target_data, self.t_pnums)
+        out.record_stream(main)
+        return out, side
+
     def forward_model(self, source_data, target_data, alpha):
         net = self.a2gnn
+        pending = None
+        if self.compute_target_logits and source_data.x.is_cuda and self.overlap_streams:
+            pending = self._target_logits_async(net, target_data)
         source_logits = net(source_data, self.s_pnums)                                   # :181
         loss = F.nll_loss(F.log_softmax(source_logits, dim=1), source_data.y)            # :182
         sb = tb = None
@@ -44,7 +64,10 @@ class A2GNN(BaseGDA):
                                                     disc.bias, alpha)
         else:                                                                            # :206-209
             loss = loss + MMD(source_features, target_features) * self.weight
-        if self.compute_target_logits:
+        if pending is not None:
+            target_logits, side = pending
+            torch.cuda.current_stream().wait_stream(side)                                # join
+        elif self.compute_target_logits:
             target_logits = net(target_data, self.t_pnums)                               # :211
         else:
             target_logits = None
@@ -56,7 +79,12 @@ class A2GNN(BaseGDA):
             raise NotImplementedError("mode='graph' is out of scope (DESIGN.md)")
         self._node_loaders(source_data, target_data)
         self.a2gnn = self.init_model(**self.kwargs)
-        optimizer = torch.optim.Adam(self.a2gnn.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        # the MMD branch never reads alpha/epoch: its step can be captured into a hipGraph
+        self._graph_safe_step = not self.adv
+        import os
+        graph = self.use_hip_graph if self.use_hip_graph is not None else os.environ.get("PYGDA_AMD_HIPGRAPH") == "1"
+        optimizer = torch.optim.Adam(self.a2gnn.parameters(), lr=self.lr, weight_decay=self.weight_decay,
+                                     capturable=bool(graph and self._graph_safe_step and self.batch_size == 0))
 
         def step(src, tgt, alpha, epoch):
             loss, source_logits, _ = self.forward_model(src, tgt, alpha)

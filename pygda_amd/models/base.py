@@ -32,6 +32,10 @@ class BaseGDA(ABC):
             raise ValueError('Number of neighbors must be int or list of int')
         self.model = None
         self.epoch_hook = None        # optional callable(epoch, loss, acc, seconds): bench / tests
+        # capture the full-batch training step into a hipGraph (pygda_amd/hipgraph.py);
+        # None = decide from the environment variable PYGDA_AMD_HIPGRAPH (default off)
+        self.use_hip_graph = kwargs.pop("use_hip_graph", None)
+        self.kwargs = kwargs
 
     # -- API of the reference -------------------------------------------------------
     def fit(self, data, **kwargs):
@@ -72,10 +76,16 @@ class BaseGDA(ABC):
         ``(loss, source_logits)``; the optimiser step happens here.  ``epochs`` (default
         ``range(self.epoch)``) lets a harness run the same loop in slices."""
         start = time.time()
+        graphed = self._maybe_graphed_step(optimizer, step_fn, before_step, net)
         for epoch in (range(self.epoch) if epochs is None else epochs):
             epoch_loss, logits, labels = 0.0, [], []
             alpha = alpha_fn(epoch)
-            for src, tgt in zip(self.source_loader, self.target_loader):
+            if graphed is not None:
+                loss, source_logits = graphed()
+                epoch_loss += loss.item()
+                logits.append(source_logits)
+                labels.append(graphed.src.y)
+            for src, tgt in (() if graphed is not None else zip(self.source_loader, self.target_loader)):
                 if before_step is not None:
                     before_step()
                 else:
@@ -96,6 +106,32 @@ class BaseGDA(ABC):
                    verbose=self.verbose, train=True)
             if self.epoch_hook is not None:
                 self.epoch_hook(epoch, epoch_loss, acc, secs)
+
+    def _maybe_graphed_step(self, optimizer, step_fn, before_step, net):
+        """A captured step when asked for and legal: one full-batch pair, single process, and a
+        step whose arithmetic does not depend on per-epoch Python scalars."""
+        import os
+        want = self.use_hip_graph
+        if want is None:
+            want = os.environ.get("PYGDA_AMD_HIPGRAPH", "0") == "1"
+        if not want or not getattr(self, "_graph_safe_step", False):
+            return None
+        if getattr(self, "_graphed", None) is not None and self._graphed_key == id(optimizer):
+            return self._graphed
+        from ..distributed import active
+        if active() or not torch.cuda.is_available():
+            return None
+        if not (getattr(self.source_loader, "full_batch", False) and getattr(self.target_loader, "full_batch", False)):
+            return None
+        if not any(g.get("capturable", False) for g in optimizer.param_groups):
+            return None
+        from ..hipgraph import GraphedStep
+        src = next(iter(self.source_loader)).to(self.device)
+        tgt = next(iter(self.target_loader)).to(self.device)
+        (before_step or net.train)()
+        self._graphed = GraphedStep(lambda s, t: step_fn(s, t, 0.0, 0), optimizer, src, tgt).capture()
+        self._graphed_key = id(optimizer)
+        return self._graphed
 
     def _predict_loader(self, loader, forward):
         """predict() of the reference (a2gnn.py:384-411) keeps only the last batch when the

@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .. import profiler
+from .. import profiler, sparse_features
 
 
 def glorot(t):
@@ -44,6 +44,10 @@ class Linear(nn.Module):
         zeros(self.bias)
 
     def forward(self, x):
+        if self.bias is None and x.dim() == 2 and x.size(1) >= sparse_features.MIN_WIDTH:
+            sf = sparse_features.lookup(x)             # identity lookup: input feature matrices only
+            if sf is not None:
+                return sparse_features.sparse_linear(self.weight, sf)
         if profiler.enabled:
             n = x.numel() // x.size(-1)
             with profiler.region(f"dense_projection[{self.in_channels}x{self.out_channels}]", 1,

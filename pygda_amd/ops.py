@@ -65,7 +65,8 @@ def propagate(x, graph: CSRGraph, K=1, bias=None):
 # ---------------------------------------------------------------------------- MMD --
 class _MMD(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, tgt, src_idx, tgt_idx, times, n, kernel_mul, kernel_num, fix_sigma):
+    def forward(ctx, src, tgt, src_idx, tgt_idx, times, n, kernel_mul, kernel_num, fix_sigma, sel=None):
+        ctx.sel = sel
         src, tgt = _f32c(src, "source_feat"), _f32c(tgt, "target_feat")
         d = src.size(1)
         if tgt.size(1) != d:
@@ -104,11 +105,42 @@ class _MMD(torch.autograd.Function):
                 "gda_mmd_bwd_f32")
         if src_idx is None:                       # rows as given, stacked [times, n, d]
             gs, gt = grad_rows[:, :n].reshape(times * n, d), grad_rows[:, n:].reshape(times * n, d)
+        elif ctx.sel is not None:                 # selection CSRs prepared on the host with the samples
+            s_rp, s_ci, t_rp, t_ci, ones = ctx.sel
+            flat = grad_rows.view(times * m, d)
+            gs = _selection_spmm(s_rp, s_ci, ones, flat, src.size(0))
+            gt = _selection_spmm(t_rp, t_ci, ones, flat, tgt.size(0))
         else:
             gs = _scatter_rows(grad_rows, src_idx, 0, n, src.size(0))
             gt = _scatter_rows(grad_rows, tgt_idx, n, n, tgt.size(0))
         return (gs if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
+
+
+def selection_csr_host(idx, num_feat_rows, offset, m, out=None):
+    """Host side of the sample-gradient scatter (native counting sort, csrc/gda_sampler.cpp):
+    for ``idx [times, n]`` (CPU int64 row samples) the CSR of the 0/1 selection matrix -- rows =
+    feature rows, columns = positions ``t*m + offset + r`` of the ``[times, m, d]`` gradient
+    buffer.  ``out = (rowptr, colidx)`` may name preallocated (pinned) CPU int32 tensors."""
+    idx = idx.contiguous()
+    times, n = idx.shape
+    if out is None:
+        out = (torch.empty(num_feat_rows + 1, dtype=torch.int32), torch.empty(times * n, dtype=torch.int32))
+    L = _lib.lib()
+    _lib.check(L.gda_selection_csr_host(idx.data_ptr(), int(times), int(n), int(num_feat_rows), int(offset),
+                                        int(m), out[0].data_ptr(), out[1].data_ptr()),
+               "gda_selection_csr_host")
+    return out
+
+
+def _selection_spmm(rowptr, colidx, ones, flat, num_feat_rows):
+    d = flat.size(1)
+    out = torch.empty(num_feat_rows, d, dtype=torch.float32, device=flat.device)
+    L = _lib.lib()
+    _lib.check(L.gda_spmm_csr_f32(_lib.ptr(rowptr), _lib.ptr(colidx), _lib.ptr(ones), num_feat_rows, d,
+                                  _lib.ptr(flat), d, _lib.ptr(out), d, None, _lib.stream()),
+               "gda_spmm_csr_f32")
+    return out
 
 
 def _scatter_rows(grad_rows, idx, offset, n, num_feat_rows):
@@ -165,7 +197,7 @@ def mmd_loss_rows(source_rows, target_rows, kernel_mul=2.0, kernel_num=5, fix_si
 
 
 def mmd_loss(source_feat, target_feat, src_idx=None, tgt_idx=None, kernel_mul=2.0, kernel_num=5,
-             fix_sigma=None):
+             fix_sigma=None, sel=None):
     """Sampled multi-kernel MMD (mmd.py:57-159).  ``src_idx/tgt_idx``: ``[times, n]`` int64
     device tensors of row samples, or both ``None`` for get_MMD on the rows as given."""
     if (src_idx is None) != (tgt_idx is None):
@@ -184,7 +216,7 @@ def mmd_loss(source_feat, target_feat, src_idx=None, tgt_idx=None, kernel_mul=2.
         times, n = src_idx.shape
         src_idx, tgt_idx = src_idx.contiguous(), tgt_idx.contiguous()
     return _MMD.apply(source_feat, target_feat, src_idx, tgt_idx, int(times), int(n), kernel_mul,
-                      kernel_num, fix_sigma)
+                      kernel_num, fix_sigma, sel)
 
 
 # ------------------------------------------------- GRL + discriminator + CE (fused) --

@@ -1,0 +1,101 @@
+"""Sparse input features for the layer-0 projection.
+
+The citation feature matrices are 0/1 bag-of-words stored dense (``x [N, 6775]``, ~1 % non
+zero; pygda/datasets/citation.py:156-163).  The reference multiplies them as dense GEMMs --
+75 % of an A2GNN step's FLOPs.  Here a feature matrix that is sparse enough is ingested
+once into CSR (+ the transposed CSR for the weight gradient) by the graph-ingestion kernel,
+and ``x @ W^T`` runs on the aggregation SpMM kernel with ``W^T`` as the gathered operand:
+the same products in index order, the structural zeros skipped (same result up to fp32
+summation order).  Registration happens where feature matrices enter the device
+(``Data.to``); lookups are by tensor identity, so hidden activations never pay a check.
+"""
+import weakref
+
+import torch
+
+from . import _lib, profiler
+from .graph import build_csr
+
+DENSITY_THRESHOLD = 0.10       # above this the dense MFMA GEMM wins
+MIN_WIDTH = 256                # hidden-width inputs are never worth it
+
+_registry = {}                 # data_ptr -> (weakref(tensor), version, shape, SparseFeatures | None)
+
+
+class SparseFeatures:
+    """CSR of X (rows = nodes, cols = feature ids) and of X^T, device resident."""
+
+    def __init__(self, x):
+        n, f = x.shape
+        nz = x.nonzero(as_tuple=False)                     # row-major order: (node, feature)
+        vals = x[nz[:, 0], nz[:, 1]].contiguous()
+        # ingestion kernel: "edge" feature -> node, weight = value; no loops, no normalisation
+        self.graph = build_csr(torch.stack([nz[:, 1], nz[:, 0]]), max(n, f), vals, add_self_loops=False,
+                               normalize=False, validate=False)
+        self.n, self.f, self.nnz = n, f, int(nz.size(0))
+
+
+def maybe_register(x):
+    """Called once per device feature matrix; decides dense vs sparse (one host sync)."""
+    if (not torch.is_tensor(x) or not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32
+            or x.size(1) < MIN_WIDTH or x.requires_grad or not x.is_contiguous()):
+        return None
+    key = x.data_ptr()
+    hit = _registry.get(key)
+    if hit is not None and hit[0]() is x and hit[1] == x._version:
+        return hit[3]
+    density = float(torch.count_nonzero(x)) / max(x.numel(), 1)
+    sf = SparseFeatures(x) if density <= DENSITY_THRESHOLD else None
+    _registry[key] = (weakref.ref(x), x._version, tuple(x.shape), sf)
+    if len(_registry) > 64:
+        for k in [k for k, v in _registry.items() if v[0]() is None]:
+            del _registry[k]
+    return sf
+
+
+def lookup(x):
+    hit = _registry.get(x.data_ptr())
+    if hit is None or hit[0]() is not x or hit[1] != x._version:
+        return None
+    return hit[3]
+
+
+def _spmm(rowptr, colidx, val, n_rows, dense, out_rows):
+    d = dense.size(1)
+    y = torch.empty(out_rows, d, dtype=torch.float32, device=dense.device)
+    L = _lib.lib()
+    _lib.check(L.gda_spmm_csr_f32(_lib.ptr(rowptr), _lib.ptr(colidx), _lib.ptr(val), n_rows, d,
+                                  _lib.ptr(dense), d, _lib.ptr(y), d, None, _lib.stream()),
+               "gda_spmm_csr_f32")
+    return y
+
+
+class _SparseLinear(torch.autograd.Function):
+    """``y = X W^T`` with X in CSR: forward gathers rows of W^T, backward is the transposed
+    SpMM ``gW^T = X^T gy``.  X itself carries no gradient (it is the input data)."""
+
+    @staticmethod
+    def forward(ctx, weight, sf):
+        wt = weight.t().contiguous()                       # [F, h]
+        g = sf.graph
+        with profiler.region(f"sparse_projection[{sf.f}x{weight.size(0)}]", 1,
+                             sf.nnz * 8 + (sf.n + 1) * 4 + 4 * (wt.numel() + sf.n * weight.size(0)),
+                             2 * sf.nnz * weight.size(0)):
+            y = _spmm(g.rowptr, g.colidx, g.val, sf.n, wt, sf.n)
+        ctx.sf = sf
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        sf = ctx.sf
+        g = sf.graph
+        gy = gy.contiguous()
+        with profiler.region(f"sparse_projection_bwd[{sf.f}x{gy.size(1)}]", 1,
+                             sf.nnz * 8 + (sf.f + 1) * 4 + 4 * (gy.numel() + sf.f * gy.size(1)),
+                             2 * sf.nnz * gy.size(1)):
+            gwt = _spmm(g.t_rowptr, g.t_colidx, g.t_val, sf.f, gy, sf.f)   # [F, h]
+        return gwt.t(), None
+
+
+def sparse_linear(weight, sf):
+    return _SparseLinear.apply(weight, sf)

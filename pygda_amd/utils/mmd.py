@@ -4,7 +4,7 @@ the backward pass."""
 import torch
 
 from .. import distributed
-from ..ops import mmd_loss, mmd_loss_rows, sample_rows
+from ..ops import mmd_loss, mmd_loss_rows, sample_rows, selection_csr_host
 
 
 def guassian_kernel(source, target, kernel_mul=2.0, kernel_num=5, fix_sigma=None):
@@ -23,6 +23,12 @@ def guassian_kernel(source, target, kernel_mul=2.0, kernel_num=5, fix_sigma=None
 def get_MMD(source_feat, target_feat, kernel_mul=2.0, kernel_num=5, fix_sigma=None):
     """mean(XX + YY - XY - YX) over the given rows (mmd.py:57-107)."""
     return mmd_loss(source_feat, target_feat, None, None, kernel_mul, kernel_num, fix_sigma)
+
+
+# Optional source of the row samples: a callable (n_src, n_tgt, times, sampling_num) -> two device
+# int64 tensors.  The hipGraph-captured training step installs one that hands out STATIC device
+# buffers which it refills (from the same CPU-generator draws) before every replay.
+sample_provider = None
 
 
 def MMD(source_feat, target_feat, sampling_num=1000, times=5):
@@ -45,7 +51,15 @@ def MMD(source_feat, target_feat, sampling_num=1000, times=5):
         s_rows = s_rows.permute(1, 0, 2, 3).reshape(times, w * per, d)
         t_rows = t_rows.permute(1, 0, 2, 3).reshape(times, w * per, d)
         return mmd_loss_rows(s_rows, t_rows)
+    if sample_provider is not None:
+        s_idx, t_idx, sel = sample_provider(source_feat.size(0), target_feat.size(0), times, sampling_num)
+        return mmd_loss(source_feat, target_feat, s_idx, t_idx, sel=sel)
     source_sample = torch.randint(source_feat.size(0), (times, sampling_num))
     target_sample = torch.randint(target_feat.size(0), (times, sampling_num))
+    m = 2 * sampling_num
+    sel = [t.to(dev, non_blocking=True) for t in
+           (*selection_csr_host(source_sample, source_feat.size(0), 0, m),
+            *selection_csr_host(target_sample, target_feat.size(0), sampling_num, m))]
+    sel.append(torch.ones(times * sampling_num, dtype=torch.float32, device=dev))
     return mmd_loss(source_feat, target_feat, source_sample.to(dev, non_blocking=True),
-                    target_sample.to(dev, non_blocking=True))
+                    target_sample.to(dev, non_blocking=True), sel=tuple(sel))

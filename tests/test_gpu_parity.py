@@ -547,3 +547,51 @@ def test_sage_gin_vs_oracle(kind):
         close(p.grad, q.grad, rtol=1e-3, atol=1e-4 * max(float(q.grad.abs().max()), 1e-3))
     with pytest.raises(NotImplementedError):
         pygda_amd.nn.GNNBase(f, h, 4, gnn="gat")
+
+
+# ------------------------------------------------------- sparse layer-0 projection --
+def test_sparse_input_projection_matches_dense():
+    """A bag-of-words feature matrix registered by Data.to() goes through the CSR projection;
+    forward and weight gradient equal the dense GEMM up to summation order."""
+    from pygda_amd import sparse_features
+    gen = torch.Generator().manual_seed(4)
+    n, f, h = 700, 1200, 128
+    x = (torch.rand(n, f, generator=gen) < 0.02).float() * torch.randn(n, f, generator=gen)
+    d = Data(x=x, edge_index=torch.randint(0, n, (2, 3000), generator=gen), y=torch.zeros(n, dtype=torch.long))
+    dd = d.to(DEV)
+    sf = sparse_features.lookup(dd.x)
+    assert sf is not None and sf.nnz == int((x != 0).sum())
+    torch.manual_seed(0)
+    lin = pygda_amd.nn.Linear(f, h, bias=False, weight_initializer="glorot").to(DEV)
+    y = lin(dd.x)                                        # sparse path (identity lookup)
+    y_dense = F.linear(dd.x.clone(), lin.weight)         # a clone is not registered -> dense GEMM
+    close(y, y_dense, rtol=1e-5, atol=1e-5)
+    gy = torch.randn(n, h, generator=gen).to(DEV)
+    (gw,) = torch.autograd.grad((y * gy).sum(), lin.weight)
+    (gw_dense,) = torch.autograd.grad((F.linear(dd.x.clone(), lin.weight) * gy).sum(), lin.weight)
+    close(gw, gw_dense, rtol=1e-4, atol=1e-5)
+    # dense features stay on the GEMM path
+    dense = Data(x=torch.randn(300, 400, generator=gen), edge_index=d.edge_index[:, :10] % 300).to(DEV)
+    assert sparse_features.lookup(dense.x) is None
+
+
+# ---------------------------------------------------------------- hipGraph capture --
+def test_hipgraph_step_matches_eager_trajectory():
+    """The captured step (forward + backward + Adam in one hipGraph) replays the same training
+    trajectory as eager mode and as the reference: per-epoch losses and final logits against
+    the 3-epoch golden, warm-up steps rolled back."""
+    g = load_golden("a2gnn_fit3_mmd")
+    s, t = _pair(g)
+    m = pygda_amd.models.A2GNN(24, 16, 5, num_layers=2, dropout=0.0, s_pnums=0, t_pnums=10, adv=False,
+                               weight=10, lr=0.01, weight_decay=0.005, device=DEV, epoch=3, verbose=0,
+                               use_hip_graph=True)
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+    torch.manual_seed(int(g["seed"]))
+    m.fit(s, t)
+    assert getattr(m, "_graphed", None) is not None, "step was not captured"
+    close([x[0] for x in seen], g["losses"], rtol=REL)
+    close([x[1] for x in seen], g["accs"], rtol=0, atol=1e-12)
+    logits, _ = m.predict(t)
+    close(logits, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    exact(logits.argmax(1), g["tgt_logits"].argmax(1))
