@@ -92,6 +92,34 @@ int gda_csr_to_coo(const int32_t* rowptr, const int32_t* colidx, int64_t N, int6
  * when K>1); x is left intact.  The backward of K steps is the same call on the
  * by-source CSR with the incoming gradient.
  * ---------------------------------------------------------------------------- */
+/* Optional load balancing for power-law graphs: rows with more than `threshold` entries are
+ * processed as chunks of `threshold` entries (partials in `scratch [n_chunks, d]`, then an
+ * ordered per-row reduce).  Built once per graph by gda_row_split_build; all pointers device. */
+typedef struct gda_row_split {
+    int32_t threshold;
+    int32_t n_long, n_chunks;
+    const int32_t* long_rows;       /* [n_long]     */
+    const int32_t* long_chunk_ptr;  /* [n_long + 1] */
+    const int32_t* chunk_long;      /* [n_chunks]   */
+    float* scratch;                 /* [n_chunks, d] caller-owned, reused across calls */
+} gda_row_split;
+
+/* Find the long rows of a CSR and lay out their chunks.  Outputs must hold the upper bounds
+ * cap_long = nnz_cap/threshold + 1 and cap_chunks = 2*nnz_cap/threshold + 2 entries;
+ * counts_out [2] (device) receives {n_long, n_chunks}: the one data-dependent pair the host
+ * reads back, once per graph. */
+size_t gda_row_split_workspace_bytes(int64_t n_rows);
+int gda_row_split_build(const int32_t* rowptr, int64_t n_rows, int32_t threshold,
+                        int32_t* long_rows, int32_t* long_chunk_ptr, int32_t* chunk_long,
+                        int32_t* counts_out, void* workspace, size_t workspace_bytes,
+                        gda_stream_t stream);
+
+/* K-step aggregation with optional row splitting (split may be NULL). */
+int gda_spmm_csr_split_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                           int64_t n_rows, int64_t d, int K, const float* x, int64_t ldx,
+                           float* y, int64_t ldy, float* tmp, const float* bias,
+                           const gda_row_split* split, gda_stream_t stream);
+
 int gda_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
                      int64_t n_rows, int64_t d, const float* x, int64_t ldx,
                      float* y, int64_t ldy, const float* bias, gda_stream_t stream);

@@ -24,6 +24,10 @@ _SIGNATURES = {
     "gda_spmm_csr_f32": (c_int, [_P, _P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P]),
     "gda_spmm_csr_kstep_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P, c_int64,
                                        _P, _P, _P]),
+    "gda_row_split_workspace_bytes": (c_size_t, [c_int64]),
+    "gda_row_split_build": (c_int, [_P, c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gda_spmm_csr_split_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P, c_int64,
+                                       _P, _P, _P, _P]),
     "gda_mmd_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64]),
     "gda_mmd_fwd_f32": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, _P, c_int, c_int64, c_float,
                                 c_int, c_float, _P, _P, _P, _P, c_size_t, _P]),
@@ -48,6 +52,13 @@ _SIGNATURES = {
     "gda_edge_list_destroy": (None, [_P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+class RowSplitStruct(ctypes.Structure):
+    """``gda_row_split`` of include/gda_hip.h."""
+    _fields_ = [("threshold", ctypes.c_int32), ("n_long", ctypes.c_int32), ("n_chunks", ctypes.c_int32),
+                ("long_rows", c_void_p), ("long_chunk_ptr", c_void_p), ("chunk_long", c_void_p),
+                ("scratch", c_void_p)]
+
 
 _lib = None
 

@@ -184,6 +184,60 @@ __global__ void k_csr_to_coo(const int32_t* __restrict__ rowptr, const int32_t* 
     dst_out[k] = row_of(rowptr, N, (int32_t)k);
 }
 
+// ---- long-row discovery for the load-balanced SpMM (gda_row_split_build) ----
+__global__ void k_split_count(const int32_t* __restrict__ rowptr, int64_t n_rows, int32_t T,
+                              int32_t* __restrict__ is_long, int32_t* __restrict__ nchunks) {
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n_rows) return;
+    const int32_t deg = rowptr[i + 1] - rowptr[i];
+    const bool lg = deg > T;
+    is_long[i] = lg ? 1 : 0;
+    nchunks[i] = lg ? (deg + T - 1) / T : 0;
+}
+
+__global__ void k_split_emit(const int32_t* __restrict__ is_long, const int32_t* __restrict__ nchunks,
+                             const int32_t* __restrict__ long_off, const int32_t* __restrict__ chunk_off,
+                             int64_t n_rows, int32_t* __restrict__ long_rows,
+                             int32_t* __restrict__ long_chunk_ptr, int32_t* __restrict__ chunk_long,
+                             int32_t* __restrict__ counts_out) {
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n_rows) return;
+    if (i == n_rows - 1) {
+        const int32_t nl = long_off[i] + is_long[i], nc = chunk_off[i] + nchunks[i];
+        counts_out[0] = nl;
+        counts_out[1] = nc;
+        long_chunk_ptr[nl] = nc;
+    }
+    if (!is_long[i]) return;
+    const int32_t li = long_off[i], c0 = chunk_off[i];
+    long_rows[li] = (int32_t)i;
+    long_chunk_ptr[li] = c0;
+    for (int32_t c = 0; c < nchunks[i]; ++c) chunk_long[c0 + c] = li;
+}
+
+struct SplitWs { int32_t* is_long; int32_t* nchunks; int32_t* long_off; int32_t* chunk_off; void* cub; size_t cub_bytes; size_t total; };
+
+SplitWs carve_split(void* base, int64_t n_rows) {
+    SplitWs w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void* p = base ? (void*)((char*)base + off) : nullptr;
+        off += gda_align_up(bytes, 256);
+        return p;
+    };
+    w.is_long = (int32_t*)take(sizeof(int32_t) * (n_rows + 1));
+    w.nchunks = (int32_t*)take(sizeof(int32_t) * (n_rows + 1));
+    w.long_off = (int32_t*)take(sizeof(int32_t) * (n_rows + 1));
+    w.chunk_off = (int32_t*)take(sizeof(int32_t) * (n_rows + 1));
+    size_t cb = 0;
+    int32_t* p = nullptr;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, cb, p, p, (int)(n_rows > 0 ? n_rows : 1));
+    w.cub_bytes = cb;
+    w.cub = take(cb);
+    w.total = off;
+    return w;
+}
+
 int bits_for(int64_t n) {
     int b = 1;
     while (((int64_t)1 << b) <= n) ++b;
@@ -262,6 +316,38 @@ extern "C" int gda_csr_to_coo(const int32_t* rowptr, const int32_t* colidx, int6
     if (nnz_cap == 0) return GDA_OK;
     k_csr_to_coo<<<(unsigned)gda_cdiv(nnz_cap, TB), TB, 0, (hipStream_t)stream_>>>(
         rowptr, colidx, N, src_out, dst_out);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+extern "C" size_t gda_row_split_workspace_bytes(int64_t n_rows) {
+    if (n_rows < 0) return 0;
+    return carve_split(nullptr, n_rows).total;
+}
+
+extern "C" int gda_row_split_build(const int32_t* rowptr, int64_t n_rows, int32_t threshold,
+                                   int32_t* long_rows, int32_t* long_chunk_ptr, int32_t* chunk_long,
+                                   int32_t* counts_out, void* workspace, size_t workspace_bytes,
+                                   gda_stream_t stream_) {
+    if (n_rows < 0 || n_rows >= INT32_MAX || threshold < 1) return GDA_E_SIZE;
+    if (!rowptr || !long_rows || !long_chunk_ptr || !chunk_long || !counts_out || !workspace) return GDA_E_NULL;
+    SplitWs ws = carve_split(workspace, n_rows);
+    if (workspace_bytes < ws.total) return GDA_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rows == 0) {
+        GDA_HIP_TRY(hipMemsetAsync(counts_out, 0, 2 * sizeof(int32_t), stream));
+        GDA_HIP_TRY(hipMemsetAsync(long_chunk_ptr, 0, sizeof(int32_t), stream));
+        return GDA_OK;
+    }
+    const unsigned g = (unsigned)gda_cdiv(n_rows, TB);
+    k_split_count<<<g, TB, 0, stream>>>(rowptr, n_rows, threshold, ws.is_long, ws.nchunks);
+    GDA_LAUNCH_CHECK();
+    size_t cb = ws.cub_bytes;
+    GDA_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws.cub, cb, ws.is_long, ws.long_off, (int)n_rows, stream));
+    cb = ws.cub_bytes;
+    GDA_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws.cub, cb, ws.nchunks, ws.chunk_off, (int)n_rows, stream));
+    k_split_emit<<<g, TB, 0, stream>>>(ws.is_long, ws.nchunks, ws.long_off, ws.chunk_off, n_rows, long_rows,
+                                       long_chunk_ptr, chunk_long, counts_out);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }

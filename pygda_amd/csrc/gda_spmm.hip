@@ -49,19 +49,55 @@ __device__ __forceinline__ void vstore(float* __restrict__ p, const float (&r)[V
 // G lanes per row, VEC columns per lane.  Columns beyond G*VEC are covered by an outer
 // chunk loop (re-walking the neighbour list), so any d works with any (G, VEC) whose
 // alignment holds.
+// Long rows (power-law hubs).  A row with more than `threshold` entries is cut into chunks of
+// `threshold` entries; each chunk is a unit of work like a row (same lane-group code path) whose
+// partial sum goes to scratch[chunk][d]; k_long_reduce then adds a row's chunks in order.  The
+// row blocks and the chunk blocks share ONE launch (blockIdx ranges), so a graph without long
+// rows pays nothing and a hub no longer serialises 10^5 gathers on one lane group.  Fixed
+// chunking + ordered reduce: deterministic; only split rows lose the bit-for-bit CPU order.
+struct RowSplit {
+    int32_t threshold;              // 0: no splitting
+    int32_t n_long, n_chunks;
+    const int32_t* long_rows;       // [n_long]     row id of each long row
+    const int32_t* long_chunk_ptr;  // [n_long + 1] chunk range of each long row
+    const int32_t* chunk_long;      // [n_chunks]   index into long_rows
+    float* scratch;                 // [n_chunks, d]
+};
+
 template <int G, int VEC>
 __global__ void __launch_bounds__(TB)
 k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
        const float* __restrict__ val, int64_t n_rows, int d,
        const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
-       const float* __restrict__ bias) {
+       const float* __restrict__ bias, RowSplit sp, unsigned row_blocks) {
     constexpr int ROWS_PER_BLOCK = TB / G;
     const int lane_in_group = threadIdx.x % G;
-    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + threadIdx.x / G;
-    const bool live = row < n_rows;
-    // keep whole groups together for the shuffles; dead groups just run empty loops
-    const int32_t start = live ? rowptr[row] : 0;
-    const int32_t end = live ? rowptr[row + 1] : 0;
+    const bool chunk_mode = blockIdx.x >= row_blocks;       // block-uniform
+    int64_t row;                                             // output row (or chunk id in chunk mode)
+    bool live;
+    int32_t start = 0, end = 0;
+    if (!chunk_mode) {
+        row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + threadIdx.x / G;
+        live = row < n_rows;
+        // keep whole groups together for the shuffles; dead groups just run empty loops
+        if (live) {
+            start = rowptr[row];
+            end = rowptr[row + 1];
+            if (sp.threshold > 0 && end - start > sp.threshold) { live = false; end = start; }   // done by chunks
+        }
+    } else {
+        row = (int64_t)(blockIdx.x - row_blocks) * ROWS_PER_BLOCK + threadIdx.x / G;
+        live = row < sp.n_chunks;
+        if (live) {
+            const int32_t li = sp.chunk_long[row];
+            const int32_t r = sp.long_rows[li];
+            start = rowptr[r] + (int32_t)(row - sp.long_chunk_ptr[li]) * sp.threshold;
+            end = min(start + sp.threshold, rowptr[r + 1]);
+        }
+        y = sp.scratch;                                      // partial sums, no bias
+        ldy = d;
+        bias = nullptr;
+    }
 
     for (int c0 = 0; c0 < d; c0 += G * VEC) {
         const int c = c0 + lane_in_group * VEC;
@@ -113,26 +149,51 @@ k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
     }
 }
 
+// y[long_row] = sum over its chunks, in chunk order (+ bias)
+__global__ void __launch_bounds__(TB)
+k_long_reduce(RowSplit sp, int d, float* __restrict__ y, int64_t ldy, const float* __restrict__ bias) {
+    const int64_t total = (int64_t)sp.n_long * d;
+    for (int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x; k < total; k += (int64_t)gridDim.x * TB) {
+        const int32_t li = (int32_t)(k / d);
+        const int c = (int)(k % d);
+        float acc = 0.f;
+        for (int32_t q = sp.long_chunk_ptr[li]; q < sp.long_chunk_ptr[li + 1]; ++q)
+            acc = __fadd_rn(acc, sp.scratch[(int64_t)q * d + c]);
+        if (bias) acc = __fadd_rn(acc, bias[c]);
+        y[(int64_t)sp.long_rows[li] * ldy + c] = acc;
+    }
+}
+
 template <int G, int VEC>
 int launch(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n_rows, int d,
-           const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias, hipStream_t s) {
+           const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias, const RowSplit& sp,
+           hipStream_t s) {
     constexpr int ROWS_PER_BLOCK = TB / G;
-    const int64_t grid = gda_cdiv(n_rows, ROWS_PER_BLOCK);
-    if (grid > INT32_MAX) return GDA_E_SIZE;
-    k_spmm<G, VEC><<<(unsigned)grid, TB, 0, s>>>(rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, bias);
+    const int64_t row_blocks = gda_cdiv(n_rows, ROWS_PER_BLOCK);
+    const int64_t chunk_blocks = sp.n_chunks > 0 ? gda_cdiv(sp.n_chunks, ROWS_PER_BLOCK) : 0;
+    if (row_blocks + chunk_blocks > INT32_MAX) return GDA_E_SIZE;
+    k_spmm<G, VEC><<<(unsigned)(row_blocks + chunk_blocks), TB, 0, s>>>(
+        rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, bias, sp, (unsigned)row_blocks);
     GDA_LAUNCH_CHECK();
+    if (sp.n_long > 0) {
+        int64_t g = gda_cdiv((int64_t)sp.n_long * d, TB);
+        if (g > 2048) g = 2048;
+        k_long_reduce<<<(unsigned)g, TB, 0, s>>>(sp, d, y, ldy, bias);
+        GDA_LAUNCH_CHECK();
+    }
     return GDA_OK;
 }
 
 int dispatch(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n_rows, int64_t d,
-             const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias, hipStream_t s) {
+             const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias, const RowSplit& sp,
+             hipStream_t s) {
     // vector width: widest that keeps every row start and column offset aligned
     const bool a16 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
                      ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
     const bool a8 = (d % 2 == 0) && (ldx % 2 == 0) && (ldy % 2 == 0) &&
                     ((uintptr_t)x % 8 == 0) && ((uintptr_t)y % 8 == 0);
     const int di = (int)d;
-#define GO(G, V) return launch<G, V>(rowptr, colidx, val, n_rows, di, x, ldx, y, ldy, bias, s)
+#define GO(G, V) return launch<G, V>(rowptr, colidx, val, n_rows, di, x, ldx, y, ldy, bias, sp, s)
     if (a16) {
         const int64_t lanes = d / 4;
         if (lanes >= 64) GO(64, 4);
@@ -167,31 +228,56 @@ int check(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_
     return GDA_OK;
 }
 
+RowSplit make_split(const gda_row_split* h) {
+    RowSplit sp{};
+    if (h && h->threshold > 0 && h->n_long > 0) {
+        sp.threshold = h->threshold; sp.n_long = h->n_long; sp.n_chunks = h->n_chunks;
+        sp.long_rows = h->long_rows; sp.long_chunk_ptr = h->long_chunk_ptr; sp.chunk_long = h->chunk_long;
+        sp.scratch = h->scratch;
+    }
+    return sp;
+}
+
+int check_split(const gda_row_split* h) {
+    if (!h || h->n_long <= 0) return GDA_OK;
+    if (h->threshold <= 0 || h->n_chunks < h->n_long) return GDA_E_SIZE;
+    if (!h->long_rows || !h->long_chunk_ptr || !h->chunk_long || !h->scratch) return GDA_E_NULL;
+    return GDA_OK;
+}
+
 }  // namespace
 
 extern "C" int gda_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
                                 int64_t n_rows, int64_t d, const float* x, int64_t ldx,
                                 float* y, int64_t ldy, const float* bias, gda_stream_t stream) {
-    const int st = check(rowptr, colidx, val, n_rows, d, x, ldx, y, ldy);
-    if (st != GDA_OK || n_rows == 0 || d == 0) return st;
-    return dispatch(rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, bias, (hipStream_t)stream);
+    return gda_spmm_csr_split_f32(rowptr, colidx, val, n_rows, d, 1, x, ldx, y, ldy, nullptr, bias, nullptr,
+                                  stream);
 }
 
 extern "C" int gda_spmm_csr_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
                                       int64_t n_rows, int64_t d, int K, const float* x, int64_t ldx,
                                       float* y, int64_t ldy, float* tmp, const float* bias,
                                       gda_stream_t stream) {
+    return gda_spmm_csr_split_f32(rowptr, colidx, val, n_rows, d, K, x, ldx, y, ldy, tmp, bias, nullptr, stream);
+}
+
+extern "C" int gda_spmm_csr_split_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                                      int64_t n_rows, int64_t d, int K, const float* x, int64_t ldx,
+                                      float* y, int64_t ldy, float* tmp, const float* bias,
+                                      const gda_row_split* split, gda_stream_t stream) {
     if (K < 1) return GDA_E_SIZE;
-    const int st = check(rowptr, colidx, val, n_rows, d, x, ldx, y, ldy);
+    int st = check(rowptr, colidx, val, n_rows, d, x, ldx, y, ldy);
     if (st != GDA_OK || n_rows == 0 || d == 0) return st;
+    if ((st = check_split(split)) != GDA_OK) return st;
     if (K > 1 && !tmp) return GDA_E_NULL;
     if (K > 1 && (tmp == y || (const float*)tmp == x)) return GDA_E_ALIAS;
+    const RowSplit sp = make_split(split);
     const float* in = x;
     int64_t ld_in = ldx;
     for (int j = 1; j <= K; ++j) {                   // step j writes y when K-j is even
         float* out = ((K - j) % 2 == 0) ? y : tmp;
         const int r = dispatch(rowptr, colidx, val, n_rows, d, in, ld_in, out, ldy,
-                               j == K ? bias : nullptr, (hipStream_t)stream);
+                               j == K ? bias : nullptr, sp, (hipStream_t)stream);
         if (r != GDA_OK) return r;
         in = out;
         ld_in = ldy;

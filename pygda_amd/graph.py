@@ -15,12 +15,53 @@ import torch
 from . import _lib
 
 
+import os
+
+# rows with more entries than this are cut into chunks (power-law hubs)
+SPLIT_THRESHOLD = int(os.environ.get("PYGDA_AMD_SPLIT_THRESHOLD", "128"))
+
+
+class RowSplit:
+    """Long-row chunk layout of one CSR (see ``gda_row_split`` in include/gda_hip.h)."""
+
+    def __init__(self, rowptr, num_rows, nnz_cap, threshold=SPLIT_THRESHOLD):
+        dev = rowptr.device
+        cap_long = nnz_cap // threshold + 1
+        cap_chunks = 2 * (nnz_cap // threshold) + 2
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.long_rows = torch.empty(cap_long, **i32)
+        self.long_chunk_ptr = torch.empty(cap_long + 1, **i32)
+        self.chunk_long = torch.empty(cap_chunks, **i32)
+        counts = torch.zeros(2, **i32)
+        L = _lib.lib()
+        ws = _lib.workspace(L.gda_row_split_workspace_bytes(num_rows), dev, "split")
+        _lib.check(L.gda_row_split_build(_lib.ptr(rowptr), num_rows, threshold, _lib.ptr(self.long_rows),
+                                         _lib.ptr(self.long_chunk_ptr), _lib.ptr(self.chunk_long),
+                                         _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream()),
+                   "gda_row_split_build")
+        self.threshold = threshold
+        self.n_long, self.n_chunks = (int(v) for v in counts.tolist())       # one sync per graph
+        self._scratch = {}                 # per stream: concurrent streams must not share partials
+
+    def struct(self, d):
+        """The C struct for a width-``d`` call (scratch grown on demand), or None without hubs."""
+        if self.n_long == 0:
+            return None
+        need = self.n_chunks * d
+        key = torch.cuda.current_stream().cuda_stream
+        buf = self._scratch.get(key)
+        if buf is None or buf.numel() < need:
+            buf = self._scratch[key] = torch.empty(need, dtype=torch.float32, device=self.long_rows.device)
+        return _lib.RowSplitStruct(self.threshold, self.n_long, self.n_chunks, self.long_rows.data_ptr(),
+                                   self.long_chunk_ptr.data_ptr(), self.chunk_long.data_ptr(), buf.data_ptr())
+
+
 class CSRGraph:
     """``rowptr/colidx/val``: rows = destination nodes (forward aggregation);
     ``t_rowptr/t_colidx/t_val``: rows = source nodes (the transpose, backward)."""
 
     __slots__ = ("num_nodes", "nnz_cap", "rowptr", "colidx", "val", "t_rowptr", "t_colidx",
-                 "t_val", "_nnz", "device")
+                 "t_val", "_nnz", "device", "_split", "_t_split")
 
     def __init__(self, num_nodes, nnz_cap, rowptr, colidx, val, t_rowptr, t_colidx, t_val):
         self.num_nodes, self.nnz_cap = num_nodes, nnz_cap
@@ -28,6 +69,17 @@ class CSRGraph:
         self.t_rowptr, self.t_colidx, self.t_val = t_rowptr, t_colidx, t_val
         self._nnz = None
         self.device = rowptr.device
+        self._split = self._t_split = None
+
+    def split(self, transposed=False):
+        """Long-row layout of the forward (or transposed) CSR, built on first use."""
+        if transposed:
+            if self._t_split is None:
+                self._t_split = RowSplit(self.t_rowptr, self.num_nodes, self.nnz_cap)
+            return self._t_split
+        if self._split is None:
+            self._split = RowSplit(self.rowptr, self.num_nodes, self.nnz_cap)
+        return self._split
 
     @property
     def nnz(self):
@@ -37,8 +89,10 @@ class CSRGraph:
         return self._nnz
 
     def transposed(self):
-        return CSRGraph(self.num_nodes, self.nnz_cap, self.t_rowptr, self.t_colidx, self.t_val,
-                        self.rowptr, self.colidx, self.val)
+        g = CSRGraph(self.num_nodes, self.nnz_cap, self.t_rowptr, self.t_colidx, self.t_val,
+                     self.rowptr, self.colidx, self.val)
+        g._split, g._t_split = self._t_split, self._split
+        return g
 
     def to_coo(self):
         """(edge_index [2, nnz], weight [nnz]) in CSR order -- what gcn_norm returns."""

@@ -1,5 +1,7 @@
 """torch.autograd wrappers over the C ABI (include/gda_hip.h).  PyTorch supplies device
 memory, the stream and autograd plumbing; every numeric kernel named here is ours."""
+import ctypes
+
 import torch
 
 from . import _lib, profiler
@@ -31,10 +33,12 @@ def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
         ctx = profiler.region(f"spmm_csr_f32[d={d}]", K, nbytes, K * 2 * graph.nnz * d)
     else:
         ctx = profiler.region("", 0)
+    sp = graph.split(transposed).struct(d)         # None unless the graph has hub rows (> SPLIT_THRESHOLD entries)
     with ctx:
-        _lib.check(L.gda_spmm_csr_kstep_f32(_lib.ptr(rp), _lib.ptr(ci), _lib.ptr(va), n, d, int(K),
+        _lib.check(L.gda_spmm_csr_split_f32(_lib.ptr(rp), _lib.ptr(ci), _lib.ptr(va), n, d, int(K),
                                             _lib.ptr(x), d, _lib.ptr(y), d, _lib.ptr(tmp), _lib.ptr(b),
-                                            _lib.stream()), "gda_spmm_csr_kstep_f32")
+                                            ctypes.byref(sp) if sp is not None else None,
+                                            _lib.stream()), "gda_spmm_csr_split_f32")
     return y
 
 

@@ -60,13 +60,16 @@ def lookup(x):
     return hit[3]
 
 
-def _spmm(rowptr, colidx, val, n_rows, dense, out_rows):
+def _spmm(rowptr, colidx, val, n_rows, dense, out_rows, split):
+    import ctypes
     d = dense.size(1)
     y = torch.empty(out_rows, d, dtype=torch.float32, device=dense.device)
+    sp = split.struct(d)                       # frequent words are hub rows of X^T
     L = _lib.lib()
-    _lib.check(L.gda_spmm_csr_f32(_lib.ptr(rowptr), _lib.ptr(colidx), _lib.ptr(val), n_rows, d,
-                                  _lib.ptr(dense), d, _lib.ptr(y), d, None, _lib.stream()),
-               "gda_spmm_csr_f32")
+    _lib.check(L.gda_spmm_csr_split_f32(_lib.ptr(rowptr), _lib.ptr(colidx), _lib.ptr(val), n_rows, d, 1,
+                                        _lib.ptr(dense), d, _lib.ptr(y), d, None, None,
+                                        ctypes.byref(sp) if sp is not None else None, _lib.stream()),
+               "gda_spmm_csr_split_f32")
     return y
 
 
@@ -81,7 +84,7 @@ class _SparseLinear(torch.autograd.Function):
         with profiler.region(f"sparse_projection[{sf.f}x{weight.size(0)}]", 1,
                              sf.nnz * 8 + (sf.n + 1) * 4 + 4 * (wt.numel() + sf.n * weight.size(0)),
                              2 * sf.nnz * weight.size(0)):
-            y = _spmm(g.rowptr, g.colidx, g.val, sf.n, wt, sf.n)
+            y = _spmm(g.rowptr, g.colidx, g.val, sf.n, wt, sf.n, g.split(False))
         ctx.sf = sf
         return y
 
@@ -93,7 +96,7 @@ class _SparseLinear(torch.autograd.Function):
         with profiler.region(f"sparse_projection_bwd[{sf.f}x{gy.size(1)}]", 1,
                              sf.nnz * 8 + (sf.f + 1) * 4 + 4 * (gy.numel() + sf.f * gy.size(1)),
                              2 * sf.nnz * gy.size(1)):
-            gwt = _spmm(g.t_rowptr, g.t_colidx, g.t_val, sf.f, gy, sf.f)   # [F, h]
+            gwt = _spmm(g.t_rowptr, g.t_colidx, g.t_val, sf.f, gy, sf.f, g.split(True))   # [F, h]
         return gwt.t(), None
 
 

@@ -595,3 +595,37 @@ def test_hipgraph_step_matches_eager_trajectory():
     logits, _ = m.predict(t)
     close(logits, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
     exact(logits.argmax(1), g["tgt_logits"].argmax(1))
+
+
+# -------------------------------------------------- hub rows (power-law graphs) --
+def test_spmm_long_rows_split_matches_dense():
+    """Rows with more than SPLIT_THRESHOLD (128) entries are processed as chunks + an ordered reduce: same
+    numbers as the dense product up to fp32 summation order, forward and transposed, and
+    bit-exact again for the short rows of the same graph."""
+    from pygda_amd import graph as G_
+    gen = torch.Generator().manual_seed(8)
+    n, d = 3000, 128
+    hub = torch.randint(0, n, (2500,), generator=gen)
+    ei = torch.cat([torch.stack([hub, torch.zeros(2500, dtype=torch.long)]),              # node 0: in-degree 2500
+                    torch.stack([torch.full((1300,), 7), torch.randint(0, n, (1300,), generator=gen)]),  # node 7: out-degree 1300
+                    torch.randint(0, n, (2, 9000), generator=gen)], dim=1)
+    g = build_csr(ei.to(DEV), n)
+    assert g.split(False).n_long >= 1 and g.split(True).n_long >= 1
+    assert g.split(False).n_chunks >= 5
+    x = torch.randn(n, d, generator=gen)
+    nei, nw = O.gcn_norm(ei, None, n)
+    want = O.propagate(nei, nw, x)
+    got = ops.spmm_kstep(g, x.to(DEV), 1)
+    close(got, want, rtol=1e-5, atol=1e-5)
+    short = (g.rowptr[1:] - g.rowptr[:-1]).cpu() <= G_.SPLIT_THRESHOLD
+    exact(got.cpu()[short], want[short])
+    want3 = O.propagate(nei, nw, O.propagate(nei, nw, want))
+    close(ops.spmm_kstep(g, x.to(DEV), 3, torch.ones(d, device=DEV)), want3 + 1.0, rtol=1e-4, atol=1e-5)
+    # transposed operator (backward) with a hub on the source side
+    xg = x.clone().requires_grad_()
+    gy = torch.randn(n, d, generator=gen)
+    O.propagate(nei, nw, xg).backward(gy)
+    close(ops.spmm_kstep(g, gy.to(DEV), 1, None, transposed=True), xg.grad, rtol=1e-5, atol=1e-5)
+    # narrow width through the same path
+    x5 = torch.randn(n, 5, generator=gen)
+    close(ops.spmm_kstep(g, x5.to(DEV), 1), O.propagate(nei, nw, x5), rtol=1e-5, atol=1e-5)
