@@ -77,6 +77,7 @@ def cpu_baseline(src, tgt, hp, edges):
     O.a2gnn_train_step(net, opt, s, t, 0.0, hp["s_pnums"], hp["t_pnums"], False, hp["weight"], chunk)
     dt = time.perf_counter() - t0
     return {"value": edges / dt, "unit": "edges/s", "cores": threads, "kind": "port",
+            "edges_per_step": edges,
             "sample": "1 full-batch A2GNN training step (fwd+bwd+Adam) of the same cfg-A workload, "
                       f"{dt:.1f} s" + ("" if chunk is None else ", MMD temporaries row-chunked"),
             "epochs_per_sec": 1.0 / dt}
@@ -132,6 +133,8 @@ def main():
     edges = edges_per_step(nnz_s, nnz_t, hp["L"], hp["s_pnums"], hp["t_pnums"])
 
     graphed = getattr(model, "_graphed", None) is not None
+    from pygda_amd import ops as _ops
+    _ops.aggregated_edges = 0
     sync()
     if not graphed:
         profiler.start()
@@ -155,6 +158,7 @@ def main():
         dt = float(t.item())
 
     prof = profiler.summary()
+    executed = _ops.aggregated_edges // args.steps     # aggregations actually launched per step x nnz
     if rank == 0:
         ms = 1e3 * dt / args.steps
 
@@ -175,7 +179,7 @@ def main():
         dominant = max(cands, key=lambda k: prof[k]["ms"])
         agg = max((k for k in prof if k.startswith("spmm")), key=lambda k: prof[k]["ms"])
         out = {
-            "metric": "edges_aggregated_per_sec", "value": world * edges * args.steps / dt, "unit": "edges/s",
+            "metric": "edges_aggregated_per_sec", "value": world * executed * args.steps / dt, "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
@@ -183,13 +187,19 @@ def main():
                                    "Ns=9360/Es=15556, Nt=5484/Et=8117, F=6775), nhid=128, L=2, s_pnums=0, "
                                    "t_pnums=10, weight=10, dropout=0.5, full batch, "
                                    + ("adversarial" if args.adv else "MMD") + " domain loss",
-                       "edges_aggregated_per_step": edges, "nnz_source": nnz_s, "nnz_target": nnz_t,
+                       "edges_aggregated_per_step": executed,
+                       "edges_aggregated_per_step_reference_equivalent": edges,
+                       "note": "value counts the aggregations EXECUTED; layer 0 is evaluated once per domain and "
+                               "shared by the two passes the reference runs separately (identical values), so a "
+                               "step executes fewer aggregations than the reference's step",
+                       "nnz_source": nnz_s, "nnz_target": nnz_t,
                        "execution": "hipGraph replay of the captured step" if graphed else "eager launches",
                        "parallelism": "single GPU" if world == 1 else
                        f"dp{world}: one full-batch replica per GPU (cfg-A has one batch per epoch), "
                        "independent dropout draws, global-batch MMD over all-gathered sample rows, "
                        "one flat RCCL gradient all-reduce per step"},
             "epochs_per_sec": world * args.steps / dt,
+            "reference_equivalent_edges_per_sec": world * edges * args.steps / dt,
             "roofline": dict(roof(dominant), timing="HIP events on the launch stream, " + (
                 "eager pass of the same K steps after the timed hipGraph region" if graphed else "timed region")),
             "roofline_aggregation": roof(agg),

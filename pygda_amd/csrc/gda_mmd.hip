@@ -8,12 +8,16 @@
 // cancellation), only the [m, m] distance matrix is kept (16 MB per resample, L2/MALL
 // resident) and the backward pass recomputes the kernel weights from it.
 //
-//   k_pairdist   tile 64x64 of L2 + per-tile partial sums          (VALU bound: 3*m^2*d flop)
+//   k_pairdist   tile 64x64 of L2 + per-tile partial sums; only tiles on/above the diagonal are
+//                computed, the mirror tile is written from registers (L2 is exactly symmetric:
+//                (a-b)^2 == (b-a)^2 in fp32)                          (VALU bound: 1.5*m^2*d flop)
 //   k_ksum       bandwidth from the partials (mmd.py:50-51), K = sum_q exp(-L2/bw_q)
 //                (mmd.py:52-55), signed block sums XX+YY-XY-YX (mmd.py:100-106)
 //   k_finalize   mean per resample, average over resamples (mmd.py:152-157)
-//   k_bwd        grad_total[i,:] = 4 * sum_j G[i,j] (total[i,:]-total[j,:]),
-//                G = dloss/dL2 (symmetric; the bandwidth is a constant, mmd.py:50 .data)
+//   k_bwd        grad_total[i,:] = 4 * ((sum_j G[i,j]) total[i,:] - sum_j G[i,j] total[j,:]),
+//                G = dloss/dL2 (symmetric; the bandwidth is a constant, mmd.py:50 .data); the
+//                G x total product runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact
+//                fp32 fma chains, measured no less accurate than the difference form here)
 // All reductions are fixed-order (no atomics): results are run-to-run deterministic.
 #include "gda_common.h"
 
@@ -79,6 +83,11 @@ k_pairdist(Rows R, int64_t d, int64_t m, float* __restrict__ l2, double* __restr
     const int t = blockIdx.z;
     const int64_t i0 = (int64_t)blockIdx.y * TILE, j0 = (int64_t)blockIdx.x * TILE;
     const int tid = threadIdx.x, ty = tid / 16, tx = tid % 16;
+    if (blockIdx.x < blockIdx.y) {                       // mirror tile: written by its twin
+        if (tid == 0) partial[((int64_t)t * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = 0.0;
+        return;
+    }
+    const bool diag = blockIdx.x == blockIdx.y;
 
     // this thread stages rows (tid/8) and (tid/8 + 32) of both tiles, features kq*4..+3
     const int lr = tid / 8, kq = (tid % 8) * 4;
@@ -143,8 +152,23 @@ k_pairdist(Rows R, int64_t d, int64_t m, float* __restrict__ l2, double* __restr
                 if (j + b < m) { out[i * m + j + b] = acc[a][b]; local += acc[a][b]; }
         }
     }
+    if (!diag) {                                         // mirror tile L2[j][i] = L2[i][j], from registers
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int64_t j = j0 + tx * 4 + b;
+            if (j >= m) continue;
+            const int64_t i = i0 + ty * 4;
+            if (i + 3 < m && (m % 4 == 0)) {
+                *reinterpret_cast<float4*>(out + j * m + i) = make_float4(acc[0][b], acc[1][b], acc[2][b], acc[3][b]);
+            } else {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    if (i + a < m) out[j * m + i + a] = acc[a][b];
+            }
+        }
+    }
     const double s = block_sum((double)local, red);
-    if (tid == 0) partial[((int64_t)t * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+    if (tid == 0) partial[((int64_t)t * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = diag ? s : 2.0 * s;
 }
 
 struct KParams {
@@ -171,32 +195,67 @@ __device__ float bandwidth_of(const double* __restrict__ partial, int tiles, int
     return bw_sh;
 }
 
+// one workgroup per resample: bandwidth[t] from the pairdist partials (mmd.py:50-51)
 __global__ void __launch_bounds__(TB)
-k_ksum(const float* __restrict__ l2, const double* __restrict__ partial, int tiles_per_t,
-       int64_t m, int64_t n, KParams kp, float* __restrict__ bandwidth,
-       double* __restrict__ kpartial) {
+k_bandwidth(const double* __restrict__ partial, int tiles_per_t, int64_t m, KParams kp,
+            float* __restrict__ bandwidth) {
     __shared__ double red[TB / 64];
-    const int t = blockIdx.z;
-    const float bw0 = bandwidth_of(partial, tiles_per_t, t, m, kp, red);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) bandwidth[t] = bw0;
-    float nib[MAXQ];                                   // -1 / (bandwidth * kernel_mul^q), mmd.py:52
+    const float bw0 = bandwidth_of(partial, tiles_per_t, blockIdx.x, m, kp, red);
+    if (threadIdx.x == 0) bandwidth[blockIdx.x] = bw0;
+}
+
+constexpr int KS_ROWS = 8;    // rows of L2 per workgroup pass in k_ksum
+
+// K = sum_q exp(-L2 / bw_q) (mmd.py:52-55) and the signed block sums XX + YY - XY - YX
+// (mmd.py:100-106).  Streams the [m, m] matrix row-wise with 16-byte loads: one workgroup takes
+// KS_ROWS consecutive rows per pass (grid-stride), HBM/Infinity-Cache bound.
+// KN = compile-time kernel_num (5 in every pygda call: fully unrolled, exponents in registers);
+// KN = 0 keeps the run-time count.
+template <int KN>
+__global__ void __launch_bounds__(TB)
+k_ksum(const float* __restrict__ l2, int64_t m, int64_t n, KParams kp,
+       const float* __restrict__ bandwidth, double* __restrict__ kpartial) {
+    __shared__ double red[TB / 64];
+    const int t = blockIdx.y;
+    const float bw0 = bandwidth[t];
+    const int kn = KN > 0 ? KN : kp.kernel_num;
+    float nib[KN > 0 ? KN : MAXQ];                     // -1 / (bandwidth * kernel_mul^q), mmd.py:52
     {
         float f = 1.f;
-        for (int q = 0; q < kp.kernel_num; ++q) { nib[q] = -1.f / (bw0 * f); f *= kp.kernel_mul; }
+#pragma unroll
+        for (int q = 0; q < kn; ++q) { nib[q] = -1.f / (bw0 * f); f *= kp.kernel_mul; }
     }
-    const int64_t i0 = (int64_t)blockIdx.y * TILE, j0 = (int64_t)blockIdx.x * TILE;
     const float* L = l2 + (int64_t)t * m * m;
+    const bool v4 = (m % 4 == 0);
     float local = 0.f;
-    for (int f = threadIdx.x; f < TILE * TILE; f += TB) {
-        const int64_t i = i0 + f / TILE, j = j0 + f % TILE;
-        if (i >= m || j >= m) continue;
-        const float dist = L[i * m + j];
-        float kv = 0.f;
-        for (int q = 0; q < kp.kernel_num; ++q) kv += expf(dist * nib[q]);              // mmd.py:53-55
-        local += ((i < n) == (j < n)) ? kv : -kv;                                       // XX+YY-XY-YX
+    for (int64_t r0 = (int64_t)blockIdx.x * KS_ROWS; r0 < m; r0 += (int64_t)gridDim.x * KS_ROWS) {
+        const int64_t r1 = r0 + KS_ROWS < m ? r0 + KS_ROWS : m;
+        if (v4) {
+            const int64_t per_row = m / 4;
+            for (int64_t f = threadIdx.x; f < (r1 - r0) * per_row; f += TB) {
+                const int64_t i = r0 + f / per_row, j = (f % per_row) * 4;
+                const float4 dv = *reinterpret_cast<const float4*>(L + i * m + j);
+                const float dd[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float kv = 0.f;
+#pragma unroll
+                    for (int q = 0; q < kn; ++q) kv += __expf(dd[c] * nib[q]);
+                    local += ((i < n) == (j + c < n)) ? kv : -kv;
+                }
+            }
+        } else {
+            for (int64_t f = threadIdx.x; f < (r1 - r0) * m; f += TB) {
+                const int64_t i = r0 + f / m, j = f % m;
+                float kv = 0.f;
+#pragma unroll
+                for (int q = 0; q < kn; ++q) kv += __expf(L[i * m + j] * nib[q]);
+                local += ((i < n) == (j < n)) ? kv : -kv;
+            }
+        }
     }
     const double s = block_sum((double)local, red);
-    if (threadIdx.x == 0) kpartial[((int64_t)t * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+    if (threadIdx.x == 0) kpartial[(int64_t)t * gridDim.x + blockIdx.x] = s;
 }
 
 __global__ void __launch_bounds__(TB)
@@ -219,46 +278,54 @@ k_finalize(const double* __restrict__ kpartial, int tiles_per_t, int times, int6
 // NSEG segments -> (m/32) * NSEG * times workgroups (1260 at m=2000, times=5) so that every
 // CU holds several workgroups; per-segment partial sums are combined in a fixed order by
 // k_bwd_reduce (deterministic, no atomics).
+//
+// Per j tile of 64 rows: G[32 x 64] is rebuilt from the saved L2 into LDS (as Gs[j][i]) and the
+// tile's rows of `total` are staged in LDS; each of the 4 waves then owns 32 feature columns and
+// accumulates  acc[32 x 32] += G[32 x 64] * total[64 x 32]  with 32 v_mfma_f32_32x32x2_f32
+// (A = G: lane l holds G[i = l&31][k = l>>5]; B: lane l holds total[k = l>>5][c = l&31]; both
+// are single conflict-free ds_read_b32).  Row sums of G accumulate beside it; the epilogue forms
+// 4 * (rowsum * total[i] - acc).
 constexpr int BI = 32;        // rows i per workgroup
 constexpr int BJ = 64;        // rows j per LDS tile
 constexpr int LDG = BI + 4;   // padded leading dimension of the G tile (16-byte aligned rows)
+using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+template <int KN>
 __global__ void __launch_bounds__(TB)
 k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* __restrict__ bandwidth,
       KParams kp, const float* __restrict__ grad_loss, int times, int nseg,
       float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float Gs[BJ][LDG];     // Gs[j][i] = G[i][j] (G symmetric)
     __shared__ __attribute__((aligned(16))) float Ts[BJ][DC];      // rows j of total, this column chunk
+    __shared__ float rowsum[BI];
     const int t = blockIdx.z;
     const int seg = blockIdx.y % nseg;
     const int64_t c0 = (int64_t)(blockIdx.y / nseg) * DC;
     const int64_t i0 = (int64_t)blockIdx.x * BI;
-    const int tid = threadIdx.x, ty = tid / 32, tx = tid % 32;
+    const int tid = threadIdx.x, wave = tid / 64, lane = tid % 64;
     const int64_t n = R.n;
 
-    float nib[MAXQ];                                                // -1 / bw_q
+    const int kn = KN > 0 ? KN : kp.kernel_num;
+    float nib[KN > 0 ? KN : MAXQ];                                  // -1 / bw_q
     {
         float f = 1.f;
         const float b0 = bandwidth[t];
-        for (int q = 0; q < kp.kernel_num; ++q) { nib[q] = -1.f / (b0 * f); f *= kp.kernel_mul; }
+#pragma unroll
+        for (int q = 0; q < kn; ++q) { nib[q] = -1.f / (b0 * f); f *= kp.kernel_mul; }
     }
     // d loss / d K[i,j] = +-1 / (n^2 * times) * upstream
     const float coef = grad_loss[0] / ((float)n * (float)n) / (float)times;
 
-    float ti[4][4], acc[4][4];
+    f32x16 acc;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int64_t i = i0 + ty * 4 + a;
-        const float* p = i < m ? row_ptr(R, t, i) : nullptr;
-        const float4 v = load4(p, c0 + tx * 4, d, R.vec4);
-        ti[a][0] = v.x; ti[a][1] = v.y; ti[a][2] = v.z; ti[a][3] = v.w;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
-    }
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float rs = 0.f;                                                 // threads 0..31: row sum of G for row tid
+    if (tid < BI) rowsum[tid] = 0.f;
 
     // this segment's j tiles: tiles seg, seg + nseg, ...
     const float* L = l2 + (int64_t)t * m * m;
     const int64_t ntiles = gda_cdiv_dev(m, BJ);
+    const int ka = lane >> 5, la = lane & 31;
     for (int64_t jt = seg; jt < ntiles; jt += nseg) {
         const int64_t j0 = jt * BJ;
         __syncthreads();
@@ -270,7 +337,8 @@ k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* _
             if (i < m && j < m) {
                 const float dist = L[j * m + i];
                 float dk = 0.f;
-                for (int q = 0; q < kp.kernel_num; ++q) dk = fmaf(expf(dist * nib[q]), nib[q], dk);
+#pragma unroll
+                for (int q = 0; q < kn; ++q) dk = fmaf(__expf(dist * nib[q]), nib[q], dk);
                 g = (((i < n) == (j < n)) ? coef : -coef) * dk;
             }
             Gs[jj][ii] = g;
@@ -282,29 +350,31 @@ k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* _
             *reinterpret_cast<float4*>(&Ts[jj][c4]) = load4(p, c0 + c4, d, R.vec4);
         }
         __syncthreads();
+        if (tid < BI) {
 #pragma unroll 8
-        for (int jj = 0; jj < BJ; ++jj) {
-            const float4 g4 = *reinterpret_cast<const float4*>(&Gs[jj][ty * 4]);
-            const float4 t4 = *reinterpret_cast<const float4*>(&Ts[jj][tx * 4]);
-            const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-            const float tj[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[a][c] = fmaf(gv[a], ti[a][c] - tj[c], acc[a][c]);
+            for (int jj = 0; jj < BJ; ++jj) rs += Gs[jj][tid];
+        }
+#pragma unroll 8
+        for (int jj = 0; jj < BJ; jj += 2) {
+            const float av = Gs[jj + ka][la];
+            const float bv = Ts[jj + ka][wave * 32 + la];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
         }
     }
+    if (tid < BI) rowsum[tid] = rs;
+    __syncthreads();
 
-    // partial sums of this segment: part[t][seg][i][c]  (seg-major so the reduce streams)
+    // epilogue: part[t][seg][i][c] = rowsum[i] * total[i][c] - acc   (the factor 4 is applied by the reduce)
     float* out = part + (((int64_t)t * nseg + seg) * m) * d;
+    const int64_t c = c0 + wave * 32 + la;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int64_t i = i0 + ty * 4 + a;
-        if (i >= m) continue;
-        const int64_t c = c0 + tx * 4;
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-            if (c + v < d) out[i * d + c + v] = acc[a][v];
+    for (int r = 0; r < 16; ++r) {
+        const int il = (r & 3) + 8 * (r >> 2) + 4 * ka;             // C/D layout of the 32x32 MFMA
+        const int64_t i = i0 + il;
+        if (i < m && c < d) {
+            const float ti = row_ptr(R, t, i)[c];
+            out[i * d + c] = fmaf(rowsum[il], ti, -acc[r]);
+        }
     }
 }
 
@@ -383,9 +453,13 @@ extern "C" int gda_mmd_fwd_f32(const float* src, int64_t ld_src, const float* tg
     const dim3 grid(nt, nt, (unsigned)times);
     k_pairdist<<<grid, TB, 0, stream>>>(R, d, m, l2_saved, ws.partial);
     GDA_LAUNCH_CHECK();
-    k_ksum<<<grid, TB, 0, stream>>>(l2_saved, ws.partial, (int)(nt * nt), m, n, kp, bandwidth, ws.kpartial);
+    k_bandwidth<<<(unsigned)times, TB, 0, stream>>>(ws.partial, (int)(nt * nt), m, kp, bandwidth);
     GDA_LAUNCH_CHECK();
-    k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, (int)(nt * nt), times, n, loss);
+    const unsigned kgrid = (unsigned)(gda_cdiv(m, KS_ROWS) < 256 ? gda_cdiv(m, KS_ROWS) : 256);
+    if (kernel_num == 5) k_ksum<5><<<dim3(kgrid, (unsigned)times), TB, 0, stream>>>(l2_saved, m, n, kp, bandwidth, ws.kpartial);
+    else k_ksum<0><<<dim3(kgrid, (unsigned)times), TB, 0, stream>>>(l2_saved, m, n, kp, bandwidth, ws.kpartial);
+    GDA_LAUNCH_CHECK();
+    k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, (int)kgrid, times, n, loss);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
@@ -408,7 +482,8 @@ extern "C" int gda_mmd_bwd_f32(const float* src, int64_t ld_src, const float* tg
     const int64_t ntiles = gda_cdiv(m, BJ);
     const int nseg = (int)(ntiles < BWD_NSEG ? ntiles : BWD_NSEG);
     const dim3 grid((unsigned)gda_cdiv(m, BI), (unsigned)(gda_cdiv(d, DC) * nseg), (unsigned)times);
-    k_bwd<<<grid, TB, 0, stream>>>(R, d, m, l2_saved, bandwidth, kp, grad_loss, times, nseg, ws.bwd_part);
+    if (kernel_num == 5) k_bwd<5><<<grid, TB, 0, stream>>>(R, d, m, l2_saved, bandwidth, kp, grad_loss, times, nseg, ws.bwd_part);
+    else k_bwd<0><<<grid, TB, 0, stream>>>(R, d, m, l2_saved, bandwidth, kp, grad_loss, times, nseg, ws.bwd_part);
     GDA_LAUNCH_CHECK();
     const int64_t total = (int64_t)times * m * d;
     int64_t rg = gda_cdiv(total, TB);

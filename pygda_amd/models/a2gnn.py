@@ -31,33 +31,41 @@ class A2GNN(BaseGDA):
                          num_layers=self.num_layers, adv=self.adv, dropout=self.dropout, act=self.act,
                          mode=self.mode, **kwargs).to(self.device)
 
-    def _target_logits_async(self, net, target_data):
+    def _target_logits_async(self, net, target_data, h0):
         """The reference's second target forward (:211) is not part of the loss.  It is issued on
-        a side HIP stream (fork/join, no autograd tape) so that its ~21 small aggregation
-        launches overlap the loss branch instead of queueing behind it; under hipGraph capture
-        the fork becomes a parallel branch of the graph."""
+        a side HIP stream (fork/join, no autograd tape) so that its small aggregation launches
+        overlap the loss branch instead of queueing behind it; under hipGraph capture the fork
+        becomes a parallel branch of the graph."""
         main = torch.cuda.current_stream()
         side = getattr(self, "_side_stream", None)
         if side is None:
             side = self._side_stream = torch.cuda.Stream()
         side.wait_stream(main)
         with torch.cuda.stream(side), torch.no_grad():
-            out = net(target_data, self.t_pnums)
+            feats = net.feat_bottleneck_from(h0.detach(), target_data.edge_index, None, self.t_pnums)
+            out = net.feat_classifier(feats, target_data.edge_index, None, 1)
         out.record_stream(main)
         return out, side
 
     def forward_model(self, source_data, target_data, alpha):
+        """a2gnn.py:146-213.  Layer 0 (projection + prop_nums aggregations, no randomness) is
+        evaluated once per domain and shared by the passes that the reference runs separately
+        (source: logits :181 and features :192; target: features :193 and logits :211) -- same
+        values, 10 aggregations and two layer-0 projections fewer per step."""
         net = self.a2gnn
+        node = self.mode == 'node'
+        sb = None if node else source_data.batch
+        tb = None if node else target_data.batch
+        h0_s = net.first_conv(source_data.x, source_data.edge_index, self.s_pnums)
+        h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
         pending = None
-        if self.compute_target_logits and source_data.x.is_cuda and self.overlap_streams:
-            pending = self._target_logits_async(net, target_data)
-        source_logits = net(source_data, self.s_pnums)                                   # :181
+        if self.compute_target_logits and node and h0_t.is_cuda and self.overlap_streams:
+            pending = self._target_logits_async(net, target_data, h0_t)
+        feats = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)
+        source_logits = net.feat_classifier(feats, source_data.edge_index, sb, 1)        # :181
         loss = F.nll_loss(F.log_softmax(source_logits, dim=1), source_data.y)            # :182
-        sb = tb = None
-        if self.mode != 'node':
-            sb, tb = source_data.batch, target_data.batch
-        source_features = net.feat_bottleneck(source_data.x, source_data.edge_index, sb, self.s_pnums)
-        target_features = net.feat_bottleneck(target_data.x, target_data.edge_index, tb, self.t_pnums)
+        source_features = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)   # :192
+        target_features = net.feat_bottleneck_from(h0_t, target_data.edge_index, tb, self.t_pnums)   # :193
         if self.adv:                                                                     # :196-205, fused
             disc = net.domain_discriminator
             loss = loss + self.weight * grl_disc_ce(source_features, target_features, disc.weight,
@@ -67,8 +75,9 @@ class A2GNN(BaseGDA):
         if pending is not None:
             target_logits, side = pending
             torch.cuda.current_stream().wait_stream(side)                                # join
-        elif self.compute_target_logits:
-            target_logits = net(target_data, self.t_pnums)                               # :211
+        elif self.compute_target_logits:                                                 # :211
+            feats_t = net.feat_bottleneck_from(h0_t, target_data.edge_index, tb, self.t_pnums)
+            target_logits = net.feat_classifier(feats_t, target_data.edge_index, tb, 1)
         else:
             target_logits = None
         return loss, source_logits, target_logits

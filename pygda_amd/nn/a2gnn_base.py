@@ -35,7 +35,18 @@ class A2GNNBase(nn.Module):
         return self.feat_classifier(h, data.edge_index, batch, prop_nums=1)
 
     def feat_bottleneck(self, x, edge_index, batch, prop_nums=30):
-        for conv in self.convs:
+        return self.feat_bottleneck_from(self.first_conv(x, edge_index, prop_nums), edge_index, batch, prop_nums)
+
+    def first_conv(self, x, edge_index, prop_nums):
+        """Output of layer 0 BEFORE activation / dropout: a deterministic function of the inputs,
+        so the two passes the trainer makes over the same graph (features and logits) can share
+        it -- the reference recomputes it, projection and all ``prop_nums`` aggregations, per pass."""
+        return self.convs[0](x, edge_index, prop_nums)
+
+    def feat_bottleneck_from(self, h0, edge_index, batch, prop_nums=30):
+        """``feat_bottleneck`` continued from a precomputed :meth:`first_conv` output."""
+        x = F.dropout(self.act(h0), p=self.dropout, training=self.training)
+        for conv in self.convs[1:]:
             x = F.dropout(self.act(conv(x, edge_index, prop_nums)), p=self.dropout, training=self.training)
         if self.mode == "graph":
             x = global_mean_pool(x, batch)

@@ -16,6 +16,10 @@ def _f32c(t, name):
 
 
 # --------------------------------------------------------------------------- SpMM --
+aggregated_edges = 0     # running count of nnz(A_hat) over every aggregation launched (bench bookkeeping;
+                         # only maintained while the profiler is on: it costs a cached-nnz lookup)
+
+
 def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
     """``A_hat^K @ x (+ bias)`` without autograd (K launches, ping-pong buffers)."""
     x = _f32c(x, "x")
@@ -29,6 +33,8 @@ def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
     b = None if bias is None else _f32c(bias, "bias")
     L = _lib.lib()
     if profiler.enabled:      # algorithmic bytes per launch: nnz*(4+4) + (N+1)*4 + 2*N*d*4
+        global aggregated_edges
+        aggregated_edges += K * graph.nnz
         nbytes = K * (graph.nnz * 8 + (n + 1) * 4 + 2 * n * d * 4)
         ctx = profiler.region(f"spmm_csr_f32[d={d}]", K, nbytes, K * 2 * graph.nnz * d)
     else:
@@ -77,17 +83,22 @@ class _MMD(torch.autograd.Function):
             raise ValueError("source and target features must have the same width")
         dev = src.device
         m = 2 * n
+        ctx.feat_rows = (src.size(0), tgt.size(0))
+        if src_idx is not None:
+            # the sampled rows are gathered ONCE into [times*n, d] (2 x 2.5 MB at the A2GNN shapes):
+            # the pair kernels and the backward then stream contiguous rows instead of chasing
+            # an int64 index per row and tile
+            src, tgt = gather_rows(src, src_idx.reshape(-1)), gather_rows(tgt, tgt_idx.reshape(-1))
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         bw = torch.empty(times, dtype=torch.float32, device=dev)
         l2 = torch.empty(times, m, m, dtype=torch.float32, device=dev)
         L = _lib.lib()
         ws = _lib.workspace(L.gda_mmd_workspace_bytes(times, n, d), dev, "mmd")
-        with profiler.region("mmd_fwd", 3, 0, times * (3 * m * m * d + 12 * m * m)):
+        with profiler.region("mmd_fwd", 3, 0, times * (3 * m * m * d // 2 + 12 * m * m)):
             _lib.check(L.gda_mmd_fwd_f32(
-                _lib.ptr(src), src.size(1), _lib.ptr(tgt), tgt.size(1), d, _lib.ptr(src_idx),
-                _lib.ptr(tgt_idx), times, n, float(kernel_mul), int(kernel_num),
-                float(fix_sigma) if fix_sigma else 0.0, _lib.ptr(loss), _lib.ptr(bw), _lib.ptr(l2),
-                _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_mmd_fwd_f32")
+                _lib.ptr(src), d, _lib.ptr(tgt), d, d, None, None, times, n, float(kernel_mul),
+                int(kernel_num), float(fix_sigma) if fix_sigma else 0.0, _lib.ptr(loss), _lib.ptr(bw),
+                _lib.ptr(l2), _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_mmd_fwd_f32")
         ctx.save_for_backward(src, tgt, src_idx, tgt_idx, bw, l2)
         ctx.cfg = (times, n, float(kernel_mul), int(kernel_num))
         return loss.reshape(())
@@ -103,20 +114,19 @@ class _MMD(torch.autograd.Function):
         ws = _lib.workspace(L.gda_mmd_workspace_bytes(times, n, d), dev, "mmd")
         with profiler.region("mmd_bwd", 2, 0, times * (3 * m * m * d + 12 * m * m)):
             _lib.check(L.gda_mmd_bwd_f32(
-                _lib.ptr(src), src.size(1), _lib.ptr(tgt), tgt.size(1), d, _lib.ptr(src_idx),
-                _lib.ptr(tgt_idx), times, n, kernel_mul, kernel_num, _lib.ptr(bw), _lib.ptr(l2),
-                _lib.ptr(gl), _lib.ptr(grad_rows), _lib.ptr(ws), ws.numel(), _lib.stream()),
-                "gda_mmd_bwd_f32")
+                _lib.ptr(src), d, _lib.ptr(tgt), d, d, None, None, times, n, kernel_mul, kernel_num,
+                _lib.ptr(bw), _lib.ptr(l2), _lib.ptr(gl), _lib.ptr(grad_rows), _lib.ptr(ws), ws.numel(),
+                _lib.stream()), "gda_mmd_bwd_f32")
         if src_idx is None:                       # rows as given, stacked [times, n, d]
             gs, gt = grad_rows[:, :n].reshape(times * n, d), grad_rows[:, n:].reshape(times * n, d)
         elif ctx.sel is not None:                 # selection CSRs prepared on the host with the samples
             s_rp, s_ci, t_rp, t_ci, ones = ctx.sel
             flat = grad_rows.view(times * m, d)
-            gs = _selection_spmm(s_rp, s_ci, ones, flat, src.size(0))
-            gt = _selection_spmm(t_rp, t_ci, ones, flat, tgt.size(0))
+            gs = _selection_spmm(s_rp, s_ci, ones, flat, ctx.feat_rows[0])
+            gt = _selection_spmm(t_rp, t_ci, ones, flat, ctx.feat_rows[1])
         else:
-            gs = _scatter_rows(grad_rows, src_idx, 0, n, src.size(0))
-            gt = _scatter_rows(grad_rows, tgt_idx, n, n, tgt.size(0))
+            gs = _scatter_rows(grad_rows, src_idx, 0, n, ctx.feat_rows[0])
+            gt = _scatter_rows(grad_rows, tgt_idx, n, n, ctx.feat_rows[1])
         return (gs if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None,
                 None, None, None, None, None, None, None, None)
 
