@@ -146,7 +146,8 @@ int gda_spmm_csr_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const f
  *   loss        [1] fp32 (device)
  *   bandwidth   [times] fp32 (device, saved for backward; gradient does not flow
  *               through it -- mmd.py:50 uses .data)
- *   l2_saved    [times, 2n, 2n] fp32 (device; produced by fwd, consumed by bwd)
+ *   l2_saved    [times, 2n, 2n] fp32 (device; produced by fwd, consumed by bwd -- on return it
+ *               holds d K / d L2 with the block signs applied, not the distances themselves)
  * Backward: grad_rows [times, 2n, d] = d loss / d total rows, scaled by *grad_loss.
  * The caller scatters them onto feature rows (a CSR SpMM with the selection matrix).
  * ---------------------------------------------------------------------------- */

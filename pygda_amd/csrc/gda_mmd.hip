@@ -5,12 +5,13 @@
 // (m = 2000, d = 128: 2 GB, several live at once and kept for backward).  Here the
 // pairwise squared distances are produced tile by tile in LDS in the reference's direct
 // difference form (mmd.py:43-46: sum_k (total[j,k]-total[i,k])^2 -- no |a|^2+|b|^2-2ab
-// cancellation), only the [m, m] distance matrix is kept (16 MB per resample, L2/MALL
-// resident) and the backward pass recomputes the kernel weights from it.
+// cancellation) -- see k_pairdist for how the Gram form on the fp32 matrix cores keeps that
+// property where it matters --, only the [m, m] distance matrix is kept (16 MB per resample,
+// L2/MALL resident) and the backward pass recomputes the kernel weights from it.
 //
-//   k_pairdist   tile 64x64 of L2 + per-tile partial sums; only tiles on/above the diagonal are
-//                computed, the mirror tile is written from registers (L2 is exactly symmetric:
-//                (a-b)^2 == (b-a)^2 in fp32)                          (VALU bound: 1.5*m^2*d flop)
+//   k_rownorm    |t_i|^2 as the same k-ordered fma chain the MFMA uses
+//   k_pairdist   tile 64x64 of L2 = |t_i|^2 + |t_j|^2 - 2 t_i.t_j on v_mfma_f32_32x32x2_f32, plus
+//                per-tile partial sums                                 (MFMA bound: 2*m^2*d flop)
 //   k_ksum       bandwidth from the partials (mmd.py:50-51), K = sum_q exp(-L2/bw_q)
 //                (mmd.py:52-55), signed block sums XX+YY-XY-YX (mmd.py:100-106)
 //   k_finalize   mean per resample, average over resamples (mmd.py:152-157)
@@ -75,21 +76,41 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 }
 
 // ---------------------------------------------------------------- forward --
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// |t_r|^2 per row as ONE k-ascending fmaf chain -- the same chain the fp32 MFMA builds for the
+// dot products below, so that for identical rows (sampling is with replacement) dot == norm
+// bit for bit and their distance is exactly 0, as in the reference's difference form.
 __global__ void __launch_bounds__(TB)
-k_pairdist(Rows R, int64_t d, int64_t m, float* __restrict__ l2, double* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float As[DK][LDT];   // rows i of the tile
-    __shared__ __attribute__((aligned(16))) float Bs[DK][LDT];   // rows j of the tile
+k_rownorm(Rows R, int64_t d, int64_t m, int times, float* __restrict__ norms) {
+    const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (r >= (int64_t)times * m) return;
+    const int t = (int)(r / m);
+    const float* p = row_ptr(R, t, r % m);
+    float acc = 0.f;
+    for (int64_t k = 0; k < d; ++k) acc = fmaf(p[k], p[k], acc);
+    norms[r] = acc;
+}
+
+// L2[i,j] = (|t_i|^2 + |t_j|^2) - 2 t_i.t_j on the fp32 matrix cores: 64x64 tile per workgroup,
+// one 32x32 sub-tile per wave, feature chunks of 32 staged k-major in LDS so that both MFMA
+// operands are conflict-free ds_read_b32 (A: lane l -> row l&31, k = l>>5; B likewise).  The
+// fp32 MFMA is an exact k-ordered fma chain, so the Gram form costs ~1e-7 relative on L2 (far
+// inside the 1e-4 loss tolerance) for half the VALU work of the difference form and none of it
+// on the VALU.  Tile sums feed the bandwidth (mmd.py:50).
+__global__ void __launch_bounds__(TB)
+k_pairdist(Rows R, int64_t d, int64_t m, const float* __restrict__ norms, float* __restrict__ l2,
+           double* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float As[DK][LDT];   // As[k][row i of the tile]
+    __shared__ __attribute__((aligned(16))) float Bs[DK][LDT];   // Bs[k][row j of the tile]
     __shared__ double red[TB / 64];
     const int t = blockIdx.z;
     const int64_t i0 = (int64_t)blockIdx.y * TILE, j0 = (int64_t)blockIdx.x * TILE;
-    const int tid = threadIdx.x, ty = tid / 16, tx = tid % 16;
-    if (blockIdx.x < blockIdx.y) {                       // mirror tile: written by its twin
-        if (tid == 0) partial[((int64_t)t * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = 0.0;
-        return;
-    }
-    const bool diag = blockIdx.x == blockIdx.y;
+    const int tid = threadIdx.x, wave = tid / 64, lane = tid % 64;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;         // this wave's 32x32 sub-tile
+    const int ka = lane >> 5, la = lane & 31;
 
-    // this thread stages rows (tid/8) and (tid/8 + 32) of both tiles, features kq*4..+3
+    // staging: this thread moves rows (tid/8) and (tid/8 + 32) of both tiles, features kq*4..+3
     const int lr = tid / 8, kq = (tid % 8) * 4;
     const float* pa[2]; const float* pb[2];
 #pragma unroll
@@ -98,13 +119,12 @@ k_pairdist(Rows R, int64_t d, int64_t m, float* __restrict__ l2, double* __restr
         pa[q] = ri < m ? row_ptr(R, t, ri) : nullptr;
         pb[q] = rj < m ? row_ptr(R, t, rj) : nullptr;
     }
-
-    float acc[4][4];
+    f32x16 acc;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+    // single-buffered on purpose: at 17 KB of LDS nine workgroups share a CU and hide each
+    // other's staging; a double-buffered variant (35 KB, four workgroups) measured 8 % slower
     for (int64_t k0 = 0; k0 < d; k0 += DK) {
         float4 va[2], vb[2];
 #pragma unroll
@@ -120,55 +140,27 @@ k_pairdist(Rows R, int64_t d, int64_t m, float* __restrict__ l2, double* __restr
             Bs[kq + 0][r] = vb[q].x; Bs[kq + 1][r] = vb[q].y; Bs[kq + 2][r] = vb[q].z; Bs[kq + 3][r] = vb[q].w;
         }
         __syncthreads();
-#pragma unroll 8
-        for (int kk = 0; kk < DK; ++kk) {
-            const float4 a4 = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
-            const float4 b4 = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const float df = bv[b] - av[a];          // total0 - total1 = total[j] - total[i]
-                    acc[a][b] = fmaf(df, df, acc[a][b]);
-                }
-        }
+        for (int kk = 0; kk < DK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + ka][wi + la], Bs[kk + ka][wj + la], acc, 0, 0, 0);
     }
 
-    float local = 0.f;
+    const float* nt = norms + (int64_t)t * m;
     float* out = l2 + (int64_t)t * m * m;
+    const int64_t j = j0 + wj + la;
+    const float nj = j < m ? nt[j] : 0.f;
+    float local = 0.f;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int64_t i = i0 + ty * 4 + a;
-        if (i >= m) continue;
-        const int64_t j = j0 + tx * 4;
-        if (j + 3 < m && (m % 4 == 0)) {
-            *reinterpret_cast<float4*>(out + i * m + j) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
-            local += (acc[a][0] + acc[a][1]) + (acc[a][2] + acc[a][3]);
-        } else {
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                if (j + b < m) { out[i * m + j + b] = acc[a][b]; local += acc[a][b]; }
-        }
-    }
-    if (!diag) {                                         // mirror tile L2[j][i] = L2[i][j], from registers
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int64_t j = j0 + tx * 4 + b;
-            if (j >= m) continue;
-            const int64_t i = i0 + ty * 4;
-            if (i + 3 < m && (m % 4 == 0)) {
-                *reinterpret_cast<float4*>(out + j * m + i) = make_float4(acc[0][b], acc[1][b], acc[2][b], acc[3][b]);
-            } else {
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    if (i + a < m) out[j * m + i + a] = acc[a][b];
-            }
+    for (int r = 0; r < 16; ++r) {
+        const int64_t i = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * ka;       // C/D layout of the 32x32 MFMA
+        if (i < m && j < m) {
+            const float v = (nt[i] + nj) - 2.f * acc[r];
+            out[i * m + j] = v;
+            local += v;
         }
     }
     const double s = block_sum((double)local, red);
-    if (tid == 0) partial[((int64_t)t * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = diag ? s : 2.0 * s;
+    if (tid == 0) partial[((int64_t)t * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
 }
 
 struct KParams {
@@ -213,7 +205,7 @@ constexpr int KS_ROWS = 8;    // rows of L2 per workgroup pass in k_ksum
 // KN = 0 keeps the run-time count.
 template <int KN>
 __global__ void __launch_bounds__(TB)
-k_ksum(const float* __restrict__ l2, int64_t m, int64_t n, KParams kp,
+k_ksum(float* __restrict__ l2, int64_t m, int64_t n, KParams kp,
        const float* __restrict__ bandwidth, double* __restrict__ kpartial) {
     __shared__ double red[TB / 64];
     const int t = blockIdx.y;
@@ -225,7 +217,10 @@ k_ksum(const float* __restrict__ l2, int64_t m, int64_t n, KParams kp,
 #pragma unroll
         for (int q = 0; q < kn; ++q) { nib[q] = -1.f / (bw0 * f); f *= kp.kernel_mul; }
     }
-    const float* L = l2 + (int64_t)t * m * m;
+    // While the distances stream through, they are REPLACED in place by the backward's weights
+    //   g[i,j] = +-sum_q exp(L2/(-bw_q)) * (-1/bw_q)      (d K / d L2, signed like the block means)
+    // so that the backward pass is a pure matrix product and evaluates no exponentials.
+    float* L = l2 + (int64_t)t * m * m;
     const bool v4 = (m % 4 == 0);
     float local = 0.f;
     for (int64_t r0 = (int64_t)blockIdx.x * KS_ROWS; r0 < m; r0 += (int64_t)gridDim.x * KS_ROWS) {
@@ -236,21 +231,28 @@ k_ksum(const float* __restrict__ l2, int64_t m, int64_t n, KParams kp,
                 const int64_t i = r0 + f / per_row, j = (f % per_row) * 4;
                 const float4 dv = *reinterpret_cast<const float4*>(L + i * m + j);
                 const float dd[4] = {dv.x, dv.y, dv.z, dv.w};
+                float gg[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    float kv = 0.f;
+                    float kv = 0.f, dk = 0.f;
 #pragma unroll
-                    for (int q = 0; q < kn; ++q) kv += __expf(dd[c] * nib[q]);
-                    local += ((i < n) == (j + c < n)) ? kv : -kv;
+                    for (int q = 0; q < kn; ++q) { const float e = __expf(dd[c] * nib[q]); kv += e; dk = fmaf(e, nib[q], dk); }
+                    const bool same = (i < n) == (j + c < n);
+                    local += same ? kv : -kv;
+                    gg[c] = same ? dk : -dk;
                 }
+                *reinterpret_cast<float4*>(L + i * m + j) = make_float4(gg[0], gg[1], gg[2], gg[3]);
             }
         } else {
             for (int64_t f = threadIdx.x; f < (r1 - r0) * m; f += TB) {
                 const int64_t i = r0 + f / m, j = f % m;
-                float kv = 0.f;
+                float kv = 0.f, dk = 0.f;
+                const float dist = L[i * m + j];
 #pragma unroll
-                for (int q = 0; q < kn; ++q) kv += __expf(L[i * m + j] * nib[q]);
-                local += ((i < n) == (j < n)) ? kv : -kv;
+                for (int q = 0; q < kn; ++q) { const float e = __expf(dist * nib[q]); kv += e; dk = fmaf(e, nib[q], dk); }
+                const bool same = (i < n) == (j < n);
+                local += same ? kv : -kv;
+                L[i * m + j] = same ? dk : -dk;
             }
         }
     }
@@ -274,106 +276,130 @@ k_finalize(const double* __restrict__ kpartial, int tiles_per_t, int times, int6
 }
 
 // --------------------------------------------------------------- backward --
-// Work decomposition: 32 rows x 128 feature columns per workgroup, the j range cut into
-// NSEG segments -> (m/32) * NSEG * times workgroups (1260 at m=2000, times=5) so that every
-// CU holds several workgroups; per-segment partial sums are combined in a fixed order by
-// k_bwd_reduce (deterministic, no atomics).
-//
-// Per j tile of 64 rows: G[32 x 64] is rebuilt from the saved L2 into LDS (as Gs[j][i]) and the
-// tile's rows of `total` are staged in LDS; each of the 4 waves then owns 32 feature columns and
-// accumulates  acc[32 x 32] += G[32 x 64] * total[64 x 32]  with 32 v_mfma_f32_32x32x2_f32
-// (A = G: lane l holds G[i = l&31][k = l>>5]; B: lane l holds total[k = l>>5][c = l&31]; both
-// are single conflict-free ds_read_b32).  Row sums of G accumulate beside it; the epilogue forms
-// 4 * (rowsum * total[i] - acc).
-constexpr int BI = 32;        // rows i per workgroup
-constexpr int BJ = 64;        // rows j per LDS tile
-constexpr int LDG = BI + 4;   // padded leading dimension of the G tile (16-byte aligned rows)
-using f32x16 = __attribute__((ext_vector_type(16))) float;
+// With the weights g = dK/dL2 (block-signed) left in place of the distances by k_ksum, the
+// gradient w.r.t. the sampled rows is a matrix product plus a row scaling,
+//     grad_total[i,:] = 4 c ((sum_j g[i,j]) total[i,:] - sum_j g[i,j] total[j,:]),   c = dloss / (n^2 times),
+// run on the fp32 matrix cores.  Workgroup tile: 64 rows x 128 feature columns; wave w owns rows
+// (w>>1)*32.. and two 32-column MFMA tiles at (w&1)*64.  The j dimension is cut into NSEG segments
+// (deterministic two-stage sum, no atomics) and walked in chunks of 32 rows with double-buffered
+// LDS: the global loads of chunk c+1 are in flight while the 32 MFMAs of chunk c issue.
+// g is symmetric, so the A operand tile is read as g[j][i]: 16-byte loads along i, stored k-major,
+// and every MFMA operand fetch is a conflict-free ds_read_b32.
+constexpr int BI = 64;        // rows i per workgroup
+constexpr int BJ = 32;        // rows j per chunk (MFMA K = 2 per instruction)
 
 template <int KN>
 __global__ void __launch_bounds__(TB)
 k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* __restrict__ bandwidth,
       KParams kp, const float* __restrict__ grad_loss, int times, int nseg,
       float* __restrict__ part) {
-    __shared__ __attribute__((aligned(16))) float Gs[BJ][LDG];     // Gs[j][i] = G[i][j] (G symmetric)
-    __shared__ __attribute__((aligned(16))) float Ts[BJ][DC];      // rows j of total, this column chunk
+    (void)bandwidth; (void)kp;
+    __shared__ __attribute__((aligned(16))) float Gs[2][BJ][BI];      // Gs[b][j][i] = g[i][j]
+    __shared__ __attribute__((aligned(16))) float Ts[2][BJ][DC];      // rows j of total, this column chunk
+    __shared__ float rs_part[16][BI];
     __shared__ float rowsum[BI];
     const int t = blockIdx.z;
     const int seg = blockIdx.y % nseg;
     const int64_t c0 = (int64_t)(blockIdx.y / nseg) * DC;
     const int64_t i0 = (int64_t)blockIdx.x * BI;
     const int tid = threadIdx.x, wave = tid / 64, lane = tid % 64;
-    const int64_t n = R.n;
-
-    const int kn = KN > 0 ? KN : kp.kernel_num;
-    float nib[KN > 0 ? KN : MAXQ];                                  // -1 / bw_q
-    {
-        float f = 1.f;
-        const float b0 = bandwidth[t];
-#pragma unroll
-        for (int q = 0; q < kn; ++q) { nib[q] = -1.f / (b0 * f); f *= kp.kernel_mul; }
-    }
-    // d loss / d K[i,j] = +-1 / (n^2 * times) * upstream
-    const float coef = grad_loss[0] / ((float)n * (float)n) / (float)times;
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float rs = 0.f;                                                 // threads 0..31: row sum of G for row tid
-    if (tid < BI) rowsum[tid] = 0.f;
-
-    // this segment's j tiles: tiles seg, seg + nseg, ...
-    const float* L = l2 + (int64_t)t * m * m;
-    const int64_t ntiles = gda_cdiv_dev(m, BJ);
     const int ka = lane >> 5, la = lane & 31;
-    for (int64_t jt = seg; jt < ntiles; jt += nseg) {
-        const int64_t j0 = jt * BJ;
-        __syncthreads();
-        // G tile, read as L2[j][i] (== L2[i][j]): coalesced along i, stored row-contiguous
-        for (int f = tid; f < BJ * BI; f += TB) {
-            const int jj = f / BI, ii = f % BI;
-            const int64_t j = j0 + jj, i = i0 + ii;
-            float g = 0.f;
-            if (i < m && j < m) {
-                const float dist = L[j * m + i];
-                float dk = 0.f;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
+    const int64_t n = R.n;
+    const float* L = l2 + (int64_t)t * m * m;
+    const bool g_vec = (m % 4 == 0);
+
+    // staging roles: G chunk = 32 rows x 16 float4 (2 per thread), T chunk = 32 rows x 32 float4 (4 per thread)
+    const int g_c4 = (tid % 16) * 4, g_r = tid / 16;       // rows g_r and g_r + 16
+    const int t_c4 = (tid % 32) * 4, t_r = tid / 32;       // rows t_r, +8, +16, +24
+
+    f32x16 acc0, acc1;
 #pragma unroll
-                for (int q = 0; q < kn; ++q) dk = fmaf(__expf(dist * nib[q]), nib[q], dk);
-                g = (((i < n) == (j < n)) ? coef : -coef) * dk;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const int64_t nchunks = gda_cdiv_dev(m, BJ);
+    float4 gq[2], tq[4];
+    auto fetch = [&](int64_t ch) {
+        const int64_t j0 = ch * BJ;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t j = j0 + g_r + 16 * q, i = i0 + g_c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < m) {
+                const float* p = L + j * m + i;
+                if (g_vec && i + 3 < m) v = *reinterpret_cast<const float4*>(p);
+                else {
+                    if (i + 0 < m) v.x = p[0];
+                    if (i + 1 < m) v.y = p[1];
+                    if (i + 2 < m) v.z = p[2];
+                    if (i + 3 < m) v.w = p[3];
+                }
             }
-            Gs[jj][ii] = g;
+            gq[q] = v;
         }
-        for (int f = tid; f < BJ * (DC / 4); f += TB) {
-            const int jj = f / (DC / 4), c4 = (f % (DC / 4)) * 4;
-            const int64_t j = j0 + jj;
-            const float* p = j < m ? row_ptr(R, t, j) : nullptr;
-            *reinterpret_cast<float4*>(&Ts[jj][c4]) = load4(p, c0 + c4, d, R.vec4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t j = j0 + t_r + 8 * q;
+            tq[q] = load4(j < m ? row_ptr(R, t, j) : nullptr, c0 + t_c4, d, R.vec4);
         }
+    };
+    auto stash = [&](int b) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *reinterpret_cast<float4*>(&Gs[b][g_r + 16 * q][g_c4]) = gq[q];
+            rs[0] += gq[q].x; rs[1] += gq[q].y; rs[2] += gq[q].z; rs[3] += gq[q].w;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(&Ts[b][t_r + 8 * q][t_c4]) = tq[q];
+    };
+
+    // this segment's chunks: seg, seg + nseg, ...
+    int64_t ch = seg;
+    int buf = 0;
+    if (ch < nchunks) { fetch(ch); stash(0); }
+    __syncthreads();
+    for (; ch < nchunks; ch += nseg) {
+        const bool more = ch + nseg < nchunks;
+        if (more) fetch(ch + nseg);                        // in flight during the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < BJ; kk += 2) {
+            const float av = Gs[buf][kk + ka][wr + la];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Ts[buf][kk + ka][wc + la], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Ts[buf][kk + ka][wc + 32 + la], acc1, 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
         __syncthreads();
-        if (tid < BI) {
-#pragma unroll 8
-            for (int jj = 0; jj < BJ; ++jj) rs += Gs[jj][tid];
-        }
-#pragma unroll 8
-        for (int jj = 0; jj < BJ; jj += 2) {
-            const float av = Gs[jj + ka][la];
-            const float bv = Ts[jj + ka][wave * 32 + la];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-        }
+        buf ^= 1;
     }
-    if (tid < BI) rowsum[tid] = rs;
+
+    // row sums of g over this segment: 16 threads hold partials for the same 4 rows
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rs_part[g_r][g_c4 + e] = rs[e];
+    __syncthreads();
+    if (tid < BI) {
+        float sres = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sres += rs_part[k][tid];
+        rowsum[tid] = sres;
+    }
     __syncthreads();
 
-    // epilogue: part[t][seg][i][c] = rowsum[i] * total[i][c] - acc   (the factor 4 is applied by the reduce)
+    // epilogue: part[t][seg][i][c] = c * (rowsum[i] * total[i][c] - acc)   (factor 4 in the reduce)
+    const float coef = grad_loss[0] / ((float)n * (float)n) / (float)times;
     float* out = part + (((int64_t)t * nseg + seg) * m) * d;
-    const int64_t c = c0 + wave * 32 + la;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int il = (r & 3) + 8 * (r >> 2) + 4 * ka;             // C/D layout of the 32x32 MFMA
-        const int64_t i = i0 + il;
-        if (i < m && c < d) {
-            const float ti = row_ptr(R, t, i)[c];
-            out[i * d + c] = fmaf(rowsum[il], ti, -acc[r]);
+    for (int half = 0; half < 2; ++half) {
+        const int64_t c = c0 + wc + 32 * half + la;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int il = wr + (r & 3) + 8 * (r >> 2) + 4 * ka;     // C/D layout of the 32x32 MFMA
+            const int64_t i = i0 + il;
+            if (i < m && c < d) {
+                const float ti = row_ptr(R, t, i)[c];
+                const float a = half == 0 ? acc0[r] : acc1[r];
+                out[i * d + c] = coef * fmaf(rowsum[il], ti, -a);
+            }
         }
     }
 }
@@ -391,9 +417,9 @@ k_bwd_reduce(const float* __restrict__ part, int64_t per_t, int nseg, int times,
     }
 }
 
-constexpr int BWD_NSEG = 4;
+constexpr int BWD_NSEG = 8;
 
-struct MmdWs { double* partial; double* kpartial; float* bwd_part; size_t total; };
+struct MmdWs { double* partial; double* kpartial; float* bwd_part; float* norms; size_t total; };
 
 MmdWs carve(void* base, int times, int64_t n, int64_t d) {
     const int64_t m = 2 * n, nt = gda_cdiv(m, TILE);
@@ -407,6 +433,7 @@ MmdWs carve(void* base, int times, int64_t n, int64_t d) {
     w.partial = (double*)take(sizeof(double) * times * nt * nt);
     w.kpartial = (double*)take(sizeof(double) * times * nt * nt);
     w.bwd_part = (float*)take(sizeof(float) * times * BWD_NSEG * m * (d > 0 ? d : 1));
+    w.norms = (float*)take(sizeof(float) * times * m);
     w.total = off;
     return w;
 }
@@ -451,7 +478,9 @@ extern "C" int gda_mmd_fwd_f32(const float* src, int64_t ld_src, const float* tg
     const Rows R = make_rows(src, ld_src, tgt, ld_tgt, src_idx, tgt_idx, n);
     const KParams kp{kernel_mul, kernel_num, fix_sigma};
     const dim3 grid(nt, nt, (unsigned)times);
-    k_pairdist<<<grid, TB, 0, stream>>>(R, d, m, l2_saved, ws.partial);
+    k_rownorm<<<(unsigned)gda_cdiv((int64_t)times * m, TB), TB, 0, stream>>>(R, d, m, times, ws.norms);
+    GDA_LAUNCH_CHECK();
+    k_pairdist<<<grid, TB, 0, stream>>>(R, d, m, ws.norms, l2_saved, ws.partial);
     GDA_LAUNCH_CHECK();
     k_bandwidth<<<(unsigned)times, TB, 0, stream>>>(ws.partial, (int)(nt * nt), m, kp, bandwidth);
     GDA_LAUNCH_CHECK();

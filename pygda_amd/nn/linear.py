@@ -27,6 +27,35 @@ def zeros(t):
             t.fill_(0)
 
 
+class _TallLinear(torch.autograd.Function):
+    """``y = x W^T`` for a tall ``x [N, in]`` and a small ``W [out, in]`` (the hidden and classifier
+    layers: N = nodes, in/out <= 128).  Forward and ``gx`` are well-shaped BLAS GEMMs; the weight
+    gradient ``gW = gy^T x`` has a tiny output and a reduction over N, for which the BLAS picks a
+    single-tile, no-split-K kernel (60 us at N = 9360).  Here the reduction is cut into S row
+    slabs -- one batched GEMM over the slabs, then a sum over S: a deterministic split-K."""
+    SLABS = 32
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return F.linear(x, weight)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            n, s = x.size(0), _TallLinear.SLABS
+            rows = (n // s) * s
+            gyv = gy[:rows].reshape(s, n // s, gy.size(1))
+            xv = x[:rows].reshape(s, n // s, x.size(1))
+            gw = torch.bmm(gyv.transpose(1, 2), xv).sum(0)
+            if rows < n:
+                gw = gw + gy[rows:].t() @ x[rows:]
+        return gx, gw
+
+
 class Linear(nn.Module):
     def __init__(self, in_channels, out_channels, bias=True, weight_initializer="glorot"):
         super().__init__()
@@ -48,6 +77,9 @@ class Linear(nn.Module):
             sf = sparse_features.lookup(x)             # identity lookup: input feature matrices only
             if sf is not None:
                 return sparse_features.sparse_linear(self.weight, sf)
+        if (self.bias is None and x.dim() == 2 and x.is_cuda and x.size(0) >= 2048
+                and self.in_channels <= 256 and self.out_channels <= 256 and torch.is_grad_enabled()):
+            return _TallLinear.apply(x, self.weight)
         if profiler.enabled:
             n = x.numel() // x.size(-1)
             with profiler.region(f"dense_projection[{self.in_channels}x{self.out_channels}]", 1,
