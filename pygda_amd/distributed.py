@@ -18,7 +18,12 @@ def info():
 
 
 def active():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True when the data-parallel exchange steps must run.  ``PYGDA_AMD_FORCE_DP=1`` switches them
+    on for a 1-rank group too (single-GPU test of the multi-GPU code path)."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("PYGDA_AMD_FORCE_DP") == "1"
 
 
 def allreduce_grads(params):
@@ -49,7 +54,10 @@ class _AllGatherRows(torch.autograd.Function):
     def forward(ctx, x):
         w = dist.get_world_size()
         out = torch.empty((w,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-        dist.all_gather(list(out.unbind(0)), x.contiguous())
+        if dist.get_backend() == "nccl":       # single-buffer form: no staging copies, graph-capturable
+            dist.all_gather_into_tensor(out, x.contiguous())
+        else:
+            dist.all_gather(list(out.unbind(0)), x.contiguous())
         ctx.rank, ctx.world = dist.get_rank(), w
         return out
 

@@ -119,8 +119,11 @@ class BaseGDA(ABC):
         if getattr(self, "_graphed", None) is not None and self._graphed_key == id(optimizer):
             return self._graphed
         from ..distributed import active
-        if active() or not torch.cuda.is_available():
+        if not torch.cuda.is_available():
             return None
+        if active():
+            return None       # RCCL collectives abort under stream capture on this stack (ROCm 7.0 /
+                              # torch 2.10): data-parallel steps stay eager
         if not (getattr(self.source_loader, "full_batch", False) and getattr(self.target_loader, "full_batch", False)):
             return None
         if not any(g.get("capturable", False) for g in optimizer.param_groups):

@@ -629,3 +629,38 @@ def test_spmm_long_rows_split_matches_dense():
     # narrow width through the same path
     x5 = torch.randn(n, 5, generator=gen)
     close(ops.spmm_kstep(g, x5.to(DEV), 1), O.propagate(nei, nw, x5), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------- data-parallel code path on one GPU (RCCL) --
+def test_dp_path_single_rank_nccl(monkeypatch):
+    """The multi-GPU exchange steps (flat gradient all-reduce, all-gathered global-batch MMD)
+    executed over a 1-rank RCCL group on this GPU: with one rank they must reproduce the
+    single-process step exactly (same CPU-generator draws, same kernels)."""
+    import torch.distributed as dist
+    import socket
+    g = load_golden("a2gnn_fit3_mmd")
+    s, t = _pair(g)
+
+    def run(dp):
+        m = pygda_amd.models.A2GNN(24, 16, 5, num_layers=2, dropout=0.0, s_pnums=0, t_pnums=10, weight=10,
+                                   lr=0.01, weight_decay=0.005, device=DEV, epoch=2, verbose=0)
+        seen = []
+        m.epoch_hook = lambda e, loss, acc, secs: seen.append(loss)
+        torch.manual_seed(int(g["seed"]))
+        m.fit(s, t)
+        return seen, m.predict(t)[0]
+
+    base_losses, base_logits = run(False)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1"); monkeypatch.setenv("MASTER_PORT", str(port))
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        monkeypatch.setenv("PYGDA_AMD_FORCE_DP", "1")
+        from pygda_amd import distributed as D
+        assert D.active()
+        dp_losses, dp_logits = run(True)
+    finally:
+        dist.destroy_process_group()
+    close(dp_losses, base_losses, rtol=1e-5)
+    close(dp_logits, base_logits, rtol=0, atol=1e-5)
