@@ -57,6 +57,24 @@ def make_cfg_a(seed=200, ns=9360, es=15556, nt=5484, et=8117, feat=6775, classes
     return graph(ns, es), graph(nt, et)
 
 
+def pmc_traffic(prefix="k_spmm<32, 4>"):
+    """HBM-side bytes per launch of the aggregation kernel from the committed rocprofv3 PMC passes
+    (profiles/*_rocprof_summary.json, made by tools/summarize_rocprof.py: separate --pmc FETCH_SIZE
+    and --pmc WRITE_SIZE runs of this same command, 2 x FETCH + WRITE per the gfx950 correction).
+    PMC counters cannot be collected from inside the timed run; None if no summary is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.json")))
+    for f in reversed(files):
+        try:
+            pmc = json.load(open(f)).get("pmc", {})
+        except Exception:
+            continue
+        for k, v in pmc.items():
+            if k.startswith(prefix):
+                return v["traffic_bytes"], os.path.basename(f)
+    return None, None
+
+
 def edges_per_step(nnz_s, nnz_t, L, s_p, t_p):
     return nnz_s * (4 * L * s_p + 2) + nnz_t * (3 * L * t_p + 1)
 
@@ -167,8 +185,10 @@ def main():
             secs = r["ms"] * 1e-3
             if name.startswith("spmm"):
                 ach = r["bytes"] / secs / 1e9
+                traffic, src_file = pmc_traffic() if "d=128" in name else (None, None)
                 return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": r["launches"],
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src_file,
+                        "launches": r["launches"],
                         "avg_launch_us": r["avg_us"], "algorithmic_bytes_per_launch": r["bytes"] / r["launches"]}
             ach = r["flops"] / secs / 1e12
             return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
