@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--adv", action="store_true", help="adversarial branch instead of MMD")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the data-parallel code path (RCCL exchange steps) on a 1-rank group")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,9 +121,27 @@ def main():
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.force_dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ["PYGDA_AMD_FORCE_DP"] = "1"
+        # RCCL prints a version banner through C stdio on stdout when the communicator comes up; keep
+        # stdout for the ONE JSON line: route fd 1 to stderr until the banner has been flushed
+        import ctypes
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+            warm = torch.ones(1, device=dev)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            ctypes.CDLL(None).fflush(None)
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     import pygda_amd
     from pygda_amd import profiler
@@ -151,6 +171,7 @@ def main():
     edges = edges_per_step(nnz_s, nnz_t, hp["L"], hp["s_pnums"], hp["t_pnums"])
 
     graphed = getattr(model, "_graphed", None) is not None
+    model._graphed_kind = "dp" if type(getattr(model, "_graphed", None)).__name__ == "GraphedStepDP" else "single"
     from pygda_amd import ops as _ops
     _ops.aggregated_edges = 0
     sync()
@@ -213,7 +234,9 @@ def main():
                                "shared by the two passes the reference runs separately (identical values), so a "
                                "step executes fewer aggregations than the reference's step",
                        "nnz_source": nnz_s, "nnz_target": nnz_t,
-                       "execution": "hipGraph replay of the captured step" if graphed else "eager launches",
+                       "execution": ("four hipGraph segments with eager RCCL collectives between them"
+                                     if type(getattr(model, "_graphed_kind", None)).__name__ == "str" and model._graphed_kind == "dp"
+                                     else "hipGraph replay of the captured step") if graphed else "eager launches",
                        "parallelism": "single GPU" if world == 1 else
                        f"dp{world}: one full-batch replica per GPU (cfg-A has one batch per epoch), "
                        "independent dropout draws, global-batch MMD over all-gathered sample rows, "
@@ -228,7 +251,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(src, tgt, hp, edges)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -87,7 +87,9 @@ class GraphedStep:
             torch.cuda.current_stream().wait_stream(side)
             self._refill()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # thread_local: API calls of other threads (RCCL's watchdog polls events) must not
+            # invalidate the capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 loss, logits = self._run()
             self.loss, self.logits = loss.detach(), logits.detach()
             with torch.no_grad():
@@ -105,4 +107,108 @@ class GraphedStep:
     def __call__(self):
         self._refill()
         self.graph.replay()
+        return self.loss, self.logits
+
+
+class GraphedStepDP:
+    """Data-parallel variant: RCCL collectives cannot be stream-captured on this stack, so the
+    step is cut at its two exchange points into four hipGraphs with the collectives launched
+    eagerly between them (same stream, so ordering is automatic):
+
+        G1  encoders, source CE, local MMD row samples            (forward, autograd tape kept)
+        --  all_gather(source rows), all_gather(target rows)      (RCCL)
+        G2  global-batch MMD forward + its gradient w.r.t. the rows; slice own rows, x W
+        G3  backward of G1 from (CE, row gradients) -> flat gradient buffer
+        --  all_reduce(flat gradients)                            (RCCL)
+        G4  average, Adam
+
+    ``part1(src, tgt, idx_s, idx_t) -> (loss_ce, source_logits, rows_s, rows_t)`` and
+    ``part2(rows_s_all, rows_t_all) -> weighted mmd`` come from the trainer.  The graphs share
+    one memory pool, the technique of torch.cuda.make_graphed_callables (forward and backward of
+    a section as separate graphs over static tensors)."""
+
+    def __init__(self, part1, part2, optimizer, src, tgt, times=5, sampling_num=1000):
+        import torch.distributed as dist
+        self.part1, self.part2, self.optimizer, self.src, self.tgt = part1, part2, optimizer, src, tgt
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.times, self.per = times, -(-sampling_num // self.world)
+        dev = src.x.device
+        shape = (times, self.per)
+        self.idx = [torch.zeros(shape, dtype=torch.int64, device=dev) for _ in range(2)]
+        self.pin = [torch.zeros(shape, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.loss = self.logits = None
+
+    def _refill(self):                       # the eager data-parallel MMD()'s draws, same order
+        torch.randint(self.src.x.size(0), tuple(self.pin[0].shape), out=self.pin[0])
+        torch.randint(self.tgt.x.size(0), tuple(self.pin[1].shape), out=self.pin[1])
+        for d, p in zip(self.idx, self.pin):
+            d.copy_(p, non_blocking=True)
+
+    def capture(self, eager_step, warmup=2):
+        import torch.distributed as dist
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        saved = [p.detach().clone() for p in params]
+        cpu_rng = torch.get_rng_state()
+        for _ in range(warmup):              # RCCL + allocator + optimiser-state warm-up, rolled back below
+            eager_step()
+        torch.cuda.synchronize()
+        self._refill()
+        dev = self.src.x.device
+        W, rank = self.world, self.rank
+        g1, g2, g3, g4 = (torch.cuda.CUDAGraph() for _ in range(4))
+        mode = dict(capture_error_mode="thread_local")    # RCCL's watchdog thread polls events meanwhile
+        with torch.cuda.graph(g1, **mode):
+            loss_ce, logits, rows_s, rows_t = self.part1(self.src, self.tgt, self.idx[0], self.idx[1])
+        pool = g1.pool()
+        self.gath = [torch.zeros((W,) + tuple(rows_s.shape), dtype=torch.float32, device=dev, requires_grad=True),
+                     torch.zeros((W,) + tuple(rows_t.shape), dtype=torch.float32, device=dev, requires_grad=True)]
+        d = rows_s.size(-1)
+        with torch.cuda.graph(g2, pool=pool, **mode):
+            S = self.gath[0].permute(1, 0, 2, 3).reshape(self.times, W * self.per, d)
+            T = self.gath[1].permute(1, 0, 2, 3).reshape(self.times, W * self.per, d)
+            dom = self.part2(S, T)
+            gS, gT = torch.autograd.grad(dom, self.gath)
+            g_rows_s, g_rows_t = gS[rank] * float(W), gT[rank] * float(W)
+            total = loss_ce.detach() + dom.detach()
+        one = torch.ones((), dtype=torch.float32, device=dev)
+        with torch.cuda.graph(g3, pool=pool, **mode):
+            grads = torch.autograd.grad([loss_ce, rows_s, rows_t], params, [one, g_rows_s, g_rows_t],
+                                        allow_unused=True)
+            flat = torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1)
+                              for g, p in zip(grads, params)])
+        off = 0
+        for p in params:                     # the optimiser reads static views of the reduced buffer
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        with torch.cuda.graph(g4, pool=pool, **mode):
+            flat.div_(float(W))
+            self.optimizer.step()
+        self._graphs, self._rows, self._flat = (g1, g2, g3, g4), (rows_s, rows_t), flat
+        # every tensor a captured kernel reads must outlive the graphs: `one` in particular lives in
+        # the ordinary pool, and once freed its block would be recycled by eager allocations
+        self._keep = (one, loss_ce, logits, gS, gT, g_rows_s, g_rows_t, dom, total, grads)
+        self.loss, self.logits = total, logits.detach()
+        with torch.no_grad():                # roll the warm-up back: a seeded fit() takes the eager steps
+            for p, v in zip(params, saved):
+                p.copy_(v)
+            for st in self.optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        torch.set_rng_state(cpu_rng)
+        self.graph = g1
+        return self
+
+    def __call__(self):
+        import torch.distributed as dist
+        g1, g2, g3, g4 = self._graphs
+        self._refill()
+        g1.replay()
+        with torch.no_grad():
+            dist.all_gather_into_tensor(self.gath[0], self._rows[0].detach())
+            dist.all_gather_into_tensor(self.gath[1], self._rows[1].detach())
+        g2.replay()
+        g3.replay()
+        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
+        g4.replay()
         return self.loss, self.logits

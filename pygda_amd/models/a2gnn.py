@@ -82,6 +82,31 @@ class A2GNN(BaseGDA):
             target_logits = None
         return loss, source_logits, target_logits
 
+    def _dp_graph_parts(self):
+        """The MMD step cut at its all-gather (pygda_amd/hipgraph.py::GraphedStepDP): everything up
+        to the local row samples, and the global-batch MMD on the gathered rows."""
+        from ..ops import mmd_loss_rows, sample_rows
+
+        def part1(src, tgt, idx_s, idx_t):
+            net = self.a2gnn
+            h0_s = net.first_conv(src.x, src.edge_index, self.s_pnums)
+            h0_t = net.first_conv(tgt.x, tgt.edge_index, self.t_pnums)
+            pending = self._target_logits_async(net, tgt, h0_t) if self.compute_target_logits else None
+            feats = net.feat_bottleneck_from(h0_s, src.edge_index, None, self.s_pnums)
+            source_logits = net.feat_classifier(feats, src.edge_index, None, 1)
+            loss_ce = F.nll_loss(F.log_softmax(source_logits, dim=1), src.y)
+            sf = net.feat_bottleneck_from(h0_s, src.edge_index, None, self.s_pnums)
+            tf = net.feat_bottleneck_from(h0_t, tgt.edge_index, None, self.t_pnums)
+            rows_s, rows_t = sample_rows(sf, idx_s), sample_rows(tf, idx_t)
+            if pending is not None:
+                torch.cuda.current_stream().wait_stream(pending[1])
+            return loss_ce, source_logits, rows_s, rows_t
+
+        def part2(rows_s_all, rows_t_all):
+            return mmd_loss_rows(rows_s_all, rows_t_all) * self.weight
+
+        return part1, part2
+
     def _prepare(self, source_data, target_data):
         """Everything fit() does before its epoch loop (a2gnn.py:254-296)."""
         if self.mode != 'node':

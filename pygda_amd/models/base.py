@@ -121,17 +121,29 @@ class BaseGDA(ABC):
         from ..distributed import active
         if not torch.cuda.is_available():
             return None
-        if active():
+        dp = active()
+        if dp and not hasattr(self, "_dp_graph_parts"):
             return None       # RCCL collectives abort under stream capture on this stack (ROCm 7.0 /
-                              # torch 2.10): data-parallel steps stay eager
+                              # torch 2.10): without a segmented step, data-parallel training stays eager
         if not (getattr(self.source_loader, "full_batch", False) and getattr(self.target_loader, "full_batch", False)):
             return None
         if not any(g.get("capturable", False) for g in optimizer.param_groups):
             return None
-        from ..hipgraph import GraphedStep
+        from ..hipgraph import GraphedStep, GraphedStepDP
         src = next(iter(self.source_loader)).to(self.device)
         tgt = next(iter(self.target_loader)).to(self.device)
         (before_step or net.train)()
+        if dp:                # collectives stay eager between four captured segments
+            def eager_step():
+                loss, _ = step_fn(src, tgt, 0.0, 0)
+                optimizer.zero_grad()
+                loss.backward()
+                _allreduce_grads(optimizer)
+                optimizer.step()
+            part1, part2 = self._dp_graph_parts()
+            self._graphed = GraphedStepDP(part1, part2, optimizer, src, tgt).capture(eager_step)
+            self._graphed_key = id(optimizer)
+            return self._graphed
         self._graphed = GraphedStep(lambda s, t: step_fn(s, t, 0.0, 0), optimizer, src, tgt).capture()
         self._graphed_key = id(optimizer)
         return self._graphed

@@ -664,3 +664,32 @@ def test_dp_path_single_rank_nccl(monkeypatch):
         dist.destroy_process_group()
     close(dp_losses, base_losses, rtol=1e-5)
     close(dp_logits, base_logits, rtol=0, atol=1e-5)
+
+
+def test_dp_segmented_hipgraph_single_rank_nccl(monkeypatch):
+    """Data-parallel step as four hipGraphs with the RCCL collectives launched eagerly between
+    them (pygda_amd/hipgraph.py::GraphedStepDP), over a 1-rank group: same 3-epoch trajectory as
+    the reference golden (per-epoch loss, final logits)."""
+    import torch.distributed as dist
+    import socket
+    g = load_golden("a2gnn_fit3_mmd")
+    s, t = _pair(g)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1"); monkeypatch.setenv("MASTER_PORT", str(port))
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        monkeypatch.setenv("PYGDA_AMD_FORCE_DP", "1")
+        m = pygda_amd.models.A2GNN(24, 16, 5, num_layers=2, dropout=0.0, s_pnums=0, t_pnums=10, weight=10,
+                                   lr=0.01, weight_decay=0.005, device=DEV, epoch=3, verbose=0, use_hip_graph=True)
+        seen = []
+        m.epoch_hook = lambda e, loss, acc, secs: seen.append(loss)
+        torch.manual_seed(int(g["seed"]))
+        m.fit(s, t)
+        from pygda_amd.hipgraph import GraphedStepDP
+        assert isinstance(getattr(m, "_graphed", None), GraphedStepDP)
+        logits, _ = m.predict(t)
+    finally:
+        dist.destroy_process_group()
+    close(seen, g["losses"], rtol=REL)
+    close(logits, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
