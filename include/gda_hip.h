@@ -71,6 +71,16 @@ int gda_build_csr_norm(const int64_t* src, const int64_t* dst, const float* w,
                        int32_t* t_rowptr, int32_t* t_colidx, float* t_val,
                        void* workspace, size_t workspace_bytes, gda_stream_t stream);
 
+/* Same, and additionally t_to_fwd [E+N]: for entry k' of the by-source CSR, the position of the
+ * same edge in the by-destination CSR -- lets a backward pass that walks the transpose read
+ * per-edge quantities (attention coefficients) stored in forward order. */
+int gda_build_csr_norm_map(const int64_t* src, const int64_t* dst, const float* w,
+                           int64_t E, int64_t N, float fill_value, int add_self_loops,
+                           int normalize, int degree_side,
+                           int32_t* rowptr, int32_t* colidx, float* val,
+                           int32_t* t_rowptr, int32_t* t_colidx, float* t_val, int32_t* t_to_fwd,
+                           void* workspace, size_t workspace_bytes, gda_stream_t stream);
+
 /* Expand a CSR back to the COO edge_index the reference returns from gcn_norm, in
  * CSR order; nnz_cap >= rowptr[N] bounds the launch (entries past rowptr[N] untouched). */
 int gda_csr_to_coo(const int32_t* rowptr, const int32_t* colidx, int64_t N, int64_t nnz_cap,
@@ -127,6 +137,29 @@ int gda_spmm_csr_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const f
                            int64_t n_rows, int64_t d, int K, const float* x, int64_t ldx,
                            float* y, int64_t ldy, float* tmp, const float* bias,
                            gda_stream_t stream);
+
+/* ------------------------------------------------------------------------------
+ * GAT aggregation (single head): edge-softmax attention + weighted neighbour sum, fused.
+ *
+ * Replaces PyG GATConv(heads=1, concat=False) as GNNBase(gnn='gat') uses it
+ * (pygda/nn/gnn_base.py:80-87): for destination i over its incoming edges k (self loop
+ * included by the ingestion),  e_k = LeakyReLU_slope(a_src[col_k] + a_dst[i]),
+ * alpha = softmax_k(e),  out[i,:] = sum_k alpha_k h[col_k,:].   h = x W^T and the two
+ * attention logits a_src = h.att_src, a_dst = h.att_dst are formed by the caller (dense).
+ *   forward : out [N,d]; alpha [nnz] (by-destination order, kept for backward)
+ *   backward: given gout [N,d] ->  gh [N,d] (the aggregation path only), ga_src [N], ga_dst [N];
+ *             the caller adds the dense chain  gh += ga_src att_src + ga_dst att_dst.
+ *             needs the by-source CSR and t_to_fwd from gda_build_csr_norm_map;
+ *             dpre [nnz] is caller-owned scratch.
+ * ---------------------------------------------------------------------------- */
+int gda_gat_fwd_f32(const int32_t* rowptr, const int32_t* colidx, int64_t n_rows, int64_t d,
+                    const float* h, const float* a_src, const float* a_dst, float slope,
+                    float* out, float* alpha, gda_stream_t stream);
+int gda_gat_bwd_f32(const int32_t* rowptr, const int32_t* colidx,
+                    const int32_t* t_rowptr, const int32_t* t_colidx, const int32_t* t_to_fwd,
+                    int64_t n_rows, int64_t d, const float* h, const float* a_src, const float* a_dst,
+                    float slope, const float* alpha, const float* gout,
+                    float* gh, float* ga_src, float* ga_dst, float* dpre, gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
  * Multi-kernel Gaussian MMD over sampled rows, forward and backward, with no

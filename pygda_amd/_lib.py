@@ -20,6 +20,11 @@ _SIGNATURES = {
     "gda_graph_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "gda_build_csr_norm": (c_int, [_P, _P, _P, c_int64, c_int64, c_float, c_int, c_int, c_int,
                                    _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gda_build_csr_norm_map": (c_int, [_P, _P, _P, c_int64, c_int64, c_float, c_int, c_int, c_int,
+                                       _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gda_gat_fwd_f32": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, c_float, _P, _P, _P]),
+    "gda_gat_bwd_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, _P, _P, _P, c_float, _P, _P,
+                                _P, _P, _P, _P, _P]),
     "gda_csr_to_coo": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P]),
     "gda_spmm_csr_f32": (c_int, [_P, _P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P]),
     "gda_spmm_csr_kstep_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P, c_int64,

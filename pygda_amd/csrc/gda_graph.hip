@@ -28,6 +28,7 @@ struct GraphWs {
     int32_t* iota;       // [cap]
     int32_t* keys_out;   // [cap]
     int32_t* perm;       // [cap]
+    int32_t* inv_perm;   // [cap] list index -> position in the by-destination CSR
     float* deg;          // [N]
     float* dis;          // [N]
     void* cub;           // hipcub temp storage
@@ -61,6 +62,7 @@ GraphWs carve(void* base, int64_t E, int64_t N) {
     w.iota = (int32_t*)take(sizeof(int32_t) * (cap + 1));
     w.keys_out = (int32_t*)take(sizeof(int32_t) * (cap + 1));
     w.perm = (int32_t*)take(sizeof(int32_t) * (cap + 1));
+    w.inv_perm = (int32_t*)take(sizeof(int32_t) * (cap + 1));
     w.deg = (float*)take(sizeof(float) * (N + 1));
     w.dis = (float*)take(sizeof(float) * (N + 1));
     w.cub_bytes = cub_bytes_needed(E, cap);
@@ -125,6 +127,21 @@ __global__ void k_csr_fill(const int32_t* __restrict__ keys_sorted, const int32_
     const int32_t p = perm[k];
     colidx[k] = other[p];
     val[k] = nw[p];
+}
+
+// inv[perm[k]] = k   (list index -> CSR position), for the transpose-to-forward edge map
+__global__ void k_invert(const int32_t* __restrict__ perm, int64_t cap, int32_t* __restrict__ inv) {
+    int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (k < cap) inv[perm[k]] = (int32_t)k;
+}
+
+// t_to_fwd[k'] = position in the by-destination CSR of the edge stored at k' of the by-source CSR
+__global__ void k_edge_map(const int32_t* __restrict__ keys_sorted, const int32_t* __restrict__ perm,
+                           const int32_t* __restrict__ inv, int64_t cap, int64_t N,
+                           int32_t* __restrict__ t_to_fwd) {
+    int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (k >= cap || keys_sorted[k] >= N) return;
+    t_to_fwd[k] = inv[perm[k]];
 }
 
 __global__ void k_rowptr(const int32_t* __restrict__ keys_sorted, int64_t cap, int64_t N,
@@ -257,6 +274,18 @@ extern "C" int gda_build_csr_norm(const int64_t* src, const int64_t* dst, const 
                                   int32_t* rowptr, int32_t* colidx, float* val,
                                   int32_t* t_rowptr, int32_t* t_colidx, float* t_val,
                                   void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    return gda_build_csr_norm_map(src, dst, w, E, N, fill_value, add_self_loops, normalize, degree_side,
+                                  rowptr, colidx, val, t_rowptr, t_colidx, t_val, nullptr, workspace,
+                                  workspace_bytes, stream_);
+}
+
+extern "C" int gda_build_csr_norm_map(const int64_t* src, const int64_t* dst, const float* w,
+                                      int64_t E, int64_t N, float fill_value, int add_self_loops,
+                                      int normalize, int degree_side,
+                                      int32_t* rowptr, int32_t* colidx, float* val,
+                                      int32_t* t_rowptr, int32_t* t_colidx, float* t_val,
+                                      int32_t* t_to_fwd,
+                                      void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
     if (E < 0 || N < 0 || E + N >= INT32_MAX) return GDA_E_SIZE;
     if ((E > 0 && (!src || !dst)) || !rowptr || !t_rowptr || !workspace) return GDA_E_NULL;
     const int64_t cap = E + N;
@@ -295,6 +324,11 @@ extern "C" int gda_build_csr_norm(const int64_t* src, const int64_t* dst, const 
         GDA_LAUNCH_CHECK();
         k_rowptr<<<gN, TB, 0, stream>>>(ws.keys_out, cap, N, rp);
         GDA_LAUNCH_CHECK();
+        if (t_to_fwd) {
+            if (pass == 0) k_invert<<<gC, TB, 0, stream>>>(ws.perm, cap, ws.inv_perm);
+            else k_edge_map<<<gC, TB, 0, stream>>>(ws.keys_out, ws.perm, ws.inv_perm, cap, N, t_to_fwd);
+            GDA_LAUNCH_CHECK();
+        }
     }
     if (normalize) {
         if (degree_side == 0) k_degree<<<gN, TB, 0, stream>>>(rowptr, val, N, ws.deg, ws.dis);

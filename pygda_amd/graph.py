@@ -61,7 +61,7 @@ class CSRGraph:
     ``t_rowptr/t_colidx/t_val``: rows = source nodes (the transpose, backward)."""
 
     __slots__ = ("num_nodes", "nnz_cap", "rowptr", "colidx", "val", "t_rowptr", "t_colidx",
-                 "t_val", "_nnz", "device", "_split", "_t_split")
+                 "t_val", "_nnz", "device", "_split", "_t_split", "t_to_fwd")
 
     def __init__(self, num_nodes, nnz_cap, rowptr, colidx, val, t_rowptr, t_colidx, t_val):
         self.num_nodes, self.nnz_cap = num_nodes, nnz_cap
@@ -70,6 +70,7 @@ class CSRGraph:
         self._nnz = None
         self.device = rowptr.device
         self._split = self._t_split = None
+        self.t_to_fwd = None      # by-source entry -> by-destination position (built on request)
 
     def split(self, transposed=False):
         """Long-row layout of the forward (or transposed) CSR, built on first use."""
@@ -106,7 +107,7 @@ class CSRGraph:
 
 
 def build_csr(edge_index, num_nodes, edge_weight=None, improved=False, add_self_loops=True,
-              normalize=True, degree_side="col", validate=True):
+              normalize=True, degree_side="col", validate=True, with_edge_map=False):
     """COO ``edge_index`` (row 0 = source, row 1 = destination) -> :class:`CSRGraph`.
 
     Semantics of gcn_norm (prop_gcn_conv.py:64-81; ``degree_side='col'``) and
@@ -138,13 +139,16 @@ def build_csr(edge_index, num_nodes, edge_weight=None, improved=False, add_self_
     L = _lib.lib()
     nbytes = L.gda_graph_workspace_bytes(E, N)
     ws = _lib.workspace(nbytes, dev, "graph")
-    _lib.check(L.gda_build_csr_norm(
+    edge_map = torch.empty(max(cap, 1), **i32) if with_edge_map else None
+    _lib.check(L.gda_build_csr_norm_map(
         _lib.ptr(src), _lib.ptr(dst), _lib.ptr(w), E, N, 2.0 if improved else 1.0,
         int(bool(add_self_loops)), int(bool(normalize)), 0 if degree_side == "col" else 1,
         _lib.ptr(rowptr), _lib.ptr(colidx), _lib.ptr(val),
-        _lib.ptr(t_rowptr), _lib.ptr(t_colidx), _lib.ptr(t_val),
-        _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_build_csr_norm")
-    return CSRGraph(N, cap, rowptr, colidx, val, t_rowptr, t_colidx, t_val)
+        _lib.ptr(t_rowptr), _lib.ptr(t_colidx), _lib.ptr(t_val), _lib.ptr(edge_map),
+        _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_build_csr_norm_map")
+    g = CSRGraph(N, cap, rowptr, colidx, val, t_rowptr, t_colidx, t_val)
+    g.t_to_fwd = edge_map
+    return g
 
 
 class _GraphCache:

@@ -10,8 +10,9 @@ from .grade_base import GRADEBase
 from .udagcn_base import UDAGCNBase
 from .adagcn_base import AdaGCNBase
 from .sage_gin_conv import SAGEConv, GINConv
+from .gat_conv import GATConv
 from .gnn_base import GNNBase
 
 __all__ = ["Linear", "glorot", "zeros", "PropGCNConv", "gcn_norm", "GCNConv", "CachedGCNConv", "PPMIConv",
-           "ppmi_edges", "GradReverse", "Attention", "A2GNNBase", "GRADEBase", "UDAGCNBase", "AdaGCNBase", "SAGEConv", "GINConv", "GNNBase",
+           "ppmi_edges", "GradReverse", "Attention", "A2GNNBase", "GRADEBase", "UDAGCNBase", "AdaGCNBase", "SAGEConv", "GINConv", "GATConv", "GNNBase",
            "global_mean_pool"]

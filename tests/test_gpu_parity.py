@@ -525,8 +525,8 @@ def test_gnn_trainer_golden():
     exact(logits.argmax(1), g["tgt_logits"].argmax(1))
 
 
-@pytest.mark.parametrize("kind", ["sage", "gin"])
-def test_sage_gin_vs_oracle(kind):
+@pytest.mark.parametrize("kind", ["sage", "gin", "gat"])
+def test_sage_gin_gat_vs_oracle(kind):
     gen = torch.Generator().manual_seed(9)
     n, f, h = 300, 24, 16
     ei = torch.randint(0, n, (2, 1500), generator=gen)
@@ -535,6 +535,8 @@ def test_sage_gin_vs_oracle(kind):
     ours = pygda_amd.nn.GNNBase(f, h, 4, num_layers=2, dropout=0.0, gnn=kind)
     ref = O.GNNBase(f, h, 4, num_layers=2, dropout=0.0, gnn=kind)
     ref.load_state_dict(ours.state_dict())
+    if kind == "gat":            # self loops in the input and duplicate edges exercise the loop merge
+        ei = torch.cat([ei, torch.tensor([[5, 9], [5, 9]]), ei[:, :20]], dim=1)
     ours = ours.to(DEV)
     xg = x.clone().to(DEV).requires_grad_()
     xr = x.clone().requires_grad_()
@@ -545,8 +547,6 @@ def test_sage_gin_vs_oracle(kind):
     close(xg.grad, xr.grad, rtol=1e-3, atol=1e-5)
     for (k, p), (_, q) in zip(ours.named_parameters(), ref.named_parameters()):
         close(p.grad, q.grad, rtol=1e-3, atol=1e-4 * max(float(q.grad.abs().max()), 1e-3))
-    with pytest.raises(NotImplementedError):
-        pygda_amd.nn.GNNBase(f, h, 4, gnn="gat")
 
 
 # ------------------------------------------------------- sparse layer-0 projection --
