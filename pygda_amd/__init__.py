@@ -3,8 +3,8 @@
 from . import _lib
 from .data import Data, NeighborLoader, to_undirected
 from .graph import CSRGraph, build_csr, graph_cache
-from . import nn, utils, metrics, models, ops
+from . import nn, utils, metrics, models, datasets, ops
 
 __version__ = "0.1.0"
 __all__ = ["Data", "NeighborLoader", "to_undirected", "CSRGraph", "build_csr", "graph_cache",
-           "nn", "utils", "metrics", "models", "ops"]
+           "nn", "utils", "metrics", "models", "datasets", "ops"]

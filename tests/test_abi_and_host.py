@@ -166,3 +166,16 @@ def test_citation_dataset_reader(tmp_path):
     assert torch.equal(again.train_mask, d.train_mask) and torch.equal(again.x, d.x)
     with pytest.raises(FileNotFoundError):
         CitationDataset(str(tmp_path / "nope"), "toy")
+
+
+def test_pygda_alias_package():
+    """Scripts written against the reference import ``pygda``; the alias resolves to this build."""
+    import pygda
+    from pygda.models import A2GNN as A, GRADE, UDAGCN, AdaGCN, DANE, GNN
+    from pygda.nn import PropGCNConv, CachedGCNConv, GradReverse, A2GNNBase
+    from pygda.utils import MMD, logger as lg
+    from pygda.metrics import eval_micro_f1 as f1
+    from pygda.datasets import CitationDataset
+    from pygda.nn.prop_gcn_conv import gcn_norm
+    assert A is A2GNN and PropGCNConv is pygda_amd.nn.PropGCNConv and MMD is pygda_amd.utils.MMD
+    assert f1 is eval_micro_f1 and lg is logger and gcn_norm is pygda_amd.nn.gcn_norm
