@@ -223,6 +223,21 @@ int gda_grl_disc_ce_bwd_f32(const float* feat_src, int64_t ld_src, int64_t n_src
 size_t gda_grl_disc_workspace_bytes(int64_t n_rows, int64_t h, int C);
 
 /* ------------------------------------------------------------------------------
+ * ReLU + inverted dropout, fused (the activation after every conv layer:
+ * pygda/nn/a2gnn_base.py:135-138, grade_base.py:146-148, gnn_base.py:166-168).
+ *   forward : y = (x > 0 && keep) ? x/(1-p) : 0, keep-bits from Philox-4x32-10 keyed on `seed`
+ *             with counter (step[0], site, element/4): `step` is a device int64 the trainer
+ *             increments once per training step (so hipGraph replays draw fresh masks), `site`
+ *             numbers the call sites inside a step.
+ *   backward: gx = (y > 0) ? gy/(1-p) : 0   -- needs only the saved output.
+ * x, y, gy, gx: n contiguous fp32 values, 16-byte aligned.
+ * ---------------------------------------------------------------------------- */
+int gda_relu_dropout_fwd_f32(const float* x, float* y, int64_t n, float p, uint64_t seed,
+                             const int64_t* step, uint32_t site, gda_stream_t stream);
+int gda_relu_dropout_bwd_f32(const float* gy, const float* y, float* gx, int64_t n, float p,
+                             gda_stream_t stream);
+
+/* ------------------------------------------------------------------------------
  * Feature-row gather  out[r,:] = x[idx[r],:]  (mini-batch assembly: the x[n_id]
  * slice PyG's NeighborLoader performs, pygda/models/a2gnn.py:260-277).
  * ---------------------------------------------------------------------------- */

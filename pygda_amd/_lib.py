@@ -43,6 +43,8 @@ _SIGNATURES = {
                                         _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gda_grl_disc_ce_bwd_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int,
                                         _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gda_relu_dropout_fwd_f32": (c_int, [_P, _P, c_int64, c_float, ctypes.c_uint64, _P, ctypes.c_uint32, _P]),
+    "gda_relu_dropout_bwd_f32": (c_int, [_P, _P, _P, c_int64, c_float, _P]),
     "gda_gather_rows_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P]),
     "gda_sampler_create": (c_int, [_P, _P, c_int64, c_int64, ctypes.POINTER(c_void_p)]),
     "gda_sampler_destroy": (None, [_P]),

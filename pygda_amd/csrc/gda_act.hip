@@ -1,0 +1,108 @@
+// Fused ReLU + inverted dropout for the activation that follows every conv layer
+// (pygda/nn/a2gnn_base.py:135-138: x = act(x); x = F.dropout(x, p, training)), gfx950.
+//
+//   forward : y = (x > 0 && keep) ? x / (1 - p) : 0        one pass, 16-byte accesses
+//   backward: gx = (y > 0) ? gy / (1 - p) : 0              (y > 0 <=> x > 0 and kept: no mask stored,
+//                                                            no random numbers needed again)
+// keep-bits come from a counter-based generator (Philox-4x32-10 keyed on the caller's seed, counter =
+// (step, call site, element/4)): reproducible, and safe under hipGraph replay because `step` is
+// read from device memory (the trainer bumps it once per step inside the captured graph) while
+// the call-site id is a launch constant.
+#include "gda_common.h"
+
+namespace {
+
+constexpr int TB = 256;
+
+struct Philox {
+    static __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+    static __device__ __forceinline__ void gen(uint64_t seed, uint64_t hi, uint64_t lo, uint32_t (&out)[4]) {
+        uint32_t c[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = c[i];
+    }
+};
+
+__global__ void __launch_bounds__(TB)
+k_relu_dropout_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p, float scale,
+                   uint64_t seed, const int64_t* __restrict__ step, uint32_t site) {
+    const uint64_t st = (uint64_t)step[0];
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (double)p * 4294967296.0);
+    const int64_t quads = (n + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x; q < quads; q += (int64_t)gridDim.x * TB) {
+        uint32_t r[4];
+        Philox::gen(seed, (st << 20) ^ site, (uint64_t)q, r);
+        const int64_t i = q * 4;
+        if (i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            float4 o;
+            o.x = (v.x > 0.f && r[0] >= thresh) ? v.x * scale : 0.f;
+            o.y = (v.y > 0.f && r[1] >= thresh) ? v.y * scale : 0.f;
+            o.z = (v.z > 0.f && r[2] >= thresh) ? v.z * scale : 0.f;
+            o.w = (v.w > 0.f && r[3] >= thresh) ? v.w * scale : 0.f;
+            *reinterpret_cast<float4*>(y + i) = o;
+        } else {
+            for (int e = 0; e < 4 && i + e < n; ++e)
+                y[i + e] = (x[i + e] > 0.f && r[e] >= thresh) ? x[i + e] * scale : 0.f;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(TB)
+k_relu_dropout_bwd(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gx,
+                   int64_t n, float scale) {
+    const int64_t quads = (n + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x; q < quads; q += (int64_t)gridDim.x * TB) {
+        const int64_t i = q * 4;
+        if (i + 3 < n) {
+            const float4 g = *reinterpret_cast<const float4*>(gy + i);
+            const float4 v = *reinterpret_cast<const float4*>(y + i);
+            float4 o;
+            o.x = v.x > 0.f ? g.x * scale : 0.f;
+            o.y = v.y > 0.f ? g.y * scale : 0.f;
+            o.z = v.z > 0.f ? g.z * scale : 0.f;
+            o.w = v.w > 0.f ? g.w * scale : 0.f;
+            *reinterpret_cast<float4*>(gx + i) = o;
+        } else {
+            for (int e = 0; e < 4 && i + e < n; ++e) gx[i + e] = y[i + e] > 0.f ? gy[i + e] * scale : 0.f;
+        }
+    }
+}
+
+unsigned grid_for(int64_t n) {
+    int64_t g = gda_cdiv((n + 3) / 4, TB);
+    if (g > 256 * 8) g = 256 * 8;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" int gda_relu_dropout_fwd_f32(const float* x, float* y, int64_t n, float p, uint64_t seed,
+                                        const int64_t* step, uint32_t site, gda_stream_t stream) {
+    if (n < 0 || !(p >= 0.f && p < 1.f)) return GDA_E_SIZE;
+    if (n == 0) return GDA_OK;
+    if (!x || !y || !step) return GDA_E_NULL;
+    if (((uintptr_t)x | (uintptr_t)y) % 16 != 0) return GDA_E_UNSUPPORTED;
+    k_relu_dropout_fwd<<<grid_for(n), TB, 0, (hipStream_t)stream>>>(x, y, n, p, 1.f / (1.f - p), seed, step, site);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+extern "C" int gda_relu_dropout_bwd_f32(const float* gy, const float* y, float* gx, int64_t n, float p,
+                                        gda_stream_t stream) {
+    if (n < 0 || !(p >= 0.f && p < 1.f)) return GDA_E_SIZE;
+    if (n == 0) return GDA_OK;
+    if (!gy || !y || !gx) return GDA_E_NULL;
+    if (((uintptr_t)gy | (uintptr_t)y | (uintptr_t)gx) % 16 != 0) return GDA_E_UNSUPPORTED;
+    k_relu_dropout_bwd<<<grid_for(n), TB, 0, (hipStream_t)stream>>>(gy, y, gx, n, 1.f / (1.f - p));
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}

@@ -62,6 +62,8 @@ class GraphedStep:
             self._fill_one(key)
 
     def _run(self):
+        from .ops import dropout_state
+        dropout_state.next_step(self.src.x.device)        # device counter: bumped by every replay too
         loss, logits = self.step_fn(self.src, self.tgt)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
@@ -158,6 +160,8 @@ class GraphedStepDP:
         g1, g2, g3, g4 = (torch.cuda.CUDAGraph() for _ in range(4))
         mode = dict(capture_error_mode="thread_local")    # RCCL's watchdog thread polls events meanwhile
         with torch.cuda.graph(g1, **mode):
+            from .ops import dropout_state
+            dropout_state.next_step(dev)
             loss_ce, logits, rows_s, rows_t = self.part1(self.src, self.tgt, self.idx[0], self.idx[1])
         pool = g1.pool()
         self.gath = [torch.zeros((W,) + tuple(rows_s.shape), dtype=torch.float32, device=dev, requires_grad=True),

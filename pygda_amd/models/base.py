@@ -91,6 +91,9 @@ class BaseGDA(ABC):
                 else:
                     net.train()
                 src, tgt = src.to(self.device), tgt.to(self.device)
+                if src.x.is_cuda:
+                    from ..ops import dropout_state
+                    dropout_state.next_step(src.x.device)      # fresh masks for the fused activations
                 loss, source_logits = step_fn(src, tgt, alpha, epoch)
                 optimizer.zero_grad()
                 loss.backward()
@@ -135,6 +138,8 @@ class BaseGDA(ABC):
         (before_step or net.train)()
         if dp:                # collectives stay eager between four captured segments
             def eager_step():
+                from ..ops import dropout_state
+                dropout_state.next_step(src.x.device)
                 loss, _ = step_fn(src, tgt, 0.0, 0)
                 optimizer.zero_grad()
                 loss.backward()

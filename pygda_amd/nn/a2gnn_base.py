@@ -43,11 +43,17 @@ class A2GNNBase(nn.Module):
         it -- the reference recomputes it, projection and all ``prop_nums`` aggregations, per pass."""
         return self.convs[0](x, edge_index, prop_nums)
 
+    def _act_dropout(self, x):
+        if self.act is F.relu and x.is_cuda:            # fused kernel; any other activation composes
+            from ..ops import relu_dropout
+            return relu_dropout(x, self.dropout, self.training)
+        return F.dropout(self.act(x), p=self.dropout, training=self.training)
+
     def feat_bottleneck_from(self, h0, edge_index, batch, prop_nums=30):
         """``feat_bottleneck`` continued from a precomputed :meth:`first_conv` output."""
-        x = F.dropout(self.act(h0), p=self.dropout, training=self.training)
+        x = self._act_dropout(h0)
         for conv in self.convs[1:]:
-            x = F.dropout(self.act(conv(x, edge_index, prop_nums)), p=self.dropout, training=self.training)
+            x = self._act_dropout(conv(x, edge_index, prop_nums))
         if self.mode == "graph":
             x = global_mean_pool(x, batch)
         return x

@@ -287,3 +287,66 @@ def gather_rows(x, idx):
     _lib.check(L.gda_gather_rows_f32(_lib.ptr(x), x.size(1), x.size(1), _lib.ptr(idx), idx.numel(),
                                      _lib.ptr(out), x.size(1), _lib.stream()), "gda_gather_rows_f32")
     return out
+
+
+# ------------------------------------------------------------ ReLU + dropout (fused) --
+class _DropoutState:
+    """Device step counter + per-step call-site numbering for the fused activation's generator."""
+
+    def __init__(self):
+        self.step = {}           # device -> int64[1]
+        self.site = 0
+        self.seed = None
+
+    def counter(self, dev):
+        t = self.step.get(dev)
+        if t is None:
+            t = self.step[dev] = torch.zeros(1, dtype=torch.int64, device=dev)
+        return t
+
+    def next_step(self, dev):
+        """Called by the trainers once per training step (inside the captured graph as well)."""
+        self.counter(dev).add_(1)
+        self.site = 0
+
+    def next_site(self):
+        self.site += 1
+        return self.site
+
+
+dropout_state = _DropoutState()
+
+
+class _ReluDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        x = _f32c(x, "x")
+        y = torch.empty_like(x)
+        st = dropout_state
+        if st.seed is None:
+            st.seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+        L = _lib.lib()
+        _lib.check(L.gda_relu_dropout_fwd_f32(_lib.ptr(x), _lib.ptr(y), x.numel(), float(p),
+                                              ctypes.c_uint64(st.seed), _lib.ptr(st.counter(x.device)),
+                                              ctypes.c_uint32(st.next_site()), _lib.stream()),
+                   "gda_relu_dropout_fwd_f32")
+        ctx.save_for_backward(y)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy)
+        L = _lib.lib()
+        _lib.check(L.gda_relu_dropout_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gx), gy.numel(), ctx.p,
+                                              _lib.stream()), "gda_relu_dropout_bwd_f32")
+        return gx, None
+
+
+def relu_dropout(x, p, training=True):
+    """``F.dropout(F.relu(x), p, training)`` in one kernel each way (no mask tensor)."""
+    if not training or p <= 0.0 or not x.is_cuda or x.dtype != torch.float32:
+        return torch.relu(x)
+    return _ReluDropout.apply(x, p)

@@ -693,3 +693,30 @@ def test_dp_segmented_hipgraph_single_rank_nccl(monkeypatch):
         dist.destroy_process_group()
     close(seen, g["losses"], rtol=REL)
     close(logits, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+
+
+# ------------------------------------------------------- fused ReLU + dropout --
+def test_relu_dropout_fused():
+    from pygda_amd.ops import dropout_state, relu_dropout
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(5484, 128, generator=gen).to(DEV).requires_grad_()
+    for p in (0.5, 0.1):
+        dropout_state.next_step(x.device)
+        y = relu_dropout(x, p, True)
+        kept = y > 0
+        pos = x.detach() > 0
+        assert not bool((kept & ~pos).any())                                  # never resurrects a negative
+        exact(y[kept], (x.detach() * (1.0 / (1.0 - p)))[kept].to(torch.float32))   # kept values scaled exactly
+        rate = 1.0 - kept.sum().item() / pos.sum().item()
+        assert abs(rate - p) < 0.01                                            # drop rate
+        gy = torch.randn(5484, 128, generator=gen).to(DEV)
+        (gx,) = torch.autograd.grad(y, x, gy)
+        exact(gx, torch.where(kept, gy * (1.0 / (1.0 - p)), torch.zeros_like(gy)))
+        # a new call site and a new step draw different masks; same (step, site) would repeat
+        y2 = relu_dropout(x, p, True)
+        assert bool(((y2 > 0) != kept).any())
+    assert torch.equal(relu_dropout(x, 0.5, False), torch.relu(x))              # eval: plain ReLU
+    odd = torch.randn(1003, generator=gen).to(DEV)                               # ragged tail
+    dropout_state.next_step(odd.device)
+    yo = relu_dropout(odd, 0.3, True)
+    assert yo.shape == odd.shape and not bool(((yo > 0) & (odd <= 0)).any())
