@@ -101,6 +101,98 @@ def cpu_baseline(src, tgt, hp, edges):
             "epochs_per_sec": 1.0 / dt}
 
 
+def make_cfg_s(nodes, avg_degree, feat, classes, seed, device):
+    """One domain of BASELINE.json configs[4]: `nodes` nodes, nodes*avg_degree directed edges
+    (uniform random pairs, both directions), x ~ N(0,1) fp32 [nodes, feat] resident on the GPU."""
+    from pygda_amd.data import Data
+    g = torch.Generator(device=device).manual_seed(seed)
+    half = nodes * avg_degree // 2
+    a = torch.randint(0, nodes, (half,), generator=g, device=device)
+    b = torch.randint(0, nodes, (half,), generator=g, device=device)
+    ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
+    x = torch.randn(nodes, feat, generator=g, device=device)
+    y = torch.randint(0, classes, (nodes,), generator=g, device=device)
+    return Data(x=x, edge_index=ei, y=y)
+
+
+def run_cfg_s(args, world, rank, dev):
+    """Sampled mini-batch A2GNN on the synthetic large graphs (configs[4]): the native host sampler
+    (prefetching), the row-gather kernel, per-batch graph ingestion, and -- with N ranks -- disjoint
+    seed shards, all-gathered MMD rows and one flat gradient all-reduce per step."""
+    import torch.distributed as dist
+    from pygda_amd import ops
+    from pygda_amd.models import A2GNN
+    hp = dict(hid=128, classes=5, L=2, lr=0.01, wd=0.005, dropout=0.5, s_pnums=0, t_pnums=10, weight=10)
+    fan = [int(v) for v in args.fanout.split(",")]
+    src = make_cfg_s(args.nodes, args.avg_degree, args.feat, hp["classes"], 200, dev)
+    tgt = make_cfg_s(args.nodes, args.avg_degree, args.feat, hp["classes"], 201, dev)
+    steps_total = args.warmup + args.steps
+    # one epoch = steps_total global steps: every rank needs that many batches of `batch` seeds
+    need = steps_total * args.batch * world
+    gsel = torch.Generator().manual_seed(7)
+    seeds_s = torch.randint(0, args.nodes, (need,), generator=gsel)
+    seeds_t = torch.randint(0, args.nodes, (need,), generator=gsel)
+    from pygda_amd.data import NeighborLoader
+    model = A2GNN(args.feat, hp["hid"], hp["classes"], num_layers=hp["L"], lr=hp["lr"], weight_decay=hp["wd"],
+                  epoch=1, dropout=hp["dropout"], s_pnums=hp["s_pnums"], t_pnums=hp["t_pnums"],
+                  weight=hp["weight"], device=dev, batch_size=args.batch, num_neigh=fan, verbose=0)
+    torch.manual_seed(1234 + rank)
+    net, optimizer, step_fn, alpha_fn = model._prepare(src, tgt)
+    kw = dict(rank=rank, world_size=world, device=dev)
+    model.source_loader = NeighborLoader(src, fan, batch_size=args.batch, input_nodes=seeds_s, **kw)
+    model.target_loader = NeighborLoader(tgt, fan, batch_size=args.batch, input_nodes=seeds_t, **kw)
+    it = zip(iter(model.source_loader), iter(model.target_loader))
+    from pygda_amd.models.base import _allreduce_grads
+
+    def one_step():
+        s, t = next(it)
+        ops.dropout_state.next_step(s.x.device)
+        net.train()
+        loss, _ = step_fn(s, t, 0.0, 0)
+        optimizer.zero_grad()
+        loss.backward()
+        _allreduce_grads(optimizer)
+        optimizer.step()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    ops.aggregation_log = []
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    sync()
+    dt = time.perf_counter() - t0
+    log, ops.aggregation_log = ops.aggregation_log, None
+    edges = sum(g.nnz * k for g, k in log)
+    if world > 1:
+        t = torch.tensor([dt, float(edges)], device=dev, dtype=torch.float64)
+        tm = t.clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, edges = float(tm[0]), float(t[1])
+    if rank == 0:
+        print(json.dumps({
+            "metric": "edges_aggregated_per_sec", "value": edges / dt, "unit": "edges/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg-S: A2GNN on synthetic source+target graphs, {args.nodes} nodes / "
+                                   f"{args.nodes * args.avg_degree} directed edges per domain, F={args.feat}, nhid=128, "
+                                   f"L=2, s_pnums=0, t_pnums=10, NeighborLoader fan-out {fan}, {args.batch} seeds per GPU "
+                                   "per step, MMD domain loss",
+                       "edges_aggregated_per_step": edges / args.steps, "final_loss": float(loss),
+                       "parallelism": "single GPU" if world == 1 else
+                       f"dp{world}: disjoint seed mini-batches per rank, graph + features replicated, all-gathered "
+                       "global-batch MMD rows, one flat RCCL gradient all-reduce per step"},
+            "steps_per_sec": args.steps / dt}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +201,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--adv", action="store_true", help="adversarial branch instead of MMD")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
+    ap.add_argument("--workload", default="cfgA", choices=["cfgA", "cfgS"],
+                    help="cfgA (default): BASELINE.json configs[1]; cfgS: sampled mini-batches on configs[4]-style graphs")
+    ap.add_argument("--nodes", type=int, default=5_000_000, help="cfgS: nodes per domain")
+    ap.add_argument("--avg-degree", type=int, default=20)
+    ap.add_argument("--feat", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=1024, help="cfgS: seeds per GPU per step")
+    ap.add_argument("--fanout", default="15,10")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel code path (RCCL exchange steps) on a 1-rank group")
     args = ap.parse_args()
@@ -146,6 +245,12 @@ def main():
     import pygda_amd
     from pygda_amd import profiler
     from pygda_amd.models import A2GNN
+
+    if args.workload == "cfgS":
+        run_cfg_s(args, world, rank, dev)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
 
     # hyper-parameters of benchmark/node/run_citation.sh:92 (A2GNN, ACMv9 -> DBLPv7)
     hp = dict(hid=128, classes=5, L=2, lr=0.01, wd=0.005, dropout=0.5, s_pnums=0, t_pnums=10, weight=10)

@@ -259,6 +259,8 @@ typedef struct gda_sampler gda_sampler;
 int gda_sampler_create(const int64_t* src_host, const int64_t* dst_host, int64_t E, int64_t N,
                        gda_sampler** out);
 void gda_sampler_destroy(gda_sampler* s);
+/* Worker threads for the neighbour picks of a hop (default 1).  The batch does not depend on it. */
+int gda_sampler_set_threads(gda_sampler* s, int workers);
 int gda_sampler_sample(gda_sampler* s, const int64_t* seeds_host, int64_t n_seeds,
                        const int32_t* fanouts, int L, uint64_t rng_seed,
                        int64_t* n_nodes_out, int64_t* n_edges_out);

@@ -48,6 +48,7 @@ _SIGNATURES = {
     "gda_gather_rows_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P]),
     "gda_sampler_create": (c_int, [_P, _P, c_int64, c_int64, ctypes.POINTER(c_void_p)]),
     "gda_sampler_destroy": (None, [_P]),
+    "gda_sampler_set_threads": (c_int, [_P, c_int]),
     "gda_sampler_sample": (c_int, [_P, _P, c_int64, _P, c_int, ctypes.c_uint64,
                                    ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
     "gda_sampler_fetch": (c_int, [_P, _P, _P, _P]),
@@ -90,7 +91,15 @@ def lib():
     return _lib
 
 
+_DEBUG_SYNC = os.environ.get("PYGDA_AMD_DEBUG_SYNC") == "1"
+
+
 def check(status, what):
+    if _DEBUG_SYNC:                       # serialise and name every C-ABI call (debugging aid)
+        import sys
+        print("[gda] launched", what, file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+        print("[gda] done    ", what, file=sys.stderr, flush=True)
     if status != 0:
         msg = lib().gda_status_string(int(status)).decode()
         raise GdaError(f"{what} failed with status {status}: {msg}")

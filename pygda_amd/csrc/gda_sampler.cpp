@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/gda_hip.h"
@@ -36,8 +37,27 @@ struct SplitMix {
 
 }  // namespace
 
+// fork-join parallel-for over [0, n): contiguous chunks, one per worker (the picks of a frontier
+// node depend only on (seed, hop, node), so any partition gives the same batch)
+template <class F>
+static void parallel_for(int64_t n, int workers, F&& body) {
+    if (workers <= 1 || n < 4096) { body(0, n, 0); return; }
+    std::vector<std::thread> pool;
+    const int64_t chunk = (n + workers - 1) / workers;
+    for (int w = 0; w < workers; ++w) {
+        const int64_t b = w * chunk, e = std::min<int64_t>(n, b + chunk);
+        if (b >= e) break;
+        pool.emplace_back([&body, b, e, w] { body(b, e, w); });
+    }
+    for (auto& t : pool) t.join();
+}
+
 struct gda_sampler {
     int64_t N = 0;
+    int workers = 1;
+    std::vector<int64_t> pick_off, picks;   // per-hop scratch: offsets / picked global ids of the frontier
+    std::vector<int64_t> first;             // [N] smallest pick index that reaches a not-yet-labelled node
+    std::vector<int64_t> newpos;            // per-pick: rank among this hop's first occurrences, or -1
     std::vector<int64_t> in_ptr;      // [N+1]  in-neighbour lists (sources of edges into v), edge order
     std::vector<int64_t> in_src;      // [E]
     std::vector<int32_t> local;       // [N] global -> local id of the batch being built, -1 if absent
@@ -63,11 +83,19 @@ extern "C" int gda_sampler_create(const int64_t* src_host, const int64_t* dst_ho
     std::vector<int64_t> cur(s->in_ptr.begin(), s->in_ptr.end() - 1);
     for (int64_t e = 0; e < E; ++e) s->in_src[cur[dst_host[e]]++] = src_host[e];   // stable: edge order kept
     s->local.assign(N, -1);
+    s->first.assign(N, INT64_MAX);
     *out = s;
     return GDA_OK;
 }
 
 extern "C" void gda_sampler_destroy(gda_sampler* s) { delete s; }
+
+extern "C" int gda_sampler_set_threads(gda_sampler* s, int workers) {
+    if (!s) return GDA_E_NULL;
+    if (workers < 1 || workers > 256) return GDA_E_SIZE;
+    s->workers = workers;
+    return GDA_OK;
+}
 
 extern "C" int gda_sampler_sample(gda_sampler* s, const int64_t* seeds_host, int64_t n_seeds,
                                   const int32_t* fanouts, int L, uint64_t rng_seed,
@@ -84,32 +112,89 @@ extern "C" int gda_sampler_sample(gda_sampler* s, const int64_t* seeds_host, int
     int64_t frontier_begin = 0;
     for (int hop = 0; hop < L; ++hop) {
         const int64_t frontier_end = (int64_t)s->nodes.size();
+        const int64_t nf = frontier_end - frontier_begin;
         const int32_t k = fanouts[hop];
-        for (int64_t f = frontier_begin; f < frontier_end; ++f) {
-            const int64_t v = s->nodes[f];
-            const int64_t b = s->in_ptr[v], deg = s->in_ptr[v + 1] - b;
-            const int32_t lv = s->local[v];
-            auto take = [&](int64_t u) {
-                if (s->local[u] < 0) { s->local[u] = (int32_t)s->nodes.size(); s->nodes.push_back(u); }
-                s->esrc.push_back(s->local[u]);
-                s->edst.push_back(lv);
-            };
-            if (k < 0 || deg <= k) {
-                for (int64_t j = 0; j < deg; ++j) take(s->in_src[b + j]);
-            } else {
-                // k distinct positions out of deg: partial Fisher-Yates on an index scratch,
-                // then restore list order so the kept edges stay in original edge order
-                SplitMix rng(rng_seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(hop + 1)) ^ (0x9E3779B97F4A7C15ull * (uint64_t)(v + 1)));
-                s->scratch.resize(deg);
-                for (int64_t j = 0; j < deg; ++j) s->scratch[j] = j;
-                for (int32_t j = 0; j < k; ++j) {
-                    const int64_t r = j + (int64_t)rng.below((uint64_t)(deg - j));
-                    std::swap(s->scratch[j], s->scratch[r]);
-                }
-                std::sort(s->scratch.begin(), s->scratch.begin() + k);
-                for (int32_t j = 0; j < k; ++j) take(s->in_src[b + s->scratch[j]]);
-            }
+        // 1. how many neighbours each frontier node contributes -> offsets (sequential, trivial)
+        s->pick_off.resize(nf + 1);
+        s->pick_off[0] = 0;
+        for (int64_t f = 0; f < nf; ++f) {
+            const int64_t v = s->nodes[frontier_begin + f];
+            const int64_t deg = s->in_ptr[v + 1] - s->in_ptr[v];
+            s->pick_off[f + 1] = s->pick_off[f] + ((k < 0 || deg <= k) ? deg : k);
         }
+        s->picks.resize(s->pick_off[nf]);
+        // 2. the picks themselves, in parallel: the cache-missing part (random reads of the edge array)
+        parallel_for(nf, s->workers, [&](int64_t fb, int64_t fe, int) {
+            std::vector<int64_t> scratch;
+            for (int64_t f = fb; f < fe; ++f) {
+                const int64_t v = s->nodes[frontier_begin + f];
+                const int64_t b = s->in_ptr[v], deg = s->in_ptr[v + 1] - b;
+                int64_t* out = s->picks.data() + s->pick_off[f];
+                if (k < 0 || deg <= k) {
+                    for (int64_t j = 0; j < deg; ++j) out[j] = s->in_src[b + j];
+                } else {
+                    // k distinct positions out of deg: partial Fisher-Yates on an index scratch, then
+                    // restore list order so the kept edges stay in original edge order
+                    SplitMix rng(rng_seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(hop + 1)) ^
+                                 (0x9E3779B97F4A7C15ull * (uint64_t)(v + 1)));
+                    scratch.resize(deg);
+                    for (int64_t j = 0; j < deg; ++j) scratch[j] = j;
+                    for (int32_t j = 0; j < k; ++j) {
+                        const int64_t r = j + (int64_t)rng.below((uint64_t)(deg - j));
+                        std::swap(scratch[j], scratch[r]);
+                    }
+                    std::sort(scratch.begin(), scratch.begin() + k);
+                    for (int32_t j = 0; j < k; ++j) out[j] = s->in_src[b + scratch[j]];
+                }
+            }
+        });
+        // 3. relabel.  Discovery order = order of first occurrence among the picks; found without a
+        //    sequential walk: (a) every pick of an unlabelled node claims it with an atomic min of
+        //    its pick index, (b) the claim winners are numbered by a prefix count, (c) all picks
+        //    read the final labels.  The random accesses into `local` / `first` run on all workers.
+        const int64_t np = s->pick_off[nf];
+        const int64_t e0 = (int64_t)s->esrc.size();
+        s->esrc.resize(e0 + np);
+        s->edst.resize(e0 + np);
+        s->newpos.resize(np);
+        parallel_for(np, s->workers, [&](int64_t qb, int64_t qe, int) {
+            for (int64_t q = qb; q < qe; ++q) {
+                const int64_t u = s->picks[q];
+                if (s->local[u] >= 0) continue;
+                int64_t cur = __atomic_load_n(&s->first[u], __ATOMIC_RELAXED);
+                while (q < cur && !__atomic_compare_exchange_n(&s->first[u], &cur, q, true, __ATOMIC_RELAXED,
+                                                                __ATOMIC_RELAXED)) {}
+            }
+        });
+        parallel_for(np, s->workers, [&](int64_t qb, int64_t qe, int) {      // claim winners (random reads)
+            for (int64_t q = qb; q < qe; ++q) {
+                const int64_t u = s->picks[q];
+                s->newpos[q] = (s->local[u] < 0 && s->first[u] == q) ? 0 : -1;
+            }
+        });
+        int64_t fresh = 0;                                  // (b) prefix count: sequential, contiguous
+        for (int64_t q = 0; q < np; ++q)
+            if (s->newpos[q] == 0) s->newpos[q] = fresh++;
+        const int64_t base = (int64_t)s->nodes.size();
+        s->nodes.resize(base + fresh);
+        parallel_for(np, s->workers, [&](int64_t qb, int64_t qe, int) {
+            for (int64_t q = qb; q < qe; ++q)
+                if (s->newpos[q] >= 0) {
+                    const int64_t u = s->picks[q];
+                    s->nodes[base + s->newpos[q]] = u;
+                    s->local[u] = (int32_t)(base + s->newpos[q]);
+                    s->first[u] = INT64_MAX;                // leave the claim table clean for the next hop / batch
+                }
+        });
+        parallel_for(nf, s->workers, [&](int64_t fb, int64_t fe, int) {
+            for (int64_t f = fb; f < fe; ++f) {
+                const int32_t lv = s->local[s->nodes[frontier_begin + f]];
+                for (int64_t q = s->pick_off[f]; q < s->pick_off[f + 1]; ++q) {
+                    s->esrc[e0 + q] = s->local[s->picks[q]];
+                    s->edst[e0 + q] = lv;
+                }
+            }
+        });
         frontier_begin = frontier_end;
     }
     *n_nodes_out = (int64_t)s->nodes.size();

@@ -92,7 +92,8 @@ class NeighborLoader:
     in-neighbourhoods, seeds first, exactly ``batch.batch_size`` of them."""
 
     def __init__(self, data, num_neighbors, batch_size=1, shuffle=False, input_nodes=None,
-                 rank=0, world_size=1, seed=0, device=None, **kwargs):
+                 rank=0, world_size=1, seed=0, device=None, prefetch=2, **kwargs):
+        self.prefetch = int(prefetch)
         self.num_neighbors = list(num_neighbors)
         self.batch_size, self.shuffle = int(batch_size), shuffle
         self.rank, self.world_size, self.seed = rank, world_size, seed
@@ -129,9 +130,47 @@ class NeighborLoader:
         from .sampler import NeighborSampler
         if self._sampler is None:
             self._sampler = NeighborSampler(self.data.edge_index, self.data.num_nodes)
-        for b, seeds in enumerate(self._batches()):
-            yield self._sampler.sample_batch(self.data, seeds, self.num_neighbors,
-                                             seed=hash((self.seed, self._epoch, b, self.rank)) & 0x7FFFFFFF)
+        batches = self._batches()
+        seeds_of = lambda b: hash((self.seed, self._epoch, b, self.rank)) & 0x7FFFFFFF
+        if self.prefetch <= 0:
+            for b, seeds in enumerate(batches):
+                yield self._sampler.sample_batch(self.data, seeds, self.num_neighbors, seed=seeds_of(b))
+        else:
+            # host sampling of the next batches runs in a background thread (the native sampler
+            # releases the GIL) while the device works on the current one; device-side assembly
+            # (row gather on the training stream) stays in the consumer thread
+            import queue
+            import threading
+            q, stop = queue.Queue(maxsize=self.prefetch), threading.Event()
+
+            def producer():
+                try:
+                    for b, seeds in enumerate(batches):
+                        if stop.is_set():
+                            return
+                        q.put((seeds, self._sampler.sample(seeds, self.num_neighbors, seed=seeds_of(b))))
+                    q.put(None)
+                except BaseException as exc:        # surface sampler errors in the consumer
+                    q.put(exc)
+
+            th = threading.Thread(target=producer, daemon=True)
+            th.start()
+            try:
+                while True:
+                    item = q.get()
+                    if item is None:
+                        break
+                    if isinstance(item, BaseException):
+                        raise item
+                    seeds, (n_id, ei) = item
+                    yield self._sampler.assemble(self.data, seeds, n_id, ei)
+            finally:
+                stop.set()
+                while th.is_alive():                 # unblock a producer waiting on a full queue
+                    try:
+                        q.get_nowait()
+                    except queue.Empty:
+                        th.join(timeout=0.01)
         self._epoch += 1
 
 

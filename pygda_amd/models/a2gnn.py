@@ -59,7 +59,11 @@ class A2GNN(BaseGDA):
         h0_s = net.first_conv(source_data.x, source_data.edge_index, self.s_pnums)
         h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
         pending = None
-        if self.compute_target_logits and node and h0_t.is_cuda and self.overlap_streams:
+        # fork the unused pass onto the side stream only for full-batch graphs, where launches are tiny
+        # and the graphs are ingested once; sampled mini-batches ingest new graphs every step on the
+        # main stream and gain nothing from the overlap
+        if (self.compute_target_logits and node and h0_t.is_cuda and self.overlap_streams
+                and getattr(target_data, "n_id", None) is None):
             pending = self._target_logits_async(net, target_data, h0_t)
         feats = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)
         source_logits = net.feat_classifier(feats, source_data.edge_index, sb, 1)        # :181

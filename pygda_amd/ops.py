@@ -18,6 +18,7 @@ def _f32c(t, name):
 # --------------------------------------------------------------------------- SpMM --
 aggregated_edges = 0     # running count of nnz(A_hat) over every aggregation launched (bench bookkeeping;
                          # only maintained while the profiler is on: it costs a cached-nnz lookup)
+aggregation_log = None   # or a list: (graph, K) per aggregation call, nnz resolved later (no sync in the loop)
 
 
 def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
@@ -32,6 +33,8 @@ def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
     tmp = torch.empty_like(x) if K > 1 else None
     b = None if bias is None else _f32c(bias, "bias")
     L = _lib.lib()
+    if aggregation_log is not None:
+        aggregation_log.append((graph, int(K)))
     if profiler.enabled:      # algorithmic bytes per launch: nnz*(4+4) + (N+1)*4 + 2*N*d*4
         global aggregated_edges
         aggregated_edges += K * graph.nnz

@@ -11,7 +11,7 @@ from .data import Data
 
 
 class NeighborSampler:
-    def __init__(self, edge_index, num_nodes):
+    def __init__(self, edge_index, num_nodes, threads=None):
         ei = edge_index.detach().cpu().contiguous()
         self.num_nodes = int(num_nodes)
         self._src = np.ascontiguousarray(ei[0].numpy(), dtype=np.int64)
@@ -20,11 +20,15 @@ class NeighborSampler:
         L = _lib.lib()
         _lib.check(L.gda_sampler_create(self._src.ctypes.data, self._dst.ctypes.data, self._src.size,
                                         self.num_nodes, ctypes.byref(self._h)), "gda_sampler_create")
+        if threads is None:
+            import os
+            threads = max(1, min(16, (os.cpu_count() or 2) // 2))
+        _lib.check(L.gda_sampler_set_threads(self._h, int(threads)), "gda_sampler_set_threads")
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
-            _lib.lib().gda_sampler_destroy(h)
+        if h and _lib is not None and getattr(_lib, "_lib", None) is not None:   # not during interpreter teardown
+            _lib._lib.gda_sampler_destroy(h)
             self._h = None
 
     def sample(self, seeds, fanouts, seed=0):
@@ -46,6 +50,10 @@ class NeighborSampler:
         """A ``Data`` batch like PyG's: ``x``/``y`` sliced to the sampled nodes (seeds are the
         first ``batch_size`` rows), local ``edge_index``, ``n_id``, ``batch_size``."""
         n_id, ei = self.sample(seeds, fanouts, seed)
+        return self.assemble(data, seeds, n_id, ei)
+
+    def assemble(self, data, seeds, n_id, ei):
+        """Device side of a batch: feature rows by the gather kernel, labels, ids."""
         dev = data.x.device
         if dev.type == "cuda":
             from .ops import gather_rows
