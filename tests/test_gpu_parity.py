@@ -720,3 +720,42 @@ def test_relu_dropout_fused():
     dropout_state.next_step(odd.device)
     yo = relu_dropout(odd, 0.3, True)
     assert yo.shape == odd.shape and not bool(((yo > 0) & (odd <= 0)).any())
+
+
+# ------------------------------------------------------- empty / ragged / extreme inputs --
+def test_edge_case_shapes():
+    """Empty and ragged inputs through every C entry point that takes a size."""
+    dev = DEV
+    # single node, no edges: the appended loop alone -> identity aggregation
+    G = build_csr(torch.zeros(2, 0, dtype=torch.int64, device=dev), 1)
+    x = torch.tensor([[1.5, -2.0, 3.0]], device=dev)
+    exact(ops.spmm_kstep(G, x, 4), x)
+    # width 1 and a width that is not a multiple of the vector size, with bias
+    ei = torch.tensor([[0, 1, 2, 2, 3], [1, 0, 3, 0, 2]], device=dev)
+    G = build_csr(ei, 5)
+    nei, nw = O.gcn_norm(ei.cpu(), None, 5)
+    for d in (1, 7):
+        xx = torch.arange(5 * d, dtype=torch.float32).reshape(5, d) / 7.0
+        b = torch.linspace(-1, 1, d)
+        exact(ops.spmm_kstep(G, xx.to(dev), 2, b.to(dev)), O.propagate(nei, nw, O.propagate(nei, nw, xx)) + b)
+    # gather of zero rows; MMD on the smallest legal problem (one row per domain)
+    assert ops.gather_rows(torch.randn(4, 8, device=dev), torch.zeros(0, dtype=torch.int64, device=dev)).shape == (0, 8)
+    s1, t1 = torch.tensor([[1.0, 2.0]], device=dev), torch.tensor([[1.5, 0.5]], device=dev)
+    close(pygda_amd.utils.get_MMD(s1, t1), O.get_MMD(s1.cpu(), t1.cpu()), rtol=1e-5)
+    # MMD rows not a multiple of any tile (n = 37, d = 3) incl. gradients
+    gen = torch.Generator().manual_seed(1)
+    s = torch.randn(37, 3, generator=gen).requires_grad_(); t = torch.randn(37, 3, generator=gen).requires_grad_()
+    sg, tg = s.detach().to(dev).requires_grad_(), t.detach().to(dev).requires_grad_()
+    want = O.get_MMD(s, t); want.backward()
+    got = pygda_amd.utils.get_MMD(sg, tg); got.backward()
+    close(got, want, rtol=1e-5); close(sg.grad, s.grad, rtol=1e-3, atol=1e-7); close(tg.grad, t.grad, rtol=1e-3, atol=1e-7)
+    # discriminator with one domain empty and with a single row
+    W, b = torch.randn(2, 6, generator=gen).to(dev), torch.zeros(2, device=dev)
+    f = torch.randn(3, 6, generator=gen).to(dev)
+    only_src = ops.grl_disc_ce(f, f[:0], W, b, 0.5)
+    close(only_src, F.cross_entropy(F.linear(f, W, b), torch.zeros(3, dtype=torch.long, device=dev)), rtol=1e-5)
+    # wrong devices / dtypes are refused loudly
+    with pytest.raises(pygda_amd._lib.GdaError):
+        ops.spmm_kstep(G, torch.zeros(5, 4, dtype=torch.float64, device=dev), 1)
+    with pytest.raises(ValueError):
+        ops.spmm_kstep(G, torch.zeros(6, 4, device=dev), 1)
