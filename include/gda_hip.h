@@ -293,6 +293,41 @@ int64_t gda_edge_list_size(const gda_edge_list* l);
 int gda_edge_list_fetch(const gda_edge_list* l, int64_t* src_out, int64_t* dst_out, float* w_out);
 void gda_edge_list_destroy(gda_edge_list* l);
 
+/* ------------------------------------------------------------------------------
+ * TDSS smoothness term (rank 1 of the "next" rows): Laplacian loss over a smoothing graph.
+ *
+ * gda_laplacian_fwd_f32 / _bwd_f32 replace TDSS.compute_laplacian_loss
+ * (pygda/models/tdss.py:435-454) and its autograd graph:
+ *     loss = 1/2 sum_e || f[row_e] dinv[row_e] - f[col_e] dinv[col_e] ||^2,
+ *     dinv[i] = (#edges with row == i)^-1/2 (inf -> 0).
+ *   rowptr_r/colidx_r : CSR whose rows are the `row` (= edge_index[0]) nodes, entries the `col` nodes
+ *                       (the by-source CSR of gda_build_csr_norm(add_self_loops=0, normalize=0))
+ *   rowptr_c/colidx_c : CSR whose rows are the `col` nodes, entries the `row` nodes (by-destination)
+ *   f [N, d] fp32 (ld = ldf); loss [1]; dinv [N] is written by fwd and read by bwd;
+ *   grad_loss [1] DEVICE scalar (upstream gradient); grad_f [N, d] overwritten.
+ * ---------------------------------------------------------------------------- */
+size_t gda_laplacian_workspace_bytes(int64_t N);
+int gda_laplacian_fwd_f32(const int32_t* rowptr_r, const int32_t* colidx_r, int64_t N, int d,
+                          const float* f, int64_t ldf, float* loss, float* dinv,
+                          void* workspace, size_t workspace_bytes, gda_stream_t stream);
+int gda_laplacian_bwd_f32(const int32_t* rowptr_r, const int32_t* colidx_r,
+                          const int32_t* rowptr_c, const int32_t* colidx_c, int64_t N, int d,
+                          const float* f, int64_t ldf, const float* dinv, const float* grad_loss,
+                          float* grad_f, int64_t ldg, gda_stream_t stream);
+
+/* Host builders of the TDSS smoothing graphs (pygda/models/tdss.py:314-388); results come back as a
+ * gda_edge_list sorted by (row, col) without duplicates (w is empty: pass NULL to _fetch).
+ *   gda_two_hop_host   : `rounds` applications of TwoHopNeighbor (tdss.py:67-87):
+ *                        E <- coalesce(E U pattern(A.A) without self loops)
+ *   gda_walk_smooth_host: one uniform random walk of walk_len steps from every node along
+ *                        row -> col (torch_cluster.random_walk semantics); edge (visited, start)
+ *                        for every visited node (tdss.py:367-373).  Own generator (`seed`):
+ *                        statistical parity. */
+int gda_two_hop_host(const int64_t* src_host, const int64_t* dst_host, int64_t E, int64_t N,
+                     int rounds, int threads, gda_edge_list** out);
+int gda_walk_smooth_host(const int64_t* src_host, const int64_t* dst_host, int64_t E, int64_t N,
+                         int walk_len, uint64_t seed, int threads, gda_edge_list** out);
+
 #ifdef __cplusplus
 }
 #endif

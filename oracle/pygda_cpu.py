@@ -382,6 +382,58 @@ def a2gnn_train_step(net: A2GNNBase, opt: torch.optim.Optimizer, src: Graph, tgt
 # ----------------------------------------------------------------------------
 # PPMI graph construction, UDAGCN, AdaGCN  (a11, a13, a14)
 # ----------------------------------------------------------------------------
+# ------------------------------------------------------------------------- TDSS --
+def two_hop_edges(edge_index: Tensor, num_nodes: int) -> Tensor:
+    """TwoHopNeighbor.__call__ without attributes (tdss.py:67-79): the pattern of A.A (spspmm),
+    self loops removed, concatenated with E and coalesced (sorted by (row, col), duplicates
+    dropped).  Pure-Python sets: for the small graphs of the parity tests."""
+    out = [set() for _ in range(num_nodes)]
+    for r, c in zip(edge_index[0].tolist(), edge_index[1].tolist()):
+        out[r].add(c)
+    pairs = []
+    for i in range(num_nodes):
+        reach = set(out[i])
+        for j in out[i]:
+            reach |= {k for k in out[j] if k != i}
+        pairs += [(i, k) for k in sorted(reach)]
+    return torch.tensor(pairs, dtype=torch.long).t().reshape(2, -1)
+
+
+def tdss_smoothness_khop(edge_index: Tensor, num_nodes: int, k: int) -> Tensor:
+    """TDSS.smoothness, K-hop branch (tdss.py:374-386)."""
+    ei = edge_index
+    for _ in range(k - 1):
+        ei = two_hop_edges(ei, num_nodes)
+    if k == 1:                       # :375-376 passes no num_nodes: PyG infers max index + 1
+        num_nodes = int(ei.max()) + 1 if ei.numel() else 0
+    w = torch.ones(ei.size(1))
+    ei, _ = add_remaining_self_loops(ei, w, 1.0, num_nodes)
+    return ei
+
+
+def laplacian_loss(features: Tensor, edge_index: Tensor) -> Tensor:
+    """TDSS.compute_laplacian_loss (tdss.py:435-454)."""
+    row, col = edge_index
+    deg = torch.zeros(features.size(0)).index_add_(0, row, torch.ones(row.numel()))     # :441-442
+    dis = deg.pow(-0.5)
+    dis[torch.isinf(dis)] = 0                                                           # :443-444
+    diff = features[row] * dis[row].view(-1, 1) - features[col] * dis[col].view(-1, 1)  # :446-448
+    return diff.pow(2).sum(dim=1).sum() / 2.                                            # :450-454
+
+
+def tdss_forward_model(net: A2GNNBase, src: Graph, tgt: Graph, smooth_ei: Tensor, s_pnums: int,
+                       t_pnums: int, alpha: float, beta: float, mmd_samples=None):
+    """tdss.py:241-312: CE(source) + alpha * MMD + beta * Laplacian(target features)."""
+    source_logits = net(src, s_pnums)                                        # :275
+    loss = F.nll_loss(F.log_softmax(source_logits, dim=1), src.y)
+    sf = net.feat_bottleneck(src.x, src.edge_index, None, s_pnums)           # :286
+    tf = net.feat_bottleneck(tgt.x, tgt.edge_index, None, t_pnums)           # :287
+    loss = loss + alpha * MMD(sf, tf, samples=mmd_samples)                   # :301-303
+    loss = loss + beta * laplacian_loss(tf, smooth_ei)                       # :306-307
+    target_logits = net(tgt, t_pnums)                                        # :309
+    return loss, source_logits, target_logits
+
+
 def ppmi_raw_edges(edge_index: Tensor, path_len: int = 5, passes: int = 40):
     """ppmi_conv.py:56-169: ``passes`` (40 in the reference) rounds of random walks (length ~
     U{1..path_len}) from every node over the symmetrised neighbour sets, ``np.random`` stream,

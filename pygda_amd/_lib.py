@@ -58,6 +58,12 @@ _SIGNATURES = {
     "gda_edge_list_size": (c_int64, [_P]),
     "gda_edge_list_fetch": (c_int, [_P, _P, _P, _P]),
     "gda_edge_list_destroy": (None, [_P]),
+    "gda_laplacian_workspace_bytes": (c_size_t, [c_int64]),
+    "gda_laplacian_fwd_f32": (c_int, [_P, _P, c_int64, c_int, _P, c_int64, _P, _P, _P, c_size_t, _P]),
+    "gda_laplacian_bwd_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, c_int64, _P, _P, _P, c_int64, _P]),
+    "gda_two_hop_host": (c_int, [_P, _P, c_int64, c_int64, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "gda_walk_smooth_host": (c_int, [_P, _P, c_int64, c_int64, c_int, ctypes.c_uint64, c_int,
+                                     ctypes.POINTER(c_void_p)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

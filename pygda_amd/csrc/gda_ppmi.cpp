@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/gda_hip.h"
+#include "gda_edge_list.h"
 
 namespace {
 
@@ -37,10 +38,6 @@ struct SplitMix {
 
 }  // namespace
 
-struct gda_edge_list {
-    std::vector<int64_t> src, dst;
-    std::vector<float> w;
-};
 
 extern "C" int gda_ppmi_build_host(const int64_t* src_host, const int64_t* dst_host, int64_t E,
                                    int64_t N, int path_len, int passes, uint64_t seed,
@@ -124,10 +121,10 @@ extern "C" int gda_edge_list_fetch(const gda_edge_list* l, int64_t* src_out, int
                                    float* w_out) {
     if (!l) return GDA_E_NULL;
     if (l->src.empty()) return GDA_OK;
-    if (!src_out || !dst_out || !w_out) return GDA_E_NULL;
+    if (!src_out || !dst_out || (!w_out && !l->w.empty())) return GDA_E_NULL;
     std::memcpy(src_out, l->src.data(), l->src.size() * sizeof(int64_t));
     std::memcpy(dst_out, l->dst.data(), l->dst.size() * sizeof(int64_t));
-    std::memcpy(w_out, l->w.data(), l->w.size() * sizeof(float));
+    if (!l->w.empty()) std::memcpy(w_out, l->w.data(), l->w.size() * sizeof(float));
     return GDA_OK;
 }
 

@@ -5,5 +5,6 @@ from .udagcn import UDAGCN
 from .adagcn import AdaGCN
 from .gnn import GNN
 from .dane import DANE
+from .tdss import TDSS
 
-__all__ = ["BaseGDA", "A2GNN", "GRADE", "UDAGCN", "AdaGCN", "GNN", "DANE"]
+__all__ = ["BaseGDA", "A2GNN", "GRADE", "UDAGCN", "AdaGCN", "GNN", "DANE", "TDSS"]

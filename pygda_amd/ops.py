@@ -353,3 +353,54 @@ def relu_dropout(x, p, training=True):
     if not training or p <= 0.0 or not x.is_cuda or x.dtype != torch.float32:
         return torch.relu(x)
     return _ReluDropout.apply(x, p)
+
+
+# ------------------------------------------------- Laplacian smoothness (TDSS) --
+class _Laplacian(torch.autograd.Function):
+    """``1/2 sum_e ||f[row] dinv[row] - f[col] dinv[col]||^2`` over the edges of ``graph`` (built
+    with ``add_self_loops=False, normalize=False``: by-source CSR = rows of ``row`` nodes)."""
+
+    @staticmethod
+    def forward(ctx, feats, graph):
+        f = _f32c(feats, "features")
+        n, d = f.shape
+        if n != graph.num_nodes:
+            raise ValueError(f"features must have num_nodes={graph.num_nodes} rows, got {n}")
+        dev = f.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dinv = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        ws = _lib.workspace(L.gda_laplacian_workspace_bytes(n), dev, "laplacian")
+        nnz = graph.nnz if profiler.enabled else 0
+        with profiler.region(f"laplacian_fwd[d={d}]", 1, nnz * 4 + n * (d * 4 + 12), 3 * nnz * d):
+            _lib.check(L.gda_laplacian_fwd_f32(_lib.ptr(graph.t_rowptr), _lib.ptr(graph.t_colidx), n, d,
+                                               _lib.ptr(f), d, _lib.ptr(loss), _lib.ptr(dinv), _lib.ptr(ws),
+                                               ws.numel(), _lib.stream()), "gda_laplacian_fwd_f32")
+        ctx.graph = graph
+        ctx.save_for_backward(f, dinv)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        f, dinv = ctx.saved_tensors
+        g = ctx.graph
+        n, d = f.shape
+        gf = torch.empty_like(f)
+        gl = gl.reshape(1).to(torch.float32).contiguous()
+        L = _lib.lib()
+        nnz = g.nnz if profiler.enabled else 0
+        with profiler.region(f"laplacian_bwd[d={d}]", 1, nnz * 8 + 2 * n * d * 4, 4 * nnz * d):
+            _lib.check(L.gda_laplacian_bwd_f32(_lib.ptr(g.t_rowptr), _lib.ptr(g.t_colidx), _lib.ptr(g.rowptr),
+                                               _lib.ptr(g.colidx), n, d, _lib.ptr(f), d, _lib.ptr(dinv),
+                                               _lib.ptr(gl), _lib.ptr(gf), d, _lib.stream()),
+                       "gda_laplacian_bwd_f32")
+        return gf, None
+
+
+def laplacian_loss(features, edge_index):
+    """TDSS.compute_laplacian_loss (pygda/models/tdss.py:390-454).  ``edge_index`` is the
+    ``[2, E]`` smoothing edge list (ingested once, cached by identity) or a ready
+    :class:`~pygda_amd.graph.CSRGraph` built with ``add_self_loops=False, normalize=False``."""
+    from .graph import as_graph
+    graph = as_graph(edge_index, features.size(0), None, False, False, False, "col")
+    return _Laplacian.apply(features, graph)

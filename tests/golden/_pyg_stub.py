@@ -24,6 +24,10 @@ boundary" (the MMD / GradReverse / Attention goldens do not go through it).
  6. ``NeighborLoader(data, [-1]*L, batch_size=N)``: one batch = the whole graph,
     nodes and edges in input order.
  7. ``to_undirected`` = both directions, duplicates merged, sorted by (row, col).
+ 8. (tdss.py only) ``coalesce`` sorts by (row, col) and drops duplicates; ``spspmm`` returns the
+    sparse product sorted by (row, col); ``dense_to_sparse`` lists non-zeros row-major;
+    ``remove_self_loops`` masks ``row != col``; ``torch_cluster.random_walk`` steps uniformly
+    along row -> col with multiplicity and stays put on a node without out-edges.
 """
 import inspect
 import math
@@ -185,8 +189,11 @@ def global_mean_pool(x, batch, size=None):
 
 
 class Data:
+    edge_attr = None         # PyG's Data answers None for the attributes it declares
+
     def __init__(self, x=None, edge_index=None, y=None, **kw):
         self.x, self.edge_index, self.y = x, edge_index, y
+        self._n = None
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -195,7 +202,62 @@ class Data:
 
     @property
     def num_nodes(self):
-        return self.x.size(0)
+        return self._n if self._n is not None else self.x.size(0)
+
+    @num_nodes.setter
+    def num_nodes(self, n):
+        self._n = n
+
+
+# --- what pygda/models/tdss.py pulls in (assumption 8) -------------------------------
+def remove_self_loops(edge_index, edge_attr=None):
+    keep = edge_index[0] != edge_index[1]
+    return edge_index[:, keep], (None if edge_attr is None else edge_attr[keep])
+
+
+def coalesce(edge_index, edge_attr=None, num_nodes=None, reduce='sum'):
+    """PyG ``coalesce``: sort by (row, col), drop duplicates; ``(edge_index, None)`` when the
+    attribute argument is given as None (tdss.py:78 passes ``N`` in the ``reduce`` slot: unused)."""
+    assert edge_attr is None
+    n = maybe_num_nodes(edge_index, num_nodes)
+    key = torch.unique(edge_index[0] * n + edge_index[1])          # sorted
+    return torch.stack([key // n, key % n]), None
+
+
+def spspmm(index_a, value_a, index_b, value_b, m, k, n, coalesced=False):
+    """torch_sparse ``spspmm``: the sparse product, entries sorted by (row, col)."""
+    a = torch.zeros(m, k).index_put_((index_a[0], index_a[1]), value_a, accumulate=True)
+    b = torch.zeros(k, n).index_put_((index_b[0], index_b[1]), value_b, accumulate=True)
+    c = a @ b
+    idx = (c != 0).nonzero().t().contiguous()
+    return idx, c[idx[0], idx[1]]
+
+
+def dense_to_sparse(adj):
+    """PyG ``dense_to_sparse``: non-zeros in row-major order."""
+    idx = adj.nonzero().t().contiguous()
+    return idx, adj[idx[0], idx[1]]
+
+
+def random_walk(row, col, start, walk_length, p=1, q=1, coalesced=True, num_nodes=None):
+    """torch_cluster ``random_walk``: uniform step along row -> col over the (row, col)-sorted
+    edge list with multiplicity; a node without out-edges stays put.  (Draws from torch's CPU
+    generator here; torch_cluster has its own stream, so RW fixtures store the resulting graph.)"""
+    n = int(max(row.max(), col.max(), start.max())) + 1 if num_nodes is None else num_nodes
+    perm = torch.argsort(row * n + col)
+    row, col = row[perm], col[perm]
+    deg = torch.zeros(n, dtype=torch.long).index_add_(0, row, torch.ones_like(row))
+    ptr = torch.zeros(n + 1, dtype=torch.long)
+    ptr[1:] = torch.cumsum(deg, 0)
+    walk = [start]
+    cur = start
+    for _ in range(walk_length):
+        d = deg[cur]
+        pick = (torch.rand(cur.numel()) * d).long().clamp(max=(d - 1).clamp(min=0))
+        nxt = torch.where(d > 0, col[(ptr[cur] + pick).clamp(max=max(col.numel() - 1, 0))], cur)
+        walk.append(nxt)
+        cur = nxt
+    return torch.stack(walk, dim=1)
 
 
 class NeighborLoader:
@@ -248,6 +310,9 @@ def install():
     utils = _mod('torch_geometric.utils')
     utils.add_remaining_self_loops = add_remaining_self_loops
     utils.is_undirected, utils.to_undirected = is_undirected, to_undirected
+    utils.remove_self_loops, utils.coalesce, utils.dense_to_sparse = remove_self_loops, coalesce, dense_to_sparse
+    tc = _mod('torch_cluster')
+    tc.random_walk = random_walk
     nn_utils = _mod('torch_geometric.utils.num_nodes')
     nn_utils.maybe_num_nodes = maybe_num_nodes
     loader = _mod('torch_geometric.loader')
@@ -264,3 +329,4 @@ def install():
     tsp.SparseTensor = SparseTensor
     for name in ('matmul', 'fill_diag', 'sum', 'mul'):
         setattr(tsp, name, None)
+    tsp.spspmm = spspmm

@@ -365,6 +365,74 @@ FIXTURES = {"mmd": fx_mmd, "grl_attention": fx_grl_attention, "gcn_norm": fx_gcn
             "gnn_dane": fx_gnn_dane}
 
 
+def fx_tdss(ref):
+    """TDSS (tdss.py): TwoHopNeighbor / smoothness() graphs, compute_laplacian_loss + gradient,
+    forward_model loss + grads (dropout=0) and a 3-epoch fit() trajectory in K-hop mode; for the
+    RW mode the smoothing graph drawn by the stub's random_walk is stored and replayed."""
+    import pygda.models.tdss as tmod
+    s, t = _domain_pair(141)
+    arrs = dict(_pair_arrays(s, t))
+    kw = dict(num_layers=2, dropout=0.0, s_pnums=0, t_pnums=10, alpha=0.7, beta=0.05, device="cpu",
+              epoch=3, verbose=0)
+    nt = t.x.size(0)
+    for k in (1, 2, 3):
+        m = ref.TDSS(24, 16, 5, smooth_mode='K-hop', k=k, **kw)
+        ei, attr = m.smoothness(t.edge_index, None, nt)
+        assert attr is None
+        arrs[f"khop{k}_ei"] = np_(ei)
+    m = ref.TDSS(24, 16, 5, smooth_mode='RW', rw_len=4, **kw)
+    torch.manual_seed(143)
+    ei_rw, _ = m.smoothness(t.edge_index, None, nt)
+    arrs["rw_ei"] = np_(ei_rw)
+    # the loss on its own, on a directed graph with duplicates and loops too
+    g = torch.Generator().manual_seed(144)
+    feats = torch.randn(nt, 16, generator=g).requires_grad_()
+    for name, ei in (("khop2", torch.from_numpy(arrs["khop2_ei"])), ("rw", ei_rw),
+                     ("raw", make_graph(nt, 500, 145, False, 3, 4))):
+        loss = m.compute_laplacian_loss(feats, ei)
+        (gf,) = torch.autograd.grad(loss, feats)
+        arrs[f"lap_{name}_loss"], arrs[f"lap_{name}_grad"] = np_(loss), np_(gf)
+        if name == "raw":
+            arrs["lap_raw_ei"] = np_(ei)
+    arrs["lap_feats"] = np_(feats)
+    # forward_model, both smoothing modes
+    for mode, smooth in (("khop", torch.from_numpy(arrs["khop2_ei"])), ("rw", ei_rw)):
+        m = ref.TDSS(24, 16, 5, smooth_mode='K-hop', k=2, **kw)
+        torch.manual_seed(146)
+        m.a2gnn = m.init_model()
+        m.a2gnn.train()
+        t.edge_index_smooth = smooth
+        torch.manual_seed(147)
+        loss, sl, tl = m.forward_model(s, t, 0.3)
+        loss.backward()
+        arrs.update({f"fwd_{mode}_loss": np_(loss), f"fwd_{mode}_src_logits": np_(sl),
+                     f"fwd_{mode}_tgt_logits": np_(tl)})
+        arrs.update(sd_arrays(m.a2gnn, f"fwd_{mode}_param/")); arrs.update(grads(m.a2gnn, f"fwd_{mode}_grad/"))
+    arrs.update(init_seed=np.int64(146), mmd_seed=np.int64(147))
+    # fit trajectory (K-hop: deterministic graph)
+    losses, accs = [], []
+    orig, oprint = tmod.logger, getattr(tmod, "print", None)
+    tmod.logger = lambda **kw_: (losses.append(kw_["loss"]), accs.append(kw_["source_train_acc"]))
+    tmod.print = lambda *a, **k_: None
+    try:
+        m = ref.TDSS(24, 16, 5, smooth_mode='K-hop', k=2, lr=0.01, weight_decay=0.005, **kw)
+        torch.manual_seed(148)
+        m.fit(s, t)
+        logits, labels = m.predict(t)
+        arrs.update(fit_seed=np.int64(148), fit_losses=np.array(losses, dtype=np.float64),
+                    fit_accs=np.array(accs, dtype=np.float64), fit_tgt_logits=np_(logits),
+                    fit_tgt_labels=np_(labels))
+        arrs.update(sd_arrays(m.a2gnn, "fit_final/"))
+    finally:
+        tmod.logger = orig
+        if oprint is None:
+            del tmod.print
+    save("tdss", **arrs)
+
+
+FIXTURES["tdss"] = fx_tdss
+
+
 def main(argv):
     ref = load_reference()
     for name in (argv or list(FIXTURES)):

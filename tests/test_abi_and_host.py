@@ -179,3 +179,60 @@ def test_pygda_alias_package():
     from pygda.nn.prop_gcn_conv import gcn_norm
     assert A is A2GNN and PropGCNConv is pygda_amd.nn.PropGCNConv and MMD is pygda_amd.utils.MMD
     assert f1 is eval_micro_f1 and lg is logger and gcn_norm is pygda_amd.nn.gcn_norm
+
+
+# ------------------------------------------------------------------------- TDSS host side --
+def test_tdss_khop_builder_matches_reference_golden():
+    """gda_two_hop_host + self-loop pass == the reference's spspmm/coalesce smoothing graphs."""
+    from pygda_amd.models import TDSS
+    from tests.conftest import load_golden, T
+    g = load_golden("tdss")
+    ei, nt = T(g["tgt_ei"]), g["tgt_x"].shape[0]
+    for k in (1, 2, 3):
+        m = TDSS(24, 16, 5, smooth_mode='K-hop', k=k, device="cpu")
+        got, attr = m.smoothness(ei, None, nt)
+        assert attr is None
+        assert np.array_equal(got.numpy(), g[f"khop{k}_ei"])
+
+
+def test_tdss_walk_builder_properties():
+    """RW smoothing graph: own generator, so structural checks -- sorted unique (visited, start)
+    pairs, every start paired with itself, every pair reachable within rw_len steps, and the
+    per-start visit counts distributed like the stub walker's."""
+    from pygda_amd.models.tdss import walk_smooth_edges
+    from oracle import pygda_cpu as O
+    from tests.conftest import load_golden, T
+    g = load_golden("tdss")
+    ei, nt = T(g["tgt_ei"]), g["tgt_x"].shape[0]
+    got = walk_smooth_edges(ei, nt, 4, seed=5).numpy()
+    key = got[0] * nt + got[1]
+    assert np.all(np.diff(key) > 0)                                   # sorted by (row, col), unique
+    pairs = set(zip(got[0].tolist(), got[1].tolist()))
+    assert all((i, i) in pairs for i in range(nt))
+    reach = O.tdss_smoothness_khop(ei, nt, 3)                         # <= 4 hops (two squarings) + loops
+    allowed = set(zip(reach[1].tolist(), reach[0].tolist()))          # (visited, start): start -> visited
+    assert pairs <= allowed
+    again = walk_smooth_edges(ei, nt, 4, seed=5).numpy()
+    assert np.array_equal(got, again)                                 # reproducible per seed
+    other = walk_smooth_edges(ei, nt, 4, seed=6).numpy()
+    assert other.shape != got.shape or not np.array_equal(other, got)
+    ref_n = g["rw_ei"].shape[1]                                       # one draw of the reference walker
+    assert abs(got.shape[1] - ref_n) < 0.15 * ref_n
+    # a node without out-edges stays put: only its own loop
+    lonely = walk_smooth_edges(torch.tensor([[0], [1]]), 3, 4, seed=1).numpy()
+    assert set(zip(lonely[0].tolist(), lonely[1].tolist())) == {(0, 0), (1, 0), (1, 1), (2, 2)}
+
+
+def test_tdss_signature_and_asserts():
+    import inspect
+    from pygda_amd.models import TDSS
+    sig = inspect.signature(TDSS.__init__)
+    want = dict(mode='node', smooth_mode='RW', num_layers=2, dropout=0., s_pnums=0, t_pnums=30, k=2, rw_len=4,
+                alpha=0.001, beta=1e-4, weight_decay=0.005, adv=False, lr=0.01, epoch=200, device='cuda:0',
+                batch_size=0, num_neigh=-1, verbose=2)
+    for name, default in want.items():
+        assert sig.parameters[name].default == default, name
+    with pytest.raises(AssertionError):
+        TDSS(4, 4, 2, mode='graph')
+    with pytest.raises(AssertionError):
+        TDSS(4, 4, 2, adv=True)

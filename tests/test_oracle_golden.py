@@ -264,3 +264,59 @@ def test_oracle_sage_gin_gat_against_dense_math():
     w = torch.exp(e - e.max()) * As                                         # multiplicity-weighted softmax
     alpha = w / w.sum(1, keepdim=True)
     eq(gat(x, ei), alpha @ hh + gat.bias, 1e-5)
+
+
+# ------------------------------------------------------------------------- TDSS --
+def test_tdss_smoothing_graphs_and_laplacian():
+    """K-hop smoothing graphs (k = 1, 2, 3) and compute_laplacian_loss + gradient (tdss.py)."""
+    g = load_golden("tdss")
+    ei, nt = T(g["tgt_ei"]), g["tgt_x"].shape[0]
+    for k in (1, 2, 3):
+        got = O.tdss_smoothness_khop(ei, nt, k)
+        assert np.array_equal(got.numpy(), g[f"khop{k}_ei"])
+    for name, key in (("khop2", "khop2_ei"), ("rw", "rw_ei"), ("raw", "lap_raw_ei")):
+        f = T(g["lap_feats"]).requires_grad_()
+        loss = O.laplacian_loss(f, T(g[key]))
+        (gf,) = torch.autograd.grad(loss, f)
+        # the CPU backward of features[row] is a multi-threaded index_add: its summation order (and
+        # so the last ulp) varies from run to run, in the reference as well
+        eq(loss, g[f"lap_{name}_loss"], tol=1e-6); eq(gf, g[f"lap_{name}_grad"], tol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["khop", "rw"])
+def test_tdss_forward_model(mode):
+    g = load_golden("tdss")
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    torch.manual_seed(int(g["init_seed"]))
+    net = O.A2GNNBase(24, 16, 5, num_layers=2, adv=False, dropout=0.0)
+    for k, v in sub(g, f"fwd_{mode}_param/").items():
+        eq(net.state_dict()[k], v)
+    net.train()
+    torch.manual_seed(int(g["mmd_seed"]))
+    smooth = T(g["khop2_ei"] if mode == "khop" else g["rw_ei"])
+    loss, sl, tl = O.tdss_forward_model(net, src, tgt, smooth, 0, 10, 0.7, 0.05)
+    loss.backward()
+    eq(loss, g[f"fwd_{mode}_loss"], tol=1e-6); eq(sl, g[f"fwd_{mode}_src_logits"]); eq(tl, g[f"fwd_{mode}_tgt_logits"])
+    for k, v in sub(g, f"fwd_{mode}_grad/").items():
+        eq(dict(net.named_parameters())[k].grad, v, tol=1e-5)
+
+
+def test_tdss_fit_trajectory():
+    g = load_golden("tdss")
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    smooth = O.tdss_smoothness_khop(tgt.edge_index, tgt.x.size(0), 2)
+    torch.manual_seed(int(g["fit_seed"]))
+    net = O.A2GNNBase(24, 16, 5, num_layers=2, adv=False, dropout=0.0)
+    opt = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=0.005)
+    losses = []
+    for _ in range(3):
+        net.train()
+        loss, _, _ = O.tdss_forward_model(net, src, tgt, smooth, 0, 10, 0.7, 0.05)
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(loss.item())
+    eq(np.array(losses), g["fit_losses"], tol=1e-5)
+    net.eval()
+    with torch.no_grad():
+        eq(net(tgt, 10), g["fit_tgt_logits"], tol=1e-5)
