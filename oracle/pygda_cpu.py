@@ -569,6 +569,56 @@ def udagcn_forward_model(net: UDAGCNBase, src: Graph, tgt: Graph, alpha: float, 
     return loss + ent * (epoch / epochs * 0.01), s_logits, t_logits                  # :199
 
 
+# ---------------------------------------------------------------------- SpecReg --
+def specreg_gradient_penalty(critic: nn.Module, x_src: Tensor, x_tgt: Tensor) -> Tensor:
+    """SpecReg.calculate_gradient_penalty (specreg.py:380-419): no interpolation -- the critic's
+    input gradient at the source and target encodings themselves."""
+    x = torch.cat([x_src, x_tgt], dim=0).requires_grad_(True)
+    out = critic(x)
+    grad = torch.autograd.grad(outputs=out, inputs=x, grad_outputs=torch.ones(out.shape),
+                               create_graph=True, retain_graph=True, only_inputs=True)[0]
+    grad = grad.view(grad.shape[0], -1)
+    return torch.mean((grad.norm(2, dim=1) - 1) ** 2)
+
+
+def specreg_forward_model(net: UDAGCNBase, critic: nn.Module, c_opt, src: Graph, tgt: Graph,
+                          eivec_s: Optional[Tensor], eivec_t: Optional[Tensor], epoch: int, epochs: int,
+                          reg_mode=True, gamma_adv=0.1, thr_smooth=-1., gamma_smooth=0.01,
+                          thr_mfr=-1., gamma_mfr=0.01):
+    """specreg.py:150-226: source CE + gamma_adv * Wasserstein gap (critic trained 5 steps with
+    gradient penalty) + spectral smoothness / maximum-frequency-response hinges on the encodings
+    projected onto the Laplacian eigenvectors + annealed target entropy."""
+    es, et = net.encode(src, "source"), net.encode(tgt, "target")
+    s_logits = net.cls_model(es)
+    loss = net.loss_func(s_logits, src.y)                                            # :185
+    xs, xt = es.detach(), et.detach()
+    for _ in range(5):                                                               # :188-194
+        c_opt.zero_grad()
+        gap = critic(xs).mean() - critic(xt).mean()
+        adv = -gap + 10 * specreg_gradient_penalty(critic, xs, xt)
+        adv.backward()
+        c_opt.step()
+    loss = loss + (critic(es).mean() - critic(et).mean()) * gamma_adv                # :196-197
+    if reg_mode:                                                                     # :199-209
+        fs = torch.einsum('nm,md->nd', eivec_s, es)
+        ft = torch.einsum('nm,md->nd', eivec_t, et)
+        if thr_smooth > 0:
+            ds, dt = (fs[:-1] - fs[1:]).abs(), (ft[:-1] - ft[1:]).abs()
+            loss = loss + (F.relu(ds - thr_smooth).mean() + F.relu(dt - thr_smooth).mean()) * gamma_smooth
+        if thr_mfr > 0:
+            loss = loss + (F.relu(fs.abs() - thr_mfr).mean() + F.relu(ft.abs() - thr_mfr).mean()) * gamma_mfr
+    t_logits = net.cls_model(et)
+    p = torch.clamp(F.softmax(t_logits, dim=-1), min=1e-9, max=1.0)
+    ent = torch.mean(torch.sum(-p * torch.log(p), dim=-1))                           # :212-216
+    return loss + ent * (epoch / epochs * 0.01), s_logits, t_logits
+
+
+def specreg_critic(hid_dim: int) -> nn.Module:
+    """specreg.py:281-287."""
+    return nn.Sequential(nn.Linear(hid_dim, hid_dim), nn.ReLU(), nn.Linear(hid_dim, hid_dim), nn.ReLU(),
+                         nn.Linear(hid_dim, 1))
+
+
 class _AdaGNN(nn.Module):
     """adagcn_base.py:11-97 (gnn_type='gcn'): L GCNConv, act + Dropout between layers."""
 

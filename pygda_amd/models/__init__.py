@@ -6,5 +6,6 @@ from .adagcn import AdaGCN
 from .gnn import GNN
 from .dane import DANE
 from .tdss import TDSS
+from .specreg import SpecReg
 
-__all__ = ["BaseGDA", "A2GNN", "GRADE", "UDAGCN", "AdaGCN", "GNN", "DANE", "TDSS"]
+__all__ = ["BaseGDA", "A2GNN", "GRADE", "UDAGCN", "AdaGCN", "GNN", "DANE", "TDSS", "SpecReg"]

@@ -88,6 +88,8 @@ def load_reference(with_pyg_stub=True):
     ns.GNN, ns.DANE = gn.GNN, da.DANE
     td = _load("pygda.models.tdss", "pygda/models/tdss.py")
     ns.TDSS, ns.TwoHopNeighbor = td.TDSS, td.TwoHopNeighbor
+    sr = _load("pygda.models.specreg", "pygda/models/specreg.py")
+    ns.SpecReg = sr.SpecReg
     ns.gcn_norm, ns.PropGCNConv = prop.gcn_norm, prop.PropGCNConv
     ns.CachedGCNConv, ns.PPMIConv = cached.CachedGCNConv, ppmi.PPMIConv
     ns.A2GNNBase, ns.GRADEBase, ns.UDAGCNBase, ns.AdaGCNBase = a2b.A2GNNBase, grb.GRADEBase, udb.UDAGCNBase, adb.AdaGCNBase

@@ -433,6 +433,65 @@ def fx_tdss(ref):
 FIXTURES["tdss"] = fx_tdss
 
 
+def fx_specreg(ref):
+    """SpecReg (specreg.py): forward_model (5 critic updates + gradient penalty + spectral hinges on
+    given eigenvector bases) with loss/grads, and a 3-epoch fit()/predict() trajectory.  GCN view only
+    (ppmi=False: the PPMI view is pinned by the UDAGCN fixtures); the module-list Dropout(0.1) of
+    UDAGCNBase is zeroed as in fx_udagcn."""
+    import pygda.models.specreg as smod
+    import torch.nn as nn
+    s, t = _domain_pair(161, ns=70, nt=50, f=12, c=3)
+    g = torch.Generator().manual_seed(162)
+    s.eivec = torch.linalg.qr(torch.randn(70, 20, generator=g))[0].t().contiguous()      # [k, N] bases
+    t.eivec = torch.linalg.qr(torch.randn(50, 20, generator=g))[0].t().contiguous()
+    arrs = dict(_pair_arrays(s, t), src_eivec=np_(s.eivec), tgt_eivec=np_(t.eivec))
+    kw = dict(num_layers=2, ppmi=False, adv_dim=6, reg_mode=True, gamma_adv=0.1, thr_smooth=0.02,
+              gamma_smooth=0.5, thr_mfr=0.05, gamma_mfr=0.5, lr=0.01, weight_decay=0.003, device="cpu",
+              epoch=3, verbose=0)
+
+    def build(m, seed):
+        torch.manual_seed(seed)
+        m.udagcn = m.init_model()
+        _zero_dropout(m.udagcn)
+        m.critic = nn.Sequential(nn.Linear(8, 8), nn.ReLU(), nn.Linear(8, 8), nn.ReLU(), nn.Linear(8, 1))
+        m.optimizer_critic = torch.optim.Adam(m.critic.parameters(), m.lr)
+
+    m = ref.SpecReg(12, 8, 3, **kw)
+    build(m, 163)
+    arrs.update(sd_arrays(m.udagcn, "fwd_param/")); arrs.update(sd_arrays(m.critic, "fwd_critic0/"))
+    loss, sl, tl = m.forward_model(s, t, 0.05, 2)
+    loss.backward()
+    arrs.update(fwd_loss=np_(loss), fwd_src_logits=np_(sl), fwd_tgt_logits=np_(tl), init_seed=np.int64(163),
+                epoch=np.int64(2), epochs=np.int64(3))
+    arrs.update({"fwd_grad/" + k: np_(p.grad) for k, p in m.udagcn.named_parameters() if p.grad is not None})
+    arrs.update(sd_arrays(m.critic, "fwd_critic5/"))
+    # fit(): the reference builds model + critic itself; zero the unregistered dropouts through init_model
+    losses, accs = [], []
+    orig = smod.logger
+    smod.logger = lambda **kw_: (losses.append(kw_["loss"]), accs.append(kw_["source_train_acc"]))
+    m = ref.SpecReg(12, 8, 3, **kw)
+    init = m.init_model
+    def init_zero(**k):
+        net = init(**k)
+        _zero_dropout(net)
+        return net
+    m.init_model = init_zero
+    try:
+        torch.manual_seed(164)
+        m.fit(s, t)
+        logits, labels = m.predict(t)
+        slogits, _ = m.predict(s, source=True)
+    finally:
+        smod.logger = orig
+    arrs.update(fit_seed=np.int64(164), fit_losses=np.array(losses, dtype=np.float64),
+                fit_accs=np.array(accs, dtype=np.float64), fit_tgt_logits=np_(logits), fit_tgt_labels=np_(labels),
+                fit_src_logits=np_(slogits))
+    save("specreg", **arrs)
+
+
+FIXTURES["specreg"] = fx_specreg
+
+
 def main(argv):
     ref = load_reference()
     for name in (argv or list(FIXTURES)):

@@ -236,3 +236,21 @@ def test_tdss_signature_and_asserts():
         TDSS(4, 4, 2, mode='graph')
     with pytest.raises(AssertionError):
         TDSS(4, 4, 2, adv=True)
+
+
+def test_svd_transform_laplacian_and_shapes(tmp_path):
+    from pygda_amd.utils.svd_transform import laplacian_dense, svd_transform
+    ei = torch.tensor([[0, 1, 1, 2, 2, 2, 0], [1, 0, 2, 1, 2, 0, 1]])            # a loop and a duplicate
+    L = laplacian_dense(ei, 4)
+    want = np.array([[2, -1, 0, 0], [-1, 2, -1, 0], [-1, -1, 2, 0], [0, 0, 0, 0]], dtype=np.float32)
+    assert np.array_equal(L, want)                                               # D - A, loops dropped
+    g = torch.Generator().manual_seed(0)
+    n = 130
+    ei = torch.randint(0, n, (2, 600), generator=g)
+    d = Data(x=torch.zeros(n, 3), edge_index=ei, y=torch.zeros(n, dtype=torch.long))
+    svd_transform(d, str(tmp_path) + "/")
+    assert d.eivec.shape == (100, n) and d.eival.shape == (100,)
+    assert torch.equal(torch.load(str(tmp_path) + "/eivec.pt"), d.eivec)
+    # principal directions of a symmetric matrix: orthonormal rows
+    gram = d.eivec @ d.eivec.t()
+    assert torch.allclose(gram, torch.eye(100), atol=1e-3)

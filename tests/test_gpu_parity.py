@@ -852,3 +852,91 @@ def test_tdss_rw_mode_trains():
     m.fit(s, t)
     logits, labels = m.predict(t)
     assert logits.shape == (t.x.size(0), 5) and torch.isfinite(logits).all()
+
+
+# ---------------------------------------------------------------------- SpecReg --
+SPECREG_KW = dict(num_layers=2, ppmi=False, adv_dim=6, reg_mode=True, gamma_adv=0.1, thr_smooth=0.02,
+                  gamma_smooth=0.5, thr_mfr=0.05, gamma_mfr=0.5, lr=0.01, weight_decay=0.003, device=DEV,
+                  epoch=3, verbose=0)
+
+
+def _specreg_pair(g):
+    s, t = _pair(g)
+    s.eivec, t.eivec = T(g["src_eivec"]), T(g["tgt_eivec"])
+    return s, t
+
+
+def test_specreg_forward_model_golden():
+    """Encoder on the aggregation kernels, 5 critic updates with gradient penalty, spectral hinges on
+    the eigenvector projections, entropy term: loss, logits, encoder gradients and the critic's
+    weights after its 5 Adam steps against the reference."""
+    g = load_golden("specreg")
+    s, t = _specreg_pair(g)
+    m = pygda_amd.models.SpecReg(12, 8, 3, **SPECREG_KW)
+    torch.manual_seed(int(g["init_seed"]))
+    m.udagcn = m.init_model()
+    _no_dropout(m.udagcn)
+    m.critic = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.ReLU(), torch.nn.Linear(8, 8),
+                                   torch.nn.ReLU(), torch.nn.Linear(8, 1)).to(DEV)
+    m.optimizer_critic = torch.optim.Adam(m.critic.parameters(), m.lr)
+    for k, v in sub(g, "fwd_param/").items():
+        exact(m.udagcn.state_dict()[k], v)
+    for k, v in sub(g, "fwd_critic0/").items():
+        exact(m.critic.state_dict()[k], v)
+    loss, sl, tl = m.forward_model(s.to(DEV), t.to(DEV), 0.05, int(g["epoch"]))
+    loss.backward()
+    close(loss, g["fwd_loss"], rtol=REL)
+    close(sl, g["fwd_src_logits"], rtol=0, atol=LOGIT_ATOL); close(tl, g["fwd_tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    for k, v in sub(g, "fwd_critic5/").items():
+        close(m.critic.state_dict()[k], v, rtol=1e-3, atol=1e-4)
+    named = dict(m.udagcn.named_parameters())
+    for k, v in sub(g, "fwd_grad/").items():
+        if k in named:
+            close(named[k].grad, v, rtol=1e-3, atol=1e-4 * max(np.abs(v).max(), 1e-3))
+
+
+def test_specreg_fit_predict_golden(monkeypatch):
+    g = load_golden("specreg")
+    s, t = _specreg_pair(g)
+    m = pygda_amd.models.SpecReg(12, 8, 3, **SPECREG_KW)
+    init = m.init_model
+
+    def init_no_dropout(**kw):
+        net = init(**kw)
+        _no_dropout(net)
+        return net
+
+    monkeypatch.setattr(m, "init_model", init_no_dropout)
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+    torch.manual_seed(int(g["fit_seed"]))
+    m.fit(s, t)
+    close([x[0] for x in seen], g["fit_losses"], rtol=REL)
+    close([x[1] for x in seen], g["fit_accs"], rtol=0, atol=1e-12)
+    logits, labels = m.predict(t)
+    close(logits, g["fit_tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    exact(labels, g["fit_tgt_labels"])
+    exact(logits.argmax(1), g["fit_tgt_logits"].argmax(1))
+    slogits, _ = m.predict(s, source=True)
+    close(slogits, g["fit_src_logits"], rtol=0, atol=LOGIT_ATOL)
+
+
+def test_specreg_with_ppmi_view_and_svd_transform_runs():
+    """Default configuration end to end: svd_transform bases (k=100), PPMI view built natively."""
+    from pygda_amd.utils import svd_transform
+    from pygda_amd.data import to_undirected
+    gen = torch.Generator().manual_seed(9)
+
+    def domain(n):
+        ei = to_undirected(torch.randint(0, n, (2, 4 * n), generator=gen), n)
+        return Data(x=(torch.rand(n, 12, generator=gen) < 0.2).float(), edge_index=ei,
+                    y=torch.randint(0, 3, (n,), generator=gen))
+
+    s, t = domain(150), domain(120)
+    svd_transform(s); svd_transform(t)
+    assert s.eivec.shape == (100, 150) and t.eivec.shape == (100, 120)
+    m = pygda_amd.models.SpecReg(12, 8, 3, num_layers=2, thr_smooth=0.1, thr_mfr=0.1, device=DEV, epoch=2, verbose=0)
+    torch.manual_seed(2)
+    m.fit(s, t)
+    logits, labels = m.predict(t)
+    assert logits.shape == (120, 3) and torch.isfinite(logits).all()

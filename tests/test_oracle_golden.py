@@ -320,3 +320,54 @@ def test_tdss_fit_trajectory():
     net.eval()
     with torch.no_grad():
         eq(net(tgt, 10), g["fit_tgt_logits"], tol=1e-5)
+
+
+# ---------------------------------------------------------------------- SpecReg --
+def _specreg_setup(g, seed):
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    torch.manual_seed(seed)
+    net = O.UDAGCNBase(12, 8, 3, num_layers=2, ppmi=False, adv_dim=6, dropout_p=0.0)
+    critic = O.specreg_critic(8)
+    c_opt = torch.optim.Adam(critic.parameters(), 0.01)
+    return src, tgt, net, critic, c_opt
+
+
+SPECREG_KW = dict(reg_mode=True, gamma_adv=0.1, thr_smooth=0.02, gamma_smooth=0.5, thr_mfr=0.05, gamma_mfr=0.5)
+
+
+def test_specreg_forward_model():
+    g = load_golden("specreg")
+    src, tgt, net, critic, c_opt = _specreg_setup(g, int(g["init_seed"]))
+    for k, v in sub(g, "fwd_param/").items():
+        eq(net.state_dict()[k], v)
+    for k, v in sub(g, "fwd_critic0/").items():
+        eq(critic.state_dict()[k], v)
+    loss, sl, tl = O.specreg_forward_model(net, critic, c_opt, src, tgt, T(g["src_eivec"]), T(g["tgt_eivec"]),
+                                           int(g["epoch"]), int(g["epochs"]), **SPECREG_KW)
+    loss.backward()
+    eq(loss, g["fwd_loss"]); eq(sl, g["fwd_src_logits"]); eq(tl, g["fwd_tgt_logits"])
+    for k, v in sub(g, "fwd_critic5/").items():
+        eq(critic.state_dict()[k], v)
+    named = dict(net.named_parameters())
+    for k, v in sub(g, "fwd_grad/").items():
+        if k in named:
+            eq(named[k].grad, v, tol=1e-6)
+
+
+def test_specreg_fit_trajectory():
+    g = load_golden("specreg")
+    src, tgt, net, critic, c_opt = _specreg_setup(g, int(g["fit_seed"]))
+    opt = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=0.003)
+    losses = []
+    for epoch in range(3):
+        net.train()
+        loss, _, _ = O.specreg_forward_model(net, critic, c_opt, src, tgt, T(g["src_eivec"]), T(g["tgt_eivec"]),
+                                             epoch, 3, **SPECREG_KW)
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(loss.item())
+    eq(np.array(losses), g["fit_losses"], tol=1e-6)
+    net.eval()
+    with torch.no_grad():
+        eq(net.cls_model(net.encode(tgt, "target")), g["fit_tgt_logits"], tol=1e-6)
+        eq(net.cls_model(net.encode(src, "source")), g["fit_src_logits"], tol=1e-6)
