@@ -57,7 +57,9 @@ const char* gda_status_string(int status);
  *   src,dst   [E] int64  edge_index[0], edge_index[1]  (message flows src -> dst)
  *   w         [E] fp32 or NULL (all ones)
  *   fill_value     self-loop weight for nodes without one (1, or 2 for improved)
- *   add_self_loops 0/1; normalize 0/1 (0: values are the raw weights)
+ *   add_self_loops 0 = edges as given; 1 = PyG add_remaining_self_loops; 2 = existing loops dropped,
+ *                  none appended (get_laplacian's remove_self_loops, pygda/nn/dgsda_base.py:128)
+ *   normalize 0/1 (0: values are the raw weights)
  *   degree_side    0 = over dst/col (PropGCNConv, GCNConv), 1 = over src/row (CachedGCNConv)
  *   rowptr  [N+1], colidx/val [E+N]  : by-destination CSR, colidx = source node
  *   t_rowptr[N+1], t_colidx/t_val [E+N] : by-source CSR, t_colidx = destination node
@@ -292,6 +294,20 @@ int gda_ppmi_build_host(const int64_t* src_host, const int64_t* dst_host, int64_
 int64_t gda_edge_list_size(const gda_edge_list* l);
 int gda_edge_list_fetch(const gda_edge_list* l, int64_t* src_out, int64_t* dst_out, float* w_out);
 void gda_edge_list_destroy(gda_edge_list* l);
+
+/* Aggregation with an affine epilogue, for polynomial graph filters:
+ *     y[i] = alpha * x[i] + beta * sum_j A[i,j] x[j] + gamma * z[i]
+ * gamma = gamma_imm * (gamma_dev ? *gamma_dev : 1); z may be NULL (then gamma is ignored).
+ * Replaces the propagate calls of BernProp.forward (pygda/nn/dgsda_base.py:128-148), where
+ * the operators are L = I - A_sym (get_laplacian 'sym', :128) and 2I - L = I + A_sym
+ * (add_self_loops(-norm, fill 2), :130): one launch per operator application, the Horner
+ * accumulation of the filter terms riding in the same pass.  gamma_dev lets a learnable filter
+ * coefficient stay on the device (hipGraph-capturable, no host sync). */
+int gda_spmm_csr_axpby_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                           int64_t n_rows, int64_t d, const float* x, int64_t ldx,
+                           float* y, int64_t ldy, float alpha, float beta,
+                           const float* z, int64_t ldz, float gamma_imm, const float* gamma_dev,
+                           const gda_row_split* split, gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
  * TDSS smoothness term (rank 1 of the "next" rows): Laplacian loss over a smoothing graph.

@@ -569,6 +569,97 @@ def udagcn_forward_model(net: UDAGCNBase, src: Graph, tgt: Graph, alpha: float, 
     return loss + ent * (epoch / epochs * 0.01), s_logits, t_logits                  # :199
 
 
+# ------------------------------------------------------------------------ DGSDA --
+def sym_laplacian(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int):
+    """PyG ``get_laplacian(..., normalization='sym')`` as called at dgsda_base.py:128: self loops
+    removed, degree over ``row``, off-diagonal ``-d^-1/2 w d^-1/2`` followed by N diagonal ones."""
+    row, col = edge_index
+    keep = row != col
+    row, col = row[keep], col[keep]
+    w = torch.ones(row.numel()) if edge_weight is None else edge_weight[keep]
+    deg = torch.zeros(num_nodes).index_add_(0, row, w)
+    dis = deg.pow(-0.5)
+    dis.masked_fill_(dis == float('inf'), 0)
+    w = dis[row] * w * dis[col]
+    loops = torch.arange(num_nodes)
+    return torch.stack([torch.cat([row, loops]), torch.cat([col, loops])]), torch.cat([-w, torch.ones(num_nodes)])
+
+
+class BernProp(nn.Module):
+    """dgsda_base.py:11-183, the reference's evaluation order: tmp[j] = (2I-L)^j x, then for every i
+    the chain L^(i+1) tmp[K-i-1]."""
+
+    def __init__(self, K: int, is_source_domain: bool = True):
+        super().__init__()
+        self.K = K
+        self.temp = nn.Parameter(torch.ones(K + 1) if is_source_domain else torch.linspace(1, 0, K + 1),
+                                 requires_grad=is_source_domain)
+
+    def forward(self, x, edge_index, edge_weight=None):
+        from math import comb
+        K, n = self.K, x.size(0)
+        TEMP = F.relu(self.temp)
+        ei1, norm1 = sym_laplacian(edge_index, edge_weight, n)                          # :128
+        loops = torch.arange(n)
+        ei2 = torch.cat([ei1, torch.stack([loops, loops])], dim=1)                      # :130 add_self_loops
+        norm2 = torch.cat([-norm1, torch.full((n,), 2.0)])
+        tmp = [x]
+        for _ in range(K):
+            x = propagate(ei2, norm2, x)
+            tmp.append(x)
+        out = (comb(K, 0) / (2 ** K)) * TEMP[0] * tmp[K]
+        for i in range(K):
+            x = tmp[K - i - 1]
+            x = propagate(ei1, norm1, x)
+            for _ in range(i):
+                x = propagate(ei1, norm1, x)
+            out = out + (comb(K, i + 1) / (2 ** K)) * TEMP[i + 1] * x
+        return out
+
+
+class DGSDABase(nn.Module):
+    """dgsda_base.py:186-315."""
+
+    def __init__(self, features, hidden, classes, dprate=0.0, K=15):
+        super().__init__()
+        self.lin1 = nn.Linear(features, hidden)
+        self.lin2 = nn.Linear(hidden, classes)
+        self.prop1, self.prop2, self.prop3 = BernProp(K), BernProp(K), BernProp(K)
+        self.dprate = dprate
+
+    def get_props(self, x, edge_index, is_source_domain=True):
+        x = F.dropout(x, p=self.dprate, training=self.training)
+        x = F.relu(self.lin1(x))
+        x = F.dropout(x, p=self.dprate, training=self.training)
+        return self.prop1(x, edge_index) if is_source_domain else self.prop2(x, edge_index)
+
+    def forward(self, data, is_source_domain=True):
+        x = self.get_props(data.x, data.edge_index, is_source_domain)
+        x = F.dropout(x, p=self.dprate, training=self.training)
+        x = self.lin2(x)
+        x = F.dropout(x, p=self.dprate, training=self.training)
+        return self.prop3(x, data.edge_index)
+
+
+def dgsda_entropy(output: Tensor) -> Tensor:
+    """DGSDA.entropy_minimization_loss (dgsda.py:222-227)."""
+    probs, log_probs = F.softmax(output, dim=1), F.log_softmax(output, dim=1)
+    a = torch.sum(probs, dim=0)
+    return -torch.sum(probs * log_probs / (a / torch.sum(a)), dim=1).mean()
+
+
+def dgsda_forward_model(net: DGSDABase, src: Graph, tgt: Graph, alpha: float, beta: float, gamma: float,
+                        mmd_samples=None):
+    """dgsda.py:144-196."""
+    s_logits = net(src)
+    loss = F.nll_loss(F.log_softmax(s_logits, dim=1), src.y)
+    loss = loss + F.l1_loss(net.prop1.temp, net.prop2.temp) * alpha
+    sf, tf = F.relu(net.lin1(src.x)), F.relu(net.lin1(tgt.x))
+    loss = loss + MMD(sf, tf, samples=mmd_samples) * beta
+    loss = loss + dgsda_entropy(net(tgt, False)) * gamma
+    return loss, s_logits
+
+
 # ---------------------------------------------------------------------- SpecReg --
 def specreg_gradient_penalty(critic: nn.Module, x_src: Tensor, x_tgt: Tensor) -> Tensor:
     """SpecReg.calculate_gradient_penalty (specreg.py:380-419): no interpolation -- the critic's

@@ -95,14 +95,14 @@ __global__ void k_fill(const int64_t* __restrict__ src, const int64_t* __restric
     if (idx >= cap) return;
     iota[idx] = (int32_t)idx;
     const int32_t n_kept = E > 0 ? pos[E - 1] + flag[E - 1] : 0;
-    const int64_t total = n_kept + (add_self_loops ? N : 0);
+    const int64_t total = n_kept + (add_self_loops == 1 ? N : 0);
     if (idx < E && flag[idx]) {                      // a kept edge, compacted in edge order
         const int32_t p = pos[idx];
         nsrc[p] = (int32_t)src[idx];
         ndst[p] = (int32_t)dst[idx];
         nw[p] = w ? w[idx] : 1.0f;
     }
-    if (add_self_loops && idx < N) {                 // appended loops, node order, LAST
+    if (add_self_loops == 1 && idx < N) {            // appended loops, node order, LAST (mode 2: dropped, none added)
         const int64_t p = n_kept + idx;
         const int32_t l = loop_last[idx];
         nsrc[p] = (int32_t)idx;

@@ -64,12 +64,38 @@ struct RowSplit {
     float* scratch;                 // [n_chunks, d]
 };
 
-template <int G, int VEC>
+// Optional epilogue (polynomial graph filters, e.g. the Bernstein filter of DGSDA):
+//     y[i] = alpha * x[i] + beta * (A x)[i] + gamma * z[i],   gamma = gamma_imm * (gamma_dev ? *gamma_dev : 1)
+// so I +- A_hat steps and Horner accumulations cost no extra pass over [N, d].
+struct Epilogue {
+    float alpha, beta, gamma_imm;
+    const float* gamma_dev;         // device scalar (a learnable filter coefficient) or NULL
+    const float* z;                 // [n_rows, d] (ld = ldz) or NULL
+    int64_t ldz;
+};
+
+template <int VEC>
+__device__ __forceinline__ void apply_epilogue(float (&acc)[VEC], const Epilogue& ep, const float* __restrict__ x,
+                                               int64_t ldx, int64_t row, int c) {
+    float xs[VEC];
+    vload<VEC>(xs, x + row * ldx + c);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = ep.alpha * xs[v] + ep.beta * acc[v];
+    if (ep.z) {
+        const float g = ep.gamma_dev ? ep.gamma_imm * *ep.gamma_dev : ep.gamma_imm;
+        float zs[VEC];
+        vload<VEC>(zs, ep.z + row * ep.ldz + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += g * zs[v];
+    }
+}
+
+template <int G, int VEC, bool EPI>
 __global__ void __launch_bounds__(TB)
 k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
        const float* __restrict__ val, int64_t n_rows, int d,
        const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
-       const float* __restrict__ bias, RowSplit sp, unsigned row_blocks) {
+       const float* __restrict__ bias, RowSplit sp, unsigned row_blocks, Epilogue ep) {
     constexpr int ROWS_PER_BLOCK = TB / G;
     const int lane_in_group = threadIdx.x % G;
     const bool chunk_mode = blockIdx.x >= row_blocks;       // block-uniform
@@ -140,6 +166,9 @@ k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
             }
         }
         if (live && col_ok) {
+            if constexpr (EPI) {
+                if (!chunk_mode) apply_epilogue<VEC>(acc, ep, x, ldx, row, c);     // chunks: done by k_long_reduce
+            }
             if (bias) {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) acc[v] = __fadd_rn(acc[v], bias[c + v]);
@@ -150,8 +179,10 @@ k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
 }
 
 // y[long_row] = sum over its chunks, in chunk order (+ bias)
+template <bool EPI>
 __global__ void __launch_bounds__(TB)
-k_long_reduce(RowSplit sp, int d, float* __restrict__ y, int64_t ldy, const float* __restrict__ bias) {
+k_long_reduce(RowSplit sp, int d, float* __restrict__ y, int64_t ldy, const float* __restrict__ bias,
+              const float* __restrict__ x, int64_t ldx, Epilogue ep) {
     const int64_t total = (int64_t)sp.n_long * d;
     for (int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x; k < total; k += (int64_t)gridDim.x * TB) {
         const int32_t li = (int32_t)(k / d);
@@ -159,6 +190,11 @@ k_long_reduce(RowSplit sp, int d, float* __restrict__ y, int64_t ldy, const floa
         float acc = 0.f;
         for (int32_t q = sp.long_chunk_ptr[li]; q < sp.long_chunk_ptr[li + 1]; ++q)
             acc = __fadd_rn(acc, sp.scratch[(int64_t)q * d + c]);
+        if constexpr (EPI) {
+            float a1[1] = {acc};
+            apply_epilogue<1>(a1, ep, x, ldx, sp.long_rows[li], c);
+            acc = a1[0];
+        }
         if (bias) acc = __fadd_rn(acc, bias[c]);
         y[(int64_t)sp.long_rows[li] * ldy + c] = acc;
     }
@@ -167,18 +203,23 @@ k_long_reduce(RowSplit sp, int d, float* __restrict__ y, int64_t ldy, const floa
 template <int G, int VEC>
 int launch(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n_rows, int d,
            const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias, const RowSplit& sp,
-           hipStream_t s) {
+           hipStream_t s, const Epilogue* ep) {
     constexpr int ROWS_PER_BLOCK = TB / G;
     const int64_t row_blocks = gda_cdiv(n_rows, ROWS_PER_BLOCK);
     const int64_t chunk_blocks = sp.n_chunks > 0 ? gda_cdiv(sp.n_chunks, ROWS_PER_BLOCK) : 0;
     if (row_blocks + chunk_blocks > INT32_MAX) return GDA_E_SIZE;
-    k_spmm<G, VEC><<<(unsigned)(row_blocks + chunk_blocks), TB, 0, s>>>(
-        rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, bias, sp, (unsigned)row_blocks);
+    if (ep)
+        k_spmm<G, VEC, true><<<(unsigned)(row_blocks + chunk_blocks), TB, 0, s>>>(
+            rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, bias, sp, (unsigned)row_blocks, *ep);
+    else
+        k_spmm<G, VEC, false><<<(unsigned)(row_blocks + chunk_blocks), TB, 0, s>>>(
+            rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, bias, sp, (unsigned)row_blocks, Epilogue{});
     GDA_LAUNCH_CHECK();
     if (sp.n_long > 0) {
         int64_t g = gda_cdiv((int64_t)sp.n_long * d, TB);
         if (g > 2048) g = 2048;
-        k_long_reduce<<<(unsigned)g, TB, 0, s>>>(sp, d, y, ldy, bias);
+        if (ep) k_long_reduce<true><<<(unsigned)g, TB, 0, s>>>(sp, d, y, ldy, bias, x, ldx, *ep);
+        else k_long_reduce<false><<<(unsigned)g, TB, 0, s>>>(sp, d, y, ldy, bias, x, ldx, Epilogue{});
         GDA_LAUNCH_CHECK();
     }
     return GDA_OK;
@@ -186,14 +227,16 @@ int launch(const int32_t* rowptr, const int32_t* colidx, const float* val, int64
 
 int dispatch(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n_rows, int64_t d,
              const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias, const RowSplit& sp,
-             hipStream_t s) {
+             hipStream_t s, const Epilogue* ep = nullptr) {
     // vector width: widest that keeps every row start and column offset aligned
-    const bool a16 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
+    const bool z16 = !ep || !ep->z || ((ep->ldz % 4 == 0) && ((uintptr_t)ep->z % 16 == 0));
+    const bool z8 = !ep || !ep->z || ((ep->ldz % 2 == 0) && ((uintptr_t)ep->z % 8 == 0));
+    const bool a16 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && z16 &&
                      ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
-    const bool a8 = (d % 2 == 0) && (ldx % 2 == 0) && (ldy % 2 == 0) &&
+    const bool a8 = (d % 2 == 0) && (ldx % 2 == 0) && (ldy % 2 == 0) && z8 &&
                     ((uintptr_t)x % 8 == 0) && ((uintptr_t)y % 8 == 0);
     const int di = (int)d;
-#define GO(G, V) return launch<G, V>(rowptr, colidx, val, n_rows, di, x, ldx, y, ldy, bias, sp, s)
+#define GO(G, V) return launch<G, V>(rowptr, colidx, val, n_rows, di, x, ldx, y, ldy, bias, sp, s, ep)
     if (a16) {
         const int64_t lanes = d / 4;
         if (lanes >= 64) GO(64, 4);
@@ -283,4 +326,19 @@ extern "C" int gda_spmm_csr_split_f32(const int32_t* rowptr, const int32_t* coli
         ld_in = ldy;
     }
     return GDA_OK;
+}
+
+extern "C" int gda_spmm_csr_axpby_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                                      int64_t n_rows, int64_t d, const float* x, int64_t ldx,
+                                      float* y, int64_t ldy, float alpha, float beta,
+                                      const float* z, int64_t ldz, float gamma, const float* gamma_dev,
+                                      const gda_row_split* split, gda_stream_t stream) {
+    int st = check(rowptr, colidx, val, n_rows, d, x, ldx, y, ldy);
+    if (st != GDA_OK || n_rows == 0 || d == 0) return st;
+    if ((st = check_split(split)) != GDA_OK) return st;
+    if (z && ldz < d) return GDA_E_SIZE;
+    if (z == y) return GDA_E_ALIAS;
+    const RowSplit sp = make_split(split);
+    const Epilogue ep{alpha, beta, gamma, gamma_dev, z, ldz};
+    return dispatch(rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, nullptr, sp, (hipStream_t)stream, &ep);
 }

@@ -112,6 +112,8 @@ def build_csr(edge_index, num_nodes, edge_weight=None, improved=False, add_self_
 
     Semantics of gcn_norm (prop_gcn_conv.py:64-81; ``degree_side='col'``) and
     CachedGCNConv.norm (cached_gcn_conv.py:88-103; ``degree_side='row'``).
+    ``add_self_loops='drop'`` removes existing self loops and appends none (the adjacency part of
+    PyG ``get_laplacian``, dgsda_base.py:128).
     """
     _lib.require_gpu_tensor(edge_index, "edge_index", torch.int64)
     if edge_index.dim() != 2 or edge_index.size(0) != 2:
@@ -142,7 +144,8 @@ def build_csr(edge_index, num_nodes, edge_weight=None, improved=False, add_self_
     edge_map = torch.empty(max(cap, 1), **i32) if with_edge_map else None
     _lib.check(L.gda_build_csr_norm_map(
         _lib.ptr(src), _lib.ptr(dst), _lib.ptr(w), E, N, 2.0 if improved else 1.0,
-        int(bool(add_self_loops)), int(bool(normalize)), 0 if degree_side == "col" else 1,
+        2 if add_self_loops == "drop" else int(bool(add_self_loops)), int(bool(normalize)),
+        0 if degree_side == "col" else 1,
         _lib.ptr(rowptr), _lib.ptr(colidx), _lib.ptr(val),
         _lib.ptr(t_rowptr), _lib.ptr(t_colidx), _lib.ptr(t_val), _lib.ptr(edge_map),
         _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_build_csr_norm_map")
@@ -161,7 +164,8 @@ class _GraphCache:
     def get(self, edge_index, num_nodes, edge_weight, improved, add_self_loops, normalize, degree_side):
         key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes),
                None if edge_weight is None else (edge_weight.data_ptr(), edge_weight._version),
-               bool(improved), bool(add_self_loops), bool(normalize), degree_side)
+               bool(improved), add_self_loops if add_self_loops == "drop" else bool(add_self_loops),
+               bool(normalize), degree_side)
         hit = self._d.get(key)
         if hit is not None:
             ref_ei, ref_w, g = hit

@@ -7,5 +7,6 @@ from .gnn import GNN
 from .dane import DANE
 from .tdss import TDSS
 from .specreg import SpecReg
+from .dgsda import DGSDA
 
-__all__ = ["BaseGDA", "A2GNN", "GRADE", "UDAGCN", "AdaGCN", "GNN", "DANE", "TDSS", "SpecReg"]
+__all__ = ["BaseGDA", "A2GNN", "GRADE", "UDAGCN", "AdaGCN", "GNN", "DANE", "TDSS", "SpecReg", "DGSDA"]

@@ -12,7 +12,8 @@ from .adagcn_base import AdaGCNBase
 from .sage_gin_conv import SAGEConv, GINConv
 from .gat_conv import GATConv
 from .gnn_base import GNNBase
+from .dgsda_base import BernProp, DGSDABase
 
 __all__ = ["Linear", "glorot", "zeros", "PropGCNConv", "gcn_norm", "GCNConv", "CachedGCNConv", "PPMIConv",
            "ppmi_edges", "GradReverse", "Attention", "A2GNNBase", "GRADEBase", "UDAGCNBase", "AdaGCNBase", "SAGEConv", "GINConv", "GATConv", "GNNBase",
-           "global_mean_pool"]
+           "global_mean_pool", "BernProp", "DGSDABase"]

@@ -404,3 +404,88 @@ def laplacian_loss(features, edge_index):
     from .graph import as_graph
     graph = as_graph(edge_index, features.size(0), None, False, False, False, "col")
     return _Laplacian.apply(features, graph)
+
+
+# ------------------------------------------- polynomial graph filters (DGSDA BernProp) --
+def spmm_axpby(graph: CSRGraph, x, alpha, beta, z=None, gamma=1.0, gamma_dev=None, transposed=False):
+    """``alpha * x + beta * (A x) + gamma * z`` in one aggregation launch (no autograd).
+    ``gamma_dev``: one-element device tensor multiplied into ``gamma`` (a learnable coefficient)."""
+    x = _f32c(x, "x")
+    if x.dim() != 2 or x.size(0) != graph.num_nodes:
+        raise ValueError(f"x must be [num_nodes={graph.num_nodes}, d], got {tuple(x.shape)}")
+    rp, ci, va = (graph.t_rowptr, graph.t_colidx, graph.t_val) if transposed else \
+                 (graph.rowptr, graph.colidx, graph.val)
+    n, d = x.shape
+    if z is not None:
+        z = _f32c(z, "z")
+        if z.shape != x.shape:
+            raise ValueError("z must have the shape of x")
+    y = torch.empty_like(x)
+    L = _lib.lib()
+    if aggregation_log is not None:
+        aggregation_log.append((graph, 1))
+    if profiler.enabled:
+        global aggregated_edges
+        aggregated_edges += graph.nnz
+        ctx = profiler.region(f"spmm_csr_axpby_f32[d={d}]", 1,
+                              graph.nnz * 8 + (n + 1) * 4 + (2 + (z is not None)) * n * d * 4, 2 * graph.nnz * d)
+    else:
+        ctx = profiler.region("", 0)
+    sp = graph.split(transposed).struct(d)
+    with ctx:
+        _lib.check(L.gda_spmm_csr_axpby_f32(_lib.ptr(rp), _lib.ptr(ci), _lib.ptr(va), n, d, _lib.ptr(x), d,
+                                            _lib.ptr(y), d, float(alpha), float(beta), _lib.ptr(z), d,
+                                            float(gamma), _lib.ptr(gamma_dev),
+                                            ctypes.byref(sp) if sp is not None else None, _lib.stream()),
+                   "gda_spmm_csr_axpby_f32")
+    return y
+
+
+class _BernFilter(torch.autograd.Function):
+    """``out = sum_k w_k (I + A)^(K-k) (I - A)^k x`` with ``w = relu(temp) * binom(K, k) / 2^K``: the
+    Bernstein-basis filter of BernProp.forward (pygda/nn/dgsda_base.py:101-151), where
+    L = I - A and 2I - L = I + A for the self-loop-free symmetric normalisation A.
+
+    The reference spends K + K(K+1)/2 propagations forward (and as many again in autograd).  L and
+    2I - L commute, so the same polynomial is evaluated as one chain v_k = L^k x and one Horner
+    sweep s_j = (I + A) s_{j-1} + w_j v_j: 2K launches forward, 2K backward (adjoint chain
+    q_j = (I + A^T)^j g, Horner in (I - A^T)), the accumulation riding in the SpMM epilogue and the
+    coefficients read from device memory.  Every term is a product of positive semi-definite
+    factors with non-negative weights, so the reordering costs rounding only (tested at 1e-5)."""
+
+    @staticmethod
+    def forward(ctx, x, temp, graph, coefs):
+        K = temp.numel() - 1
+        w = (torch.relu(temp.detach()) * coefs).contiguous()
+        v = [_f32c(x.detach(), "x")]
+        for _ in range(K):
+            v.append(spmm_axpby(graph, v[-1], 1.0, -1.0))
+        s = v[0] * w[0]
+        for j in range(1, K + 1):
+            s = spmm_axpby(graph, s, 1.0, 1.0, z=v[j], gamma=1.0, gamma_dev=w[j:j + 1])
+        ctx.graph, ctx.K = graph, K
+        ctx.save_for_backward(temp, coefs, w, *v)
+        return s
+
+    @staticmethod
+    def backward(ctx, g):
+        temp, coefs, w, *v = ctx.saved_tensors
+        graph, K = ctx.graph, ctx.K
+        q = [g.contiguous()]
+        for _ in range(K):
+            q.append(spmm_axpby(graph, q[-1], 1.0, 1.0, transposed=True))
+        g_temp = None
+        if ctx.needs_input_grad[1]:
+            dots = torch.stack([torch.dot(q[K - k].reshape(-1), v[k].reshape(-1)) for k in range(K + 1)])
+            g_temp = dots * coefs * (temp > 0).to(dots.dtype)
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            t = q[0] * w[K]
+            for j in range(1, K + 1):
+                t = spmm_axpby(graph, t, 1.0, -1.0, z=q[j], gamma=1.0, gamma_dev=w[K - j:K - j + 1], transposed=True)
+            g_x = t
+        return g_x, g_temp, None, None
+
+
+def bern_filter(x, temp, graph: CSRGraph, coefs):
+    return _BernFilter.apply(x, temp, graph, coefs)

@@ -28,6 +28,9 @@ boundary" (the MMD / GradReverse / Attention goldens do not go through it).
     sparse product sorted by (row, col); ``dense_to_sparse`` lists non-zeros row-major;
     ``remove_self_loops`` masks ``row != col``; ``torch_cluster.random_walk`` steps uniformly
     along row -> col with multiplicity and stays put on a node without out-edges.
+ 9. (dgsda_base.py only) ``get_laplacian(normalization='sym')`` removes self loops, takes the
+    degree over ``row`` and returns ``-D^-1/2 W D^-1/2`` followed by N diagonal ones;
+    ``add_self_loops`` appends N loops with the fill value.
 """
 import inspect
 import math
@@ -239,6 +242,34 @@ def dense_to_sparse(adj):
     return idx, adj[idx[0], idx[1]]
 
 
+def add_self_loops(edge_index, edge_attr=None, fill_value=1., num_nodes=None):
+    """PyG ``add_self_loops``: N loops appended last, existing ones untouched."""
+    n = maybe_num_nodes(edge_index, num_nodes)
+    loops = torch.arange(n, dtype=edge_index.dtype)
+    ei = torch.cat([edge_index, torch.stack([loops, loops])], dim=1)
+    if edge_attr is None:
+        return ei, None
+    return ei, torch.cat([edge_attr, torch.full((n,), float(fill_value), dtype=edge_attr.dtype)])
+
+
+def get_laplacian(edge_index, edge_weight=None, normalization=None, dtype=None, num_nodes=None):
+    """PyG ``get_laplacian``: self loops removed, degree over row; 'sym': -D^-1/2 W D^-1/2 plus N
+    diagonal ones; None: -W plus the degrees."""
+    edge_index, edge_weight = remove_self_loops(edge_index, edge_weight)
+    if edge_weight is None:
+        edge_weight = torch.ones(edge_index.size(1), dtype=dtype or torch.float32)
+    n = maybe_num_nodes(edge_index, num_nodes)
+    row, col = edge_index
+    deg = torch.zeros(n, dtype=edge_weight.dtype).index_add_(0, row, edge_weight)
+    if normalization is None:
+        return add_self_loops(edge_index, -edge_weight, 1., n)[0], torch.cat([-edge_weight, deg])
+    assert normalization == 'sym'
+    dis = deg.pow(-0.5)
+    dis.masked_fill_(dis == float('inf'), 0)
+    w = dis[row] * edge_weight * dis[col]
+    return add_self_loops(edge_index, -w, 1., n)
+
+
 def random_walk(row, col, start, walk_length, p=1, q=1, coalesced=True, num_nodes=None):
     """torch_cluster ``random_walk``: uniform step along row -> col over the (row, col)-sorted
     edge list with multiplicity; a node without out-edges stays put.  (Draws from torch's CPU
@@ -311,6 +342,7 @@ def install():
     utils.add_remaining_self_loops = add_remaining_self_loops
     utils.is_undirected, utils.to_undirected = is_undirected, to_undirected
     utils.remove_self_loops, utils.coalesce, utils.dense_to_sparse = remove_self_loops, coalesce, dense_to_sparse
+    utils.add_self_loops, utils.get_laplacian = add_self_loops, get_laplacian
     tc = _mod('torch_cluster')
     tc.random_walk = random_walk
     nn_utils = _mod('torch_geometric.utils.num_nodes')

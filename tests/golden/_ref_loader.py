@@ -88,6 +88,10 @@ def load_reference(with_pyg_stub=True):
     ns.GNN, ns.DANE = gn.GNN, da.DANE
     td = _load("pygda.models.tdss", "pygda/models/tdss.py")
     ns.TDSS, ns.TwoHopNeighbor = td.TDSS, td.TwoHopNeighbor
+    dgb = _load("pygda.nn.dgsda_base", "pygda/nn/dgsda_base.py")
+    NN.DGSDABase = dgb.DGSDABase
+    dg = _load("pygda.models.dgsda", "pygda/models/dgsda.py")
+    ns.BernProp, ns.DGSDABase, ns.DGSDA = dgb.BernProp, dgb.DGSDABase, dg.DGSDA
     sr = _load("pygda.models.specreg", "pygda/models/specreg.py")
     ns.SpecReg = sr.SpecReg
     ns.gcn_norm, ns.PropGCNConv = prop.gcn_norm, prop.PropGCNConv

@@ -492,6 +492,58 @@ def fx_specreg(ref):
 FIXTURES["specreg"] = fx_specreg
 
 
+def fx_dgsda(ref):
+    """DGSDA (dgsda_base.py / dgsda.py): BernProp forward + gradients (x and the filter coefficients,
+    incl. a negative one that relu clips), forward_model loss + grads, 3-epoch fit()/predict()."""
+    import pygda.models.dgsda as dmod
+    s, t = _domain_pair(171, ns=120, nt=90, f=12, c=3)
+    arrs = dict(_pair_arrays(s, t))
+    g = torch.Generator().manual_seed(172)
+    for K in (3, 8):
+        prop = ref.BernProp(K)
+        with torch.no_grad():
+            prop.temp.copy_(torch.rand(K + 1, generator=g) * 1.5 - 0.25)
+        x = torch.randn(90, 10, generator=g).requires_grad_()
+        out = prop(x, t.edge_index)
+        wgt = torch.randn(90, 10, generator=g)
+        (out * wgt).sum().backward()
+        arrs.update({f"bern{K}_temp": np_(prop.temp), f"bern{K}_x": np_(x), f"bern{K}_out": np_(out),
+                     f"bern{K}_w": np_(wgt), f"bern{K}_gx": np_(x.grad), f"bern{K}_gtemp": np_(prop.temp.grad)})
+    kw = dict(num_layers=2, dropout=0.0, K=4, alpha=0.05, beta=0.5, gamma=0.05, lr=0.01, weight_decay=0.001,
+              device="cpu", epoch=3, verbose=0)
+    m = ref.DGSDA(12, 8, 3, **kw)
+    torch.manual_seed(173)
+    m.dgsda = m.init_model()
+    with torch.no_grad():
+        m.dgsda.prop2.temp.mul_(torch.linspace(1.0, 0.3, 5))          # theta_s != theta_t: the L1 term is live
+    m.dgsda.train()
+    arrs.update(sd_arrays(m.dgsda, "fwd_param/"))
+    torch.manual_seed(174)
+    loss, sl = m.forward_model(s, t)
+    loss.backward()
+    arrs.update(fwd_loss=np_(loss), fwd_src_logits=np_(sl), init_seed=np.int64(173), mmd_seed=np.int64(174))
+    arrs.update(grads(m.dgsda, "fwd_grad/"))
+    losses, accs = [], []
+    orig = dmod.logger
+    dmod.logger = lambda **kw_: (losses.append(kw_["loss"]), accs.append(kw_["source_train_acc"]))
+    try:
+        m = ref.DGSDA(12, 8, 3, **kw)
+        torch.manual_seed(175)
+        m.fit(s, t)
+        logits, labels = m.predict(t)
+        slogits, _ = m.predict(s, source=True)
+    finally:
+        dmod.logger = orig
+    arrs.update(fit_seed=np.int64(175), fit_losses=np.array(losses, dtype=np.float64),
+                fit_accs=np.array(accs, dtype=np.float64), fit_tgt_logits=np_(logits), fit_tgt_labels=np_(labels),
+                fit_src_logits=np_(slogits))
+    arrs.update(sd_arrays(m.dgsda, "fit_final/"))
+    save("dgsda", **arrs)
+
+
+FIXTURES["dgsda"] = fx_dgsda
+
+
 def main(argv):
     ref = load_reference()
     for name in (argv or list(FIXTURES)):

@@ -940,3 +940,89 @@ def test_specreg_with_ppmi_view_and_svd_transform_runs():
     m.fit(s, t)
     logits, labels = m.predict(t)
     assert logits.shape == (120, 3) and torch.isfinite(logits).all()
+
+
+# ------------------------------------------------------------------------ DGSDA --
+def test_spmm_axpby_epilogue_vs_oracle():
+    """alpha*x + beta*(A x) + gamma*z in one launch, forward and transposed CSR, with and without z,
+    device-resident gamma, odd widths, and a hub row that goes through the chunked path."""
+    gen = torch.Generator().manual_seed(21)
+    n = 600
+    src = torch.randint(0, n, (5000,), generator=gen)
+    dst = torch.randint(0, n, (5000,), generator=gen)
+    dst[:900] = 7                                                    # hub destination (> SPLIT_THRESHOLD)
+    ei = torch.stack([src, dst])
+    graph = build_csr(ei.to(DEV), n, add_self_loops="drop", normalize=True, degree_side="row")
+    eio, wo = graph.to_coo()
+    eio, wo = eio.cpu(), wo.cpu()
+    assert bool((eio[0] != eio[1]).all())                            # loops dropped, none appended
+    for d in (128, 10, 3):
+        x = torch.randn(n, d, generator=gen)
+        z = torch.randn(n, d, generator=gen)
+        gam = torch.tensor([0.37])
+        ax = O.propagate(eio, wo, x)
+        axt = O.propagate(eio.flip(0), wo, x)
+        got = ops.spmm_axpby(graph, x.to(DEV), 1.0, -1.0)
+        close(got, x - ax, rtol=1e-5, atol=1e-5)
+        got = ops.spmm_axpby(graph, x.to(DEV), 0.5, 2.0, z=z.to(DEV), gamma=3.0, gamma_dev=gam.to(DEV))
+        close(got, 0.5 * x + 2.0 * ax + 3.0 * 0.37 * z, rtol=1e-5, atol=1e-5)
+        got = ops.spmm_axpby(graph, x.to(DEV), 1.0, 1.0, z=z.to(DEV), gamma=-1.0, transposed=True)
+        close(got, x + axt - z, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("K", [3, 8])
+def test_bern_prop_golden(K):
+    """BernProp forward and both gradients against the reference's O(K^2) evaluation (2K launches
+    here): 1e-5 relative to the largest entry."""
+    from pygda_amd.nn import BernProp
+    g = load_golden("dgsda")
+    prop = BernProp(K).to(DEV)
+    with torch.no_grad():
+        prop.temp.copy_(T(g[f"bern{K}_temp"], DEV))
+    x = T(g[f"bern{K}_x"], DEV).requires_grad_()
+    out = prop(x, T(g["tgt_ei"], DEV))
+    (out * T(g[f"bern{K}_w"], DEV)).sum().backward()
+    for got, want in ((out, g[f"bern{K}_out"]), (x.grad, g[f"bern{K}_gx"]), (prop.temp.grad, g[f"bern{K}_gtemp"])):
+        close(got, want, rtol=1e-4, atol=1e-5 * float(np.abs(want).max()))
+    assert float(prop.temp.grad[torch.from_numpy(g[f"bern{K}_temp"] < 0)].abs().sum()) == 0.0   # relu-clipped
+
+
+def test_dgsda_forward_model_golden():
+    g = load_golden("dgsda")
+    s, t = _pair(g)
+    m = pygda_amd.models.DGSDA(12, 8, 3, num_layers=2, dropout=0.0, K=4, alpha=0.05, beta=0.5, gamma=0.05,
+                               lr=0.01, weight_decay=0.001, device=DEV, epoch=3, verbose=0)
+    torch.manual_seed(int(g["init_seed"]))
+    m.dgsda = m.init_model()
+    with torch.no_grad():
+        m.dgsda.prop2.temp.mul_(torch.linspace(1.0, 0.3, 5, device=DEV))
+    for k, v in sub(g, "fwd_param/").items():
+        close(m.dgsda.state_dict()[k], v, rtol=0, atol=1e-7)
+    m.dgsda.train()
+    torch.manual_seed(int(g["mmd_seed"]))
+    loss, sl = m.forward_model(s.to(DEV), t.to(DEV))
+    loss.backward()
+    close(loss, g["fwd_loss"], rtol=REL)
+    close(sl, g["fwd_src_logits"], rtol=0, atol=LOGIT_ATOL)
+    params = dict(m.dgsda.named_parameters())
+    for k, v in sub(g, "fwd_grad/").items():
+        close(params[k].grad, v, rtol=1e-3, atol=1e-4 * max(np.abs(v).max(), 1e-3))
+
+
+def test_dgsda_fit_predict_golden():
+    g = load_golden("dgsda")
+    s, t = _pair(g)
+    m = pygda_amd.models.DGSDA(12, 8, 3, num_layers=2, dropout=0.0, K=4, alpha=0.05, beta=0.5, gamma=0.05,
+                               lr=0.01, weight_decay=0.001, device=DEV, epoch=3, verbose=0)
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+    torch.manual_seed(int(g["fit_seed"]))
+    m.fit(s, t)
+    close([x[0] for x in seen], g["fit_losses"], rtol=REL)
+    close([x[1] for x in seen], g["fit_accs"], rtol=0, atol=1e-12)
+    logits, labels = m.predict(t)
+    close(logits, g["fit_tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    exact(labels, g["fit_tgt_labels"])
+    exact(logits.argmax(1), g["fit_tgt_logits"].argmax(1))
+    slogits, _ = m.predict(s, source=True)
+    close(slogits, g["fit_src_logits"], rtol=0, atol=LOGIT_ATOL)

@@ -371,3 +371,49 @@ def test_specreg_fit_trajectory():
     with torch.no_grad():
         eq(net.cls_model(net.encode(tgt, "target")), g["fit_tgt_logits"], tol=1e-6)
         eq(net.cls_model(net.encode(src, "source")), g["fit_src_logits"], tol=1e-6)
+
+
+# ------------------------------------------------------------------------ DGSDA --
+@pytest.mark.parametrize("K", [3, 8])
+def test_bern_prop(K):
+    g = load_golden("dgsda")
+    prop = O.BernProp(K)
+    with torch.no_grad():
+        prop.temp.copy_(T(g[f"bern{K}_temp"]))
+    x = T(g[f"bern{K}_x"]).requires_grad_()
+    out = prop(x, T(g["tgt_ei"]))
+    (out * T(g[f"bern{K}_w"])).sum().backward()
+    eq(out, g[f"bern{K}_out"]); eq(x.grad, g[f"bern{K}_gx"], tol=1e-6); eq(prop.temp.grad, g[f"bern{K}_gtemp"], tol=1e-5)
+
+
+def test_dgsda_forward_model_and_fit():
+    g = load_golden("dgsda")
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    torch.manual_seed(int(g["init_seed"]))
+    net = O.DGSDABase(12, 8, 3, dprate=0.0, K=4)
+    with torch.no_grad():
+        net.prop2.temp.mul_(torch.linspace(1.0, 0.3, 5))
+    for k, v in sub(g, "fwd_param/").items():
+        eq(net.state_dict()[k], v)
+    net.train()
+    torch.manual_seed(int(g["mmd_seed"]))
+    loss, sl = O.dgsda_forward_model(net, src, tgt, 0.05, 0.5, 0.05)
+    loss.backward()
+    eq(loss, g["fwd_loss"], tol=1e-6); eq(sl, g["fwd_src_logits"])
+    for k, v in sub(g, "fwd_grad/").items():
+        eq(dict(net.named_parameters())[k].grad, v, tol=1e-5)
+    # three epochs of dgsda.py:300-336
+    torch.manual_seed(int(g["fit_seed"]))
+    net = O.DGSDABase(12, 8, 3, dprate=0.0, K=4)
+    opt = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=0.001)
+    losses = []
+    for _ in range(3):
+        net.train()
+        loss, _ = O.dgsda_forward_model(net, src, tgt, 0.05, 0.5, 0.05)
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(loss.item())
+    eq(np.array(losses), g["fit_losses"], tol=1e-5)
+    net.eval()
+    with torch.no_grad():
+        eq(net(tgt, False), g["fit_tgt_logits"], tol=1e-5); eq(net(src), g["fit_src_logits"], tol=1e-5)
