@@ -11,8 +11,25 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import sparse_features
 from ..graph import as_graph
 from ..ops import bern_filter
+
+
+class _InputLinear(nn.Linear):
+    """``nn.Linear`` (same parameters, same init stream) whose product with a registered sparse
+    input matrix -- the raw bag-of-words features -- runs on the aggregation kernel."""
+
+    def forward(self, x, dropout=0.0):
+        """``linear(dropout(x))``: for a registered sparse input the mask is applied to the stored
+        non-zeros and the product stays sparse (no dense [N, F] mask pass, no dense GEMM)."""
+        if x.dim() == 2 and x.size(1) >= sparse_features.MIN_WIDTH:
+            sf = sparse_features.lookup(x)
+            if sf is not None:
+                return sparse_features.sparse_linear(self.weight, sf, dropout) + self.bias
+        if dropout > 0.0:
+            x = F.dropout(x, p=dropout, training=True)
+        return F.linear(x, self.weight, self.bias)
 
 
 class BernProp(nn.Module):
@@ -43,7 +60,7 @@ class BernProp(nn.Module):
 class DGSDABase(nn.Module):
     def __init__(self, features, hidden, classes, dprate=0.0, K=15):
         super().__init__()
-        self.lin1 = nn.Linear(features, hidden)
+        self.lin1 = _InputLinear(features, hidden)
         self.lin2 = nn.Linear(hidden, classes)
         self.prop1 = BernProp(K)
         self.prop2 = BernProp(K)
@@ -62,7 +79,6 @@ class DGSDABase(nn.Module):
         return self.prop3(x, edge_index)
 
     def get_props(self, x, edge_index, is_source_domain=True):               # :278-315
-        x = F.dropout(x, p=self.dprate, training=self.training)
-        x = F.relu(self.lin1(x))
+        x = F.relu(self.lin1(x, self.dprate if self.training else 0.0))        # dropout folded into lin1
         x = F.dropout(x, p=self.dprate, training=self.training)
         return self.prop1(x, edge_index) if is_source_domain else self.prop2(x, edge_index)

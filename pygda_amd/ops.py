@@ -407,9 +407,10 @@ def laplacian_loss(features, edge_index):
 
 
 # ------------------------------------------- polynomial graph filters (DGSDA BernProp) --
-def spmm_axpby(graph: CSRGraph, x, alpha, beta, z=None, gamma=1.0, gamma_dev=None, transposed=False):
+def spmm_axpby(graph: CSRGraph, x, alpha, beta, z=None, gamma=1.0, gamma_dev=None, transposed=False, out=None):
     """``alpha * x + beta * (A x) + gamma * z`` in one aggregation launch (no autograd).
-    ``gamma_dev``: one-element device tensor multiplied into ``gamma`` (a learnable coefficient)."""
+    ``gamma_dev``: one-element device tensor multiplied into ``gamma`` (a learnable coefficient);
+    ``out``: contiguous ``[n, d]`` fp32 destination (e.g. a slice of a chain buffer)."""
     x = _f32c(x, "x")
     if x.dim() != 2 or x.size(0) != graph.num_nodes:
         raise ValueError(f"x must be [num_nodes={graph.num_nodes}, d], got {tuple(x.shape)}")
@@ -420,7 +421,12 @@ def spmm_axpby(graph: CSRGraph, x, alpha, beta, z=None, gamma=1.0, gamma_dev=Non
         z = _f32c(z, "z")
         if z.shape != x.shape:
             raise ValueError("z must have the shape of x")
-    y = torch.empty_like(x)
+    if out is None:
+        y = torch.empty_like(x)
+    else:
+        y = out
+        if y.shape != x.shape or y.dtype != torch.float32 or not y.is_contiguous() or y.device != x.device:
+            raise ValueError("out must be a contiguous fp32 tensor of the shape of x on its device")
     L = _lib.lib()
     if aggregation_log is not None:
         aggregation_log.append((graph, 1))
@@ -457,32 +463,36 @@ class _BernFilter(torch.autograd.Function):
     def forward(ctx, x, temp, graph, coefs):
         K = temp.numel() - 1
         w = (torch.relu(temp.detach()) * coefs).contiguous()
-        v = [_f32c(x.detach(), "x")]
-        for _ in range(K):
-            v.append(spmm_axpby(graph, v[-1], 1.0, -1.0))
+        x = _f32c(x.detach(), "x")
+        v = torch.empty((K + 1,) + tuple(x.shape), dtype=torch.float32, device=x.device)   # the chain L^k x
+        v[0].copy_(x)
+        for k in range(1, K + 1):
+            spmm_axpby(graph, v[k - 1], 1.0, -1.0, out=v[k])
         s = v[0] * w[0]
         for j in range(1, K + 1):
             s = spmm_axpby(graph, s, 1.0, 1.0, z=v[j], gamma=1.0, gamma_dev=w[j:j + 1])
         ctx.graph, ctx.K = graph, K
-        ctx.save_for_backward(temp, coefs, w, *v)
+        ctx.save_for_backward(temp, coefs, w, v)
         return s
 
     @staticmethod
     def backward(ctx, g):
-        temp, coefs, w, *v = ctx.saved_tensors
+        temp, coefs, w, v = ctx.saved_tensors
         graph, K = ctx.graph, ctx.K
-        q = [g.contiguous()]
-        for _ in range(K):
-            q.append(spmm_axpby(graph, q[-1], 1.0, 1.0, transposed=True))
+        q = torch.empty_like(v)                     # q[K - j] = (I + A^T)^j g: slot k pairs with v[k]
+        q[K].copy_(g)
+        for j in range(1, K + 1):
+            spmm_axpby(graph, q[K - j + 1], 1.0, 1.0, transposed=True, out=q[K - j])
         g_temp = None
-        if ctx.needs_input_grad[1]:
-            dots = torch.stack([torch.dot(q[K - k].reshape(-1), v[k].reshape(-1)) for k in range(K + 1)])
+        if ctx.needs_input_grad[1]:                 # <(I+A^T)^(K-k) g, L^k x> for all k at once
+            dots = (q.view(K + 1, -1) * v.view(K + 1, -1)).sum(dim=1)
             g_temp = dots * coefs * (temp > 0).to(dots.dtype)
         g_x = None
         if ctx.needs_input_grad[0]:
-            t = q[0] * w[K]
+            t = q[K] * w[K]
             for j in range(1, K + 1):
-                t = spmm_axpby(graph, t, 1.0, -1.0, z=q[j], gamma=1.0, gamma_dev=w[K - j:K - j + 1], transposed=True)
+                t = spmm_axpby(graph, t, 1.0, -1.0, z=q[K - j], gamma=1.0, gamma_dev=w[K - j:K - j + 1],
+                               transposed=True)
             g_x = t
         return g_x, g_temp, None, None
 

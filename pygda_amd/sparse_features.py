@@ -31,8 +31,23 @@ class SparseFeatures:
         vals = x[nz[:, 0], nz[:, 1]].contiguous()
         # ingestion kernel: "edge" feature -> node, weight = value; no loops, no normalisation
         self.graph = build_csr(torch.stack([nz[:, 1], nz[:, 0]]), max(n, f), vals, add_self_loops=False,
-                               normalize=False, validate=False)
+                               normalize=False, validate=False, with_edge_map=True)
         self.n, self.f, self.nnz = n, f, int(nz.size(0))
+        self._t_map = None
+
+    @property
+    def t_map(self):
+        """by-feature CSR entry -> by-node CSR position (int64, for index_select), built on first use."""
+        if self._t_map is None:
+            self._t_map = self.graph.t_to_fwd[:self.nnz].to(torch.int64)
+        return self._t_map
+
+    def dropped_values(self, p):
+        """Inverted dropout applied to the stored non-zeros only (zeros stay zero either way, so this
+        is ``F.dropout(x, p)`` on the dense matrix in distribution): values for both CSRs."""
+        keep = (torch.rand(self.nnz, device=self.graph.val.device) >= p).to(torch.float32) / (1.0 - p)
+        val = self.graph.val[:self.nnz] * keep
+        return val, val.index_select(0, self.t_map)
 
 
 def maybe_register(x):
@@ -78,14 +93,15 @@ class _SparseLinear(torch.autograd.Function):
     SpMM ``gW^T = X^T gy``.  X itself carries no gradient (it is the input data)."""
 
     @staticmethod
-    def forward(ctx, weight, sf):
+    def forward(ctx, weight, sf, vals=None):
         wt = weight.t().contiguous()                       # [F, h]
         g = sf.graph
+        val, t_val = (g.val, g.t_val) if vals is None else vals
         with profiler.region(f"sparse_projection[{sf.f}x{weight.size(0)}]", 1,
                              sf.nnz * 8 + (sf.n + 1) * 4 + 4 * (wt.numel() + sf.n * weight.size(0)),
                              2 * sf.nnz * weight.size(0)):
-            y = _spmm(g.rowptr, g.colidx, g.val, sf.n, wt, sf.n, g.split(False))
-        ctx.sf = sf
+            y = _spmm(g.rowptr, g.colidx, val, sf.n, wt, sf.n, g.split(False))
+        ctx.sf, ctx.t_val = sf, t_val
         return y
 
     @staticmethod
@@ -96,9 +112,12 @@ class _SparseLinear(torch.autograd.Function):
         with profiler.region(f"sparse_projection_bwd[{sf.f}x{gy.size(1)}]", 1,
                              sf.nnz * 8 + (sf.f + 1) * 4 + 4 * (gy.numel() + sf.f * gy.size(1)),
                              2 * sf.nnz * gy.size(1)):
-            gwt = _spmm(g.t_rowptr, g.t_colidx, g.t_val, sf.f, gy, sf.f, g.split(True))   # [F, h]
-        return gwt.t(), None
+            gwt = _spmm(g.t_rowptr, g.t_colidx, ctx.t_val, sf.f, gy, sf.f, g.split(True))   # [F, h]
+        return gwt.t(), None, None
 
 
-def sparse_linear(weight, sf):
+def sparse_linear(weight, sf, dropout=0.0):
+    """``X W^T``; with ``dropout > 0`` the product uses ``dropout(X)`` (mask drawn per call)."""
+    if dropout > 0.0:
+        return _SparseLinear.apply(weight, sf, sf.dropped_values(dropout))
     return _SparseLinear.apply(weight, sf)

@@ -1009,11 +1009,13 @@ def test_dgsda_forward_model_golden():
         close(params[k].grad, v, rtol=1e-3, atol=1e-4 * max(np.abs(v).max(), 1e-3))
 
 
-def test_dgsda_fit_predict_golden():
+@pytest.mark.parametrize("graphed", [False, True])
+def test_dgsda_fit_predict_golden(graphed):
     g = load_golden("dgsda")
     s, t = _pair(g)
     m = pygda_amd.models.DGSDA(12, 8, 3, num_layers=2, dropout=0.0, K=4, alpha=0.05, beta=0.5, gamma=0.05,
-                               lr=0.01, weight_decay=0.001, device=DEV, epoch=3, verbose=0)
+                               lr=0.01, weight_decay=0.001, device=DEV, epoch=3, verbose=0,
+                               use_hip_graph=graphed)
     seen = []
     m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
     torch.manual_seed(int(g["fit_seed"]))
