@@ -210,6 +210,9 @@ def main():
     ap.add_argument("--fanout", default="15,10")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel code path (RCCL exchange steps) on a 1-rank group")
+    ap.add_argument("--rccl-direct", action="store_true",
+                    help="collectives through the C ABI's own RCCL communicator (gda_allreduce_f32 / "
+                         "gda_allgather_f32): the whole data-parallel step is then ONE hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -226,6 +229,8 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
             os.environ["PYGDA_AMD_FORCE_DP"] = "1"
+        if args.rccl_direct:
+            os.environ["PYGDA_AMD_RCCL_DIRECT"] = "1"
         # RCCL prints a version banner through C stdio on stdout when the communicator comes up; keep
         # stdout for the ONE JSON line: route fd 1 to stderr until the banner has been flushed
         import ctypes
@@ -237,6 +242,10 @@ def main():
             warm = torch.ones(1, device=dev)
             dist.all_reduce(warm)
             torch.cuda.synchronize()
+            if os.environ.get("PYGDA_AMD_RCCL_DIRECT") == "1":
+                from pygda_amd import distributed as _D
+                _D.direct().all_reduce_(warm)
+                torch.cuda.synchronize()
         finally:
             ctypes.CDLL(None).fflush(None)
             os.dup2(saved_fd, 1)
@@ -276,7 +285,9 @@ def main():
     edges = edges_per_step(nnz_s, nnz_t, hp["L"], hp["s_pnums"], hp["t_pnums"])
 
     graphed = getattr(model, "_graphed", None) is not None
-    model._graphed_kind = "dp" if type(getattr(model, "_graphed", None)).__name__ == "GraphedStepDP" else "single"
+    _g = getattr(model, "_graphed", None)
+    model._graphed_kind = ("dp" if type(_g).__name__ == "GraphedStepDP" else
+                           "dp-whole" if getattr(_g, "dp", False) else "single")
     from pygda_amd import ops as _ops
     _ops.aggregated_edges = 0
     sync()
@@ -339,9 +350,11 @@ def main():
                                "shared by the two passes the reference runs separately (identical values), so a "
                                "step executes fewer aggregations than the reference's step",
                        "nnz_source": nnz_s, "nnz_target": nnz_t,
-                       "execution": ("four hipGraph segments with eager RCCL collectives between them"
-                                     if type(getattr(model, "_graphed_kind", None)).__name__ == "str" and model._graphed_kind == "dp"
-                                     else "hipGraph replay of the captured step") if graphed else "eager launches",
+                       "execution": ({"dp": "four hipGraph segments with eager RCCL collectives between them",
+                                      "dp-whole": "hipGraph replay of the whole data-parallel step, RCCL collectives "
+                                                  "captured (library-owned communicator)"}
+                                     .get(getattr(model, "_graphed_kind", "single"),
+                                          "hipGraph replay of the captured step")) if graphed else "eager launches",
                        "parallelism": "single GPU" if world == 1 else
                        f"dp{world}: one full-batch replica per GPU (cfg-A has one batch per epoch), "
                        "independent dropout draws, global-batch MMD over all-gathered sample rows, "

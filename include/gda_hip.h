@@ -36,6 +36,7 @@ extern "C" {
 #define GDA_E_WORKSPACE (-3) /* workspace too small */
 #define GDA_E_UNSUPPORTED (-4)
 #define GDA_E_ALIAS (-5)     /* output aliases an input that must stay intact */
+#define GDA_E_RCCL (-100)    /* RCCL failure: status = GDA_E_RCCL - ncclResult_t */
 
 typedef void* gda_stream_t;
 
@@ -343,6 +344,29 @@ int gda_two_hop_host(const int64_t* src_host, const int64_t* dst_host, int64_t E
                      int rounds, int threads, gda_edge_list** out);
 int gda_walk_smooth_host(const int64_t* src_host, const int64_t* dst_host, int64_t E, int64_t N,
                          int walk_len, uint64_t seed, int threads, gda_edge_list** out);
+
+/* ------------------------------------------------------------------------------
+ * Data-parallel exchange steps over RCCL (xGMI inside a node), on a communicator owned by this
+ * library and on the caller's stream.  The reference is single-GPU; these are the
+ * collectives SURVEY 8e assigns to the path: ONE flat gradient all-reduce per step and the
+ * all-gather of the MMD sample rows.
+ *   gda_rccl_load       bind librccl at run time (dlopen `path`; NULL/"" = "librccl.so"); pass the
+ *                       copy the host framework already loaded so one RCCL lives in the process.
+ *                       Without it every function below returns GDA_E_UNSUPPORTED.
+ *   gda_comm_unique_id  rank 0 fills 128 bytes (ncclUniqueId) and ships them to the other ranks
+ *                       out of band (the host uses its rendezvous store / a broadcast)
+ *   gda_comm_init_rank  collective over all ranks; returns the communicator handle
+ *   gda_allreduce_f32   in-place sum of buf[count] over the ranks
+ *   gda_allgather_f32   recv[rank * count_per_rank ...] = send of that rank
+ * ---------------------------------------------------------------------------- */
+typedef void* gda_comm_t;
+int gda_rccl_load(const char* path);
+int gda_comm_unique_id(void* id_out, size_t bytes);
+int gda_comm_init_rank(const void* id, size_t bytes, int nranks, int rank, gda_comm_t* comm_out);
+int gda_comm_destroy(gda_comm_t comm);
+int gda_allreduce_f32(float* buf, int64_t count, gda_comm_t comm, gda_stream_t stream);
+int gda_allgather_f32(const float* send, float* recv, int64_t count_per_rank, gda_comm_t comm,
+                      gda_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgda_hip.so")
 SOURCES = ["gda_graph.hip", "gda_spmm.hip", "gda_mmd.hip", "gda_disc.hip", "gda_misc.hip", "gda_gat.hip", "gda_act.hip",
-           "gda_laplacian.hip", "gda_sampler.cpp", "gda_ppmi.cpp", "gda_smooth.cpp"]
+           "gda_laplacian.hip", "gda_sampler.cpp", "gda_ppmi.cpp", "gda_smooth.cpp", "gda_comm.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wno-unused-result", "-Wno-unused-value"]
 
@@ -51,7 +51,7 @@ def build_library(force=False, verbose=False):
     with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     tmp = LIB + ".tmp"
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp],
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", tmp],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

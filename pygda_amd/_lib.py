@@ -63,6 +63,12 @@ _SIGNATURES = {
     "gda_laplacian_workspace_bytes": (c_size_t, [c_int64]),
     "gda_laplacian_fwd_f32": (c_int, [_P, _P, c_int64, c_int, _P, c_int64, _P, _P, _P, c_size_t, _P]),
     "gda_laplacian_bwd_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, c_int64, _P, _P, _P, c_int64, _P]),
+    "gda_rccl_load": (c_int, [ctypes.c_char_p]),
+    "gda_comm_unique_id": (c_int, [_P, c_size_t]),
+    "gda_comm_init_rank": (c_int, [_P, c_size_t, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "gda_comm_destroy": (c_int, [_P]),
+    "gda_allreduce_f32": (c_int, [_P, c_int64, _P, _P]),
+    "gda_allgather_f32": (c_int, [_P, _P, c_int64, _P, _P]),
     "gda_two_hop_host": (c_int, [_P, _P, c_int64, c_int64, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "gda_walk_smooth_host": (c_int, [_P, _P, c_int64, c_int64, c_int, ctypes.c_uint64, c_int,
                                      ctypes.POINTER(c_void_p)]),

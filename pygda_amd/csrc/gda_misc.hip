@@ -39,6 +39,7 @@ extern "C" const char* gda_status_string(int status) {
         default: break;
     }
     if (status > 0) return hipGetErrorString((hipError_t)status);
+    if (status <= GDA_E_RCCL) return "gda: RCCL call failed (ncclResult_t = GDA_E_RCCL - status)";
     return "gda: unknown status";
 }
 

@@ -7,8 +7,69 @@ Two exchange steps per training step, both small and latency-bound:
 * an all-gather of the MMD sample rows, so that the pairwise loss is taken over the GLOBAL
   batch (the cross-domain statistic cannot be formed from per-rank losses).
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
+
+
+class _DirectComm:
+    """RCCL communicator owned by libgda_hip.so (include/gda_hip.h: gda_comm_*): the two exchange
+    steps become plain enqueues on the current stream -- no ProcessGroup work objects, no watchdog
+    events -- which is what lets a whole data-parallel step be captured into ONE hipGraph.
+    Opt-in (``PYGDA_AMD_RCCL_DIRECT=1``); the rendezvous (shipping the 128-byte id) still rides on
+    the torch.distributed group the launcher set up."""
+
+    def __init__(self):
+        from . import _lib
+        self.L = L = _lib.lib()
+        self._lib = _lib
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        _lib.check(L.gda_rccl_load(path.encode() if os.path.isfile(path) else None), "gda_rccl_load")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if dist.get_rank() == 0:
+            buf = (ctypes.c_char * 128)()
+            _lib.check(L.gda_comm_unique_id(buf, 128), "gda_comm_unique_id")
+            uid = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+        uid = uid.to(dev)
+        dist.broadcast(uid, src=0)
+        raw = bytes(uid.cpu().tolist())
+        handle = ctypes.c_void_p()
+        _lib.check(L.gda_comm_init_rank(raw, 128, dist.get_world_size(), dist.get_rank(), ctypes.byref(handle)),
+                   "gda_comm_init_rank")
+        self.handle = handle
+
+    def all_reduce_(self, flat):
+        self._lib.check(self.L.gda_allreduce_f32(self._lib.ptr(flat), flat.numel(), self.handle,
+                                                 self._lib.stream()), "gda_allreduce_f32")
+
+    def all_gather(self, out, x):
+        self._lib.check(self.L.gda_allgather_f32(self._lib.ptr(x), self._lib.ptr(out), x.numel(), self.handle,
+                                                 self._lib.stream()), "gda_allgather_f32")
+
+
+_direct = None
+
+
+def direct():
+    """The library-owned communicator, or None (default: collectives go through torch.distributed)."""
+    global _direct
+    if os.environ.get("PYGDA_AMD_RCCL_DIRECT") != "1" or not active() or dist.get_backend() != "nccl":
+        return None
+    if _direct is None:
+        _direct = _DirectComm()
+    return _direct
+
+
+def shutdown_direct():
+    """Destroy the library-owned communicator (tests; normal runs keep it for the process lifetime)."""
+    global _direct
+    if _direct is not None:
+        torch.cuda.synchronize()
+        _direct._lib.check(_direct.L.gda_comm_destroy(_direct.handle), "gda_comm_destroy")
+        _direct = None
 
 
 def info():
@@ -20,7 +81,6 @@ def info():
 def active():
     """True when the data-parallel exchange steps must run.  ``PYGDA_AMD_FORCE_DP=1`` switches them
     on for a 1-rank group too (single-GPU test of the multi-GPU code path)."""
-    import os
     if not (dist.is_available() and dist.is_initialized()):
         return False
     return dist.get_world_size() > 1 or os.environ.get("PYGDA_AMD_FORCE_DP") == "1"
@@ -35,7 +95,11 @@ def allreduce_grads(params):
         if p.grad is None:
             p.grad = torch.zeros_like(p)
     flat = torch.cat([p.grad.reshape(-1) for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    comm = direct() if flat.dtype == torch.float32 and flat.is_cuda else None
+    if comm is not None:
+        comm.all_reduce_(flat)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat.div_(dist.get_world_size())
     off = 0
     for p in params:
@@ -54,7 +118,10 @@ class _AllGatherRows(torch.autograd.Function):
     def forward(ctx, x):
         w = dist.get_world_size()
         out = torch.empty((w,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-        if dist.get_backend() == "nccl":       # single-buffer form: no staging copies, graph-capturable
+        comm = direct() if x.dtype == torch.float32 and x.is_cuda else None
+        if comm is not None:
+            comm.all_gather(out, x.contiguous())
+        elif dist.get_backend() == "nccl":     # single-buffer form: no staging copies
             dist.all_gather_into_tensor(out, x.contiguous())
         else:
             dist.all_gather(list(out.unbind(0)), x.contiguous())

@@ -21,8 +21,12 @@ from .utils import mmd as _mmd
 class GraphedStep:
     """Captures ``loss, logits = step_fn(src, tgt)``, ``backward`` and ``optimizer.step()``."""
 
-    def __init__(self, step_fn, optimizer, src, tgt, warmup=3):
-        self.step_fn, self.optimizer, self.src, self.tgt = step_fn, optimizer, src, tgt
+    def __init__(self, step_fn, optimizer, src, tgt, warmup=3, dp=False):
+        """``dp``: data-parallel step with the library-owned RCCL communicator -- the gradient
+        all-reduce and the MMD row all-gather are enqueued on the capturing stream like any kernel,
+        so the whole step is still ONE graph."""
+        self.step_fn, self.optimizer, self.src, self.tgt, self.dp = step_fn, optimizer, src, tgt, dp
+        self._dp_idx = {}                 # (ns, nt, times, per) -> (dev_s, dev_t, pin_s, pin_t)
         self._samples = {}                # (ns, nt, times, n) -> (dev_s, dev_t, pin_s, pin_t)
         self._order = []
         self.graph = None
@@ -57,9 +61,29 @@ class GraphedStep:
         for d, p in zip(devb, pins):
             d.copy_(p, non_blocking=True)
 
+    def _provider_dp(self, ns, nt, times, per):
+        key = (ns, nt, times, per)
+        if key not in self._dp_idx:
+            dev = self.src.x.device
+            bufs = [torch.zeros((times, per), dtype=torch.int64, device=dev) for _ in range(2)]
+            pins = [torch.zeros((times, per), dtype=torch.int64).pin_memory() for _ in range(2)]
+            self._dp_idx[key] = (bufs, pins)
+            self._fill_dp(key)
+        return tuple(self._dp_idx[key][0])
+
+    def _fill_dp(self, key):
+        ns, nt, times, per = key
+        bufs, pins = self._dp_idx[key]
+        torch.randint(ns, (times, per), out=pins[0])                # the eager DP branch's draws, same order
+        torch.randint(nt, (times, per), out=pins[1])
+        for d, p in zip(bufs, pins):
+            d.copy_(p, non_blocking=True)
+
     def _refill(self):
         for key in self._order:
             self._fill_one(key)
+        for key in self._dp_idx:
+            self._fill_dp(key)
 
     def _run(self):
         from .ops import dropout_state
@@ -67,6 +91,9 @@ class GraphedStep:
         loss, logits = self.step_fn(self.src, self.tgt)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        if self.dp:
+            from .distributed import allreduce_grads
+            allreduce_grads(p for g in self.optimizer.param_groups for p in g["params"])
         self.optimizer.step()
         return loss, logits
 
@@ -74,8 +101,9 @@ class GraphedStep:
     def capture(self):
         """Warm-up steps are rolled back afterwards (parameters, Adam moments / step counters,
         the CPU generator), so a seeded fit() takes exactly the steps eager mode would."""
-        prev = _mmd.sample_provider
+        prev, prev_dp = _mmd.sample_provider, _mmd.dp_index_provider
         _mmd.sample_provider = self._provider
+        _mmd.dp_index_provider = self._provider_dp if self.dp else None
         params = [p for g in self.optimizer.param_groups for p in g["params"]]
         saved = [p.detach().clone() for p in params]
         cpu_rng = torch.get_rng_state()
@@ -103,7 +131,7 @@ class GraphedStep:
                             v.zero_()
             torch.set_rng_state(cpu_rng)
         finally:
-            _mmd.sample_provider = prev
+            _mmd.sample_provider, _mmd.dp_index_provider = prev, prev_dp
         return self
 
     def __call__(self):

@@ -124,8 +124,10 @@ class BaseGDA(ABC):
         from ..distributed import active
         if not torch.cuda.is_available():
             return None
+        from ..distributed import direct
         dp = active()
-        if dp and not hasattr(self, "_dp_graph_parts"):
+        whole = dp and direct() is not None           # library-owned RCCL communicator: collectives capture
+        if dp and not whole and not hasattr(self, "_dp_graph_parts"):
             return None       # RCCL collectives abort under stream capture on this stack (ROCm 7.0 /
                               # torch 2.10): without a segmented step, data-parallel training stays eager
         if not (getattr(self.source_loader, "full_batch", False) and getattr(self.target_loader, "full_batch", False)):
@@ -136,6 +138,10 @@ class BaseGDA(ABC):
         src = next(iter(self.source_loader)).to(self.device)
         tgt = next(iter(self.target_loader)).to(self.device)
         (before_step or net.train)()
+        if whole:
+            self._graphed = GraphedStep(lambda s, t: step_fn(s, t, 0.0, 0), optimizer, src, tgt, dp=True).capture()
+            self._graphed_key = id(optimizer)
+            return self._graphed
         if dp:                # collectives stay eager between four captured segments
             def eager_step():
                 from ..ops import dropout_state

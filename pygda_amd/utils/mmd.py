@@ -29,6 +29,7 @@ def get_MMD(source_feat, target_feat, kernel_mul=2.0, kernel_num=5, fix_sigma=No
 # int64 tensors.  The hipGraph-captured training step installs one that hands out STATIC device
 # buffers which it refills (from the same CPU-generator draws) before every replay.
 sample_provider = None
+dp_index_provider = None       # same idea for the data-parallel branch: (n_src, n_tgt, times, per) -> indices
 
 
 def MMD(source_feat, target_feat, sampling_num=1000, times=5):
@@ -43,8 +44,11 @@ def MMD(source_feat, target_feat, sampling_num=1000, times=5):
         # evaluates the same global-batch MMD; gradients return to the rows a rank owns.
         w = distributed.info()["world_size"]
         per = -(-sampling_num // w)
-        s_idx = torch.randint(source_feat.size(0), (times, per)).to(dev, non_blocking=True)
-        t_idx = torch.randint(target_feat.size(0), (times, per)).to(dev, non_blocking=True)
+        if dp_index_provider is not None:       # captured step: static device buffers, refilled per replay
+            s_idx, t_idx = dp_index_provider(source_feat.size(0), target_feat.size(0), times, per)
+        else:
+            s_idx = torch.randint(source_feat.size(0), (times, per)).to(dev, non_blocking=True)
+            t_idx = torch.randint(target_feat.size(0), (times, per)).to(dev, non_blocking=True)
         s_rows = distributed.all_gather_rows(sample_rows(source_feat, s_idx))     # [W, times, per, d]
         t_rows = distributed.all_gather_rows(sample_rows(target_feat, t_idx))
         d = source_feat.size(1)

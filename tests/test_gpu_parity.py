@@ -695,6 +695,48 @@ def test_dp_segmented_hipgraph_single_rank_nccl(monkeypatch):
     close(logits, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
 
 
+@pytest.mark.parametrize("graphed", [False, True])
+def test_dp_direct_rccl_single_rank(monkeypatch, graphed):
+    """The exchange steps through the C ABI's own RCCL communicator (gda_comm_* / gda_allreduce_f32 /
+    gda_allgather_f32 on the current stream), eager and with the WHOLE data-parallel step -- both
+    collectives included -- captured into one hipGraph; 1-rank group, reference trajectory."""
+    import torch.distributed as dist
+    import socket
+    from pygda_amd import distributed as D
+    from pygda_amd.hipgraph import GraphedStep
+    g = load_golden("a2gnn_fit3_mmd")
+    s, t = _pair(g)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1"); monkeypatch.setenv("MASTER_PORT", str(port))
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        monkeypatch.setenv("PYGDA_AMD_FORCE_DP", "1")
+        monkeypatch.setenv("PYGDA_AMD_RCCL_DIRECT", "1")
+        assert D.direct() is not None
+        x = torch.arange(12, dtype=torch.float32, device=DEV)
+        D.direct().all_reduce_(x)                                   # 1 rank: identity
+        exact(x, np.arange(12, dtype=np.float32))
+        out = torch.empty(1, 12, device=DEV)
+        D.direct().all_gather(out, x)
+        exact(out[0], x)
+        m = pygda_amd.models.A2GNN(24, 16, 5, num_layers=2, dropout=0.0, s_pnums=0, t_pnums=10, weight=10,
+                                   lr=0.01, weight_decay=0.005, device=DEV, epoch=3, verbose=0,
+                                   use_hip_graph=graphed)
+        seen = []
+        m.epoch_hook = lambda e, loss, acc, secs: seen.append(loss)
+        torch.manual_seed(int(g["seed"]))
+        m.fit(s, t)
+        if graphed:
+            assert isinstance(getattr(m, "_graphed", None), GraphedStep) and m._graphed.dp
+        logits, _ = m.predict(t)
+    finally:
+        D.shutdown_direct()
+        dist.destroy_process_group()
+    close(seen, g["losses"], rtol=REL)
+    close(logits, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+
+
 # ------------------------------------------------------- fused ReLU + dropout --
 def test_relu_dropout_fused():
     from pygda_amd.ops import dropout_state, relu_dropout
