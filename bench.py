@@ -57,7 +57,7 @@ def make_cfg_a(seed=200, ns=9360, es=15556, nt=5484, et=8117, feat=6775, classes
     return graph(ns, es), graph(nt, et)
 
 
-def pmc_traffic(prefix="k_spmm<32, 4>"):
+def pmc_traffic(prefix="k_spmm<32, 4"):
     """HBM-side bytes per launch of the aggregation kernel from the committed rocprofv3 PMC passes
     (profiles/*_rocprof_summary.json, made by tools/summarize_rocprof.py: separate --pmc FETCH_SIZE
     and --pmc WRITE_SIZE runs of this same command, 2 x FETCH + WRITE per the gfx950 correction).
