@@ -34,32 +34,59 @@ class GraphedStep:
         self.loss = self.logits = None
 
     # -- MMD sample plumbing ---------------------------------------------------------
+    @staticmethod
+    def _carve(block, shapes):
+        """Typed views of one byte block (offsets 16-byte aligned)."""
+        views, off = [], 0
+        for sh, dt in shapes:
+            n = 1
+            for v in sh:
+                n *= v
+            nbytes = n * torch.empty(0, dtype=dt).element_size()
+            views.append(block[off:off + nbytes].view(dt).view(sh))
+            off += (nbytes + 15) // 16 * 16
+        return views
+
     def _provider(self, ns, nt, times, n):
-        """Static device buffers: the row samples and the selection CSRs of their scatter."""
+        """Static device buffers: the row samples and the selection CSRs of their scatter -- ONE
+        device block and two pinned host blocks (double-buffered), so a refill is one H2D copy and
+        the host may prepare step e+1 while the copy of step e is still in flight."""
         key = (ns, nt, times, n)
         if key not in self._samples:
             dev = self.src.x.device
             shapes = [((times, n), torch.int64), ((times, n), torch.int64), ((ns + 1,), torch.int32),
                       ((times * n,), torch.int32), ((nt + 1,), torch.int32), ((times * n,), torch.int32)]
-            devb = [torch.zeros(sh, dtype=dt, device=dev) for sh, dt in shapes]
-            pins = [torch.zeros(sh, dtype=dt).pin_memory() for sh, dt in shapes]
+            total = sum((torch.empty(0, dtype=dt).element_size() * int(torch.tensor(sh).prod()) + 15) // 16 * 16
+                        for sh, dt in shapes)
+            dev_block = torch.zeros(total, dtype=torch.uint8, device=dev)
+            pin_blocks = [torch.zeros(total, dtype=torch.uint8).pin_memory() for _ in range(2)]
             ones = torch.ones(times * n, dtype=torch.float32, device=dev)
-            self._samples[key] = (devb, pins, ones)
+            self._samples[key] = dict(dev=dev_block, devv=self._carve(dev_block, shapes), pin=pin_blocks,
+                                      pinv=[self._carve(b, shapes) for b in pin_blocks],
+                                      done=[None, None], turn=0, ones=ones)
             self._order.append(key)
             self._fill_one(key)
-        devb, _, ones = self._samples[key]
-        return devb[0], devb[1], (devb[2], devb[3], devb[4], devb[5], ones)
+        e = self._samples[key]
+        d = e["devv"]
+        return d[0], d[1], (d[2], d[3], d[4], d[5], e["ones"])
 
     def _fill_one(self, key):
         from .ops import selection_csr_host
         ns, nt, times, n = key
-        devb, pins, _ = self._samples[key]
+        e = self._samples[key]
+        k = e["turn"]
+        e["turn"] = 1 - k
+        if e["done"][k] is not None:
+            e["done"][k].synchronize()                              # the copy that last read this block
+        pins = e["pinv"][k]
         torch.randint(ns, (times, n), out=pins[0])                  # eager MMD()'s draws, same order,
         torch.randint(nt, (times, n), out=pins[1])                  # straight into pinned memory
         selection_csr_host(pins[0], ns, 0, 2 * n, out=(pins[2], pins[3]))
         selection_csr_host(pins[1], nt, n, 2 * n, out=(pins[4], pins[5]))
-        for d, p in zip(devb, pins):
-            d.copy_(p, non_blocking=True)
+        e["dev"].copy_(e["pin"][k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        e["done"][k] = ev
 
     def _provider_dp(self, ns, nt, times, per):
         key = (ns, nt, times, per)
@@ -121,7 +148,14 @@ class GraphedStep:
             # invalidate the capture
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 loss, logits = self._run()
+                # per-epoch numbers of the reference's loop (loss, source micro-F1 = accuracy): two
+                # doubles produced inside the graph, so an epoch needs ONE small D2H
+                correct = (logits.detach().argmax(dim=1) == self.src.y).sum()
+                self.stats = torch.stack([loss.detach().double(), correct.double()])
             self.loss, self.logits = loss.detach(), logits.detach()
+            self._stat_pins = [torch.zeros(2, dtype=torch.float64).pin_memory() for _ in range(2)]
+            self._stat_events = [None, None]
+            self._stat_turn = 0
             with torch.no_grad():
                 for p, v in zip(params, saved):
                     p.copy_(v)
@@ -138,6 +172,26 @@ class GraphedStep:
         self._refill()
         self.graph.replay()
         return self.loss, self.logits
+
+    # -- pipelined epochs: launch step e+1 before reading the numbers of step e --------------
+    def launch(self):
+        """Refill + replay + asynchronous read-back of (loss, correct); returns a ticket."""
+        self._refill()
+        self.graph.replay()
+        k = self._stat_turn
+        self._stat_turn = 1 - k
+        self._stat_pins[k].copy_(self.stats, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._stat_events[k] = ev
+        return k
+
+    def result(self, ticket):
+        """(loss, source accuracy) of the step behind ``ticket`` (at most one newer launch may exist)."""
+        self._stat_events[ticket].synchronize()
+        loss, correct = self._stat_pins[ticket].tolist()
+        n = self.src.y.numel()
+        return loss, (correct / n if n else 0.0)
 
 
 class GraphedStepDP:

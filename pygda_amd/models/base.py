@@ -77,6 +77,8 @@ class BaseGDA(ABC):
         ``range(self.epoch)``) lets a harness run the same loop in slices."""
         start = time.time()
         graphed = self._maybe_graphed_step(optimizer, step_fn, before_step, net)
+        if graphed is not None and hasattr(graphed, "launch"):
+            return self._graphed_epochs(graphed, range(self.epoch) if epochs is None else epochs, start)
         for epoch in (range(self.epoch) if epochs is None else epochs):
             epoch_loss, logits, labels = 0.0, [], []
             alpha = alpha_fn(epoch)
@@ -109,6 +111,27 @@ class BaseGDA(ABC):
                    verbose=self.verbose, train=True)
             if self.epoch_hook is not None:
                 self.epoch_hook(epoch, epoch_loss, acc, secs)
+
+    def _graphed_epochs(self, graphed, epochs, start):
+        """Full-batch epochs as hipGraph replays, software-pipelined by one step: the host draws the
+        MMD samples of epoch e+1 and launches it while epoch e's two numbers (loss, source accuracy --
+        micro-F1 of single-label predictions -- computed inside the graph) travel back, so the GPU
+        never waits for the log line.  Same values, same order, reported one launch later."""
+        def report(epoch, ticket):
+            loss, acc = graphed.result(ticket)
+            secs = time.time() - start
+            logger(epoch=epoch, loss=loss, source_train_acc=acc, time=secs, verbose=self.verbose, train=True)
+            if self.epoch_hook is not None:
+                self.epoch_hook(epoch, loss, acc, secs)
+
+        pending = None
+        for epoch in epochs:
+            ticket = graphed.launch()
+            if pending is not None:
+                report(*pending)
+            pending = (epoch, ticket)
+        if pending is not None:
+            report(*pending)
 
     def _maybe_graphed_step(self, optimizer, step_fn, before_step, net):
         """A captured step when asked for and legal: one full-batch pair, single process, and a
