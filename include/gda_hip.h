@@ -368,6 +368,28 @@ int gda_allreduce_f32(float* buf, int64_t count, gda_comm_t comm, gda_stream_t s
 int gda_allgather_f32(const float* send, float* recv, int64_t count_per_rank, gda_comm_t comm,
                       gda_stream_t stream);
 
+/* ------------------------------------------------------------------------------
+ * Step epilogue: the Adam update.
+ *
+ * gda_adam_multi_f32: one torch.optim.Adam step (amsgrad off, maximize off) over up to
+ *   GDA_ADAM_MAX_TENSORS fp32 tensors in one launch -- the optimiser of every trainer
+ *   (pygda/models/a2gnn.py:290-294).  grad += weight_decay * param; m = lerp(m, grad, 1-beta1);
+ *   v = beta2 v + (1-beta2) grad^2; param -= lr/(1-beta1^t) * m / (sqrt(v)/sqrt(1-beta2^t) + eps).
+ *   `step` of every tensor is a device float holding t-1 (torch keeps one per parameter); it is
+ *   incremented first (capturable: no host state).  Tensors with numel 0 are skipped.
+ * ---------------------------------------------------------------------------- */
+#define GDA_ADAM_MAX_TENSORS 48
+typedef struct gda_adam_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    float* step;
+    int64_t numel;
+} gda_adam_tensor;
+int gda_adam_multi_f32(const gda_adam_tensor* tensors /* HOST array */, int n_tensors, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, gda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

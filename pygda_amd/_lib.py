@@ -63,6 +63,7 @@ _SIGNATURES = {
     "gda_laplacian_workspace_bytes": (c_size_t, [c_int64]),
     "gda_laplacian_fwd_f32": (c_int, [_P, _P, c_int64, c_int, _P, c_int64, _P, _P, _P, c_size_t, _P]),
     "gda_laplacian_bwd_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, c_int64, _P, _P, _P, c_int64, _P]),
+    "gda_adam_multi_f32": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, c_float, _P]),
     "gda_rccl_load": (c_int, [ctypes.c_char_p]),
     "gda_comm_unique_id": (c_int, [_P, c_size_t]),
     "gda_comm_init_rank": (c_int, [_P, c_size_t, c_int, c_int, ctypes.POINTER(c_void_p)]),
@@ -74,6 +75,12 @@ _SIGNATURES = {
                                      ctypes.POINTER(c_void_p)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+class AdamTensorStruct(ctypes.Structure):
+    """``gda_adam_tensor`` of include/gda_hip.h."""
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
+                ("step", c_void_p), ("numel", c_int64)]
+
 
 class RowSplitStruct(ctypes.Structure):
     """``gda_row_split`` of include/gda_hip.h."""

@@ -122,9 +122,11 @@ class A2GNN(BaseGDA):
         import os
         graph = self.use_hip_graph if self.use_hip_graph is not None else os.environ.get("PYGDA_AMD_HIPGRAPH") == "1"
         on_gpu = torch.device(self.device).type == "cuda"
-        optimizer = torch.optim.Adam(self.a2gnn.parameters(), lr=self.lr, weight_decay=self.weight_decay,
-                                     capturable=bool(graph and self._graph_safe_step and self.batch_size == 0),
-                                     fused=True if on_gpu else None)      # one kernel instead of ~10
+        if on_gpu:           # torch.optim.Adam's update in one multi-tensor launch (pygda_amd/optim.py)
+            from ..optim import Adam
+            optimizer = Adam(self.a2gnn.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        else:
+            optimizer = torch.optim.Adam(self.a2gnn.parameters(), lr=self.lr, weight_decay=self.weight_decay)
 
         def step(src, tgt, alpha, epoch):
             loss, source_logits, _ = self.forward_model(src, tgt, alpha)

@@ -50,9 +50,11 @@ class DGSDA(BaseGDA):
         self._graph_safe_step = True          # nothing in the step depends on per-epoch Python scalars
         graph = self.use_hip_graph if self.use_hip_graph is not None else os.environ.get("PYGDA_AMD_HIPGRAPH") == "1"
         on_gpu = torch.device(self.device).type == "cuda"
-        optimizer = torch.optim.Adam(self.dgsda.parameters(), lr=self.lr, weight_decay=self.weight_decay,
-                                     capturable=bool(graph and self.batch_size == 0),
-                                     fused=True if on_gpu else None)
+        if on_gpu:
+            from ..optim import Adam
+            optimizer = Adam(self.dgsda.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        else:
+            optimizer = torch.optim.Adam(self.dgsda.parameters(), lr=self.lr, weight_decay=self.weight_decay)
 
         def step(src, tgt, alpha, epoch):
             return self.forward_model(src, tgt)

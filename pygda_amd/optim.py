@@ -1,0 +1,60 @@
+"""``torch.optim.Adam`` semantics on one multi-tensor HIP launch (include/gda_hip.h:
+``gda_adam_multi_f32``).  Every trainer of the reference builds ``torch.optim.Adam(params, lr,
+weight_decay)`` (pygda/models/a2gnn.py:290-294); torch's fused implementation chunks tensors by
+65536 elements, which leaves a model with one 867k-element weight and a few small ones on ~20
+workgroups (42 us per step at cfg-A).  Same update rule, 2048-element work items, device-resident
+step counters (hipGraph-capturable by construction)."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+MAX_TENSORS = 48
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError("invalid Adam hyper-parameter")
+        # `capturable` is what the hipGraph step looks for (pygda_amd/models/base.py)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=True))
+
+    def _state(self, p):
+        st = self.state[p]
+        if not st:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.lib()
+        for group in self.param_groups:
+            live = [p for p in group["params"] if p.grad is not None]
+            for i in range(0, len(live), MAX_TENSORS):
+                chunk = live[i:i + MAX_TENSORS]
+                table = (_lib.AdamTensorStruct * len(chunk))()
+                keep = []
+                for k, p in enumerate(chunk):
+                    _lib.require_gpu_tensor(p, "parameter", torch.float32)
+                    g = p.grad
+                    if g.is_sparse or g.dtype != torch.float32:
+                        raise _lib.GdaError("Adam: dense fp32 gradients only")
+                    if not p.is_contiguous():
+                        raise _lib.GdaError("Adam: parameters must be contiguous")
+                    g = g.contiguous()
+                    keep.append(g)
+                    st = self._state(p)
+                    table[k] = _lib.AdamTensorStruct(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                                     st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), p.numel())
+                b1, b2 = group["betas"]
+                _lib.check(L.gda_adam_multi_f32(table, len(chunk), float(group["lr"]), float(b1), float(b2),
+                                                float(group["eps"]), float(group["weight_decay"]), _lib.stream()),
+                           "gda_adam_multi_f32")
+        return loss

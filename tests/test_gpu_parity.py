@@ -1070,3 +1070,28 @@ def test_dgsda_fit_predict_golden(graphed):
     exact(logits.argmax(1), g["fit_tgt_logits"].argmax(1))
     slogits, _ = m.predict(s, source=True)
     close(slogits, g["fit_src_logits"], rtol=0, atol=LOGIT_ATOL)
+
+
+# ------------------------------------------------------------ step epilogue kernels --
+def test_fused_adam_matches_torch_adam():
+    """Same trajectory as torch.optim.Adam over 6 steps: weight decay, a parameter that receives no
+    gradient in some steps (its step counter must not advance), a large and a tiny tensor."""
+    from pygda_amd.optim import Adam
+    gen = torch.Generator().manual_seed(4)
+    shapes = [(6775, 128), (128,), (128, 128), (5,), (3, 1)]
+    init = [torch.randn(s, generator=gen) for s in shapes]
+    ours = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    ref = [torch.nn.Parameter(t.clone().double()) for t in init]
+    o1 = Adam(ours, lr=0.01, weight_decay=0.005)
+    o2 = torch.optim.Adam(ref, lr=0.01, weight_decay=0.005)
+    for step in range(6):
+        for k, (a, b) in enumerate(zip(ours, ref)):
+            if k == 3 and step % 2 == 1:
+                a.grad, b.grad = None, None
+                continue
+            g = torch.randn(shapes[k], generator=gen)
+            a.grad, b.grad = g.to(DEV), g.double()
+        o1.step(); o2.step()
+    for a, b in zip(ours, ref):
+        close(a, b.float(), rtol=2e-5, atol=1e-6)
+    assert float(o1.state[ours[3]]["step"]) == 3.0 and float(o1.state[ours[0]]["step"]) == 6.0
