@@ -390,6 +390,24 @@ typedef struct gda_adam_tensor {
 int gda_adam_multi_f32(const gda_adam_tensor* tensors /* HOST array */, int n_tensors, float lr, float beta1,
                        float beta2, float eps, float weight_decay, gda_stream_t stream);
 
+/* ------------------------------------------------------------------------------
+ * Tall-skinny fp32 GEMMs on the matrix cores: the dense projection of the hidden / classifier
+ * layers and its two gradient products (`self.lin(x)`, pygda/nn/prop_gcn_conv.py:204,
+ * cached_gcn_conv.py:129, and autograd's dgrad / wgrad).  One operand is tall (rows = nodes).
+ *   GDA_GEMM_NT  C[M,N] = A[M,K] * B[N,K]^T      forward  y  = x W^T
+ *   GDA_GEMM_NN  C[M,N] = A[M,K] * B[K,N]        dgrad    gx = gy W
+ *   GDA_GEMM_TN  C[M,N] = A[K,M]^T * B[K,N]      wgrad    gW = gy^T x  (K = nodes; deterministic split
+ *                                                over row slabs, scratch from gda_gemm_workspace_bytes)
+ * Row-major with leading dimensions in elements; C must not alias A or B.
+ * ---------------------------------------------------------------------------- */
+#define GDA_GEMM_NT 0
+#define GDA_GEMM_NN 1
+#define GDA_GEMM_TN 2
+size_t gda_gemm_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K);
+int gda_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                 const float* B, int64_t ldb, float* C, int64_t ldc,
+                 void* workspace, size_t workspace_bytes, gda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,230 @@
+// fp32 GEMMs of the hidden / classifier projections on the gfx950 matrix cores, for the shapes this
+// path has: one TALL operand (rows = nodes, 10^3..10^7) against a SMALL weight (<= 256 x 256).
+//
+// Replaces the dense part of `self.lin(x)` in PropGCNConv / CachedGCNConv / GCNConv
+// (pygda/nn/prop_gcn_conv.py:204, cached_gcn_conv.py:129) and its two autograd GEMMs.  The BLAS
+// picks 128x128 macro-tiles for these shapes (74 workgroups for 9360 rows: under a third of the
+// chip, 14 us for a 0.3 GFLOP product that moves 10 MB); here a workgroup owns a 64x64 tile
+// (294 workgroups), one 32x32 v_mfma_f32_32x32x2_f32 accumulator per wave, 32-deep K chunks staged
+// k-major in LDS so that both operands are conflict-free ds_read_b32 -- the tiling of k_pairdist
+// (gda_mmd.hip).  The fp32 MFMA is an exact k-ordered fma chain: results differ from the BLAS only
+// by summation order.
+//
+//   NT  C[i,n] = sum_k A[i,k] B[n,k]   forward  y  = x W^T      (A tall)
+//   NN  C[i,n] = sum_k A[i,k] B[k,n]   dgrad    gx = gy W       (A tall)
+//   TN  C[m,n] = sum_i A[i,m] B[i,n]   wgrad    gW = gy^T x     (reduction over the tall dimension:
+//                                      split into row slabs, partial tiles summed in slab order --
+//                                      a deterministic split-K)
+#include "gda_common.h"
+
+namespace {
+
+constexpr int TB = 256;
+constexpr int TILE = 64;
+constexpr int DK = 32;
+constexpr int LDT = TILE + 4;
+constexpr int PF = 4;           // K chunks in flight per workgroup
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// element (r, c) of a row-major matrix with bounds (zero outside), 4 consecutive columns
+__device__ __forceinline__ float4 ld4(const float* __restrict__ p, int64_t ld, int64_t r, int64_t c,
+                                      int64_t rows, int64_t cols, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r >= rows) return v;
+    const float* q = p + r * ld + c;
+    if (vec && c + 3 < cols) return *reinterpret_cast<const float4*>(q);
+    if (c + 0 < cols) v.x = q[0];
+    if (c + 1 < cols) v.y = q[1];
+    if (c + 2 < cols) v.z = q[2];
+    if (c + 3 < cols) v.w = q[3];
+    return v;
+}
+
+// branch-free variant for the common case (16-byte aligned rows, column count a multiple of 4, so a
+// float4 is inside or outside as a whole): out-of-range addresses are clamped, the value zeroed
+__device__ __forceinline__ float4 ld4_fast(const float* __restrict__ p, int64_t ld, int64_t r, int64_t c,
+                                           int64_t rows, int64_t cols) {
+    const int64_t rr = min(r, rows - 1), cc = min(c, cols - 4);
+    float4 v = *reinterpret_cast<const float4*>(p + rr * ld + cc);
+    const bool in = r < rows && c < cols;
+    v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
+    return v;
+}
+
+// Operand tile into S[k][x] (k-major).  TRANS = false: the matrix is [x, k] row-major (k contiguous):
+// each thread loads 4 consecutive k of one x and scatters them; TRANS = true: the matrix is [k, x]
+// row-major: rows of the tile are copied as they are.
+template <bool TRANS, bool FAST>
+__device__ __forceinline__ void stage_load(float4 (&v)[2], const float* __restrict__ p, int64_t ld,
+                                           int64_t x0, int64_t k0, int64_t nx, int64_t nk, bool vec) {
+    const int tid = threadIdx.x;
+    if constexpr (!TRANS) {
+        const int lr = tid / 8, kq = (tid % 8) * 4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            v[q] = FAST ? ld4_fast(p, ld, x0 + lr + 32 * q, k0 + kq, nx, nk)
+                        : ld4(p, ld, x0 + lr + 32 * q, k0 + kq, nx, nk, vec);
+    } else {
+        const int kk = tid / 16, c4 = (tid % 16) * 4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            v[q] = FAST ? ld4_fast(p, ld, k0 + kk + 16 * q, x0 + c4, nk, nx)
+                        : ld4(p, ld, k0 + kk + 16 * q, x0 + c4, nk, nx, vec);
+    }
+}
+
+template <bool TRANS>
+__device__ __forceinline__ void stage_store(float (&S)[DK][LDT], const float4 (&v)[2]) {
+    const int tid = threadIdx.x;
+    if constexpr (!TRANS) {
+        const int lr = tid / 8, kq = (tid % 8) * 4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = lr + 32 * q;
+            S[kq + 0][r] = v[q].x; S[kq + 1][r] = v[q].y; S[kq + 2][r] = v[q].z; S[kq + 3][r] = v[q].w;
+        }
+    } else {
+        const int kk = tid / 16, c4 = (tid % 16) * 4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<float4*>(&S[kk + 16 * q][c4]) = v[q];
+    }
+}
+
+// C tile (i0.., j0..) = sum over k in [kbeg, kend) of Aop[i][k] * Bop[k][j]
+//   TA = false: A is [M, K] (NT / NN);  TA = true: A is [K, M] (TN)
+//   TB_ = false: B is [N, K] (NT);      TB_ = true: B is [K, N] (NN / TN)
+template <bool TA, bool TB_, bool FAST>
+__global__ void __launch_bounds__(TB)
+k_gemm(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+       float* __restrict__ C, int64_t ldc, int64_t M, int64_t N, int64_t K, int64_t k_slab, bool vec_a,
+       bool vec_b) {
+    __shared__ __attribute__((aligned(16))) float As[DK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[DK][LDT];
+    const int64_t i0 = (int64_t)blockIdx.y * TILE, j0 = (int64_t)blockIdx.x * TILE;
+    const int64_t kbeg = (int64_t)blockIdx.z * k_slab, kend = min(K, kbeg + k_slab);
+    const int tid = threadIdx.x, wave = tid / 64, lane = tid % 64;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    const int ka = lane >> 5, la = lane & 31;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // A block is alone on its CU at these grid sizes, so nothing hides a chunk's global-load latency
+    // but the block itself: PF chunks are kept in flight in registers (all of K for the 128-wide
+    // hidden layers), refilled as they are consumed.
+    float4 va[PF][2], vb[PF][2];
+#pragma unroll
+    for (int c = 0; c < PF; ++c)
+        if (kbeg + c * DK < kend) {
+            stage_load<TA, FAST>(va[c], A, lda, i0, kbeg + c * DK, M, kend, vec_a);
+            stage_load<TB_, FAST>(vb[c], B, ldb, j0, kbeg + c * DK, N, kend, vec_b);
+        }
+    for (int64_t kb = kbeg; kb < kend; kb += PF * DK) {
+#pragma unroll
+        for (int c = 0; c < PF; ++c) {
+            const int64_t k0 = kb + c * DK;
+            if (k0 >= kend) break;                                   // block-uniform
+            __syncthreads();
+            stage_store<TA>(As, va[c]);
+            stage_store<TB_>(Bs, vb[c]);
+            if (k0 + PF * DK < kend) {
+                stage_load<TA, FAST>(va[c], A, lda, i0, k0 + PF * DK, M, kend, vec_a);
+                stage_load<TB_, FAST>(vb[c], B, ldb, j0, k0 + PF * DK, N, kend, vec_b);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < DK; kk += 2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + ka][wi + la], Bs[kk + ka][wj + la], acc, 0, 0, 0);
+        }
+    }
+    float* out = C + (int64_t)blockIdx.z * M * ldc;              // split-K: slab z writes its own [M, ldc] plane
+    const int64_t j = j0 + wj + la;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t i = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * ka;   // C/D layout of the 32x32 MFMA
+        if (i < M && j < N) out[i * ldc + j] = acc[r];
+    }
+}
+
+// C[m, n] = sum_z partial[z][m][n] in a fixed order
+__global__ void __launch_bounds__(TB)
+k_slab_sum(const float* __restrict__ partial, int slabs, int64_t M, int64_t N, float* __restrict__ C,
+           int64_t ldc) {
+    const int64_t idx = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (idx >= M * N) return;
+    // four interleaved partial sums (fixed assignment z % 4): the loads of a batch are independent
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int64_t plane = M * N;
+    int z = 0;
+    for (; z + 3 < slabs; z += 4) {
+        a0 += partial[(int64_t)z * plane + idx];
+        a1 += partial[(int64_t)(z + 1) * plane + idx];
+        a2 += partial[(int64_t)(z + 2) * plane + idx];
+        a3 += partial[(int64_t)(z + 3) * plane + idx];
+    }
+    for (; z < slabs; ++z) a0 += partial[(int64_t)z * plane + idx];
+    C[(idx / N) * ldc + idx % N] = (a0 + a1) + (a2 + a3);
+}
+
+bool vec_ok(const float* p, int64_t ld) { return ld % 4 == 0 && ((uintptr_t)p & 15) == 0; }
+
+int slabs_for(int64_t K) {
+    int64_t s = gda_cdiv(K, 256);
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+
+}  // namespace
+
+extern "C" size_t gda_gemm_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
+    if (mode != GDA_GEMM_TN || M <= 0 || N <= 0 || K <= 0) return 0;
+    const int s = slabs_for(K);
+    return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" int gda_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                            const float* B, int64_t ldb, float* C, int64_t ldc,
+                            void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    if (mode != GDA_GEMM_NT && mode != GDA_GEMM_NN && mode != GDA_GEMM_TN) return GDA_E_UNSUPPORTED;
+    if (M < 0 || N < 0 || K < 0 || ldc < N) return GDA_E_SIZE;
+    if ((mode == GDA_GEMM_TN ? lda < M : lda < K) || (mode == GDA_GEMM_NT ? ldb < K : ldb < N)) return GDA_E_SIZE;
+    if (M == 0 || N == 0) return GDA_OK;
+    if (!C || (K > 0 && (!A || !B))) return GDA_E_NULL;
+    if (C == A || C == B) return GDA_E_ALIAS;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t gx = gda_cdiv(N, TILE), gy = gda_cdiv(M, TILE);
+    if (gx > 65535 * 16 || gy > INT32_MAX) return GDA_E_SIZE;
+    if (K == 0) {
+        GDA_HIP_TRY(hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, (size_t)M, stream));
+        return GDA_OK;
+    }
+    const bool va = vec_ok(A, lda), vb = vec_ok(B, ldb);
+    // branch-free loads need whole float4s: the contiguous extent of each operand a multiple of 4
+    const int64_t a_cols = mode == GDA_GEMM_TN ? M : K, b_cols = mode == GDA_GEMM_NT ? K : N;
+    const bool fast = va && vb && a_cols % 4 == 0 && b_cols % 4 == 0 && a_cols >= 4 && b_cols >= 4;
+#define GDA_GEMM_LAUNCH(TA_, TB__, grid, Cp, ldc_, kslab)                                                   \
+    do {                                                                                                  \
+        if (fast) k_gemm<TA_, TB__, true><<<grid, TB, 0, stream>>>(A, lda, B, ldb, Cp, ldc_, M, N, K, kslab, va, vb); \
+        else k_gemm<TA_, TB__, false><<<grid, TB, 0, stream>>>(A, lda, B, ldb, Cp, ldc_, M, N, K, kslab, va, vb);    \
+    } while (0)
+    if (mode == GDA_GEMM_TN) {
+        const int s = slabs_for(K);
+        const int64_t k_slab = gda_cdiv(gda_cdiv(K, s), DK) * DK;        // whole chunks per slab
+        if (s > 1) {
+            if (!workspace || workspace_bytes < gda_gemm_workspace_bytes(mode, M, N, K)) return GDA_E_WORKSPACE;
+            GDA_GEMM_LAUNCH(true, true, dim3((unsigned)gx, (unsigned)gy, s), (float*)workspace, N, k_slab);
+            GDA_LAUNCH_CHECK();
+            k_slab_sum<<<(unsigned)gda_cdiv(M * N, TB), TB, 0, stream>>>((const float*)workspace, s, M, N, C, ldc);
+        } else {
+            GDA_GEMM_LAUNCH(true, true, dim3((unsigned)gx, (unsigned)gy, 1), C, ldc, K);
+        }
+    } else if (mode == GDA_GEMM_NT) {
+        GDA_GEMM_LAUNCH(false, false, dim3((unsigned)gx, (unsigned)gy, 1), C, ldc, K);
+    } else {
+        GDA_GEMM_LAUNCH(false, true, dim3((unsigned)gx, (unsigned)gy, 1), C, ldc, K);
+    }
+#undef GDA_GEMM_LAUNCH
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}

@@ -29,30 +29,24 @@ def zeros(t):
 
 class _TallLinear(torch.autograd.Function):
     """``y = x W^T`` for a tall ``x [N, in]`` and a small ``W [out, in]`` (the hidden and classifier
-    layers: N = nodes, in/out <= 128).  Forward and ``gx`` are well-shaped BLAS GEMMs; the weight
-    gradient ``gW = gy^T x`` has a tiny output and a reduction over N, for which the BLAS picks a
-    single-tile, no-split-K kernel (60 us at N = 9360).  Here the reduction is cut into S row
-    slabs -- one batched GEMM over the slabs, then a sum over S: a deterministic split-K."""
-    SLABS = 32
+    layers: N = nodes, in/out <= 256) on the hand-written matrix-core kernels (csrc/gda_gemm.hip):
+    64x64 tiles fill the chip where the BLAS's 128x128 macro-tiles leave two thirds of it idle, and
+    the weight gradient ``gW = gy^T x`` (tiny output, reduction over N) is a deterministic split
+    over row slabs."""
 
     @staticmethod
     def forward(ctx, x, weight):
+        from ..ops import GEMM_NT, gemm
         ctx.save_for_backward(x, weight)
-        return F.linear(x, weight)
+        return gemm(GEMM_NT, x, weight)
 
     @staticmethod
     def backward(ctx, gy):
+        from ..ops import GEMM_NN, GEMM_TN, gemm
         x, weight = ctx.saved_tensors
-        gx = gy @ weight if ctx.needs_input_grad[0] else None
-        gw = None
-        if ctx.needs_input_grad[1]:
-            n, s = x.size(0), _TallLinear.SLABS
-            rows = (n // s) * s
-            gyv = gy[:rows].reshape(s, n // s, gy.size(1))
-            xv = x[:rows].reshape(s, n // s, x.size(1))
-            gw = torch.bmm(gyv.transpose(1, 2), xv).sum(0)
-            if rows < n:
-                gw = gw + gy[rows:].t() @ x[rows:]
+        gy = gy.contiguous()
+        gx = gemm(GEMM_NN, gy, weight) if ctx.needs_input_grad[0] else None
+        gw = gemm(GEMM_TN, gy, x) if ctx.needs_input_grad[1] else None
         return gx, gw
 
 
@@ -77,8 +71,8 @@ class Linear(nn.Module):
             sf = sparse_features.lookup(x)             # identity lookup: input feature matrices only
             if sf is not None:
                 return sparse_features.sparse_linear(self.weight, sf)
-        if (self.bias is None and x.dim() == 2 and x.is_cuda and x.size(0) >= 2048
-                and self.in_channels <= 256 and self.out_channels <= 256 and torch.is_grad_enabled()):
+        if (self.bias is None and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and x.size(0) >= 1024
+                and self.in_channels <= 256 and self.out_channels <= 256):
             return _TallLinear.apply(x, self.weight)
         if profiler.enabled:
             n = x.numel() // x.size(-1)

@@ -15,6 +15,35 @@ def _f32c(t, name):
     return t.contiguous()
 
 
+# --------------------------------------------------------- tall-skinny GEMMs (MFMA) --
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+
+
+def gemm(mode, a, b):
+    """fp32 product on the matrix cores (include/gda_hip.h: gda_gemm_f32), no autograd.
+    NT: ``a [M,K] @ b [N,K]^T``; NN: ``a [M,K] @ b [K,N]``; TN: ``a [K,M]^T @ b [K,N]``."""
+    a, b = _f32c(a, "a"), _f32c(b, "b")
+    if mode == GEMM_NT:
+        (M, K), (N, K2) = a.shape, b.shape
+    elif mode == GEMM_NN:
+        (M, K), (K2, N) = a.shape, b.shape
+    else:
+        (K, M), (K2, N) = a.shape, b.shape
+    if K != K2:
+        raise ValueError(f"inner dimensions differ: {tuple(a.shape)} x {tuple(b.shape)} (mode {mode})")
+    c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    L = _lib.lib()
+    need = L.gda_gemm_workspace_bytes(mode, M, N, K)
+    ws = _lib.workspace(need, a.device, "gemm") if need else None
+    name = ("dense_projection", "dense_projection_dgrad", "dense_projection_wgrad")[mode]
+    with profiler.region(f"{name}[{K}x{N}]" if mode != GEMM_TN else f"{name}[{M}x{N}]", 1,
+                         4 * (a.numel() + b.numel() + c.numel()), 2 * M * N * K):
+        _lib.check(L.gda_gemm_f32(mode, M, N, K, _lib.ptr(a), a.size(1), _lib.ptr(b), b.size(1), _lib.ptr(c), N,
+                                  _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream()),
+                   "gda_gemm_f32")
+    return c
+
+
 # --------------------------------------------------------------------------- SpMM --
 aggregated_edges = 0     # running count of nnz(A_hat) over every aggregation launched (bench bookkeeping;
                          # only maintained while the profiler is on: it costs a cached-nnz lookup)

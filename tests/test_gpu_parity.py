@@ -1095,3 +1095,33 @@ def test_fused_adam_matches_torch_adam():
     for a, b in zip(ours, ref):
         close(a, b.float(), rtol=2e-5, atol=1e-6)
     assert float(o1.state[ours[3]]["step"]) == 3.0 and float(o1.state[ours[0]]["step"]) == 6.0
+
+
+@pytest.mark.parametrize("M,N,K", [(9360, 128, 128), (5484, 5, 128), (1000, 130, 70), (77, 3, 5), (20000, 64, 256)])
+def test_tall_gemm_vs_fp64(M, N, K):
+    """NT / NN / TN products on the matrix cores against fp64: fp32 fma chains, 1e-5 of the largest
+    entry; ragged sizes exercise the zero-filled tile edges and the scalar-load path."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=gen)
+    w = torch.randn(N, K, generator=gen)
+    gy = torch.randn(M, N, generator=gen)
+    ad, wd, gyd = a.to(DEV), w.to(DEV), gy.to(DEV)
+    for got, want in ((ops.gemm(ops.GEMM_NT, ad, wd), a.double() @ w.double().t()),
+                      (ops.gemm(ops.GEMM_NN, gyd, wd), gy.double() @ w.double()),
+                      (ops.gemm(ops.GEMM_TN, gyd, ad), gy.double().t() @ a.double())):
+        close(got, want, rtol=0, atol=2e-6 * float(want.abs().max()) * max(1.0, (max(M, K) / 128) ** 0.5))
+    exact(ops.gemm(ops.GEMM_TN, gyd, ad), ops.gemm(ops.GEMM_TN, gyd, ad))      # split-K is deterministic
+
+
+def test_linear_layer_uses_tall_gemm_with_autograd():
+    lin = pygda_amd.nn.Linear(128, 128, bias=False).to(DEV)
+    x = torch.randn(3000, 128, device=DEV, requires_grad=True)
+    y = lin(x)
+    (y * y).sum().backward()
+    xr = x.detach().clone().requires_grad_()
+    wr = lin.weight.detach().clone().requires_grad_()
+    yr = F.linear(xr, wr)
+    (yr * yr).sum().backward()
+    close(y, yr, rtol=1e-4, atol=1e-4)
+    close(x.grad, xr.grad, rtol=1e-4, atol=1e-3)
+    close(lin.weight.grad, wr.grad, rtol=1e-4, atol=1e-2)
