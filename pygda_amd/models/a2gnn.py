@@ -11,6 +11,11 @@ from ..utils import MMD
 from .base import BaseGDA
 
 
+import contextlib
+
+_null = contextlib.nullcontext
+
+
 class A2GNN(BaseGDA):
     def __init__(self, in_dim, hid_dim, num_classes, mode='node', num_layers=3, dropout=0.,
                  act=F.relu, s_pnums=0, t_pnums=30, adv=False, weight=5, weight_decay=0., lr=4e-3,
@@ -56,20 +61,36 @@ class A2GNN(BaseGDA):
         node = self.mode == 'node'
         sb = None if node else source_data.batch
         tb = None if node else target_data.batch
-        h0_s = net.first_conv(source_data.x, source_data.edge_index, self.s_pnums)
+        # Full-batch graphs: every kernel of a step is a few microseconds, so a step costs (kernels on
+        # the critical path) x (dependent-launch latency), not work.  The source branch, the target
+        # feature branch and the loss-unused target logits pass are independent until the domain
+        # loss, so they are issued on three HIP streams (fork/join; parallel branches of the hipGraph
+        # under capture).  Autograd runs every backward node on its forward stream, so the backward
+        # pass splits the same way.  Sampled mini-batches ingest new graphs every step on the main
+        # stream and keep the single-stream order.
+        fork = (node and source_data.x.is_cuda and self.overlap_streams
+                and getattr(target_data, "n_id", None) is None and getattr(source_data, "n_id", None) is None)
+        main = torch.cuda.current_stream() if fork else None
+        if fork:
+            src_stream = getattr(self, "_src_stream", None)
+            if src_stream is None:
+                src_stream = self._src_stream = torch.cuda.Stream()
+            src_stream.wait_stream(main)
+        with (torch.cuda.stream(src_stream) if fork else _null()):
+            h0_s = net.first_conv(source_data.x, source_data.edge_index, self.s_pnums)
+            feats = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)
+            source_logits = net.feat_classifier(feats, source_data.edge_index, sb, 1)        # :181
+            loss = F.nll_loss(F.log_softmax(source_logits, dim=1), source_data.y)            # :182
+            source_features = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)   # :192
         h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
         pending = None
-        # fork the unused pass onto the side stream only for full-batch graphs, where launches are tiny
-        # and the graphs are ingested once; sampled mini-batches ingest new graphs every step on the
-        # main stream and gain nothing from the overlap
-        if (self.compute_target_logits and node and h0_t.is_cuda and self.overlap_streams
-                and getattr(target_data, "n_id", None) is None):
+        if self.compute_target_logits and fork:
             pending = self._target_logits_async(net, target_data, h0_t)
-        feats = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)
-        source_logits = net.feat_classifier(feats, source_data.edge_index, sb, 1)        # :181
-        loss = F.nll_loss(F.log_softmax(source_logits, dim=1), source_data.y)            # :182
-        source_features = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)   # :192
         target_features = net.feat_bottleneck_from(h0_t, target_data.edge_index, tb, self.t_pnums)   # :193
+        if fork:
+            main.wait_stream(src_stream)                                                 # join
+            for t in (loss, source_logits, source_features):
+                t.record_stream(main)
         if self.adv:                                                                     # :196-205, fused
             disc = net.domain_discriminator
             loss = loss + self.weight * grl_disc_ce(source_features, target_features, disc.weight,
