@@ -408,6 +408,15 @@ int gda_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int6
                  const float* B, int64_t ldb, float* C, int64_t ldc,
                  void* workspace, size_t workspace_bytes, gda_stream_t stream);
 
+/* C = A * A of a CSR operator on the host (threaded, deterministic order), for STATIC full-batch
+ * graphs: a K-step propagation (pygda/nn/prop_gcn_conv.py:208-210) then takes K/2 dependent
+ * launches -- at citation-graph sizes a launch costs its latency, not its edges.  rowptr / colidx /
+ * val are HOST arrays.  The result comes back as an edge list (src = row, dst = column, w = value),
+ * rows ascending, columns ascending inside a row; EMPTY when it would hold more than max_nnz
+ * entries (max_nnz < 0: no limit). */
+int gda_csr_square_host(const int32_t* rowptr_host, const int32_t* colidx_host, const float* val_host,
+                        int64_t N, int threads, int64_t max_nnz, gda_edge_list** out);
+
 #ifdef __cplusplus
 }
 #endif

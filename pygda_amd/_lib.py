@@ -73,6 +73,7 @@ _SIGNATURES = {
     "gda_comm_destroy": (c_int, [_P]),
     "gda_allreduce_f32": (c_int, [_P, c_int64, _P, _P]),
     "gda_allgather_f32": (c_int, [_P, _P, c_int64, _P, _P]),
+    "gda_csr_square_host": (c_int, [_P, _P, _P, c_int64, c_int, c_int64, ctypes.POINTER(c_void_p)]),
     "gda_two_hop_host": (c_int, [_P, _P, c_int64, c_int64, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "gda_walk_smooth_host": (c_int, [_P, _P, c_int64, c_int64, c_int, ctypes.c_uint64, c_int,
                                      ctypes.POINTER(c_void_p)]),

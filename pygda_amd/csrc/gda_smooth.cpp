@@ -162,3 +162,52 @@ extern "C" int gda_walk_smooth_host(const int64_t* src_host, const int64_t* dst_
     *out = L;
     return GDA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// C = A * A for a CSR operator (host, threaded over rows): the two-step aggregation operator of a
+// STATIC full-batch graph, so that a K-step propagation (pygda/nn/prop_gcn_conv.py:208-210 runs K
+// dependent scatter passes) needs K/2 dependent launches.  Row i of C accumulates a_ij * a_jk in
+// the fixed order (j in row order of A, k in row order of row j) into a dense per-thread
+// accumulator; entries come out sorted by column.  Returned as an edge list (src = row, dst =
+// column, w = value).
+extern "C" int gda_csr_square_host(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t N,
+                                   int threads, int64_t max_nnz, gda_edge_list** out) {
+    if (!out || !rowptr || (rowptr && N > 0 && rowptr[N] > 0 && (!colidx || !val))) return GDA_E_NULL;
+    if (N < 0 || N >= INT32_MAX) return GDA_E_SIZE;
+    std::vector<std::vector<int32_t>> cols(N);
+    std::vector<std::vector<float>> vals(N);
+    parallel_nodes(N, threads, [&](int, int64_t lo, int64_t hi) {
+        std::vector<float> acc(N, 0.f);
+        std::vector<int64_t> stamp(N, -1);
+        std::vector<int32_t> touched;
+        for (int64_t i = lo; i < hi; ++i) {
+            touched.clear();
+            for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+                const int32_t j = colidx[p];
+                const float a = val[p];
+                for (int32_t q = rowptr[j]; q < rowptr[j + 1]; ++q) {
+                    const int32_t k = colidx[q];
+                    if (stamp[k] != i) { stamp[k] = i; acc[k] = 0.f; touched.push_back(k); }
+                    acc[k] += a * val[q];
+                }
+            }
+            std::sort(touched.begin(), touched.end());
+            cols[i] = touched;
+            vals[i].resize(touched.size());
+            for (size_t t = 0; t < touched.size(); ++t) vals[i][t] = acc[touched[t]];
+        }
+    });
+    int64_t total = 0;
+    for (int64_t i = 0; i < N; ++i) total += (int64_t)cols[i].size();
+    if (total >= INT32_MAX) return GDA_E_SIZE;
+    gda_edge_list* L = new (std::nothrow) gda_edge_list();
+    if (!L) return GDA_E_WORKSPACE;
+    if (max_nnz >= 0 && total > max_nnz) { *out = L; return GDA_OK; }        // too dense to pay off: empty list
+    L->src.reserve(total); L->dst.reserve(total); L->w.reserve(total);
+    for (int64_t i = 0; i < N; ++i)
+        for (size_t t = 0; t < cols[i].size(); ++t) {
+            L->src.push_back(i); L->dst.push_back(cols[i][t]); L->w.push_back(vals[i][t]);
+        }
+    *out = L;
+    return GDA_OK;
+}

@@ -64,6 +64,8 @@ class Data:
             if device.type == "cuda" and hit.x is not None:
                 from . import sparse_features          # bag-of-words inputs: CSR once, SpMM projection
                 sparse_features.maybe_register(hit.x)
+        if getattr(self, "_static_graph", False) and hit.edge_index is not None:
+            hit.edge_index._gda_static = True
         return hit
 
     def cpu(self):
@@ -125,6 +127,9 @@ class NeighborLoader:
 
     def __iter__(self):
         if self.full_batch:
+            self.data._static_graph = True        # the same graph every step: operators derived from it
+            if self.data.edge_index is not None:  # (A*A for K-step propagation) may be cached
+                self.data.edge_index._gda_static = True
             yield self.data
             return
         from .sampler import NeighborSampler

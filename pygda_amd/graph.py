@@ -61,7 +61,7 @@ class CSRGraph:
     ``t_rowptr/t_colidx/t_val``: rows = source nodes (the transpose, backward)."""
 
     __slots__ = ("num_nodes", "nnz_cap", "rowptr", "colidx", "val", "t_rowptr", "t_colidx",
-                 "t_val", "_nnz", "device", "_split", "_t_split", "t_to_fwd")
+                 "t_val", "_nnz", "device", "_split", "_t_split", "t_to_fwd", "static", "_squared")
 
     def __init__(self, num_nodes, nnz_cap, rowptr, colidx, val, t_rowptr, t_colidx, t_val):
         self.num_nodes, self.nnz_cap = num_nodes, nnz_cap
@@ -71,6 +71,16 @@ class CSRGraph:
         self.device = rowptr.device
         self._split = self._t_split = None
         self.t_to_fwd = None      # by-source entry -> by-destination position (built on request)
+        self.static = False       # graph of a full-batch loader: lives for the whole fit()
+        self._squared = None      # A*A (and its transpose) of a static graph, or False if too dense
+
+    def squared(self):
+        """``A*A`` as a :class:`CSRGraph` (forward CSR from the forward CSR, transposed CSR from the
+        transposed one), built once on the host (csrc/gda_smooth.cpp) -- or None when the product
+        would hold more than ``SQUARE_MAX_FILL`` x the entries of A (power-law graphs)."""
+        if self._squared is None:
+            self._squared = _square(self) or False
+        return self._squared or None
 
     def split(self, transposed=False):
         """Long-row layout of the forward (or transposed) CSR, built on first use."""
@@ -104,6 +114,52 @@ class CSRGraph:
         _lib.check(L.gda_csr_to_coo(_lib.ptr(self.rowptr), _lib.ptr(self.colidx), self.num_nodes, nnz,
                                     _lib.ptr(src), _lib.ptr(dst), _lib.stream()), "gda_csr_to_coo")
         return torch.stack([src[:nnz], dst[:nnz]]), self.val[:nnz]
+
+
+SQUARE_MAX_FILL = float(os.environ.get("PYGDA_AMD_SQUARE_MAX_FILL", "6"))
+SQUARE = os.environ.get("PYGDA_AMD_SQUARE", "1") == "1"
+
+
+def _square_half(rowptr, colidx, val, n, nnz, max_nnz):
+    import ctypes
+    import numpy as np
+    L = _lib.lib()
+    rp = rowptr.cpu().numpy()
+    ci = colidx[:nnz].cpu().numpy()
+    va = val[:nnz].cpu().numpy()
+    h = ctypes.c_void_p()
+    _lib.check(L.gda_csr_square_host(rp.ctypes.data, ci.ctypes.data, va.ctypes.data, n,
+                                     max(1, min(16, os.cpu_count() or 1)), int(max_nnz), ctypes.byref(h)),
+               "gda_csr_square_host")
+    try:
+        m = L.gda_edge_list_size(h)
+        if m == 0:
+            return None
+        ei = np.empty((2, m), dtype=np.int64)
+        w = np.empty(m, dtype=np.float32)
+        _lib.check(L.gda_edge_list_fetch(h, ei[0].ctypes.data, ei[1].ctypes.data, w.ctypes.data), "gda_edge_list_fetch")
+    finally:
+        L.gda_edge_list_destroy(h)
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(ei[0], minlength=n), out=ptr[1:])
+    dev = rowptr.device
+    return (torch.from_numpy(ptr.astype(np.int32)).to(dev), torch.from_numpy(ei[1].astype(np.int32)).to(dev),
+            torch.from_numpy(w).to(dev))
+
+
+def _square(g):
+    nnz = g.nnz
+    if nnz == 0:
+        return None
+    limit = int(SQUARE_MAX_FILL * nnz)
+    fwd = _square_half(g.rowptr, g.colidx, g.val, g.num_nodes, nnz, limit)
+    if fwd is None:
+        return None
+    bwd = _square_half(g.t_rowptr, g.t_colidx, g.t_val, g.num_nodes, nnz, -1)
+    sq = CSRGraph(g.num_nodes, int(fwd[1].numel()), fwd[0], fwd[1], fwd[2], bwd[0], bwd[1], bwd[2])
+    sq._nnz = int(fwd[1].numel())
+    sq._squared = False
+    return sq
 
 
 def build_csr(edge_index, num_nodes, edge_weight=None, improved=False, add_self_loops=True,
@@ -190,5 +246,7 @@ def as_graph(edge_index, num_nodes, edge_weight=None, improved=False, add_self_l
     """``edge_index`` may already be a :class:`CSRGraph` (then it is used as is)."""
     if isinstance(edge_index, CSRGraph):
         return edge_index
-    return graph_cache.get(edge_index, num_nodes, edge_weight, improved, add_self_loops, normalize,
-                           degree_side)
+    g = graph_cache.get(edge_index, num_nodes, edge_weight, improved, add_self_loops, normalize, degree_side)
+    if getattr(edge_index, "_gda_static", False):      # tagged by the full-batch loader (pygda_amd/data.py)
+        g.static = True
+    return g

@@ -50,17 +50,10 @@ aggregated_edges = 0     # running count of nnz(A_hat) over every aggregation la
 aggregation_log = None   # or a list: (graph, K) per aggregation call, nnz resolved later (no sync in the loop)
 
 
-def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
-    """``A_hat^K @ x (+ bias)`` without autograd (K launches, ping-pong buffers)."""
-    x = _f32c(x, "x")
-    if x.dim() != 2 or x.size(0) != graph.num_nodes:
-        raise ValueError(f"x must be [num_nodes={graph.num_nodes}, d], got {tuple(x.shape)}")
+def _launch_kstep(graph, x, K, bias, transposed, y, tmp):
     rp, ci, va = (graph.t_rowptr, graph.t_colidx, graph.t_val) if transposed else \
                  (graph.rowptr, graph.colidx, graph.val)
     n, d = x.shape
-    y = torch.empty_like(x)
-    tmp = torch.empty_like(x) if K > 1 else None
-    b = None if bias is None else _f32c(bias, "bias")
     L = _lib.lib()
     if aggregation_log is not None:
         aggregation_log.append((graph, int(K)))
@@ -74,9 +67,33 @@ def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
     sp = graph.split(transposed).struct(d)         # None unless the graph has hub rows (> SPLIT_THRESHOLD entries)
     with ctx:
         _lib.check(L.gda_spmm_csr_split_f32(_lib.ptr(rp), _lib.ptr(ci), _lib.ptr(va), n, d, int(K),
-                                            _lib.ptr(x), d, _lib.ptr(y), d, _lib.ptr(tmp), _lib.ptr(b),
+                                            _lib.ptr(x), d, _lib.ptr(y), d, _lib.ptr(tmp), _lib.ptr(bias),
                                             ctypes.byref(sp) if sp is not None else None,
                                             _lib.stream()), "gda_spmm_csr_split_f32")
+
+
+def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
+    """``A_hat^K @ x (+ bias)`` without autograd (ping-pong buffers).  K launches -- or, for the
+    STATIC graph of a full-batch loader, K // 2 launches of the cached ``A_hat * A_hat`` plus K % 2
+    of ``A_hat``: at citation-graph sizes a dependent launch costs its latency (5-7 us), not its
+    edges, and a K-step chain sits on the critical path of the step.  Same product up to fp32
+    summation order (the exact edge-order sums remain the behaviour for every other graph)."""
+    from .graph import SQUARE
+    x = _f32c(x, "x")
+    if x.dim() != 2 or x.size(0) != graph.num_nodes:
+        raise ValueError(f"x must be [num_nodes={graph.num_nodes}, d], got {tuple(x.shape)}")
+    y = torch.empty_like(x)
+    b = None if bias is None else _f32c(bias, "bias")
+    sq = graph.squared() if (SQUARE and K >= 2 and graph.static) else None
+    if sq is None:
+        _launch_kstep(graph, x, K, b, transposed, y, torch.empty_like(x) if K > 1 else None)
+        return y
+    pairs, single = K // 2, K % 2
+    if single:
+        mid = torch.empty_like(x)
+        _launch_kstep(graph, x, 1, None, transposed, mid, None)
+        x = mid
+    _launch_kstep(sq, x, pairs, b, transposed, y, torch.empty_like(x) if pairs > 1 else None)
     return y
 
 

@@ -1125,3 +1125,39 @@ def test_linear_layer_uses_tall_gemm_with_autograd():
     close(y, yr, rtol=1e-4, atol=1e-4)
     close(x.grad, xr.grad, rtol=1e-4, atol=1e-3)
     close(lin.weight.grad, wr.grad, rtol=1e-4, atol=1e-2)
+
+
+def test_squared_operator_for_static_graphs():
+    """K-step propagation over a static (full-batch) graph runs on the cached A*A: same result as the
+    exact K-step chain to fp32 rounding, forward and backward, odd and even K; untagged graphs keep
+    the exact edge-order path; a power-law graph whose square would be too dense is left alone."""
+    g = load_golden("a2gnn_forward_mmd")
+    ei = T(g["tgt_ei"], DEV)
+    n = g["tgt_x"].shape[0]
+    exact_graph = build_csr(ei, n)
+    tagged = ei.clone()
+    tagged._gda_static = True
+    from pygda_amd.graph import as_graph
+    static_graph = as_graph(tagged, n)
+    assert static_graph.static and static_graph.squared() is not None and exact_graph.static is False
+    x = torch.randn(n, 128, device=DEV)
+    bias = torch.randn(128, device=DEV)
+    for K in (2, 3, 10):
+        for tr in (False, True):
+            want = ops.spmm_kstep(exact_graph, x, K, bias, transposed=tr)
+            got = ops.spmm_kstep(static_graph, x, K, bias, transposed=tr)
+            close(got, want, rtol=1e-5, atol=1e-5)
+    exact(ops.spmm_kstep(static_graph, x, 1, bias), ops.spmm_kstep(exact_graph, x, 1, bias))
+    # autograd through the squared path
+    xa = x.clone().requires_grad_()
+    xb = x.clone().requires_grad_()
+    ops.propagate(xa, static_graph, 10, bias).square().sum().backward()
+    ops.propagate(xb, exact_graph, 10, bias).square().sum().backward()
+    close(xa.grad, xb.grad, rtol=1e-4, atol=1e-4)
+    # hub graph: A*A would be ~N^2/4 entries
+    hub = torch.stack([torch.zeros(400, dtype=torch.long), torch.arange(1, 401)])
+    hub = torch.cat([hub, hub.flip(0)], 1).to(DEV)
+    hub._gda_static = True
+    hg = as_graph(hub, 401)
+    assert hg.static and hg.squared() is None
+    close(ops.spmm_kstep(hg, torch.ones(401, 4, device=DEV), 2), ops.spmm_kstep(build_csr(hub.clone(), 401), torch.ones(401, 4, device=DEV), 2))

@@ -11,8 +11,17 @@ src, tgt = bench.make_cfg_a()
 m = A2GNN(6775, 128, 5, num_layers=2, lr=0.01, weight_decay=0.005, epoch=60, dropout=0.5, s_pnums=0, t_pnums=10,
           weight=10, device=dev, verbose=0, use_hip_graph=True)
 torch.manual_seed(0)
+if os.environ.get("PROBE_NO_TLOGITS"):
+    m.compute_target_logits = False
+if os.environ.get("PROBE_NO_MMD"):
+    import pygda_amd.models.a2gnn as _a
+    _a.MMD = lambda s, t: (s.sum() + t.sum()) * 0.0
+if os.environ.get("PROBE_NO_OVERLAP"):
+    m.overlap_streams = False
 state = m._prepare(src, tgt)
 m._train_epochs(*state, epochs=range(10))
+if os.environ.get("PROBE_NO_TLOGITS"):
+    pass
 g = m._graphed
 def t(fn, n=200):
     torch.cuda.synchronize(); t0 = time.perf_counter()
