@@ -117,7 +117,7 @@ class CSRGraph:
 
 
 SQUARE_MAX_FILL = float(os.environ.get("PYGDA_AMD_SQUARE_MAX_FILL", "6"))
-SQUARE = os.environ.get("PYGDA_AMD_SQUARE", "1") == "1"
+SQUARE = os.environ.get("PYGDA_AMD_SQUARE", "0") == "1"      # opt-in: see ops.spmm_kstep
 
 
 def _square_half(rowptr, colidx, val, n, nnz, max_nnz):

@@ -18,6 +18,45 @@ import torch
 from .utils import mmd as _mmd
 
 
+class _DPSamples:
+    """Static device block + double-buffered pinned blocks holding one rank's MMD row samples of both
+    domains and the CSRs of their 0/1 selection matrices (backward scatter): drawn on the host from
+    the CPU generator in the eager data-parallel MMD()'s order, shipped with one copy."""
+
+    def __init__(self, dev, ns, nt, times, per):
+        self.ns, self.nt, self.times, self.per = ns, nt, times, per
+        shapes = [((times, per), torch.int64), ((times, per), torch.int64), ((ns + 1,), torch.int32),
+                  ((times * per,), torch.int32), ((nt + 1,), torch.int32), ((times * per,), torch.int32)]
+        total = sum((torch.empty(0, dtype=dt).element_size() * int(torch.tensor(sh).prod()) + 15) // 16 * 16
+                    for sh, dt in shapes)
+        self.dev = torch.zeros(total, dtype=torch.uint8, device=dev)
+        self.devv = GraphedStep._carve(self.dev, shapes)
+        self.pin = [torch.zeros(total, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.pinv = [GraphedStep._carve(b, shapes) for b in self.pin]
+        self.done, self.turn = [None, None], 0
+        self.ones = torch.ones(times * per, dtype=torch.float32, device=dev)
+
+    def fill(self):
+        from .ops import selection_csr_host
+        k = self.turn
+        self.turn = 1 - k
+        if self.done[k] is not None:
+            self.done[k].synchronize()
+        p = self.pinv[k]
+        torch.randint(self.ns, (self.times, self.per), out=p[0])
+        torch.randint(self.nt, (self.times, self.per), out=p[1])
+        selection_csr_host(p[0], self.ns, 0, self.per, out=(p[2], p[3]))
+        selection_csr_host(p[1], self.nt, 0, self.per, out=(p[4], p[5]))
+        self.dev.copy_(self.pin[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.done[k] = ev
+
+    def views(self):
+        d = self.devv
+        return d[0], d[1], (d[2], d[3], self.ones), (d[4], d[5], self.ones)
+
+
 class GraphedStep:
     """Captures ``loss, logits = step_fn(src, tgt)``, ``backward`` and ``optimizer.step()``."""
 
@@ -89,28 +128,18 @@ class GraphedStep:
         e["done"][k] = ev
 
     def _provider_dp(self, ns, nt, times, per):
+        """Data-parallel branch of MMD(): local row samples + the selection CSRs of their scatter."""
         key = (ns, nt, times, per)
         if key not in self._dp_idx:
-            dev = self.src.x.device
-            bufs = [torch.zeros((times, per), dtype=torch.int64, device=dev) for _ in range(2)]
-            pins = [torch.zeros((times, per), dtype=torch.int64).pin_memory() for _ in range(2)]
-            self._dp_idx[key] = (bufs, pins)
-            self._fill_dp(key)
-        return tuple(self._dp_idx[key][0])
-
-    def _fill_dp(self, key):
-        ns, nt, times, per = key
-        bufs, pins = self._dp_idx[key]
-        torch.randint(ns, (times, per), out=pins[0])                # the eager DP branch's draws, same order
-        torch.randint(nt, (times, per), out=pins[1])
-        for d, p in zip(bufs, pins):
-            d.copy_(p, non_blocking=True)
+            self._dp_idx[key] = _DPSamples(self.src.x.device, ns, nt, times, per)
+            self._dp_idx[key].fill()
+        return self._dp_idx[key].views()
 
     def _refill(self):
         for key in self._order:
             self._fill_one(key)
-        for key in self._dp_idx:
-            self._fill_dp(key)
+        for e in self._dp_idx.values():
+            e.fill()
 
     def _run(self):
         from .ops import dropout_state
@@ -216,20 +245,13 @@ class GraphedStepDP:
         self.part1, self.part2, self.optimizer, self.src, self.tgt = part1, part2, optimizer, src, tgt
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.times, self.per = times, -(-sampling_num // self.world)
-        dev = src.x.device
-        shape = (times, self.per)
-        self.idx = [torch.zeros(shape, dtype=torch.int64, device=dev) for _ in range(2)]
-        self.pin = [torch.zeros(shape, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.samples = _DPSamples(src.x.device, src.x.size(0), tgt.x.size(0), times, self.per)
         self.loss = self.logits = None
 
     def _refill(self):                       # the eager data-parallel MMD()'s draws, same order
-        torch.randint(self.src.x.size(0), tuple(self.pin[0].shape), out=self.pin[0])
-        torch.randint(self.tgt.x.size(0), tuple(self.pin[1].shape), out=self.pin[1])
-        for d, p in zip(self.idx, self.pin):
-            d.copy_(p, non_blocking=True)
+        self.samples.fill()
 
     def capture(self, eager_step, warmup=2):
-        import torch.distributed as dist
         params = [p for g in self.optimizer.param_groups for p in g["params"]]
         saved = [p.detach().clone() for p in params]
         cpu_rng = torch.get_rng_state()
@@ -244,17 +266,17 @@ class GraphedStepDP:
         with torch.cuda.graph(g1, **mode):
             from .ops import dropout_state
             dropout_state.next_step(dev)
-            loss_ce, logits, rows_s, rows_t = self.part1(self.src, self.tgt, self.idx[0], self.idx[1])
+            loss_ce, logits, rows_s, rows_t = self.part1(self.src, self.tgt, *self.samples.views())
+            rows_st = torch.stack([rows_s.detach(), rows_t.detach()])      # ONE all-gather for both domains
         pool = g1.pool()
-        self.gath = [torch.zeros((W,) + tuple(rows_s.shape), dtype=torch.float32, device=dev, requires_grad=True),
-                     torch.zeros((W,) + tuple(rows_t.shape), dtype=torch.float32, device=dev, requires_grad=True)]
+        self.gath = torch.zeros((W,) + tuple(rows_st.shape), dtype=torch.float32, device=dev, requires_grad=True)
         d = rows_s.size(-1)
         with torch.cuda.graph(g2, pool=pool, **mode):
-            S = self.gath[0].permute(1, 0, 2, 3).reshape(self.times, W * self.per, d)
-            T = self.gath[1].permute(1, 0, 2, 3).reshape(self.times, W * self.per, d)
+            S = self.gath[:, 0].permute(1, 0, 2, 3).reshape(self.times, W * self.per, d)
+            T = self.gath[:, 1].permute(1, 0, 2, 3).reshape(self.times, W * self.per, d)
             dom = self.part2(S, T)
-            gS, gT = torch.autograd.grad(dom, self.gath)
-            g_rows_s, g_rows_t = gS[rank] * float(W), gT[rank] * float(W)
+            (gG,) = torch.autograd.grad(dom, [self.gath])
+            g_rows_s, g_rows_t = gG[rank, 0] * float(W), gG[rank, 1] * float(W)
             total = loss_ce.detach() + dom.detach()
         one = torch.ones((), dtype=torch.float32, device=dev)
         with torch.cuda.graph(g3, pool=pool, **mode):
@@ -269,11 +291,15 @@ class GraphedStepDP:
         with torch.cuda.graph(g4, pool=pool, **mode):
             flat.div_(float(W))
             self.optimizer.step()
-        self._graphs, self._rows, self._flat = (g1, g2, g3, g4), (rows_s, rows_t), flat
+            correct = (logits.detach().argmax(dim=1) == self.src.y).sum()
+            self.stats = torch.stack([total.double(), correct.double()])   # this replica's epoch numbers
+        self._graphs, self._rows_st, self._flat = (g1, g2, g3, g4), rows_st, flat
         # every tensor a captured kernel reads must outlive the graphs: `one` in particular lives in
         # the ordinary pool, and once freed its block would be recycled by eager allocations
-        self._keep = (one, loss_ce, logits, gS, gT, g_rows_s, g_rows_t, dom, total, grads)
+        self._keep = (one, loss_ce, logits, rows_s, rows_t, gG, g_rows_s, g_rows_t, dom, total, grads, correct)
         self.loss, self.logits = total, logits.detach()
+        self._stat_pins = [torch.zeros(2, dtype=torch.float64).pin_memory() for _ in range(2)]
+        self._stat_events, self._stat_turn = [None, None], 0
         with torch.no_grad():                # roll the warm-up back: a seeded fit() takes the eager steps
             for p, v in zip(params, saved):
                 p.copy_(v)
@@ -291,10 +317,26 @@ class GraphedStepDP:
         self._refill()
         g1.replay()
         with torch.no_grad():
-            dist.all_gather_into_tensor(self.gath[0], self._rows[0].detach())
-            dist.all_gather_into_tensor(self.gath[1], self._rows[1].detach())
+            dist.all_gather_into_tensor(self.gath, self._rows_st)
         g2.replay()
         g3.replay()
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
         g4.replay()
         return self.loss, self.logits
+
+    # -- pipelined epochs (see GraphedStep.launch / result) ----------------------------------
+    def launch(self):
+        self()
+        k = self._stat_turn
+        self._stat_turn = 1 - k
+        self._stat_pins[k].copy_(self.stats, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._stat_events[k] = ev
+        return k
+
+    def result(self, ticket):
+        self._stat_events[ticket].synchronize()
+        loss, correct = self._stat_pins[ticket].tolist()
+        n = self.src.y.numel()
+        return loss, (correct / n if n else 0.0)

@@ -52,11 +52,9 @@ class A2GNN(BaseGDA):
         out.record_stream(main)
         return out, side
 
-    def forward_model(self, source_data, target_data, alpha):
-        """a2gnn.py:146-213.  Layer 0 (projection + prop_nums aggregations, no randomness) is
-        evaluated once per domain and shared by the passes that the reference runs separately
-        (source: logits :181 and features :192; target: features :193 and logits :211) -- same
-        values, 10 aggregations and two layer-0 projections fewer per step."""
+    def _branches(self, source_data, target_data):
+        """Everything of a step up to the domain loss: ``(ce_loss, source_logits, source_features,
+        target_features, h0_t, pending)``; ``pending`` = the forked target logits pass or None."""
         net = self.a2gnn
         node = self.mode == 'node'
         sb = None if node else source_data.batch
@@ -91,6 +89,16 @@ class A2GNN(BaseGDA):
             main.wait_stream(src_stream)                                                 # join
             for t in (loss, source_logits, source_features):
                 t.record_stream(main)
+        return loss, source_logits, source_features, target_features, h0_t, pending, (sb, tb)
+
+    def forward_model(self, source_data, target_data, alpha):
+        """a2gnn.py:146-213.  Layer 0 (projection + prop_nums aggregations, no randomness) is
+        evaluated once per domain and shared by the passes that the reference runs separately
+        (source: logits :181 and features :192; target: features :193 and logits :211) -- same
+        values, 10 aggregations and two layer-0 projections fewer per step."""
+        loss, source_logits, source_features, target_features, h0_t, pending, (sb, tb) = \
+            self._branches(source_data, target_data)
+        net = self.a2gnn
         if self.adv:                                                                     # :196-205, fused
             disc = net.domain_discriminator
             loss = loss + self.weight * grl_disc_ce(source_features, target_features, disc.weight,
@@ -112,17 +120,9 @@ class A2GNN(BaseGDA):
         to the local row samples, and the global-batch MMD on the gathered rows."""
         from ..ops import mmd_loss_rows, sample_rows
 
-        def part1(src, tgt, idx_s, idx_t):
-            net = self.a2gnn
-            h0_s = net.first_conv(src.x, src.edge_index, self.s_pnums)
-            h0_t = net.first_conv(tgt.x, tgt.edge_index, self.t_pnums)
-            pending = self._target_logits_async(net, tgt, h0_t) if self.compute_target_logits else None
-            feats = net.feat_bottleneck_from(h0_s, src.edge_index, None, self.s_pnums)
-            source_logits = net.feat_classifier(feats, src.edge_index, None, 1)
-            loss_ce = F.nll_loss(F.log_softmax(source_logits, dim=1), src.y)
-            sf = net.feat_bottleneck_from(h0_s, src.edge_index, None, self.s_pnums)
-            tf = net.feat_bottleneck_from(h0_t, tgt.edge_index, None, self.t_pnums)
-            rows_s, rows_t = sample_rows(sf, idx_s), sample_rows(tf, idx_t)
+        def part1(src, tgt, idx_s, idx_t, sel_s=None, sel_t=None):
+            loss_ce, source_logits, sf, tf, _, pending, _ = self._branches(src, tgt)
+            rows_s, rows_t = sample_rows(sf, idx_s, sel_s), sample_rows(tf, idx_t, sel_t)
             if pending is not None:
                 torch.cuda.current_stream().wait_stream(pending[1])
             return loss_ce, source_logits, rows_s, rows_t

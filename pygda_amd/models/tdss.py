@@ -124,16 +124,8 @@ class TDSS(A2GNN):
                 "TDSS with sampled mini-batches: the reference indexes the batch's features with the "
                 "smoothing graph of the WHOLE target graph (tdss.py:306) -- only full-batch training "
                 "(batch_size=0) is well defined")
-        h0_s = net.first_conv(source_data.x, source_data.edge_index, self.s_pnums)
-        h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
-        pending = None
-        if self.compute_target_logits and h0_t.is_cuda and self.overlap_streams:
-            pending = self._target_logits_async(net, target_data, h0_t)
-        feats = net.feat_bottleneck_from(h0_s, source_data.edge_index, None, self.s_pnums)
-        source_logits = net.feat_classifier(feats, source_data.edge_index, None, 1)       # :275
-        loss = F.nll_loss(F.log_softmax(source_logits, dim=1), source_data.y)
-        source_features = net.feat_bottleneck_from(h0_s, source_data.edge_index, None, self.s_pnums)   # :286
-        target_features = net.feat_bottleneck_from(h0_t, target_data.edge_index, None, self.t_pnums)   # :287
+        loss, source_logits, source_features, target_features, h0_t, pending, _ = \
+            self._branches(source_data, target_data)                                      # :275-287, three streams
         loss = loss + self.alpha * MMD(source_features, target_features)                  # :301-303
         loss = loss + self.beta * self.compute_laplacian_loss(target_features, smooth)    # :306-307
         if pending is not None:

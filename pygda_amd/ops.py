@@ -50,16 +50,19 @@ aggregated_edges = 0     # running count of nnz(A_hat) over every aggregation la
 aggregation_log = None   # or a list: (graph, K) per aggregation call, nnz resolved later (no sync in the loop)
 
 
-def _launch_kstep(graph, x, K, bias, transposed, y, tmp):
+def _launch_kstep(graph, x, K, bias, transposed, y, tmp, counts_as=None):
+    """``counts_as = (graph, steps)``: what the launches stand for in the edges-aggregated bookkeeping
+    (a launch of the cached A*A counts as two aggregations over the edges of A, not over its own)."""
     rp, ci, va = (graph.t_rowptr, graph.t_colidx, graph.t_val) if transposed else \
                  (graph.rowptr, graph.colidx, graph.val)
     n, d = x.shape
     L = _lib.lib()
+    book_graph, book_steps = counts_as if counts_as is not None else (graph, int(K))
     if aggregation_log is not None:
-        aggregation_log.append((graph, int(K)))
+        aggregation_log.append((book_graph, book_steps))
     if profiler.enabled:      # algorithmic bytes per launch: nnz*(4+4) + (N+1)*4 + 2*N*d*4
         global aggregated_edges
-        aggregated_edges += K * graph.nnz
+        aggregated_edges += book_steps * book_graph.nnz
         nbytes = K * (graph.nnz * 8 + (n + 1) * 4 + 2 * n * d * 4)
         ctx = profiler.region(f"spmm_csr_f32[d={d}]", K, nbytes, K * 2 * graph.nnz * d)
     else:
@@ -73,11 +76,12 @@ def _launch_kstep(graph, x, K, bias, transposed, y, tmp):
 
 
 def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
-    """``A_hat^K @ x (+ bias)`` without autograd (ping-pong buffers).  K launches -- or, for the
-    STATIC graph of a full-batch loader, K // 2 launches of the cached ``A_hat * A_hat`` plus K % 2
-    of ``A_hat``: at citation-graph sizes a dependent launch costs its latency (5-7 us), not its
-    edges, and a K-step chain sits on the critical path of the step.  Same product up to fp32
-    summation order (the exact edge-order sums remain the behaviour for every other graph)."""
+    """``A_hat^K @ x (+ bias)`` without autograd (ping-pong buffers), K launches.
+
+    Opt-in (``PYGDA_AMD_SQUARE=1``): for the STATIC graph of a full-batch loader, K // 2 launches of
+    the cached ``A_hat * A_hat`` plus K % 2 of ``A_hat`` -- at citation-graph sizes a dependent launch
+    costs its latency (5-7 us), not its edges.  Same product up to fp32 summation order; measured
+    +4 % epochs/s at cfg-A, at the price of the bit-exact edge-order sums, so it is off by default."""
     from .graph import SQUARE
     x = _f32c(x, "x")
     if x.dim() != 2 or x.size(0) != graph.num_nodes:
@@ -93,7 +97,8 @@ def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
         mid = torch.empty_like(x)
         _launch_kstep(graph, x, 1, None, transposed, mid, None)
         x = mid
-    _launch_kstep(sq, x, pairs, b, transposed, y, torch.empty_like(x) if pairs > 1 else None)
+    _launch_kstep(sq, x, pairs, b, transposed, y, torch.empty_like(x) if pairs > 1 else None,
+                  counts_as=(graph, 2 * pairs))
     return y
 
 
@@ -233,20 +238,27 @@ class _SampleRows(torch.autograd.Function):
     deterministic selection-matrix SpMM backward (duplicates summed in a fixed order)."""
 
     @staticmethod
-    def forward(ctx, feat, idx):
+    def forward(ctx, feat, idx, sel=None):
         ctx.save_for_backward(idx)
-        ctx.rows = feat.size(0)
+        ctx.rows, ctx.sel = feat.size(0), sel
         return gather_rows(feat, idx.reshape(-1)).view(idx.size(0), idx.size(1), feat.size(1))
 
     @staticmethod
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
         times, n, d = g.shape
-        return _scatter_rows(g.contiguous().view(times, n, d), idx, 0, n, ctx.rows), None
+        g = g.contiguous()
+        if ctx.sel is not None:               # selection CSR prepared on the host with the draws
+            rowptr, colidx, ones = ctx.sel
+            return _selection_spmm(rowptr, colidx, ones, g.view(times * n, d), ctx.rows), None, None
+        return _scatter_rows(g.view(times, n, d), idx, 0, n, ctx.rows), None, None
 
 
-def sample_rows(feat, idx):
-    return _SampleRows.apply(_f32c(feat, "feat"), idx)
+def sample_rows(feat, idx, sel=None):
+    """``sel = (rowptr, colidx, ones)``: device CSR of the 0/1 selection matrix of ``idx`` (columns
+    ``t * n + r``; :func:`selection_csr_host` with ``offset=0, m=n``) -- without it the backward
+    pass builds that CSR on the device (a sort per call)."""
+    return _SampleRows.apply(_f32c(feat, "feat"), idx, sel)
 
 
 def mmd_loss_rows(source_rows, target_rows, kernel_mul=2.0, kernel_num=5, fix_sigma=None):

@@ -29,7 +29,7 @@ def get_MMD(source_feat, target_feat, kernel_mul=2.0, kernel_num=5, fix_sigma=No
 # int64 tensors.  The hipGraph-captured training step installs one that hands out STATIC device
 # buffers which it refills (from the same CPU-generator draws) before every replay.
 sample_provider = None
-dp_index_provider = None       # same idea for the data-parallel branch: (n_src, n_tgt, times, per) -> indices
+dp_index_provider = None       # data-parallel branch: (n_src, n_tgt, times, per) -> (idx_s, idx_t, sel_s, sel_t)
 
 
 def MMD(source_feat, target_feat, sampling_num=1000, times=5):
@@ -44,13 +44,17 @@ def MMD(source_feat, target_feat, sampling_num=1000, times=5):
         # evaluates the same global-batch MMD; gradients return to the rows a rank owns.
         w = distributed.info()["world_size"]
         per = -(-sampling_num // w)
+        ns, nt = source_feat.size(0), target_feat.size(0)
         if dp_index_provider is not None:       # captured step: static device buffers, refilled per replay
-            s_idx, t_idx = dp_index_provider(source_feat.size(0), target_feat.size(0), times, per)
+            s_idx, t_idx, sel_s, sel_t = dp_index_provider(ns, nt, times, per)
         else:
-            s_idx = torch.randint(source_feat.size(0), (times, per)).to(dev, non_blocking=True)
-            t_idx = torch.randint(target_feat.size(0), (times, per)).to(dev, non_blocking=True)
-        s_rows = distributed.all_gather_rows(sample_rows(source_feat, s_idx))     # [W, times, per, d]
-        t_rows = distributed.all_gather_rows(sample_rows(target_feat, t_idx))
+            s_cpu, t_cpu = torch.randint(ns, (times, per)), torch.randint(nt, (times, per))
+            ones = torch.ones(times * per, dtype=torch.float32, device=dev)
+            sel_s = tuple(t.to(dev, non_blocking=True) for t in selection_csr_host(s_cpu, ns, 0, per)) + (ones,)
+            sel_t = tuple(t.to(dev, non_blocking=True) for t in selection_csr_host(t_cpu, nt, 0, per)) + (ones,)
+            s_idx, t_idx = s_cpu.to(dev, non_blocking=True), t_cpu.to(dev, non_blocking=True)
+        s_rows = distributed.all_gather_rows(sample_rows(source_feat, s_idx, sel_s))    # [W, times, per, d]
+        t_rows = distributed.all_gather_rows(sample_rows(target_feat, t_idx, sel_t))
         d = source_feat.size(1)
         s_rows = s_rows.permute(1, 0, 2, 3).reshape(times, w * per, d)
         t_rows = t_rows.permute(1, 0, 2, 3).reshape(times, w * per, d)

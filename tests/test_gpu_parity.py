@@ -1127,10 +1127,12 @@ def test_linear_layer_uses_tall_gemm_with_autograd():
     close(lin.weight.grad, wr.grad, rtol=1e-4, atol=1e-2)
 
 
-def test_squared_operator_for_static_graphs():
-    """K-step propagation over a static (full-batch) graph runs on the cached A*A: same result as the
-    exact K-step chain to fp32 rounding, forward and backward, odd and even K; untagged graphs keep
-    the exact edge-order path; a power-law graph whose square would be too dense is left alone."""
+def test_squared_operator_for_static_graphs(monkeypatch):
+    """Opt-in: K-step propagation over a static (full-batch) graph on the cached A*A: same result as
+    the exact K-step chain to fp32 rounding, forward and backward, odd and even K; untagged graphs
+    keep the exact edge-order path; a power-law graph whose square would be too dense is left alone."""
+    import pygda_amd.graph as G
+    monkeypatch.setattr(G, "SQUARE", True)
     g = load_golden("a2gnn_forward_mmd")
     ei = T(g["tgt_ei"], DEV)
     n = g["tgt_x"].shape[0]
