@@ -33,7 +33,8 @@ class BaseGDA(ABC):
         self.model = None
         self.epoch_hook = None        # optional callable(epoch, loss, acc, seconds): bench / tests
         # capture the full-batch training step into a hipGraph (pygda_amd/hipgraph.py);
-        # None = decide from the environment variable PYGDA_AMD_HIPGRAPH (default off)
+        # None = decide from the environment variable PYGDA_AMD_HIPGRAPH (default on: a step whose
+        # capture fails falls back to eager launches with a warning)
         self.use_hip_graph = kwargs.pop("use_hip_graph", None)
         self.kwargs = kwargs
 
@@ -139,7 +140,7 @@ class BaseGDA(ABC):
         import os
         want = self.use_hip_graph
         if want is None:
-            want = os.environ.get("PYGDA_AMD_HIPGRAPH", "0") == "1"
+            want = os.environ.get("PYGDA_AMD_HIPGRAPH", "1") == "1"
         if not want or not getattr(self, "_graph_safe_step", False):
             return None
         if getattr(self, "_graphed", None) is not None and self._graphed_key == id(optimizer):
@@ -161,24 +162,44 @@ class BaseGDA(ABC):
         src = next(iter(self.source_loader)).to(self.device)
         tgt = next(iter(self.target_loader)).to(self.device)
         (before_step or net.train)()
-        if whole:
-            self._graphed = GraphedStep(lambda s, t: step_fn(s, t, 0.0, 0), optimizer, src, tgt, dp=True).capture()
-            self._graphed_key = id(optimizer)
-            return self._graphed
-        if dp:                # collectives stay eager between four captured segments
-            def eager_step():
-                from ..ops import dropout_state
-                dropout_state.next_step(src.x.device)
-                loss, _ = step_fn(src, tgt, 0.0, 0)
-                optimizer.zero_grad()
-                loss.backward()
-                _allreduce_grads(optimizer)
-                optimizer.step()
-            part1, part2 = self._dp_graph_parts()
-            self._graphed = GraphedStepDP(part1, part2, optimizer, src, tgt).capture(eager_step)
-            self._graphed_key = id(optimizer)
-            return self._graphed
-        self._graphed = GraphedStep(lambda s, t: step_fn(s, t, 0.0, 0), optimizer, src, tgt).capture()
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+        saved = [p.detach().clone() for p in params]
+        cpu_rng = torch.get_rng_state()
+        try:
+            if whole:
+                graphed = GraphedStep(lambda s, t: step_fn(s, t, 0.0, 0), optimizer, src, tgt, dp=True).capture()
+            elif dp:          # collectives stay eager between four captured segments
+                def eager_step():
+                    from ..ops import dropout_state
+                    dropout_state.next_step(src.x.device)
+                    loss, _ = step_fn(src, tgt, 0.0, 0)
+                    optimizer.zero_grad()
+                    loss.backward()
+                    _allreduce_grads(optimizer)
+                    optimizer.step()
+                part1, part2 = self._dp_graph_parts()
+                graphed = GraphedStepDP(part1, part2, optimizer, src, tgt).capture(eager_step)
+            else:
+                graphed = GraphedStep(lambda s, t: step_fn(s, t, 0.0, 0), optimizer, src, tgt).capture()
+        except Exception as exc:       # anything a custom activation / exotic configuration may do under capture
+            if self.use_hip_graph:     # explicitly requested: do not hide the failure
+                raise
+            import warnings
+            warnings.warn(f"hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); "
+                          "falling back to eager launches")
+            torch.cuda.synchronize()
+            with torch.no_grad():      # undo whatever the warm-up steps did
+                for p, v in zip(params, saved):
+                    p.copy_(v)
+                    p.grad = None
+                for st in optimizer.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+            torch.set_rng_state(cpu_rng)
+            self._graph_safe_step = False
+            return None
+        self._graphed = graphed
         self._graphed_key = id(optimizer)
         return self._graphed
 
