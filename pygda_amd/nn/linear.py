@@ -50,6 +50,36 @@ class _TallLinear(torch.autograd.Function):
         return gx, gw
 
 
+class _BlasTallLinear(torch.autograd.Function):
+    """Same contraction through the ROCm BLAS, for row counts where its 128x128 macro-tiles fill the
+    chip (sampled sub-graphs of 10^5 rows and more: measured 20-30 % ahead of the 64x64-tile kernels
+    there, tools/gemm_bench.py).  The weight gradient is cut into 32 row slabs (one batched GEMM + a
+    sum): the BLAS otherwise runs it as a single no-split-K tile."""
+    SLABS = 32
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return F.linear(x, weight)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            n, s = x.size(0), _BlasTallLinear.SLABS
+            rows = (n // s) * s
+            gw = torch.bmm(gy[:rows].reshape(s, n // s, gy.size(1)).transpose(1, 2),
+                           x[:rows].reshape(s, n // s, x.size(1))).sum(0)
+            if rows < n:
+                gw = gw + gy[rows:].t() @ x[rows:]
+        return gx, gw
+
+
+TALL_GEMM_MAX_ROWS = 50_000      # above: BLAS (see _BlasTallLinear)
+
+
 class Linear(nn.Module):
     def __init__(self, in_channels, out_channels, bias=True, weight_initializer="glorot"):
         super().__init__()
@@ -73,6 +103,8 @@ class Linear(nn.Module):
                 return sparse_features.sparse_linear(self.weight, sf)
         if (self.bias is None and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and x.size(0) >= 1024
                 and self.in_channels <= 256 and self.out_channels <= 256):
+            if x.size(0) > TALL_GEMM_MAX_ROWS:
+                return _BlasTallLinear.apply(x, self.weight)
             return _TallLinear.apply(x, self.weight)
         if profiler.enabled:
             n = x.numel() // x.size(-1)
