@@ -660,6 +660,135 @@ def dgsda_forward_model(net: DGSDABase, src: Graph, tgt: Graph, alpha: float, be
     return loss, s_logits
 
 
+# ----------------------------------------------------------------------- StruRW --
+def _mean_aggregate_t2s(edge_index: Tensor, msg: Tensor, n: int) -> Tensor:
+    """PyG aggr='mean' with flow='target_to_source': messages averaged at edge_index[0] over their
+    NUMBER (not their weight); nodes without messages stay zero."""
+    out = torch.zeros(n, msg.size(1)).index_add_(0, edge_index[0], msg)
+    cnt = torch.zeros(n).index_add_(0, edge_index[0], torch.ones(edge_index.size(1)))
+    return out / cnt.clamp(min=1).view(-1, 1)
+
+
+class GSReweight(nn.Module):
+    """GS_reweight (reweight_gnn.py:252-372): lin on the gathered neighbour rows, message
+    (1-lmda) m + lmda w_e m, mean aggregation, agg_lin(cat(aggr, x)), relu."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.lin = nn.Linear(in_channels, out_channels)
+        self.agg_lin = nn.Linear(out_channels + in_channels, out_channels)
+
+    def forward(self, x, edge_index, edge_weight, lmda):
+        m = self.lin(x.index_select(0, edge_index[1]))                                   # :308-309
+        m = (1 - lmda) * m + lmda * (edge_weight.view(-1, 1) * m)                        # :310
+        aggr = _mean_aggregate_t2s(edge_index, m, x.size(0))
+        return F.relu(self.agg_lin(torch.cat((aggr, x), dim=-1)))                        # :342-347
+
+
+class GCNReweight(nn.Module):
+    """GCN_reweight (reweight_gnn.py:51-250) as ReweightGNN builds it (aggr = pooling): with
+    aggr='mean' the edge list is gcn-normalised WITHOUT self loops (column degree, unit weights)
+    and the messages are additionally averaged; with aggr='add' no normalisation at all."""
+
+    def __init__(self, in_channels, out_channels, aggr="mean"):
+        super().__init__()
+        self.aggr = aggr
+        self.lin = _Lin(in_channels, out_channels)
+        glorot_(self.lin.weight)                       # __init__ draws, reset_parameters() draws again (:115-116)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+
+    def forward(self, x, edge_index, edge_weight, lmda):
+        rw, n = edge_weight, x.size(0)
+        w = torch.ones_like(rw)
+        if self.aggr != "add":                                                           # :96-99, :151-160
+            deg = torch.zeros(n).index_add_(0, edge_index[1], w)
+            dis = deg.pow(-0.5)
+            dis.masked_fill_(dis == float("inf"), 0)
+            w = dis[edge_index[0]] * w * dis[edge_index[1]]
+        h = x @ self.lin.weight.t()
+        m = w.view(-1, 1) * h.index_select(0, edge_index[1])                             # :222
+        m = (1 - lmda) * m + lmda * (rw.view(-1, 1) * m)                                 # :223
+        if self.aggr == "add":
+            out = torch.zeros(n, m.size(1)).index_add_(0, edge_index[0], m)
+        else:
+            out = _mean_aggregate_t2s(edge_index, m, n)
+        return out + self.bias
+
+
+class ReweightGNN(nn.Module):
+    """reweight_gnn.py:375-502.  ``conv`` lists prop_input once and the SAME prop_hidden module
+    gnn_layers-1 times; dropout is applied with training=True regardless of the mode (:488)."""
+
+    def __init__(self, input_dim, gnn_dim, output_dim, cls_dim, gnn_layers=3, cls_layers=2, backbone="GS",
+                 pooling="mean", dropout=0.5, bn=False, rw_lmda=1.0):
+        super().__init__()
+        if backbone == "GCN":
+            self.prop_input, self.prop_hidden = GCNReweight(input_dim, gnn_dim, pooling), GCNReweight(gnn_dim, gnn_dim, pooling)
+        else:
+            self.prop_input, self.prop_hidden = GSReweight(input_dim, gnn_dim), GSReweight(gnn_dim, gnn_dim)
+        self.dropout, self.bn, self.lmda = dropout, bn, rw_lmda
+        self.conv = nn.ModuleList([self.prop_input] + [self.prop_hidden] * (gnn_layers - 1))
+        self.bns = nn.ModuleList(nn.BatchNorm1d(gnn_dim) for _ in range(gnn_layers - 1))
+        self.bn_mlp = nn.BatchNorm1d(cls_dim)
+        dims = [gnn_dim, output_dim] if cls_layers == 1 else [gnn_dim] + [cls_dim] * (cls_layers - 1) + [output_dim]
+        self.mlp_classify = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, data, h):
+        x = h
+        for layer in self.conv:
+            x = F.relu(layer(x, data.edge_index, data.edge_weight, self.lmda))
+            x = F.dropout(x, p=self.dropout)
+        y = x
+        for i, lin in enumerate(self.mlp_classify):
+            y = lin(y)
+            if i != len(self.mlp_classify) - 1:
+                if self.bn:
+                    y = self.bn_mlp(y)
+                y = F.relu(y)
+        return x, y
+
+
+def strurw_edge_weights(src: Graph, tgt: Graph, tgt_pred: Tensor, num_classes: int) -> Tensor:
+    """StruRW.cal_reweight + cal_edge_prob_sep (strurw.py:446-547): class-pair edge probabilities of
+    the source (labels) and the target (pseudo labels), ratio tgt/src with inf/nan -> 1, and for a
+    source edge (u, v): weight = ratio[label(v), label(u)] (:476-481: edge_index[0] against the
+    column class j, edge_index[1] against the row class i).  Counting edges per class pair replaces
+    the dense Y^T A Y products (to_dense_adj sums duplicate edges, so the counts agree)."""
+    def pair_prob(ei, lab, n, eps):
+        c = num_classes
+        cnt = torch.zeros(c * c, dtype=torch.float64).index_add_(
+            0, lab[ei[0]] * c + lab[ei[1]], torch.ones(ei.size(1), dtype=torch.float64)).view(c, c)
+        per = torch.bincount(lab, minlength=c).double()
+        return cnt / (per.view(-1, 1) * per.view(1, -1) + eps)
+    src_prob = pair_prob(src.edge_index, src.y, src.x.size(0), 0.0)                    # :540
+    tgt_prob = pair_prob(tgt.edge_index, tgt_pred, tgt.x.size(0), 1e-12)               # :541
+    ratio = tgt_prob / src_prob
+    ratio[torch.isinf(ratio)] = 1
+    ratio[torch.isnan(ratio)] = 1
+    lab = src.y
+    return ratio[lab[src.edge_index[1]], lab[src.edge_index[0]]].float()
+
+
+def strurw_forward_model(net: ReweightGNN, src: Graph, tgt: Graph, alpha: float, epoch: int, mode="erm",
+                         reweight=True, pseudo=True, ew_start=100, ew_freq=20, disc: Optional[nn.Module] = None,
+                         num_classes: int = 0, mmd_samples=None):
+    """strurw.py:189-257.  ``src.edge_weight`` is replaced in place when the re-weighting fires."""
+    t_feat, t_logits = net(tgt, tgt.x)
+    t_pred = F.softmax(t_logits, dim=1).max(dim=1)[1]
+    if reweight and (epoch + 1) >= ew_start:
+        if (pseudo and (epoch + 1) % ew_freq == 0) or (not pseudo and epoch == ew_start - 1):
+            src.edge_weight = strurw_edge_weights(src, tgt, t_pred, num_classes)
+    s_feat, s_logits = net(src, src.x)
+    loss = F.nll_loss(F.log_softmax(s_logits, dim=1), src.y)
+    if mode == "adv":
+        sd, td = disc(grad_reverse(s_feat, alpha)), disc(grad_reverse(t_feat, alpha))
+        lab = torch.tensor([0] * src.x.shape[0] + [1] * tgt.x.shape[0])
+        loss = loss + F.cross_entropy(torch.cat([sd, td], 0), lab)
+    elif mode == "mmd":
+        loss = loss + MMD(s_feat, t_feat, samples=mmd_samples)
+    return loss, s_logits, t_logits
+
+
 # ---------------------------------------------------------------------- SpecReg --
 def specreg_gradient_penalty(critic: nn.Module, x_src: Tensor, x_tgt: Tensor) -> Tensor:
     """SpecReg.calculate_gradient_penalty (specreg.py:380-419): no interpolation -- the critic's

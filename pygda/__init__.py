@@ -1,7 +1,7 @@
 """Drop-in alias: ``import pygda`` / ``from pygda.models import A2GNN`` resolve to the
 MI355X-native implementation in :mod:`pygda_amd`, so scripts written against pygda-team/pygda
 (benchmark/node/*.py, examples/demo.py) run unchanged for the trainers this build covers:
-A2GNN, GRADE, UDAGCN, AdaGCN, DANE, GNN, TDSS, SpecReg, DGSDA and the ``pygda.nn`` operators they use."""
+A2GNN, GRADE, UDAGCN, AdaGCN, DANE, GNN, TDSS, SpecReg, DGSDA, StruRW and the ``pygda.nn`` operators they use."""
 import sys
 
 import pygda_amd

@@ -8,5 +8,6 @@ from .dane import DANE
 from .tdss import TDSS
 from .specreg import SpecReg
 from .dgsda import DGSDA
+from .strurw import StruRW
 
-__all__ = ["BaseGDA", "A2GNN", "GRADE", "UDAGCN", "AdaGCN", "GNN", "DANE", "TDSS", "SpecReg", "DGSDA"]
+__all__ = ["BaseGDA", "A2GNN", "GRADE", "UDAGCN", "AdaGCN", "GNN", "DANE", "TDSS", "SpecReg", "DGSDA", "StruRW"]

@@ -13,7 +13,8 @@ from .sage_gin_conv import SAGEConv, GINConv
 from .gat_conv import GATConv
 from .gnn_base import GNNBase
 from .dgsda_base import BernProp, DGSDABase
+from .reweight_gnn import GCN_reweight, GS_reweight, ReweightGNN
 
 __all__ = ["Linear", "glorot", "zeros", "PropGCNConv", "gcn_norm", "GCNConv", "CachedGCNConv", "PPMIConv",
            "ppmi_edges", "GradReverse", "Attention", "A2GNNBase", "GRADEBase", "UDAGCNBase", "AdaGCNBase", "SAGEConv", "GINConv", "GATConv", "GNNBase",
-           "global_mean_pool", "BernProp", "DGSDABase"]
+           "global_mean_pool", "BernProp", "DGSDABase", "GCN_reweight", "GS_reweight", "ReweightGNN"]

@@ -31,6 +31,10 @@ boundary" (the MMD / GradReverse / Attention goldens do not go through it).
  9. (dgsda_base.py only) ``get_laplacian(normalization='sym')`` removes self loops, takes the
     degree over ``row`` and returns ``-D^-1/2 W D^-1/2`` followed by N diagonal ones;
     ``add_self_loops`` appends N loops with the fill value.
+10. (reweight_gnn.py / strurw.py only) ``MessagePassing(aggr='mean', flow='target_to_source')``:
+    messages from ``x[edge_index[1]]`` averaged at ``edge_index[0]`` over the number of messages;
+    ``update`` receives the propagate kwargs it names; ``to_dense_adj`` sums duplicate edges;
+    ``torch_geometric.nn.conv.gcn_conv.gcn_norm`` = assumption 5's normalisation (column degree).
 """
 import inspect
 import math
@@ -120,26 +124,37 @@ class Linear(torch.nn.Module):
 
 
 class MessagePassing(torch.nn.Module):
+    """add / mean aggregation; ``flow='target_to_source'`` swaps the roles of the two edge rows
+    (x_j = x[edge_index[1]], aggregated at edge_index[0]) -- reweight_gnn.py only.  'mean' divides the
+    per-node sum by the number of incoming messages (nodes without messages stay zero)."""
+
     def __init__(self, aggr='add', flow='source_to_target', node_dim=-2, **kwargs):
         super().__init__()
-        assert aggr == 'add' and flow == 'source_to_target'
+        assert aggr in ('add', 'mean') and flow in ('source_to_target', 'target_to_source')
         self.aggr, self.flow, self.node_dim = aggr, flow, node_dim
 
     def propagate(self, edge_index, size=None, **kwargs):
         x = kwargs['x']
         n = x.size(0)
+        j, i = (0, 1) if self.flow == 'source_to_target' else (1, 0)
         params = inspect.signature(self.message).parameters
         margs = {}
         for name in params:
             if name == 'x_j':
-                margs[name] = x.index_select(0, edge_index[0])
+                margs[name] = x.index_select(0, edge_index[j])
             elif name == 'x_i':
-                margs[name] = x.index_select(0, edge_index[1])
+                margs[name] = x.index_select(0, edge_index[i])
+            elif name == 'edge_index':
+                margs[name] = edge_index
             else:
                 margs[name] = kwargs.get(name)
         msg = self.message(**margs)
-        out = torch.zeros((n,) + tuple(msg.shape[1:]), dtype=msg.dtype).index_add_(0, edge_index[1], msg)
-        return self.update(out)
+        out = torch.zeros((n,) + tuple(msg.shape[1:]), dtype=msg.dtype).index_add_(0, edge_index[i], msg)
+        if self.aggr == 'mean':
+            cnt = torch.zeros(n, dtype=msg.dtype).index_add_(0, edge_index[i], torch.ones(edge_index.size(1), dtype=msg.dtype))
+            out = out / cnt.clamp(min=1).view(-1, 1)
+        uparams = [k for k in inspect.signature(self.update).parameters if k != 'aggr_out']
+        return self.update(out, **{k: kwargs.get(k) for k in uparams})
 
     def message(self, x_j):
         return x_j
@@ -234,6 +249,13 @@ def spspmm(index_a, value_a, index_b, value_b, m, k, n, coalesced=False):
     c = a @ b
     idx = (c != 0).nonzero().t().contiguous()
     return idx, c[idx[0], idx[1]]
+
+
+def to_dense_adj(edge_index, batch=None, edge_attr=None, max_num_nodes=None):
+    """PyG ``to_dense_adj`` for a single graph: ``[1, N, N]``, duplicate edges summed."""
+    n = maybe_num_nodes(edge_index, max_num_nodes)
+    adj = torch.zeros(n, n).index_put_((edge_index[0], edge_index[1]), torch.ones(edge_index.size(1)), accumulate=True)
+    return adj.unsqueeze(0)
 
 
 def dense_to_sparse(adj):
@@ -343,6 +365,11 @@ def install():
     utils.is_undirected, utils.to_undirected = is_undirected, to_undirected
     utils.remove_self_loops, utils.coalesce, utils.dense_to_sparse = remove_self_loops, coalesce, dense_to_sparse
     utils.add_self_loops, utils.get_laplacian = add_self_loops, get_laplacian
+    utils.to_dense_adj = to_dense_adj
+    gconv = _mod('torch_geometric.nn.conv.gcn_conv')
+    gconv.gcn_norm = lambda ei, ew=None, num_nodes=None, improved=False, add_self_loops=True, flow="source_to_target", dtype=None: \
+        _gcn_norm(ei, ew, num_nodes, improved, add_self_loops)
+    typing_m.OptTensor = Optional[Tensor]
     tc = _mod('torch_cluster')
     tc.random_walk = random_walk
     nn_utils = _mod('torch_geometric.utils.num_nodes')
@@ -361,4 +388,5 @@ def install():
     tsp.SparseTensor = SparseTensor
     for name in ('matmul', 'fill_diag', 'sum', 'mul'):
         setattr(tsp, name, None)
+    tsp.matmul = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError('SparseTensor inputs are never used'))
     tsp.spspmm = spspmm

@@ -92,6 +92,10 @@ def load_reference(with_pyg_stub=True):
     NN.DGSDABase = dgb.DGSDABase
     dg = _load("pygda.models.dgsda", "pygda/models/dgsda.py")
     ns.BernProp, ns.DGSDABase, ns.DGSDA = dgb.BernProp, dgb.DGSDABase, dg.DGSDA
+    rwg = _load("pygda.nn.reweight_gnn", "pygda/nn/reweight_gnn.py")
+    NN.ReweightGNN, NN.MixupBase = rwg.ReweightGNN, None      # mixup mode is outside the covered rows
+    stw = _load("pygda.models.strurw", "pygda/models/strurw.py")
+    ns.ReweightGNN, ns.GCN_reweight, ns.GS_reweight, ns.StruRW = rwg.ReweightGNN, rwg.GCN_reweight, rwg.GS_reweight, stw.StruRW
     sr = _load("pygda.models.specreg", "pygda/models/specreg.py")
     ns.SpecReg = sr.SpecReg
     ns.gcn_norm, ns.PropGCNConv = prop.gcn_norm, prop.PropGCNConv

@@ -544,6 +544,65 @@ def fx_dgsda(ref):
 FIXTURES["dgsda"] = fx_dgsda
 
 
+def fx_strurw(ref):
+    """StruRW (strurw.py / reweight_gnn.py), modes erm / mmd / adv on the GS and GCN reweighting
+    backbones: forward_model with the edge re-weighting step firing (pseudo-label class-pair edge
+    probabilities -> per-edge source weights), loss + grads, and a 3-epoch fit()/predict()."""
+    import pygda.models.strurw as smod
+    import torch.nn as nn
+    s, t = _domain_pair(181, ns=90, nt=70, f=12, c=3)
+    arrs = dict(_pair_arrays(s, t))
+    smod.print = lambda *a, **k: None
+    losses, accs = [], []
+    orig = smod.logger
+    smod.logger = lambda **kw_: (losses.append(kw_["loss"]), accs.append(kw_["source_train_acc"]))
+    try:
+        for gnn, mode in (("GS", "erm"), ("GCN", "mmd"), ("GS", "adv"), ("GCN", "erm")):
+            tag = f"{gnn}_{mode}"
+            kw = dict(num_layers=2, cls_dim=6, cls_layers=2, dropout=0.0, gnn=gnn, pooling="mean", reweight=True,
+                      pseudo=True, ew_start=1, ew_freq=1, lamb=0.8, mode=mode, lr=0.01, weight_decay=0.001,
+                      device="cpu", epoch=3, verbose=0)
+            m = ref.StruRW(12, 8, 3, **kw)
+            torch.manual_seed(182)
+            m.gnn = m.init_model()
+            if mode == "adv":
+                m.domain_discriminator = nn.Linear(8, 2)
+            m.gnn.train()
+            s.edge_weight, t.edge_weight = torch.ones(s.edge_index.size(1)), torch.ones(t.edge_index.size(1))
+            arrs.update(sd_arrays(m.gnn, f"{tag}/param/"))
+            if mode == "adv":
+                arrs.update(sd_arrays(m.domain_discriminator, f"{tag}/disc/"))
+            torch.manual_seed(183)
+            loss, sl, tl = m.forward_model(s, t, 0.4, 0)
+            loss.backward()
+            arrs.update({f"{tag}/loss": np_(loss), f"{tag}/src_logits": np_(sl), f"{tag}/tgt_logits": np_(tl),
+                         f"{tag}/src_edge_weight": np_(s.edge_weight)})
+            arrs.update(grads(m.gnn, f"{tag}/grad/"))
+        arrs.update(init_seed=np.int64(182), mmd_seed=np.int64(183), alpha=np.float64(0.4))
+        # fit trajectory: re-weighting from the second epoch on
+        for gnn, mode in (("GS", "mmd"), ("GCN", "erm")):
+            tag = f"fit_{gnn}_{mode}"
+            losses.clear(); accs.clear()
+            m = ref.StruRW(12, 8, 3, num_layers=2, cls_dim=6, cls_layers=2, dropout=0.0, gnn=gnn, reweight=True,
+                           pseudo=True, ew_start=2, ew_freq=1, lamb=0.8, mode=mode, lr=0.01, weight_decay=0.001,
+                           device="cpu", epoch=3, verbose=0)
+            s.edge_weight, t.edge_weight = None, None
+            torch.manual_seed(184)
+            m.fit(s, t)
+            logits, labels = m.predict(t)
+            arrs.update({f"{tag}/losses": np.array(losses, dtype=np.float64), f"{tag}/accs": np.array(accs, dtype=np.float64),
+                         f"{tag}/tgt_logits": np_(logits), f"{tag}/tgt_labels": np_(labels),
+                         f"{tag}/src_edge_weight": np_(s.edge_weight)})
+        arrs.update(fit_seed=np.int64(184))
+    finally:
+        smod.logger = orig
+        del smod.print
+    save("strurw", **arrs)
+
+
+FIXTURES["strurw"] = fx_strurw
+
+
 def main(argv):
     ref = load_reference()
     for name in (argv or list(FIXTURES)):

@@ -254,3 +254,18 @@ def test_svd_transform_laplacian_and_shapes(tmp_path):
     # principal directions of a symmetric matrix: orthonormal rows
     gram = d.eivec @ d.eivec.t()
     assert torch.allclose(gram, torch.eye(100), atol=1e-3)
+
+
+def test_strurw_signature_and_mode_guard():
+    import inspect
+    from pygda_amd.models import StruRW
+    sig = inspect.signature(StruRW.__init__).parameters
+    want = dict(num_layers=2, cls_dim=128, cls_layers=2, dropout=0., gnn='GS', pooling='mean', reweight=True,
+                pseudo=True, ew_start=100, ew_freq=20, lamb=0.8, mode='erm', bn=False, weight_decay=0.0001, lr=0.05,
+                epoch=100, device='cuda:0', batch_size=0, num_neigh=-1, verbose=2)
+    for k, v in want.items():
+        assert sig[k].default == v, k
+    with pytest.raises(AssertionError):
+        StruRW(4, 4, 2, mode='other')
+    with pytest.raises(NotImplementedError):
+        StruRW(4, 4, 2, mode='mixup')

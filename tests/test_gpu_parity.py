@@ -1163,3 +1163,65 @@ def test_squared_operator_for_static_graphs(monkeypatch):
     hg = as_graph(hub, 401)
     assert hg.static and hg.squared() is None
     close(ops.spmm_kstep(hg, torch.ones(401, 4, device=DEV), 2), ops.spmm_kstep(build_csr(hub.clone(), 401), torch.ones(401, 4, device=DEV), 2))
+
+
+# ----------------------------------------------------------------------- StruRW --
+def _strurw_pair(g):
+    s, t = _pair(g)
+    return s, t
+
+
+@pytest.mark.parametrize("gnn,mode", [("GS", "erm"), ("GCN", "mmd"), ("GS", "adv"), ("GCN", "erm")])
+def test_strurw_forward_model_golden(gnn, mode):
+    """Re-weighted aggregation as one CSR launch per layer + the device-side class-pair re-weighting,
+    against the reference: edge weights exact, loss / logits / gradients at the usual tolerances."""
+    g = load_golden("strurw")
+    tag = f"{gnn}_{mode}"
+    s, t = _strurw_pair(g)
+    m = pygda_amd.models.StruRW(12, 8, 3, num_layers=2, cls_dim=6, cls_layers=2, dropout=0.0, gnn=gnn, pooling="mean",
+                                reweight=True, pseudo=True, ew_start=1, ew_freq=1, lamb=0.8, mode=mode, lr=0.01,
+                                weight_decay=0.001, device=DEV, epoch=3, verbose=0)
+    torch.manual_seed(int(g["init_seed"]))
+    m.gnn = m.init_model()
+    if mode == "adv":
+        m.domain_discriminator = torch.nn.Linear(8, 2).to(DEV)
+        for k, v in sub(g, f"{tag}/disc/").items():
+            exact(m.domain_discriminator.state_dict()[k], v)
+    sd = m.gnn.state_dict()
+    for k, v in sub(g, f"{tag}/param/").items():
+        exact(sd[k], v)                                             # init RNG stream incl. the shared modules
+    m.gnn.train()
+    sd_, td_ = s.to(DEV), t.to(DEV)
+    sd_.edge_weight = torch.ones(sd_.edge_index.size(1), device=DEV)
+    td_.edge_weight = torch.ones(td_.edge_index.size(1), device=DEV)
+    torch.manual_seed(int(g["mmd_seed"]))
+    loss, sl, tl = m.forward_model(sd_, td_, float(g["alpha"]), 0)
+    loss.backward()
+    exact(sd_.edge_weight, g[f"{tag}/src_edge_weight"])
+    close(loss, g[f"{tag}/loss"], rtol=REL)
+    close(sl, g[f"{tag}/src_logits"], rtol=0, atol=LOGIT_ATOL); close(tl, g[f"{tag}/tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    named = dict(m.gnn.named_parameters())
+    for k, v in sub(g, f"{tag}/grad/").items():
+        if k in named and named[k].grad is not None:
+            close(named[k].grad, v, rtol=1e-3, atol=1e-4 * max(np.abs(v).max(), 1e-3))
+
+
+@pytest.mark.parametrize("gnn,mode", [("GS", "mmd"), ("GCN", "erm")])
+def test_strurw_fit_predict_golden(gnn, mode):
+    g = load_golden("strurw")
+    tag = f"fit_{gnn}_{mode}"
+    s, t = _strurw_pair(g)
+    m = pygda_amd.models.StruRW(12, 8, 3, num_layers=2, cls_dim=6, cls_layers=2, dropout=0.0, gnn=gnn, reweight=True,
+                                pseudo=True, ew_start=2, ew_freq=1, lamb=0.8, mode=mode, lr=0.01, weight_decay=0.001,
+                                device=DEV, epoch=3, verbose=0)
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+    torch.manual_seed(int(g["fit_seed"]))
+    m.fit(s, t)
+    close([x[0] for x in seen], g[f"{tag}/losses"], rtol=REL)
+    close([x[1] for x in seen], g[f"{tag}/accs"], rtol=0, atol=1e-12)
+    close(s.edge_weight, g[f"{tag}/src_edge_weight"], rtol=1e-6, atol=1e-7)
+    logits, labels = m.predict(t)
+    close(logits, g[f"{tag}/tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    exact(labels, g[f"{tag}/tgt_labels"])
+    exact(logits.argmax(1), g[f"{tag}/tgt_logits"].argmax(1))

@@ -417,3 +417,57 @@ def test_dgsda_forward_model_and_fit():
     net.eval()
     with torch.no_grad():
         eq(net(tgt, False), g["fit_tgt_logits"], tol=1e-5); eq(net(src), g["fit_src_logits"], tol=1e-5)
+
+
+# ----------------------------------------------------------------------- StruRW --
+def _strurw_graphs(g):
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    src.edge_weight, tgt.edge_weight = torch.ones(src.edge_index.size(1)), torch.ones(tgt.edge_index.size(1))
+    return src, tgt
+
+
+@pytest.mark.parametrize("gnn,mode", [("GS", "erm"), ("GCN", "mmd"), ("GS", "adv"), ("GCN", "erm")])
+def test_strurw_forward_model(gnn, mode):
+    g = load_golden("strurw")
+    tag = f"{gnn}_{mode}"
+    src, tgt = _strurw_graphs(g)
+    torch.manual_seed(int(g["init_seed"]))
+    net = O.ReweightGNN(12, 8, 3, 6, gnn_layers=2, cls_layers=2, backbone=gnn, pooling="mean", dropout=0.0, rw_lmda=0.8)
+    disc = torch.nn.Linear(8, 2) if mode == "adv" else None
+    for k, v in sub(g, f"{tag}/param/").items():
+        eq(net.state_dict()[k], v)
+    for k, v in sub(g, f"{tag}/disc/").items():
+        eq(disc.state_dict()[k], v)
+    net.train()
+    torch.manual_seed(int(g["mmd_seed"]))
+    loss, sl, tl = O.strurw_forward_model(net, src, tgt, float(g["alpha"]), 0, mode, True, True, 1, 1, disc, 3)
+    loss.backward()
+    eq(src.edge_weight, g[f"{tag}/src_edge_weight"])
+    eq(loss, g[f"{tag}/loss"], tol=1e-6); eq(sl, g[f"{tag}/src_logits"], tol=1e-6); eq(tl, g[f"{tag}/tgt_logits"], tol=1e-6)
+    named = dict(net.named_parameters())
+    for k, v in sub(g, f"{tag}/grad/").items():
+        if k in named and named[k].grad is not None:
+            eq(named[k].grad, v, tol=1e-5)
+
+
+@pytest.mark.parametrize("gnn,mode", [("GS", "mmd"), ("GCN", "erm")])
+def test_strurw_fit_trajectory(gnn, mode):
+    g = load_golden("strurw")
+    tag = f"fit_{gnn}_{mode}"
+    src, tgt = _strurw_graphs(g)
+    torch.manual_seed(int(g["fit_seed"]))
+    net = O.ReweightGNN(12, 8, 3, 6, gnn_layers=2, cls_layers=2, backbone=gnn, pooling="mean", dropout=0.0, rw_lmda=0.8)
+    opt = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=0.001)
+    losses = []
+    for epoch in range(3):
+        net.train()
+        alpha = 2. / (1. + np.exp(-10. * float(epoch) / 3)) - 1
+        loss, _, _ = O.strurw_forward_model(net, src, tgt, alpha, epoch, mode, True, True, 2, 1, None, 3)
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(loss.item())
+    eq(np.array(losses), g[f"{tag}/losses"], tol=1e-5)
+    eq(src.edge_weight, g[f"{tag}/src_edge_weight"], tol=1e-6)
+    net.eval()
+    with torch.no_grad():
+        eq(net(tgt, tgt.x)[1], g[f"{tag}/tgt_logits"], tol=1e-5)
