@@ -9,8 +9,8 @@
 // property where it matters --, only the [m, m] distance matrix is kept (16 MB per resample,
 // L2/MALL resident) and the backward pass recomputes the kernel weights from it.
 //
-//   k_rownorm    |t_i|^2 as the same k-ordered fma chain the MFMA uses
-//   k_pairdist   tile 64x64 of L2 = |t_i|^2 + |t_j|^2 - 2 t_i.t_j on v_mfma_f32_32x32x2_f32, plus
+//   k_pairdist   tile 64x64 of L2 = |t_i|^2 + |t_j|^2 - 2 t_i.t_j on v_mfma_f32_32x32x2_f32 (norms as the
+//                same k-ordered fma chain, from the staged tiles), plus
 //                per-tile partial sums                                 (MFMA bound: 2*m^2*d flop)
 //   k_ksum       bandwidth from the partials (mmd.py:50-51), K = sum_q exp(-L2/bw_q)
 //                (mmd.py:52-55), signed block sums XX+YY-XY-YX (mmd.py:100-106)
@@ -78,20 +78,6 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 // ---------------------------------------------------------------- forward --
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-// |t_r|^2 per row as ONE k-ascending fmaf chain -- the same chain the fp32 MFMA builds for the
-// dot products below, so that for identical rows (sampling is with replacement) dot == norm
-// bit for bit and their distance is exactly 0, as in the reference's difference form.
-__global__ void __launch_bounds__(TB)
-k_rownorm(Rows R, int64_t d, int64_t m, int times, float* __restrict__ norms) {
-    const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (r >= (int64_t)times * m) return;
-    const int t = (int)(r / m);
-    const float* p = row_ptr(R, t, r % m);
-    float acc = 0.f;
-    for (int64_t k = 0; k < d; ++k) acc = fmaf(p[k], p[k], acc);
-    norms[r] = acc;
-}
-
 // L2[i,j] = (|t_i|^2 + |t_j|^2) - 2 t_i.t_j on the fp32 matrix cores: 64x64 tile per workgroup,
 // one 32x32 sub-tile per wave, feature chunks of 32 staged k-major in LDS so that both MFMA
 // operands are conflict-free ds_read_b32 (A: lane l -> row l&31, k = l>>5; B likewise).  The
@@ -99,10 +85,10 @@ k_rownorm(Rows R, int64_t d, int64_t m, int times, float* __restrict__ norms) {
 // inside the 1e-4 loss tolerance) for half the VALU work of the difference form and none of it
 // on the VALU.  Tile sums feed the bandwidth (mmd.py:50).
 __global__ void __launch_bounds__(TB)
-k_pairdist(Rows R, int64_t d, int64_t m, const float* __restrict__ norms, float* __restrict__ l2,
-           double* __restrict__ partial) {
+k_pairdist(Rows R, int64_t d, int64_t m, float* __restrict__ l2, double* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float As[DK][LDT];   // As[k][row i of the tile]
     __shared__ __attribute__((aligned(16))) float Bs[DK][LDT];   // Bs[k][row j of the tile]
+    __shared__ float nA[TILE], nB[TILE];                          // |t_i|^2, |t_j|^2 of the tile rows
     __shared__ double red[TB / 64];
     const int t = blockIdx.z;
     const int64_t i0 = (int64_t)blockIdx.y * TILE, j0 = (int64_t)blockIdx.x * TILE;
@@ -122,6 +108,14 @@ k_pairdist(Rows R, int64_t d, int64_t m, const float* __restrict__ norms, float*
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // Row norms as ONE k-ascending fmaf chain per row, walked on the staged tiles by threads 0..63
+    // (A rows) and 64..127 (B rows) -- the chain the fp32 MFMA builds for the dot products, so for
+    // identical rows (sampling is with replacement) dot == norm bit for bit and their distance is
+    // exactly 0, as in the reference's difference form.  (Was a separate kernel: one thread per row
+    // striding through global memory, 20 us on the critical path.)
+    float nacc = 0.f;
+    float (*Sn)[LDT] = tid < TILE ? As : Bs;
+    const int nrow = tid & (TILE - 1);
 
     // single-buffered on purpose: at 17 KB of LDS nine workgroups share a CU and hide each
     // other's staging; a double-buffered variant (35 KB, four workgroups) measured 8 % slower
@@ -140,21 +134,28 @@ k_pairdist(Rows R, int64_t d, int64_t m, const float* __restrict__ norms, float*
             Bs[kq + 0][r] = vb[q].x; Bs[kq + 1][r] = vb[q].y; Bs[kq + 2][r] = vb[q].z; Bs[kq + 3][r] = vb[q].w;
         }
         __syncthreads();
+        if (tid < 2 * TILE) {
+#pragma unroll
+            for (int kk = 0; kk < DK; ++kk) nacc = fmaf(Sn[kk][nrow], Sn[kk][nrow], nacc);
+        }
 #pragma unroll
         for (int kk = 0; kk < DK; kk += 2)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + ka][wi + la], Bs[kk + ka][wj + la], acc, 0, 0, 0);
     }
+    if (tid < TILE) nA[nrow] = nacc;
+    else if (tid < 2 * TILE) nB[nrow] = nacc;
+    __syncthreads();
 
-    const float* nt = norms + (int64_t)t * m;
     float* out = l2 + (int64_t)t * m * m;
     const int64_t j = j0 + wj + la;
-    const float nj = j < m ? nt[j] : 0.f;
+    const float nj = nB[wj + la];
     float local = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int64_t i = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * ka;       // C/D layout of the 32x32 MFMA
+        const int li = wi + (r & 3) + 8 * (r >> 2) + 4 * ka;              // C/D layout of the 32x32 MFMA
+        const int64_t i = i0 + li;
         if (i < m && j < m) {
-            const float v = (nt[i] + nj) - 2.f * acc[r];
+            const float v = (nA[li] + nj) - 2.f * acc[r];
             out[i * m + j] = v;
             local += v;
         }
@@ -187,15 +188,6 @@ __device__ float bandwidth_of(const double* __restrict__ partial, int tiles, int
     return bw_sh;
 }
 
-// one workgroup per resample: bandwidth[t] from the pairdist partials (mmd.py:50-51)
-__global__ void __launch_bounds__(TB)
-k_bandwidth(const double* __restrict__ partial, int tiles_per_t, int64_t m, KParams kp,
-            float* __restrict__ bandwidth) {
-    __shared__ double red[TB / 64];
-    const float bw0 = bandwidth_of(partial, tiles_per_t, blockIdx.x, m, kp, red);
-    if (threadIdx.x == 0) bandwidth[blockIdx.x] = bw0;
-}
-
 constexpr int KS_ROWS = 8;    // rows of L2 per workgroup pass in k_ksum
 
 // K = sum_q exp(-L2 / bw_q) (mmd.py:52-55) and the signed block sums XX + YY - XY - YX
@@ -205,11 +197,15 @@ constexpr int KS_ROWS = 8;    // rows of L2 per workgroup pass in k_ksum
 // KN = 0 keeps the run-time count.
 template <int KN>
 __global__ void __launch_bounds__(TB)
-k_ksum(float* __restrict__ l2, int64_t m, int64_t n, KParams kp,
-       const float* __restrict__ bandwidth, double* __restrict__ kpartial) {
+k_ksum(float* __restrict__ l2, int64_t m, int64_t n, KParams kp, const double* __restrict__ partial,
+       int tiles_per_t, float* __restrict__ bandwidth, double* __restrict__ kpartial) {
     __shared__ double red[TB / 64];
     const int t = blockIdx.y;
-    const float bw0 = bandwidth[t];
+    // every workgroup folds the pairdist partials itself (a few hundred L2-resident doubles, fixed
+    // order): no separate bandwidth kernel on the critical path; workgroup 0 publishes the value
+    // for the backward pass
+    const float bw0 = bandwidth_of(partial, tiles_per_t, t, m, kp, red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) bandwidth[t] = bw0;
     const int kn = KN > 0 ? KN : kp.kernel_num;
     float nib[KN > 0 ? KN : MAXQ];                     // -1 / (bandwidth * kernel_mul^q), mmd.py:52
     {
@@ -419,7 +415,7 @@ k_bwd_reduce(const float* __restrict__ part, int64_t per_t, int nseg, int times,
 
 constexpr int BWD_NSEG = 8;
 
-struct MmdWs { double* partial; double* kpartial; float* bwd_part; float* norms; size_t total; };
+struct MmdWs { double* partial; double* kpartial; float* bwd_part; size_t total; };
 
 MmdWs carve(void* base, int times, int64_t n, int64_t d) {
     const int64_t m = 2 * n, nt = gda_cdiv(m, TILE);
@@ -433,7 +429,6 @@ MmdWs carve(void* base, int times, int64_t n, int64_t d) {
     w.partial = (double*)take(sizeof(double) * times * nt * nt);
     w.kpartial = (double*)take(sizeof(double) * times * nt * nt);
     w.bwd_part = (float*)take(sizeof(float) * times * BWD_NSEG * m * (d > 0 ? d : 1));
-    w.norms = (float*)take(sizeof(float) * times * m);
     w.total = off;
     return w;
 }
@@ -478,15 +473,11 @@ extern "C" int gda_mmd_fwd_f32(const float* src, int64_t ld_src, const float* tg
     const Rows R = make_rows(src, ld_src, tgt, ld_tgt, src_idx, tgt_idx, n);
     const KParams kp{kernel_mul, kernel_num, fix_sigma};
     const dim3 grid(nt, nt, (unsigned)times);
-    k_rownorm<<<(unsigned)gda_cdiv((int64_t)times * m, TB), TB, 0, stream>>>(R, d, m, times, ws.norms);
-    GDA_LAUNCH_CHECK();
-    k_pairdist<<<grid, TB, 0, stream>>>(R, d, m, ws.norms, l2_saved, ws.partial);
-    GDA_LAUNCH_CHECK();
-    k_bandwidth<<<(unsigned)times, TB, 0, stream>>>(ws.partial, (int)(nt * nt), m, kp, bandwidth);
+    k_pairdist<<<grid, TB, 0, stream>>>(R, d, m, l2_saved, ws.partial);
     GDA_LAUNCH_CHECK();
     const unsigned kgrid = (unsigned)(gda_cdiv(m, KS_ROWS) < 256 ? gda_cdiv(m, KS_ROWS) : 256);
-    if (kernel_num == 5) k_ksum<5><<<dim3(kgrid, (unsigned)times), TB, 0, stream>>>(l2_saved, m, n, kp, bandwidth, ws.kpartial);
-    else k_ksum<0><<<dim3(kgrid, (unsigned)times), TB, 0, stream>>>(l2_saved, m, n, kp, bandwidth, ws.kpartial);
+    if (kernel_num == 5) k_ksum<5><<<dim3(kgrid, (unsigned)times), TB, 0, stream>>>(l2_saved, m, n, kp, ws.partial, (int)(nt * nt), bandwidth, ws.kpartial);
+    else k_ksum<0><<<dim3(kgrid, (unsigned)times), TB, 0, stream>>>(l2_saved, m, n, kp, ws.partial, (int)(nt * nt), bandwidth, ws.kpartial);
     GDA_LAUNCH_CHECK();
     k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, (int)kgrid, times, n, loss);
     GDA_LAUNCH_CHECK();
