@@ -86,6 +86,23 @@ def active():
     return dist.get_world_size() > 1 or os.environ.get("PYGDA_AMD_FORCE_DP") == "1"
 
 
+def broadcast_parameters(module, src=0):
+    """Every replica starts from rank ``src``'s parameters and buffers (what DistributedDataParallel does
+    at construction): ranks may have seeded their generators differently (dropout, MMD samples)."""
+    if not active():
+        return
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers() if b.is_floating_point()]
+    if not tensors:
+        return
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+    dist.broadcast(flat, src=src)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+
+
 def allreduce_grads(params):
     """ONE collective per step: flatten, all-reduce(sum), divide by the world size."""
     if not active():

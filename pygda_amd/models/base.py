@@ -77,6 +77,10 @@ class BaseGDA(ABC):
         ``(loss, source_logits)``; the optimiser step happens here.  ``epochs`` (default
         ``range(self.epoch)``) lets a harness run the same loop in slices."""
         start = time.time()
+        if not getattr(self, "_dp_synced", None) is net:      # data-parallel: one set of initial weights
+            from ..distributed import broadcast_parameters
+            broadcast_parameters(net)
+            self._dp_synced = net
         graphed = self._maybe_graphed_step(optimizer, step_fn, before_step, net)
         if graphed is not None and hasattr(graphed, "launch"):
             return self._graphed_epochs(graphed, range(self.epoch) if epochs is None else epochs, start)

@@ -51,6 +51,15 @@ def _worker(rank, world, port, q):
             assert torch.allclose(p.grad, want, atol=1e-7)
         assert unused.grad is not None and torch.equal(unused.grad, torch.zeros(2))
 
+        # ---- 1b. replicas start from rank 0's weights whatever each rank's seed was -----------
+        torch.manual_seed(50 + rank)
+        rep = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.BatchNorm1d(3))
+        D.broadcast_parameters(rep)
+        mine = torch.cat([t.reshape(-1) for t in rep.state_dict().values() if t.is_floating_point()])
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        assert all(torch.equal(every[0], e) for e in every)
+
         # ---- 2. all-gather of sample rows: global loss, per-rank gradient slices ------------
         g = torch.Generator().manual_seed(7 + rank)
         rs = torch.randn(3, 5, 4, generator=g, requires_grad=True)      # [times, per, d] of this rank
