@@ -20,7 +20,6 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -251,7 +250,6 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
-    import pygda_amd
     from pygda_amd import profiler
     from pygda_amd.models import A2GNN
 

@@ -140,8 +140,6 @@ class A2GNN(BaseGDA):
         self.a2gnn = self.init_model(**self.kwargs)
         # the MMD branch never reads alpha/epoch: its step can be captured into a hipGraph
         self._graph_safe_step = not self.adv
-        import os
-        graph = self.use_hip_graph if self.use_hip_graph is not None else os.environ.get("PYGDA_AMD_HIPGRAPH") == "1"
         on_gpu = torch.device(self.device).type == "cuda"
         if on_gpu:           # torch.optim.Adam's update in one multi-tensor launch (pygda_amd/optim.py)
             from ..optim import Adam

@@ -8,7 +8,6 @@ its CPU path is the CPU generator -- so a seeded run here reproduces the referen
 As in AdaGCN, the encoder outputs are detached inside the discriminator loop: the reference
 back-propagates into the encoder there and discards the result (``g_optimizer.zero_grad()``
 at :511 precedes the only generator step)."""
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F

@@ -44,11 +44,9 @@ class DGSDA(BaseGDA):
         return -torch.sum(probs * log_probs / (a / torch.sum(a)), dim=1).mean()
 
     def fit(self, source_data, target_data):
-        import os
         self._node_loaders(source_data, target_data)
         self.dgsda = self.init_model(**self.kwargs)
         self._graph_safe_step = True          # nothing in the step depends on per-epoch Python scalars
-        graph = self.use_hip_graph if self.use_hip_graph is not None else os.environ.get("PYGDA_AMD_HIPGRAPH") == "1"
         on_gpu = torch.device(self.device).type == "cuda"
         if on_gpu:
             from ..optim import Adam

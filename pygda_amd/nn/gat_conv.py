@@ -6,7 +6,6 @@
 import weakref
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from .. import _lib

@@ -4,8 +4,6 @@ weight_decay)`` (pygda/models/a2gnn.py:290-294); torch's fused implementation ch
 65536 elements, which leaves a model with one 867k-element weight and a few small ones on ~20
 workgroups (42 us per step at cfg-A).  Same update rule, 2048-element work items, device-resident
 step counters (hipGraph-capturable by construction)."""
-import ctypes
-
 import torch
 
 from . import _lib
