@@ -115,6 +115,10 @@ typedef struct gda_row_split {
     const int32_t* long_chunk_ptr;  /* [n_long + 1] */
     const int32_t* chunk_long;      /* [n_chunks]   */
     float* scratch;                 /* [n_chunks, d] caller-owned, reused across calls */
+    const int32_t* counts_dev;      /* NULL, or the device {n_long, n_chunks} written by gda_row_split_build:
+                                       n_long / n_chunks above then hold the CAPACITIES (grid bounds) and
+                                       the kernels read the live counts themselves -- no host read-back,
+                                       for graphs that live one step (sampled mini-batches) */
 } gda_row_split;
 
 /* Find the long rows of a CSR and lay out their chunks.  Outputs must hold the upper bounds

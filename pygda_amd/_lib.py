@@ -90,7 +90,7 @@ class RowSplitStruct(ctypes.Structure):
     """``gda_row_split`` of include/gda_hip.h."""
     _fields_ = [("threshold", ctypes.c_int32), ("n_long", ctypes.c_int32), ("n_chunks", ctypes.c_int32),
                 ("long_rows", c_void_p), ("long_chunk_ptr", c_void_p), ("chunk_long", c_void_p),
-                ("scratch", c_void_p)]
+                ("scratch", c_void_p), ("counts_dev", c_void_p)]
 
 
 _lib = None

@@ -62,6 +62,8 @@ struct RowSplit {
     const int32_t* long_chunk_ptr;  // [n_long + 1] chunk range of each long row
     const int32_t* chunk_long;      // [n_chunks]   index into long_rows
     float* scratch;                 // [n_chunks, d]
+    const int32_t* counts;          // device {n_long, n_chunks} when the host never read them back:
+                                    // n_long / n_chunks above are then CAPACITIES (grid bounds only)
 };
 
 // Optional epilogue (polynomial graph filters, e.g. the Bernstein filter of DGSDA):
@@ -113,7 +115,7 @@ k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
         }
     } else {
         row = (int64_t)(blockIdx.x - row_blocks) * ROWS_PER_BLOCK + threadIdx.x / G;
-        live = row < sp.n_chunks;
+        live = row < (sp.counts ? sp.counts[1] : sp.n_chunks);
         if (live) {
             const int32_t li = sp.chunk_long[row];
             const int32_t r = sp.long_rows[li];
@@ -183,7 +185,7 @@ template <bool EPI>
 __global__ void __launch_bounds__(TB)
 k_long_reduce(RowSplit sp, int d, float* __restrict__ y, int64_t ldy, const float* __restrict__ bias,
               const float* __restrict__ x, int64_t ldx, Epilogue ep) {
-    const int64_t total = (int64_t)sp.n_long * d;
+    const int64_t total = (int64_t)(sp.counts ? sp.counts[0] : sp.n_long) * d;
     for (int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x; k < total; k += (int64_t)gridDim.x * TB) {
         const int32_t li = (int32_t)(k / d);
         const int c = (int)(k % d);
@@ -276,7 +278,7 @@ RowSplit make_split(const gda_row_split* h) {
     if (h && h->threshold > 0 && h->n_long > 0) {
         sp.threshold = h->threshold; sp.n_long = h->n_long; sp.n_chunks = h->n_chunks;
         sp.long_rows = h->long_rows; sp.long_chunk_ptr = h->long_chunk_ptr; sp.chunk_long = h->chunk_long;
-        sp.scratch = h->scratch;
+        sp.scratch = h->scratch; sp.counts = h->counts_dev;
     }
     return sp;
 }

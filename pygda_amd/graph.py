@@ -24,7 +24,10 @@ SPLIT_THRESHOLD = int(os.environ.get("PYGDA_AMD_SPLIT_THRESHOLD", "128"))
 class RowSplit:
     """Long-row chunk layout of one CSR (see ``gda_row_split`` in include/gda_hip.h)."""
 
-    def __init__(self, rowptr, num_rows, nnz_cap, threshold=SPLIT_THRESHOLD):
+    def __init__(self, rowptr, num_rows, nnz_cap, threshold=SPLIT_THRESHOLD, deferred=False):
+        """``deferred``: never read the counts back (no host sync): launches are sized by the capacity
+        bounds and the kernels pick up the live counts from device memory -- for graphs that live one
+        step, where a sync per graph would drain the queue every mini-batch."""
         dev = rowptr.device
         cap_long = nnz_cap // threshold + 1
         cap_chunks = 2 * (nnz_cap // threshold) + 2
@@ -40,7 +43,11 @@ class RowSplit:
                                          _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream()),
                    "gda_row_split_build")
         self.threshold = threshold
-        self.n_long, self.n_chunks = (int(v) for v in counts.tolist())       # one sync per graph
+        self.counts = counts if deferred else None
+        if deferred:
+            self.n_long, self.n_chunks = cap_long, cap_chunks
+        else:
+            self.n_long, self.n_chunks = (int(v) for v in counts.tolist())   # one sync per graph
         self._scratch = {}                 # per stream: concurrent streams must not share partials
 
     def struct(self, d):
@@ -53,7 +60,8 @@ class RowSplit:
         if buf is None or buf.numel() < need:
             buf = self._scratch[key] = torch.empty(need, dtype=torch.float32, device=self.long_rows.device)
         return _lib.RowSplitStruct(self.threshold, self.n_long, self.n_chunks, self.long_rows.data_ptr(),
-                                   self.long_chunk_ptr.data_ptr(), self.chunk_long.data_ptr(), buf.data_ptr())
+                                   self.long_chunk_ptr.data_ptr(), self.chunk_long.data_ptr(), buf.data_ptr(),
+                                   self.counts.data_ptr() if self.counts is not None else None)
 
 
 class CSRGraph:
@@ -61,7 +69,7 @@ class CSRGraph:
     ``t_rowptr/t_colidx/t_val``: rows = source nodes (the transpose, backward)."""
 
     __slots__ = ("num_nodes", "nnz_cap", "rowptr", "colidx", "val", "t_rowptr", "t_colidx",
-                 "t_val", "_nnz", "device", "_split", "_t_split", "t_to_fwd", "static", "_squared")
+                 "t_val", "_nnz", "device", "_split", "_t_split", "t_to_fwd", "static", "_squared", "transient")
 
     def __init__(self, num_nodes, nnz_cap, rowptr, colidx, val, t_rowptr, t_colidx, t_val):
         self.num_nodes, self.nnz_cap = num_nodes, nnz_cap
@@ -72,6 +80,7 @@ class CSRGraph:
         self._split = self._t_split = None
         self.t_to_fwd = None      # by-source entry -> by-destination position (built on request)
         self.static = False       # graph of a full-batch loader: lives for the whole fit()
+        self.transient = False    # graph of one sampled mini-batch: nothing about it is worth a host sync
         self._squared = None      # A*A (and its transpose) of a static graph, or False if too dense
 
     def squared(self):
@@ -86,10 +95,10 @@ class CSRGraph:
         """Long-row layout of the forward (or transposed) CSR, built on first use."""
         if transposed:
             if self._t_split is None:
-                self._t_split = RowSplit(self.t_rowptr, self.num_nodes, self.nnz_cap)
+                self._t_split = RowSplit(self.t_rowptr, self.num_nodes, self.nnz_cap, deferred=self.transient)
             return self._t_split
         if self._split is None:
-            self._split = RowSplit(self.rowptr, self.num_nodes, self.nnz_cap)
+            self._split = RowSplit(self.rowptr, self.num_nodes, self.nnz_cap, deferred=self.transient)
         return self._split
 
     @property
@@ -175,7 +184,7 @@ def build_csr(edge_index, num_nodes, edge_weight=None, improved=False, add_self_
     if edge_index.dim() != 2 or edge_index.size(0) != 2:
         raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
     E, N = int(edge_index.size(1)), int(num_nodes)
-    if validate and E > 0:
+    if validate and E > 0 and not getattr(edge_index, "_gda_trusted", False):   # sampler output: in range by construction
         lo, hi = int(edge_index.min()), int(edge_index.max())
         if lo < 0 or hi >= N:
             raise IndexError(f"edge_index values must lie in [0, {N}), found [{lo}, {hi}]")
@@ -249,4 +258,6 @@ def as_graph(edge_index, num_nodes, edge_weight=None, improved=False, add_self_l
     g = graph_cache.get(edge_index, num_nodes, edge_weight, improved, add_self_loops, normalize, degree_side)
     if getattr(edge_index, "_gda_static", False):      # tagged by the full-batch loader (pygda_amd/data.py)
         g.static = True
+    if getattr(edge_index, "_gda_trusted", False):     # relabelled sub-graph of one mini-batch (pygda_amd/sampler.py)
+        g.transient = True
     return g

@@ -60,7 +60,9 @@ class NeighborSampler:
             n_dev = n_id.to(dev, non_blocking=True)
             x = gather_rows(data.x, n_dev)
             y = None if data.y is None else data.y[n_dev]
-            return Data(x=x, edge_index=ei.to(dev, non_blocking=True), y=y, n_id=n_dev,
+            ei = ei.to(dev, non_blocking=True)
+            ei._gda_trusted = True            # relabelled ids are in range by construction: no validation sync
+            return Data(x=x, edge_index=ei, y=y, n_id=n_dev,
                         batch_size=int(torch.as_tensor(seeds).numel()))
         return Data(x=data.x[n_id], edge_index=ei, y=None if data.y is None else data.y[n_id], n_id=n_id,
                     batch_size=int(torch.as_tensor(seeds).numel()))
