@@ -73,6 +73,11 @@ class A2GNN(BaseGDA):
             src_stream = getattr(self, "_src_stream", None)
             if src_stream is None:
                 src_stream = self._src_stream = torch.cuda.Stream()
+                # parameters are shared by branches on different streams on purpose; autograd syncs
+                # the accumulation itself and only warns about the mismatch
+                quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+                if quiet is not None:
+                    quiet(False)
             src_stream.wait_stream(main)
         with (torch.cuda.stream(src_stream) if fork else _null()):
             h0_s = net.first_conv(source_data.x, source_data.edge_index, self.s_pnums)
