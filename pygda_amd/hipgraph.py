@@ -141,16 +141,30 @@ class GraphedStep:
         for e in self._dp_idx.values():
             e.fill()
 
-    def _run(self):
+    def _run(self, with_stats=False):
         from .ops import dropout_state
         dropout_state.next_step(self.src.x.device)        # device counter: bumped by every replay too
         loss, logits = self.step_fn(self.src, self.tgt)
+        if with_stats:
+            # per-epoch numbers of the reference's loop (loss, source micro-F1 = accuracy): two doubles
+            # produced inside the graph, on a side branch that runs beside the backward pass
+            main = torch.cuda.current_stream()
+            side = self._stat_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                correct = (logits.detach().argmax(dim=1) == self.src.y).sum()
+                self.stats = torch.stack([loss.detach().double(), correct.double()])
+            for t in (loss, logits):
+                t.record_stream(side)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         if self.dp:
             from .distributed import allreduce_grads
             allreduce_grads(p for g in self.optimizer.param_groups for p in g["params"])
         self.optimizer.step()
+        if with_stats:
+            main.wait_stream(side)
+            self.stats.record_stream(main)
         return loss, logits
 
     # -- public ------------------------------------------------------------------------
@@ -175,12 +189,9 @@ class GraphedStep:
             self.graph = torch.cuda.CUDAGraph()
             # thread_local: API calls of other threads (RCCL's watchdog polls events) must not
             # invalidate the capture
+            self._stat_stream = torch.cuda.Stream()
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                loss, logits = self._run()
-                # per-epoch numbers of the reference's loop (loss, source micro-F1 = accuracy): two
-                # doubles produced inside the graph, so an epoch needs ONE small D2H
-                correct = (logits.detach().argmax(dim=1) == self.src.y).sum()
-                self.stats = torch.stack([loss.detach().double(), correct.double()])
+                loss, logits = self._run(with_stats=True)      # an epoch then needs ONE small D2H
             self.loss, self.logits = loss.detach(), logits.detach()
             self._stat_pins = [torch.zeros(2, dtype=torch.float64).pin_memory() for _ in range(2)]
             self._stat_events = [None, None]
