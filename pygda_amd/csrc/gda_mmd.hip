@@ -413,7 +413,7 @@ k_bwd_reduce(const float* __restrict__ part, int64_t per_t, int nseg, int times,
     }
 }
 
-constexpr int BWD_NSEG = 8;
+constexpr int BWD_NSEG = 4;        // measured: 2 -> 141+5 us, 4 -> 97+7, 8 -> 102+10, 16 -> 119+18 (k_bwd + k_bwd_reduce)
 
 struct MmdWs { double* partial; double* kpartial; float* bwd_part; size_t total; };
 
