@@ -18,7 +18,7 @@ import os
 
 def find(d, suffix):
     hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None       # newest run when a directory was reused
 
 
 def short(name):
