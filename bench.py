@@ -362,6 +362,9 @@ def main():
             "roofline": dict(roof(dominant), timing="HIP events on the launch stream, " + (
                 "eager pass of the same K steps after the timed hipGraph region" if graphed else "timed region")),
             "roofline_aggregation": roof(agg),
+            # BASELINE.json also asks for the MFMA utilisation of the dense projection: the hidden-layer
+            # products on the hand-written matrix-core kernels (layer 0 is a sparse projection here)
+            "roofline_dense_projection": {k: roof(k) for k in sorted(prof) if k.startswith("dense_projection")},
             "kernel_time_ms_per_step": {k: v["ms"] / args.steps for k, v in sorted(prof.items())},
         }
         if world == 1 and not args.no_cpu_baseline:
