@@ -421,6 +421,19 @@ int gda_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int6
 int gda_csr_square_host(const int32_t* rowptr_host, const int32_t* colidx_host, const float* val_host,
                         int64_t N, int threads, int64_t max_nnz, gda_edge_list** out);
 
+/* ------------------------------------------------------------------------------
+ * Source classification loss: mean_i( -log_softmax(logits_i)[labels_i] ), forward and backward.
+ * Replaces F.nll_loss(F.log_softmax(source_logits, dim=1), source_data.y)
+ * (pygda/models/a2gnn.py:182 and the same line of every trainer).  logits [N, C] fp32 (C <= 64),
+ * labels [N] int64 in [0, C); loss [1]; grad_loss [1] DEVICE scalar; grad_logits [N, C].
+ * Labels are trusted (no ignore_index): the trainers pass dataset labels.
+ * ---------------------------------------------------------------------------- */
+size_t gda_softmax_nll_workspace_bytes(void);
+int gda_softmax_nll_fwd_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
+                            float* loss, void* workspace, size_t workspace_bytes, gda_stream_t stream);
+int gda_softmax_nll_bwd_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
+                            const float* grad_loss, float* grad_logits, int64_t ldg, gda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,9 @@ _SIGNATURES = {
     "gda_laplacian_workspace_bytes": (c_size_t, [c_int64]),
     "gda_laplacian_fwd_f32": (c_int, [_P, _P, c_int64, c_int, _P, c_int64, _P, _P, _P, c_size_t, _P]),
     "gda_laplacian_bwd_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, c_int64, _P, _P, _P, c_int64, _P]),
+    "gda_softmax_nll_workspace_bytes": (c_size_t, []),
+    "gda_softmax_nll_fwd_f32": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, c_size_t, _P]),
+    "gda_softmax_nll_bwd_f32": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, c_int64, _P]),
     "gda_gemm_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64]),
     "gda_gemm_f32": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64,
                              _P, c_size_t, _P]),

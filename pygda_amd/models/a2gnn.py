@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 
 from ..nn import A2GNNBase
-from ..ops import grl_disc_ce
+from ..ops import grl_disc_ce, source_ce
 from ..utils import MMD
 from .base import BaseGDA
 
@@ -83,7 +83,7 @@ class A2GNN(BaseGDA):
             h0_s = net.first_conv(source_data.x, source_data.edge_index, self.s_pnums)
             feats = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)
             source_logits = net.feat_classifier(feats, source_data.edge_index, sb, 1)        # :181
-            loss = F.nll_loss(F.log_softmax(source_logits, dim=1), source_data.y)            # :182
+            loss = source_ce(source_logits, source_data.y)                                   # :182, fused
             source_features = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)   # :192
         h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
         pending = None

@@ -4,6 +4,7 @@ Bernstein-filter network of :mod:`pygda_amd.nn.dgsda_base`."""
 import torch
 import torch.nn.functional as F
 
+from ..ops import source_ce
 from ..nn.dgsda_base import DGSDABase
 from ..utils import MMD
 from .base import BaseGDA
@@ -28,7 +29,7 @@ class DGSDA(BaseGDA):
     def forward_model(self, source_data, target_data):
         net = self.dgsda
         source_logits = net(source_data)                                                  # :172
-        loss = F.nll_loss(F.log_softmax(source_logits, dim=1), source_data.y)
+        loss = source_ce(source_logits, source_data.y)
         loss = loss + F.l1_loss(net.prop1.temp, net.prop2.temp) * self.alpha              # :176-179
         source_feature = F.relu(net.lin1(source_data.x))
         target_feature = F.relu(net.lin1(target_data.x))

@@ -4,6 +4,7 @@ GDA trainers it stores no loaders)."""
 import torch
 import torch.nn.functional as F
 
+from ..ops import source_ce
 from ..data import NeighborLoader
 from ..metrics import eval_micro_f1
 from ..nn import GNNBase
@@ -29,7 +30,7 @@ class GNN(BaseGDA):
         source_logits = self.gnn(source_data.x, source_data.edge_index)
         target_logits = self.gnn(target_data.x, target_data.edge_index)
         # GNNBase already returns log-probabilities; the reference applies log_softmax again (:146)
-        return F.nll_loss(F.log_softmax(source_logits, dim=1), source_data.y), source_logits, target_logits
+        return source_ce(source_logits, source_data.y), source_logits, target_logits
 
     def fit(self, source_data, target_data):
         import time

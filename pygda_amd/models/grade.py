@@ -5,6 +5,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from ..ops import source_ce
 from ..nn import GRADEBase
 from ..ops import grl_disc_ce
 from ..utils import MMD
@@ -30,7 +31,7 @@ class GRADE(BaseGDA):
         net = self.grade
         source_logits, source_feats = net(source_data)
         target_logits, target_feats = net(target_data)
-        loss = F.nll_loss(F.log_softmax(source_logits, dim=1), source_data.y)
+        loss = source_ce(source_logits, source_data.y)
         lin = net.discriminator[0]
         domain_loss = 0
         if self.disc == 'JS':                                                      # :169-176

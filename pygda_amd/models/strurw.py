@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..ops import source_ce
 from ..metrics import eval_micro_f1
 from ..nn.reverse_layer import GradReverse
 from ..nn.reweight_gnn import ReweightGNN
@@ -54,7 +55,7 @@ class StruRW(BaseGDA):
             elif epoch == self.ew_start - 1:
                 self.cal_reweight(source_data, target_data, target_pred)
         source_feat, source_logits = self.gnn.forward(source_data, source_data.x)
-        loss = F.nll_loss(F.log_softmax(source_logits, dim=1), source_data.y)
+        loss = source_ce(source_logits, source_data.y)
         if self.mode == 'adv':                                                          # :240-250
             source_dlogits = self.domain_discriminator(GradReverse.apply(source_feat, alpha))
             target_dlogits = self.domain_discriminator(GradReverse.apply(target_feat, alpha))

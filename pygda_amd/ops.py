@@ -15,6 +15,48 @@ def _f32c(t, name):
     return t.contiguous()
 
 
+# ------------------------------------------------------ source classification loss --
+class _SoftmaxNLL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        x = _f32c(logits, "logits")
+        _lib.require_gpu_tensor(labels, "labels", torch.int64)
+        if x.dim() != 2 or labels.dim() != 1 or labels.numel() != x.size(0):
+            raise ValueError(f"logits [N, C] and labels [N] expected, got {tuple(x.shape)} and {tuple(labels.shape)}")
+        n, c = x.shape
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        L = _lib.lib()
+        ws = _lib.workspace(L.gda_softmax_nll_workspace_bytes(), x.device, "ce")
+        _lib.check(L.gda_softmax_nll_fwd_f32(_lib.ptr(x), c, _lib.ptr(labels.contiguous()), n, c, _lib.ptr(loss),
+                                             _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_softmax_nll_fwd_f32")
+        ctx.save_for_backward(x, labels)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        x, labels = ctx.saved_tensors
+        n, c = x.shape
+        gx = torch.empty_like(x)
+        gl = gl.reshape(1).to(torch.float32).contiguous()
+        _lib.check(_lib.lib().gda_softmax_nll_bwd_f32(_lib.ptr(x), c, _lib.ptr(labels.contiguous()), n, c, _lib.ptr(gl),
+                                                      _lib.ptr(gx), c, _lib.stream()), "gda_softmax_nll_bwd_f32")
+        return gx, None
+
+
+def softmax_nll(logits, labels):
+    """``F.nll_loss(F.log_softmax(logits, dim=1), labels)`` (mean over rows) in one pass each way."""
+    return _SoftmaxNLL.apply(logits, labels)
+
+
+def source_ce(logits, labels):
+    """The trainers' source loss line (pygda/models/a2gnn.py:182): fused kernel for device logits with
+    up to 64 classes, the torch composition otherwise."""
+    if logits.is_cuda and logits.dim() == 2 and logits.size(1) <= 64 and logits.dtype == torch.float32:
+        return softmax_nll(logits, labels)
+    import torch.nn.functional as F
+    return F.nll_loss(F.log_softmax(logits, dim=1), labels)
+
+
 # --------------------------------------------------------- tall-skinny GEMMs (MFMA) --
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 

@@ -1225,3 +1225,18 @@ def test_strurw_fit_predict_golden(gnn, mode):
     close(logits, g[f"{tag}/tgt_logits"], rtol=0, atol=LOGIT_ATOL)
     exact(labels, g[f"{tag}/tgt_labels"])
     exact(logits.argmax(1), g[f"{tag}/tgt_logits"].argmax(1))
+
+
+@pytest.mark.parametrize("n,c", [(9360, 5), (150000, 5), (7, 3), (1000, 64), (1, 2)])
+def test_softmax_nll_vs_torch(n, c):
+    gen = torch.Generator().manual_seed(n + c)
+    x = (torch.randn(n, c, generator=gen) * 3).to(DEV).requires_grad_()
+    y = torch.randint(0, c, (n,), generator=gen).to(DEV)
+    loss = ops.softmax_nll(x, y)
+    (gx,) = torch.autograd.grad(loss * 2.5, x)
+    xr = x.detach().double().requires_grad_()
+    want = F.nll_loss(F.log_softmax(xr, dim=1), y)
+    (gr,) = torch.autograd.grad(want * 2.5, xr)
+    close(loss, want.float(), rtol=1e-6, atol=1e-7)
+    close(gx, gr.float(), rtol=1e-5, atol=1e-9)
+    exact(ops.softmax_nll(x, y), loss)                               # deterministic
