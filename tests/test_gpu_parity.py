@@ -1240,3 +1240,30 @@ def test_softmax_nll_vs_torch(n, c):
     close(loss, want.float(), rtol=1e-6, atol=1e-7)
     close(gx, gr.float(), rtol=1e-5, atol=1e-9)
     exact(ops.softmax_nll(x, y), loss)                               # deterministic
+
+
+def test_deferred_row_split_matches_synced():
+    """Hub rows of a one-step (sampled) graph: the chunk layout is consumed from device counts with
+    capacity-sized launches -- same result, bit for bit, as the host-synchronised layout."""
+    gen = torch.Generator().manual_seed(77)
+    n = 3000
+    src = torch.randint(0, n, (40000,), generator=gen)
+    dst = torch.randint(0, n, (40000,), generator=gen)
+    dst[:2000] = 11; src[2000:3500] = 29                          # an in-hub and an out-hub
+    ei = torch.stack([src, dst]).to(DEV)
+    synced = build_csr(ei, n)
+    deferred = build_csr(ei.clone(), n)
+    deferred.transient = True
+    x = torch.randn(n, 128, generator=gen).to(DEV)
+    bias = torch.randn(128, generator=gen).to(DEV)
+    for tr in (False, True):
+        a = ops.spmm_kstep(synced, x, 3, bias, transposed=tr)
+        b = ops.spmm_kstep(deferred, x, 3, bias, transposed=tr)
+        exact(a, b)
+    assert deferred.split(False).counts is not None and synced.split(False).counts is None
+    # and a graph without any hub pays only empty capacity blocks
+    small = build_csr(torch.stack([torch.arange(50), (torch.arange(50) + 1) % 50]).to(DEV), 50)
+    small.transient = True
+    ref = build_csr(torch.stack([torch.arange(50), (torch.arange(50) + 1) % 50]).to(DEV), 50)
+    xs = torch.randn(50, 8, device=DEV)
+    exact(ops.spmm_kstep(small, xs, 2), ops.spmm_kstep(ref, xs, 2))
