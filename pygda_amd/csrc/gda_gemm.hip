@@ -101,7 +101,7 @@ k_gemm(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, in
        bool vec_b) {
     __shared__ __attribute__((aligned(16))) float As[DK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[DK][LDT];
-    const int64_t i0 = (int64_t)blockIdx.y * TILE, j0 = (int64_t)blockIdx.x * TILE;
+    const int64_t i0 = (int64_t)blockIdx.x * TILE, j0 = (int64_t)blockIdx.y * TILE;   // rows on grid.x: 2^31 tiles
     const int64_t kbeg = (int64_t)blockIdx.z * k_slab, kend = min(K, kbeg + k_slab);
     const int tid = threadIdx.x, wave = tid / 64, lane = tid % 64;
     const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
@@ -194,7 +194,7 @@ extern "C" int gda_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const flo
     if (C == A || C == B) return GDA_E_ALIAS;
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t gx = gda_cdiv(N, TILE), gy = gda_cdiv(M, TILE);
-    if (gx > 65535 * 16 || gy > INT32_MAX) return GDA_E_SIZE;
+    if (gx > 65535 || gy > INT32_MAX) return GDA_E_SIZE;          // row tiles ride on grid.x, column tiles on grid.y
     if (K == 0) {
         GDA_HIP_TRY(hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, (size_t)M, stream));
         return GDA_OK;
@@ -213,16 +213,16 @@ extern "C" int gda_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const flo
         const int64_t k_slab = gda_cdiv(gda_cdiv(K, s), DK) * DK;        // whole chunks per slab
         if (s > 1) {
             if (!workspace || workspace_bytes < gda_gemm_workspace_bytes(mode, M, N, K)) return GDA_E_WORKSPACE;
-            GDA_GEMM_LAUNCH(true, true, dim3((unsigned)gx, (unsigned)gy, s), (float*)workspace, N, k_slab);
+            GDA_GEMM_LAUNCH(true, true, dim3((unsigned)gy, (unsigned)gx, s), (float*)workspace, N, k_slab);
             GDA_LAUNCH_CHECK();
             k_slab_sum<<<(unsigned)gda_cdiv(M * N, TB), TB, 0, stream>>>((const float*)workspace, s, M, N, C, ldc);
         } else {
-            GDA_GEMM_LAUNCH(true, true, dim3((unsigned)gx, (unsigned)gy, 1), C, ldc, K);
+            GDA_GEMM_LAUNCH(true, true, dim3((unsigned)gy, (unsigned)gx, 1), C, ldc, K);
         }
     } else if (mode == GDA_GEMM_NT) {
-        GDA_GEMM_LAUNCH(false, false, dim3((unsigned)gx, (unsigned)gy, 1), C, ldc, K);
+        GDA_GEMM_LAUNCH(false, false, dim3((unsigned)gy, (unsigned)gx, 1), C, ldc, K);
     } else {
-        GDA_GEMM_LAUNCH(false, true, dim3((unsigned)gx, (unsigned)gy, 1), C, ldc, K);
+        GDA_GEMM_LAUNCH(false, true, dim3((unsigned)gy, (unsigned)gx, 1), C, ldc, K);
     }
 #undef GDA_GEMM_LAUNCH
     GDA_LAUNCH_CHECK();

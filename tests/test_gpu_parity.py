@@ -1097,7 +1097,8 @@ def test_fused_adam_matches_torch_adam():
     assert float(o1.state[ours[3]]["step"]) == 3.0 and float(o1.state[ours[0]]["step"]) == 6.0
 
 
-@pytest.mark.parametrize("M,N,K", [(9360, 128, 128), (5484, 5, 128), (1000, 130, 70), (77, 3, 5), (20000, 64, 256)])
+@pytest.mark.parametrize("M,N,K", [(9360, 128, 128), (5484, 5, 128), (1000, 130, 70), (77, 3, 5), (20000, 64, 256),
+                                   (4_400_000, 8, 16)])          # > 65535 row tiles: rows ride on grid.x
 def test_tall_gemm_vs_fp64(M, N, K):
     """NT / NN / TN products on the matrix cores against fp64: fp32 fma chains, 1e-5 of the largest
     entry; ragged sizes exercise the zero-filled tile edges and the scalar-load path."""
