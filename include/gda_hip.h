@@ -434,6 +434,17 @@ int gda_softmax_nll_fwd_f32(const float* logits, int64_t ld, const int64_t* labe
 int gda_softmax_nll_bwd_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
                             const float* grad_loss, float* grad_logits, int64_t ldg, gda_stream_t stream);
 
+/* PPMI graph construction on the DEVICE: the estimator and the walks of gda_ppmi_build_host (same
+ * counter-based generator, so both builders count the same visits), as sorts + run-length counts.
+ *   src/dst [E] int64 device; out_src/out_dst [cap] int64, out_w [cap] fp32 with
+ *   cap = N * passes * path_len (upper bound of distinct (start, visited) pairs); out_count [1] int64
+ *   DEVICE: the number of pairs written, sorted by (src, dst).
+ * Returns GDA_E_UNSUPPORTED when 2E or N*passes*path_len does not fit int32 (use the host builder). */
+size_t gda_ppmi_workspace_bytes(int64_t E, int64_t N, int path_len, int passes);
+int gda_ppmi_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int path_len, int passes,
+                   uint64_t seed, int64_t* out_src, int64_t* out_dst, float* out_w, int64_t* out_count,
+                   void* workspace, size_t workspace_bytes, gda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,9 @@ _SIGNATURES = {
     "gda_selection_csr_host": (c_int, [_P, c_int, c_int64, c_int64, c_int64, c_int64, _P, _P]),
     "gda_ppmi_build_host": (c_int, [_P, _P, c_int64, c_int64, c_int, c_int, ctypes.c_uint64,
                                     ctypes.POINTER(c_void_p)]),
+    "gda_ppmi_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
+    "gda_ppmi_build": (c_int, [_P, _P, c_int64, c_int64, c_int, c_int, ctypes.c_uint64, _P, _P, _P, _P, _P,
+                               c_size_t, _P]),
     "gda_edge_list_size": (c_int64, [_P]),
     "gda_edge_list_fetch": (c_int, [_P, _P, _P, _P]),
     "gda_edge_list_destroy": (None, [_P]),

@@ -1268,3 +1268,31 @@ def test_deferred_row_split_matches_synced():
     ref = build_csr(torch.stack([torch.arange(50), (torch.arange(50) + 1) % 50]).to(DEV), 50)
     xs = torch.randn(50, 8, device=DEV)
     exact(ops.spmm_kstep(small, xs, 2), ops.spmm_kstep(ref, xs, 2))
+
+
+def test_ppmi_device_builder_equals_host_builder():
+    """Walks, sorts and run-length counts on the GPU produce the host builder's PPMI graph: same
+    pairs, same weights (the walks are a pure function of (seed, pass, start); counts and column
+    sums are accumulated in the same order) -- on a graph with an isolated node, a self loop and
+    duplicate edges."""
+    from pygda_amd.nn.ppmi_conv import ppmi_edges
+    g = load_golden("udagcn_forward_ppmi")
+    ei = T(g["src_ei"])
+    n = g["src_x"].shape[0]
+    extra = torch.tensor([[3, 3, 5], [3, 7, 9]])
+    ei = torch.cat([ei, extra, extra[:, 1:]], dim=1)                # self loop 3-3, duplicates
+    for path_len, passes in ((10, 40), (3, 5)):
+        h_ei, h_w = ppmi_edges(ei, n + 1, path_len, passes, seed=1234)              # node n: isolated
+        d_ei, d_w = ppmi_edges(ei.to(DEV), n + 1, path_len, passes, seed=1234)
+        assert d_ei.is_cuda
+        exact(d_ei, h_ei)
+        close(d_w, h_w, rtol=2e-7, atol=0)
+    again = ppmi_edges(ei.to(DEV), n + 1, 10, 40, seed=1234)
+    exact(again[1], ppmi_edges(ei.to(DEV), n + 1, 10, 40, seed=1234)[1])           # reproducible
+    # at the cfg-A source size the pair count stays far below the capacity bound
+    import bench
+    s, _ = bench.make_cfg_a()
+    big_ei, big_w = ppmi_edges(s.edge_index.to(DEV), s.x.size(0), 10, 40, seed=7)
+    ref_ei, ref_w = ppmi_edges(s.edge_index, s.x.size(0), 10, 40, seed=7)
+    exact(big_ei, ref_ei)
+    close(big_w, ref_w, rtol=2e-7, atol=0)
