@@ -18,6 +18,38 @@ import torch
 from .utils import mmd as _mmd
 
 
+# Host-generator draws inside a training step (the reference draws e.g. the gradient-penalty
+# interpolation weights with ``torch.rand(...).to(device)``, pygda/models/adagcn.py:423-434).  Eager:
+# exactly that.  Captured: a static device buffer per call site, refilled from the same CPU draws (same
+# order) before every replay.
+host_rand_provider = None
+
+
+def host_rand(shape, device):
+    if host_rand_provider is not None:
+        return host_rand_provider(tuple(shape))
+    return torch.rand(shape).to(device)
+
+
+class _RandSlot:
+    def __init__(self, shape, dev):
+        self.shape = shape
+        self.dev = torch.zeros(shape, dtype=torch.float32, device=dev)
+        self.pin = [torch.zeros(shape, dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.done, self.turn = [None, None], 0
+
+    def fill(self):
+        k = self.turn
+        self.turn = 1 - k
+        if self.done[k] is not None:
+            self.done[k].synchronize()
+        torch.rand(self.shape, out=self.pin[k])
+        self.dev.copy_(self.pin[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.done[k] = ev
+
+
 class _DPSamples:
     """Static device block + double-buffered pinned blocks holding one rank's MMD row samples of both
     domains and the CSRs of their 0/1 selection matrices (backward scatter): drawn on the host from
@@ -60,11 +92,13 @@ class _DPSamples:
 class GraphedStep:
     """Captures ``loss, logits = step_fn(src, tgt)``, ``backward`` and ``optimizer.step()``."""
 
-    def __init__(self, step_fn, optimizer, src, tgt, warmup=3, dp=False):
+    def __init__(self, step_fn, optimizer, src, tgt, warmup=3, dp=False, extra_optimizers=()):
         """``dp``: data-parallel step with the library-owned RCCL communicator -- the gradient
         all-reduce and the MMD row all-gather are enqueued on the capturing stream like any kernel,
         so the whole step is still ONE graph."""
         self.step_fn, self.optimizer, self.src, self.tgt, self.dp = step_fn, optimizer, src, tgt, dp
+        self.extra_optimizers = list(extra_optimizers)    # stepped INSIDE step_fn (critics): rolled back too
+        self._rand_slots, self._rand_cursor = [], 0
         self._dp_idx = {}                 # (ns, nt, times, per) -> (dev_s, dev_t, pin_s, pin_t)
         self._samples = {}                # (ns, nt, times, n) -> (dev_s, dev_t, pin_s, pin_t)
         self._order = []
@@ -103,7 +137,7 @@ class GraphedStep:
             self._samples[key] = dict(dev=dev_block, devv=self._carve(dev_block, shapes), pin=pin_blocks,
                                       pinv=[self._carve(b, shapes) for b in pin_blocks],
                                       done=[None, None], turn=0, ones=ones)
-            self._order.append(key)
+            self._order.append(lambda key=key: self._fill_one(key))
             self._fill_one(key)
         e = self._samples[key]
         d = e["devv"]
@@ -135,14 +169,29 @@ class GraphedStep:
             self._dp_idx[key].fill()
         return self._dp_idx[key].views()
 
+    def _provider_rand(self, shape):
+        """k-th ``host_rand`` call of a step -> slot k (created, and filled, at its first call)."""
+        k = self._rand_cursor
+        self._rand_cursor += 1
+        if k == len(self._rand_slots):
+            slot = _RandSlot(shape, self.src.x.device)
+            self._rand_slots.append(slot)
+            self._order.append(slot.fill)
+            slot.fill()
+        slot = self._rand_slots[k]
+        if slot.shape != shape:
+            raise RuntimeError("host_rand call sequence changed between steps: the step cannot be replayed")
+        return slot.dev
+
     def _refill(self):
-        for key in self._order:
-            self._fill_one(key)
+        for fill in self._order:
+            fill()
         for e in self._dp_idx.values():
             e.fill()
 
     def _run(self, with_stats=False):
         from .ops import dropout_state
+        self._rand_cursor = 0
         dropout_state.next_step(self.src.x.device)        # device counter: bumped by every replay too
         loss, logits = self.step_fn(self.src, self.tgt)
         if with_stats:
@@ -171,10 +220,13 @@ class GraphedStep:
     def capture(self):
         """Warm-up steps are rolled back afterwards (parameters, Adam moments / step counters,
         the CPU generator), so a seeded fit() takes exactly the steps eager mode would."""
-        prev, prev_dp = _mmd.sample_provider, _mmd.dp_index_provider
+        global host_rand_provider
+        prev, prev_dp, prev_rand = _mmd.sample_provider, _mmd.dp_index_provider, host_rand_provider
         _mmd.sample_provider = self._provider
         _mmd.dp_index_provider = self._provider_dp if self.dp else None
-        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        host_rand_provider = self._provider_rand
+        optimizers = [self.optimizer] + self.extra_optimizers
+        params = [p for o in optimizers for g in o.param_groups for p in g["params"]]
         saved = [p.detach().clone() for p in params]
         cpu_rng = torch.get_rng_state()
         try:
@@ -199,13 +251,14 @@ class GraphedStep:
             with torch.no_grad():
                 for p, v in zip(params, saved):
                     p.copy_(v)
-                for st in self.optimizer.state.values():      # fresh optimiser: everything back to zero
-                    for v in st.values():
-                        if torch.is_tensor(v):
-                            v.zero_()
+                for o in optimizers:                           # fresh optimisers: everything back to zero
+                    for st in o.state.values():
+                        for v in st.values():
+                            if torch.is_tensor(v):
+                                v.zero_()
             torch.set_rng_state(cpu_rng)
         finally:
-            _mmd.sample_provider, _mmd.dp_index_provider = prev, prev_dp
+            _mmd.sample_provider, _mmd.dp_index_provider, host_rand_provider = prev, prev_dp, prev_rand
         return self
 
     def __call__(self):

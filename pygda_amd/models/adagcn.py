@@ -58,11 +58,19 @@ class AdaGCN(BaseGDA):
             raise NotImplementedError("mode='graph' is out of scope (DESIGN.md)")
         self._node_loaders(source_data, target_data)
         self.adagcn = self.init_model(**self.kwargs)
-        optimizer = torch.optim.Adam(self.adagcn.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        on_gpu = torch.device(self.device).type == "cuda"
+        if on_gpu:       # torch.optim.Adam's rule in one capturable launch (pygda_amd/optim.py)
+            from ..optim import Adam
+        else:
+            Adam = torch.optim.Adam
+        optimizer = Adam(self.adagcn.parameters(), lr=self.lr, weight_decay=self.weight_decay)
         self.discriminator = nn.Sequential(nn.Linear(self.hid_dim, self.adv_dim), nn.ReLU(), nn.Dropout(0.1),
                                            nn.Linear(self.adv_dim, 1), nn.Sigmoid()).to(self.device)   # :264-270
-        self.c_optimizer = torch.optim.Adam(self.discriminator.parameters(), lr=self.lr,
-                                            weight_decay=self.weight_decay)
+        self.c_optimizer = Adam(self.discriminator.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        # no per-epoch scalar enters the step, its host draws go through hipgraph.host_rand and the critic's
+        # optimiser is rolled back with the encoder's: the step (10 critic updates + encoder update) replays
+        self._graph_safe_step = True
+        self._graph_extra_optimizers = [self.c_optimizer]
 
         def step(src, tgt, alpha, epoch):
             loss, source_logits, _ = self.forward_model(src, tgt)
@@ -83,20 +91,22 @@ class AdaGCN(BaseGDA):
 
     def gradient_penalty(self, encoded_source, encoded_target):
         """WGAN-GP over cat(source, target, interpolates) (:387-454); interpolation weights from
-        the CPU generator, as in the reference (``torch.rand(...).to(device)``)."""
+        the CPU generator, as in the reference (``torch.rand(...).to(device)``) -- through
+        ``hipgraph.host_rand`` so that a captured step is fed the same draws."""
+        from ..hipgraph import host_rand
         num_s, num_t = encoded_source.shape[0], encoded_target.shape[0]
         dev = encoded_source.device
         if num_s < num_t:
             hidden_s = torch.cat((encoded_source, encoded_source), dim=0)
             hidden_t = torch.cat((encoded_target[0:num_s], encoded_target[-num_s:]), dim=0)
-            alpha = torch.rand((2 * num_s, 1)).to(dev)
+            alpha = host_rand((2 * num_s, 1), dev)
         elif num_s > num_t:
             hidden_s = torch.cat((encoded_source[0:num_t], encoded_source[-num_t:]), dim=0)
             hidden_t = torch.cat((encoded_target, encoded_target), dim=0)
-            alpha = torch.rand((2 * num_t, 1)).to(dev)
+            alpha = host_rand((2 * num_t, 1), dev)
         else:
             hidden_s, hidden_t = encoded_source, encoded_target
-            alpha = torch.rand((num_t, 1)).to(dev)
+            alpha = host_rand((num_t, 1), dev)
         interpolates = hidden_t + alpha * (hidden_s - hidden_t)
         inputs = torch.cat((encoded_source, encoded_target, interpolates), dim=0)
         if not inputs.requires_grad:

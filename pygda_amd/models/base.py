@@ -160,13 +160,14 @@ class BaseGDA(ABC):
                               # torch 2.10): without a segmented step, data-parallel training stays eager
         if not (getattr(self.source_loader, "full_batch", False) and getattr(self.target_loader, "full_batch", False)):
             return None
-        if not any(g.get("capturable", False) for g in optimizer.param_groups):
+        extra = getattr(self, "_graph_extra_optimizers", ())
+        if not all(any(g.get("capturable", False) for g in o.param_groups) for o in (optimizer, *extra)):
             return None
         from ..hipgraph import GraphedStep, GraphedStepDP
         src = next(iter(self.source_loader)).to(self.device)
         tgt = next(iter(self.target_loader)).to(self.device)
         (before_step or net.train)()
-        params = [p for g in optimizer.param_groups for p in g["params"]]
+        params = [p for o in (optimizer, *extra) for g in o.param_groups for p in g["params"]]
         saved = [p.detach().clone() for p in params]
         cpu_rng = torch.get_rng_state()
         try:
@@ -184,7 +185,8 @@ class BaseGDA(ABC):
                 part1, part2 = self._dp_graph_parts()
                 graphed = GraphedStepDP(part1, part2, optimizer, src, tgt).capture(eager_step)
             else:
-                graphed = GraphedStep(lambda s, t: step_fn(s, t, 0.0, 0), optimizer, src, tgt).capture()
+                graphed = GraphedStep(lambda s, t: step_fn(s, t, 0.0, 0), optimizer, src, tgt,
+                                      extra_optimizers=getattr(self, "_graph_extra_optimizers", ())).capture()
         except Exception as exc:       # anything a custom activation / exotic configuration may do under capture
             if self.use_hip_graph:     # explicitly requested: do not hide the failure
                 raise
@@ -196,10 +198,11 @@ class BaseGDA(ABC):
                 for p, v in zip(params, saved):
                     p.copy_(v)
                     p.grad = None
-                for st in optimizer.state.values():
-                    for v in st.values():
-                        if torch.is_tensor(v):
-                            v.zero_()
+                for o in (optimizer, *extra):
+                    for st in o.state.values():
+                        for v in st.values():
+                            if torch.is_tensor(v):
+                                v.zero_()
             torch.set_rng_state(cpu_rng)
             self._graph_safe_step = False
             return None

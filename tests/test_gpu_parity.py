@@ -1296,3 +1296,35 @@ def test_ppmi_device_builder_equals_host_builder():
     ref_ei, ref_w = ppmi_edges(s.edge_index, s.x.size(0), 10, 40, seed=7)
     exact(big_ei, ref_ei)
     close(big_w, ref_w, rtol=2e-7, atol=0)
+
+
+def test_adagcn_captured_step_matches_eager_trajectory(monkeypatch):
+    """The AdaGCN step (10 critic updates with gradient penalty, each fed CPU-generator interpolation
+    weights, then the encoder update) replayed as a hipGraph: same 4-epoch trajectory as eager from
+    the same seed -- host draws arrive through static buffers in the eager order, and the critic's
+    optimiser is rolled back after the warm-up together with the encoder's."""
+    import torch.nn as nn
+    g = load_golden("adagcn_forward")
+    s, t = _pair(g)
+
+    def run(graphed):
+        m = pygda_amd.models.AdaGCN(12, 8, 3, num_layers=2, adv_dim=6, gp_weight=5, domain_weight=1, lr=0.01,
+                                    dropout=0.0, device=DEV, epoch=4, verbose=0, use_hip_graph=graphed)
+        orig = nn.Dropout.__init__
+        monkeypatch.setattr(nn.Dropout, "__init__", lambda self, p=0.5, inplace=False: orig(self, 0.0, inplace))
+        seen = []
+        m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+        torch.manual_seed(5)
+        m.fit(s, t)
+        monkeypatch.setattr(nn.Dropout, "__init__", orig)
+        return seen, m.predict(t)[0], [p.detach().clone() for p in m.discriminator.parameters()], m
+
+    e_seen, e_logits, e_disc, _ = run(False)
+    g_seen, g_logits, g_disc, gm = run(True)
+    from pygda_amd.hipgraph import GraphedStep
+    assert isinstance(getattr(gm, "_graphed", None), GraphedStep) and len(gm._graphed._rand_slots) == 10
+    close([x[0] for x in g_seen], [x[0] for x in e_seen], rtol=1e-4)
+    close([x[1] for x in g_seen], [x[1] for x in e_seen], rtol=0, atol=1e-12)
+    close(g_logits, e_logits, rtol=0, atol=LOGIT_ATOL)
+    for a, b in zip(g_disc, e_disc):
+        close(a, b, rtol=1e-3, atol=1e-5)
