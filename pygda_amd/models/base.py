@@ -83,7 +83,7 @@ class BaseGDA(ABC):
             self._dp_synced = net
         graphed = self._maybe_graphed_step(optimizer, step_fn, before_step, net)
         if graphed is not None and hasattr(graphed, "launch"):
-            return self._graphed_epochs(graphed, range(self.epoch) if epochs is None else epochs, start)
+            return self._graphed_epochs(graphed, range(self.epoch) if epochs is None else epochs, start, alpha_fn)
         for epoch in (range(self.epoch) if epochs is None else epochs):
             epoch_loss, logits, labels = 0.0, [], []
             alpha = alpha_fn(epoch)
@@ -117,7 +117,7 @@ class BaseGDA(ABC):
             if self.epoch_hook is not None:
                 self.epoch_hook(epoch, epoch_loss, acc, secs)
 
-    def _graphed_epochs(self, graphed, epochs, start):
+    def _graphed_epochs(self, graphed, epochs, start, alpha_fn=None):
         """Full-batch epochs as hipGraph replays, software-pipelined by one step: the host draws the
         MMD samples of epoch e+1 and launches it while epoch e's two numbers (loss, source accuracy --
         micro-F1 of single-label predictions -- computed inside the graph) travel back, so the GPU
@@ -131,6 +131,9 @@ class BaseGDA(ABC):
 
         pending = None
         for epoch in epochs:
+            if alpha_fn is not None and getattr(self, "_graph_uses_scalars", False):
+                self._g_alpha.fill_(float(alpha_fn(epoch)))
+                self._g_epoch.fill_(float(epoch))
             ticket = graphed.launch()
             if pending is not None:
                 report(*pending)
@@ -170,9 +173,14 @@ class BaseGDA(ABC):
         params = [p for o in (optimizer, *extra) for g in o.param_groups for p in g["params"]]
         saved = [p.detach().clone() for p in params]
         cpu_rng = torch.get_rng_state()
+        # per-epoch scalars of the reference's loops (GRL alpha, epoch) as 0-dim device tensors: refreshed
+        # before every replay, so the captured arithmetic sees the current value
+        self._g_alpha = torch.zeros((), dtype=torch.float32, device=src.x.device)
+        self._g_epoch = torch.zeros((), dtype=torch.float32, device=src.x.device)
+        scalar_step = lambda s, t: step_fn(s, t, self._g_alpha, self._g_epoch)      # noqa: E731
         try:
             if whole:
-                graphed = GraphedStep(lambda s, t: step_fn(s, t, 0.0, 0), optimizer, src, tgt, dp=True).capture()
+                graphed = GraphedStep(scalar_step, optimizer, src, tgt, dp=True).capture()
             elif dp:          # collectives stay eager between four captured segments
                 def eager_step():
                     from ..ops import dropout_state
@@ -185,7 +193,7 @@ class BaseGDA(ABC):
                 part1, part2 = self._dp_graph_parts()
                 graphed = GraphedStepDP(part1, part2, optimizer, src, tgt).capture(eager_step)
             else:
-                graphed = GraphedStep(lambda s, t: step_fn(s, t, 0.0, 0), optimizer, src, tgt,
+                graphed = GraphedStep(scalar_step, optimizer, src, tgt,
                                       extra_optimizers=getattr(self, "_graph_extra_optimizers", ())).capture()
         except Exception as exc:       # anything a custom activation / exotic configuration may do under capture
             if self.use_hip_graph:     # explicitly requested: do not hide the failure

@@ -51,7 +51,13 @@ class GRADE(BaseGDA):
             raise NotImplementedError("mode='graph' is out of scope (DESIGN.md)")
         self._node_loaders(source_data, target_data)
         self.grade = self.init_model(**self.kwargs)
-        optimizer = torch.optim.Adam(self.grade.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        if torch.device(self.device).type == "cuda":       # one capturable multi-tensor launch (pygda_amd/optim.py)
+            from ..optim import Adam
+        else:
+            Adam = torch.optim.Adam
+        optimizer = Adam(self.grade.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        # the step replays as a hipGraph: its only per-epoch scalar, the GRL alpha, is a device tensor there
+        self._graph_safe_step, self._graph_uses_scalars = True, self.disc != 'MMD'
 
         def step(src, tgt, alpha, epoch):
             loss, source_logits, _ = self.forward_model(src, tgt, alpha)

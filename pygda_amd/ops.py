@@ -375,7 +375,14 @@ class _GrlDiscCE(torch.autograd.Function):
 
 def grl_disc_ce(source_feat, target_feat, weight, bias, alpha, labels=None):
     """``F.cross_entropy(Linear(GradReverse(cat(source, target))), domain_labels)`` fused
-    (a2gnn.py:197-205 / grade.py:170-176).  Default labels: 0 for source rows, 1 for target."""
+    (a2gnn.py:197-205 / grade.py:170-176).  Default labels: 0 for source rows, 1 for target.
+    ``alpha`` may be a 0-dim DEVICE tensor (the captured step updates it per epoch without touching
+    the graph): the fused kernel then runs with the reversal folded out (alpha = -1) behind a
+    tensor-valued GradReverse."""
+    if torch.is_tensor(alpha):
+        from .nn.reverse_layer import GradReverse
+        return _GrlDiscCE.apply(GradReverse.apply(source_feat, alpha), GradReverse.apply(target_feat, alpha),
+                                weight, bias, -1.0, labels)
     return _GrlDiscCE.apply(source_feat, target_feat, weight, bias, alpha, labels)
 
 
