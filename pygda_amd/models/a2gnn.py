@@ -143,8 +143,9 @@ class A2GNN(BaseGDA):
             raise NotImplementedError("mode='graph' is out of scope (DESIGN.md)")
         self._node_loaders(source_data, target_data)
         self.a2gnn = self.init_model(**self.kwargs)
-        # the MMD branch never reads alpha/epoch: its step can be captured into a hipGraph
-        self._graph_safe_step = not self.adv
+        # the MMD branch never reads alpha/epoch; the adversarial branch reads the GRL alpha, which the
+        # captured step receives as a 0-dim device tensor refreshed per epoch: both replay as a hipGraph
+        self._graph_safe_step, self._graph_uses_scalars = True, bool(self.adv)
         on_gpu = torch.device(self.device).type == "cuda"
         if on_gpu:           # torch.optim.Adam's update in one multi-tensor launch (pygda_amd/optim.py)
             from ..optim import Adam
