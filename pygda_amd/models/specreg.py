@@ -76,7 +76,11 @@ class SpecReg(BaseGDA):
         self._node_loaders(source_data, target_data)
         self.udagcn = self.init_model(**self.kwargs)
         params = itertools.chain(*[m.parameters() for m in self.udagcn.models])
-        optimizer = torch.optim.Adam(params, lr=self.lr, weight_decay=self.weight_decay)
+        # the shared conv Parameters are listed twice (encoder + ppmi_encoder), as in the reference; its CPU
+        # path then updates them twice per step, one after the other.  torch's multi-tensor CUDA kernels would
+        # process the two list entries concurrently (one racy update): the per-tensor loop keeps the CPU
+        # path's semantics.
+        optimizer = torch.optim.Adam(params, lr=self.lr, weight_decay=self.weight_decay, foreach=False)
         self.critic = nn.Sequential(nn.Linear(self.hid_dim, self.hid_dim), nn.ReLU(),
                                     nn.Linear(self.hid_dim, self.hid_dim), nn.ReLU(),
                                     nn.Linear(self.hid_dim, 1)).to(self.device)          # :281-287

@@ -57,7 +57,11 @@ class UDAGCN(BaseGDA):
         self._node_loaders(source_data, target_data)
         self.udagcn = self.init_model(**self.kwargs)
         params = itertools.chain(*[m.parameters() for m in self.udagcn.models])            # :262-268
-        optimizer = torch.optim.Adam(params, lr=self.lr, weight_decay=self.weight_decay)
+        # the shared conv Parameters are listed twice (encoder + ppmi_encoder), as in the reference; its CPU
+        # path then updates them twice per step, one after the other.  torch's multi-tensor CUDA kernels would
+        # process the two list entries concurrently (one racy update): the per-tensor loop keeps the CPU
+        # path's semantics.
+        optimizer = torch.optim.Adam(params, lr=self.lr, weight_decay=self.weight_decay, foreach=False)
 
         def step(src, tgt, alpha, epoch):
             loss, source_logits, _ = self.forward_model(src, tgt, alpha, epoch)

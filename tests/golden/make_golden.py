@@ -287,6 +287,42 @@ def fx_udagcn(ref):
         save("udagcn_forward_ppmi" if ppmi else "udagcn_forward_gcn", **arrs)
 
 
+def fx_udagcn_fit(ref):
+    """UDAGCN.fit for three epochs with the PPMI view: the optimiser holds the shared conv weights
+    twice (encoder + ppmi_encoder list the same Parameters, udagcn.py:262-268), so this pins what a
+    step does to them.  Dropouts zeroed; the PPMI graphs the reference walked are stored."""
+    import pygda.models.udagcn as umod
+    s, t = _domain_pair(191, ns=60, nt=50, f=12, c=3)
+    losses, accs = [], []
+    orig = umod.logger
+    umod.logger = lambda **kw_: (losses.append(kw_["loss"]), accs.append(kw_["source_train_acc"]))
+    try:
+        m = ref.UDAGCN(12, 8, 3, num_layers=2, ppmi=True, adv_dim=6, lr=0.01, weight_decay=0.003, device="cpu",
+                       epoch=3, verbose=0)
+        init = m.init_model
+
+        def init_zero(**k):
+            net = init(**k)
+            _zero_dropout(net)
+            return net
+
+        m.init_model = init_zero
+        torch.manual_seed(192)
+        np.random.seed(193)
+        m.fit(s, t)
+        logits, labels = m.predict(t)
+    finally:
+        umod.logger = orig
+    arrs = dict(_pair_arrays(s, t), seed=np.int64(192), np_seed=np.int64(193), losses=np.array(losses, dtype=np.float64),
+                accs=np.array(accs, dtype=np.float64), tgt_logits=np_(logits), tgt_labels=np_(labels))
+    for name in ("source", "target"):
+        for li, conv in enumerate(m.udagcn.ppmi_encoder.conv_layers):
+            ei, w = conv.cache_dict[name]
+            arrs[f"ppmi/{name}/{li}/edge_index"], arrs[f"ppmi/{name}/{li}/weight"] = np_(ei), np_(w)
+    arrs.update(sd_arrays(m.udagcn, "final/"))
+    save("udagcn_fit3", **arrs)
+
+
 def fx_adagcn(ref):
     """AdaGCN.forward_model: 10 critic updates (gradient penalty, CPU torch.rand) + encoder loss."""
     s, t = _domain_pair(101, ns=70, nt=55, f=12, c=3)
@@ -431,6 +467,7 @@ def fx_tdss(ref):
 
 
 FIXTURES["tdss"] = fx_tdss
+FIXTURES["udagcn_fit"] = fx_udagcn_fit
 
 
 def fx_specreg(ref):

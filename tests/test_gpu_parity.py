@@ -1354,3 +1354,38 @@ def test_grade_captured_step_matches_eager_trajectory(disc):
     close([x[0] for x in g_seen], [x[0] for x in e_seen], rtol=1e-4)
     close([x[1] for x in g_seen], [x[1] for x in e_seen], rtol=0, atol=1e-12)
     close(g_logits, e_logits, rtol=0, atol=LOGIT_ATOL)
+
+
+def test_udagcn_fit_predict_golden(monkeypatch):
+    """UDAGCN.fit for three epochs with the PPMI view against the reference: the optimiser sees the
+    shared conv weights twice, as in udagcn.py:262-268.  The PPMI graphs are the ones the reference
+    walked (loaded into the layer caches); everything else is computed."""
+    g = load_golden("udagcn_fit3")
+    s, t = _pair(g)
+    m = pygda_amd.models.UDAGCN(12, 8, 3, num_layers=2, ppmi=True, adv_dim=6, lr=0.01, weight_decay=0.003,
+                                device=DEV, epoch=3, verbose=0)
+    init = m.init_model
+
+    def init_with_reference_ppmi(**kw):
+        net = init(**kw)
+        _no_dropout(net)
+        for name, data in (("source", s), ("target", t)):
+            for li, conv in enumerate(net.ppmi_encoder.conv_layers):
+                ei, w = T(g[f"ppmi/{name}/{li}/edge_index"], DEV), T(g[f"ppmi/{name}/{li}/weight"], DEV)
+                conv.cache_dict[name] = build_csr(ei, data.num_nodes, w, add_self_loops=False, normalize=False)
+        return net
+
+    monkeypatch.setattr(m, "init_model", init_with_reference_ppmi)
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+    torch.manual_seed(int(g["seed"]))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.fit(s, t)
+    close([x[0] for x in seen], g["losses"], rtol=REL)
+    close([x[1] for x in seen], g["accs"], rtol=0, atol=1e-12)
+    logits, labels = m.predict(t)
+    close(logits, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    exact(labels, g["tgt_labels"])
+    exact(logits.argmax(1), g["tgt_logits"].argmax(1))

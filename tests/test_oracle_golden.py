@@ -471,3 +471,35 @@ def test_strurw_fit_trajectory(gnn, mode):
     net.eval()
     with torch.no_grad():
         eq(net(tgt, tgt.x)[1], g[f"{tag}/tgt_logits"], tol=1e-5)
+
+
+def test_udagcn_fit_trajectory_with_shared_parameters():
+    """Three epochs of udagcn.py:270-336 with the PPMI view.  The reference hands Adam the shared conv
+    Parameters twice (encoder + ppmi_encoder, :262-268); the restated loop does the same, so whatever
+    this torch does with duplicates is what both do."""
+    import itertools
+    g = load_golden("udagcn_fit3")
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    torch.manual_seed(int(g["seed"]))
+    np.random.seed(int(g["np_seed"]))
+    net = O.UDAGCNBase(12, 8, 3, num_layers=2, ppmi=True, adv_dim=6, dropout_p=0.0)
+    models = [net.encoder, net.cls_model, net.domain_model, net.ppmi_encoder, net.att_model]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        opt = torch.optim.Adam(itertools.chain(*[m.parameters() for m in models]), lr=0.01, weight_decay=0.003)
+    losses = []
+    for epoch in range(3):
+        net.train()
+        alpha = min((epoch + 1) / 3, 0.05)
+        loss, _, _ = O.udagcn_forward_model(net, src, tgt, alpha, epoch, 3)
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(loss.item())
+    eq(np.array(losses), g["losses"], tol=1e-6)
+    for name in ("source", "target"):
+        for li, conv in enumerate(net.ppmi_encoder.conv_layers):
+            eq(conv.cache_dict[name][0], g[f"ppmi/{name}/{li}/edge_index"])
+    net.eval()
+    with torch.no_grad():
+        eq(net.cls_model(net.encode(tgt, "target")), g["tgt_logits"], tol=1e-5)
