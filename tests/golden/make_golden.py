@@ -470,6 +470,43 @@ FIXTURES["tdss"] = fx_tdss
 FIXTURES["udagcn_fit"] = fx_udagcn_fit
 
 
+def fx_grade_adagcn_fit(ref):
+    """3-epoch fit()/predict() trajectories of GRADE (JS: the GRL coefficient follows its epoch
+    schedule) and AdaGCN (10 critic updates per step, CPU-generator interpolation weights); every
+    Dropout constructed during the run has p = 0."""
+    import pygda.models.grade as gmod
+    import pygda.models.adagcn as amod
+    import torch.nn as nn
+    s, t = _domain_pair(201, ns=70, nt=55, f=12, c=3)
+    arrs = dict(_pair_arrays(s, t))
+    orig_init = nn.Dropout.__init__
+    nn.Dropout.__init__ = lambda self, p=0.5, inplace=False: orig_init(self, 0.0, inplace)
+    try:
+        for tag, mod, make in (("grade", gmod, lambda: ref.GRADE(12, 8, 3, num_layers=2, dropout=0.0, disc="JS", weight=0.5,
+                                                                  lr=0.01, weight_decay=0.001, device="cpu", epoch=3, verbose=0)),
+                               ("adagcn", amod, lambda: ref.AdaGCN(12, 8, 3, num_layers=2, dropout=0.0, adv_dim=6, gp_weight=5,
+                                                                    domain_weight=1, lr=0.01, device="cpu", epoch=3, verbose=0))):
+            losses, accs = [], []
+            orig = mod.logger
+            mod.logger = lambda **kw_: (losses.append(kw_["loss"]), accs.append(kw_["source_train_acc"]))
+            try:
+                m = make()
+                torch.manual_seed(202)
+                m.fit(s, t)
+                logits, labels = m.predict(t)
+            finally:
+                mod.logger = orig
+            arrs.update({f"{tag}/losses": np.array(losses, dtype=np.float64), f"{tag}/accs": np.array(accs, dtype=np.float64),
+                         f"{tag}/tgt_logits": np_(logits), f"{tag}/tgt_labels": np_(labels)})
+    finally:
+        nn.Dropout.__init__ = orig_init
+    arrs.update(seed=np.int64(202))
+    save("grade_adagcn_fit3", **arrs)
+
+
+FIXTURES["grade_adagcn_fit"] = fx_grade_adagcn_fit
+
+
 def fx_specreg(ref):
     """SpecReg (specreg.py): forward_model (5 critic updates + gradient penalty + spectral hinges on
     given eigenvector bases) with loss/grads, and a 3-epoch fit()/predict() trajectory.  GCN view only

@@ -1389,3 +1389,30 @@ def test_udagcn_fit_predict_golden(monkeypatch):
     close(logits, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
     exact(labels, g["tgt_labels"])
     exact(logits.argmax(1), g["tgt_logits"].argmax(1))
+
+
+@pytest.mark.parametrize("which,graphed", [("grade", False), ("grade", True), ("adagcn", False), ("adagcn", True)])
+def test_grade_adagcn_fit_predict_golden(monkeypatch, which, graphed):
+    """3-epoch fit()/predict() of GRADE (JS) and AdaGCN against the reference, eager and as a
+    replayed hipGraph (default): per-epoch loss and source accuracy, final logits, labels."""
+    import torch.nn as nn
+    g = load_golden("grade_adagcn_fit3")
+    s, t = _pair(g)
+    orig = nn.Dropout.__init__
+    monkeypatch.setattr(nn.Dropout, "__init__", lambda self, p=0.5, inplace=False: orig(self, 0.0, inplace))
+    if which == "grade":
+        m = pygda_amd.models.GRADE(12, 8, 3, num_layers=2, dropout=0.0, disc="JS", weight=0.5, lr=0.01,
+                                   weight_decay=0.001, device=DEV, epoch=3, verbose=0, use_hip_graph=graphed)
+    else:
+        m = pygda_amd.models.AdaGCN(12, 8, 3, num_layers=2, dropout=0.0, adv_dim=6, gp_weight=5, domain_weight=1,
+                                    lr=0.01, device=DEV, epoch=3, verbose=0, use_hip_graph=graphed)
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+    torch.manual_seed(int(g["seed"]))
+    m.fit(s, t)
+    close([x[0] for x in seen], g[f"{which}/losses"], rtol=REL)
+    close([x[1] for x in seen], g[f"{which}/accs"], rtol=0, atol=1e-12)
+    logits, labels = m.predict(t)
+    close(logits, g[f"{which}/tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    exact(labels, g[f"{which}/tgt_labels"])
+    exact(logits.argmax(1), g[f"{which}/tgt_logits"].argmax(1))

@@ -503,3 +503,41 @@ def test_udagcn_fit_trajectory_with_shared_parameters():
     net.eval()
     with torch.no_grad():
         eq(net.cls_model(net.encode(tgt, "target")), g["tgt_logits"], tol=1e-5)
+
+
+def test_grade_and_adagcn_fit_trajectories():
+    """3-epoch loops of grade.py:233-300 (GRL schedule 2/(1+e^{-10p})-1) and adagcn.py:254-340."""
+    g = load_golden("grade_adagcn_fit3")
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    torch.manual_seed(int(g["seed"]))
+    net = O.GRADEBase(12, 8, 3, num_layers=2, dropout=0.0, disc="JS")
+    opt = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=0.001)
+    losses = []
+    for epoch in range(3):
+        net.train()
+        alpha = 2 / (1 + np.exp(-10 * epoch / 3)) - 1
+        loss, _, _ = O.grade_forward_model(net, src, tgt, alpha, "JS", 0.5)
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(loss.item())
+    eq(np.array(losses), g["grade/losses"], tol=1e-6)
+    net.eval()
+    with torch.no_grad():
+        eq(net(tgt)[0], g["grade/tgt_logits"], tol=1e-5)
+    # AdaGCN: encoder, then the critic (adagcn.py:262-275), both Adam(lr, weight_decay = 0 default)
+    torch.manual_seed(int(g["seed"]))
+    enc = O.AdaGCNBase(12, 8, 3, num_layers=2, dropout_p=0.0)
+    e_opt = torch.optim.Adam(enc.parameters(), lr=0.01, weight_decay=0.0)
+    disc = torch.nn.Sequential(torch.nn.Linear(8, 6), torch.nn.ReLU(), torch.nn.Dropout(0.0),
+                               torch.nn.Linear(6, 1), torch.nn.Sigmoid())
+    c_opt = torch.optim.Adam(disc.parameters(), lr=0.01, weight_decay=0.0)
+    losses = []
+    for _ in range(3):
+        enc.train()
+        loss, _, _ = O.adagcn_forward_model(enc, disc, c_opt, src, tgt, 5, 1)
+        e_opt.zero_grad(); loss.backward(); e_opt.step()
+        losses.append(loss.item())
+    eq(np.array(losses), g["adagcn/losses"], tol=1e-6)
+    enc.eval()
+    with torch.no_grad():
+        eq(enc.cls_model(enc(tgt)), g["adagcn/tgt_logits"], tol=1e-5)
