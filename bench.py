@@ -266,7 +266,7 @@ def main():
     model = A2GNN(src.x.size(1), hp["hid"], hp["classes"], num_layers=hp["L"], lr=hp["lr"],
                   weight_decay=hp["wd"], epoch=total_epochs, dropout=hp["dropout"], s_pnums=hp["s_pnums"],
                   t_pnums=hp["t_pnums"], weight=hp["weight"], adv=args.adv, device=dev, verbose=0,
-                  use_hip_graph=not args.eager)
+                  use_hip_graph=False if args.eager else None)   # None: captured, with the eager fallback if capture fails
     torch.manual_seed(1234 + rank)
     state = model._prepare(src, tgt)
     src_d, tgt_d = src.to(dev), tgt.to(dev)          # inputs resident in HBM before the timed region
