@@ -167,6 +167,12 @@ class BaseGDA(ABC):
         if not all(any(g.get("capturable", False) for g in o.param_groups) for o in (optimizer, *extra)):
             return None
         from ..hipgraph import GraphedStep, GraphedStepDP
+        # A trainer and its captured graphs form a reference cycle, so an earlier, dropped trainer's
+        # hipGraphs die whenever the cyclic collector runs -- destroying a graph (and its memory pool) in
+        # the middle of this trainer's replays has crashed the runtime.  Collect them now, device idle.
+        import gc
+        torch.cuda.synchronize()
+        gc.collect()
         src = next(iter(self.source_loader)).to(self.device)
         tgt = next(iter(self.target_loader)).to(self.device)
         (before_step or net.train)()

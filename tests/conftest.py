@@ -24,6 +24,20 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _settle_device_state(request):
+    """A trainer and its captured hipGraphs form a reference cycle (trainer -> GraphedStep -> step
+    closure -> trainer), so they die whenever the cyclic collector happens to run -- possibly in the
+    middle of another test's capture or replay.  Collect them between tests instead, with the device
+    idle, so that every graph is destroyed at a quiet point."""
+    yield
+    if "gpu" in request.keywords and torch.cuda.is_available():
+        import gc
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.synchronize()
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     return {k: z[k] for k in z.files}
