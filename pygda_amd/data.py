@@ -94,27 +94,28 @@ class NeighborLoader:
     in-neighbourhoods, seeds first, exactly ``batch.batch_size`` of them."""
 
     def __init__(self, data, num_neighbors, batch_size=1, shuffle=False, input_nodes=None,
-                 rank=0, world_size=1, seed=0, device=None, prefetch=2, **kwargs):
+                 rank=0, world_size=1, seed=0, device=None, prefetch=2, full_batch=None, **kwargs):
         self.prefetch = int(prefetch)
         self.num_neighbors = list(num_neighbors)
         self.batch_size, self.shuffle = int(batch_size), shuffle
         self.rank, self.world_size, self.seed = rank, world_size, seed
         n = data.num_nodes
+        # ``full_batch=False`` sends a whole-graph request (fan-out -1, one batch) through the sampler
+        # anyway: the sampled-batch code path on an input whose result is known (tests)
         full = (all(k == -1 for k in self.num_neighbors) and self.batch_size >= n
-                and input_nodes is None and world_size == 1)
+                and input_nodes is None and world_size == 1 and full_batch is not False)
         # sampled mode keeps the feature matrix resident on the training device: batches are
         # assembled there by the row-gather kernel, only node / edge ids cross PCIe
         self.data = data.to(device) if (device is not None and not full) else data
         self.input_nodes = torch.arange(n) if input_nodes is None else torch.as_tensor(input_nodes).long().cpu()
-        self.full_batch = (all(k == -1 for k in self.num_neighbors) and self.batch_size >= n
-                           and input_nodes is None and world_size == 1)
+        self.full_batch = full
         self._sampler = None
         self._epoch = 0
 
-    def _batches(self):
+    def _batches(self, epoch=None):
         seeds = self.input_nodes
         if self.shuffle:
-            g = torch.Generator().manual_seed(self.seed + self._epoch)
+            g = torch.Generator().manual_seed(self.seed + (self._epoch if epoch is None else epoch))
             seeds = seeds[torch.randperm(seeds.numel(), generator=g)]
         chunks = list(torch.split(seeds, self.batch_size))
         # data-parallel shard of the seed batches; every rank gets the same count (short ranks
@@ -135,8 +136,13 @@ class NeighborLoader:
         from .sampler import NeighborSampler
         if self._sampler is None:
             self._sampler = NeighborSampler(self.data.edge_index, self.data.num_nodes)
-        batches = self._batches()
-        seeds_of = lambda b: hash((self.seed, self._epoch, b, self.rank)) & 0x7FFFFFFF
+        # the epoch counter advances when iteration STARTS: ``zip(source_loader, target_loader)`` never
+        # resumes the second generator after the first one is exhausted, so a bump after the last yield
+        # would leave the target loader on epoch 0 (same neighbourhoods and shuffle every epoch)
+        epoch = self._epoch
+        self._epoch += 1
+        batches = self._batches(epoch)
+        seeds_of = lambda b: hash((self.seed, epoch, b, self.rank)) & 0x7FFFFFFF
         if self.prefetch <= 0:
             for b, seeds in enumerate(batches):
                 yield self._sampler.sample_batch(self.data, seeds, self.num_neighbors, seed=seeds_of(b))
@@ -176,7 +182,6 @@ class NeighborLoader:
                         q.get_nowait()
                     except queue.Empty:
                         th.join(timeout=0.01)
-        self._epoch += 1
 
 
 class DataLoader:

@@ -95,12 +95,60 @@ def broadcast_parameters(module, src=0):
     if not tensors:
         return
     flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
-    dist.broadcast(flat, src=src)
+    if flat.is_cuda and dist.get_backend() != "nccl":      # gloo group over device tensors: via the host
+        h = flat.cpu()
+        dist.broadcast(h, src=src)
+        flat.copy_(h)
+    else:
+        dist.broadcast(flat, src=src)
     off = 0
     for t in tensors:
         n = t.numel()
         t.copy_(flat[off:off + n].view_as(t))
         off += n
+
+
+def _all_reduce_sum(t):
+    """In-place sum over ranks.  ``gloo`` groups (CPU tests; two processes sharing one GPU in the
+    GPU equality test) stage device tensors through the host instead of relying on gloo's optional
+    device support."""
+    if t.is_cuda and dist.get_backend() != "nccl":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+class _GlobalMean(torch.autograd.Function):
+    """Mean over the rows of ALL ranks from each rank's local mean and row count.
+
+    Ranks own sub-graphs of different sizes, so the average of per-rank means is not the mean over
+    the global batch.  Forward: ``sum_r n_r * mean_r / sum_r n_r`` (one 2-float
+    all-reduce).  Backward: the gradient of that global mean w.r.t. this rank's local mean is
+    ``n_r / N``; it is multiplied by W because :func:`allreduce_grads` later averages over ranks --
+    the averaged gradient then equals the 1-rank gradient on the concatenated batch."""
+
+    @staticmethod
+    def forward(ctx, mean_local, n_local):
+        buf = torch.stack([mean_local.detach().to(torch.float32).reshape(()) * float(n_local),
+                           torch.tensor(float(n_local), dtype=torch.float32, device=mean_local.device)])
+        _all_reduce_sum(buf)
+        ctx.scale = buf.new_tensor(float(n_local) * dist.get_world_size()) / buf[1]
+        return (buf[0] / buf[1]).to(mean_local.dtype).reshape(mean_local.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.scale.to(g.dtype), None
+
+
+def global_mean(mean_local, n_local):
+    """``mean_local``: a 0-dim loss that is a mean over ``n_local`` rows of this rank's batch ->
+    the mean over every rank's rows, differentiable (identity in single-process runs)."""
+    if not active():
+        return mean_local
+    return _GlobalMean.apply(mean_local, int(n_local))
 
 
 def allreduce_grads(params):
@@ -116,7 +164,7 @@ def allreduce_grads(params):
     if comm is not None:
         comm.all_reduce_(flat)
     else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        _all_reduce_sum(flat)
     flat.div_(dist.get_world_size())
     off = 0
     for p in params:
@@ -140,6 +188,10 @@ class _AllGatherRows(torch.autograd.Function):
             comm.all_gather(out, x.contiguous())
         elif dist.get_backend() == "nccl":     # single-buffer form: no staging copies
             dist.all_gather_into_tensor(out, x.contiguous())
+        elif x.is_cuda:                        # gloo group over device tensors: via the host
+            parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(w)]
+            dist.all_gather(parts, x.detach().cpu().contiguous())
+            out.copy_(torch.stack(parts))
         else:
             dist.all_gather(list(out.unbind(0)), x.contiguous())
         ctx.rank, ctx.world = dist.get_rank(), w

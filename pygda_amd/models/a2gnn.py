@@ -83,7 +83,7 @@ class A2GNN(BaseGDA):
             h0_s = net.first_conv(source_data.x, source_data.edge_index, self.s_pnums)
             feats = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)
             source_logits = net.feat_classifier(feats, source_data.edge_index, sb, 1)        # :181
-            loss = source_ce(source_logits, source_data.y)                                   # :182, fused
+            loss = self._gmean(source_ce(source_logits, source_data.y), source_logits.size(0))   # :182, fused
             source_features = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)   # :192
         h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
         pending = None
@@ -106,8 +106,8 @@ class A2GNN(BaseGDA):
         net = self.a2gnn
         if self.adv:                                                                     # :196-205, fused
             disc = net.domain_discriminator
-            loss = loss + self.weight * grl_disc_ce(source_features, target_features, disc.weight,
-                                                    disc.bias, alpha)
+            dom = grl_disc_ce(source_features, target_features, disc.weight, disc.bias, alpha)
+            loss = loss + self.weight * self._gmean(dom, source_features.size(0) + target_features.size(0))
         else:                                                                            # :206-209
             loss = loss + MMD(source_features, target_features) * self.weight
         if pending is not None:
@@ -122,7 +122,11 @@ class A2GNN(BaseGDA):
 
     def _dp_graph_parts(self):
         """The MMD step cut at its all-gather (pygda_amd/hipgraph.py::GraphedStepDP): everything up
-        to the local row samples, and the global-batch MMD on the gathered rows."""
+        to the local row samples, and the global-batch MMD on the gathered rows.  None for the
+        adversarial objective: it has no row exchange to cut at (its domain loss is a mean over local
+        rows), so that data-parallel step runs eagerly."""
+        if self.adv:
+            return None
         from ..ops import mmd_loss_rows, sample_rows
 
         def part1(src, tgt, idx_s, idx_t, sel_s=None, sel_t=None):

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..nn import AdaGCNBase
-from .base import BaseGDA
+from .base import BaseGDA, _allreduce_grads
 
 
 class AdaGCN(BaseGDA):
@@ -33,7 +33,9 @@ class AdaGCN(BaseGDA):
                           gnn_type=self.gnn_type, mode=self.mode, **kwargs).to(self.device)
 
     def _critic_gap(self, es, et):
-        return torch.mean(self.discriminator(es).reshape(-1)) - torch.mean(self.discriminator(et).reshape(-1))
+        # data-parallel: E D(s), E D(t) are means over every rank's rows (node-count weighted)
+        return self._gmean(torch.mean(self.discriminator(es).reshape(-1)), es.size(0)) \
+            - self._gmean(torch.mean(self.discriminator(et).reshape(-1)), et.size(0))
 
     def forward_model(self, source_data, target_data):
         for _ in range(self.critic_steps):                                            # :169-183
@@ -44,11 +46,12 @@ class AdaGCN(BaseGDA):
             loss = -torch.abs(self._critic_gap(encoded_source, encoded_target)) + self.gp_weight * gp_loss
             self.c_optimizer.zero_grad()
             loss.backward()
+            _allreduce_grads(self.c_optimizer)       # data-parallel: replica critics stay identical
             self.c_optimizer.step()
         encoded_source = self.adagcn(source_data)                                     # :186-196
         encoded_target = self.adagcn(target_data)
         source_logits = self.adagcn.cls_model(encoded_source)
-        cls_loss = self.adagcn.loss_func(source_logits, source_data.y)
+        cls_loss = self._gmean(self.adagcn.loss_func(source_logits, source_data.y), source_logits.size(0))
         dis_loss = torch.abs(self._critic_gap(encoded_source, encoded_target))
         target_logits = self.adagcn.cls_model(encoded_target)
         return cls_loss + dis_loss * self.domain_weight, source_logits, target_logits
@@ -71,6 +74,7 @@ class AdaGCN(BaseGDA):
         # optimiser is rolled back with the encoder's: the step (10 critic updates + encoder update) replays
         self._graph_safe_step = True
         self._graph_extra_optimizers = [self.c_optimizer]
+        self._dp_aux_modules = [self.discriminator]      # broadcast from rank 0 with the encoder
 
         def step(src, tgt, alpha, epoch):
             loss, source_logits, _ = self.forward_model(src, tgt)
@@ -115,4 +119,4 @@ class AdaGCN(BaseGDA):
         gradient = torch.autograd.grad(inputs=inputs, outputs=scores, grad_outputs=torch.ones_like(scores),
                                        create_graph=True, retain_graph=True, only_inputs=True)[0]
         gradient_norm = gradient.view(gradient.shape[0], -1).norm(2, dim=1)
-        return torch.mean((gradient_norm - 1) ** 2)
+        return self._gmean(torch.mean((gradient_norm - 1) ** 2), gradient_norm.size(0))

@@ -36,6 +36,8 @@ class BaseGDA(ABC):
         # None = decide from the environment variable PYGDA_AMD_HIPGRAPH (default on: a step whose
         # capture fails falls back to eager launches with a warning)
         self.use_hip_graph = kwargs.pop("use_hip_graph", None)
+        # tests: route even a whole-graph request (fan-out -1, batch_size >= N) through the sampler
+        self.force_sampler = kwargs.pop("force_sampler", False)
         self.kwargs = kwargs
 
     # -- API of the reference -------------------------------------------------------
@@ -68,7 +70,7 @@ class BaseGDA(ABC):
         else:
             sb = tb = self.batch_size
         full = self.batch_size == 0
-        kw = {} if full else dict(dist, device=self.device)
+        kw = {} if full else dict(dist, device=self.device, full_batch=False if self.force_sampler else None)
         self.source_loader = NeighborLoader(source_data, self.num_neigh, batch_size=sb, **kw)
         self.target_loader = NeighborLoader(target_data, self.num_neigh, batch_size=tb, **kw)
 
@@ -80,6 +82,8 @@ class BaseGDA(ABC):
         if not getattr(self, "_dp_synced", None) is net:      # data-parallel: one set of initial weights
             from ..distributed import broadcast_parameters
             broadcast_parameters(net)
+            for aux in getattr(self, "_dp_aux_modules", ()):      # critics / discriminators with their own optimiser
+                broadcast_parameters(aux)
             self._dp_synced = net
         graphed = self._maybe_graphed_step(optimizer, step_fn, before_step, net)
         if graphed is not None and hasattr(graphed, "launch"):
@@ -158,7 +162,8 @@ class BaseGDA(ABC):
         from ..distributed import direct
         dp = active()
         whole = dp and direct() is not None           # library-owned RCCL communicator: collectives capture
-        if dp and not whole and not hasattr(self, "_dp_graph_parts"):
+        parts = self._dp_graph_parts() if (dp and not whole and hasattr(self, "_dp_graph_parts")) else None
+        if dp and not whole and parts is None:
             return None       # RCCL collectives abort under stream capture on this stack (ROCm 7.0 /
                               # torch 2.10): without a segmented step, data-parallel training stays eager
         if not (getattr(self.source_loader, "full_batch", False) and getattr(self.target_loader, "full_batch", False)):
@@ -196,7 +201,7 @@ class BaseGDA(ABC):
                     loss.backward()
                     _allreduce_grads(optimizer)
                     optimizer.step()
-                part1, part2 = self._dp_graph_parts()
+                part1, part2 = parts
                 graphed = GraphedStepDP(part1, part2, optimizer, src, tgt).capture(eager_step)
             else:
                 graphed = GraphedStep(scalar_step, optimizer, src, tgt,
@@ -223,6 +228,15 @@ class BaseGDA(ABC):
         self._graphed = graphed
         self._graphed_key = id(optimizer)
         return self._graphed
+
+    def _gmean(self, mean_local, n_local):
+        """A loss that is a mean over ``n_local`` rows of this rank's batch -> the mean over every rank's
+        rows (sub-graphs differ in size, so CE means are weighted by node counts).  Identity in
+        single-process runs and for full-batch replicas, whose counts are equal by construction."""
+        from ..distributed import active, global_mean
+        if not active() or getattr(getattr(self, "source_loader", None), "full_batch", False):
+            return mean_local
+        return global_mean(mean_local, n_local)
 
     def _predict_loader(self, loader, forward):
         """predict() of the reference (a2gnn.py:384-411) keeps only the last batch when the

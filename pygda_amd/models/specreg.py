@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from ..metrics import eval_micro_f1
 from ..nn import UDAGCNBase
 from ..utils import logger
-from .base import BaseGDA
+from .base import BaseGDA, _allreduce_grads
 
 
 class SpecReg(BaseGDA):
@@ -48,6 +48,7 @@ class SpecReg(BaseGDA):
             loss_1 = self.critic(_x_src).mean() - self.critic(_x_tgt).mean()
             loss_2 = self.calculate_gradient_penalty(_x_src, _x_tgt)
             (-loss_1 + 10 * loss_2).backward()
+            _allreduce_grads(self.optimizer_critic)      # data-parallel replicas: one critic
             self.optimizer_critic.step()
         loss_grl = self.critic(encoded_source).mean() - self.critic(encoded_target).mean()
         loss = cls_loss + loss_grl * self.gamma_adv
@@ -85,6 +86,9 @@ class SpecReg(BaseGDA):
                                     nn.Linear(self.hid_dim, self.hid_dim), nn.ReLU(),
                                     nn.Linear(self.hid_dim, 1)).to(self.device)          # :281-287
         self.optimizer_critic = torch.optim.Adam(self.critic.parameters(), self.lr)
+        from ..distributed import broadcast_parameters
+        broadcast_parameters(self.udagcn)                # data-parallel replicas start from rank 0's weights
+        broadcast_parameters(self.critic)
         start_time = time.time()
         for epoch in range(self.epoch):
             epoch_loss, logits, labels = 0.0, [], []
@@ -101,6 +105,7 @@ class SpecReg(BaseGDA):
                 epoch_loss += loss.item()
                 optimizer.zero_grad()
                 loss.backward()
+                _allreduce_grads(optimizer)
                 optimizer.step()
                 lg, lb = self.predict(src, source=True)
                 logits.append(lg)

@@ -30,25 +30,36 @@ class UDAGCN(BaseGDA):
                           adv_dim=self.adv_dim, **kwargs).to(self.device)
 
     def _cache_key(self, data, name):
-        n_id = getattr(data, "n_id", None)          # sampled mini-batch: one cache entry per batch
-        return name if n_id is None else f"{name}:{int(n_id[0])}:{n_id.numel()}:{data.edge_index.size(1)}"
+        """Full batch: the reference's keys.  Sampled mini-batch: ONE transient key per domain whose
+        entries are dropped from every conv layer before the batch is encoded -- the graphs of a batch
+        live for that batch only (no growth with the number of steps, no host sync for a key, no stale
+        hit when two batches happen to agree in their first seed and sizes)."""
+        if getattr(data, "n_id", None) is None:
+            return name
+        key = name + ":minibatch"
+        for enc in (self.udagcn.encoder, getattr(self.udagcn, "ppmi_encoder", None)):
+            for conv in (() if enc is None else enc.conv_layers):
+                conv.cache_dict.pop(key, None)
+        return key
 
     def forward_model(self, source_data, target_data, alpha, epoch):
         net = self.udagcn
         encoded_source = net.encode(source_data, self._cache_key(source_data, "source"))
         encoded_target = net.encode(target_data, self._cache_key(target_data, "target"))
         source_logits = net.cls_model(encoded_source)
-        loss = net.loss_func(source_logits, source_data.y)                                   # :172
+        gm = self._gmean
+        ns, nt = encoded_source.size(0), encoded_target.size(0)
+        loss = gm(net.loss_func(source_logits, source_data.y), ns)                           # :172
         dev = encoded_source.device
         source_domain_preds = net.domain_model(GradReverse.apply(encoded_source, alpha))
         target_domain_preds = net.domain_model(GradReverse.apply(encoded_target, alpha))
-        loss = loss + net.loss_func(source_domain_preds,
-                                    torch.zeros(source_domain_preds.size(0), dtype=torch.long, device=dev)) \
-                    + net.loss_func(target_domain_preds,
-                                    torch.ones(target_domain_preds.size(0), dtype=torch.long, device=dev))
+        loss = loss + gm(net.loss_func(source_domain_preds,
+                                       torch.zeros(source_domain_preds.size(0), dtype=torch.long, device=dev)), ns) \
+                    + gm(net.loss_func(target_domain_preds,
+                                       torch.ones(target_domain_preds.size(0), dtype=torch.long, device=dev)), nt)
         target_logits = net.cls_model(encoded_target)
         target_probs = torch.clamp(F.softmax(target_logits, dim=-1), min=1e-9, max=1.0)
-        loss_entropy = torch.mean(torch.sum(-target_probs * torch.log(target_probs), dim=-1))  # :193-197
+        loss_entropy = gm(torch.mean(torch.sum(-target_probs * torch.log(target_probs), dim=-1)), nt)  # :193-197
         return loss + loss_entropy * (epoch / self.epoch * 0.01), source_logits, target_logits
 
     def _prepare(self, source_data, target_data):

@@ -4,7 +4,7 @@ one aggregation, bias added afterwards."""
 import torch
 from torch import nn
 
-from ..graph import CSRGraph, build_csr
+from ..graph import CSRGraph, as_graph, build_csr
 from ..ops import propagate
 from .linear import glorot, zeros
 
@@ -39,7 +39,8 @@ class CachedGCNConv(nn.Module):
             return edge_index
         g = self.cache_dict.get(cache_name)
         if g is None:                     # :132-136 -- never invalidated, exactly like the reference
-            g = build_csr(edge_index, x.size(0), edge_weight, self.improved, True, True, "row")
+            # identity-keyed LRU underneath: the L layers of an encoder share one ingestion per edge tensor
+            g = as_graph(edge_index, x.size(0), edge_weight, self.improved, True, True, "row")
             self.cache_dict[cache_name] = g
         return g
 

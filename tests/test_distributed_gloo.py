@@ -112,3 +112,24 @@ def test_two_rank_gloo():
         p.join(timeout=60)
     for rank, msg in results:
         assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+@pytest.mark.parametrize("adv", [False, True])
+def test_two_rank_a2gnn_step_equals_concatenated_batch(adv):
+    """SURVEY 8(e)'s equality test on the trainer itself: two ranks run ``A2GNN.forward_model`` on their
+    own sampled mini-batches (sub-graphs of different sizes), exchange the MMD sample rows, weight their
+    CE means by node counts and average their gradients; the result equals the gradient of ONE process
+    on the concatenated batch.  CPU tensors, the oracle injected under the operator layer
+    (tests/dp_equality.py) -- the same test runs on the HIP kernels in tests/test_gpu_configs.py."""
+    from tests import dp_equality as E
+    results = E.run_ranks(2, "cpu", adv, oracle=True)
+    for k, v in results[0]["state"].items():                       # replicas started from rank 0's weights
+        assert torch.equal(v, results[1]["state"][k]), k
+    for k, v in results[0]["grads"].items():                       # one averaged gradient on every rank
+        assert torch.equal(v, results[1]["grads"][k]), k
+    ref_loss, ref_grads, (ns, nt) = E.concatenated_reference(results, "cpu", adv, oracle=True)
+    assert ns[0] != ns[1] or nt[0] != nt[1]                        # the count weighting is exercised
+    assert abs(results[0]["loss"] - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    assert abs(results[1]["loss"] - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    for k, g in ref_grads.items():
+        assert torch.allclose(results[0]["grads"][k], g, rtol=1e-4, atol=1e-6), (k, (results[0]["grads"][k] - g).abs().max())
