@@ -146,6 +146,40 @@ int gda_spmm_csr_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const f
                            gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
+ * K-step aggregation in ONE launch for graphs whose feature columns fit a CU's LDS
+ * (n_rows <= gda_kstep_max_rows() = 16380; the citation-graph regime), csrc/gda_kstep.hip.
+ *
+ * Replaces the same prop_nums loop (pygda/nn/prop_gcn_conv.py:208-210) as gda_spmm_csr_kstep_f32,
+ * with the same results bit for bit (per-row sums in CSR order, separately rounded multiply and
+ * add): A_hat^K x is independent per feature column, so a workgroup keeps one column of all rows in
+ * LDS across the K steps and the graph is compiled once into a per-lane register program.
+ *
+ * gda_kstep_plan_host compiles a CSR given as HOST arrays into `plan_host` (caller-owned host
+ * memory of gda_kstep_plan_bytes(12) bytes; the first gda_kstep_plan_bytes(S) are meaningful) and
+ * returns S (6, 8, 10 or 12 slots per thread), 0 when the graph is not eligible (too many rows /
+ * a row longer than 4*S entries / more slots than one workgroup holds) -- callers then use
+ * gda_spmm_csr_kstep_f32 --, or a negative status.  The plan is copied to the device by the caller.
+ *
+ * gda_kstep_lds_f32: x [n_rows, ldx] -> y [n_rows, ldy] row-major, bias ([d] or NULL) added once
+ * at the end; scratchT holds 2 * d * round_up(n_rows, 4) floats (the column-major copies).
+ * gda_kstep_lds_colmajor_f32: the kernel alone on column-major operands xT, yT [d, ld] (ld >=
+ * round_up(n_rows, 4), 16-byte aligned columns), K >= 0.
+ * gda_transpose_f32: out [cols, ldo] = in [rows, ldi]^T.
+ * ---------------------------------------------------------------------------- */
+int gda_kstep_max_rows(void);
+size_t gda_kstep_plan_bytes(int slots);
+int gda_kstep_plan_host(const int32_t* rowptr_host, const int32_t* colidx_host, const float* val_host,
+                        int64_t n_rows, void* plan_host, size_t plan_bytes);
+int gda_kstep_lds_f32(const void* plan, int slots, int64_t n_rows, int64_t d, int K,
+                      const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias,
+                      float* scratchT, gda_stream_t stream);
+int gda_kstep_lds_colmajor_f32(const void* plan, int slots, int64_t n_rows, int64_t d, int K,
+                               const float* xT, int64_t ldx, float* yT, int64_t ldy,
+                               const float* bias, gda_stream_t stream);
+int gda_transpose_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols,
+                      gda_stream_t stream);
+
+/* ------------------------------------------------------------------------------
  * GAT aggregation (single head): edge-softmax attention + weighted neighbour sum, fused.
  *
  * Replaces PyG GATConv(heads=1, concat=False) as GNNBase(gnn='gat') uses it

@@ -3,11 +3,14 @@
 // Replaces the torch elementwise chain of pygda/utils/mmd.py:4-159 (guassian_kernel,
 // get_MMD, MMD), which materialises an [m, m, d] difference tensor per resample
 // (m = 2000, d = 128: 2 GB, several live at once and kept for backward).  Here the
-// pairwise squared distances are produced tile by tile in LDS in the reference's direct
-// difference form (mmd.py:43-46: sum_k (total[j,k]-total[i,k])^2 -- no |a|^2+|b|^2-2ab
-// cancellation) -- see k_pairdist for how the Gram form on the fp32 matrix cores keeps that
-// property where it matters --, only the [m, m] distance matrix is kept (16 MB per resample,
-// L2/MALL resident) and the backward pass recomputes the kernel weights from it.
+// pairwise squared distances (mmd.py:43-46: sum_k (total[j,k]-total[i,k])^2) are produced tile by
+// tile on the fp32 matrix cores in Gram form |a'|^2 + |b'|^2 - 2 a'.b' over PIVOT-SHIFTED rows
+// a' = a - p, p = the first sampled row of the resample: the statistic only depends on differences,
+// (a - p) - (b - p) = a - b, and after the shift the operands are of the size of the spread of the
+// batch, not of its common offset -- so the Gram form does not cancel when the domains collapse onto a
+// far-away point (features c + eps * noise, c >> eps), the regime the loss drives training into.  The
+// result is clamped at 0 (the reference's sum of squares cannot be negative).  Only the [m, m] matrix
+// is kept (16 MB per resample, L2/MALL resident) and the backward pass reuses it.
 //
 //   k_pairdist   tile 64x64 of L2 = |t_i|^2 + |t_j|^2 - 2 t_i.t_j on v_mfma_f32_32x32x2_f32 (norms as the
 //                same k-ordered fma chain, from the staged tiles), plus
@@ -61,6 +64,12 @@ __device__ __forceinline__ float4 load4(const float* __restrict__ p, int64_t k, 
     return v;
 }
 
+// a - p where the row exists (missing rows stay all-zero)
+__device__ __forceinline__ float4 sub4(float4 a, float4 p, bool live) {
+    if (!live) return a;
+    return make_float4(a.x - p.x, a.y - p.y, a.z - p.z, a.w - p.w);
+}
+
 __device__ __forceinline__ int64_t gda_cdiv_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 __device__ __forceinline__ double block_sum(double v, double* sh) {
@@ -78,7 +87,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 // ---------------------------------------------------------------- forward --
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-// L2[i,j] = (|t_i|^2 + |t_j|^2) - 2 t_i.t_j on the fp32 matrix cores: 64x64 tile per workgroup,
+// L2[i,j] = (|t_i|^2 + |t_j|^2) - 2 t_i.t_j over the pivot-shifted rows on the fp32 matrix cores: 64x64 tile per workgroup,
 // one 32x32 sub-tile per wave, feature chunks of 32 staged k-major in LDS so that both MFMA
 // operands are conflict-free ds_read_b32 (A: lane l -> row l&31, k = l>>5; B likewise).  The
 // fp32 MFMA is an exact k-ordered fma chain, so the Gram form costs ~1e-7 relative on L2 (far
@@ -98,6 +107,7 @@ k_pairdist(Rows R, int64_t d, int64_t m, float* __restrict__ l2, double* __restr
 
     // staging: this thread moves rows (tid/8) and (tid/8 + 32) of both tiles, features kq*4..+3
     const int lr = tid / 8, kq = (tid % 8) * 4;
+    const float* pivot = row_ptr(R, t, 0);               // common shift of every row of this resample
     const float* pa[2]; const float* pb[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -121,10 +131,11 @@ k_pairdist(Rows R, int64_t d, int64_t m, float* __restrict__ l2, double* __restr
     // other's staging; a double-buffered variant (35 KB, four workgroups) measured 8 % slower
     for (int64_t k0 = 0; k0 < d; k0 += DK) {
         float4 va[2], vb[2];
+        const float4 pv = load4(pivot, k0 + kq, d, R.vec4);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            va[q] = load4(pa[q], k0 + kq, d, R.vec4);
-            vb[q] = load4(pb[q], k0 + kq, d, R.vec4);
+            va[q] = sub4(load4(pa[q], k0 + kq, d, R.vec4), pv, pa[q] != nullptr);
+            vb[q] = sub4(load4(pb[q], k0 + kq, d, R.vec4), pv, pb[q] != nullptr);
         }
         __syncthreads();
 #pragma unroll
@@ -155,7 +166,8 @@ k_pairdist(Rows R, int64_t d, int64_t m, float* __restrict__ l2, double* __restr
         const int li = wi + (r & 3) + 8 * (r >> 2) + 4 * ka;              // C/D layout of the 32x32 MFMA
         const int64_t i = i0 + li;
         if (i < m && j < m) {
-            const float v = (nA[li] + nj) - 2.f * acc[r];
+            float v = (nA[li] + nj) - 2.f * acc[r];
+            v = v < 0.f ? 0.f : v;                                     // a sum of squares; NaN stays NaN
             out[i * m + j] = v;
             local += v;
         }
@@ -308,6 +320,10 @@ k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* _
     // staging roles: G chunk = 32 rows x 16 float4 (2 per thread), T chunk = 32 rows x 32 float4 (4 per thread)
     const int g_c4 = (tid % 16) * 4, g_r = tid / 16;       // rows g_r and g_r + 16
     const int t_c4 = (tid % 32) * 4, t_r = tid / 32;       // rows t_r, +8, +16, +24
+    // the same pivot shift as the forward: sum_j g_ij (t_i - t_j) is unchanged by it, and the two
+    // products it is computed from no longer carry the batch's common offset
+    const float* pivot = row_ptr(R, t, 0);
+    const float4 pv = load4(pivot, c0 + t_c4, d, R.vec4);
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -337,7 +353,7 @@ k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* _
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int64_t j = j0 + t_r + 8 * q;
-            tq[q] = load4(j < m ? row_ptr(R, t, j) : nullptr, c0 + t_c4, d, R.vec4);
+            tq[q] = sub4(load4(j < m ? row_ptr(R, t, j) : nullptr, c0 + t_c4, d, R.vec4), pv, j < m);
         }
     };
     auto stash = [&](int b) {
@@ -392,7 +408,7 @@ k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* _
             const int il = wr + (r & 3) + 8 * (r >> 2) + 4 * ka;     // C/D layout of the 32x32 MFMA
             const int64_t i = i0 + il;
             if (i < m && c < d) {
-                const float ti = row_ptr(R, t, i)[c];
+                const float ti = row_ptr(R, t, i)[c] - pivot[c];
                 const float a = half == 0 ? acc0[r] : acc1[r];
                 out[i * d + c] = coef * fmaf(rowsum[il], ti, -a);
             }

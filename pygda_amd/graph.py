@@ -69,7 +69,8 @@ class CSRGraph:
     ``t_rowptr/t_colidx/t_val``: rows = source nodes (the transpose, backward)."""
 
     __slots__ = ("num_nodes", "nnz_cap", "rowptr", "colidx", "val", "t_rowptr", "t_colidx",
-                 "t_val", "_nnz", "device", "_split", "_t_split", "t_to_fwd", "static", "_squared", "transient")
+                 "t_val", "_nnz", "device", "_split", "_t_split", "t_to_fwd", "static", "_squared", "transient",
+                 "_kplan", "_t_kplan")
 
     def __init__(self, num_nodes, nnz_cap, rowptr, colidx, val, t_rowptr, t_colidx, t_val):
         self.num_nodes, self.nnz_cap = num_nodes, nnz_cap
@@ -82,6 +83,7 @@ class CSRGraph:
         self.static = False       # graph of a full-batch loader: lives for the whole fit()
         self.transient = False    # graph of one sampled mini-batch: nothing about it is worth a host sync
         self._squared = None      # A*A (and its transpose) of a static graph, or False if too dense
+        self._kplan = self._t_kplan = None     # register programs of the LDS-resident K-step kernel, or False
 
     def squared(self):
         """``A*A`` as a :class:`CSRGraph` (forward CSR from the forward CSR, transposed CSR from the
@@ -90,6 +92,19 @@ class CSRGraph:
         if self._squared is None:
             self._squared = _square(self) or False
         return self._squared or None
+
+    def kstep_plan(self, transposed=False):
+        """``(plan, slots)`` for the one-launch LDS-resident K-step kernel (csrc/gda_kstep.hip), compiled on
+        the host from this CSR on first use (one device-to-host copy of the graph: static graphs only), or
+        None when the graph is not eligible (more than 16,380 nodes, a row beyond 48 entries, ...)."""
+        hit = self._t_kplan if transposed else self._kplan
+        if hit is None:
+            hit = _kstep_plan(self, transposed) or False
+            if transposed:
+                self._t_kplan = hit
+            else:
+                self._kplan = hit
+        return hit or None
 
     def split(self, transposed=False):
         """Long-row layout of the forward (or transposed) CSR, built on first use."""
@@ -124,6 +139,31 @@ class CSRGraph:
                                     _lib.ptr(src), _lib.ptr(dst), _lib.stream()), "gda_csr_to_coo")
         return torch.stack([src[:nnz], dst[:nnz]]), self.val[:nnz]
 
+
+def _kstep_plan(g, transposed):
+    import ctypes
+    L = _lib.lib()
+    n = g.num_nodes
+    if n == 0 or n > L.gda_kstep_max_rows():
+        return None
+    rp, ci, va = (g.t_rowptr, g.t_colidx, g.t_val) if transposed else (g.rowptr, g.colidx, g.val)
+    nnz = g.nnz
+    rp_h = rp.cpu().numpy()
+    ci_h = ci[:nnz].cpu().numpy()
+    va_h = va[:nnz].cpu().numpy()
+    cap = L.gda_kstep_plan_bytes(12)
+    buf = torch.empty(cap, dtype=torch.uint8)
+    slots = L.gda_kstep_plan_host(rp_h.ctypes.data, ci_h.ctypes.data if nnz else None,
+                                  va_h.ctypes.data if nnz else None, n, buf.data_ptr(), cap)
+    if slots < 0:
+        _lib.check(slots, "gda_kstep_plan_host")
+    if slots == 0:
+        return None
+    return buf[:L.gda_kstep_plan_bytes(slots)].to(g.device), int(slots)
+
+
+KSTEP_LDS = os.environ.get("PYGDA_AMD_KSTEP_LDS", "1") == "1"
+KSTEP_LDS_MIN_K = int(os.environ.get("PYGDA_AMD_KSTEP_LDS_MIN_K", "3"))
 
 SQUARE_MAX_FILL = float(os.environ.get("PYGDA_AMD_SQUARE_MAX_FILL", "6"))
 SQUARE = os.environ.get("PYGDA_AMD_SQUARE", "0") == "1"      # opt-in: see ops.spmm_kstep

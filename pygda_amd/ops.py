@@ -117,6 +117,26 @@ def _launch_kstep(graph, x, K, bias, transposed, y, tmp, counts_as=None):
                                             _lib.stream()), "gda_spmm_csr_split_f32")
 
 
+def _launch_kstep_lds(graph, plan, slots, x, K, bias, transposed, y):
+    """All K steps in one launch on the LDS-resident kernel (csrc/gda_kstep.hip): same sums, bit for bit."""
+    n, d = x.shape
+    L = _lib.lib()
+    if aggregation_log is not None:
+        aggregation_log.append((graph, int(K)))
+    if profiler.enabled:
+        global aggregated_edges
+        aggregated_edges += int(K) * graph.nnz
+        ctx = profiler.region(f"kstep_lds_f32[d={d}]", 3, K * (graph.nnz * 8 + (n + 1) * 4 + 2 * n * d * 4),
+                              K * 2 * graph.nnz * d)
+    else:
+        ctx = profiler.region("", 0)
+    n_pad = (n + 3) // 4 * 4
+    ws = _lib.workspace(2 * d * n_pad * 4, x.device, "kstep")
+    with ctx:
+        _lib.check(L.gda_kstep_lds_f32(_lib.ptr(plan), slots, n, d, int(K), _lib.ptr(x), d, _lib.ptr(y), d,
+                                       _lib.ptr(bias), _lib.ptr(ws), _lib.stream()), "gda_kstep_lds_f32")
+
+
 def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
     """``A_hat^K @ x (+ bias)`` without autograd (ping-pong buffers), K launches.
 
@@ -124,13 +144,18 @@ def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
     the cached ``A_hat * A_hat`` plus K % 2 of ``A_hat`` -- at citation-graph sizes a dependent launch
     costs its latency (5-7 us), not its edges.  Same product up to fp32 summation order; measured
     +4 % epochs/s at cfg-A, at the price of the bit-exact edge-order sums, so it is off by default."""
-    from .graph import SQUARE
+    from .graph import KSTEP_LDS, KSTEP_LDS_MIN_K, SQUARE
     x = _f32c(x, "x")
     if x.dim() != 2 or x.size(0) != graph.num_nodes:
         raise ValueError(f"x must be [num_nodes={graph.num_nodes}, d], got {tuple(x.shape)}")
     y = torch.empty_like(x)
     b = None if bias is None else _f32c(bias, "bias")
     sq = graph.squared() if (SQUARE and K >= 2 and graph.static) else None
+    if sq is None and KSTEP_LDS and K >= KSTEP_LDS_MIN_K and graph.static:
+        hit = graph.kstep_plan(transposed)       # static full-batch graphs at citation size: one launch
+        if hit is not None:
+            _launch_kstep_lds(graph, hit[0], hit[1], x, K, b, transposed, y)
+            return y
     if sq is None:
         _launch_kstep(graph, x, K, b, transposed, y, torch.empty_like(x) if K > 1 else None)
         return y

@@ -88,6 +88,36 @@ def fx_mmd(ref):
          gsrc=np_(s.grad), gtgt=np_(t.grad))
 
 
+def fx_mmd_offset(ref):
+    """True oracle (mmd.py imported directly) on COLLAPSED domains: features c + eps * noise with c >> eps
+    (the regime a working domain loss drives training into), a small domain gap, duplicated rows.
+    The reference takes differences first (exact in fp32 for nearby values), so its distances carry no
+    cancellation; a Gram-form kernel without a common shift would."""
+    cases = {"c10_e2_d128": (10.0, 1e-2, 128, 128), "c100_e3_d128": (100.0, 1e-3, 128, 128),
+             "c100_e2_d645": (100.0, 1e-2, 645, 96), "c10_e3_d64": (10.0, 1e-3, 64, 160)}
+    arrs = {}
+    for i, (tag, (c, eps, d, n)) in enumerate(cases.items()):
+        g = torch.Generator().manual_seed(300 + i)
+        s = c + eps * torch.randn(n, d, generator=g)
+        t = c + eps * (torch.randn(n, d, generator=g) * 1.2 + 0.3)
+        s[5] = s[2]; t[7] = t[0]; t[9] = s[11]                     # duplicates inside and across domains
+        s.requires_grad_(); t.requires_grad_()
+        loss = ref.get_MMD(s, t)
+        loss.backward()
+        arrs.update({f"{tag}/src": np_(s), f"{tag}/tgt": np_(t), f"{tag}/loss": np_(loss),
+                     f"{tag}/gsrc": np_(s.grad), f"{tag}/gtgt": np_(t.grad)})
+    # the sampled entry point on a collapsed batch (CPU randint stream replayed by the seed)
+    g = torch.Generator().manual_seed(310)
+    s = (50.0 + 5e-3 * torch.randn(400, 32, generator=g)).requires_grad_()
+    t = (50.0 + 5e-3 * (torch.randn(300, 32, generator=g) + 0.2)).requires_grad_()
+    torch.manual_seed(311)
+    loss = ref.MMD(s, t, sampling_num=200, times=3)
+    loss.backward()
+    arrs.update({"sampled/src": np_(s), "sampled/tgt": np_(t), "sampled/loss": np_(loss), "sampled/seed": np.int64(311),
+                 "sampled/gsrc": np_(s.grad), "sampled/gtgt": np_(t.grad)})
+    save("mmd_offset", **arrs)
+
+
 def fx_grl_attention(ref):
     g = torch.Generator().manual_seed(11)
     x = torch.randn(17, 6, generator=g).requires_grad_()
@@ -395,7 +425,7 @@ def fx_gnn_dane(ref):
         gmod.logger = orig
 
 
-FIXTURES = {"mmd": fx_mmd, "grl_attention": fx_grl_attention, "gcn_norm": fx_gcn_norm,
+FIXTURES = {"mmd": fx_mmd, "mmd_offset": fx_mmd_offset, "grl_attention": fx_grl_attention, "gcn_norm": fx_gcn_norm,
             "prop_gcn_conv": fx_prop_gcn_conv, "cached_gcn_conv": fx_cached_gcn_conv,
             "a2gnn": fx_a2gnn, "grade": fx_grade, "udagcn": fx_udagcn, "adagcn": fx_adagcn,
             "gnn_dane": fx_gnn_dane}

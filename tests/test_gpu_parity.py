@@ -192,6 +192,47 @@ def test_get_mmd_golden():
         pygda_amd.utils.get_MMD(s[:10], t[:20])
 
 
+@pytest.mark.parametrize("tag", ["c10_e2_d128", "c100_e3_d128", "c100_e2_d645", "c10_e3_d64"])
+def test_mmd_collapsed_domains_golden(tag):
+    """Collapsed domains -- features c + eps * noise with c / eps up to 1e5, a small domain gap, duplicated
+    rows -- against the reference's own mmd.py (tests/golden/make_golden.py::fx_mmd_offset).  The reference
+    takes differences first; the kernels run the Gram form on pivot-shifted rows, which keeps the loss and the
+    gradients inside the usual tolerances here (an unshifted Gram form loses every digit at c = 100, eps = 1e-3:
+    |a|^2 ~ 1e6 per feature against squared distances of ~1e-4)."""
+    g = sub(load_golden("mmd_offset"), tag + "/")
+    s, t = T(g["src"], DEV).requires_grad_(), T(g["tgt"], DEV).requires_grad_()
+    loss = pygda_amd.utils.get_MMD(s, t)
+    loss.backward()
+    close(loss, g["loss"], rtol=REL, atol=1e-6)
+    close(s.grad, g["gsrc"], rtol=1e-3, atol=1e-4 * np.abs(g["gsrc"]).max())
+    close(t.grad, g["gtgt"], rtol=1e-3, atol=1e-4 * np.abs(g["gtgt"]).max())
+    # and against the oracle on a fresh draw of the same kind at the A2GNN sample size
+    gen = torch.Generator().manual_seed(77)
+    a = 100.0 + 1e-3 * torch.randn(1000, 128, generator=gen)
+    b = 100.0 + 1e-3 * (torch.randn(1000, 128, generator=gen) + 0.25)
+    a[3] = a[1]; b[4] = a[8]
+    ao, bo = a.clone().requires_grad_(), b.clone().requires_grad_()
+    want = O.get_MMD(ao, bo, chunk_rows=200)
+    want.backward()
+    ad, bd = a.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    got = pygda_amd.utils.get_MMD(ad, bd)
+    got.backward()
+    close(got, want, rtol=REL, atol=1e-6)
+    close(ad.grad, ao.grad, rtol=1e-3, atol=1e-4 * float(ao.grad.abs().max()))
+    close(bd.grad, bo.grad, rtol=1e-3, atol=1e-4 * float(bo.grad.abs().max()))
+
+
+def test_mmd_collapsed_sampled_golden():
+    g = sub(load_golden("mmd_offset"), "sampled/")
+    s, t = T(g["src"], DEV).requires_grad_(), T(g["tgt"], DEV).requires_grad_()
+    torch.manual_seed(int(g["seed"]))
+    loss = pygda_amd.utils.MMD(s, t, sampling_num=200, times=3)
+    loss.backward()
+    close(loss, g["loss"], rtol=REL, atol=1e-6)
+    close(s.grad, g["gsrc"], rtol=1e-3, atol=1e-4 * np.abs(g["gsrc"]).max())
+    close(t.grad, g["gtgt"], rtol=1e-3, atol=1e-4 * np.abs(g["gtgt"]).max())
+
+
 def test_mmd_properties():
     gen = torch.Generator(device=DEV).manual_seed(5)
     a = torch.randn(512, 645, generator=gen, device=DEV)         # GRADE width hid*L + C, not a multiple of 4
@@ -1416,3 +1457,105 @@ def test_grade_adagcn_fit_predict_golden(monkeypatch, which, graphed):
     close(logits, g[f"{which}/tgt_logits"], rtol=0, atol=LOGIT_ATOL)
     exact(labels, g[f"{which}/tgt_labels"])
     exact(logits.argmax(1), g[f"{which}/tgt_logits"].argmax(1))
+
+
+# ------------------------------------------- one-launch LDS-resident K-step aggregation --
+@pytest.mark.parametrize("name,d", [("g7", 3), ("g64", 8), ("g300d", 128), ("g300u", 5), ("g300u", 260)])
+@pytest.mark.parametrize("K", [3, 10, 11])
+def test_kstep_lds_bit_exact_vs_oracle(name, d, K):
+    """csrc/gda_kstep.hip (static full-batch graphs, K >= 3): every feature column stays in LDS for the K
+    steps and the graph runs as a per-lane register program -- the result is the K-launch chain's and the CPU
+    oracle's, bit for bit, forward and transposed, with and without the bias."""
+    from pygda_amd import graph as G_
+    g = sub(load_golden("gcn_norm"), name + "/")
+    ei, n = T(g["edge_index"]), int(g["n"])
+    gen = torch.Generator().manual_seed(d * 17 + K)
+    x = torch.randn(n, d, generator=gen)
+    bias = torch.randn(d, generator=gen)
+    nei, nw = O.gcn_norm(ei, None, n)
+    want = x
+    for _ in range(K):
+        want = O.propagate(nei, nw, want)
+    G = build_csr(ei.to(DEV), n)
+    G.static = True
+    assert G_.KSTEP_LDS and G.kstep_plan(False) is not None and G.kstep_plan(True) is not None
+    exact(ops.spmm_kstep(G, x.to(DEV), K, bias.to(DEV)), want + bias)
+    exact(ops.spmm_kstep(G, x.to(DEV), K, None), want)
+    gy = torch.randn(n, d, generator=gen)
+    xg = x.clone().requires_grad_()
+    out = xg
+    for _ in range(K):
+        out = O.propagate(nei, nw, out)
+    out.backward(gy)
+    exact(ops.spmm_kstep(G, gy.to(DEV), K, None, transposed=True), xg.grad)
+    # the chain of K launches on a non-static copy of the same graph gives the same bits
+    G2 = build_csr(ei.to(DEV), n)
+    exact(ops.spmm_kstep(G2, x.to(DEV), K, bias.to(DEV)), want + bias)
+
+
+def test_kstep_lds_ragged_rows_and_fallback():
+    """Empty rows (no self loops), rows spanning several 4-entry slots, non-finite features staying in their
+    rows; a row beyond 48 entries or more than 16,380 nodes is not eligible and takes the launch chain."""
+    gen = torch.Generator().manual_seed(21)
+    n, d, K = 2000, 64, 5
+    ei = torch.randint(0, n, (2, 9000), generator=gen)
+    ei = ei[:, (ei[1] % 7 != 3)]                               # every 7th node receives nothing: empty rows
+    extra = torch.stack([torch.randint(0, n, (40,), generator=gen), torch.full((40,), 11)])   # a 40+-entry row
+    ei = torch.cat([ei, extra], dim=1)
+    w = torch.rand(ei.size(1), generator=gen) + 0.1
+    G = build_csr(ei.to(DEV), n, w.to(DEV), add_self_loops=False, normalize=False)
+    G.static = True
+    assert G.kstep_plan(False) is not None
+    x = torch.randn(n, d, generator=gen)
+    want = x
+    for _ in range(K):
+        want = O.propagate(ei, w, want)
+    got = ops.spmm_kstep(G, x.to(DEV), K)
+    exact(got, want)
+    assert bool((got.cpu()[torch.arange(n) % 7 == 3] == 0).all())
+    xn = x.clone(); xn[5, 0] = float("inf"); xn[9, 1] = float("nan")
+    wantn = O.propagate(ei, w, O.propagate(ei, w, O.propagate(ei, w, xn)))
+    gotn = ops.spmm_kstep(G, xn.to(DEV), 3).cpu()
+    assert torch.equal(torch.isnan(gotn), torch.isnan(wantn)) and torch.equal(torch.isinf(gotn), torch.isinf(wantn))
+    fin = torch.isfinite(wantn)
+    exact(gotn[fin], wantn[fin])
+    # not eligible: a hub row
+    hub = torch.cat([ei, torch.stack([torch.randint(0, n, (60,), generator=gen), torch.full((60,), 13)])], dim=1)
+    Gh = build_csr(hub.to(DEV), n, None, add_self_loops=False, normalize=False)
+    Gh.static = True
+    assert Gh.kstep_plan(False) is None
+    wh = torch.ones(hub.size(1))
+    wanth = O.propagate(hub, wh, O.propagate(hub, wh, O.propagate(hub, wh, x)))
+    exact(ops.spmm_kstep(Gh, x.to(DEV), 3), wanth)
+    # not eligible: too many rows for one CU's LDS
+    nb = 20000
+    eb = torch.randint(0, nb, (2, 60000), generator=gen)
+    Gb = build_csr(eb.to(DEV), nb)
+    Gb.static = True
+    assert Gb.kstep_plan(False) is None
+    xb = torch.randn(nb, 8, generator=gen)
+    nei, nw = O.gcn_norm(eb, None, nb)
+    exact(ops.spmm_kstep(Gb, xb.to(DEV), 3), O.propagate(nei, nw, O.propagate(nei, nw, O.propagate(nei, nw, xb))))
+
+
+def test_kstep_lds_cfg_a_target_graph_through_the_conv():
+    """PropGCNConv at the cfg-A target shapes (N=5,484, nnz=21,718, d=128, prop_nums=10) on the static graph
+    of a full-batch loader: forward and input gradient equal the launch-chain path bit for bit."""
+    from bench import make_cfg_a
+    from pygda_amd import graph as G_
+    _, tgt = make_cfg_a(seed=200)
+    ei = tgt.edge_index.to(DEV)
+    gen = torch.Generator().manual_seed(4)
+    h = torch.randn(tgt.num_nodes, 128, generator=gen).to(DEV)
+    gy = torch.randn(tgt.num_nodes, 128, generator=gen).to(DEV)
+    G = build_csr(ei, tgt.num_nodes)
+    Gs = build_csr(ei, tgt.num_nodes)
+    Gs.static = True
+    assert Gs.kstep_plan(False) is not None and Gs.kstep_plan(True) is not None
+    bias = torch.randn(128, generator=gen).to(DEV)
+    exact(ops.spmm_kstep(Gs, h, 10, bias), ops.spmm_kstep(G, h, 10, bias))
+    exact(ops.spmm_kstep(Gs, gy, 10, None, transposed=True), ops.spmm_kstep(G, gy, 10, None, transposed=True))
+    ha, hb = h.clone().requires_grad_(), h.clone().requires_grad_()
+    ops.propagate(ha, Gs, 10, bias).backward(gy)
+    ops.propagate(hb, G, 10, bias).backward(gy)
+    exact(ha.grad, hb.grad)

@@ -40,6 +40,25 @@ def test_get_mmd_and_kernel():
     eq(loss, g["loss"]); eq(s.grad, g["gsrc"]); eq(t.grad, g["gtgt"])
 
 
+@pytest.mark.parametrize("tag", ["c10_e2_d128", "c100_e3_d128", "c100_e2_d645", "c10_e3_d64"])
+def test_mmd_collapsed_domains_true_oracle(tag):
+    """Features c + eps * noise (c >> eps), duplicated rows: the regime where a Gram-form kernel cancels."""
+    g = sub(load_golden("mmd_offset"), tag + "/")
+    s, t = T(g["src"]).requires_grad_(), T(g["tgt"]).requires_grad_()
+    loss = O.get_MMD(s, t)
+    loss.backward()
+    eq(loss, g["loss"]); eq(s.grad, g["gsrc"]); eq(t.grad, g["gtgt"])
+
+
+def test_mmd_collapsed_sampled_true_oracle():
+    g = sub(load_golden("mmd_offset"), "sampled/")
+    s, t = T(g["src"]).requires_grad_(), T(g["tgt"]).requires_grad_()
+    torch.manual_seed(int(g["seed"]))
+    loss = O.MMD(s, t, sampling_num=200, times=3)
+    loss.backward()
+    eq(loss, g["loss"]); eq(s.grad, g["gsrc"]); eq(t.grad, g["gtgt"])
+
+
 def test_grl_attention():
     g = load_golden("grl_attention")
     x = T(g["x"]).requires_grad_()
