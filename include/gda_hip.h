@@ -160,10 +160,12 @@ int gda_spmm_csr_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const f
  * a row longer than 4*S entries / more slots than one workgroup holds) -- callers then use
  * gda_spmm_csr_kstep_f32 --, or a negative status.  The plan is copied to the device by the caller.
  *
- * gda_kstep_lds_f32: x [n_rows, ldx] -> y [n_rows, ldy] row-major, bias ([d] or NULL) added once
- * at the end; scratchT holds 2 * d * round_up(n_rows, 4) floats (the column-major copies).
- * gda_kstep_lds_colmajor_f32: the kernel alone on column-major operands xT, yT [d, ld] (ld >=
- * round_up(n_rows, 4), 16-byte aligned columns), K >= 0.
+ * gda_kstep_lds_f32: K >= 1 steps; x is row-major [n_rows, ldx] (x_colmajor = 0) or column-major
+ * [d, ldx] (x_colmajor = 1: ldx >= round_up(n_rows, 4), 16-byte aligned columns), y likewise; bias ([d] or
+ * NULL) is added once at the end; colsum ([d] or NULL) receives the column sums of the INPUT over the
+ * real rows in a fixed order (the bias gradient when the call is the backward pass of the layer);
+ * scratchT holds 2 * d * round_up(n_rows, 4) floats for the transposes of row-major operands.
+ * gda_kstep_lds_colmajor_f32: the kernel alone on column-major operands, K >= 0.
  * gda_transpose_f32: out [cols, ldo] = in [rows, ldi]^T.
  * ---------------------------------------------------------------------------- */
 int gda_kstep_max_rows(void);
@@ -171,11 +173,11 @@ size_t gda_kstep_plan_bytes(int slots);
 int gda_kstep_plan_host(const int32_t* rowptr_host, const int32_t* colidx_host, const float* val_host,
                         int64_t n_rows, void* plan_host, size_t plan_bytes);
 int gda_kstep_lds_f32(const void* plan, int slots, int64_t n_rows, int64_t d, int K,
-                      const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias,
-                      float* scratchT, gda_stream_t stream);
+                      const float* x, int64_t ldx, int x_colmajor, float* y, int64_t ldy, int y_colmajor,
+                      const float* bias, float* colsum, float* scratchT, gda_stream_t stream);
 int gda_kstep_lds_colmajor_f32(const void* plan, int slots, int64_t n_rows, int64_t d, int K,
                                const float* xT, int64_t ldx, float* yT, int64_t ldy,
-                               const float* bias, gda_stream_t stream);
+                               const float* bias, float* colsum, gda_stream_t stream);
 int gda_transpose_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int64_t rows, int64_t cols,
                       gda_stream_t stream);
 
@@ -277,6 +279,15 @@ int gda_relu_dropout_fwd_f32(const float* x, float* y, int64_t n, float p, uint6
                              const int64_t* step, uint32_t site, gda_stream_t stream);
 int gda_relu_dropout_bwd_f32(const float* gy, const float* y, float* gx, int64_t n, float p,
                              gda_stream_t stream);
+/* The same activation across a layout change, next to the LDS-resident K-step kernel (which works on
+ * column-major activations): forward reads xT [d, ldT] column-major and writes y [n, d] row-major, backward
+ * reads gy, y [n, d] row-major and writes gxT [d, ldT] column-major (rows n..ldT-1 of a column untouched) --
+ * the transposition rides through LDS tiles, no separate pass.  Same keep-bits as the plain kernels (keyed on
+ * the row-major element index); d % 4 == 0. */
+int gda_relu_dropout_fwd_cm_f32(const float* xT, int64_t ldT, float* y, int64_t n, int64_t d, float p,
+                               uint64_t seed, const int64_t* step, uint32_t site, gda_stream_t stream);
+int gda_relu_dropout_bwd_cm_f32(const float* gy, const float* y, float* gxT, int64_t ldT, int64_t n, int64_t d,
+                               float p, gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
  * Feature-row gather  out[r,:] = x[idx[r],:]  (mini-batch assembly: the x[n_id]

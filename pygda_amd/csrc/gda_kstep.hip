@@ -71,8 +71,8 @@ __device__ __forceinline__ void ks_step(const unsigned (&ea)[S * KS_L], const fl
 template <int S>
 __global__ void __launch_bounds__(KS_TB)
 k_kstep_lds(const int2* __restrict__ ent, const unsigned* __restrict__ outa, const unsigned* __restrict__ keepm,
-            int n_pad, int K, const float* __restrict__ xT, int64_t ldx, float* __restrict__ yT, int64_t ldy,
-            const float* __restrict__ bias) {
+            int n_rows, int n_pad, int K, const float* __restrict__ xT, int64_t ldx, float* __restrict__ yT, int64_t ldy,
+            const float* __restrict__ bias, float* __restrict__ colsum) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int R = S * KS_L;
     const int c = blockIdx.x;
@@ -80,9 +80,29 @@ k_kstep_lds(const int2* __restrict__ ent, const unsigned* __restrict__ outa, con
     float* bufA = reinterpret_cast<float*>(lds);
     float* bufB = reinterpret_cast<float*>(lds + KS_OFFB);
     const float* xc = xT + (int64_t)c * ldx;
-    for (int i = t * 4; i < n_pad; i += KS_TB * 4)
-        *reinterpret_cast<float4*>(bufA + i) = *reinterpret_cast<const float4*>(xc + i);
+    float csum = 0.f;
+    for (int i = t * 4; i < n_pad; i += KS_TB * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(xc + i);
+        *reinterpret_cast<float4*>(bufA + i) = v;
+        if (colsum) {                                        // column sum of the INPUT over the real rows
+            csum += (i + 0 < n_rows ? v.x : 0.f); csum += (i + 1 < n_rows ? v.y : 0.f);
+            csum += (i + 2 < n_rows ? v.z : 0.f); csum += (i + 3 < n_rows ? v.w : 0.f);
+        }
+    }
     if (t < 2) { bufA[n_pad + t] = 0.f; bufB[n_pad + t] = 0.f; }        // the zero word (+ dump word) of each buffer
+    if (colsum) {      // fixed-order block reduction (wave butterflies, then 16 leaders through the spare LDS above both buffers)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) csum += __shfl_down(csum, off, 64);
+        float* red = reinterpret_cast<float*>(lds + KS_OFFB) + n_pad + 2;
+        if ((t & 63) == 0) red[t >> 6] = csum;
+        __syncthreads();
+        if (t == 0) {
+            float sres = 0.f;
+#pragma unroll
+            for (int k = 0; k < KS_TB / 64; ++k) sres += red[k];
+            colsum[c] = sres;
+        }
+    }
     unsigned ea[R], oa[S];
     float ew[R];
     const int w = t >> 6, lane = t & 63;
@@ -135,16 +155,16 @@ k_transpose(const float* __restrict__ in, int64_t ldi, float* __restrict__ out, 
 }
 
 template <int S>
-int ks_launch(const int2* ent, const unsigned* outa, const unsigned* keep, int n_pad, int d, int K,
-              const float* xT, int64_t ldx, float* yT, int64_t ldy, const float* bias, hipStream_t s) {
-    const size_t lds = (size_t)KS_OFFB + (size_t)(n_pad + 2) * 4;
+int ks_launch(const int2* ent, const unsigned* outa, const unsigned* keep, int n_rows, int n_pad, int d, int K,
+              const float* xT, int64_t ldx, float* yT, int64_t ldy, const float* bias, float* colsum, hipStream_t s) {
+    const size_t lds = (size_t)KS_OFFB + (size_t)(n_pad + 2 + KS_TB / 64) * 4;
     static bool configured = false;          // idempotent attribute; racing first calls set the same value
     if (!configured) {
         GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_kstep_lds<S>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
-    k_kstep_lds<S><<<(unsigned)d, KS_TB, lds, s>>>(ent, outa, keep, n_pad, K, xT, ldx, yT, ldy, bias);
+    k_kstep_lds<S><<<(unsigned)d, KS_TB, lds, s>>>(ent, outa, keep, n_rows, n_pad, K, xT, ldx, yT, ldy, bias, colsum);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
@@ -224,10 +244,11 @@ extern "C" int gda_kstep_plan_host(const int32_t* rowptr_host, const int32_t* co
 
 // Column-major entry point: xT, yT are [d, ld*] with ld* >= n_pad = round_up(n_rows, 4) and 16-byte aligned
 // columns; rows n_rows..n_pad-1 of xT must be readable (their values are never used).  plan = device copy of
-// the gda_kstep_plan_host output for S = slots.
+// the gda_kstep_plan_host output for S = slots.  colsum ([d] or NULL) receives the column sums of the INPUT
+// over the n_rows real rows (the bias gradient when the call is the backward pass), fixed order.
 extern "C" int gda_kstep_lds_colmajor_f32(const void* plan, int slots, int64_t n_rows, int64_t d, int K,
                                           const float* xT, int64_t ldx, float* yT, int64_t ldy,
-                                          const float* bias, gda_stream_t stream) {
+                                          const float* bias, float* colsum, gda_stream_t stream) {
     if (n_rows < 0 || d < 0 || K < 0 || n_rows > KS_MAX_ROWS || d > 65535) return GDA_E_SIZE;
     if (n_rows == 0 || d == 0) return GDA_OK;
     if (!plan || !xT || !yT) return GDA_E_NULL;
@@ -238,11 +259,12 @@ extern "C" int gda_kstep_lds_colmajor_f32(const void* plan, int slots, int64_t n
     const unsigned* outa = reinterpret_cast<const unsigned*>(ent + (size_t)KS_TB * R);
     const unsigned* keep = outa + (size_t)KS_TB * slots;
     hipStream_t s = (hipStream_t)stream;
+    const int n = (int)n_rows;
     switch (slots) {
-        case 6: return ks_launch<6>(ent, outa, keep, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, s);
-        case 8: return ks_launch<8>(ent, outa, keep, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, s);
-        case 10: return ks_launch<10>(ent, outa, keep, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, s);
-        case 12: return ks_launch<12>(ent, outa, keep, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, s);
+        case 6: return ks_launch<6>(ent, outa, keep, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
+        case 8: return ks_launch<8>(ent, outa, keep, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
+        case 10: return ks_launch<10>(ent, outa, keep, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
+        case 12: return ks_launch<12>(ent, outa, keep, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
         default: return GDA_E_UNSUPPORTED;
     }
 }
@@ -260,20 +282,27 @@ extern "C" int gda_transpose_f32(const float* in, int64_t ldi, float* out, int64
     return GDA_OK;
 }
 
-// Row-major wrapper with the signature shape of gda_spmm_csr_kstep_f32: x [n_rows, ldx] -> y [n_rows, ldy].
-// scratchT: 2 * d * n_pad floats (the column-major input and output).
+// General wrapper.  x is row-major [n_rows, ldx] (x_colmajor = 0) or column-major [d, ldx] (x_colmajor = 1,
+// ldx >= n_pad, 16-byte aligned); y likewise.  Row-major operands are transposed through scratchT
+// (2 * d * n_pad floats; may be NULL when both operands are column-major).  K >= 1.
 extern "C" int gda_kstep_lds_f32(const void* plan, int slots, int64_t n_rows, int64_t d, int K,
-                                 const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias,
-                                 float* scratchT, gda_stream_t stream) {
-    if (n_rows < 0 || d < 0 || K < 1 || n_rows > KS_MAX_ROWS || ldx < d || ldy < d) return GDA_E_SIZE;
+                                 const float* x, int64_t ldx, int x_colmajor, float* y, int64_t ldy, int y_colmajor,
+                                 const float* bias, float* colsum, float* scratchT, gda_stream_t stream) {
+    if (n_rows < 0 || d < 0 || K < 1 || n_rows > KS_MAX_ROWS) return GDA_E_SIZE;
+    if ((!x_colmajor && ldx < d) || (!y_colmajor && ldy < d)) return GDA_E_SIZE;
     if (n_rows == 0 || d == 0) return GDA_OK;
-    if (!plan || !x || !y || !scratchT) return GDA_E_NULL;
+    if (!plan || !x || !y || (!scratchT && (!x_colmajor || !y_colmajor))) return GDA_E_NULL;
     const int64_t n_pad = (n_rows + 3) / 4 * 4;
-    float* xT = scratchT;
-    float* yT = scratchT + d * n_pad;
-    int st = gda_transpose_f32(x, ldx, xT, n_pad, n_rows, d, stream);
-    if (st != GDA_OK) return st;
-    st = gda_kstep_lds_colmajor_f32(plan, slots, n_rows, d, K, xT, n_pad, yT, n_pad, bias, stream);
-    if (st != GDA_OK) return st;
+    const float* xT = x;
+    int64_t ldxT = ldx;
+    if (!x_colmajor) {
+        int st = gda_transpose_f32(x, ldx, scratchT, n_pad, n_rows, d, stream);
+        if (st != GDA_OK) return st;
+        xT = scratchT; ldxT = n_pad;
+    }
+    float* yT = y_colmajor ? y : scratchT + d * n_pad;
+    const int64_t ldyT = y_colmajor ? ldy : n_pad;
+    int st = gda_kstep_lds_colmajor_f32(plan, slots, n_rows, d, K, xT, ldxT, yT, ldyT, bias, colsum, stream);
+    if (st != GDA_OK || y_colmajor) return st;
     return gda_transpose_f32(yT, n_pad, y, ldy, d, n_rows, stream);
 }

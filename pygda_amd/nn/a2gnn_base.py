@@ -41,10 +41,17 @@ class A2GNNBase(nn.Module):
         """Output of layer 0 BEFORE activation / dropout: a deterministic function of the inputs,
         so the two passes the trainer makes over the same graph (features and logits) can share
         it -- the reference recomputes it, projection and all ``prop_nums`` aggregations, per pass."""
-        return self.convs[0](x, edge_index, prop_nums)
+        conv = self.convs[0]
+        return conv.forward_colmajor(x, edge_index, prop_nums) if self._fused_act(x) else conv(x, edge_index, prop_nums)
+
+    def _fused_act(self, x):
+        """ReLU on the device: the conv may hand its result over in the K-step kernel's column-major
+        layout, which the fused activation kernel consumes directly (no transpose pass in between)."""
+        return self.act is F.relu and x.is_cuda and self.mode == "node"
 
     def _act_dropout(self, x):
-        if self.act is F.relu and x.is_cuda:            # fused kernel; any other activation composes
+        from ..ops import ColMajor
+        if isinstance(x, ColMajor) or (self.act is F.relu and x.is_cuda):   # fused kernel; other activations compose
             from ..ops import relu_dropout
             return relu_dropout(x, self.dropout, self.training)
         return F.dropout(self.act(x), p=self.dropout, training=self.training)
@@ -53,7 +60,8 @@ class A2GNNBase(nn.Module):
         """``feat_bottleneck`` continued from a precomputed :meth:`first_conv` output."""
         x = self._act_dropout(h0)
         for conv in self.convs[1:]:
-            x = self._act_dropout(conv(x, edge_index, prop_nums))
+            x = self._act_dropout(conv.forward_colmajor(x, edge_index, prop_nums) if self._fused_act(x)
+                                  else conv(x, edge_index, prop_nums))
         if self.mode == "graph":
             x = global_mean_pool(x, batch)
         return x

@@ -60,9 +60,18 @@ class PropGCNConv(nn.Module):
         return g
 
     def forward(self, x, edge_index, prop_nums=1, edge_weight=None):
+        return self._forward(x, edge_index, prop_nums, edge_weight, False)
+
+    def forward_colmajor(self, x, edge_index, prop_nums=1, edge_weight=None):
+        """forward() whose result may come back as an :class:`~pygda_amd.ops.ColMajor` (the K-step kernel's own
+        layout) for the fused activation kernel that follows a conv in A2GNNBase; not in the reference."""
+        return self._forward(x, edge_index, prop_nums, edge_weight, True)
+
+    def _forward(self, x, edge_index, prop_nums, edge_weight, colmajor_out):
         out = self.lin(x)                                        # :205
         if prop_nums > 0:                                        # :208-213, bias fused in the last step
-            return propagate(out, self._graph(x, edge_index, edge_weight), prop_nums, self.bias)
+            return propagate(out, self._graph(x, edge_index, edge_weight), prop_nums, self.bias,
+                             colmajor_out=colmajor_out)
         if self.bias is not None:
             out = out + self.bias
         return out

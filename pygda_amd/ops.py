@@ -117,9 +117,12 @@ def _launch_kstep(graph, x, K, bias, transposed, y, tmp, counts_as=None):
                                             _lib.stream()), "gda_spmm_csr_split_f32")
 
 
-def _launch_kstep_lds(graph, plan, slots, x, K, bias, transposed, y):
-    """All K steps in one launch on the LDS-resident kernel (csrc/gda_kstep.hip): same sums, bit for bit."""
-    n, d = x.shape
+def _launch_kstep_lds(graph, plan, slots, x, K, bias, transposed, y, x_colmajor=False, y_colmajor=False,
+                      colsum=None):
+    """All K steps in one launch on the LDS-resident kernel (csrc/gda_kstep.hip): same sums, bit for bit.
+    Column-major operands are ``[d, round_up(n, 4)]`` tensors and skip the transposition on their side."""
+    n = graph.num_nodes
+    d = x.size(0) if x_colmajor else x.size(1)
     L = _lib.lib()
     if aggregation_log is not None:
         aggregation_log.append((graph, int(K)))
@@ -133,8 +136,11 @@ def _launch_kstep_lds(graph, plan, slots, x, K, bias, transposed, y):
     n_pad = (n + 3) // 4 * 4
     ws = _lib.workspace(2 * d * n_pad * 4, x.device, "kstep")
     with ctx:
-        _lib.check(L.gda_kstep_lds_f32(_lib.ptr(plan), slots, n, d, int(K), _lib.ptr(x), d, _lib.ptr(y), d,
-                                       _lib.ptr(bias), _lib.ptr(ws), _lib.stream()), "gda_kstep_lds_f32")
+        _lib.check(L.gda_kstep_lds_f32(_lib.ptr(plan), slots, n, d, int(K),
+                                       _lib.ptr(x), n_pad if x_colmajor else d, int(x_colmajor),
+                                       _lib.ptr(y), n_pad if y_colmajor else d, int(y_colmajor),
+                                       _lib.ptr(bias), _lib.ptr(colsum), _lib.ptr(ws), _lib.stream()),
+                   "gda_kstep_lds_f32")
 
 
 def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
@@ -169,6 +175,68 @@ def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
     return y
 
 
+class ColMajor:
+    """A ``[n, d]`` activation held column-major as ``t [d, round_up(n, 4)]`` -- the layout the LDS-resident
+    K-step kernel computes in.  Produced by :func:`propagate` (``colmajor_out=True``) for its one consumer,
+    :func:`relu_dropout`, whose kernel transposes on the fly; ``dense()`` gives the ordinary tensor."""
+    __slots__ = ("t", "n")
+
+    def __init__(self, t, n):
+        self.t, self.n = t, n
+
+    def detach(self):
+        return ColMajor(self.t.detach(), self.n)
+
+    @property
+    def shape(self):
+        return torch.Size((self.n, self.t.size(0)))
+
+    def size(self, k=None):
+        return self.shape if k is None else self.shape[k]
+
+    def dense(self):
+        return self.t[:, :self.n].t().contiguous()
+
+
+def lds_kstep_plan(graph, K, transposed=False):
+    """``(plan, slots)`` when ``K`` aggregation steps over ``graph`` run on the one-launch LDS kernel."""
+    from .graph import KSTEP_LDS, KSTEP_LDS_MIN_K, SQUARE
+    if not KSTEP_LDS or SQUARE or K < KSTEP_LDS_MIN_K or not graph.static:
+        return None
+    return graph.kstep_plan(transposed)
+
+
+class _PropagateT(torch.autograd.Function):
+    """K-step aggregation with a COLUMN-MAJOR result (forward) and gradient (backward): the transposes on
+    the activation side of the LDS kernel disappear into the fused activation kernels
+    (``gda_relu_dropout_*_cm_f32``), and the bias gradient is the column sum the backward kernel takes of its
+    input while loading it -- no reduction launch."""
+
+    @staticmethod
+    def forward(ctx, x, bias, graph, K):
+        x = _f32c(x, "x")
+        n, d = x.shape
+        plan, slots = graph.kstep_plan(False)
+        n_pad = (n + 3) // 4 * 4
+        yT = torch.empty(d, n_pad, dtype=torch.float32, device=x.device)
+        b = None if bias is None else _f32c(bias, "bias")
+        _launch_kstep_lds(graph, plan, slots, x, K, b, False, yT, y_colmajor=True)
+        ctx.graph, ctx.K, ctx.has_bias, ctx.n = graph, K, bias is not None, n
+        return yT
+
+    @staticmethod
+    def backward(ctx, gT):
+        graph, n = ctx.graph, ctx.n
+        gT = gT.contiguous()
+        d = gT.size(0)
+        plan, slots = graph.kstep_plan(True)
+        want_b = ctx.has_bias and ctx.needs_input_grad[1]
+        gb = torch.empty(d, dtype=torch.float32, device=gT.device) if want_b else None
+        gx = torch.empty(n, d, dtype=torch.float32, device=gT.device)
+        _launch_kstep_lds(graph, plan, slots, gT, ctx.K, None, True, gx, x_colmajor=True, colsum=gb)
+        return (gx if ctx.needs_input_grad[0] else None), gb, None, None
+
+
 class _Propagate(torch.autograd.Function):
     """K-step neighbour aggregation.  Linear in x, so nothing but the graph is saved:
     backward is the same K-step kernel on the by-source CSR (A_hat^T)."""
@@ -186,10 +254,15 @@ class _Propagate(torch.autograd.Function):
         return gx, gb, None, None
 
 
-def propagate(x, graph: CSRGraph, K=1, bias=None):
-    """``out = A_hat^K x + bias`` with autograd (prop_gcn_conv.py:208-213)."""
+def propagate(x, graph: CSRGraph, K=1, bias=None, colmajor_out=False):
+    """``out = A_hat^K x + bias`` with autograd (prop_gcn_conv.py:208-213).  ``colmajor_out``: hand the result
+    to the fused activation as a :class:`ColMajor` when the LDS-resident kernel runs this call (static graph
+    at citation size, K >= 3, width a multiple of 4) -- otherwise the ordinary tensor comes back."""
     if K < 1:
         raise ValueError("K must be >= 1")
+    if (colmajor_out and x.dim() == 2 and x.size(1) % 4 == 0 and x.is_cuda and x.dtype == torch.float32
+            and lds_kstep_plan(graph, int(K), False) is not None and lds_kstep_plan(graph, int(K), True) is not None):
+        return ColMajor(_PropagateT.apply(x, bias, graph, int(K)), x.size(0))
     return _Propagate.apply(x, bias, graph, int(K))
 
 
@@ -480,8 +553,45 @@ class _ReluDropout(torch.autograd.Function):
         return gx, None
 
 
+class _ReluDropoutT(torch.autograd.Function):
+    """The activation across the layout change: column-major input ``[d, n_pad]`` -> row-major ``[n, d]``
+    output, and back in the backward pass (gda_relu_dropout_{fwd,bwd}_cm_f32)."""
+
+    @staticmethod
+    def forward(ctx, xT, n, p):
+        d, n_pad = xT.shape
+        y = torch.empty(n, d, dtype=torch.float32, device=xT.device)
+        st = dropout_state
+        if st.seed is None:
+            st.seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+        L = _lib.lib()
+        _lib.check(L.gda_relu_dropout_fwd_cm_f32(_lib.ptr(xT), n_pad, _lib.ptr(y), n, d, float(p),
+                                                ctypes.c_uint64(st.seed), _lib.ptr(st.counter(xT.device)),
+                                                ctypes.c_uint32(st.next_site()), _lib.stream()),
+                   "gda_relu_dropout_fwd_cm_f32")
+        ctx.save_for_backward(y)
+        ctx.p, ctx.n_pad = float(p), n_pad
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        n, d = y.shape
+        gy = gy.contiguous()
+        gxT = torch.empty(d, ctx.n_pad, dtype=torch.float32, device=gy.device)
+        if ctx.n_pad != n:
+            gxT[:, n:].zero_()                   # the padding rows of a column are never read as values,
+        L = _lib.lib()                           # but they may be summed with another consumer's gradient
+        _lib.check(L.gda_relu_dropout_bwd_cm_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gxT), ctx.n_pad, n, d, ctx.p,
+                                                _lib.stream()), "gda_relu_dropout_bwd_cm_f32")
+        return gxT, None, None
+
+
 def relu_dropout(x, p, training=True):
-    """``F.dropout(F.relu(x), p, training)`` in one kernel each way (no mask tensor)."""
+    """``F.dropout(F.relu(x), p, training)`` in one kernel each way (no mask tensor).  A :class:`ColMajor`
+    input (the K-step kernel's layout) is consumed as it is and comes out as the ordinary row-major tensor."""
+    if isinstance(x, ColMajor):
+        return _ReluDropoutT.apply(x.t, x.n, float(p) if training else 0.0)
     if not training or p <= 0.0 or not x.is_cuda or x.dtype != torch.float32:
         return torch.relu(x)
     return _ReluDropout.apply(x, p)

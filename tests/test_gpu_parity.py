@@ -1559,3 +1559,42 @@ def test_kstep_lds_cfg_a_target_graph_through_the_conv():
     ops.propagate(ha, Gs, 10, bias).backward(gy)
     ops.propagate(hb, G, 10, bias).backward(gy)
     exact(ha.grad, hb.grad)
+
+
+def test_kstep_lds_fused_activation_equals_unfused(monkeypatch):
+    """conv -> ReLU -> dropout on a static citation-size graph: the K-step kernel hands its column-major
+    result straight to the transposing activation kernel (and takes the activation's column-major gradient
+    back, with the bias gradient as a by-product of its load) -- values, keep-bits and every gradient equal
+    the unfused path (row-major propagate, plain activation kernel, gy.sum(0)) bit for bit."""
+    from bench import make_cfg_a
+    from pygda_amd import graph as G_
+    from pygda_amd.ops import ColMajor, dropout_state, propagate, relu_dropout
+    _, tgt = make_cfg_a(seed=200)
+    n = tgt.num_nodes
+    G = build_csr(tgt.edge_index.to(DEV), n)
+    G.static = True
+    gen = torch.Generator().manual_seed(12)
+    h = torch.randn(n, 128, generator=gen).to(DEV)
+    bias = torch.randn(128, generator=gen).to(DEV)
+    gy1, gy2 = torch.randn(n, 128, generator=gen).to(DEV), torch.randn(n, 128, generator=gen).to(DEV)
+
+    def run(fused):
+        monkeypatch.setattr(G_, "KSTEP_LDS", True)
+        x, b = h.clone().requires_grad_(), bias.clone().requires_grad_()
+        dropout_state.next_step(h.device)
+        dropout_state.counter(h.device).fill_(41)
+        dropout_state.site = 0
+        out = propagate(x, G, 10, b, colmajor_out=fused)
+        assert isinstance(out, ColMajor) == fused
+        y1 = relu_dropout(out, 0.5, True)            # two consumers of one conv output, as in A2GNN's layer 0
+        y2 = relu_dropout(out, 0.5, True)
+        ((y1 * gy1).sum() + (y2 * gy2).sum()).backward()
+        return y1.detach(), y2.detach(), x.grad, b.grad
+
+    a, b = run(True), run(False)
+    assert bool((a[0] != a[1]).any())                                   # two call sites, two masks
+    exact(a[0], b[0]); exact(a[1], b[1]); exact(a[2], b[2])
+    close(a[3], b[3], rtol=1e-5, atol=1e-5 * float(b[3].abs().max()))   # column sums in a different fixed order
+    # eval mode: plain ReLU either way
+    exact(relu_dropout(propagate(h, G, 10, bias, colmajor_out=True), 0.5, False),
+          torch.relu(propagate(h, G, 10, bias)))

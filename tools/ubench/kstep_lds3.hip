@@ -89,9 +89,9 @@ int main(int argc, char** argv) {
         printf("chain of K launches      : %8.2f us (%.2f per step)\n", time_us(e0, e1, iters), time_us(e0, e1, iters) / K);
     }
     // row-major wrapper (transpose + kernel + transpose): correctness + time
-    for (int w = 0; w < 5; ++w) CG(gda_kstep_lds_f32(dplan, S, n, d, K, x, d, y, d, dbias, scratch, nullptr));
+    for (int w = 0; w < 5; ++w) CG(gda_kstep_lds_f32(dplan, S, n, d, K, x, d, 0, y, d, 0, dbias, nullptr, scratch, nullptr));
     CK(hipEventRecord(e0));
-    for (int it = 0; it < iters; ++it) CG(gda_kstep_lds_f32(dplan, S, n, d, K, x, d, y, d, dbias, scratch, nullptr));
+    for (int it = 0; it < iters; ++it) CG(gda_kstep_lds_f32(dplan, S, n, d, K, x, d, 0, y, d, 0, dbias, nullptr, scratch, nullptr));
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     std::vector<float> got((size_t)n * d);
     CK(hipMemcpy(got.data(), y, got.size() * 4, hipMemcpyDeviceToHost));
@@ -100,9 +100,9 @@ int main(int argc, char** argv) {
     printf("row-major wrapper K=%d    : %8.2f us   mismatches %zu\n", K, time_us(e0, e1, iters), bad);
     float* xT = scratch; float* yT = scratch + (size_t)npad * d;
     for (int Kx : {10, 0, 1, 2, 30}) {
-        for (int w = 0; w < 3; ++w) CG(gda_kstep_lds_colmajor_f32(dplan, S, n, d, Kx, xT, npad, yT, npad, dbias, nullptr));
+        for (int w = 0; w < 3; ++w) CG(gda_kstep_lds_colmajor_f32(dplan, S, n, d, Kx, xT, npad, yT, npad, dbias, nullptr, nullptr));
         CK(hipEventRecord(e0));
-        for (int it = 0; it < iters; ++it) CG(gda_kstep_lds_colmajor_f32(dplan, S, n, d, Kx, xT, npad, yT, npad, dbias, nullptr));
+        for (int it = 0; it < iters; ++it) CG(gda_kstep_lds_colmajor_f32(dplan, S, n, d, Kx, xT, npad, yT, npad, dbias, nullptr, nullptr));
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         printf("column-major kernel K=%2d : %8.2f us\n", Kx, time_us(e0, e1, iters));
     }
