@@ -448,6 +448,10 @@ int gda_adam_multi_f32(const gda_adam_tensor* tensors /* HOST array */, int n_te
  *   GDA_GEMM_TN  C[M,N] = A[K,M]^T * B[K,N]      wgrad    gW = gy^T x  (K = nodes; deterministic split
  *                                                over row slabs, scratch from gda_gemm_workspace_bytes)
  * Row-major with leading dimensions in elements; C must not alias A or B.
+ * The same three modes serve activations kept COLUMN-MAJOR (hT [out, ld] next to the LDS-resident K-step
+ * kernel): forward hT = W x^T is NT with A = W, B = x; dgrad gx = gT^T W is TN with A = gT; wgrad
+ * gW = gT x is NN whose K is the node count -- NN with K >= 1024 and M, N <= 512 takes the deterministic
+ * row-slab split as well (gda_gemm_workspace_bytes says how much scratch that needs).
  * ---------------------------------------------------------------------------- */
 #define GDA_GEMM_NT 0
 #define GDA_GEMM_NN 1

@@ -177,8 +177,14 @@ int slabs_for(int64_t K) {
 
 }  // namespace
 
+// the reduction dimension is the tall one (nodes) and the output small: TN always, NN when its K is the tall
+// side (the weight gradient from a column-major gradient: gW = gT x with gT [out, nodes])
+bool split_k(int mode, int64_t M, int64_t N, int64_t K) {
+    return mode == GDA_GEMM_TN || (mode == GDA_GEMM_NN && K >= 1024 && M <= 512 && N <= 512);
+}
+
 extern "C" size_t gda_gemm_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
-    if (mode != GDA_GEMM_TN || M <= 0 || N <= 0 || K <= 0) return 0;
+    if (M <= 0 || N <= 0 || K <= 0 || !split_k(mode, M, N, K)) return 0;
     const int s = slabs_for(K);
     return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
@@ -208,16 +214,20 @@ extern "C" int gda_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const flo
         if (fast) k_gemm<TA_, TB__, true><<<grid, TB, 0, stream>>>(A, lda, B, ldb, Cp, ldc_, M, N, K, kslab, va, vb); \
         else k_gemm<TA_, TB__, false><<<grid, TB, 0, stream>>>(A, lda, B, ldb, Cp, ldc_, M, N, K, kslab, va, vb);    \
     } while (0)
-    if (mode == GDA_GEMM_TN) {
+    if (split_k(mode, M, N, K)) {
+        const bool tn = mode == GDA_GEMM_TN;
         const int s = slabs_for(K);
         const int64_t k_slab = gda_cdiv(gda_cdiv(K, s), DK) * DK;        // whole chunks per slab
         if (s > 1) {
             if (!workspace || workspace_bytes < gda_gemm_workspace_bytes(mode, M, N, K)) return GDA_E_WORKSPACE;
-            GDA_GEMM_LAUNCH(true, true, dim3((unsigned)gy, (unsigned)gx, s), (float*)workspace, N, k_slab);
+            if (tn) GDA_GEMM_LAUNCH(true, true, dim3((unsigned)gy, (unsigned)gx, s), (float*)workspace, N, k_slab);
+            else GDA_GEMM_LAUNCH(false, true, dim3((unsigned)gy, (unsigned)gx, s), (float*)workspace, N, k_slab);
             GDA_LAUNCH_CHECK();
             k_slab_sum<<<(unsigned)gda_cdiv(M * N, TB), TB, 0, stream>>>((const float*)workspace, s, M, N, C, ldc);
-        } else {
+        } else if (tn) {
             GDA_GEMM_LAUNCH(true, true, dim3((unsigned)gy, (unsigned)gx, 1), C, ldc, K);
+        } else {
+            GDA_GEMM_LAUNCH(false, true, dim3((unsigned)gy, (unsigned)gx, 1), C, ldc, K);
         }
     } else if (mode == GDA_GEMM_NT) {
         GDA_GEMM_LAUNCH(false, false, dim3((unsigned)gy, (unsigned)gx, 1), C, ldc, K);

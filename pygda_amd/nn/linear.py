@@ -96,6 +96,14 @@ class Linear(nn.Module):
             nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
         zeros(self.bias)
 
+    def tall_gemm_ok(self, x):
+        """``x`` goes to the hand-written matrix-core kernels (not the sparse-input path, not the BLAS)."""
+        if self.bias is not None or x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32:
+            return False
+        if x.size(1) >= sparse_features.MIN_WIDTH and sparse_features.lookup(x) is not None:
+            return False
+        return 1024 <= x.size(0) <= TALL_GEMM_MAX_ROWS and self.in_channels <= 256 and self.out_channels <= 256
+
     def forward(self, x):
         if self.bias is None and x.dim() == 2 and x.size(1) >= sparse_features.MIN_WIDTH:
             sf = sparse_features.lookup(x)             # identity lookup: input feature matrices only

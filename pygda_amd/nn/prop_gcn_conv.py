@@ -68,6 +68,15 @@ class PropGCNConv(nn.Module):
         return self._forward(x, edge_index, prop_nums, edge_weight, True)
 
     def _forward(self, x, edge_index, prop_nums, edge_weight, colmajor_out):
+        if colmajor_out and prop_nums > 0 and self.lin.tall_gemm_ok(x):
+            # dense projection on the matrix-core kernels: it can write the K-step kernel's column-major
+            # layout itself (and read the column-major gradient), so no transposition is left around the
+            # aggregation of this layer
+            from ..ops import lds_kstep_plan, tall_linear_colmajor
+            g = self._graph(x, edge_index, edge_weight)
+            if (self.out_channels % 4 == 0 and lds_kstep_plan(g, prop_nums, False) is not None
+                    and lds_kstep_plan(g, prop_nums, True) is not None):
+                return propagate(tall_linear_colmajor(x, self.lin.weight), g, prop_nums, self.bias)
         out = self.lin(x)                                        # :205
         if prop_nums > 0:                                        # :208-213, bias fused in the last step
             return propagate(out, self._graph(x, edge_index, edge_weight), prop_nums, self.bias,

@@ -61,6 +61,19 @@ def source_ce(logits, labels):
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 
 
+def gemm_raw(mode, M, N, K, a, lda, b, ldb, c, ldc, name="dense_projection"):
+    """gda_gemm_f32 on explicit leading dimensions (column-major activations are row-major matrices of the
+    transposed shape with a padded leading dimension)."""
+    L = _lib.lib()
+    need = L.gda_gemm_workspace_bytes(mode, M, N, K)
+    ws = _lib.workspace(need, c.device, "gemm") if need else None
+    with profiler.region(name, 1, 4 * (M * K + N * K + M * N), 2 * M * N * K):
+        _lib.check(L.gda_gemm_f32(mode, M, N, K, _lib.ptr(a), lda, _lib.ptr(b), ldb, _lib.ptr(c), ldc,
+                                  _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream()),
+                   "gda_gemm_f32")
+    return c
+
+
 def gemm(mode, a, b):
     """fp32 product on the matrix cores (include/gda_hip.h: gda_gemm_f32), no autograd.
     NT: ``a [M,K] @ b [N,K]^T``; NN: ``a [M,K] @ b [K,N]``; TN: ``a [K,M]^T @ b [K,N]``."""
@@ -206,6 +219,44 @@ def lds_kstep_plan(graph, K, transposed=False):
     return graph.kstep_plan(transposed)
 
 
+class _TallLinearT(torch.autograd.Function):
+    """``h = x W^T`` handed over COLUMN-MAJOR (``hT [out, round_up(n, 4)]``) to the K-step kernel: the same
+    matrix-core kernels as ``nn.linear._TallLinear`` with the operands swapped -- ``hT = W x^T`` is the NT
+    product of the small matrix with the tall one --, and in the backward pass ``gx = gT^T W`` (TN) and
+    ``gW = gT x`` (NN with the deterministic row-slab split) straight from the column-major gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x, weight = _f32c(x, "x"), _f32c(weight, "weight")
+        n, k = x.shape
+        out = weight.size(0)
+        n_pad = (n + 3) // 4 * 4
+        hT = torch.empty(out, n_pad, dtype=torch.float32, device=x.device)
+        gemm_raw(GEMM_NT, out, n, k, weight, k, x, k, hT, n_pad, f"dense_projection[{k}x{out}]")
+        ctx.save_for_backward(x, weight)
+        return hT
+
+    @staticmethod
+    def backward(ctx, gT):
+        x, weight = ctx.saved_tensors
+        n, k = x.shape
+        out = weight.size(0)
+        gT = gT.contiguous()
+        n_pad = gT.size(1)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(n, k, dtype=torch.float32, device=x.device)
+            gemm_raw(GEMM_TN, n, k, out, gT, n_pad, weight, k, gx, k, f"dense_projection_dgrad[{out}x{k}]")
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty(out, k, dtype=torch.float32, device=x.device)
+            gemm_raw(GEMM_NN, out, k, n, gT, n_pad, x, k, gw, k, f"dense_projection_wgrad[{out}x{k}]")
+        return gx, gw
+
+
+def tall_linear_colmajor(x, weight):
+    return ColMajor(_TallLinearT.apply(x, weight), x.size(0))
+
+
 class _PropagateT(torch.autograd.Function):
     """K-step aggregation with a COLUMN-MAJOR result (forward) and gradient (backward): the transposes on
     the activation side of the LDS kernel disappear into the fused activation kernels
@@ -213,28 +264,37 @@ class _PropagateT(torch.autograd.Function):
     input while loading it -- no reduction launch."""
 
     @staticmethod
-    def forward(ctx, x, bias, graph, K):
+    def forward(ctx, x, bias, graph, K, x_colmajor=False):
+        """``x``: ``[n, d]`` row-major, or (``x_colmajor``) ``[d, round_up(n, 4)]`` column-major -- then the
+        gradient goes back column-major as well and no transposition is left on either side."""
         x = _f32c(x, "x")
-        n, d = x.shape
+        n = graph.num_nodes
+        d = x.size(0) if x_colmajor else x.size(1)
         plan, slots = graph.kstep_plan(False)
         n_pad = (n + 3) // 4 * 4
         yT = torch.empty(d, n_pad, dtype=torch.float32, device=x.device)
         b = None if bias is None else _f32c(bias, "bias")
-        _launch_kstep_lds(graph, plan, slots, x, K, b, False, yT, y_colmajor=True)
-        ctx.graph, ctx.K, ctx.has_bias, ctx.n = graph, K, bias is not None, n
+        _launch_kstep_lds(graph, plan, slots, x, K, b, False, yT, x_colmajor=x_colmajor, y_colmajor=True)
+        ctx.graph, ctx.K, ctx.has_bias, ctx.n, ctx.x_colmajor = graph, K, bias is not None, n, x_colmajor
         return yT
 
     @staticmethod
     def backward(ctx, gT):
         graph, n = ctx.graph, ctx.n
         gT = gT.contiguous()
-        d = gT.size(0)
+        d, n_pad = gT.shape
         plan, slots = graph.kstep_plan(True)
         want_b = ctx.has_bias and ctx.needs_input_grad[1]
         gb = torch.empty(d, dtype=torch.float32, device=gT.device) if want_b else None
-        gx = torch.empty(n, d, dtype=torch.float32, device=gT.device)
-        _launch_kstep_lds(graph, plan, slots, gT, ctx.K, None, True, gx, x_colmajor=True, colsum=gb)
-        return (gx if ctx.needs_input_grad[0] else None), gb, None, None
+        if ctx.x_colmajor:
+            gx = torch.empty(d, n_pad, dtype=torch.float32, device=gT.device)
+            if n_pad != n:
+                gx[:, n:].zero_()
+        else:
+            gx = torch.empty(n, d, dtype=torch.float32, device=gT.device)
+        _launch_kstep_lds(graph, plan, slots, gT, ctx.K, None, True, gx, x_colmajor=True,
+                          y_colmajor=ctx.x_colmajor, colsum=gb)
+        return (gx if ctx.needs_input_grad[0] else None), gb, None, None, None
 
 
 class _Propagate(torch.autograd.Function):
@@ -260,10 +320,17 @@ def propagate(x, graph: CSRGraph, K=1, bias=None, colmajor_out=False):
     at citation size, K >= 3, width a multiple of 4) -- otherwise the ordinary tensor comes back."""
     if K < 1:
         raise ValueError("K must be >= 1")
-    if (colmajor_out and x.dim() == 2 and x.size(1) % 4 == 0 and x.is_cuda and x.dtype == torch.float32
-            and lds_kstep_plan(graph, int(K), False) is not None and lds_kstep_plan(graph, int(K), True) is not None):
+    if isinstance(x, ColMajor):              # from tall_linear_colmajor(): eligibility was checked there
+        return ColMajor(_PropagateT.apply(x.t, bias, graph, int(K), True), x.n)
+    if colmajor_out and lds_colmajor_ok(x, graph, K):
         return ColMajor(_PropagateT.apply(x, bias, graph, int(K)), x.size(0))
     return _Propagate.apply(x, bias, graph, int(K))
+
+
+def lds_colmajor_ok(x, graph, K):
+    """The K-step call on ``x [n, d]`` runs on the LDS kernel and may hand over a column-major result."""
+    return (x.dim() == 2 and x.size(1) % 4 == 0 and x.is_cuda and x.dtype == torch.float32
+            and lds_kstep_plan(graph, int(K), False) is not None and lds_kstep_plan(graph, int(K), True) is not None)
 
 
 # ---------------------------------------------------------------------------- MMD --

@@ -1598,3 +1598,40 @@ def test_kstep_lds_fused_activation_equals_unfused(monkeypatch):
     # eval mode: plain ReLU either way
     exact(relu_dropout(propagate(h, G, 10, bias, colmajor_out=True), 0.5, False),
           torch.relu(propagate(h, G, 10, bias)))
+
+
+def test_conv_layer_colmajor_pipeline_equals_rowmajor(monkeypatch):
+    """A hidden layer at the cfg-A target shapes (dense 128 -> 128 projection, 10 aggregation steps, ReLU +
+    dropout): with the projection writing the K-step kernel's column-major layout and reading its column-major
+    gradient (``_TallLinearT``), no transposition is left around the aggregation -- outputs and all gradients
+    equal the row-major pipeline (same matrix-core kernels, operands swapped)."""
+    from bench import make_cfg_a
+    from pygda_amd import graph as G_
+    from pygda_amd.ops import dropout_state
+    _, tgt = make_cfg_a(seed=200)
+    n = tgt.num_nodes
+    ei = tgt.edge_index.to(DEV)
+    ei._gda_static = True
+    gen = torch.Generator().manual_seed(31)
+    x0 = torch.randn(n, 128, generator=gen).to(DEV)
+    gy = torch.randn(n, 128, generator=gen).to(DEV)
+    net = A2GNNBase(128, 128, 5, num_layers=2, dropout=0.5).to(DEV).train()
+    conv = net.convs[1]
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(128, generator=gen))
+
+    def run(lds):
+        monkeypatch.setattr(G_, "KSTEP_LDS", lds)
+        x = x0.clone().requires_grad_()
+        conv.zero_grad()
+        dropout_state.counter(x.device).fill_(7)
+        dropout_state.site = 0
+        y = net._act_dropout(conv.forward_colmajor(x, ei, 10) if net._fused_act(x) else conv(x, ei, 10))
+        (y * gy).sum().backward()
+        return y.detach(), x.grad, conv.lin.weight.grad.clone(), conv.bias.grad.clone()
+
+    a, b = run(True), run(False)
+    exact(a[0], b[0])
+    close(a[1], b[1], rtol=1e-5, atol=1e-6 * float(b[1].abs().max()))
+    close(a[2], b[2], rtol=1e-4, atol=1e-5 * float(b[2].abs().max()))
+    close(a[3], b[3], rtol=1e-4, atol=1e-5 * float(b[3].abs().max()))
