@@ -12,11 +12,15 @@
 // result is clamped at 0 (the reference's sum of squares cannot be negative).  Only the [m, m] matrix
 // is kept (16 MB per resample, L2/MALL resident) and the backward pass reuses it.
 //
+//   k_rowstats   per 64-row chunk: sum |t_i|^2 and the column sums of the shifted rows
+//   k_bandwidth  bandwidth per resample (mmd.py:50-51) from those sufficient statistics:
+//                sum_ij |t_i - t_j|^2 = 2 m sum_i |t_i|^2 - 2 |sum_i t_i|^2  -- O(m d) instead of a pass over
+//                the [m, m] matrix, so the kernel weights can be formed where the distances are produced
 //   k_pairdist   tile 64x64 of L2 = |t_i|^2 + |t_j|^2 - 2 t_i.t_j on v_mfma_f32_32x32x2_f32 (norms as the
-//                same k-ordered fma chain, from the staged tiles), plus
-//                per-tile partial sums                                 (MFMA bound: 2*m^2*d flop)
-//   k_ksum       bandwidth from the partials (mmd.py:50-51), K = sum_q exp(-L2/bw_q)
-//                (mmd.py:52-55), signed block sums XX+YY-XY-YX (mmd.py:100-106)
+//                same k-ordered fma chain, from the staged tiles)      (MFMA bound: 2*m^2*d flop), and in
+//                its epilogue K = sum_q exp(-L2/bw_q) (mmd.py:52-55), the signed block sums
+//                XX+YY-XY-YX (mmd.py:100-106) and the backward's weights g = dK/dL2, which is all that is
+//                written: the distance matrix itself never reaches memory
 //   k_finalize   mean per resample, average over resamples (mmd.py:152-157)
 //   k_bwd        grad_total[i,:] = 4 * ((sum_j G[i,j]) total[i,:] - sum_j G[i,j] total[j,:]),
 //                G = dloss/dL2 (symmetric; the bandwidth is a constant, mmd.py:50 .data); the
@@ -84,6 +88,83 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     return s;   // valid on thread 0
 }
 
+// ------------------------------------------------------- bandwidth statistics --
+struct KParams {
+    float kernel_mul; int kernel_num; float fix_sigma;
+};
+
+constexpr int SR = 16;        // rows per k_rowstats workgroup (4 per thread: independent loads, many workgroups)
+
+// chunk (t, blockIdx.x): s1 = sum over its rows of |t_i - p|^2, col[c] = sum over its rows of (t_i - p)[c]
+__global__ void __launch_bounds__(TB)
+k_rowstats(Rows R, int64_t d, int64_t m, double* __restrict__ part_s1, float* __restrict__ part_col) {
+    __shared__ double red[TB / 64];
+    __shared__ float colsh[TB / 64][64];
+    const int t = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * SR;
+    const int lane = threadIdx.x % 64, rg = threadIdx.x / 64;
+    const float* pivot = row_ptr(R, t, 0);
+    float* out = part_col + ((int64_t)t * gridDim.x + blockIdx.x) * d;
+    float s1 = 0.f;
+    for (int64_t c0 = 0; c0 < d; c0 += 64) {
+        const int64_t c = c0 + lane;
+        float col = 0.f;
+        if (c < d) {
+            const float pv = pivot[c];
+            for (int rr = rg; rr < SR; rr += TB / 64) {
+                const int64_t r = r0 + rr;
+                if (r < m) { const float v = row_ptr(R, t, r)[c] - pv; s1 = fmaf(v, v, s1); col += v; }
+            }
+        }
+        colsh[rg][lane] = col;
+        __syncthreads();
+        if (rg == 0 && c < d) out[c] = (colsh[0][lane] + colsh[1][lane]) + (colsh[2][lane] + colsh[3][lane]);
+        __syncthreads();
+    }
+    const double s = block_sum((double)s1, red);
+    if (threadIdx.x == 0) part_s1[(int64_t)t * gridDim.x + blockIdx.x] = s;
+}
+
+// bandwidth[t] = (sum_ij L2 + 1e-6) / (m^2 - m) / kernel_mul^(kernel_num/2)     (mmd.py:50-51)
+__global__ void __launch_bounds__(TB)
+k_bandwidth(const double* __restrict__ part_s1, const float* __restrict__ part_col, int chunks, int64_t d,
+            int64_t m, KParams kp, float* __restrict__ bandwidth) {
+    __shared__ double red[TB / 64];
+    const int t = blockIdx.x;
+    double s2 = 0.0;
+    for (int64_t c = threadIdx.x; c < d; c += TB) {
+        double cs = 0.0;
+        const float* pc = part_col + (int64_t)t * chunks * d + c;
+        int k = 0;
+        for (; k + 8 <= chunks; k += 8) {                  // eight loads in flight, summed in chunk order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pc[(int64_t)(k + u) * d];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cs += (double)v[u];
+        }
+        for (; k < chunks; ++k) cs += (double)pc[(int64_t)k * d];
+        s2 += cs * cs;
+    }
+    double s1 = 0.0;
+    for (int k = threadIdx.x; k < chunks; k += TB) s1 += part_s1[(int64_t)t * chunks + k];
+    const double S2 = block_sum(s2, red);
+    __syncthreads();
+    const double S1 = block_sum(s1, red);
+    if (threadIdx.x == 0) {
+        float bw;
+        if (kp.fix_sigma > 0.f) bw = kp.fix_sigma;
+        else {
+            double tot = 2.0 * (double)m * S1 - 2.0 * S2;
+            if (tot < 0.0) tot = 0.0;
+            bw = ((float)tot + 1e-6f) / (float)(m * m - m);
+        }
+        float div = 1.f;
+        for (int q = 0; q < kp.kernel_num / 2; ++q) div *= kp.kernel_mul;
+        bandwidth[t] = bw / div;
+    }
+}
+
 // ---------------------------------------------------------------- forward --
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -93,14 +174,32 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // fp32 MFMA is an exact k-ordered fma chain, so the Gram form costs ~1e-7 relative on L2 (far
 // inside the 1e-4 loss tolerance) for half the VALU work of the difference form and none of it
 // on the VALU.  Tile sums feed the bandwidth (mmd.py:50).
+// The matrix is symmetric: only the tiles (I, J) with I <= J are computed (half the matrix-core work and half
+// the exponentials); an off-diagonal tile is stored twice, as it is and transposed -- the transposed store is
+// the MFMA accumulator's natural 16-byte direction (four consecutive i per lane) -- and counts twice in the
+// block sums.  SQ: kernel_mul == 2 with five kernels (every pygda call): the five exponentials
+// exp(-L2 / (bw 2^q)) are one __expf and four squarings (e_q = e_{q+1}^2).
+template <int KN, bool SQ>
 __global__ void __launch_bounds__(TB)
-k_pairdist(Rows R, int64_t d, int64_t m, float* __restrict__ l2, double* __restrict__ partial) {
+k_pairdist(Rows R, int64_t d, int64_t m, int nt, const float* __restrict__ bandwidth, KParams kp,
+           float* __restrict__ l2, double* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float As[DK][LDT];   // As[k][row i of the tile]
     __shared__ __attribute__((aligned(16))) float Bs[DK][LDT];   // Bs[k][row j of the tile]
     __shared__ float nA[TILE], nB[TILE];                          // |t_i|^2, |t_j|^2 of the tile rows
     __shared__ double red[TB / 64];
     const int t = blockIdx.z;
-    const int64_t i0 = (int64_t)blockIdx.y * TILE, j0 = (int64_t)blockIdx.x * TILE;
+    // linear index -> (I, J), I <= J, rows of the upper triangle laid end to end
+    int I, J;
+    {
+        const int q = (int)blockIdx.x;
+        const float b = (float)(2 * nt + 1);
+        I = (int)((b - sqrtf(b * b - 8.f * (float)q)) * 0.5f);
+        I = I < 0 ? 0 : (I > nt - 1 ? nt - 1 : I);
+        while (I > 0 && q < I * nt - I * (I - 1) / 2) --I;
+        while (q >= (I + 1) * nt - (I + 1) * I / 2) ++I;
+        J = I + (q - (I * nt - I * (I - 1) / 2));
+    }
+    const int64_t i0 = (int64_t)I * TILE, j0 = (int64_t)J * TILE;
     const int tid = threadIdx.x, wave = tid / 64, lane = tid % 64;
     const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;         // this wave's 32x32 sub-tile
     const int ka = lane >> 5, la = lane & 31;
@@ -157,115 +256,64 @@ k_pairdist(Rows R, int64_t d, int64_t m, float* __restrict__ l2, double* __restr
     else if (tid < 2 * TILE) nB[nrow] = nacc;
     __syncthreads();
 
-    float* out = l2 + (int64_t)t * m * m;
-    const int64_t j = j0 + wj + la;
-    const float nj = nB[wj + la];
-    float local = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int li = wi + (r & 3) + 8 * (r >> 2) + 4 * ka;              // C/D layout of the 32x32 MFMA
-        const int64_t i = i0 + li;
-        if (i < m && j < m) {
-            float v = (nA[li] + nj) - 2.f * acc[r];
-            v = v < 0.f ? 0.f : v;                                     // a sum of squares; NaN stays NaN
-            out[i * m + j] = v;
-            local += v;
-        }
-    }
-    const double s = block_sum((double)local, red);
-    if (tid == 0) partial[((int64_t)t * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
-}
-
-struct KParams {
-    float kernel_mul; int kernel_num; float fix_sigma;
-};
-
-// bandwidth of resample t from the pairdist partials (every workgroup recomputes it in the
-// same fixed order: a few hundred L2-resident doubles)
-__device__ float bandwidth_of(const double* __restrict__ partial, int tiles, int t, int64_t m,
-                              KParams kp, double* sh) {
-    double v = 0.0;
-    for (int k = threadIdx.x; k < tiles; k += TB) v += partial[(int64_t)t * tiles + k];
-    const double s = block_sum(v, sh);
-    __shared__ float bw_sh;
-    if (threadIdx.x == 0) {
-        float bw;
-        if (kp.fix_sigma > 0.f) bw = kp.fix_sigma;
-        else bw = ((float)s + 1e-6f) / (float)(m * m - m);          // mmd.py:50
-        float div = 1.f;
-        for (int q = 0; q < kp.kernel_num / 2; ++q) div *= kp.kernel_mul;
-        bw_sh = bw / div;                                            // mmd.py:51
-    }
-    __syncthreads();
-    return bw_sh;
-}
-
-constexpr int KS_ROWS = 8;    // rows of L2 per workgroup pass in k_ksum
-
-// K = sum_q exp(-L2 / bw_q) (mmd.py:52-55) and the signed block sums XX + YY - XY - YX
-// (mmd.py:100-106).  Streams the [m, m] matrix row-wise with 16-byte loads: one workgroup takes
-// KS_ROWS consecutive rows per pass (grid-stride), HBM/Infinity-Cache bound.
-// KN = compile-time kernel_num (5 in every pygda call: fully unrolled, exponents in registers);
-// KN = 0 keeps the run-time count.
-template <int KN>
-__global__ void __launch_bounds__(TB)
-k_ksum(float* __restrict__ l2, int64_t m, int64_t n, KParams kp, const double* __restrict__ partial,
-       int tiles_per_t, float* __restrict__ bandwidth, double* __restrict__ kpartial) {
-    __shared__ double red[TB / 64];
-    const int t = blockIdx.y;
-    // every workgroup folds the pairdist partials itself (a few hundred L2-resident doubles, fixed
-    // order): no separate bandwidth kernel on the critical path; workgroup 0 publishes the value
-    // for the backward pass
-    const float bw0 = bandwidth_of(partial, tiles_per_t, t, m, kp, red);
-    if (blockIdx.x == 0 && threadIdx.x == 0) bandwidth[t] = bw0;
+    // Epilogue: the distances never leave the registers.  K = sum_q exp(L2 * (-1/bw_q)) feeds the signed block
+    // sums of the loss; what is stored is the backward's weight g[i,j] = +-sum_q exp(.) * (-1/bw_q) = dK/dL2,
+    // so the backward pass is a pure matrix product and evaluates no exponentials.
     const int kn = KN > 0 ? KN : kp.kernel_num;
     float nib[KN > 0 ? KN : MAXQ];                     // -1 / (bandwidth * kernel_mul^q), mmd.py:52
     {
+        const float bw0 = bandwidth[t];
         float f = 1.f;
 #pragma unroll
         for (int q = 0; q < kn; ++q) { nib[q] = -1.f / (bw0 * f); f *= kp.kernel_mul; }
     }
-    // While the distances stream through, they are REPLACED in place by the backward's weights
-    //   g[i,j] = +-sum_q exp(L2/(-bw_q)) * (-1/bw_q)      (d K / d L2, signed like the block means)
-    // so that the backward pass is a pure matrix product and evaluates no exponentials.
-    float* L = l2 + (int64_t)t * m * m;
-    const bool v4 = (m % 4 == 0);
+    float* out = l2 + (int64_t)t * m * m;
+    const int64_t j = j0 + wj + la;
+    const float nj = nB[wj + la];
+    const int64_t n = R.n;
+    const bool offdiag = I != J;
+    const bool vecT = (m % 4 == 0) && (((uintptr_t)out & 15) == 0);
     float local = 0.f;
-    for (int64_t r0 = (int64_t)blockIdx.x * KS_ROWS; r0 < m; r0 += (int64_t)gridDim.x * KS_ROWS) {
-        const int64_t r1 = r0 + KS_ROWS < m ? r0 + KS_ROWS : m;
-        if (v4) {
-            const int64_t per_row = m / 4;
-            for (int64_t f = threadIdx.x; f < (r1 - r0) * per_row; f += TB) {
-                const int64_t i = r0 + f / per_row, j = (f % per_row) * 4;
-                const float4 dv = *reinterpret_cast<const float4*>(L + i * m + j);
-                const float dd[4] = {dv.x, dv.y, dv.z, dv.w};
-                float gg[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float kv = 0.f, dk = 0.f;
+    for (int g4 = 0; g4 < 4; ++g4) {
+        float gv[4];
 #pragma unroll
-                    for (int q = 0; q < kn; ++q) { const float e = __expf(dd[c] * nib[q]); kv += e; dk = fmaf(e, nib[q], dk); }
-                    const bool same = (i < n) == (j + c < n);
-                    local += same ? kv : -kv;
-                    gg[c] = same ? dk : -dk;
-                }
-                *reinterpret_cast<float4*>(L + i * m + j) = make_float4(gg[0], gg[1], gg[2], gg[3]);
-            }
-        } else {
-            for (int64_t f = threadIdx.x; f < (r1 - r0) * m; f += TB) {
-                const int64_t i = r0 + f / m, j = f % m;
+        for (int e = 0; e < 4; ++e) {
+            const int r = g4 * 4 + e;
+            const int li = wi + e + 8 * g4 + 4 * ka;                      // C/D layout of the 32x32 MFMA
+            const int64_t i = i0 + li;
+            gv[e] = 0.f;
+            if (i < m && j < m) {
+                float v = (nA[li] + nj) - 2.f * acc[r];
+                v = v < 0.f ? 0.f : v;                                 // a sum of squares; NaN stays NaN
                 float kv = 0.f, dk = 0.f;
-                const float dist = L[i * m + j];
+                if constexpr (SQ) {
+                    const float e4 = __expf(v * nib[4]);
+                    const float e3 = e4 * e4, e2 = e3 * e3, e1 = e2 * e2, e0 = e1 * e1;
+                    kv = (((e0 + e1) + e2) + e3) + e4;
+                    dk = fmaf(e4, nib[4], fmaf(e3, nib[3], fmaf(e2, nib[2], fmaf(e1, nib[1], e0 * nib[0]))));
+                } else {
 #pragma unroll
-                for (int q = 0; q < kn; ++q) { const float e = __expf(dist * nib[q]); kv += e; dk = fmaf(e, nib[q], dk); }
+                    for (int q = 0; q < kn; ++q) { const float ex = __expf(v * nib[q]); kv += ex; dk = fmaf(ex, nib[q], dk); }
+                }
                 const bool same = (i < n) == (j < n);
                 local += same ? kv : -kv;
-                L[i * m + j] = same ? dk : -dk;
+                gv[e] = same ? dk : -dk;
+                out[i * m + j] = gv[e];
+            }
+        }
+        if (offdiag && j < m) {                                        // the mirror tile: out[j][i..i+3]
+            const int64_t ib = i0 + wi + 8 * g4 + 4 * ka;
+            if (vecT && ib + 3 < m) *reinterpret_cast<float4*>(out + j * m + ib) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (ib + e < m) out[j * m + ib + e] = gv[e];
             }
         }
     }
+    if (offdiag) local *= 2.f;
     const double s = block_sum((double)local, red);
-    if (threadIdx.x == 0) kpartial[(int64_t)t * gridDim.x + blockIdx.x] = s;
+    if (tid == 0) partial[(int64_t)t * gridDim.x + blockIdx.x] = s;
 }
 
 __global__ void __launch_bounds__(TB)
@@ -284,7 +332,7 @@ k_finalize(const double* __restrict__ kpartial, int tiles_per_t, int times, int6
 }
 
 // --------------------------------------------------------------- backward --
-// With the weights g = dK/dL2 (block-signed) left in place of the distances by k_ksum, the
+// With the weights g = dK/dL2 (block-signed) written by the epilogue of k_pairdist, the
 // gradient w.r.t. the sampled rows is a matrix product plus a row scaling,
 //     grad_total[i,:] = 4 c ((sum_j g[i,j]) total[i,:] - sum_j g[i,j] total[j,:]),   c = dloss / (n^2 times),
 // run on the fp32 matrix cores.  Workgroup tile: 64 rows x 128 feature columns; wave w owns rows
@@ -431,7 +479,7 @@ k_bwd_reduce(const float* __restrict__ part, int64_t per_t, int nseg, int times,
 
 constexpr int BWD_NSEG = 4;        // measured: 2 -> 141+5 us, 4 -> 97+7, 8 -> 102+10, 16 -> 119+18 (k_bwd + k_bwd_reduce)
 
-struct MmdWs { double* partial; double* kpartial; float* bwd_part; size_t total; };
+struct MmdWs { double* kpartial; double* part_s1; float* part_col; float* bwd_part; size_t total; };
 
 MmdWs carve(void* base, int times, int64_t n, int64_t d) {
     const int64_t m = 2 * n, nt = gda_cdiv(m, TILE);
@@ -442,8 +490,10 @@ MmdWs carve(void* base, int times, int64_t n, int64_t d) {
         off += gda_align_up(bytes, 256);
         return p;
     };
-    w.partial = (double*)take(sizeof(double) * times * nt * nt);
+    const int64_t chunks = gda_cdiv(m, SR);
     w.kpartial = (double*)take(sizeof(double) * times * nt * nt);
+    w.part_s1 = (double*)take(sizeof(double) * times * chunks);
+    w.part_col = (float*)take(sizeof(float) * times * chunks * (d > 0 ? d : 1));
     w.bwd_part = (float*)take(sizeof(float) * times * BWD_NSEG * m * (d > 0 ? d : 1));
     w.total = off;
     return w;
@@ -488,14 +538,21 @@ extern "C" int gda_mmd_fwd_f32(const float* src, int64_t ld_src, const float* tg
     const unsigned nt = (unsigned)gda_cdiv(m, TILE);
     const Rows R = make_rows(src, ld_src, tgt, ld_tgt, src_idx, tgt_idx, n);
     const KParams kp{kernel_mul, kernel_num, fix_sigma};
-    const dim3 grid(nt, nt, (unsigned)times);
-    k_pairdist<<<grid, TB, 0, stream>>>(R, d, m, l2_saved, ws.partial);
+    const unsigned chunks = (unsigned)gda_cdiv(m, SR);
+    k_rowstats<<<dim3(chunks, (unsigned)times), TB, 0, stream>>>(R, d, m, ws.part_s1, ws.part_col);
     GDA_LAUNCH_CHECK();
-    const unsigned kgrid = (unsigned)(gda_cdiv(m, KS_ROWS) < 256 ? gda_cdiv(m, KS_ROWS) : 256);
-    if (kernel_num == 5) k_ksum<5><<<dim3(kgrid, (unsigned)times), TB, 0, stream>>>(l2_saved, m, n, kp, ws.partial, (int)(nt * nt), bandwidth, ws.kpartial);
-    else k_ksum<0><<<dim3(kgrid, (unsigned)times), TB, 0, stream>>>(l2_saved, m, n, kp, ws.partial, (int)(nt * nt), bandwidth, ws.kpartial);
+    k_bandwidth<<<(unsigned)times, TB, 0, stream>>>(ws.part_s1, ws.part_col, (int)chunks, d, m, kp, bandwidth);
     GDA_LAUNCH_CHECK();
-    k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, (int)kgrid, times, n, loss);
+    const unsigned ntri = nt * (nt + 1) / 2;
+    const dim3 grid(ntri, 1, (unsigned)times);
+    if (kernel_num == 5 && kernel_mul == 2.0f)
+        k_pairdist<5, true><<<grid, TB, 0, stream>>>(R, d, m, (int)nt, bandwidth, kp, l2_saved, ws.kpartial);
+    else if (kernel_num == 5)
+        k_pairdist<5, false><<<grid, TB, 0, stream>>>(R, d, m, (int)nt, bandwidth, kp, l2_saved, ws.kpartial);
+    else
+        k_pairdist<0, false><<<grid, TB, 0, stream>>>(R, d, m, (int)nt, bandwidth, kp, l2_saved, ws.kpartial);
+    GDA_LAUNCH_CHECK();
+    k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, (int)ntri, times, n, loss);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
