@@ -56,13 +56,13 @@ def make_cfg_a(seed=200, ns=9360, es=15556, nt=5484, et=8117, feat=6775, classes
     return graph(ns, es), graph(nt, et)
 
 
-def pmc_traffic(prefix="k_spmm<32, 4"):
+def pmc_traffic(prefix="k_spmm<32, 4", pattern="*_rocprof_summary.json"):
     """HBM-side bytes per launch of the aggregation kernel from the committed rocprofv3 PMC passes
     (profiles/*_rocprof_summary.json, made by tools/summarize_rocprof.py: separate --pmc FETCH_SIZE
     and --pmc WRITE_SIZE runs of this same command, 2 x FETCH + WRITE per the gfx950 correction).
     PMC counters cannot be collected from inside the timed run; None if no summary is present."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=os.path.getmtime)
     for f in reversed(files):
         try:
             pmc = json.load(open(f)).get("pmc", {})
@@ -78,10 +78,21 @@ def edges_per_step(nnz_s, nnz_t, L, s_p, t_p):
     return nnz_s * (4 * L * s_p + 2) + nnz_t * (3 * L * t_p + 1)
 
 
-def cpu_baseline(src, tgt, hp, edges):
-    """The CPU oracle (oracle/pygda_cpu.py, kind='port') on the same workload: one training
-    step (forward + backward + Adam), the reference's own op sequence incl. the [2000,2000,128]
-    MMD temporaries.  ~10-25 s of CPU work on 8+ cores."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(src, tgt, hp, edges, what="cfg-A"):
+    """The CPU oracle (oracle/pygda_cpu.py, kind='port') on the same workload: full training steps (forward
+    + backward + Adam), the reference's own op sequence incl. the [2000,2000,128] MMD temporaries.  One
+    untimed warm-up step (the first call pays the allocator's page faults on those 2 GB temporaries: SURVEY
+    6 measured ~10x), then ONE timed step: ~10-15 s each on the GPU box's host cores."""
     import psutil
     from oracle import pygda_cpu as O
     threads = torch.get_num_threads()
@@ -92,12 +103,57 @@ def cpu_baseline(src, tgt, hp, edges):
     chunk = None if psutil.virtual_memory().available > 48 * 2 ** 30 else 128
     t0 = time.perf_counter()
     O.a2gnn_train_step(net, opt, s, t, 0.0, hp["s_pnums"], hp["t_pnums"], False, hp["weight"], chunk)
+    warm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.a2gnn_train_step(net, opt, s, t, 0.0, hp["s_pnums"], hp["t_pnums"], False, hp["weight"], chunk)
     dt = time.perf_counter() - t0
-    return {"value": edges / dt, "unit": "edges/s", "cores": threads, "kind": "port",
+    return {"value": edges / dt, "unit": "edges/s", "cores": threads, "cpu": cpu_model(), "kind": "port",
             "edges_per_step": edges,
-            "sample": "1 full-batch A2GNN training step (fwd+bwd+Adam) of the same cfg-A workload, "
-                      f"{dt:.1f} s" + ("" if chunk is None else ", MMD temporaries row-chunked"),
-            "epochs_per_sec": 1.0 / dt}
+            "sample": f"1 timed A2GNN training step (fwd+bwd+Adam) of the same {what} workload after 1 untimed "
+                      f"warm-up step ({warm:.1f} s): {dt:.1f} s" + ("" if chunk is None else ", MMD temporaries row-chunked"),
+            "steps_per_sec": 1.0 / dt}
+
+
+def hbm_regime_probe(device, nodes=5_000_000, avg_degree=20, d=128, iters=5):
+    """The aggregation kernel where its roofline is HBM: ONE full-graph SpMM at BASELINE.json configs[4]'s
+    per-domain size (5 M nodes, 100 M directed edges + self loops, d = 128: the feature matrix alone is 2.56 GB,
+    ten times the Infinity Cache), timed with HIP events in this process.  `achieved` uses SURVEY 8(d)'s
+    algorithmic bytes nnz*8 + (N+1)*4 + 2*N*d*4; `gather_model_GBs` is the no-reuse figure nnz*(8+4d) + N*d*4
+    (uniform random neighbours share nothing, so every neighbour row is a distinct 512-byte read): the rate
+    the memory system actually sustains.  Counter traffic comes from the committed PMC passes of
+    tools/spmm_sweep.py --big (profiles/r2_spmm5m_rocprof_summary.json)."""
+    from pygda_amd import ops
+    from pygda_amd.graph import build_csr
+    gen = torch.Generator(device=device).manual_seed(200)
+    half = nodes * avg_degree // 2
+    a = torch.randint(0, nodes, (half,), generator=gen, device=device)
+    b = torch.randint(0, nodes, (half,), generator=gen, device=device)
+    ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
+    del a, b
+    G = build_csr(ei, nodes, validate=False)
+    nnz = G.nnz
+    x = torch.randn(nodes, d, device=device, generator=gen)
+    for _ in range(2):
+        y = ops.spmm_kstep(G, x, 1)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        y = ops.spmm_kstep(G, x, 1)
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / iters
+    alg = nnz * 8 + (nodes + 1) * 4 + 2 * nodes * d * 4
+    gather = nnz * (8 + 4 * d) + nodes * d * 4
+    traffic, src_file = pmc_traffic("k_spmm<32, 4", "r2_spmm5m*_summary.json")
+    del G, x, y, ei
+    torch.cuda.empty_cache()
+    return {"kernel": f"spmm_csr_f32[d={d}] (k_spmm<32,4>), N={nodes}, nnz={nnz}", "bound": "hbm",
+            "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src_file, "avg_launch_us": us, "launches": iters,
+            "algorithmic_bytes_per_launch": alg, "gather_model_bytes_per_launch": gather,
+            "gather_model_GBs": gather / us / 1e3, "gather_model_frac": gather / us / 1e3 / HBM_PEAK_GBS,
+            "timing": "HIP events on the launch stream, same process, after the timed region"}
 
 
 def make_cfg_s(nodes, avg_degree, feat, classes, seed, device):
@@ -170,6 +226,37 @@ def run_cfg_s(args, world, rank, dev):
     dt = time.perf_counter() - t0
     log, ops.aggregation_log = ops.aggregation_log, None
     edges = sum(g.nnz * k for g, k in log)
+    # roofline inputs: a short pass of the same steps with HIP events around every kernel family (the timed
+    # region above runs without them)
+    from pygda_amd import profiler
+    prof_steps = max(1, min(5, args.steps))
+    extra_seeds = prof_steps * args.batch * world
+    model.source_loader = NeighborLoader(src, fan, batch_size=args.batch,
+                                         input_nodes=torch.randint(0, args.nodes, (extra_seeds,), generator=gsel), **kw)
+    model.target_loader = NeighborLoader(tgt, fan, batch_size=args.batch,
+                                         input_nodes=torch.randint(0, args.nodes, (extra_seeds,), generator=gsel), **kw)
+    it = zip(iter(model.source_loader), iter(model.target_loader))
+    last = {}
+
+    def one_step_keep():
+        s, t = next(it)
+        last["s"], last["t"] = s, t
+        ops.dropout_state.next_step(s.x.device)
+        net.train()
+        loss, _ = step_fn(s, t, 0.0, 0)
+        optimizer.zero_grad()
+        loss.backward()
+        _allreduce_grads(optimizer)
+        optimizer.step()
+
+    one_step = one_step_keep
+    sync()
+    profiler.start()
+    for _ in range(prof_steps):
+        one_step()
+    sync()
+    profiler.stop()
+    prof = profiler.summary()
     if world > 1:
         t = torch.tensor([dt, float(edges)], device=dev, dtype=torch.float64)
         tm = t.clone()
@@ -177,7 +264,23 @@ def run_cfg_s(args, world, rank, dev):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt, edges = float(tm[0]), float(t[1])
     if rank == 0:
-        print(json.dumps({
+        def roof(name):
+            r = prof[name]
+            secs = r["ms"] * 1e-3
+            if name.startswith("spmm") or name.startswith("kstep_lds"):
+                ach = r["bytes"] / secs / 1e9
+                traffic, src_file = pmc_traffic("k_spmm<32, 4", "r2_cfgS*_summary.json") if "d=128" in name else (None, None)
+                return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src_file,
+                        "launches": r["launches"], "avg_launch_us": r["avg_us"],
+                        "algorithmic_bytes_per_launch": r["bytes"] / r["launches"]}
+            ach = r["flops"] / secs / 1e12
+            return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None, "launches": r["launches"],
+                    "avg_launch_us": r["avg_us"]}
+        cands = [k for k in prof if k.startswith("spmm") or k.startswith("dense") or k.startswith("kstep_lds")]
+        dominant = max(cands, key=lambda k: prof[k]["ms"])
+        out = {
             "metric": "edges_aggregated_per_sec", "value": edges / dt, "unit": "edges/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -189,7 +292,24 @@ def run_cfg_s(args, world, rank, dev):
                        "parallelism": "single GPU" if world == 1 else
                        f"dp{world}: disjoint seed mini-batches per rank, graph + features replicated, all-gathered "
                        "global-batch MMD rows, one flat RCCL gradient all-reduce per step"},
-            "steps_per_sec": args.steps / dt}))
+            "steps_per_sec": args.steps / dt,
+            "roofline": dict(roof(dominant), timing=f"HIP events on the launch stream, {prof_steps} extra steps after "
+                                                    "the timed region"),
+            "roofline_dense_projection": {k: roof(k) for k in sorted(prof) if k.startswith("dense_projection")},
+            "kernel_time_ms_per_step": {k: v["ms"] / prof_steps for k, v in sorted(prof.items())}}
+        if world == 1 and not args.no_cpu_baseline:
+            # the oracle's training step on ONE sampled batch pair of this run (its sub-graphs, its features)
+            sb, tb = last["s"], last["t"]
+            from pygda_amd.data import Data
+            cs = Data(x=sb.x.cpu(), edge_index=sb.edge_index.cpu(), y=sb.y.cpu())
+            ct = Data(x=tb.x.cpu(), edge_index=tb.edge_index.cpu(), y=tb.y.cpu())
+            from oracle import pygda_cpu as O
+            nnz_s = O.gcn_norm(cs.edge_index, None, cs.x.size(0))[0].size(1)
+            nnz_t = O.gcn_norm(ct.edge_index, None, ct.x.size(0))[0].size(1)
+            out["cpu_baseline"] = cpu_baseline(cs, ct, hp, edges_per_step(nnz_s, nnz_t, hp["L"], hp["s_pnums"],
+                                                                         hp["t_pnums"]),
+                                               what=f"cfg-S sampled batch pair ({cs.x.size(0)} + {ct.x.size(0)} nodes)")
+        print(json.dumps(out))
 
 
 def main():
@@ -198,6 +318,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-probe", action="store_true",
+                    help="skip the 5 M-node / 100 M-edge aggregation timed after the cfg-A region (roofline_hbm_regime)")
     ap.add_argument("--adv", action="store_true", help="adversarial branch instead of MMD")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
     ap.add_argument("--workload", default="cfgA", choices=["cfgA", "cfgS"],
@@ -318,9 +440,12 @@ def main():
         def roof(name):
             r = prof[name]
             secs = r["ms"] * 1e-3
-            if name.startswith("spmm"):
+            if name.startswith("spmm") or name.startswith("kstep_lds"):
                 ach = r["bytes"] / secs / 1e9
-                traffic, src_file = pmc_traffic() if "d=128" in name else (None, None)
+                if name.startswith("kstep_lds"):     # one launch = K aggregations whose operands never leave LDS
+                    traffic, src_file = pmc_traffic("k_kstep_lds", "r2*_rocprof_summary.json")
+                else:
+                    traffic, src_file = pmc_traffic() if "d=128" in name else (None, None)
                 return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src_file,
                         "launches": r["launches"],
@@ -330,9 +455,9 @@ def main():
                     "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None, "launches": r["launches"],
                     "avg_launch_us": r["avg_us"]}
 
-        cands = [k for k in prof if k.startswith("spmm") or k.startswith("dense")]
+        cands = [k for k in prof if k.startswith("spmm") or k.startswith("kstep_lds") or k.startswith("dense")]
         dominant = max(cands, key=lambda k: prof[k]["ms"])
-        agg = max((k for k in prof if k.startswith("spmm")), key=lambda k: prof[k]["ms"])
+        agg = max((k for k in prof if k.startswith("spmm") or k.startswith("kstep_lds")), key=lambda k: prof[k]["ms"])
         out = {
             "metric": "edges_aggregated_per_sec", "value": world * executed * args.steps / dt, "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -367,6 +492,12 @@ def main():
             "roofline_dense_projection": {k: roof(k) for k in sorted(prof) if k.startswith("dense_projection")},
             "kernel_time_ms_per_step": {k: v["ms"] / args.steps for k, v in sorted(prof.items())},
         }
+        if world == 1 and not args.no_hbm_probe:
+            # cfg-A's graphs are cache resident, so the HBM fraction above says little about the kernel:
+            # the same aggregation kernel timed at configs[4]'s per-domain size, where HBM is the bound
+            del model, state
+            torch.cuda.empty_cache()
+            out["roofline_hbm_regime"] = hbm_regime_probe(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(src, tgt, hp, edges)
         print(json.dumps(out))

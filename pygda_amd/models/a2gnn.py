@@ -30,6 +30,7 @@ class A2GNN(BaseGDA):
         self.compute_target_logits = True
         import os
         self.overlap_streams = os.environ.get("PYGDA_AMD_OVERLAP", "1") == "1"
+        self._source_late = int(os.environ.get("PYGDA_AMD_SRC_LATE", "0"))
 
     def init_model(self, **kwargs):
         return A2GNNBase(in_dim=self.in_dim, hid_dim=self.hid_dim, num_classes=self.num_classes,
@@ -79,17 +80,36 @@ class A2GNN(BaseGDA):
                 if quiet is not None:
                     quiet(False)
             src_stream.wait_stream(main)
-        with (torch.cuda.stream(src_stream) if fork else _null()):
+        def source_branch():
             h0_s = net.first_conv(source_data.x, source_data.edge_index, self.s_pnums)
             feats = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)
             source_logits = net.feat_classifier(feats, source_data.edge_index, sb, 1)        # :181
             loss = self._gmean(source_ce(source_logits, source_data.y), source_logits.size(0))   # :182, fused
             source_features = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)   # :192
-        h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
-        pending = None
-        if self.compute_target_logits and fork:
-            pending = self._target_logits_async(net, target_data, h0_t)
-        target_features = net.feat_bottleneck_from(h0_t, target_data.edge_index, tb, self.t_pnums)   # :193
+            return loss, source_logits, source_features
+
+        def target_branch():
+            h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
+            pending = None
+            if self.compute_target_logits and fork:
+                pending = self._target_logits_async(net, target_data, h0_t)
+            target_features = net.feat_bottleneck_from(h0_t, target_data.edge_index, tb, self.t_pnums)   # :193
+            return h0_t, pending, target_features
+
+        # issue order = node order of the captured graph: the longer (target) branch first when forked
+        late = fork and self._source_late
+        if late == 1:
+            h0_t, pending, target_features = target_branch()
+        elif late == 2:      # fork the source branch from INSIDE the target chain (after its first conv)
+            h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
+            src_stream.wait_stream(main)
+        with (torch.cuda.stream(src_stream) if fork else _null()):
+            loss, source_logits, source_features = source_branch()
+        if late == 2:
+            pending = self._target_logits_async(net, target_data, h0_t) if self.compute_target_logits else None
+            target_features = net.feat_bottleneck_from(h0_t, target_data.edge_index, tb, self.t_pnums)
+        elif not late:
+            h0_t, pending, target_features = target_branch()
         if fork:
             main.wait_stream(src_stream)                                                 # join
             for t in (loss, source_logits, source_features):

@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--bench")
     ap.add_argument("--out", default="profiles")
+    ap.add_argument("--cmd", default=None, help="the profiled command, for the record")
+    ap.add_argument("--largest-grid", action="store_true",
+                    help="PMC: per kernel keep only the dispatches with the largest grid (a sweep's biggest case)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     lines = [f"# rocprofv3 summary `{a.tag}`", ""]
@@ -43,10 +46,13 @@ def main():
         if txt:
             b = json.loads(txt[-1])
             result["bench"] = b
-            lines += ["Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
-                      f"--steps {b['steps']} --warmup {b['warmup']} --no-cpu-baseline`", "",
+            cmd = a.cmd or f"python bench.py --steps {b['steps']} --warmup {b['warmup']} --no-cpu-baseline"
+            lines += [f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}`", "",
                       f"bench line under the profiler: {b['ms_per_step']:.3f} ms/step, "
                       f"{b['value']:.4g} {b['unit']}", ""]
+    if a.cmd and not (a.bench and os.path.exists(a.bench)):
+        lines += [f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- {a.cmd}` "
+                  "(PMC passes: the same command under `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`)", ""]
     if a.stats:
         f = find(a.stats, "kernel_stats.csv")
         rows = list(csv.DictReader(open(f)))
@@ -68,22 +74,28 @@ def main():
             continue
         f = find(d, "counter_collection.csv")
         agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter:
-                agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        rows_c = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+        biggest = collections.defaultdict(int)
+        for r in rows_c:
+            biggest[short(r["Kernel_Name"])] = max(biggest[short(r["Kernel_Name"])], int(r["Grid_Size"]))
+        for r in rows_c:
+            if a.largest_grid and int(r["Grid_Size"]) != biggest[short(r["Kernel_Name"])]:
+                continue
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             pmc.setdefault(k, {})[counter] = dict(launches=len(v), avg_kib=sum(v) / len(v))
     if pmc:
         lines += ["## HBM-side traffic per launch (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes)", "",
                   "FETCH_SIZE/WRITE_SIZE are KiB at the L2's fabric side (Infinity-Cache hits included). "
                   "`traffic` = 2 x FETCH + WRITE for kernels with 16 B/lane loads (gfx950 correction), "
-                  "FETCH + WRITE otherwise.", "",
+                  "FETCH + WRITE otherwise." + (" Per kernel only the dispatches with the LARGEST grid are averaged "
+                                                "(the sweep's biggest case)." if a.largest_grid else ""), "",
                   "| kernel | launches | FETCH KiB | WRITE KiB | traffic MB/launch |", "|---|---|---|---|---|"]
         ours = {}
         for k, v in sorted(pmc.items(), key=lambda kv: -(kv[1].get("FETCH_SIZE", {}).get("avg_kib", 0) *
                                                          kv[1].get("FETCH_SIZE", {}).get("launches", 0)))[:25]:
             fe, wr = v.get("FETCH_SIZE", {}).get("avg_kib", 0.0), v.get("WRITE_SIZE", {}).get("avg_kib", 0.0)
-            wide = k.startswith("k_spmm<") and k.split(",")[1].strip().startswith("4")
+            wide = (k.startswith("k_spmm<") and k.split(",")[1].strip().startswith("4")) or k.startswith("k_kstep_lds")
             traffic = ((2 if wide else 1) * fe + wr) * 1024
             n = v.get("FETCH_SIZE", v.get("WRITE_SIZE"))["launches"]
             lines.append(f"| `{k}` | {n} | {fe:.1f} | {wr:.1f} | {traffic/1e6:.3f} |")
