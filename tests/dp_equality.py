@@ -45,7 +45,7 @@ def inject_oracle():
     def _graph(self, x, edge_index, edge_weight):
         return O.gcn_norm(edge_index, edge_weight, x.size(0))
 
-    def propagate(x, graph, K=1, bias=None):
+    def propagate(x, graph, K=1, bias=None, colmajor_out=False):
         ei, w = graph
         for _ in range(K):
             x = O.propagate(ei, w, x)
