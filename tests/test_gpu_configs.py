@@ -284,3 +284,56 @@ def test_grade_nominal_width_vs_oracle(disc):
         # fp32 summation-order noise proportional to the sum of magnitudes (the oracle's own CPU sums are
         # order dependent at this level); 1e-3 of the gradient's largest entry
         close(p.grad, v, rtol=1e-3, atol=1e-3 * max(float(v.abs().max()), 1e-3))
+
+
+# ------------------------------------------------ a11 / f2: device PPMI builder vs the oracle --
+def test_device_ppmi_builder_matches_oracle_statistically():
+    """csrc/gda_ppmi_dev.hip (walks + radix sorts + run-length counts on the GPU) against the oracle's replay
+    of ppmi_conv.py:98-169.  The generators differ, so parity is statistical -- the method of
+    tests/test_sampler_host.py for the host builder, applied to the device builder: with many passes the
+    device estimator is as close to the reference algorithm as two runs of the reference are to each other
+    (the noise ceiling), and at the reference's 40 passes the support size and weight statistics agree."""
+    from pygda_amd.nn.ppmi_conv import ppmi_edges
+    g = torch.Generator().manual_seed(5)
+    n = 120
+    ei = torch.randint(0, n - 1, (2, 260), generator=g)          # node n-1 isolated
+    ei = ei[:, ei[0] != ei[1]]
+
+    def as_dict(e, w):
+        return {(int(a), int(b)): float(x) for (a, b), x in zip(e.t().tolist(), w.tolist())}
+
+    def agreement(x, y):
+        common = [k for k in x if k in y and (x[k] > 0 or y[k] > 0)]
+        a, b = np.array([x[k] for k in common]), np.array([y[k] for k in common])
+        return np.corrcoef(a, b)[0, 1], len(common), a.mean(), b.mean()
+
+    np.random.seed(0)
+    ref = as_dict(*O.ppmi_raw_edges(ei, path_len=5, passes=600))
+    np.random.seed(7)
+    ref2 = as_dict(*O.ppmi_raw_edges(ei, path_len=5, passes=600))
+    dev_e, dev_w = ppmi_edges(ei.to(DEV), n, path_len=5, passes=600, seed=1)
+    assert dev_e.is_cuda                                           # the device builder ran
+    mine = as_dict(dev_e.cpu(), dev_w.cpu())
+    ceiling, _, _, _ = agreement(ref, ref2)
+    corr, n_common, ma_, mb_ = agreement(ref, mine)
+    assert n_common > 200 and ceiling > 0.95
+    assert corr > ceiling - 0.02
+    assert abs(ma_ - mb_) < 0.03 * ma_
+    np.random.seed(1)
+    r40 = as_dict(*O.ppmi_raw_edges(ei, path_len=5))
+    e40, w40 = ppmi_edges(ei.to(DEV), n, path_len=5, seed=2)
+    m40 = as_dict(e40.cpu(), w40.cpu())
+    ra, ma = np.array(list(r40.values())), np.array(list(m40.values()))
+    assert abs(len(r40) - len(m40)) < 0.05 * len(r40)
+    assert abs((ra > 0).mean() - (ma > 0).mean()) < 0.05
+    assert abs(ra[ra > 0].mean() - ma[ma > 0].mean()) < 0.08 * ra[ra > 0].mean()
+    assert all(a != n - 1 and b != n - 1 for a, b in m40)
+    # the normalised PPMI operator PPMIConv aggregates with: device build vs oracle ppmi_norm, same statistics
+    from pygda_amd.nn import PPMIConv
+    conv = PPMIConv(4, 4, path_len=5).to(DEV)
+    np.random.seed(11)
+    nei, nw = conv.norm(ei.to(DEV), n)
+    np.random.seed(12)
+    oei, ow = O.ppmi_norm(ei, n, path_len=5)
+    assert abs(nei.size(1) - oei.size(1)) < 0.05 * oei.size(1)
+    assert abs(float(nw.sum()) - float(ow.sum())) < 0.05 * float(ow.sum())
