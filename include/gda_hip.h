@@ -266,6 +266,27 @@ int gda_grl_disc_ce_bwd_f32(const float* feat_src, int64_t ld_src, int64_t n_src
 size_t gda_grl_disc_workspace_bytes(int64_t n_rows, int64_t h, int C);
 
 /* ------------------------------------------------------------------------------
+ * Wasserstein critic update with gradient penalty (WGAN-GP), loss and parameter gradients in closed form
+ * (csrc/gda_critic.hip).  Replaces the body of AdaGCN's critic loop, pygda/models/adagcn.py:169-183 with
+ * gradient_penalty (:387-454), for the critic built at :264-270:
+ *     D(x) = sigmoid(w2 . dropout_p(relu(W1 x + b1)) + b2),   W1 [a, h] row-major, b1 [a], w2 [a], b2 [1]
+ *     loss = -| mean D(es) - mean D(et) | + gp_weight * mean_i (|| grad_x D(x_i) ||_2 - 1)^2,
+ *     x_i over cat(es, et, interpolates),  interpolates_i = et[idx_t[i]] + alpha[i] * (es[idx_s[i]] - et[idx_t[i]])
+ * es [n_s, h], et [n_t, h] contiguous; idx_s / idx_t int32 [n_i], alpha [n_i] (the reference draws it from the
+ * host generator).  The three critic evaluations (on es, on et, on the penalty rows) draw independent dropout
+ * masks from Philox keyed on (seed, step[0], site + {0, 1, 2}); dropout_p = 0 needs no step.  Outputs: loss [1]
+ * and the gradients gW1 [a, h], gb1 [a], gw2 [a], gb2 [1] of that loss (deterministic reductions).
+ * h <= 256, h % 4 == 0, a <= 64.
+ * ---------------------------------------------------------------------------- */
+size_t gda_wgan_critic_workspace_bytes(int64_t n_s, int64_t n_t, int64_t n_i, int h, int a);
+int gda_wgan_critic_f32(const float* es, int64_t n_s, const float* et, int64_t n_t, int h,
+                        const int32_t* idx_s, const int32_t* idx_t, const float* alpha, int64_t n_i,
+                        const float* W1, const float* b1, const float* w2, const float* b2, int a,
+                        float dropout_p, uint64_t seed, const int64_t* step, uint32_t site,
+                        float gp_weight, float* loss, float* gW1, float* gb1, float* gw2, float* gb2,
+                        void* workspace, size_t workspace_bytes, gda_stream_t stream);
+
+/* ------------------------------------------------------------------------------
  * ReLU + inverted dropout, fused (the activation after every conv layer:
  * pygda/nn/a2gnn_base.py:135-138, grade_base.py:146-148, gnn_base.py:166-168).
  *   forward : y = (x > 0 && keep) ? x/(1-p) : 0, keep-bits from Philox-4x32-10 keyed on `seed`

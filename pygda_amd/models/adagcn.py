@@ -26,6 +26,8 @@ class AdaGCN(BaseGDA):
         self.gnn_type, self.adv_dim, self.gp_weight = gnn_type, adv_dim, gp_weight
         self.domain_weight, self.mode = domain_weight, mode
         self.critic_steps = 10                                                        # :169
+        import os
+        self.use_fused_critic = os.environ.get("PYGDA_AMD_FUSED_CRITIC", "1") == "1"
 
     def init_model(self, **kwargs):
         return AdaGCNBase(in_dim=self.in_dim, hid_dim=self.hid_dim, num_classes=self.num_classes,
@@ -37,11 +39,65 @@ class AdaGCN(BaseGDA):
         return self._gmean(torch.mean(self.discriminator(es).reshape(-1)), es.size(0)) \
             - self._gmean(torch.mean(self.discriminator(et).reshape(-1)), et.size(0))
 
+    def _fused_critic(self, es):
+        """The closed-form critic update (csrc/gda_critic.hip) applies: the reference's critic
+        (Linear -> ReLU -> Dropout -> Linear(., 1) -> Sigmoid) on the GPU, means taken over this process's rows."""
+        d = self.discriminator
+        from ..distributed import active
+        if active() and not getattr(getattr(self, "source_loader", None), "full_batch", False):
+            return False                      # node-count weighted global means: the composed path
+        return (es.is_cuda and isinstance(d, nn.Sequential) and len(d) == 5 and isinstance(d[0], nn.Linear)
+                and isinstance(d[1], nn.ReLU) and isinstance(d[2], nn.Dropout) and isinstance(d[3], nn.Linear)
+                and isinstance(d[4], nn.Sigmoid) and d[3].out_features == 1 and d[0].in_features % 4 == 0
+                and d[0].in_features <= 256 and d[0].out_features <= 64 and self.use_fused_critic)
+
+    def _interp_indices(self, num_s, num_t, dev):
+        """Row pairs of the interpolates (:423-434): the smaller domain twice against the head and the tail
+        of the larger one."""
+        key = (num_s, num_t, str(dev))
+        if not hasattr(self, "_interp_cache"):
+            self._interp_cache = {}
+        hit = self._interp_cache.get(key)
+        if hit is None:
+            m = min(num_s, num_t)
+            if num_s == num_t:
+                i_s = i_t = torch.arange(m)
+            elif num_s < num_t:
+                i_s = torch.cat([torch.arange(m), torch.arange(m)])
+                i_t = torch.cat([torch.arange(m), torch.arange(num_t - m, num_t)])
+            else:
+                i_s = torch.cat([torch.arange(m), torch.arange(num_s - m, num_s)])
+                i_t = torch.cat([torch.arange(m), torch.arange(m)])
+            hit = (i_s.to(torch.int32).to(dev), i_t.to(torch.int32).to(dev))
+            self._interp_cache[key] = hit
+        return hit
+
+    def _critic_update_fused(self, es, et):
+        from ..hipgraph import host_rand
+        from ..ops import wgan_critic_grads
+        d = self.discriminator
+        idx_s, idx_t = self._interp_indices(es.size(0), et.size(0), es.device)
+        alpha = host_rand((idx_s.numel(), 1), es.device)                            # the reference's CPU draw
+        params = (d[0].weight, d[0].bias, d[3].weight, d[3].bias)
+        for p in params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        if getattr(self, "_critic_loss", None) is None or self._critic_loss.device != es.device:
+            self._critic_loss = torch.zeros(1, dtype=torch.float32, device=es.device)
+        p_drop = d[2].p if d.training else 0.0
+        wgan_critic_grads(es, et, idx_s, idx_t, alpha, *params, p_drop, self.gp_weight,
+                          (self._critic_loss, *(p.grad for p in params)))
+        _allreduce_grads(self.c_optimizer)       # data-parallel: replica critics stay identical
+        self.c_optimizer.step()
+
     def forward_model(self, source_data, target_data):
         for _ in range(self.critic_steps):                                            # :169-183
             with torch.no_grad():
                 encoded_source = self.adagcn(source_data)
                 encoded_target = self.adagcn(target_data)
+            if self._fused_critic(encoded_source):
+                self._critic_update_fused(encoded_source, encoded_target)
+                continue
             gp_loss = self.gradient_penalty(encoded_source, encoded_target)
             loss = -torch.abs(self._critic_gap(encoded_source, encoded_target)) + self.gp_weight * gp_loss
             self.c_optimizer.zero_grad()

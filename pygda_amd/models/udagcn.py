@@ -72,7 +72,16 @@ class UDAGCN(BaseGDA):
         # path then updates them twice per step, one after the other.  torch's multi-tensor CUDA kernels would
         # process the two list entries concurrently (one racy update): the per-tensor loop keeps the CPU
         # path's semantics.
-        optimizer = torch.optim.Adam(params, lr=self.lr, weight_decay=self.weight_decay, foreach=False)
+        if torch.device(self.device).type == "cuda":
+            # one capturable multi-tensor launch per round of duplicates (pygda_amd/optim.py): the second listing
+            # of a shared Parameter is updated after the first, as in the per-tensor loop
+            from ..optim import Adam
+            optimizer = Adam(list(params), lr=self.lr, weight_decay=self.weight_decay)
+            # the step's per-epoch scalars (GRL alpha, entropy weight) reach the kernels as 0-dim device tensors
+            # refreshed before every replay: the full-batch step replays as a hipGraph
+            self._graph_safe_step, self._graph_uses_scalars = True, True
+        else:
+            optimizer = torch.optim.Adam(params, lr=self.lr, weight_decay=self.weight_decay, foreach=False)
 
         def step(src, tgt, alpha, epoch):
             loss, source_logits, _ = self.forward_model(src, tgt, alpha, epoch)

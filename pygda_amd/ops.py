@@ -568,6 +568,34 @@ def grl_disc_ce(source_feat, target_feat, weight, bias, alpha, labels=None):
     return _GrlDiscCE.apply(source_feat, target_feat, weight, bias, alpha, labels)
 
 
+# ------------------------------------------- Wasserstein critic update (WGAN-GP), fused --
+def wgan_critic_grads(es, et, idx_s, idx_t, alpha, W1, b1, W2, b2, dropout_p, gp_weight, out):
+    """Loss and parameter gradients of one critic update of AdaGCN (pygda/models/adagcn.py:169-183,387-454)
+    in closed form (include/gda_hip.h: gda_wgan_critic_f32): ``out = (loss [1], gW1, gb1, gW2, gb2)``
+    preallocated like the parameters -- the gradients land where the critic's optimiser reads them."""
+    es, et = _f32c(es, "encoded_source"), _f32c(et, "encoded_target")
+    n_s, h = es.shape
+    n_t = et.size(0)
+    a = W1.size(0)
+    n_i = 0 if idx_s is None else idx_s.numel()
+    L = _lib.lib()
+    ws = _lib.workspace(L.gda_wgan_critic_workspace_bytes(n_s, n_t, n_i, h, a), es.device, "critic")
+    st = dropout_state
+    if st.seed is None:
+        st.seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+    site = st.next_site()
+    st.next_site(); st.next_site()                          # three mask sets: D(es), D(et), penalty rows
+    loss, gW1, gb1, gW2, gb2 = out
+    _lib.check(L.gda_wgan_critic_f32(
+        _lib.ptr(es), n_s, _lib.ptr(et), n_t, h, _lib.ptr(idx_s), _lib.ptr(idx_t),
+        _lib.ptr(None if alpha is None else _f32c(alpha, "alpha")), n_i,
+        _lib.ptr(_f32c(W1, "W1")), _lib.ptr(_f32c(b1, "b1")), _lib.ptr(_f32c(W2, "W2")), _lib.ptr(_f32c(b2, "b2")), a,
+        float(dropout_p), ctypes.c_uint64(st.seed), _lib.ptr(st.counter(es.device)), ctypes.c_uint32(site),
+        float(gp_weight), _lib.ptr(loss), _lib.ptr(gW1), _lib.ptr(gb1), _lib.ptr(gW2), _lib.ptr(gb2),
+        _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_wgan_critic_f32")
+    return loss
+
+
 # -------------------------------------------------------------------------- gather --
 def gather_rows(x, idx):
     """``x[idx]`` for a ``[N, d]`` fp32 feature matrix (mini-batch assembly)."""

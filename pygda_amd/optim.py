@@ -34,9 +34,21 @@ class Adam(torch.optim.Optimizer):
                 loss = closure()
         L = _lib.lib()
         for group in self.param_groups:
-            live = [p for p in group["params"] if p.grad is not None]
-            for i in range(0, len(live), MAX_TENSORS):
-                chunk = live[i:i + MAX_TENSORS]
+            # A Parameter listed twice (UDAGCN / SpecReg hand the optimiser the conv weights their two
+            # encoders share twice, pygda/models/udagcn.py:262-268) is updated twice per step, one update after
+            # the other, by torch's per-tensor CPU loop.  The k-th occurrence of every tensor goes into the k-th
+            # round of launches: rounds run in stream order, so the second update sees the first one's result.
+            rounds, seen = [], {}
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                k = seen.get(id(p), 0)
+                seen[id(p)] = k + 1
+                while len(rounds) <= k:
+                    rounds.append([])
+                rounds[k].append(p)
+            chunks = [r[i:i + MAX_TENSORS] for r in rounds for i in range(0, len(r), MAX_TENSORS)]
+            for chunk in chunks:
                 table = (_lib.AdamTensorStruct * len(chunk))()
                 keep = []
                 for k, p in enumerate(chunk):

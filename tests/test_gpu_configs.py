@@ -337,3 +337,78 @@ def test_device_ppmi_builder_matches_oracle_statistically():
     oei, ow = O.ppmi_norm(ei, n, path_len=5)
     assert abs(nei.size(1) - oei.size(1)) < 0.05 * oei.size(1)
     assert abs(float(nw.sum()) - float(ow.sum())) < 0.05 * float(ow.sum())
+
+
+# ------------------------------------------- a14: fused Wasserstein critic update (WGAN-GP) --
+@pytest.mark.parametrize("ns,nt", [(300, 420), (500, 260), (256, 256)])
+def test_wgan_critic_fused_vs_autograd(ns, nt):
+    """csrc/gda_critic.hip against the composed torch path of the reference's critic update (adagcn.py:169-183
+    with gradient_penalty :387-454; double backward through autograd): loss and all four parameter gradients,
+    for the three size rules of the interpolates, same host draws of the interpolation weights."""
+    import torch.nn as nn
+    m = pygda_amd.models.AdaGCN(16, 128, 3, num_layers=2, adv_dim=40, gp_weight=5, domain_weight=1, device=DEV,
+                                epoch=1, verbose=0)
+    torch.manual_seed(3)
+    m.discriminator = nn.Sequential(nn.Linear(128, 40), nn.ReLU(), nn.Dropout(0.0), nn.Linear(40, 1), nn.Sigmoid()).to(DEV)
+    with torch.no_grad():
+        m.discriminator[0].weight.mul_(2.0)                      # gradient norms on both sides of 1
+    gen = torch.Generator().manual_seed(ns)
+    es = torch.randn(ns, 128, generator=gen).relu().to(DEV)
+    et = (torch.randn(nt, 128, generator=gen) * 1.2 + 0.1).relu().to(DEV)
+    # composed path
+    torch.manual_seed(17)
+    gp = m.gradient_penalty(es, et)
+    loss = -torch.abs(m._critic_gap(es, et)) + m.gp_weight * gp
+    m.discriminator.zero_grad()
+    loss.backward()
+    want = [p.grad.clone() for p in m.discriminator.parameters()]
+    # fused path: same CPU generator state -> same interpolation weights
+    from pygda_amd.ops import wgan_critic_grads
+    torch.manual_seed(17)
+    idx_s, idx_t = m._interp_indices(ns, nt, torch.device(DEV))
+    alpha = torch.rand(idx_s.numel(), 1).to(DEV)
+    d = m.discriminator
+    out = (torch.zeros(1, device=DEV),) + tuple(torch.full_like(p, 7.0) for p in d.parameters())
+    wgan_critic_grads(es, et, idx_s, idx_t, alpha, d[0].weight, d[0].bias, d[3].weight, d[3].bias, 0.0, m.gp_weight, out)
+    close(out[0][0], loss, rtol=1e-4, atol=1e-6)
+    for got, w in zip(out[1:], want):
+        close(got, w, rtol=2e-3, atol=2e-5 * max(float(w.abs().max()), 1e-3))
+    # dropout inside the critic: masks are a pure function of (seed, step, site): reproducible, and they matter
+    from pygda_amd.ops import dropout_state
+    outs = []
+    for _ in range(2):
+        dropout_state.counter(es.device).fill_(5); dropout_state.site = 0
+        o = (torch.zeros(1, device=DEV),) + tuple(torch.zeros_like(p) for p in d.parameters())
+        wgan_critic_grads(es, et, idx_s, idx_t, alpha, d[0].weight, d[0].bias, d[3].weight, d[3].bias, 0.1, m.gp_weight, o)
+        outs.append(o)
+    exact(outs[0][1], outs[1][1]); exact(outs[0][0], outs[1][0])
+    assert bool((outs[0][1] != out[1]).any()) and bool(torch.isfinite(outs[0][1]).all())
+
+
+def test_adagcn_fused_critic_trajectory_equals_composed(monkeypatch):
+    """AdaGCN.fit for three epochs with the fused critic update against the composed (torch autograd) one: same
+    host draws, dropout off -> same losses, accuracies and critic weights."""
+    import torch.nn as nn
+    g = load_golden("grade_adagcn_fit3")
+    s, t = _pair(g)
+    orig = nn.Dropout.__init__
+    monkeypatch.setattr(nn.Dropout, "__init__", lambda self, p=0.5, inplace=False: orig(self, 0.0, inplace))
+
+    def run(fused):
+        monkeypatch.setenv("PYGDA_AMD_FUSED_CRITIC", "1" if fused else "0")
+        m = pygda_amd.models.AdaGCN(12, 8, 3, num_layers=2, dropout=0.0, adv_dim=6, gp_weight=5, domain_weight=1,
+                                    lr=0.01, device=DEV, epoch=3, verbose=0, use_hip_graph=False)
+        seen = []
+        m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+        torch.manual_seed(int(g["seed"]))
+        m.fit(s, t)
+        return seen, m.predict(t)[0], [p.detach().clone() for p in m.discriminator.parameters()], m
+
+    f_seen, f_logits, f_disc, fm = run(True)
+    c_seen, c_logits, c_disc, _ = run(False)
+    assert fm._fused_critic(torch.zeros(4, 8, device=DEV))
+    close([x[0] for x in f_seen], [x[0] for x in c_seen], rtol=1e-4)
+    close(f_logits, c_logits, rtol=0, atol=LOGIT_ATOL)
+    for a, b in zip(f_disc, c_disc):
+        close(a, b, rtol=1e-3, atol=1e-5)
+    close([x[0] for x in f_seen], g["adagcn/losses"], rtol=REL)
