@@ -3,7 +3,11 @@ penalty (10 critic updates per encoder update), then source CE + domain_weight *
 E D(t)|.  The encoder runs on the MI355X aggregation kernels; the critic is a 3-layer MLP
 whose double backward (gradient penalty) stays in torch autograd.
 
-One saving over the reference with identical results: inside the critic loop the encoder
+The critic update (loss, gradient penalty and all four parameter gradients) runs as the fused closed-form
+kernels of csrc/gda_critic.hip; the composed torch-autograd form is kept for critics of another shape.
+
+Savings over the reference with identical results: the encoder's first conv is evaluated once per domain
+and step (it is deterministic) and shared by the 11 encoder passes; inside the critic loop the encoder
 outputs are detached.  The reference back-propagates the critic loss into the encoder ten
 times per step and then discards those gradients (``optimizer.zero_grad()`` at :292 precedes
 the only encoder step), i.e. 10 x L wasted backward aggregations per domain."""
@@ -91,10 +95,13 @@ class AdaGCN(BaseGDA):
         self.c_optimizer.step()
 
     def forward_model(self, source_data, target_data):
+        net = self.adagcn
+        # the first conv of the encoder (projection + aggregation, nothing random) once per domain and step
+        h0_s, h0_t = net.first_conv(source_data), net.first_conv(target_data)
         for _ in range(self.critic_steps):                                            # :169-183
             with torch.no_grad():
-                encoded_source = self.adagcn(source_data)
-                encoded_target = self.adagcn(target_data)
+                encoded_source = net.forward_from(h0_s.detach(), source_data)
+                encoded_target = net.forward_from(h0_t.detach(), target_data)
             if self._fused_critic(encoded_source):
                 self._critic_update_fused(encoded_source, encoded_target)
                 continue
@@ -104,8 +111,8 @@ class AdaGCN(BaseGDA):
             loss.backward()
             _allreduce_grads(self.c_optimizer)       # data-parallel: replica critics stay identical
             self.c_optimizer.step()
-        encoded_source = self.adagcn(source_data)                                     # :186-196
-        encoded_target = self.adagcn(target_data)
+        encoded_source = net.forward_from(h0_s, source_data)                          # :186-196
+        encoded_target = net.forward_from(h0_t, target_data)
         source_logits = self.adagcn.cls_model(encoded_source)
         cls_loss = self._gmean(self.adagcn.loss_func(source_logits, source_data.y), source_logits.size(0))
         dis_loss = torch.abs(self._critic_gap(encoded_source, encoded_target))

@@ -20,9 +20,18 @@ class GNN(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x, edge_index, batch, mode='node'):
+        return self.forward_from(self.conv_layers[0](x, edge_index), edge_index, batch, mode)
+
+    def forward_from(self, h0, edge_index, batch, mode='node'):
+        """The stack continued from the output of its first conv (before activation / dropout).  That output
+        is a deterministic function of the inputs and the weights, so the trainer evaluates it once per domain
+        and step and shares it between the 11 encoder passes the reference makes per step (10 inside the critic
+        loop, 1 for the encoder update): same values, 20 first-layer projections + aggregations fewer."""
+        x = h0
         last = len(self.conv_layers) - 1
         for i, conv in enumerate(self.conv_layers):
-            x = conv(x, edge_index)
+            if i > 0:
+                x = conv(x, edge_index)
             if i < last:
                 x = self.dropout(self.act(x))
         return global_mean_pool(x, batch) if mode == 'graph' else x
@@ -40,3 +49,10 @@ class AdaGCNBase(nn.Module):
     def forward(self, data):
         batch = None if self.mode == 'node' else data.batch
         return self.encoder(data.x, data.edge_index, batch, mode=self.mode)
+
+    def first_conv(self, data):
+        return self.encoder.conv_layers[0](data.x, data.edge_index)
+
+    def forward_from(self, h0, data):
+        batch = None if self.mode == 'node' else data.batch
+        return self.encoder.forward_from(h0, data.edge_index, batch, mode=self.mode)
