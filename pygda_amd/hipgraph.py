@@ -261,16 +261,19 @@ class GraphedStep:
             _mmd.sample_provider, _mmd.dp_index_provider, host_rand_provider = prev, prev_dp, prev_rand
         return self
 
+    def _replay(self):
+        self.graph.replay()
+
     def __call__(self):
         self._refill()
-        self.graph.replay()
+        self._replay()
         return self.loss, self.logits
 
     # -- pipelined epochs: launch step e+1 before reading the numbers of step e --------------
     def launch(self):
         """Refill + replay + asynchronous read-back of (loss, correct); returns a ticket."""
         self._refill()
-        self.graph.replay()
+        self._replay()
         k = self._stat_turn
         self._stat_turn = 1 - k
         self._stat_pins[k].copy_(self.stats, non_blocking=True)
@@ -285,6 +288,120 @@ class GraphedStep:
         loss, correct = self._stat_pins[ticket].tolist()
         n = self.src.y.numel()
         return loss, (correct / n if n else 0.0)
+
+
+class GraphedStepSplit(GraphedStep):
+    """The step as THREE hipGraphs: source forward (stream A) and target forward (stream B) replayed at the same
+    time, then -- on the main stream -- domain loss, epoch statistics, backward through both tapes and the
+    optimiser step.
+
+    Why: on this runtime a forked capture replays with 5-6 us of spacing per kernel and runs branches forked at
+    its root one after the other (tools/graph_fork_*.py) -- the one-graph A2GNN step spends the first
+    110 us on the source branch alone.  Single-branch graphs replay gap-free through pre-built AQL packets, and two
+    graph launches on two streams do overlap.  Autograd's tape spans the captures (the technique of
+    torch.cuda.make_graphed_callables and of GraphedStepDP): the forward graphs keep their outputs and saved
+    tensors alive in their own pools, the third capture walks the tape backwards (autograd runs each node on its
+    forward stream, so the backward of the two branches forks inside the third graph, mid-chain, where the
+    runtime does overlap).  The dropout step counter is bumped eagerly in front of the three launches.
+
+    ``parts = (src_part(src), tgt_part(tgt), rest_part(src_out, tgt_out, alpha))`` come from the trainer."""
+
+    def __init__(self, parts, scalar_alpha, step_fn, optimizer, src, tgt, warmup=3):
+        super().__init__(step_fn, optimizer, src, tgt, warmup=warmup)
+        self.parts, self.alpha = parts, scalar_alpha
+
+    def _run_split(self, capture):
+        """One step through the three parts; ``capture`` = the three CUDAGraph objects or None (eager)."""
+        from .ops import dropout_state
+        src_part, tgt_part, rest_part = self.parts
+        main = torch.cuda.current_stream()
+        mode = dict(capture_error_mode="thread_local")
+        dropout_state.site = 0                       # call sites number through the three captures
+        if capture is None:
+            a = src_part(self.src)
+            b = tgt_part(self.tgt)
+            return self._tail(rest_part, a, b, True)
+        g1, g2, g3 = capture
+        with torch.cuda.graph(g1, stream=self._sa, **mode):
+            a = src_part(self.src)
+        with torch.cuda.graph(g2, stream=self._sb, **mode):
+            b = tgt_part(self.tgt)
+        with torch.cuda.graph(g3, **mode):
+            out = self._tail(rest_part, a, b, True)
+        self._keep = (a, b)                          # the forward graphs' outputs stay alive with the graphs
+        return out
+
+    def _tail(self, rest_part, a, b, with_stats):
+        loss, logits = rest_part(a, b, self.alpha)
+        main = torch.cuda.current_stream()
+        if with_stats:
+            side = self._stat_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                correct = (logits.detach().argmax(dim=1) == self.src.y).sum()
+                self.stats = torch.stack([loss.detach().double(), correct.double()])
+            for t in (loss, logits):
+                t.record_stream(side)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optimizer.step()
+        if with_stats:
+            main.wait_stream(side)
+            self.stats.record_stream(main)
+        return loss, logits
+
+    def capture(self):
+        from .ops import dropout_state
+        prev = _mmd.sample_provider
+        _mmd.sample_provider = self._provider
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        saved = [p.detach().clone() for p in params]
+        cpu_rng = torch.get_rng_state()
+        dev = self.src.x.device
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(self.warmup):           # allocator warm-up, first sample buffers, K-step plans
+                    self._refill()
+                    self._run()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._refill()
+            self._sa, self._sb, self._stat_stream = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+            self.graphs = tuple(torch.cuda.CUDAGraph() for _ in range(3))
+            dropout_state.next_step(dev)               # eager, as in front of every replay
+            loss, logits = self._run_split(self.graphs)
+            self.loss, self.logits = loss.detach(), logits.detach()
+            self._stat_pins = [torch.zeros(2, dtype=torch.float64).pin_memory() for _ in range(2)]
+            self._stat_events = [None, None]
+            self._stat_turn = 0
+            with torch.no_grad():
+                for p, v in zip(params, saved):
+                    p.copy_(v)
+                for st in self.optimizer.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+            torch.set_rng_state(cpu_rng)
+        finally:
+            _mmd.sample_provider = prev
+        return self
+
+    def _replay(self):
+        from .ops import dropout_state
+        main = torch.cuda.current_stream()
+        dropout_state.next_step(self.src.x.device)     # fresh dropout masks: the counter all three graphs read
+        g1, g2, g3 = self.graphs
+        self._sa.wait_stream(main)
+        self._sb.wait_stream(main)
+        with torch.cuda.stream(self._sa):
+            g1.replay()
+        with torch.cuda.stream(self._sb):
+            g2.replay()
+        main.wait_stream(self._sa)
+        main.wait_stream(self._sb)
+        g3.replay()
 
 
 class GraphedStepDP:

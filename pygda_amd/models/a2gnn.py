@@ -30,7 +30,7 @@ class A2GNN(BaseGDA):
         self.compute_target_logits = True
         import os
         self.overlap_streams = os.environ.get("PYGDA_AMD_OVERLAP", "1") == "1"
-        self._source_late = int(os.environ.get("PYGDA_AMD_SRC_LATE", "0"))
+        self.split_graphs = os.environ.get("PYGDA_AMD_SPLIT_GRAPHS", "0") == "1"   # measured slower: opt-in
 
     def init_model(self, **kwargs):
         return A2GNNBase(in_dim=self.in_dim, hid_dim=self.hid_dim, num_classes=self.num_classes,
@@ -52,6 +52,66 @@ class A2GNN(BaseGDA):
             out = net.feat_classifier(feats, target_data.edge_index, None, 1)
         out.record_stream(main)
         return out, side
+
+    def _source_branch(self, source_data):
+        """Source logits pass (:181-182) and source feature pass (:192) over one shared layer 0."""
+        net = self.a2gnn
+        sb = None if self.mode == 'node' else source_data.batch
+        h0_s = net.first_conv(source_data.x, source_data.edge_index, self.s_pnums)
+        # The feature pass (:192) is issued BEFORE the logits pass (:181-182) although the reference runs them the
+        # other way round (independent passes, same values): autograd walks newer nodes first, so the backward of
+        # the logits / cross-entropy path -- which needs nothing from the domain loss -- is enqueued on this
+        # branch's stream first and runs beside the MMD's backward kernel instead of queueing behind the feature
+        # path that has to wait for it (~100 us off the step's critical path).
+        source_features = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)   # :192
+        feats = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)
+        source_logits = net.feat_classifier(feats, source_data.edge_index, sb, 1)            # :181
+        loss = self._gmean(source_ce(source_logits, source_data.y), source_logits.size(0))   # :182, fused
+        return loss, source_logits, source_features
+
+    def _target_branch(self, target_data, fork):
+        """Target feature pass (:193); the loss-unused logits pass (:211) forked from its layer 0."""
+        net = self.a2gnn
+        tb = None if self.mode == 'node' else target_data.batch
+        h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
+        pending = None
+        if self.compute_target_logits and fork:
+            pending = self._target_logits_async(net, target_data, h0_t)
+        target_features = net.feat_bottleneck_from(h0_t, target_data.edge_index, tb, self.t_pnums)   # :193
+        return h0_t, pending, target_features
+
+    def _domain_loss(self, loss, source_features, target_features, alpha):
+        net = self.a2gnn
+        if self.adv:                                                                     # :196-205, fused
+            disc = net.domain_discriminator
+            dom = grl_disc_ce(source_features, target_features, disc.weight, disc.bias, alpha)
+            return loss + self.weight * self._gmean(dom, source_features.size(0) + target_features.size(0))
+        return loss + MMD(source_features, target_features) * self.weight                # :206-209
+
+    def _split_graph_parts(self):
+        """The step as three captures (pygda_amd/hipgraph.py::GraphedStepSplit): source forward and target
+        forward as separate single-branch graphs replayed on two streams at once, then the domain loss, the
+        backward pass and the optimiser step.  A forked capture serialises branches forked at its root on this
+        runtime and pays 5-6 us per kernel, so the source branch of the one-graph step runs BEFORE the target
+        branch; as two graphs they run side by side."""
+        if type(self) is not A2GNN or self.mode != 'node' or not self.overlap_streams or not self.split_graphs:
+            return None
+
+        def src_part(src):
+            return self._source_branch(src)
+
+        def tgt_part(tgt):
+            h0_t, pending, tf = self._target_branch(tgt, True)
+            if pending is not None:
+                torch.cuda.current_stream().wait_stream(pending[1])
+                return tf, pending[0]
+            return (tf,)
+
+        def rest_part(src_out, tgt_out, alpha):
+            ce, source_logits, sf = src_out
+            return self._domain_loss(ce, sf, tgt_out[0], alpha), source_logits
+
+        return src_part, tgt_part, rest_part
 
     def _branches(self, source_data, target_data):
         """Everything of a step up to the domain loss: ``(ce_loss, source_logits, source_features,
@@ -80,36 +140,9 @@ class A2GNN(BaseGDA):
                 if quiet is not None:
                     quiet(False)
             src_stream.wait_stream(main)
-        def source_branch():
-            h0_s = net.first_conv(source_data.x, source_data.edge_index, self.s_pnums)
-            feats = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)
-            source_logits = net.feat_classifier(feats, source_data.edge_index, sb, 1)        # :181
-            loss = self._gmean(source_ce(source_logits, source_data.y), source_logits.size(0))   # :182, fused
-            source_features = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)   # :192
-            return loss, source_logits, source_features
-
-        def target_branch():
-            h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
-            pending = None
-            if self.compute_target_logits and fork:
-                pending = self._target_logits_async(net, target_data, h0_t)
-            target_features = net.feat_bottleneck_from(h0_t, target_data.edge_index, tb, self.t_pnums)   # :193
-            return h0_t, pending, target_features
-
-        # issue order = node order of the captured graph: the longer (target) branch first when forked
-        late = fork and self._source_late
-        if late == 1:
-            h0_t, pending, target_features = target_branch()
-        elif late == 2:      # fork the source branch from INSIDE the target chain (after its first conv)
-            h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
-            src_stream.wait_stream(main)
         with (torch.cuda.stream(src_stream) if fork else _null()):
-            loss, source_logits, source_features = source_branch()
-        if late == 2:
-            pending = self._target_logits_async(net, target_data, h0_t) if self.compute_target_logits else None
-            target_features = net.feat_bottleneck_from(h0_t, target_data.edge_index, tb, self.t_pnums)
-        elif not late:
-            h0_t, pending, target_features = target_branch()
+            loss, source_logits, source_features = self._source_branch(source_data)
+        h0_t, pending, target_features = self._target_branch(target_data, fork)
         if fork:
             main.wait_stream(src_stream)                                                 # join
             for t in (loss, source_logits, source_features):
@@ -124,12 +157,7 @@ class A2GNN(BaseGDA):
         loss, source_logits, source_features, target_features, h0_t, pending, (sb, tb) = \
             self._branches(source_data, target_data)
         net = self.a2gnn
-        if self.adv:                                                                     # :196-205, fused
-            disc = net.domain_discriminator
-            dom = grl_disc_ce(source_features, target_features, disc.weight, disc.bias, alpha)
-            loss = loss + self.weight * self._gmean(dom, source_features.size(0) + target_features.size(0))
-        else:                                                                            # :206-209
-            loss = loss + MMD(source_features, target_features) * self.weight
+        loss = self._domain_loss(loss, source_features, target_features, alpha)
         if pending is not None:
             target_logits, side = pending
             torch.cuda.current_stream().wait_stream(side)                                # join

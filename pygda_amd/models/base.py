@@ -204,8 +204,13 @@ class BaseGDA(ABC):
                 part1, part2 = parts
                 graphed = GraphedStepDP(part1, part2, optimizer, src, tgt).capture(eager_step)
             else:
-                graphed = GraphedStep(scalar_step, optimizer, src, tgt,
-                                      extra_optimizers=getattr(self, "_graph_extra_optimizers", ())).capture()
+                split = self._split_graph_parts() if hasattr(self, "_split_graph_parts") else None
+                if split is not None and not getattr(self, "_graph_extra_optimizers", ()):
+                    from ..hipgraph import GraphedStepSplit
+                    graphed = GraphedStepSplit(split, self._g_alpha, scalar_step, optimizer, src, tgt).capture()
+                else:
+                    graphed = GraphedStep(scalar_step, optimizer, src, tgt,
+                                          extra_optimizers=getattr(self, "_graph_extra_optimizers", ())).capture()
         except Exception as exc:       # anything a custom activation / exotic configuration may do under capture
             if self.use_hip_graph:     # explicitly requested: do not hide the failure
                 raise
