@@ -481,6 +481,13 @@ size_t gda_gemm_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K);
 int gda_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                  const float* B, int64_t ldb, float* C, int64_t ldc,
                  void* workspace, size_t workspace_bytes, gda_stream_t stream);
+/* The same with the two by-products of a biased layer `y = x W^T + b` (prop_gcn_conv.py:204,212-213 with
+ * prop_nums = 0): `bias` [N] (NT only) is added in the forward epilogue; `colsum` [M] (TN only) receives
+ * sum_k A[k, m] -- with A = gy that is the bias gradient, formed beside the weight gradient gy^T x from the tiles
+ * the kernel stages anyway (deterministic row-slab partials like the product itself).  Either may be NULL. */
+int gda_gemm_ex_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                    const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, float* colsum,
+                    void* workspace, size_t workspace_bytes, gda_stream_t stream);
 
 /* C = A * A of a CSR operator on the host (threaded, deterministic order), for STATIC full-batch
  * graphs: a K-step propagation (pygda/nn/prop_gcn_conv.py:208-210) then takes K/2 dependent

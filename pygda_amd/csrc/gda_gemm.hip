@@ -98,7 +98,7 @@ template <bool TA, bool TB_, bool FAST>
 __global__ void __launch_bounds__(TB)
 k_gemm(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
        float* __restrict__ C, int64_t ldc, int64_t M, int64_t N, int64_t K, int64_t k_slab, bool vec_a,
-       bool vec_b) {
+       bool vec_b, const float* __restrict__ bias, float* __restrict__ colsum) {
     __shared__ __attribute__((aligned(16))) float As[DK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[DK][LDT];
     const int64_t i0 = (int64_t)blockIdx.x * TILE, j0 = (int64_t)blockIdx.y * TILE;   // rows on grid.x: 2^31 tiles
@@ -109,6 +109,8 @@ k_gemm(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, in
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float csum = 0.f;                  // TN only: column sum of A (= the bias gradient beside the weight gradient)
+    const bool do_colsum = TA && colsum != nullptr && blockIdx.y == 0 && tid < TILE;
     // A block is alone on its CU at these grid sizes, so nothing hides a chunk's global-load latency
     // but the block itself: PF chunks are kept in flight in registers (all of K for the 128-wide
     // hidden layers), refilled as they are consumed.
@@ -132,6 +134,10 @@ k_gemm(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, in
                 stage_load<TB_, FAST>(vb[c], B, ldb, j0, k0 + PF * DK, N, kend, vec_b);
             }
             __syncthreads();
+            if (do_colsum) {
+#pragma unroll
+                for (int kk = 0; kk < DK; ++kk) csum += As[kk][tid];      // rows beyond K were staged as zeros
+            }
 #pragma unroll
             for (int kk = 0; kk < DK; kk += 2)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + ka][wi + la], Bs[kk + ka][wj + la], acc, 0, 0, 0);
@@ -139,19 +145,29 @@ k_gemm(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, in
     }
     float* out = C + (int64_t)blockIdx.z * M * ldc;              // split-K: slab z writes its own [M, ldc] plane
     const int64_t j = j0 + wj + la;
+    const float bj = (bias != nullptr && j < N) ? bias[j] : 0.f;  // forward epilogue: + bias along N
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t i = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * ka;   // C/D layout of the 32x32 MFMA
-        if (i < M && j < N) out[i * ldc + j] = acc[r];
+        if (i < M && j < N) out[i * ldc + j] = acc[r] + bj;
     }
+    if (do_colsum && i0 + tid < M) colsum[(int64_t)blockIdx.z * M + i0 + tid] = csum;   // slab z's partial
 }
 
-// C[m, n] = sum_z partial[z][m][n] in a fixed order
+// C[m, n] = sum_z partial[z][m][n] in a fixed order; the extra M entries (idx >= M*N) are the column sums
 __global__ void __launch_bounds__(TB)
 k_slab_sum(const float* __restrict__ partial, int slabs, int64_t M, int64_t N, float* __restrict__ C,
-           int64_t ldc) {
+           int64_t ldc, const float* __restrict__ cs_partial, float* __restrict__ colsum) {
     const int64_t idx = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (idx >= M * N) return;
+    if (idx >= M * N) {
+        const int64_t m = idx - M * N;
+        if (colsum != nullptr && m < M) {
+            float a = 0.f;
+            for (int z = 0; z < slabs; ++z) a += cs_partial[(int64_t)z * M + m];
+            colsum[m] = a;
+        }
+        return;
+    }
     // four interleaved partial sums (fixed assignment z % 4): the loads of a batch are independent
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const int64_t plane = M * N;
@@ -186,12 +202,20 @@ bool split_k(int mode, int64_t M, int64_t N, int64_t K) {
 extern "C" size_t gda_gemm_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0 || !split_k(mode, M, N, K)) return 0;
     const int s = slabs_for(K);
-    return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
+    return s > 1 ? (size_t)s * (size_t)M * (size_t)(N + 1) * sizeof(float) : 0;     // + one column-sum partial per slab
 }
 
 extern "C" int gda_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                             const float* B, int64_t ldb, float* C, int64_t ldc,
                             void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    return gda_gemm_ex_f32(mode, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int gda_gemm_ex_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                               const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                               float* colsum, void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    if (bias != nullptr && mode != GDA_GEMM_NT) return GDA_E_UNSUPPORTED;
+    if (colsum != nullptr && mode != GDA_GEMM_TN) return GDA_E_UNSUPPORTED;
     if (mode != GDA_GEMM_NT && mode != GDA_GEMM_NN && mode != GDA_GEMM_TN) return GDA_E_UNSUPPORTED;
     if (M < 0 || N < 0 || K < 0 || ldc < N) return GDA_E_SIZE;
     if ((mode == GDA_GEMM_TN ? lda < M : lda < K) || (mode == GDA_GEMM_NT ? ldb < K : ldb < N)) return GDA_E_SIZE;
@@ -211,19 +235,23 @@ extern "C" int gda_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const flo
     const bool fast = va && vb && a_cols % 4 == 0 && b_cols % 4 == 0 && a_cols >= 4 && b_cols >= 4;
 #define GDA_GEMM_LAUNCH(TA_, TB__, grid, Cp, ldc_, kslab)                                                   \
     do {                                                                                                  \
-        if (fast) k_gemm<TA_, TB__, true><<<grid, TB, 0, stream>>>(A, lda, B, ldb, Cp, ldc_, M, N, K, kslab, va, vb); \
-        else k_gemm<TA_, TB__, false><<<grid, TB, 0, stream>>>(A, lda, B, ldb, Cp, ldc_, M, N, K, kslab, va, vb);    \
+        if (fast) k_gemm<TA_, TB__, true><<<grid, TB, 0, stream>>>(A, lda, B, ldb, Cp, ldc_, M, N, K, kslab, va, vb, bias, csp); \
+        else k_gemm<TA_, TB__, false><<<grid, TB, 0, stream>>>(A, lda, B, ldb, Cp, ldc_, M, N, K, kslab, va, vb, bias, csp);    \
     } while (0)
+    float* csp = colsum;                         // where the kernel writes its column-sum (partials)
     if (split_k(mode, M, N, K)) {
         const bool tn = mode == GDA_GEMM_TN;
         const int s = slabs_for(K);
         const int64_t k_slab = gda_cdiv(gda_cdiv(K, s), DK) * DK;        // whole chunks per slab
         if (s > 1) {
             if (!workspace || workspace_bytes < gda_gemm_workspace_bytes(mode, M, N, K)) return GDA_E_WORKSPACE;
+            float* cs_part = (float*)workspace + (size_t)s * M * N;
+            if (colsum) csp = cs_part;
             if (tn) GDA_GEMM_LAUNCH(true, true, dim3((unsigned)gy, (unsigned)gx, s), (float*)workspace, N, k_slab);
             else GDA_GEMM_LAUNCH(false, true, dim3((unsigned)gy, (unsigned)gx, s), (float*)workspace, N, k_slab);
             GDA_LAUNCH_CHECK();
-            k_slab_sum<<<(unsigned)gda_cdiv(M * N, TB), TB, 0, stream>>>((const float*)workspace, s, M, N, C, ldc);
+            k_slab_sum<<<(unsigned)gda_cdiv(M * N + (colsum ? M : 0), TB), TB, 0, stream>>>(
+                (const float*)workspace, s, M, N, C, ldc, cs_part, colsum);
         } else if (tn) {
             GDA_GEMM_LAUNCH(true, true, dim3((unsigned)gy, (unsigned)gx, 1), C, ldc, K);
         } else {

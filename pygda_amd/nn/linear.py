@@ -50,6 +50,32 @@ class _TallLinear(torch.autograd.Function):
         return gx, gw
 
 
+class _TallLinearBias(torch.autograd.Function):
+    """``y = x W^T + b`` (a conv with ``prop_nums = 0``, prop_gcn_conv.py:204,212-213): the bias rides in the forward
+    kernel's epilogue and its gradient ``gy.sum(0)`` is a by-product of the weight-gradient kernel (column sums of
+    the ``gy`` tiles it stages anyway) -- no elementwise add, no fill + reduction launches."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from ..ops import GEMM_NT, gemm
+        ctx.save_for_backward(x, weight)
+        return gemm(GEMM_NT, x, weight, bias=bias.contiguous())
+
+    @staticmethod
+    def backward(ctx, gy):
+        from ..ops import GEMM_NN, GEMM_TN, gemm
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gemm(GEMM_NN, gy, weight) if ctx.needs_input_grad[0] else None
+        gb = torch.empty(weight.size(0), dtype=torch.float32, device=gy.device)
+        gw = gemm(GEMM_TN, gy, x, colsum=gb)
+        return gx, gw, gb
+
+
+def tall_linear_bias(x, weight, bias):
+    return _TallLinearBias.apply(x, weight, bias)
+
+
 class _BlasTallLinear(torch.autograd.Function):
     """Same contraction through the ROCm BLAS, for row counts where its 128x128 macro-tiles fill the
     chip (sampled sub-graphs of 10^5 rows and more: measured 20-30 % ahead of the 64x64-tile kernels

@@ -77,6 +77,9 @@ class PropGCNConv(nn.Module):
             if (self.out_channels % 4 == 0 and lds_kstep_plan(g, prop_nums, False) is not None
                     and lds_kstep_plan(g, prop_nums, True) is not None):
                 return propagate(tall_linear_colmajor(x, self.lin.weight), g, prop_nums, self.bias)
+        if prop_nums <= 0 and self.bias is not None and self.lin.tall_gemm_ok(x):
+            from .linear import tall_linear_bias               # projection + bias (and both gradients) in the GEMMs
+            return tall_linear_bias(x, self.lin.weight, self.bias)
         out = self.lin(x)                                        # :205
         if prop_nums > 0:                                        # :208-213, bias fused in the last step
             return propagate(out, self._graph(x, edge_index, edge_weight), prop_nums, self.bias,

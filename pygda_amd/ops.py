@@ -74,9 +74,10 @@ def gemm_raw(mode, M, N, K, a, lda, b, ldb, c, ldc, name="dense_projection"):
     return c
 
 
-def gemm(mode, a, b):
-    """fp32 product on the matrix cores (include/gda_hip.h: gda_gemm_f32), no autograd.
-    NT: ``a [M,K] @ b [N,K]^T``; NN: ``a [M,K] @ b [K,N]``; TN: ``a [K,M]^T @ b [K,N]``."""
+def gemm(mode, a, b, bias=None, colsum=None):
+    """fp32 product on the matrix cores (include/gda_hip.h: gda_gemm_ex_f32), no autograd.
+    NT: ``a [M,K] @ b [N,K]^T`` (+ ``bias [N]`` in the epilogue); NN: ``a [M,K] @ b [K,N]``;
+    TN: ``a [K,M]^T @ b [K,N]`` (``colsum [M]`` receives ``a.sum(0)``, the bias gradient beside the weight's)."""
     a, b = _f32c(a, "a"), _f32c(b, "b")
     if mode == GEMM_NT:
         (M, K), (N, K2) = a.shape, b.shape
@@ -93,9 +94,10 @@ def gemm(mode, a, b):
     name = ("dense_projection", "dense_projection_dgrad", "dense_projection_wgrad")[mode]
     with profiler.region(f"{name}[{K}x{N}]" if mode != GEMM_TN else f"{name}[{M}x{N}]", 1,
                          4 * (a.numel() + b.numel() + c.numel()), 2 * M * N * K):
-        _lib.check(L.gda_gemm_f32(mode, M, N, K, _lib.ptr(a), a.size(1), _lib.ptr(b), b.size(1), _lib.ptr(c), N,
-                                  _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream()),
-                   "gda_gemm_f32")
+        _lib.check(L.gda_gemm_ex_f32(mode, M, N, K, _lib.ptr(a), a.size(1), _lib.ptr(b), b.size(1), _lib.ptr(c), N,
+                                     _lib.ptr(bias), _lib.ptr(colsum),
+                                     _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream()),
+                   "gda_gemm_ex_f32")
     return c
 
 

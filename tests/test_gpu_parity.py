@@ -1635,3 +1635,31 @@ def test_conv_layer_colmajor_pipeline_equals_rowmajor(monkeypatch):
     close(a[1], b[1], rtol=1e-5, atol=1e-6 * float(b[1].abs().max()))
     close(a[2], b[2], rtol=1e-4, atol=1e-5 * float(b[2].abs().max()))
     close(a[3], b[3], rtol=1e-4, atol=1e-5 * float(b[3].abs().max()))
+
+
+def test_linear_bias_fused_in_gemms():
+    """A conv with prop_nums = 0 (projection + bias): bias in the forward GEMM's epilogue, bias gradient as the
+    column sum the weight-gradient GEMM takes of the tiles it stages -- against the composed torch form."""
+    gen = torch.Generator().manual_seed(8)
+    for n, fin, fout in ((9360, 128, 128), (5484, 128, 64), (1500, 64, 128)):
+        x0 = torch.randn(n, fin, generator=gen).to(DEV)
+        gy = torch.randn(n, fout, generator=gen).to(DEV)
+        conv = PropGCNConv(fin, fout).to(DEV)
+        with torch.no_grad():
+            conv.bias.copy_(torch.randn(fout, generator=gen))
+        ei = torch.zeros(2, 0, dtype=torch.int64, device=DEV)
+        x = x0.clone().requires_grad_()
+        assert conv.lin.tall_gemm_ok(x)
+        y = conv(x, ei, 0)
+        (y * gy).sum().backward()
+        xr = x0.clone().requires_grad_()
+        yr = F.linear(xr, conv.lin.weight.detach()) + conv.bias.detach()
+        close(y, yr, rtol=1e-5, atol=1e-5)
+        close(x.grad, gy @ conv.lin.weight.detach(), rtol=1e-4, atol=1e-4)
+        close(conv.lin.weight.grad, gy.t() @ x0, rtol=1e-4, atol=1e-3)
+        close(conv.bias.grad, gy.sum(0), rtol=1e-4, atol=1e-3)
+        # deterministic
+        conv.zero_grad()
+        x2 = x0.clone().requires_grad_()
+        (conv(x2, ei, 0) * gy).sum().backward()
+        exact(x2.grad, x.grad)
