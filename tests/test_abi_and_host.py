@@ -326,3 +326,25 @@ def test_kstep_plan_is_the_csr_program():
     rp3 = np.zeros(big + 1, dtype=np.int32)
     assert L.gda_kstep_plan_host(rp3.ctypes.data, None, None, big, buf.ctypes.data, cap) == 0
     assert L.gda_kstep_plan_host(None, None, None, 5, buf.ctypes.data, cap) == -1
+
+
+def test_int32_limits_are_rejected_not_wrapped():
+    """Indices inside the library are int32: sizes that do not fit come back as GDA_E_SIZE before anything touches a
+    device (cfg-S times eight would otherwise wrap silently) -- and the Python layer turns the status into GdaError."""
+    import ctypes
+    L = _lib.lib()
+    one = ctypes.c_void_p(1)                      # non-NULL dummies: the size checks come first
+    big = 2 ** 31
+    assert L.gda_spmm_csr_f32(one, one, one, big, 4, one, 4, one, 4, None, None) == -2            # rows
+    assert L.gda_spmm_csr_f32(one, one, one, 10, big, one, big, one, big, None, None) == -2       # width
+    assert L.gda_build_csr_norm(one, one, None, big, 10, 1.0, 1, 1, 0, one, one, one, one, one, one, one, 1 << 40,
+                                None) != 0                                                        # E + N >= 2^31
+    assert L.gda_mmd_fwd_f32(one, 128, one, 128, 128, None, None, 5, 46341, 2.0, 5, 0.0, one, one, one, one, 1 << 40,
+                             None) == -2                                                          # m*m beyond the limit
+    assert L.gda_kstep_lds_f32(one, 8, L.gda_kstep_max_rows() + 1, 128, 10, one, 128, 0, one, 128, 0, None, None, one,
+                               None) == -2
+    assert L.gda_wgan_critic_f32(one, 2 ** 29, one, 2 ** 29, 128, None, None, None, 0, one, one, one, one, 40, 0.0, 0, None,
+                                 0, 5.0, one, one, one, one, one, one, 1 << 40, None) == -2
+    assert L.gda_gemm_f32(0, -1, 4, 4, one, 4, one, 4, one, 4, None, 0, None) == -2
+    with pytest.raises(_lib.GdaError):
+        _lib.check(-2, "size check")
