@@ -238,6 +238,25 @@ int gda_mmd_bwd_f32(const float* src, int64_t ld_src, const float* tgt, int64_t 
                     int times, int64_t n, float kernel_mul, int kernel_num,
                     const float* bandwidth, const float* l2_saved, const float* grad_loss,
                     float* grad_rows, void* workspace, size_t workspace_bytes, gda_stream_t stream);
+/* The same two calls with the glue of the trainer's loss line folded in (`loss = CE + MMD(...) * weight`,
+ * pygda/models/a2gnn.py:207-209): forward returns add[0] + scale * mmd (add may be NULL); backward scales the
+ * incoming gradient by `scale`, and -- given the 0/1 selection CSRs of the sampled rows (rows = feature rows of a
+ * domain, columns = positions t*2n + i of the [times, 2n, d] row-gradient array: gda_selection_csr_host) -- sums the
+ * row gradients straight onto the feature rows: gsrc [n_src_rows, d], gtgt [n_tgt_rows, d] (grad_rows unused then;
+ * the same values as grad_rows followed by the selection-matrix SpMM, bit for bit). */
+int gda_mmd_fwd_ex_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
+                       int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
+                       int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
+                       float scale, const float* add, float* loss, float* bandwidth, float* l2_saved,
+                       void* workspace, size_t workspace_bytes, gda_stream_t stream);
+int gda_mmd_bwd_ex_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
+                       int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
+                       int times, int64_t n, float kernel_mul, int kernel_num,
+                       const float* bandwidth, const float* l2_saved, const float* grad_loss, float scale,
+                       float* grad_rows,
+                       const int32_t* sel_s_rowptr, const int32_t* sel_s_col, int64_t n_src_rows, float* gsrc,
+                       const int32_t* sel_t_rowptr, const int32_t* sel_t_col, int64_t n_tgt_rows, float* gtgt,
+                       void* workspace, size_t workspace_bytes, gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
  * Gradient-reversal + linear domain discriminator + softmax cross-entropy, fused.

@@ -318,7 +318,7 @@ k_pairdist(Rows R, int64_t d, int64_t m, int nt, const float* __restrict__ bandw
 
 __global__ void __launch_bounds__(TB)
 k_finalize(const double* __restrict__ kpartial, int tiles_per_t, int times, int64_t n,
-           float* __restrict__ loss) {
+           float scale, const float* __restrict__ add, float* __restrict__ loss) {
     __shared__ double red[TB / 64];
     float total = 0.f;
     for (int t = 0; t < times; ++t) {
@@ -328,7 +328,10 @@ k_finalize(const double* __restrict__ kpartial, int tiles_per_t, int times, int6
         if (threadIdx.x == 0) total += (float)(s / ((double)n * (double)n));            // mmd.py:106 mean
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] = total / (float)times;                               // mmd.py:157
+    if (threadIdx.x == 0) {                            // mmd.py:157; `add + scale * mmd` in one go when asked for
+        const float v = total / (float)times;
+        loss[0] = (add ? add[0] : 0.f) + (scale != 1.f ? scale * v : v);
+    }
 }
 
 // --------------------------------------------------------------- backward --
@@ -347,7 +350,7 @@ constexpr int BJ = 32;        // rows j per chunk (MFMA K = 2 per instruction)
 template <int KN>
 __global__ void __launch_bounds__(TB)
 k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* __restrict__ bandwidth,
-      KParams kp, const float* __restrict__ grad_loss, int times, int nseg,
+      KParams kp, const float* __restrict__ grad_loss, float scale, int times, int nseg,
       float* __restrict__ part) {
     (void)bandwidth; (void)kp;
     __shared__ __attribute__((aligned(16))) float Gs[2][BJ][BI];      // Gs[b][j][i] = g[i][j]
@@ -446,7 +449,7 @@ k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* _
     __syncthreads();
 
     // epilogue: part[t][seg][i][c] = c * (rowsum[i] * total[i][c] - acc)   (factor 4 in the reduce)
-    const float coef = grad_loss[0] / ((float)n * (float)n) / (float)times;
+    const float coef = grad_loss[0] * scale / ((float)n * (float)n) / (float)times;
     float* out = part + (((int64_t)t * nseg + seg) * m) * d;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -474,6 +477,43 @@ k_bwd_reduce(const float* __restrict__ part, int64_t per_t, int nseg, int times,
         float s = 0.f;
         for (int g = 0; g < nseg; ++g) s += part[(t * nseg + g) * per_t + r];
         grad_rows[k] = 4.f * s;
+    }
+}
+
+// Segment reduce AND scatter onto the sampled feature rows in one pass: feature row r of a domain receives
+//     sum over its selection entries p (positions t*m + i in the [times, m, d] row-gradient array, CSR order)
+//         of 4 * (sum over the nseg segment partials of position p, in segment order)
+// -- the values k_bwd_reduce followed by the selection-matrix SpMM produce, bit for bit; rows nobody sampled get 0.
+__global__ void __launch_bounds__(TB)
+k_bwd_scatter(const float* __restrict__ part, int64_t m, int64_t d, int nseg,
+              const int32_t* __restrict__ s_rowptr, const int32_t* __restrict__ s_col, int64_t n_src_rows,
+              float* __restrict__ gsrc, const int32_t* __restrict__ t_rowptr, const int32_t* __restrict__ t_col,
+              int64_t n_tgt_rows, float* __restrict__ gtgt) {
+    const int64_t rows_per_block = TB / 32;               // 32 lanes x float4 = one 128-wide row slab
+    const int lane = threadIdx.x % 32;
+    const int64_t r = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / 32;
+    const bool tgt = blockIdx.y == 1;
+    const int64_t n_rows = tgt ? n_tgt_rows : n_src_rows;
+    if (r >= n_rows) return;
+    const int32_t* rp = tgt ? t_rowptr : s_rowptr;
+    const int32_t* ci = tgt ? t_col : s_col;
+    float* out = (tgt ? gtgt : gsrc) + r * d;
+    const int32_t b = rp[r], e = rp[r + 1];
+    for (int64_t c = (int64_t)lane * 4; c < d; c += 128) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int32_t k = b; k < e; ++k) {
+            const int64_t p = ci[k], t = p / m, i = p % m;
+            float sg[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < nseg; ++g) {
+                const float* q = part + (((int64_t)t * nseg + g) * m + i) * d + c;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) if (c + v < d) sg[v] += q[v];
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[v] = __fadd_rn(acc[v], __fmul_rn(1.0f, 4.f * sg[v]));
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) if (c + v < d) out[c + v] = acc[v];
     }
 }
 
@@ -528,6 +568,15 @@ extern "C" int gda_mmd_fwd_f32(const float* src, int64_t ld_src, const float* tg
                                int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
                                float* loss, float* bandwidth, float* l2_saved,
                                void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    return gda_mmd_fwd_ex_f32(src, ld_src, tgt, ld_tgt, d, src_idx, tgt_idx, times, n, kernel_mul, kernel_num, fix_sigma,
+                              1.0f, nullptr, loss, bandwidth, l2_saved, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int gda_mmd_fwd_ex_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
+                                  int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
+                                  int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
+                                  float scale, const float* add, float* loss, float* bandwidth, float* l2_saved,
+                                  void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
     int st = check_common(src, ld_src, tgt, ld_tgt, d, src_idx, tgt_idx, times, n, kernel_num);
     if (st != GDA_OK) return st;
     if (!loss || !bandwidth || !l2_saved || !workspace) return GDA_E_NULL;
@@ -552,7 +601,7 @@ extern "C" int gda_mmd_fwd_f32(const float* src, int64_t ld_src, const float* tg
     else
         k_pairdist<0, false><<<grid, TB, 0, stream>>>(R, d, m, (int)nt, bandwidth, kp, l2_saved, ws.kpartial);
     GDA_LAUNCH_CHECK();
-    k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, (int)ntri, times, n, loss);
+    k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, (int)ntri, times, n, scale, add, loss);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
@@ -563,9 +612,26 @@ extern "C" int gda_mmd_bwd_f32(const float* src, int64_t ld_src, const float* tg
                                const float* bandwidth, const float* l2_saved, const float* grad_loss,
                                float* grad_rows, void* workspace, size_t workspace_bytes,
                                gda_stream_t stream_) {
+    if (!grad_rows) return GDA_E_NULL;
+    return gda_mmd_bwd_ex_f32(src, ld_src, tgt, ld_tgt, d, src_idx, tgt_idx, times, n, kernel_mul, kernel_num, bandwidth,
+                              l2_saved, grad_loss, 1.0f, grad_rows, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0,
+                              nullptr, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int gda_mmd_bwd_ex_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
+                                  int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
+                                  int times, int64_t n, float kernel_mul, int kernel_num,
+                                  const float* bandwidth, const float* l2_saved, const float* grad_loss, float scale,
+                                  float* grad_rows,
+                                  const int32_t* sel_s_rowptr, const int32_t* sel_s_col, int64_t n_src_rows, float* gsrc,
+                                  const int32_t* sel_t_rowptr, const int32_t* sel_t_col, int64_t n_tgt_rows, float* gtgt,
+                                  void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
     int st = check_common(src, ld_src, tgt, ld_tgt, d, src_idx, tgt_idx, times, n, kernel_num);
     if (st != GDA_OK) return st;
-    if (!bandwidth || !l2_saved || !grad_loss || !grad_rows || !workspace) return GDA_E_NULL;
+    const bool scatter = sel_s_rowptr != nullptr;
+    if (!bandwidth || !l2_saved || !grad_loss || !workspace || (!scatter && !grad_rows)) return GDA_E_NULL;
+    if (scatter && (!sel_s_col || !sel_t_rowptr || !sel_t_col || !gsrc || !gtgt || n_src_rows < 0 || n_tgt_rows < 0))
+        return GDA_E_NULL;
     MmdWs ws = carve(workspace, times, n, d);
     if (workspace_bytes < ws.total) return GDA_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
@@ -575,9 +641,18 @@ extern "C" int gda_mmd_bwd_f32(const float* src, int64_t ld_src, const float* tg
     const int64_t ntiles = gda_cdiv(m, BJ);
     const int nseg = (int)(ntiles < BWD_NSEG ? ntiles : BWD_NSEG);
     const dim3 grid((unsigned)gda_cdiv(m, BI), (unsigned)(gda_cdiv(d, DC) * nseg), (unsigned)times);
-    if (kernel_num == 5) k_bwd<5><<<grid, TB, 0, stream>>>(R, d, m, l2_saved, bandwidth, kp, grad_loss, times, nseg, ws.bwd_part);
-    else k_bwd<0><<<grid, TB, 0, stream>>>(R, d, m, l2_saved, bandwidth, kp, grad_loss, times, nseg, ws.bwd_part);
+    if (kernel_num == 5) k_bwd<5><<<grid, TB, 0, stream>>>(R, d, m, l2_saved, bandwidth, kp, grad_loss, scale, times, nseg, ws.bwd_part);
+    else k_bwd<0><<<grid, TB, 0, stream>>>(R, d, m, l2_saved, bandwidth, kp, grad_loss, scale, times, nseg, ws.bwd_part);
     GDA_LAUNCH_CHECK();
+    if (scatter) {
+        const int64_t most = n_src_rows > n_tgt_rows ? n_src_rows : n_tgt_rows;
+        if (most > 0) {
+            k_bwd_scatter<<<dim3((unsigned)gda_cdiv(most, TB / 32), 2), TB, 0, stream>>>(
+                ws.bwd_part, m, d, nseg, sel_s_rowptr, sel_s_col, n_src_rows, gsrc, sel_t_rowptr, sel_t_col, n_tgt_rows, gtgt);
+            GDA_LAUNCH_CHECK();
+        }
+        return GDA_OK;
+    }
     const int64_t total = (int64_t)times * m * d;
     int64_t rg = gda_cdiv(total, TB);
     if (rg > 4096) rg = 4096;

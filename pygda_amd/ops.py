@@ -353,10 +353,18 @@ def lds_colmajor_ok(x, graph, K):
 
 
 # ---------------------------------------------------------------------------- MMD --
+import os as _os
+MMD_INDEX_IN_KERNEL = _os.environ.get("PYGDA_AMD_MMD_INDEX", "0") == "1"     # sampled rows read through their index inside the kernels (no gather pass)
+MMD_SCATTER_FUSED = _os.environ.get("PYGDA_AMD_MMD_SCATTER", "1") == "1"
+
+
 class _MMD(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, tgt, src_idx, tgt_idx, times, n, kernel_mul, kernel_num, fix_sigma, sel=None):
-        ctx.sel = sel
+    def forward(ctx, src, tgt, src_idx, tgt_idx, times, n, kernel_mul, kernel_num, fix_sigma, sel=None, scale=1.0,
+                add=None):
+        """``(add +) scale * MMD``: the trainer's loss line ``loss = CE + MMD(...) * weight`` (a2gnn.py:207-209)
+        without elementwise glue kernels around the loss kernels."""
+        ctx.sel, ctx.scale, ctx.has_add = sel, float(scale), add is not None
         src, tgt = _f32c(src, "source_feat"), _f32c(tgt, "target_feat")
         d = src.size(1)
         if tgt.size(1) != d:
@@ -364,22 +372,26 @@ class _MMD(torch.autograd.Function):
         dev = src.device
         m = 2 * n
         ctx.feat_rows = (src.size(0), tgt.size(0))
+        idx_s = idx_t = None
         if src_idx is not None:
-            # the sampled rows are gathered ONCE into [times*n, d] (2 x 2.5 MB at the A2GNN shapes):
-            # the pair kernels and the backward then stream contiguous rows instead of chasing
-            # an int64 index per row and tile
-            src, tgt = gather_rows(src, src_idx.reshape(-1)), gather_rows(tgt, tgt_idx.reshape(-1))
+            if MMD_INDEX_IN_KERNEL and sel is not None:
+                idx_s, idx_t = src_idx, tgt_idx           # the kernels chase the index themselves
+            else:
+                # the sampled rows gathered ONCE into [times*n, d] (2 x 2.5 MB at the A2GNN shapes)
+                src, tgt = gather_rows(src, src_idx.reshape(-1)), gather_rows(tgt, tgt_idx.reshape(-1))
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         bw = torch.empty(times, dtype=torch.float32, device=dev)
         l2 = torch.empty(times, m, m, dtype=torch.float32, device=dev)
         L = _lib.lib()
         ws = _lib.workspace(L.gda_mmd_workspace_bytes(times, n, d), dev, "mmd")
-        with profiler.region("mmd_fwd", 3, 0, times * (3 * m * m * d // 2 + 12 * m * m)):
-            _lib.check(L.gda_mmd_fwd_f32(
-                _lib.ptr(src), d, _lib.ptr(tgt), d, d, None, None, times, n, float(kernel_mul),
-                int(kernel_num), float(fix_sigma) if fix_sigma else 0.0, _lib.ptr(loss), _lib.ptr(bw),
-                _lib.ptr(l2), _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_mmd_fwd_f32")
+        addc = None if add is None else add.detach().to(torch.float32).reshape(1).contiguous()
+        with profiler.region("mmd_fwd", 4, 0, times * (3 * m * m * d // 2 + 12 * m * m)):
+            _lib.check(L.gda_mmd_fwd_ex_f32(
+                _lib.ptr(src), d, _lib.ptr(tgt), d, d, _lib.ptr(idx_s), _lib.ptr(idx_t), times, n, float(kernel_mul),
+                int(kernel_num), float(fix_sigma) if fix_sigma else 0.0, float(scale), _lib.ptr(addc), _lib.ptr(loss),
+                _lib.ptr(bw), _lib.ptr(l2), _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_mmd_fwd_ex_f32")
         ctx.save_for_backward(src, tgt, src_idx, tgt_idx, bw, l2)
+        ctx.in_kernel = idx_s is not None
         ctx.cfg = (times, n, float(kernel_mul), int(kernel_num))
         return loss.reshape(())
 
@@ -388,15 +400,32 @@ class _MMD(torch.autograd.Function):
         src, tgt, src_idx, tgt_idx, bw, l2 = ctx.saved_tensors
         times, n, kernel_mul, kernel_num = ctx.cfg
         d, dev, m = src.size(1), src.device, 2 * n
-        grad_rows = torch.empty(times, m, d, dtype=torch.float32, device=dev)
-        gl = gl.reshape(1).to(torch.float32).contiguous()
+        glc = gl.reshape(1).to(torch.float32).contiguous()
         L = _lib.lib()
         ws = _lib.workspace(L.gda_mmd_workspace_bytes(times, n, d), dev, "mmd")
+        idx_s, idx_t = (src_idx, tgt_idx) if ctx.in_kernel else (None, None)
+        g_add = gl if ctx.has_add else None
+        tail = (None,) * 9 + (g_add,)
+        if src_idx is not None and ctx.sel is not None and MMD_SCATTER_FUSED:
+            # row gradients summed straight onto the sampled feature rows (segment reduce + scatter in one kernel)
+            s_rp, s_ci, t_rp, t_ci, _ones = ctx.sel
+            gs = torch.empty(ctx.feat_rows[0], d, dtype=torch.float32, device=dev)
+            gt = torch.empty(ctx.feat_rows[1], d, dtype=torch.float32, device=dev)
+            with profiler.region("mmd_bwd", 2, 0, times * (3 * m * m * d + 12 * m * m)):
+                _lib.check(L.gda_mmd_bwd_ex_f32(
+                    _lib.ptr(src), d, _lib.ptr(tgt), d, d, _lib.ptr(idx_s), _lib.ptr(idx_t), times, n, kernel_mul,
+                    kernel_num, _lib.ptr(bw), _lib.ptr(l2), _lib.ptr(glc), ctx.scale, None,
+                    _lib.ptr(s_rp), _lib.ptr(s_ci), ctx.feat_rows[0], _lib.ptr(gs),
+                    _lib.ptr(t_rp), _lib.ptr(t_ci), ctx.feat_rows[1], _lib.ptr(gt),
+                    _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_mmd_bwd_ex_f32")
+            return (gs if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None) + tail
+        grad_rows = torch.empty(times, m, d, dtype=torch.float32, device=dev)
         with profiler.region("mmd_bwd", 2, 0, times * (3 * m * m * d + 12 * m * m)):
-            _lib.check(L.gda_mmd_bwd_f32(
+            _lib.check(L.gda_mmd_bwd_ex_f32(
                 _lib.ptr(src), d, _lib.ptr(tgt), d, d, None, None, times, n, kernel_mul, kernel_num,
-                _lib.ptr(bw), _lib.ptr(l2), _lib.ptr(gl), _lib.ptr(grad_rows), _lib.ptr(ws), ws.numel(),
-                _lib.stream()), "gda_mmd_bwd_f32")
+                _lib.ptr(bw), _lib.ptr(l2), _lib.ptr(glc), ctx.scale, _lib.ptr(grad_rows),
+                None, None, 0, None, None, None, 0, None, _lib.ptr(ws), ws.numel(), _lib.stream()),
+                "gda_mmd_bwd_ex_f32")
         if src_idx is None:                       # rows as given, stacked [times, n, d]
             gs, gt = grad_rows[:, :n].reshape(times * n, d), grad_rows[:, n:].reshape(times * n, d)
         elif ctx.sel is not None:                 # selection CSRs prepared on the host with the samples
@@ -407,8 +436,7 @@ class _MMD(torch.autograd.Function):
         else:
             gs = _scatter_rows(grad_rows, src_idx, 0, n, ctx.feat_rows[0])
             gt = _scatter_rows(grad_rows, tgt_idx, n, n, ctx.feat_rows[1])
-        return (gs if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None,
-                None, None, None, None, None, None, None, None)
+        return (gs if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None) + tail
 
 
 def selection_csr_host(idx, num_feat_rows, offset, m, out=None):
@@ -498,7 +526,7 @@ def mmd_loss_rows(source_rows, target_rows, kernel_mul=2.0, kernel_num=5, fix_si
 
 
 def mmd_loss(source_feat, target_feat, src_idx=None, tgt_idx=None, kernel_mul=2.0, kernel_num=5,
-             fix_sigma=None, sel=None):
+             fix_sigma=None, sel=None, scale=1.0, add=None):
     """Sampled multi-kernel MMD (mmd.py:57-159).  ``src_idx/tgt_idx``: ``[times, n]`` int64
     device tensors of row samples, or both ``None`` for get_MMD on the rows as given."""
     if (src_idx is None) != (tgt_idx is None):
@@ -517,7 +545,7 @@ def mmd_loss(source_feat, target_feat, src_idx=None, tgt_idx=None, kernel_mul=2.
         times, n = src_idx.shape
         src_idx, tgt_idx = src_idx.contiguous(), tgt_idx.contiguous()
     return _MMD.apply(source_feat, target_feat, src_idx, tgt_idx, int(times), int(n), kernel_mul,
-                      kernel_num, fix_sigma, sel)
+                      kernel_num, fix_sigma, sel, scale, add)
 
 
 # ------------------------------------------------- GRL + discriminator + CE (fused) --

@@ -32,8 +32,11 @@ sample_provider = None
 dp_index_provider = None       # data-parallel branch: (n_src, n_tgt, times, per) -> (idx_s, idx_t, sel_s, sel_t)
 
 
-def MMD(source_feat, target_feat, sampling_num=1000, times=5):
-    """Average of ``times`` MMDs over ``sampling_num`` rows drawn with replacement per
+def MMD(source_feat, target_feat, sampling_num=1000, times=5, *, scale=1.0, add=None):
+    """``scale`` / ``add`` (keyword-only, not in the reference): return ``add + scale * MMD`` from the loss
+    kernels themselves -- the trainers' ``loss = CE + MMD(...) * weight`` line without glue kernels.
+
+    Average of ``times`` MMDs over ``sampling_num`` rows drawn with replacement per
     domain (mmd.py:109-159).  The draws come from the CPU default generator exactly as in
     the reference (``torch.randint`` without a device, :148-149), so a seeded run samples
     the same rows; only the 2 x times x sampling_num indices cross PCIe."""
@@ -58,10 +61,12 @@ def MMD(source_feat, target_feat, sampling_num=1000, times=5):
         d = source_feat.size(1)
         s_rows = s_rows.permute(1, 0, 2, 3).reshape(times, w * per, d)
         t_rows = t_rows.permute(1, 0, 2, 3).reshape(times, w * per, d)
-        return mmd_loss_rows(s_rows, t_rows)
+        out = mmd_loss_rows(s_rows, t_rows)
+        out = out * scale if scale != 1.0 else out
+        return out if add is None else add + out
     if sample_provider is not None:
         s_idx, t_idx, sel = sample_provider(source_feat.size(0), target_feat.size(0), times, sampling_num)
-        return mmd_loss(source_feat, target_feat, s_idx, t_idx, sel=sel)
+        return mmd_loss(source_feat, target_feat, s_idx, t_idx, sel=sel, scale=scale, add=add)
     source_sample = torch.randint(source_feat.size(0), (times, sampling_num))
     target_sample = torch.randint(target_feat.size(0), (times, sampling_num))
     m = 2 * sampling_num
@@ -70,4 +75,4 @@ def MMD(source_feat, target_feat, sampling_num=1000, times=5):
             *selection_csr_host(target_sample, target_feat.size(0), sampling_num, m))]
     sel.append(torch.ones(times * sampling_num, dtype=torch.float32, device=dev))
     return mmd_loss(source_feat, target_feat, source_sample.to(dev, non_blocking=True),
-                    target_sample.to(dev, non_blocking=True), sel=tuple(sel))
+                    target_sample.to(dev, non_blocking=True), sel=tuple(sel), scale=scale, add=add)
