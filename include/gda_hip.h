@@ -330,6 +330,32 @@ int gda_relu_dropout_bwd_cm_f32(const float* gy, const float* y, float* gxT, int
                                float p, gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
+ * Layer epilogue of StruRW's mixup backbone -- replaces the elementwise tail of the three
+ * MixUpGCNConv calls per layer in pygda/nn/mixup_base.py:146-196 (out = Agg(lin(x)) + lin_cen(x_cen)
+ * + bias, pygda/nn/mixup_gcnconv.py:231-236).  With P = Agg(lin(x)) [n, h] (one aggregation: the
+ * shuffled graph of pygda/models/strurw.py:735-758 is a renumbering, so its aggregate is P[perm]):
+ *     XX[i]     = drop(relu(P[i] + C[i]  + bias))                                       (x')
+ *     XX[n + i] = drop(lam relu(P[i] + Cm[i] + bias) + (1-lam) relu(Pb[i] + Cm[i] + bias))   (x_mix')
+ * Pb = P[perm[i]] when the pointer is NULL, else an explicit [n, h] aggregate (foreign edge_index_b).
+ *   first != 0: CC = C = lin_cen(x) is [n, h] and Cm[i] = lam C[i] + (1-lam) C[perm[i]]  (x_mix of the
+ *               input features is never formed);   first == 0: CC = [C ; Cm] is [2n, h] = lin_cen(XX_prev).
+ * mask [n, h] bytes (relu bits of the two mixed terms + keep bit) is written for the backward pass.
+ * Keep-bits as in gda_relu_dropout_fwd_f32, two call sites (plain row, mixed row).  h % 4 == 0, h <= 1024.
+ * Backward: gXX [2n, h] -> gP [n, h] (incl. the P[perm] route, gathered through inv_perm), gPb [n, h] iff the
+ * forward had an explicit Pb (else NULL), gCC ([n, h] if first else [2n, h]), gbias [h] (deterministic
+ * two-stage column sum; workspace from gda_mixup_combine_workspace_bytes).
+ * ---------------------------------------------------------------------------- */
+size_t gda_mixup_combine_workspace_bytes(int64_t n, int64_t h);
+int gda_mixup_combine_fwd_f32(const float* P, const float* Pb, const float* CC, int first, const float* bias,
+                              const int64_t* perm, int64_t n, int64_t h, float lam, float p, uint64_t seed,
+                              const int64_t* step, uint32_t site_x, uint32_t site_m, float* XX, uint8_t* mask,
+                              gda_stream_t stream);
+int gda_mixup_combine_bwd_f32(const float* gXX, const float* XX, const uint8_t* mask, const int64_t* inv_perm,
+                              int first, int64_t n, int64_t h, float lam, float p, float* gP, float* gPb,
+                              float* gCC, float* gbias, void* workspace, size_t workspace_bytes,
+                              gda_stream_t stream);
+
+/* ------------------------------------------------------------------------------
  * Feature-row gather  out[r,:] = x[idx[r],:]  (mini-batch assembly: the x[n_id]
  * slice PyG's NeighborLoader performs, pygda/models/a2gnn.py:260-277).
  * ---------------------------------------------------------------------------- */

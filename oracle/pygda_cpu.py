@@ -789,6 +789,99 @@ def strurw_forward_model(net: ReweightGNN, src: Graph, tgt: Graph, alpha: float,
     return loss, s_logits, t_logits
 
 
+class MixUpGCNConv(nn.Module):
+    """MixUpGCNConv (mixup_gcnconv.py:69-247), flow source_to_target, add aggregation: the edge list is
+    gcn-normalised with UNIT weights and no self loops (:204-214; the weight it is handed is the
+    re-weighting factor, set aside as ``edge_rw`` :200-201), the message is
+    ``(1-lmda) n_e x_j + lmda rw_e n_e x_j`` (:242-245) and the centre term ``lin_cen(x_cen)`` plus the
+    bias is added to the aggregate (:231-236).  RNG order of __init__: lin, lin_cen, lin again (:122-133)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.lin = _Lin(in_channels, out_channels)
+        self.lin_cen = _Lin(in_channels, out_channels)
+        glorot_(self.lin.weight)                        # reset_parameters(): lin only
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+
+    def forward(self, x, x_cen, edge_index, edge_weight, lmda=1):
+        n = x.size(0)
+        deg = torch.zeros(n).index_add_(0, edge_index[1], torch.ones(edge_index.size(1)))
+        dis = deg.pow(-0.5)
+        dis.masked_fill_(dis == float("inf"), 0)
+        norm = dis[edge_index[0]] * dis[edge_index[1]]
+        h = x @ self.lin.weight.t()
+        m = norm.view(-1, 1) * h.index_select(0, edge_index[0])
+        m = (1 - lmda) * m + lmda * (edge_weight.view(-1, 1) * m)
+        out = torch.zeros(n, m.size(1)).index_add_(0, edge_index[1], m)
+        return out + x_cen @ self.lin_cen.weight.t() + self.bias
+
+
+class MixupBase(nn.Module):
+    """mixup_base.py:10-200: per layer three convolutions -- the plain one (x, x), the mixed-centre one
+    on the graph (x, x_mix) and the mixed-centre one on the SHUFFLED graph (x[perm], x_mix, edge_index_b)
+    -- and ``x_mix <- dropout(lam * act(new) + (1-lam) * act(new_b))``.  Needs num_layers >= 2 (:150)."""
+
+    def __init__(self, in_dim, hid_dim, num_classes, num_layers=1, dropout=0.1, act=F.relu, rw_lmda=0.8):
+        super().__init__()
+        self.dropout, self.act, self.rw_lmda = dropout, act, rw_lmda
+        self.convs = nn.ModuleList([MixUpGCNConv(in_dim, hid_dim)] +
+                                   [MixUpGCNConv(hid_dim, hid_dim) for _ in range(num_layers - 1)])
+        self.cls = nn.Linear(hid_dim, num_classes)
+
+    def _drop(self, x):
+        return F.dropout(x, p=self.dropout, training=self.training)
+
+    def feat_bottleneck(self, x, edge_index, edge_index_b, lam, id_new_value_old, edge_weight):
+        c, rw = self.convs, self.rw_lmda
+        x1 = self._drop(self.act(c[0](x, x, edge_index, edge_weight, rw)))              # :146-148
+        x2 = self._drop(self.act(c[1](x1, x1, edge_index, edge_weight, rw)))            # :150-152
+        x0_b, x1_b = x[id_new_value_old], x1[id_new_value_old]
+        x_mix = x * lam + x0_b * (1 - lam)                                              # :157
+        new_x1 = self.act(c[0](x, x_mix, edge_index, edge_weight, rw))
+        new_x1_b = self.act(c[0](x0_b, x_mix, edge_index_b, edge_weight, rw))
+        x1_mix = self._drop(new_x1 * lam + new_x1_b * (1 - lam))                        # :165-166
+        new_x2 = self.act(c[1](x1, x1_mix, edge_index, edge_weight, rw))
+        new_x2_b = self.act(c[1](x1_b, x1_mix, edge_index_b, edge_weight, rw))
+        x2_mix = self._drop(new_x2 * lam + new_x2_b * (1 - lam))                        # :174-175
+        x, x_mix = x2, x2_mix
+        for i in range(2, len(c)):                                                      # :180-194
+            x_t = self._drop(self.act(c[i](x, x, edge_index, edge_weight, rw)))
+            x_b = x[id_new_value_old]
+            new_x = self.act(c[i](x, x_mix, edge_index, edge_weight, rw))
+            new_x_b = self.act(c[i](x_b, x_mix, edge_index_b, edge_weight, rw))
+            x_mix = self._drop(new_x * lam + new_x_b * (1 - lam))
+            x = x_t
+        return x_mix
+
+    def forward(self, x, edge_index, edge_index_b, lam, id_new_value_old, edge_weight):
+        return self.cls(self.feat_bottleneck(x, edge_index, edge_index_b, lam, id_new_value_old, edge_weight))
+
+
+def strurw_shuffle(edge_index: Tensor, perm) -> Tensor:
+    """StruRW.shuffle_data + id_node (strurw.py:702-758): ``perm`` = id_new_value_old (new position -> old
+    node); the edge list relabelled old -> new, edge order unchanged."""
+    perm = torch.as_tensor(perm, dtype=torch.long)
+    old_to_new = torch.zeros(perm.numel(), dtype=torch.long)
+    old_to_new[perm] = torch.arange(perm.numel())
+    return torch.stack([old_to_new[edge_index[0]], old_to_new[edge_index[1]]], dim=0)
+
+
+def strurw_forward_model_mixup(net: MixupBase, src: Graph, tgt: Graph, epoch: int, lam: float, perm,
+                               reweight=True, pseudo=True, ew_start=100, ew_freq=20, num_classes: int = 0):
+    """strurw.py:259-313; the caller draws ``lam`` (np.random.beta(4, 4)) and ``perm`` (np.random.shuffle of
+    arange) in that order, as :292-293 do."""
+    import numpy as _np
+    n_t = tgt.x.size(0)
+    t_logits = net(tgt.x, tgt.edge_index, tgt.edge_index, 1, _np.arange(n_t), tgt.edge_weight)
+    t_pred = F.softmax(t_logits, dim=1).max(dim=1)[1]
+    if reweight and (epoch + 1) >= ew_start:
+        if (pseudo and (epoch + 1) % ew_freq == 0) or (not pseudo and epoch == ew_start - 1):
+            src.edge_weight = strurw_edge_weights(src, tgt, t_pred, num_classes)
+    s_logits = net(src.x, src.edge_index, strurw_shuffle(src.edge_index, perm), lam, perm, src.edge_weight)
+    loss = F.nll_loss(F.log_softmax(s_logits, dim=1), src.y)
+    return loss, s_logits, t_logits
+
+
 # ---------------------------------------------------------------------- SpecReg --
 def specreg_gradient_penalty(critic: nn.Module, x_src: Tensor, x_tgt: Tensor) -> Tensor:
     """SpecReg.calculate_gradient_penalty (specreg.py:380-419): no interpolation -- the critic's

@@ -14,7 +14,10 @@ from .gat_conv import GATConv
 from .gnn_base import GNNBase
 from .dgsda_base import BernProp, DGSDABase
 from .reweight_gnn import GCN_reweight, GS_reweight, ReweightGNN
+from .mixup_gcnconv import MixUpGCNConv
+from .mixup_base import MixupBase, ShuffledEdges
 
 __all__ = ["Linear", "glorot", "zeros", "PropGCNConv", "gcn_norm", "GCNConv", "CachedGCNConv", "PPMIConv",
            "ppmi_edges", "GradReverse", "Attention", "A2GNNBase", "GRADEBase", "UDAGCNBase", "AdaGCNBase", "SAGEConv", "GINConv", "GATConv", "GNNBase",
-           "global_mean_pool", "BernProp", "DGSDABase", "GCN_reweight", "GS_reweight", "ReweightGNN"]
+           "global_mean_pool", "BernProp", "DGSDABase", "GCN_reweight", "GS_reweight", "ReweightGNN", "MixUpGCNConv", "MixupBase",
+           "ShuffledEdges"]

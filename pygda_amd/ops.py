@@ -739,6 +739,63 @@ def relu_dropout(x, p, training=True):
     return _ReluDropout.apply(x, p)
 
 
+# ------------------------------------------ mixup layer epilogue (StruRW mode='mixup') --
+class _MixupCombine(torch.autograd.Function):
+    """gda_mixup_combine_{fwd,bwd}_f32: ``XX' = [drop(relu(P + C + b)) ; drop(lam relu(P + Cm + b) +
+    (1-lam) relu(Pb + Cm + b))]`` with ``Pb = P[perm]`` unless given (pygda/nn/mixup_base.py:146-196)."""
+
+    @staticmethod
+    def forward(ctx, P, Pb, CC, bias, perm, inv, lam, p, first):
+        P, CC, bias = _f32c(P, "P"), _f32c(CC, "CC"), _f32c(bias, "bias")
+        if Pb is not None:
+            Pb = _f32c(Pb, "Pb")
+        n, h = P.shape
+        if CC.shape != ((n, h) if first else (2 * n, h)):
+            raise ValueError(f"centre projections must be {'[n, h]' if first else '[2n, h]'}, got {tuple(CC.shape)}")
+        XX = torch.empty(2 * n, h, dtype=torch.float32, device=P.device)
+        mask = torch.empty(n, h, dtype=torch.uint8, device=P.device)
+        st = dropout_state
+        if st.seed is None:
+            st.seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+        L = _lib.lib()
+        _lib.check(L.gda_mixup_combine_fwd_f32(
+            _lib.ptr(P), _lib.ptr(Pb), _lib.ptr(CC), int(first), _lib.ptr(bias), _lib.ptr(perm), n, h, float(lam),
+            float(p), ctypes.c_uint64(st.seed), _lib.ptr(st.counter(P.device)), ctypes.c_uint32(st.next_site()),
+            ctypes.c_uint32(st.next_site()), _lib.ptr(XX), _lib.ptr(mask), _lib.stream()), "gda_mixup_combine_fwd_f32")
+        ctx.save_for_backward(XX, mask, inv)
+        ctx.cfg = (float(lam), float(p), bool(first), Pb is not None)
+        return XX
+
+    @staticmethod
+    def backward(ctx, gXX):
+        XX, mask, inv = ctx.saved_tensors
+        lam, p, first, sep = ctx.cfg
+        n, h = mask.shape
+        gXX = gXX.contiguous()
+        f32 = dict(dtype=torch.float32, device=gXX.device)
+        gP = torch.empty(n, h, **f32)
+        gPb = torch.empty(n, h, **f32) if sep else None
+        gCC = torch.empty(n if first else 2 * n, h, **f32)
+        gb = torch.empty(h, **f32)
+        L = _lib.lib()
+        nbytes = L.gda_mixup_combine_workspace_bytes(n, h)
+        ws = _lib.workspace(nbytes, gXX.device, "mixup")
+        _lib.check(L.gda_mixup_combine_bwd_f32(
+            _lib.ptr(gXX), _lib.ptr(XX), _lib.ptr(mask), _lib.ptr(inv), int(first), n, h, lam, p, _lib.ptr(gP),
+            _lib.ptr(gPb), _lib.ptr(gCC), _lib.ptr(gb), _lib.ptr(ws), nbytes, _lib.stream()), "gda_mixup_combine_bwd_f32")
+        return gP, gPb, gCC, gb, None, None, None, None, None
+
+
+def mixup_combine_ok(P, h):
+    return P.is_cuda and P.dtype == torch.float32 and h % 4 == 0 and h <= 1024
+
+
+def mixup_combine(P, Pb, CC, bias, perm, inv, lam, p, training, first):
+    """One mixup layer's epilogue -> the stacked pair ``[x' ; x_mix']`` ``[2n, h]``.  ``perm`` / ``inv`` are
+    int64 device vectors (new position -> old node and its inverse)."""
+    return _MixupCombine.apply(P, Pb, CC, bias, perm, inv, float(lam), float(p) if training else 0.0, bool(first))
+
+
 # ------------------------------------------------- Laplacian smoothness (TDSS) --
 class _Laplacian(torch.autograd.Function):
     """``1/2 sum_e ||f[row] dinv[row] - f[col] dinv[col]||^2`` over the edges of ``graph`` (built

@@ -106,6 +106,12 @@ def zeros(t):
         t.data.fill_(0)
 
 
+def uniform(size, t):        # imported by mixup_gcnconv.py for a GraphConv class StruRW never builds
+    if t is not None:
+        bound = 1.0 / math.sqrt(size)
+        t.data.uniform_(-bound, bound)
+
+
 class Linear(torch.nn.Module):
     def __init__(self, in_channels, out_channels, bias=True, weight_initializer=None,
                  bias_initializer=None):
@@ -352,7 +358,7 @@ def install():
     for missing in ('SAGEConv', 'GATConv', 'GINConv'):
         setattr(nn_m, missing, None)
     inits = _mod('torch_geometric.nn.inits')
-    inits.glorot, inits.zeros = glorot, zeros
+    inits.glorot, inits.zeros, inits.uniform = glorot, zeros, uniform
     dense = _mod('torch_geometric.nn.dense')
     lin = _mod('torch_geometric.nn.dense.linear')
     lin.Linear = Linear

@@ -93,7 +93,11 @@ def load_reference(with_pyg_stub=True):
     dg = _load("pygda.models.dgsda", "pygda/models/dgsda.py")
     ns.BernProp, ns.DGSDABase, ns.DGSDA = dgb.BernProp, dgb.DGSDABase, dg.DGSDA
     rwg = _load("pygda.nn.reweight_gnn", "pygda/nn/reweight_gnn.py")
-    NN.ReweightGNN, NN.MixupBase = rwg.ReweightGNN, None      # mixup mode is outside the covered rows
+    mxc = _load("pygda.nn.mixup_gcnconv", "pygda/nn/mixup_gcnconv.py")
+    NN.MixUpGCNConv = mxc.MixUpGCNConv
+    mxb = _load("pygda.nn.mixup_base", "pygda/nn/mixup_base.py")
+    NN.ReweightGNN, NN.MixupBase = rwg.ReweightGNN, mxb.MixupBase
+    ns.MixUpGCNConv, ns.MixupBase = mxc.MixUpGCNConv, mxb.MixupBase
     stw = _load("pygda.models.strurw", "pygda/models/strurw.py")
     ns.ReweightGNN, ns.GCN_reweight, ns.GS_reweight, ns.StruRW = rwg.ReweightGNN, rwg.GCN_reweight, rwg.GS_reweight, stw.StruRW
     sr = _load("pygda.models.specreg", "pygda/models/specreg.py")

@@ -707,6 +707,62 @@ def fx_strurw(ref):
 FIXTURES["strurw"] = fx_strurw
 
 
+def fx_strurw_mixup(ref):
+    """StruRW(mode='mixup') (strurw.py:259-313, mixup_base.py, mixup_gcnconv.py): forward_model_mixup with the
+    re-weighting step firing, for 2 and 3 layers (the i >= 2 loop of MixupBase), loss + grads; the numpy draws
+    (``lam`` = beta(4, 4), then the node shuffle) are stored so that a restatement can be handed the same ones;
+    and a 3-epoch fit()/predict() trajectory from fixed torch and numpy seeds."""
+    import pygda.models.strurw as smod
+    s, t = _domain_pair(191, ns=90, nt=70, f=12, c=3)
+    arrs = dict(_pair_arrays(s, t))
+    smod.print = lambda *a, **k: None
+    losses, accs = [], []
+    orig = smod.logger
+    smod.logger = lambda **kw_: (losses.append(kw_["loss"]), accs.append(kw_["source_train_acc"]))
+    try:
+        for layers in (2, 3):
+            tag = f"L{layers}"
+            m = ref.StruRW(12, 8, 3, num_layers=layers, dropout=0.0, reweight=True, pseudo=True, ew_start=1,
+                           ew_freq=1, lamb=0.8, mode="mixup", lr=0.01, weight_decay=0.001, device="cpu", epoch=3,
+                           verbose=0)
+            torch.manual_seed(192)
+            m.gnn = m.init_model()
+            m.gnn.train()
+            s.edge_weight, t.edge_weight = torch.ones(s.edge_index.size(1)), torch.ones(t.edge_index.size(1))
+            arrs.update(sd_arrays(m.gnn, f"{tag}/param/"))
+            np.random.seed(193)
+            lam = np.random.beta(4.0, 4.0)                     # the draws forward_model_mixup is about to make
+            perm = np.arange(s.x.size(0)); np.random.shuffle(perm)
+            np.random.seed(193)
+            loss, sl, tl = m.forward_model_mixup(s, t, 0)
+            loss.backward()
+            arrs.update({f"{tag}/lam": np.float64(lam), f"{tag}/perm": perm.astype(np.int64), f"{tag}/loss": np_(loss),
+                         f"{tag}/src_logits": np_(sl), f"{tag}/tgt_logits": np_(tl),
+                         f"{tag}/src_edge_weight": np_(s.edge_weight)})
+            arrs.update(grads(m.gnn, f"{tag}/grad/"))
+        arrs.update(init_seed=np.int64(192), np_seed=np.int64(193))
+        losses.clear(); accs.clear()
+        m = ref.StruRW(12, 8, 3, num_layers=2, dropout=0.0, reweight=True, pseudo=True, ew_start=2, ew_freq=1,
+                       lamb=0.8, mode="mixup", lr=0.01, weight_decay=0.001, device="cpu", epoch=3, verbose=0)
+        s.edge_weight, t.edge_weight = None, None
+        torch.manual_seed(194)
+        np.random.seed(195)
+        m.fit(s, t)
+        logits, labels = m.predict(t)
+        arrs.update({"fit/losses": np.array(losses, dtype=np.float64), "fit/accs": np.array(accs, dtype=np.float64),
+                     "fit/tgt_logits": np_(logits), "fit/tgt_labels": np_(labels),
+                     "fit/src_edge_weight": np_(s.edge_weight)})
+        arrs.update(sd_arrays(m.gnn, "fit/final/"))
+        arrs.update(fit_seed=np.int64(194), fit_np_seed=np.int64(195))
+    finally:
+        smod.logger = orig
+        del smod.print
+    save("strurw_mixup", **arrs)
+
+
+FIXTURES["strurw_mixup"] = fx_strurw_mixup
+
+
 def main(argv):
     ref = load_reference()
     for name in (argv or list(FIXTURES)):

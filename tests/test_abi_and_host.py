@@ -267,8 +267,79 @@ def test_strurw_signature_and_mode_guard():
         assert sig[k].default == v, k
     with pytest.raises(AssertionError):
         StruRW(4, 4, 2, mode='other')
-    with pytest.raises(NotImplementedError):
-        StruRW(4, 4, 2, mode='mixup')
+    assert StruRW(4, 4, 2, mode='mixup', device='cpu').init_model().__class__.__name__ == 'MixupBase'
+
+
+def _mixup_on_oracle(monkeypatch):
+    """The mixup trainer's host logic on CPU tensors: the oracle's scatter-add underneath the conv's graph /
+    aggregation calls (the product kernels have no CPU path), everything above them is the product's code."""
+    from oracle import pygda_cpu as O
+    import pygda_amd.nn.mixup_gcnconv as MC
+
+    def build_csr(edge_index, n, val, add_self_loops=False, normalize=False):
+        return edge_index, val
+
+    def propagate(x, graph, K=1, bias=None):
+        return O.propagate(graph[0], graph[1], x)
+
+    monkeypatch.setattr(MC, "build_csr", build_csr)
+    monkeypatch.setattr(MC, "propagate", propagate)
+
+
+def test_strurw_mixup_host_logic_against_reference_fit(monkeypatch):
+    """fit()/predict() of mode='mixup' against the reference's 3-epoch trajectory: numpy draws in the
+    reference's order (lam, then the shuffle), re-weighting on the step that computes it, unit weights put back
+    by predict(), ONE aggregation per layer standing in for the reference's three (the shuffled graph is a
+    renumbering)."""
+    from tests.conftest import load_golden, sub
+    from pygda_amd.data import Data
+    from pygda_amd.models import StruRW
+    _mixup_on_oracle(monkeypatch)
+    g = load_golden("strurw_mixup")
+    T = torch.from_numpy
+    s = Data(x=T(g["src_x"]), edge_index=T(g["src_ei"]), y=T(g["src_y"]))
+    t = Data(x=T(g["tgt_x"]), edge_index=T(g["tgt_ei"]), y=T(g["tgt_y"]))
+    losses = []
+    m = StruRW(12, 8, 3, num_layers=2, dropout=0.0, reweight=True, pseudo=True, ew_start=2, ew_freq=1, lamb=0.8,
+               mode="mixup", lr=0.01, weight_decay=0.001, device="cpu", epoch=3, verbose=0)
+    m.epoch_hook = lambda e, loss, acc, secs: losses.append((loss, acc))
+    torch.manual_seed(int(g["fit_seed"]))
+    np.random.seed(int(g["fit_np_seed"]))
+    m.fit(s, t)
+    np.testing.assert_allclose([l for l, _ in losses], g["fit/losses"], rtol=1e-5)
+    np.testing.assert_allclose([a for _, a in losses], g["fit/accs"], rtol=1e-6)
+    logits, labels = m.predict(t)
+    np.testing.assert_allclose(logits.numpy(), g["fit/tgt_logits"], atol=2e-5)
+    assert np.array_equal(labels.numpy(), g["fit/tgt_labels"])
+    for k, v in sub(g, "fit/final/").items():
+        np.testing.assert_allclose(m.gnn.state_dict()[k].numpy(), v, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("layers", [2, 3])
+def test_mixup_base_foreign_edge_index_b(monkeypatch, layers):
+    """A materialised ``edge_index_b`` tensor (what a caller of the reference's MixupBase passes) takes the
+    second-aggregation route and lands on the reference's numbers, like the ShuffledEdges record does."""
+    from tests.conftest import load_golden, sub
+    from pygda_amd.nn import MixupBase, ShuffledEdges
+    _mixup_on_oracle(monkeypatch)
+    g = load_golden("strurw_mixup")
+    tag = f"L{layers}"
+    T = torch.from_numpy
+    x, ei, y = T(g["src_x"]), T(g["src_ei"]), T(g["src_y"])
+    w = T(g[f"{tag}/src_edge_weight"])
+    perm, lam = g[f"{tag}/perm"], float(g[f"{tag}/lam"])
+    torch.manual_seed(int(g["init_seed"]))
+    net = MixupBase(12, 8, 3, num_layers=layers, dropout=0.0, rw_lmda=0.8)
+    for k, v in sub(g, f"{tag}/param/").items():
+        np.testing.assert_array_equal(net.state_dict()[k].numpy(), v, err_msg=k)
+    record = ShuffledEdges(ei, perm)
+    for edge_index_b in (record, record.tensor()):
+        net.zero_grad()
+        logits = net(x, ei, edge_index_b, lam, perm, w)
+        np.testing.assert_allclose(logits.detach().numpy(), g[f"{tag}/src_logits"], atol=1e-5)
+        torch.nn.functional.cross_entropy(logits, y).backward()
+        for k, v in sub(g, f"{tag}/grad/").items():
+            np.testing.assert_allclose(dict(net.named_parameters())[k].grad.numpy(), v, atol=1e-5, err_msg=k)
 
 
 def test_kstep_plan_is_the_csr_program():

@@ -1269,6 +1269,162 @@ def test_strurw_fit_predict_golden(gnn, mode):
     exact(logits.argmax(1), g[f"{tag}/tgt_logits"].argmax(1))
 
 
+# ------------------------------------------------------------ StruRW, mode='mixup' --
+def _mixup_composition(P, Pb, CC, b, perm, lam, first, keep_x=None, keep_m=None, scale=1.0):
+    """mixup_base.py:146-196's tail as torch ops (float64 inputs -> the reference value of the fused kernel)."""
+    n = P.size(0)
+    C, Cm = (CC, lam * CC + (1 - lam) * CC[perm]) if first else (CC[:n], CC[n:])
+    Pb = P[perm] if Pb is None else Pb
+    xn = torch.relu(P + C + b)
+    xm = lam * torch.relu(P + Cm + b) + (1 - lam) * torch.relu(Pb + Cm + b)
+    if keep_x is not None:
+        xn, xm = xn * keep_x * scale, xm * keep_m * scale
+    return torch.cat([xn, xm])
+
+
+@pytest.mark.parametrize("n,h", [(90, 8), (1000, 128), (4097, 36), (3, 1024), (20000, 64)])
+@pytest.mark.parametrize("first", [True, False])
+@pytest.mark.parametrize("sep", [False, True])
+def test_mixup_combine_matches_composition(n, h, first, sep):
+    """gda_mixup_combine_{fwd,bwd}_f32 against the torch composition in float64: every output and all four
+    gradients (aggregate incl. its P[perm] route, explicit Pb, centre projections, bias)."""
+    gen = torch.Generator().manual_seed(n * 7 + h)
+    mk = lambda *shape: torch.randn(*shape, generator=gen).to(DEV).requires_grad_()
+    P, CC, b = mk(n, h), mk(n if first else 2 * n, h), mk(h)
+    Pb = mk(n, h) if sep else None
+    perm = torch.randperm(n, generator=gen).to(DEV)
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(n, device=DEV)
+    lam = 0.37
+    XX = ops.mixup_combine(P, Pb, CC, b, perm, inv, lam, 0.0, True, first)
+    w = torch.randn(2 * n, h, generator=gen).to(DEV)
+    ins = [t for t in (P, Pb, CC, b) if t is not None]
+    got = torch.autograd.grad((XX * w).sum(), ins)
+    d = [t.detach().double().requires_grad_() for t in ins]
+    Pd, Pbd, CCd, bd = (d[0], d[1], d[2], d[3]) if sep else (d[0], None, d[1], d[2])
+    want = _mixup_composition(Pd, Pbd, CCd, bd, perm, lam, first)
+    wg = torch.autograd.grad((want * w.double()).sum(), d)
+    close(XX, want.float(), rtol=1e-5, atol=1e-6)
+    for a, r in zip(got, wg):
+        close(a, r.float(), rtol=1e-4, atol=1e-4 * float(r.abs().max()))
+    exact(ops.mixup_combine(P, Pb, CC, b, perm, inv, lam, 0.0, True, first), XX)
+    got2 = torch.autograd.grad((ops.mixup_combine(P, Pb, CC, b, perm, inv, lam, 0.0, True, first) * w).sum(), ins)
+    for a, r in zip(got, got2):
+        exact(a, r)                                                  # the bias column sum is a fixed-order reduction
+
+
+@pytest.mark.parametrize("first", [True, False])
+def test_mixup_combine_dropout(first):
+    """p > 0: the dropped fraction, kept values = 1/(1-p) x the p = 0 values, independent masks on the two
+    halves, and the backward pass = autograd through the composition with the forward's own masks."""
+    n, h, p, lam = 3000, 64, 0.3, 0.6
+    gen = torch.Generator().manual_seed(5)
+    mk = lambda *shape: torch.randn(*shape, generator=gen).to(DEV).requires_grad_()
+    P, CC, b = mk(n, h), mk(n if first else 2 * n, h), mk(h)
+    perm = torch.randperm(n, generator=gen).to(DEV)
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(n, device=DEV)
+    ops.dropout_state.next_step(torch.device(DEV))
+    XX = ops.mixup_combine(P, None, CC, b, perm, inv, lam, p, True, first)
+    base = ops.mixup_combine(P, None, CC, b, perm, inv, lam, 0.0, True, first).detach()
+    live = base > 0
+    kept = (XX != 0) & live
+    for half in (slice(0, n), slice(n, 2 * n)):
+        frac = 1.0 - kept[half].sum().item() / live[half].sum().item()
+        assert abs(frac - p) < 0.01, frac
+    close(XX[kept], base[kept] / (1 - p), rtol=1e-6)
+    assert (XX[~kept] == 0).all()
+    assert 0.35 < ((kept[:n] == kept[n:]) & live[:n] & live[n:]).sum().item() / (live[:n] & live[n:]).sum().item() < 0.75
+    w = torch.randn(2 * n, h, generator=gen).to(DEV)
+    got = torch.autograd.grad((XX * w).sum(), [P, CC, b])
+    d = [t.detach().double().requires_grad_() for t in (P, CC, b)]
+    want = _mixup_composition(d[0], None, d[1], d[2], perm, lam, first, kept[:n].double(), kept[n:].double(), 1 / (1 - p))
+    wg = torch.autograd.grad((want * w.double()).sum(), d)
+    for a, r in zip(got, wg):
+        close(a, r.float(), rtol=1e-4, atol=1e-4 * float(r.abs().max()))
+    assert (ops.mixup_combine(P, None, CC, b, perm, inv, lam, p, False, first) == base).all()    # eval: no dropout
+
+
+def _mixup_trainer(layers, **kw):
+    cfg = dict(num_layers=layers, dropout=0.0, reweight=True, pseudo=True, ew_start=1, ew_freq=1, lamb=0.8, mode="mixup",
+               lr=0.01, weight_decay=0.001, device=DEV, epoch=3, verbose=0)
+    cfg.update(kw)
+    return pygda_amd.models.StruRW(12, 8, 3, **cfg)
+
+
+@pytest.mark.parametrize("layers", [2, 3])
+def test_strurw_mixup_forward_model_golden(layers):
+    """forward_model_mixup (strurw.py:259-313) with ONE aggregation per layer + the fused epilogue against the
+    reference's three convolutions per layer: numpy draws reproduced from the seed, re-weighted edges exact,
+    loss / logits / gradients at the usual tolerances."""
+    g = load_golden("strurw_mixup")
+    tag = f"L{layers}"
+    s, t = _pair(g)
+    m = _mixup_trainer(layers)
+    torch.manual_seed(int(g["init_seed"]))
+    m.gnn = m.init_model()
+    for k, v in sub(g, f"{tag}/param/").items():
+        exact(m.gnn.state_dict()[k], v)
+    m.gnn.train()
+    sd_, td_ = s.to(DEV), t.to(DEV)
+    sd_.edge_weight = torch.ones(sd_.edge_index.size(1), device=DEV)
+    td_.edge_weight = torch.ones(td_.edge_index.size(1), device=DEV)
+    np.random.seed(int(g["np_seed"]))
+    loss, sl, tl = m.forward_model_mixup(sd_, td_, 0)
+    loss.backward()
+    exact(sd_.edge_weight, g[f"{tag}/src_edge_weight"])
+    close(loss, g[f"{tag}/loss"], rtol=REL)
+    close(sl, g[f"{tag}/src_logits"], rtol=0, atol=LOGIT_ATOL); close(tl, g[f"{tag}/tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    named = dict(m.gnn.named_parameters())
+    for k, v in sub(g, f"{tag}/grad/").items():
+        close(named[k].grad, v, rtol=1e-3, atol=1e-4 * max(np.abs(v).max(), 1e-3))
+    # a caller of the reference's MixupBase hands a renumbered edge tensor: second-aggregation route, same numbers
+    from pygda_amd.nn import ShuffledEdges
+    perm, lam = g[f"{tag}/perm"], float(g[f"{tag}/lam"])
+    ei_b = ShuffledEdges(sd_.edge_index, perm).tensor()
+    exact(ei_b, O.strurw_shuffle(T(g["src_ei"]), perm))
+    close(m.gnn(sd_.x, sd_.edge_index, ei_b, lam, perm, sd_.edge_weight), g[f"{tag}/src_logits"], rtol=0, atol=LOGIT_ATOL)
+
+
+def test_strurw_mixup_fit_predict_golden():
+    g = load_golden("strurw_mixup")
+    s, t = _pair(g)
+    m = _mixup_trainer(2, ew_start=2)
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+    torch.manual_seed(int(g["fit_seed"]))
+    np.random.seed(int(g["fit_np_seed"]))
+    m.fit(s, t)
+    close([x[0] for x in seen], g["fit/losses"], rtol=REL)
+    close([x[1] for x in seen], g["fit/accs"], rtol=0, atol=1e-12)
+    exact(s.edge_weight, g["fit/src_edge_weight"])                   # predict() put the unit weights back (:694-696)
+    logits, labels = m.predict(t)
+    close(logits, g["fit/tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    exact(labels, g["fit/tgt_labels"])
+    exact(logits.argmax(1), g["fit/tgt_logits"].argmax(1))
+    for k, v in sub(g, "fit/final/").items():
+        close(m.gnn.state_dict()[k], v, rtol=1e-3, atol=1e-5)
+
+
+def test_strurw_mixup_dropout_and_wide_layers_train():
+    """hid_dim = 128 on a 5k-node pair with dropout: the fused epilogue on the sizes it is built for -- finite,
+    the loss falls, and eval-mode predict() is deterministic."""
+    gen = torch.Generator().manual_seed(9)
+    def dom(n, e):
+        y = torch.randint(0, 4, (n,), generator=gen)
+        x = torch.randn(n, 32, generator=gen) + F.one_hot(y, 32).float() * 2
+        return Data(x=x, edge_index=torch.randint(0, n, (2, e), generator=gen), y=y)
+    s, t = dom(5000, 30000), dom(4000, 24000)
+    m = pygda_amd.models.StruRW(32, 128, 4, num_layers=3, dropout=0.2, ew_start=3, ew_freq=2, mode="mixup", lr=0.01,
+                                device=DEV, epoch=8, verbose=0)
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append(loss)
+    torch.manual_seed(1); np.random.seed(1)
+    m.fit(s, t)
+    assert np.isfinite(seen).all() and seen[-1] < seen[0]
+    a, _ = m.predict(t)
+    b, _ = m.predict(t)
+    exact(a, b)
+
+
 @pytest.mark.parametrize("n,c", [(9360, 5), (150000, 5), (7, 3), (1000, 64), (1, 2)])
 def test_softmax_nll_vs_torch(n, c):
     gen = torch.Generator().manual_seed(n + c)

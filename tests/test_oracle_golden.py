@@ -544,6 +544,57 @@ def test_strurw_fit_trajectory(gnn, mode):
         eq(net(tgt, tgt.x)[1], g[f"{tag}/tgt_logits"], tol=1e-5)
 
 
+@pytest.mark.parametrize("layers", [2, 3])
+def test_strurw_mixup_forward_model(layers):
+    """mode='mixup' (strurw.py:259-313): the restated MixupBase / MixUpGCNConv against the reference's loss,
+    logits, re-weighted source edges and gradients, handed the reference's own numpy draws."""
+    g = load_golden("strurw_mixup")
+    tag = f"L{layers}"
+    src, tgt = _strurw_graphs(g)
+    torch.manual_seed(int(g["init_seed"]))
+    net = O.MixupBase(12, 8, 3, num_layers=layers, dropout=0.0, rw_lmda=0.8)
+    for k, v in sub(g, f"{tag}/param/").items():
+        eq(net.state_dict()[k], v)
+    net.train()
+    loss, sl, tl = O.strurw_forward_model_mixup(net, src, tgt, 0, float(g[f"{tag}/lam"]), g[f"{tag}/perm"],
+                                                True, True, 1, 1, 3)
+    loss.backward()
+    eq(src.edge_weight, g[f"{tag}/src_edge_weight"])
+    eq(loss, g[f"{tag}/loss"], tol=1e-6); eq(sl, g[f"{tag}/src_logits"], tol=1e-6); eq(tl, g[f"{tag}/tgt_logits"], tol=1e-6)
+    named = dict(net.named_parameters())
+    for k, v in sub(g, f"{tag}/grad/").items():
+        eq(named[k].grad, v, tol=1e-5)
+
+
+def test_strurw_mixup_fit_trajectory():
+    """Three epochs of fit() in mixup mode: ``lam`` and the shuffle come from numpy's global generator in the
+    reference's order (:292-293), and predict() puts unit weights back on the graph it is handed (:694-696),
+    so the re-weighting lives for the step that computed it."""
+    g = load_golden("strurw_mixup")
+    src, tgt = _strurw_graphs(g)
+    torch.manual_seed(int(g["fit_seed"]))
+    np.random.seed(int(g["fit_np_seed"]))
+    net = O.MixupBase(12, 8, 3, num_layers=2, dropout=0.0, rw_lmda=0.8)
+    opt = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=0.001)
+    losses = []
+    for epoch in range(3):
+        net.train()
+        lam = np.random.beta(4.0, 4.0)
+        perm = np.arange(src.x.size(0)); np.random.shuffle(perm)
+        loss, _, _ = O.strurw_forward_model_mixup(net, src, tgt, epoch, lam, perm, True, True, 2, 1, 3)
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(loss.item())
+        src.edge_weight = torch.ones(src.edge_index.size(1))          # predict(source) of the epoch loop
+    eq(np.array(losses), g["fit/losses"], tol=1e-5)
+    eq(src.edge_weight, g["fit/src_edge_weight"])
+    for k, v in sub(g, "fit/final/").items():
+        eq(net.state_dict()[k], v, tol=1e-5)
+    net.eval()
+    with torch.no_grad():
+        out = net(tgt.x, tgt.edge_index, tgt.edge_index, 1, np.arange(tgt.x.size(0)), tgt.edge_weight)
+    eq(out, g["fit/tgt_logits"], tol=1e-5)
+
+
 def test_udagcn_fit_trajectory_with_shared_parameters():
     """Three epochs of udagcn.py:270-336 with the PPMI view.  The reference hands Adam the shared conv
     Parameters twice (encoder + ppmi_encoder, :262-268); the restated loop does the same, so whatever
