@@ -329,6 +329,27 @@ int gda_relu_dropout_fwd_cm_f32(const float* xT, int64_t ldT, float* y, int64_t 
 int gda_relu_dropout_bwd_cm_f32(const float* gy, const float* y, float* gxT, int64_t ldT, int64_t n, int64_t d,
                                float p, gda_stream_t stream);
 
+/* Two independent dropout draws of one activation, stacked: y [2n, d], y[i] = drop_a(relu(x[i])),
+ * y[n + i] = drop_b(relu(x[i])) -- A2GNN's source feature pass and source logits pass (pygda/models/a2gnn.py:181,192:
+ * the same layers on the same input, separate dropout draws) continue as ONE pass over 2n rows.  Backward sums the
+ * halves: gx[i] = ((y[i] > 0) gy[i] + (y[n+i] > 0) gy[n+i]) / (1 - p).  d % 4 == 0.
+ * gda_stack2_f32: out = [a ; b] of half_elems floats each (a NULL half reads as zeros) -- the gradient of such a
+ * pair whose halves went to different consumers (MMD rows / classifier). */
+int gda_relu_dropout_pair_fwd_f32(const float* x, float* y, int64_t n, int64_t d, float p, uint64_t seed,
+                                  const int64_t* step, uint32_t site_a, uint32_t site_b, gda_stream_t stream);
+/* colsum (may be NULL) [d]: column sums of gx as a by-product (the bias gradient of the layer that produced x);
+ * needs workspace of gda_relu_dropout_pair_workspace_bytes(d) and d <= 1024. */
+size_t gda_relu_dropout_pair_workspace_bytes(int64_t d);
+int gda_relu_dropout_pair_bwd_f32(const float* gy, const float* y, float* gx, int64_t n, int64_t d, float p,
+                                  float* colsum, void* workspace, size_t workspace_bytes, gda_stream_t stream);
+int gda_stack2_f32(const float* a, const float* b, float* out, int64_t half_elems, gda_stream_t stream);
+
+/* Column sums of a row-major [n, d] matrix (ld = ldx): the bias gradient `gy.sum(0)` of a conv layer
+ * (out += self.bias, pygda/nn/prop_gcn_conv.py:212-213) as a deterministic two-stage sum; d <= 1024. */
+size_t gda_colsum_workspace_bytes(int64_t n, int64_t d);
+int gda_colsum_f32(const float* x, int64_t ldx, int64_t n, int64_t d, float* out, void* workspace,
+                   size_t workspace_bytes, gda_stream_t stream);
+
 /* ------------------------------------------------------------------------------
  * Layer epilogue of StruRW's mixup backbone -- replaces the elementwise tail of the three
  * MixUpGCNConv calls per layer in pygda/nn/mixup_base.py:146-196 (out = Agg(lin(x)) + lin_cen(x_cen)
@@ -553,6 +574,12 @@ int gda_csr_square_host(const int32_t* rowptr_host, const int32_t* colidx_host, 
 size_t gda_softmax_nll_workspace_bytes(void);
 int gda_softmax_nll_fwd_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
                             float* loss, void* workspace, size_t workspace_bytes, gda_stream_t stream);
+/* _ex: stats (may be NULL) [2] doubles = {loss, number of rows whose argmax (first maximum, as torch.argmax) is the
+ * label}: the per-epoch log line of every trainer (loss.item(), source micro-F1 = accuracy of the single-label
+ * predictions, pygda/models/a2gnn.py:326-343) as a by-product of the pass that reads the logits anyway. */
+int gda_softmax_nll_fwd_ex_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
+                               float* loss, double* stats, void* workspace, size_t workspace_bytes,
+                               gda_stream_t stream);
 int gda_softmax_nll_bwd_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
                             const float* grad_loss, float* grad_logits, int64_t ldg, gda_stream_t stream);
 

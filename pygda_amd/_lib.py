@@ -74,6 +74,14 @@ _SIGNATURES = {
     "gda_kstep_lds_f32": (c_int, [_P, c_int, c_int64, c_int64, c_int, _P, c_int64, c_int, _P, c_int64, c_int,
                                   _P, _P, _P, _P]),
     "gda_kstep_lds_colmajor_f32": (c_int, [_P, c_int, c_int64, c_int64, c_int, _P, c_int64, _P, c_int64, _P, _P, _P]),
+    "gda_relu_dropout_pair_fwd_f32": (c_int, [_P, _P, c_int64, c_int64, c_float, ctypes.c_uint64, _P, ctypes.c_uint32,
+                                              ctypes.c_uint32, _P]),
+    "gda_relu_dropout_pair_workspace_bytes": (ctypes.c_size_t, [c_int64]),
+    "gda_relu_dropout_pair_bwd_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_float, _P, _P, ctypes.c_size_t, _P]),
+    "gda_stack2_f32": (c_int, [_P, _P, _P, c_int64, _P]),
+    "gda_colsum_workspace_bytes": (ctypes.c_size_t, [c_int64, c_int64]),
+    "gda_colsum_f32": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, ctypes.c_size_t, _P]),
+    "gda_softmax_nll_fwd_ex_f32": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, _P, ctypes.c_size_t, _P]),
     "gda_mixup_combine_workspace_bytes": (ctypes.c_size_t, [c_int64, c_int64]),
     "gda_mixup_combine_fwd_f32": (c_int, [_P, _P, _P, c_int, _P, _P, c_int64, c_int64, c_float, c_float, ctypes.c_uint64,
                                           _P, ctypes.c_uint32, ctypes.c_uint32, _P, _P, _P]),

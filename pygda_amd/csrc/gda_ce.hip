@@ -23,37 +23,61 @@ __device__ __forceinline__ float row_lse(const float* __restrict__ x, int C, flo
     return mx + logf(s);
 }
 
-__global__ void __launch_bounds__(TB)
-k_ce_fwd(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ y, int64_t N, int C,
-         double* __restrict__ partial) {
-    __shared__ double sh[TB];
-    double acc = 0.0;
-    float v[MAXC];
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < N; i += (int64_t)gridDim.x * TB) {
-        const float lse = row_lse(x + i * ldx, C, v);
-        acc += (double)(lse - x[i * ldx + y[i]]);
-    }
+// first index attaining the row maximum, NaN counting as the largest value (torch.argmax)
+__device__ __forceinline__ int row_argmax(const float (&v)[MAXC], int C) {
+    float best = v[0];
+    int bi = 0;
+    for (int c = 1; c < C; ++c)
+        if (v[c] > best || (v[c] != v[c] && best == best)) { best = v[c]; bi = c; }
+    return bi;
+}
+
+__device__ __forceinline__ double block_sum(double (&sh)[TB], double acc) {
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int s = TB / 2; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// partial[b] = loss sum of block b; COUNT: partial[CE_BLOCKS + b] = rows of block b whose argmax is the label
+template <bool COUNT>
+__global__ void __launch_bounds__(TB)
+k_ce_fwd(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ y, int64_t N, int C,
+         double* __restrict__ partial) {
+    __shared__ double sh[TB];
+    double acc = 0.0, hit = 0.0;
+    float v[MAXC];
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < N; i += (int64_t)gridDim.x * TB) {
+        const float lse = row_lse(x + i * ldx, C, v);
+        acc += (double)(lse - x[i * ldx + y[i]]);
+        if (COUNT) hit += row_argmax(v, C) == (int)y[i] ? 1.0 : 0.0;
+    }
+    const double a = block_sum(sh, acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = a;
+    if (COUNT) {
+        const double h = block_sum(sh, hit);
+        if (threadIdx.x == 0) partial[CE_BLOCKS + blockIdx.x] = h;
+    }
 }
 
 __global__ void __launch_bounds__(TB)
-k_ce_final(const double* __restrict__ partial, int n, int64_t N, float* __restrict__ loss) {
+k_ce_final(const double* __restrict__ partial, int n, int64_t N, float* __restrict__ loss, double* __restrict__ stats) {
     __shared__ double sh[TB];
-    double a = 0.0;
+    double a = 0.0, h = 0.0;
     for (int k = threadIdx.x; k < n; k += TB) a += partial[k];
-    sh[threadIdx.x] = a;
-    __syncthreads();
-    for (int s = TB / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-        __syncthreads();
+    if (stats)
+        for (int k = threadIdx.x; k < n; k += TB) h += partial[CE_BLOCKS + k];
+    a = block_sum(sh, a);
+    if (stats) h = block_sum(sh, h);
+    if (threadIdx.x == 0) {
+        *loss = (float)(a / (double)N);
+        if (stats) { stats[0] = (double)*loss; stats[1] = h; }
     }
-    if (threadIdx.x == 0) *loss = (float)(sh[0] / (double)N);
 }
 
 __global__ void __launch_bounds__(TB)
@@ -71,11 +95,11 @@ k_ce_bwd(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ y
 
 }  // namespace
 
-extern "C" size_t gda_softmax_nll_workspace_bytes(void) { return CE_BLOCKS * sizeof(double); }
+extern "C" size_t gda_softmax_nll_workspace_bytes(void) { return 2 * CE_BLOCKS * sizeof(double); }
 
-extern "C" int gda_softmax_nll_fwd_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
-                                       float* loss, void* workspace, size_t workspace_bytes,
-                                       gda_stream_t stream_) {
+extern "C" int gda_softmax_nll_fwd_ex_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
+                                          float* loss, double* stats, void* workspace, size_t workspace_bytes,
+                                          gda_stream_t stream_) {
     if (N < 0 || C < 1 || C > MAXC || ld < C) return C > MAXC ? GDA_E_UNSUPPORTED : GDA_E_SIZE;
     if (!loss || !workspace || (N > 0 && (!logits || !labels))) return GDA_E_NULL;
     if (workspace_bytes < gda_softmax_nll_workspace_bytes()) return GDA_E_WORKSPACE;
@@ -83,14 +107,25 @@ extern "C" int gda_softmax_nll_fwd_f32(const float* logits, int64_t ld, const in
     if (N == 0) {                                             // mean over nothing: nan, as torch
         const float nanv = __builtin_nanf("");
         GDA_HIP_TRY(hipMemcpyAsync(loss, &nanv, sizeof(float), hipMemcpyHostToDevice, stream));
+        if (stats) {
+            const double st[2] = {(double)nanv, 0.0};
+            GDA_HIP_TRY(hipMemcpyAsync(stats, st, sizeof(st), hipMemcpyHostToDevice, stream));
+        }
         return GDA_OK;
     }
     const int blocks = (int)(gda_cdiv(N, TB) < CE_BLOCKS ? gda_cdiv(N, TB) : CE_BLOCKS);
-    k_ce_fwd<<<blocks, TB, 0, stream>>>(logits, ld, labels, N, C, (double*)workspace);
+    if (stats) k_ce_fwd<true><<<blocks, TB, 0, stream>>>(logits, ld, labels, N, C, (double*)workspace);
+    else k_ce_fwd<false><<<blocks, TB, 0, stream>>>(logits, ld, labels, N, C, (double*)workspace);
     GDA_LAUNCH_CHECK();
-    k_ce_final<<<1, TB, 0, stream>>>((const double*)workspace, blocks, N, loss);
+    k_ce_final<<<1, TB, 0, stream>>>((const double*)workspace, blocks, N, loss, stats);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
+}
+
+extern "C" int gda_softmax_nll_fwd_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
+                                       float* loss, void* workspace, size_t workspace_bytes,
+                                       gda_stream_t stream_) {
+    return gda_softmax_nll_fwd_ex_f32(logits, ld, labels, N, C, loss, nullptr, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int gda_softmax_nll_bwd_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,

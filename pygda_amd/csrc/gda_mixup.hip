@@ -150,13 +150,23 @@ k_mixup_bwd(const float* __restrict__ gXX, const float* __restrict__ XX, const u
     }
 }
 
+// gbias[c] = sum_b partial[b][c]: 32 columns per block, 8 lanes per column over the partials, fixed-order finish
 __global__ void __launch_bounds__(TB)
 k_mixup_bias(const float* __restrict__ partial, int blocks, int h, float* __restrict__ gbias) {
-    const int c = blockIdx.x * TB + threadIdx.x;
-    if (c >= h) return;
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int b = 0; b < blocks; ++b) s += partial[(int64_t)b * h + c];
-    gbias[c] = s;
+    if (c < h)
+        for (int b = lane; b < blocks; b += 8) s += partial[(int64_t)b * h + c];
+    red[lane][cl] = s;
+    __syncthreads();
+    if (lane == 0 && c < h) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int l = 1; l < 8; ++l) t += red[l][cl];
+        gbias[c] = t;
+    }
 }
 
 int blocks_for(int64_t n, int h) {
@@ -223,7 +233,7 @@ extern "C" int gda_mixup_combine_bwd_f32(const float* gXX, const float* XX, cons
     else       { if (gPb) GDA_MIXUP_BWD(false, true); else GDA_MIXUP_BWD(false, false); }
 #undef GDA_MIXUP_BWD
     GDA_LAUNCH_CHECK();
-    k_mixup_bias<<<(unsigned)gda_cdiv(h, TB), TB, 0, s>>>(partial, blocks, (int)h, gbias);
+    k_mixup_bias<<<(unsigned)gda_cdiv(h, 32), TB, 0, s>>>(partial, blocks, (int)h, gbias);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }

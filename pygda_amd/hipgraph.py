@@ -201,8 +201,14 @@ class GraphedStep:
             side = self._stat_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                correct = (logits.detach().argmax(dim=1) == self.src.y).sum()
-                self.stats = torch.stack([loss.detach().double(), correct.double()])
+                from .ops import ce_stats_for
+                by_product = ce_stats_for(logits, self.src.y)     # the loss kernel counted the correct rows already
+                if by_product is not None:
+                    by_product[0:1].copy_(loss.detach().reshape(1))   # slot 0: the TOTAL loss of the step
+                    self.stats = by_product
+                else:
+                    correct = (logits.detach().argmax(dim=1) == self.src.y).sum()
+                    self.stats = torch.stack([loss.detach().double(), correct.double()])
             for t in (loss, logits):
                 t.record_stream(side)
         self.optimizer.zero_grad(set_to_none=True)
@@ -338,8 +344,14 @@ class GraphedStepSplit(GraphedStep):
             side = self._stat_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                correct = (logits.detach().argmax(dim=1) == self.src.y).sum()
-                self.stats = torch.stack([loss.detach().double(), correct.double()])
+                from .ops import ce_stats_for
+                by_product = ce_stats_for(logits, self.src.y)     # the loss kernel counted the correct rows already
+                if by_product is not None:
+                    by_product[0:1].copy_(loss.detach().reshape(1))   # slot 0: the TOTAL loss of the step
+                    self.stats = by_product
+                else:
+                    correct = (logits.detach().argmax(dim=1) == self.src.y).sum()
+                    self.stats = torch.stack([loss.detach().double(), correct.double()])
             for t in (loss, logits):
                 t.record_stream(side)
         self.optimizer.zero_grad(set_to_none=True)

@@ -63,8 +63,8 @@ class A2GNN(BaseGDA):
         # the logits / cross-entropy path -- which needs nothing from the domain loss -- is enqueued on this
         # branch's stream first and runs beside the MMD's backward kernel instead of queueing behind the feature
         # path that has to wait for it (~100 us off the step's critical path).
-        source_features = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)   # :192
-        feats = net.feat_bottleneck_from(h0_s, source_data.edge_index, sb, self.s_pnums)
+        # With s_pnums = 0 (the default) the two passes are one pass over stacked rows (A2GNNBase.feat_pair_from).
+        source_features, feats = net.feat_pair_from(h0_s, source_data.edge_index, sb, self.s_pnums)   # :192, :181
         source_logits = net.feat_classifier(feats, source_data.edge_index, sb, 1)            # :181
         loss = self._gmean(source_ce(source_logits, source_data.y), source_logits.size(0))   # :182, fused
         return loss, source_logits, source_features

@@ -66,6 +66,22 @@ class A2GNNBase(nn.Module):
             x = global_mean_pool(x, batch)
         return x
 
+    def feat_pair_from(self, h0, edge_index, batch, prop_nums=30):
+        """TWO ``feat_bottleneck_from`` passes over the same ``h0`` (independent dropout draws) -- the trainer's
+        feature pass and logits pass over one domain.  With ``prop_nums = 0`` every layer acts row by row, so
+        the two passes run as ONE pass over the stacked rows ``[2n, h]``: half the launches each way, one weight
+        gradient GEMM per layer instead of two plus an accumulation, the gradient of ``h0`` summed inside the
+        activation's backward kernel.  Otherwise: two passes, the first result first."""
+        from ..ops import relu_dropout_pair, relu_dropout_pair_ok, split_halves
+        if not (prop_nums <= 0 and self.mode == "node" and self.act is F.relu and relu_dropout_pair_ok(h0)
+                and self.hid_dim % 4 == 0):
+            return (self.feat_bottleneck_from(h0, edge_index, batch, prop_nums),
+                    self.feat_bottleneck_from(h0, edge_index, batch, prop_nums))
+        x = relu_dropout_pair(h0, self.dropout, self.training)
+        for conv in self.convs[1:]:
+            x = self._act_dropout(conv(x, edge_index, prop_nums))
+        return split_halves(x)
+
     def feat_classifier(self, x, edge_index, batch, prop_nums=1):
         return self.cls(x, edge_index, prop_nums) if self.mode == "node" else self.cls(x)
 

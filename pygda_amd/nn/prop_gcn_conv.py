@@ -9,6 +9,7 @@ re-runs the same kernel on the transposed CSR instead of saving K intermediates.
 import torch
 from torch import nn
 
+from .. import sparse_features
 from ..graph import CSRGraph, as_graph, build_csr
 from ..ops import propagate
 from .linear import Linear, zeros
@@ -80,6 +81,10 @@ class PropGCNConv(nn.Module):
         if prop_nums <= 0 and self.bias is not None and self.lin.tall_gemm_ok(x):
             from .linear import tall_linear_bias               # projection + bias (and both gradients) in the GEMMs
             return tall_linear_bias(x, self.lin.weight, self.bias)
+        if prop_nums <= 0 and self.bias is not None and x.dim() == 2 and x.size(1) >= sparse_features.MIN_WIDTH:
+            sf = sparse_features.lookup(x)                       # sparse input features: bias in the SpMM's epilogue
+            if sf is not None:
+                return sparse_features.sparse_linear(self.lin.weight, sf, bias=self.bias)
         out = self.lin(x)                                        # :205
         if prop_nums > 0:                                        # :208-213, bias fused in the last step
             return propagate(out, self._graph(x, edge_index, edge_weight), prop_nums, self.bias,

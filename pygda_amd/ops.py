@@ -2,6 +2,8 @@
 memory, the stream and autograd plumbing; every numeric kernel named here is ours."""
 import ctypes
 
+import os as _os
+
 import torch
 
 from . import _lib, profiler
@@ -25,10 +27,14 @@ class _SoftmaxNLL(torch.autograd.Function):
             raise ValueError(f"logits [N, C] and labels [N] expected, got {tuple(x.shape)} and {tuple(labels.shape)}")
         n, c = x.shape
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        stats = torch.empty(2, dtype=torch.float64, device=x.device)       # {loss, #(argmax == label)}: the epoch log
         L = _lib.lib()
         ws = _lib.workspace(L.gda_softmax_nll_workspace_bytes(), x.device, "ce")
-        _lib.check(L.gda_softmax_nll_fwd_f32(_lib.ptr(x), c, _lib.ptr(labels.contiguous()), n, c, _lib.ptr(loss),
-                                             _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_softmax_nll_fwd_f32")
+        _lib.check(L.gda_softmax_nll_fwd_ex_f32(_lib.ptr(x), c, _lib.ptr(labels.contiguous()), n, c, _lib.ptr(loss),
+                                                _lib.ptr(stats), _lib.ptr(ws), ws.numel(), _lib.stream()),
+                   "gda_softmax_nll_fwd_ex_f32")
+        global _ce_stats
+        _ce_stats = (logits.data_ptr(), labels.data_ptr(), n, stats)
         ctx.save_for_backward(x, labels)
         return loss.reshape(())
 
@@ -41,6 +47,19 @@ class _SoftmaxNLL(torch.autograd.Function):
         _lib.check(_lib.lib().gda_softmax_nll_bwd_f32(_lib.ptr(x), c, _lib.ptr(labels.contiguous()), n, c, _lib.ptr(gl),
                                                       _lib.ptr(gx), c, _lib.stream()), "gda_softmax_nll_bwd_f32")
         return gx, None
+
+
+_ce_stats = None
+
+
+def ce_stats_for(logits, labels):
+    """``[loss, number of correct argmax predictions]`` (float64, device) left by the LAST softmax_nll call if it
+    was made on exactly these logits and labels, else None.  Lets a trainer's epoch log line (loss, source
+    micro-F1) ride on the loss kernel instead of an argmax / compare / sum / cast / stack chain."""
+    hit = _ce_stats
+    if hit is not None and hit[0] == logits.data_ptr() and hit[1] == labels.data_ptr() and hit[2] == logits.size(0):
+        return hit[3]
+    return None
 
 
 def softmax_nll(logits, labels):
@@ -276,6 +295,28 @@ def tall_linear_colmajor(x, weight):
     return ColMajor(_TallLinearT.apply(x, weight), x.size(0))
 
 
+_colsum_hint = None      # (data_ptr, column sums, the tensor itself) left by a kernel that produced both
+
+
+def colsum(x):
+    """``x.sum(0)`` of a row-major ``[n, d]`` fp32 device matrix (bias gradients): deterministic two-stage sum --
+    or the by-product of the kernel that just wrote ``x`` (the stacked activation's backward), when there is one."""
+    global _colsum_hint
+    hint, _colsum_hint = _colsum_hint, None
+    if hint is not None and hint[0] == x.data_ptr() and hint[2].shape == x.shape and x.is_contiguous():
+        return hint[1]
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 0 < x.size(1) <= 1024 and x.stride(1) == 1):
+        return x.sum(0)
+    n, d = x.shape
+    out = torch.empty(d, dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    nbytes = L.gda_colsum_workspace_bytes(n, d)
+    ws = _lib.workspace(nbytes, x.device, "colsum")
+    _lib.check(L.gda_colsum_f32(_lib.ptr(x), x.stride(0), n, d, _lib.ptr(out), _lib.ptr(ws), nbytes, _lib.stream()),
+               "gda_colsum_f32")
+    return out
+
+
 class _PropagateT(torch.autograd.Function):
     """K-step aggregation with a COLUMN-MAJOR result (forward) and gradient (backward): the transposes on
     the activation side of the LDS kernel disappear into the fused activation kernels
@@ -329,7 +370,7 @@ class _Propagate(torch.autograd.Function):
     def backward(ctx, gy):
         gx = spmm_kstep(ctx.graph, gy.contiguous(), ctx.K, None, transposed=True) \
             if ctx.needs_input_grad[0] else None
-        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[1] else None
+        gb = colsum(gy) if ctx.has_bias and ctx.needs_input_grad[1] else None
         return gx, gb, None, None
 
 
@@ -353,7 +394,6 @@ def lds_colmajor_ok(x, graph, K):
 
 
 # ---------------------------------------------------------------------------- MMD --
-import os as _os
 MMD_INDEX_IN_KERNEL = _os.environ.get("PYGDA_AMD_MMD_INDEX", "0") == "1"     # sampled rows read through their index inside the kernels (no gather pass)
 MMD_SCATTER_FUSED = _os.environ.get("PYGDA_AMD_MMD_SCATTER", "1") == "1"
 
@@ -727,6 +767,84 @@ class _ReluDropoutT(torch.autograd.Function):
         _lib.check(L.gda_relu_dropout_bwd_cm_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gxT), ctx.n_pad, n, d, ctx.p,
                                                 _lib.stream()), "gda_relu_dropout_bwd_cm_f32")
         return gxT, None, None
+
+
+class _ReluDropoutPair(torch.autograd.Function):
+    """gda_relu_dropout_pair_{fwd,bwd}_f32: ``[drop_a(relu(x)) ; drop_b(relu(x))]`` ``[2n, d]``."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        x = _f32c(x, "x")
+        n, d = x.shape
+        y = torch.empty(2 * n, d, dtype=torch.float32, device=x.device)
+        st = dropout_state
+        if st.seed is None:
+            st.seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+        L = _lib.lib()
+        _lib.check(L.gda_relu_dropout_pair_fwd_f32(_lib.ptr(x), _lib.ptr(y), n, d, float(p), ctypes.c_uint64(st.seed),
+                                                   _lib.ptr(st.counter(x.device)), ctypes.c_uint32(st.next_site()),
+                                                   ctypes.c_uint32(st.next_site()), _lib.stream()),
+                   "gda_relu_dropout_pair_fwd_f32")
+        ctx.save_for_backward(y)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        n, d = y.size(0) // 2, y.size(1)
+        gy = gy.contiguous()
+        gx = torch.empty(n, d, dtype=torch.float32, device=gy.device)
+        L = _lib.lib()
+        cs = ws = None
+        nbytes = 0
+        if d <= 1024:                     # column sums of gx ride along: the bias gradient of the layer below
+            cs = torch.empty(d, dtype=torch.float32, device=gy.device)
+            nbytes = L.gda_relu_dropout_pair_workspace_bytes(d)
+            ws = _lib.workspace(nbytes, gy.device, "pair_colsum")
+        _lib.check(L.gda_relu_dropout_pair_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gx), n, d, ctx.p, _lib.ptr(cs),
+                                                   _lib.ptr(ws), nbytes, _lib.stream()), "gda_relu_dropout_pair_bwd_f32")
+        global _colsum_hint
+        _colsum_hint = (gx.data_ptr(), cs, gx) if cs is not None else None
+        return gx, None
+
+
+def relu_dropout_pair_ok(x):
+    return torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.size(1) % 4 == 0
+
+
+def relu_dropout_pair(x, p, training=True):
+    """Two independent ``F.dropout(F.relu(x), p)`` draws of the same ``x [n, d]`` as one stacked ``[2n, d]``."""
+    return _ReluDropoutPair.apply(x, float(p) if training else 0.0)
+
+
+class _SplitHalves(torch.autograd.Function):
+    """``x [2n, d] -> (x[:n], x[n:])``; backward stacks the two gradients in one launch (a missing one reads as
+    zeros) instead of autograd's fill + copy + add per slice."""
+
+    @staticmethod
+    def forward(ctx, x):
+        n = x.size(0) // 2
+        ctx.shape = (n, x.size(1))
+        ctx.set_materialize_grads(False)
+        return x.narrow(0, 0, n), x.narrow(0, n, n)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        n, d = ctx.shape
+        ref = ga if ga is not None else gb
+        if ref is None:
+            return None
+        out = torch.empty(2 * n, d, dtype=torch.float32, device=ref.device)
+        ga = None if ga is None else ga.contiguous()
+        gb = None if gb is None else gb.contiguous()
+        _lib.check(_lib.lib().gda_stack2_f32(_lib.ptr(ga), _lib.ptr(gb), _lib.ptr(out), n * d, _lib.stream()),
+                   "gda_stack2_f32")
+        return out
+
+
+def split_halves(x):
+    return _SplitHalves.apply(x)
 
 
 def relu_dropout(x, p, training=True):

@@ -75,14 +75,14 @@ def lookup(x):
     return hit[3]
 
 
-def _spmm(rowptr, colidx, val, n_rows, dense, out_rows, split):
+def _spmm(rowptr, colidx, val, n_rows, dense, out_rows, split, bias=None):
     import ctypes
     d = dense.size(1)
     y = torch.empty(out_rows, d, dtype=torch.float32, device=dense.device)
     sp = split.struct(d)                       # frequent words are hub rows of X^T
     L = _lib.lib()
     _lib.check(L.gda_spmm_csr_split_f32(_lib.ptr(rowptr), _lib.ptr(colidx), _lib.ptr(val), n_rows, d, 1,
-                                        _lib.ptr(dense), d, _lib.ptr(y), d, None, None,
+                                        _lib.ptr(dense), d, _lib.ptr(y), d, None, _lib.ptr(bias),
                                         ctypes.byref(sp) if sp is not None else None, _lib.stream()),
                "gda_spmm_csr_split_f32")
     return y
@@ -93,15 +93,18 @@ class _SparseLinear(torch.autograd.Function):
     SpMM ``gW^T = X^T gy``.  X itself carries no gradient (it is the input data)."""
 
     @staticmethod
-    def forward(ctx, weight, sf, vals=None):
-        wt = weight.t().contiguous()                       # [F, h]
+    def forward(ctx, weight, sf, vals=None, bias=None):
+        # [F, h].  Sharing one transposed copy between the source and the target branch (formed before the streams
+        # fork) was measured and dropped: a kernel ahead of the fork costs the captured step 60-70 us (DESIGN 4.7)
+        wt = weight.t().contiguous()
         g = sf.graph
         val, t_val = (g.val, g.t_val) if vals is None else vals
         with profiler.region(f"sparse_projection[{sf.f}x{weight.size(0)}]", 1,
                              sf.nnz * 8 + (sf.n + 1) * 4 + 4 * (wt.numel() + sf.n * weight.size(0)),
                              2 * sf.nnz * weight.size(0)):
-            y = _spmm(g.rowptr, g.colidx, val, sf.n, wt, sf.n, g.split(False))
-        ctx.sf, ctx.t_val = sf, t_val
+            y = _spmm(g.rowptr, g.colidx, val, sf.n, wt, sf.n, g.split(False),
+                      None if bias is None else bias.contiguous())
+        ctx.sf, ctx.t_val, ctx.has_bias = sf, t_val, bias is not None
         return y
 
     @staticmethod
@@ -113,11 +116,15 @@ class _SparseLinear(torch.autograd.Function):
                              sf.nnz * 8 + (sf.f + 1) * 4 + 4 * (gy.numel() + sf.f * gy.size(1)),
                              2 * sf.nnz * gy.size(1)):
             gwt = _spmm(g.t_rowptr, g.t_colidx, ctx.t_val, sf.f, gy, sf.f, g.split(True))   # [F, h]
-        return gwt.t(), None, None
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            from .ops import colsum
+            gb = colsum(gy)
+        return gwt.t(), None, None, gb
 
 
-def sparse_linear(weight, sf, dropout=0.0):
-    """``X W^T``; with ``dropout > 0`` the product uses ``dropout(X)`` (mask drawn per call)."""
+def sparse_linear(weight, sf, dropout=0.0, bias=None):
+    """``X W^T (+ bias)``; with ``dropout > 0`` the product uses ``dropout(X)`` (mask drawn per call)."""
     if dropout > 0.0:
-        return _SparseLinear.apply(weight, sf, sf.dropped_values(dropout))
-    return _SparseLinear.apply(weight, sf)
+        return _SparseLinear.apply(weight, sf, sf.dropped_values(dropout), bias)
+    return _SparseLinear.apply(weight, sf, None, bias)
