@@ -249,6 +249,16 @@ int gda_mmd_fwd_ex_f32(const float* src, int64_t ld_src, const float* tgt, int64
                        int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
                        float scale, const float* add, float* loss, float* bandwidth, float* l2_saved,
                        void* workspace, size_t workspace_bytes, gda_stream_t stream);
+/* _gather: with row indices, rows_src / rows_tgt ([times*n, d] each, both or neither) receive the sampled rows
+ * (`source_feat[source_samples]` mmd.py:153-154) as a by-product of the statistics pass, and the later kernels --
+ * and the backward call, which is then handed these buffers without indices -- read them instead of chasing the
+ * index again: no separate gather launches. */
+int gda_mmd_fwd_gather_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
+                           int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
+                           int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
+                           float scale, const float* add, float* rows_src, float* rows_tgt,
+                           float* loss, float* bandwidth, float* l2_saved,
+                           void* workspace, size_t workspace_bytes, gda_stream_t stream);
 int gda_mmd_bwd_ex_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
                        int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
                        int times, int64_t n, float kernel_mul, int kernel_num,

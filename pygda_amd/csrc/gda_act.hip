@@ -267,23 +267,33 @@ k_colsum_partial(const float* __restrict__ x, int64_t ldx, int64_t n, int d, flo
     }
 }
 
-// out[c] = sum_b partial[b][c]: 32 columns per block, 8 lanes per column over the partials, fixed-order finish
+// out[c] = sum_b partial[b][c]: 8 columns per block, 32 lanes per column over the partials (lane g adds the
+// partials g, g + 32, ... in that order, four loads in flight), then a fixed binary tree over the 32 lane sums.
+constexpr int CF_COLS = 8, CF_LANES = TB / CF_COLS;
+
 __global__ void __launch_bounds__(TB)
 k_colsum_final(const float* __restrict__ partial, int blocks, int d, float* __restrict__ out) {
-    __shared__ float red[8][32];
-    const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ float red[CF_LANES][CF_COLS];
+    const int cl = threadIdx.x % CF_COLS, g = threadIdx.x / CF_COLS;
+    const int c = blockIdx.x * CF_COLS + cl;
     float s = 0.f;
-    if (c < d)
-        for (int b = lane; b < blocks; b += 8) s += partial[(int64_t)b * d + c];
-    red[lane][cl] = s;
-    __syncthreads();
-    if (lane == 0 && c < d) {
-        float t = red[0][cl];
-#pragma unroll
-        for (int l = 1; l < 8; ++l) t += red[l][cl];
-        out[c] = t;
+    if (c < d) {
+        int b = g;
+        for (; b + 3 * CF_LANES < blocks; b += 4 * CF_LANES) {
+            const float v0 = partial[(int64_t)b * d + c], v1 = partial[(int64_t)(b + CF_LANES) * d + c];
+            const float v2 = partial[(int64_t)(b + 2 * CF_LANES) * d + c], v3 = partial[(int64_t)(b + 3 * CF_LANES) * d + c];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; b < blocks; b += CF_LANES) s += partial[(int64_t)b * d + c];
     }
+    red[g][cl] = s;
+    __syncthreads();
+#pragma unroll
+    for (int w = CF_LANES / 2; w > 0; w >>= 1) {
+        if (g < w) red[g][cl] += red[g + w][cl];
+        __syncthreads();
+    }
+    if (g == 0 && c < d) out[c] = red[0][cl];
 }
 
 int colsum_blocks(int64_t n, int d) {
@@ -388,7 +398,7 @@ extern "C" int gda_relu_dropout_pair_bwd_f32(const float* gy, const float* y, fl
     float* partial = static_cast<float*>(workspace);
     k_relu_dropout_pair_bwd_colsum<<<blocks, TB, 0, s>>>(gy, y, gx, n, (int)d, 1.f / (1.f - p), partial);
     GDA_LAUNCH_CHECK();
-    k_colsum_final<<<(unsigned)gda_cdiv(d, 32), TB, 0, s>>>(partial, blocks, (int)d, colsum);
+    k_colsum_final<<<(unsigned)gda_cdiv(d, CF_COLS), TB, 0, s>>>(partial, blocks, (int)d, colsum);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
@@ -424,7 +434,7 @@ extern "C" int gda_colsum_f32(const float* x, int64_t ldx, int64_t n, int64_t d,
     const int blocks = colsum_blocks(n, (int)d);
     k_colsum_partial<<<blocks, TB, 0, s>>>(x, ldx, n, (int)d, static_cast<float*>(workspace));
     GDA_LAUNCH_CHECK();
-    k_colsum_final<<<(unsigned)gda_cdiv(d, 32), TB, 0, s>>>(static_cast<const float*>(workspace), blocks, (int)d, out);
+    k_colsum_final<<<(unsigned)gda_cdiv(d, CF_COLS), TB, 0, s>>>(static_cast<const float*>(workspace), blocks, (int)d, out);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }

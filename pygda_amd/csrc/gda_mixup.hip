@@ -150,23 +150,33 @@ k_mixup_bwd(const float* __restrict__ gXX, const float* __restrict__ XX, const u
     }
 }
 
-// gbias[c] = sum_b partial[b][c]: 32 columns per block, 8 lanes per column over the partials, fixed-order finish
+// gbias[c] = sum_b partial[b][c]: 8 columns per block, 32 lanes per column over the partials (lane g adds the
+// partials g, g + 32, ... in that order, four loads in flight), then a fixed binary tree over the 32 lane sums.
+constexpr int CF_COLS = 8, CF_LANES = TB / CF_COLS;
+
 __global__ void __launch_bounds__(TB)
 k_mixup_bias(const float* __restrict__ partial, int blocks, int h, float* __restrict__ gbias) {
-    __shared__ float red[8][32];
-    const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ float red[CF_LANES][CF_COLS];
+    const int cl = threadIdx.x % CF_COLS, g = threadIdx.x / CF_COLS;
+    const int c = blockIdx.x * CF_COLS + cl;
     float s = 0.f;
-    if (c < h)
-        for (int b = lane; b < blocks; b += 8) s += partial[(int64_t)b * h + c];
-    red[lane][cl] = s;
-    __syncthreads();
-    if (lane == 0 && c < h) {
-        float t = red[0][cl];
-#pragma unroll
-        for (int l = 1; l < 8; ++l) t += red[l][cl];
-        gbias[c] = t;
+    if (c < h) {
+        int b = g;
+        for (; b + 3 * CF_LANES < blocks; b += 4 * CF_LANES) {
+            const float v0 = partial[(int64_t)b * h + c], v1 = partial[(int64_t)(b + CF_LANES) * h + c];
+            const float v2 = partial[(int64_t)(b + 2 * CF_LANES) * h + c], v3 = partial[(int64_t)(b + 3 * CF_LANES) * h + c];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; b < blocks; b += CF_LANES) s += partial[(int64_t)b * h + c];
     }
+    red[g][cl] = s;
+    __syncthreads();
+#pragma unroll
+    for (int w = CF_LANES / 2; w > 0; w >>= 1) {
+        if (g < w) red[g][cl] += red[g + w][cl];
+        __syncthreads();
+    }
+    if (g == 0 && c < h) gbias[c] = red[0][cl];
 }
 
 int blocks_for(int64_t n, int h) {
@@ -233,7 +243,7 @@ extern "C" int gda_mixup_combine_bwd_f32(const float* gXX, const float* XX, cons
     else       { if (gPb) GDA_MIXUP_BWD(false, true); else GDA_MIXUP_BWD(false, false); }
 #undef GDA_MIXUP_BWD
     GDA_LAUNCH_CHECK();
-    k_mixup_bias<<<(unsigned)gda_cdiv(h, 32), TB, 0, s>>>(partial, blocks, (int)h, gbias);
+    k_mixup_bias<<<(unsigned)gda_cdiv(h, CF_COLS), TB, 0, s>>>(partial, blocks, (int)h, gbias);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }

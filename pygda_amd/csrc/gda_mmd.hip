@@ -97,7 +97,8 @@ constexpr int SR = 16;        // rows per k_rowstats workgroup (4 per thread: in
 
 // chunk (t, blockIdx.x): s1 = sum over its rows of |t_i - p|^2, col[c] = sum over its rows of (t_i - p)[c]
 __global__ void __launch_bounds__(TB)
-k_rowstats(Rows R, int64_t d, int64_t m, double* __restrict__ part_s1, float* __restrict__ part_col) {
+k_rowstats(Rows R, int64_t d, int64_t m, double* __restrict__ part_s1, float* __restrict__ part_col,
+           float* __restrict__ rows_src, float* __restrict__ rows_tgt) {
     __shared__ double red[TB / 64];
     __shared__ float colsh[TB / 64][64];
     const int t = blockIdx.y;
@@ -113,7 +114,14 @@ k_rowstats(Rows R, int64_t d, int64_t m, double* __restrict__ part_s1, float* __
             const float pv = pivot[c];
             for (int rr = rg; rr < SR; rr += TB / 64) {
                 const int64_t r = r0 + rr;
-                if (r < m) { const float v = row_ptr(R, t, r)[c] - pv; s1 = fmaf(v, v, s1); col += v; }
+                if (r < m) {
+                    const float raw = row_ptr(R, t, r)[c];
+                    if (rows_src)                          // the gather rides along: rows stacked [times, n, d] per domain
+                        (r < R.n ? rows_src + ((int64_t)t * R.n + r) * d : rows_tgt + ((int64_t)t * R.n + (r - R.n)) * d)[c] = raw;
+                    const float v = raw - pv;
+                    s1 = fmaf(v, v, s1);
+                    col += v;
+                }
             }
         }
         colsh[rg][lane] = col;
@@ -577,19 +585,33 @@ extern "C" int gda_mmd_fwd_ex_f32(const float* src, int64_t ld_src, const float*
                                   int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
                                   float scale, const float* add, float* loss, float* bandwidth, float* l2_saved,
                                   void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    return gda_mmd_fwd_gather_f32(src, ld_src, tgt, ld_tgt, d, src_idx, tgt_idx, times, n, kernel_mul, kernel_num,
+                                  fix_sigma, scale, add, nullptr, nullptr, loss, bandwidth, l2_saved, workspace,
+                                  workspace_bytes, stream_);
+}
+
+extern "C" int gda_mmd_fwd_gather_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
+                                      int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
+                                      int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
+                                      float scale, const float* add, float* rows_src, float* rows_tgt,
+                                      float* loss, float* bandwidth, float* l2_saved,
+                                      void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
     int st = check_common(src, ld_src, tgt, ld_tgt, d, src_idx, tgt_idx, times, n, kernel_num);
     if (st != GDA_OK) return st;
     if (!loss || !bandwidth || !l2_saved || !workspace) return GDA_E_NULL;
+    if ((rows_src == nullptr) != (rows_tgt == nullptr) || (rows_src && !src_idx)) return GDA_E_NULL;
+    if (rows_src && (rows_src == src || rows_tgt == tgt)) return GDA_E_ALIAS;
     MmdWs ws = carve(workspace, times, n, d);
     if (workspace_bytes < ws.total) return GDA_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t m = 2 * n;
     const unsigned nt = (unsigned)gda_cdiv(m, TILE);
-    const Rows R = make_rows(src, ld_src, tgt, ld_tgt, src_idx, tgt_idx, n);
     const KParams kp{kernel_mul, kernel_num, fix_sigma};
     const unsigned chunks = (unsigned)gda_cdiv(m, SR);
-    k_rowstats<<<dim3(chunks, (unsigned)times), TB, 0, stream>>>(R, d, m, ws.part_s1, ws.part_col);
+    Rows R = make_rows(src, ld_src, tgt, ld_tgt, src_idx, tgt_idx, n);
+    k_rowstats<<<dim3(chunks, (unsigned)times), TB, 0, stream>>>(R, d, m, ws.part_s1, ws.part_col, rows_src, rows_tgt);
     GDA_LAUNCH_CHECK();
+    if (rows_src) R = make_rows(rows_src, d, rows_tgt, d, nullptr, nullptr, n);      // gathered: no index from here on
     k_bandwidth<<<(unsigned)times, TB, 0, stream>>>(ws.part_s1, ws.part_col, (int)chunks, d, m, kp, bandwidth);
     GDA_LAUNCH_CHECK();
     const unsigned ntri = nt * (nt + 1) / 2;

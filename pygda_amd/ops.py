@@ -412,13 +412,14 @@ class _MMD(torch.autograd.Function):
         dev = src.device
         m = 2 * n
         ctx.feat_rows = (src.size(0), tgt.size(0))
-        idx_s = idx_t = None
+        idx_s = idx_t = rows_s = rows_t = None
         if src_idx is not None:
-            if MMD_INDEX_IN_KERNEL and sel is not None:
-                idx_s, idx_t = src_idx, tgt_idx           # the kernels chase the index themselves
-            else:
-                # the sampled rows gathered ONCE into [times*n, d] (2 x 2.5 MB at the A2GNN shapes)
-                src, tgt = gather_rows(src, src_idx.reshape(-1)), gather_rows(tgt, tgt_idx.reshape(-1))
+            idx_s, idx_t = src_idx.contiguous(), tgt_idx.contiguous()
+            if not (MMD_INDEX_IN_KERNEL and sel is not None):
+                # the sampled rows gathered ONCE into [times*n, d] (2 x 2.5 MB at the A2GNN shapes) -- by the
+                # statistics kernel, which reads them through the index anyway; everything after reads the copy
+                rows_s = torch.empty(times * n, d, dtype=torch.float32, device=dev)
+                rows_t = torch.empty(times * n, d, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         bw = torch.empty(times, dtype=torch.float32, device=dev)
         l2 = torch.empty(times, m, m, dtype=torch.float32, device=dev)
@@ -426,12 +427,15 @@ class _MMD(torch.autograd.Function):
         ws = _lib.workspace(L.gda_mmd_workspace_bytes(times, n, d), dev, "mmd")
         addc = None if add is None else add.detach().to(torch.float32).reshape(1).contiguous()
         with profiler.region("mmd_fwd", 4, 0, times * (3 * m * m * d // 2 + 12 * m * m)):
-            _lib.check(L.gda_mmd_fwd_ex_f32(
+            _lib.check(L.gda_mmd_fwd_gather_f32(
                 _lib.ptr(src), d, _lib.ptr(tgt), d, d, _lib.ptr(idx_s), _lib.ptr(idx_t), times, n, float(kernel_mul),
-                int(kernel_num), float(fix_sigma) if fix_sigma else 0.0, float(scale), _lib.ptr(addc), _lib.ptr(loss),
-                _lib.ptr(bw), _lib.ptr(l2), _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_mmd_fwd_ex_f32")
+                int(kernel_num), float(fix_sigma) if fix_sigma else 0.0, float(scale), _lib.ptr(addc),
+                _lib.ptr(rows_s), _lib.ptr(rows_t), _lib.ptr(loss), _lib.ptr(bw), _lib.ptr(l2), _lib.ptr(ws), ws.numel(),
+                _lib.stream()), "gda_mmd_fwd_gather_f32")
+        if rows_s is not None:
+            src, tgt = rows_s, rows_t
         ctx.save_for_backward(src, tgt, src_idx, tgt_idx, bw, l2)
-        ctx.in_kernel = idx_s is not None
+        ctx.in_kernel = idx_s is not None and rows_s is None
         ctx.cfg = (times, n, float(kernel_mul), int(kernel_num))
         return loss.reshape(())
 
