@@ -565,6 +565,7 @@ int gda_gemm_ex_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, i
                     const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, float* colsum,
                     void* workspace, size_t workspace_bytes, gda_stream_t stream);
 
+
 /* C = A * A of a CSR operator on the host (threaded, deterministic order), for STATIC full-batch
  * graphs: a K-step propagation (pygda/nn/prop_gcn_conv.py:208-210) then takes K/2 dependent
  * launches -- at citation-graph sizes a launch costs its latency, not its edges.  rowptr / colidx /
