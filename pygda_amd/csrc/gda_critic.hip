@@ -52,6 +52,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+__device__ __forceinline__ double wave_sum_d_fwd(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 // keep-factor of hidden unit k of row `row` at call site `site`: 0 or 1/(1-p)
 __device__ __forceinline__ float keep_factor(const Drop& dr, uint64_t st, uint32_t site, int64_t row, int a, int k) {
     if (dr.p <= 0.f) return 1.f;
@@ -254,6 +260,309 @@ k_critic_rows(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same rows on the fp32 MATRIX CORES (h % 32 == 0, a % 4 == 0): a wavefront takes 32 rows; the three per-row
+// matrix-vector products become 32-row tile products with the rows as the MFMA's column index,
+//     Z^T [unit, row] = W1 X^T,      V^T [column, row] = W1^T U^T,      T^T [unit, row] = W1 Vhat^T,
+// so that a lane pair (l, l + 32) owns ONE row and holds 32 of its 64 (padded) hidden units / half of its columns in
+// accumulator registers: every per-row scalar (z, s, |v|, cA, cB) is lane-local plus one cross-half shuffle.  The B
+// operands (X, then U, then Vhat) go through one per-wave LDS tile [32][h + 1] (row stride odd: conflict-free operand
+// reads), W1 sits in LDS as before.  The readlane version above spends two VALU instructions per (row, weight): 119 us
+// for the 35 k rows of an AdaGCN critic step; this one 336 MFMAs per 32 penalty rows.
+// Same keep-bits as the readlane kernel (keyed on row and unit; one Philox call covers a lane's four adjacent units).
+constexpr int RT = 32;
+
+__host__ __device__ inline size_t lds_floats_mfma(int h, int a) { return (size_t)a * (h + 1) + (size_t)WAVES * RT * (h + 1); }
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// Where row g of cat(e_s, e_t, interpolates) comes from, WITHOUT branches: x = t + al (s - t) with s = t and al = 0
+// for the plain rows (exact: t + 0 * 0).  Loads behind per-lane branches cannot be batched by the compiler -- every one
+// of a lane's 16 row pieces then costs its own memory round trip (123 us for this kernel, 2 x 16 round trips per tile).
+struct RowSrc { const float* t; const float* s; float al; };
+
+__device__ __forceinline__ RowSrc row_src(const RowsIn& R, int h, int64_t g, bool valid) {
+    g = valid ? g : 0;
+    const bool is_s = g < R.n_s, is_t = !is_s && g < R.n_s + R.n_t, plain = is_s || is_t;
+    const int64_t i = plain ? 0 : g - R.n_s - R.n_t;
+    int32_t si = 0, ti = 0;
+    float al = 0.f;
+    if (R.n_i > 0) { si = R.is[i]; ti = R.it[i]; al = R.alpha[i]; }         // uniform condition
+    const float* t = is_s ? R.es + g * h : (is_t ? R.et + (g - R.n_s) * h : R.et + (int64_t)ti * h);
+    const float* sp = plain ? t : R.es + (int64_t)si * h;
+    return RowSrc{t, sp, plain ? 0.f : al};
+}
+
+__device__ __forceinline__ float4 mix4(const float4 t, const float4 s, float al, bool valid) {
+    const float4 v = make_float4(t.x + al * (s.x - t.x), t.y + al * (s.y - t.y), t.z + al * (s.z - t.z), t.w + al * (s.w - t.w));
+    return valid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int HT>
+__global__ void __launch_bounds__(TB)
+k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restrict__ U, float* __restrict__ Y, int ldy,
+                   double* __restrict__ part_rows) {
+    extern __shared__ __attribute__((aligned(16))) float W1s[];
+    __shared__ float b1s[AMAX], w2s[AMAX];
+    const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    const int h = C.h, a = C.a, ldw = h + 1;
+    float* Ts = W1s + (size_t)a * ldw + (size_t)wave * RT * ldw;           // this wave's tile [32][h + 1]
+    load_w1(C, W1s);
+    if (threadIdx.x < AMAX) {
+        b1s[threadIdx.x] = threadIdx.x < a ? C.b1[threadIdx.x] : 0.f;
+        w2s[threadIdx.x] = threadIdx.x < a ? C.w2[threadIdx.x] : 0.f;
+    }
+    __syncthreads();
+    const uint64_t st = dr.p > 0.f ? (uint64_t)dr.step[0] : 0;
+    const uint32_t thresh = (uint32_t)((double)dr.p * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (double)dr.p * 4294967296.0);
+    const float keep_on = 1.f / (1.f - dr.p);
+    const int rl = lane & 31, half = lane >> 5;
+    const int64_t n_gap = R.n_s + R.n_t, m_gp = R.n_s + R.n_t + R.n_i;
+    const int64_t g_gap = (n_gap + RT - 1) / RT, g_gp = (m_gp + RT - 1) / RT;
+    const float b2 = C.b2[0];
+    const int nit = a > 32 ? 2 : 1;                                         // unit tiles that hold real units
+    // w2 gradient terms: after every group the 32 row slots of a half-wave are summed by a butterfly and lane rl keeps
+    // the sum of "its" unit register (tile rl / 16, register rl % 16): two accumulators per lane instead of 64 -- the
+    // kernel has to stay under 256 VGPRs (beyond them values live in AGPRs and every use costs a copy; the first
+    // version ran 1300 cycles per 2-MFMA loop iteration that way)
+    float w2sum_gap = 0.f, w2sum_gp = 0.f;
+    double acc_b2[2] = {0.0, 0.0}, acc_gp = 0.0, acc_ds = 0.0, acc_dt = 0.0;
+
+    // W1 as the MFMA's row operand: unit i = rl + 32 it, column k   (zero rows past a)
+    // (no per-lane branch around the load: a branch inside the MFMA loops made the compiler carry the accumulators in
+    // VGPRs and copy all 32 of them to and from the AGPRs around every MFMA)
+    const float* w1row0 = W1s + (size_t)rl * ldw;                           // unit rl      (always < a: a >= 32 or rows read as 0 below)
+    const float* w1row1 = W1s + (size_t)(rl + 32 < a ? rl + 32 : 0) * ldw;  // unit rl + 32 (clamped; masked by on1)
+    const float on0 = rl < a ? 1.f : 0.f, on1 = rl + 32 < a ? 1.f : 0.f;
+    const float* w1row0c = rl < a ? w1row0 : W1s;
+
+    for (int64_t grp = (int64_t)blockIdx.x * WAVES + wave; grp < g_gap + g_gp; grp += (int64_t)gridDim.x * WAVES) {
+        const bool is_gap = grp < g_gap;
+        const int64_t base = is_gap ? grp * RT : (grp - g_gap) * RT;
+        const int64_t limit = is_gap ? n_gap : m_gp;
+        const int64_t r = base + rl;                                        // this lane pair's row in its space
+        const bool live = r < limit;
+        lds_settle();                                                       // the previous group's tile reads are done
+        // ---- X tile -> LDS (rows past the limit read as zeros)
+        {
+            // HT passes of 4 row pieces each: the 8 loads of a pass are issued before the first one is consumed (a
+            // wavefront is alone on its SIMD here: every dependent load is a full memory round trip)
+#pragma unroll
+            for (int ps = 0; ps < HT; ++ps) {
+                RowSrc src[4];
+                float4 xt[4], xs[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t g = base + (lane + 64 * (4 * ps + q)) / (8 * HT);
+                    src[q] = row_src(R, h, g, g < limit);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c4 = ((lane + 64 * (4 * ps + q)) % (8 * HT)) * 4;
+                    xt[q] = *reinterpret_cast<const float4*>(src[q].t + c4);
+                    xs[q] = *reinterpret_cast<const float4*>(src[q].s + c4);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                               // gap space = the first rows of the penalty space
+                    const int idx = lane + 64 * (4 * ps + q), row = idx / (8 * HT), c4 = (idx % (8 * HT)) * 4;
+                    const float4 v = mix4(xt[q], xs[q], src[q].al, base + row < limit);
+                    float* t = Ts + (size_t)row * ldw + c4;
+                    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+                }
+            }
+        }
+        lds_settle();
+        // ---- Z^T = W1 X^T
+        f32x16 accz[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) accz[it][q] = 0.f;
+        if (nit > 1) {
+#pragma unroll 8
+            for (int kk = 0; kk < h; kk += 2) {
+                const float xb = Ts[(size_t)rl * ldw + kk + half];
+                accz[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(on0 * w1row0c[kk + half], xb, accz[0], 0, 0, 0);
+                accz[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(on1 * w1row1[kk + half], xb, accz[1], 0, 0, 0);
+            }
+        } else {
+#pragma unroll 8
+            for (int kk = 0; kk < h; kk += 2)
+                accz[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(on0 * w1row0c[kk + half], Ts[(size_t)rl * ldw + kk + half], accz[0], 0, 0, 0);
+        }
+        // ---- per unit: a, relu, keep, hid, u; per row: z, s, s'
+        float mr[2][16];                                                    // keep / (1 - p) where the unit is on; accz becomes a = W1 x + b1
+        float zpart = 0.f;
+        const uint32_t site = is_gap ? dr.site + (r < R.n_s ? 0u : 1u) : dr.site + 2u;
+        const int64_t rowkey = is_gap ? (r < R.n_s ? r : r - R.n_s) : r;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int i0 = 32 * it + 8 * g4 + 4 * half;                 // units i0 .. i0 + 3 = registers 4 g4 .. 4 g4 + 3
+                uint32_t rn[4] = {~0u, ~0u, ~0u, ~0u};
+                if (dr.p > 0.f && i0 < a) GdaPhilox::gen(dr.seed, (st << 20) ^ site, ((uint64_t)rowkey * (uint64_t)a + (uint64_t)i0) >> 2, rn);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = i0 + e, q = 4 * g4 + e;
+                    const float av = accz[it][q] + b1s[i];
+                    const float kf = dr.p > 0.f ? (rn[e] >= thresh ? keep_on : 0.f) : 1.f;
+                    const float m = (live && i < a && av > 0.f) ? kf : 0.f;
+                    accz[it][q] = av;
+                    mr[it][q] = m;
+                    zpart = fmaf(w2s[i], m * av, zpart);                    // hid = m a, u = m w2
+                }
+            }
+        const float z = zpart + __shfl_xor(zpart, 32, 64) + b2;
+        const float sg = 1.f / (1.f + __expf(-z)), sp = sg * (1.f - sg);
+        float cA = 0.f, cB = 0.f;
+        f32x16 accv[HT];                                                    // V^T, then Vhat^T: this row's columns
+#pragma unroll
+        for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) accv[jt][q] = 0.f;
+        f32x16 acct[2];                                                     // T^T = W1 Vhat^T (zero for the gap rows)
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acct[it][q] = 0.f;
+        if (is_gap) {
+            cA = live ? (r < R.n_s ? sp / (float)R.n_s : -sp / (float)R.n_t) : 0.f;      // d gap / d z_i
+            if (live && half == 0) { if (r < R.n_s) acc_ds += (double)sg; else acc_dt += (double)sg; }
+        } else {
+            // ---- U tile -> LDS (over the X tile), V^T = W1^T U^T
+            lds_settle();
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int i = 32 * it + (q & 3) + 8 * (q >> 2) + 4 * half;
+                    Ts[(size_t)rl * ldw + i] = mr[it][q] * w2s[i];          // u: columns 0..63 of the tile row
+                }
+            lds_settle();
+#pragma unroll 4
+            for (int kk = 0; kk < a; kk += 2) {                             // a is a multiple of 4
+                const int i = kk + half;
+                const float ub = Ts[(size_t)rl * ldw + i];
+                const float* wrow = W1s + (size_t)i * ldw + rl;
+#pragma unroll
+                for (int jt = 0; jt < HT; ++jt) accv[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[32 * jt], ub, accv[jt], 0, 0, 0);
+            }
+            float n2 = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) n2 = fmaf(accv[jt][q], accv[jt][q], n2);
+            n2 += __shfl_xor(n2, 32, 64);
+            const float nv = sqrtf(n2), inv = nv > 0.f ? 1.f / nv : 0.f;
+            // ---- Vhat tile -> LDS, T^T = W1 Vhat^T
+            lds_settle();
+#pragma unroll
+            for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    accv[jt][q] *= inv;
+                    Ts[(size_t)rl * ldw + 32 * jt + (q & 3) + 8 * (q >> 2) + 4 * half] = accv[jt][q];
+                }
+            lds_settle();
+            if (nit > 1) {
+#pragma unroll 8
+                for (int kk = 0; kk < h; kk += 2) {
+                    const float vb = Ts[(size_t)rl * ldw + kk + half];
+                    acct[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(on0 * w1row0c[kk + half], vb, acct[0], 0, 0, 0);
+                    acct[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(on1 * w1row1[kk + half], vb, acct[1], 0, 0, 0);
+                }
+            } else {
+#pragma unroll 8
+                for (int kk = 0; kk < h; kk += 2)
+                    acct[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(on0 * w1row0c[kk + half], Ts[(size_t)rl * ldw + kk + half], acct[0], 0, 0, 0);
+            }
+            const float nrm = sp * nv;
+            const float e = live ? gp_weight / (float)m_gp * 2.f * (nrm - 1.f) : 0.f;
+            cA = e * nv * sp * (1.f - 2.f * sg);
+            cB = e * sp;
+            if (live && half == 0) acc_gp += (double)((nrm - 1.f) * (nrm - 1.f));
+        }
+        // ---- outputs of this row
+        {
+            float mine = 0.f;
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float v = mr[it][q] * (cA * accz[it][q] + cB * acct[it][q]);          // cA hid + cB m (W1 vhat)
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);   // over the 32 rows of this half
+                    mine = rl == 16 * it + q ? v : mine;
+                }
+            if (is_gap) w2sum_gap += mine; else w2sum_gp += mine;
+        }
+        if (live) {
+            const int64_t ro = (is_gap ? 0 : n_gap) + r;
+            float* yrow = Y + ro * (int64_t)ldy;
+            const RowSrc me = row_src(R, h, r, true);                        // gap rows = the first penalty rows
+#pragma unroll
+            for (int jt = 0; jt < HT; ++jt) {                                // one column tile at a time: 8 loads in flight
+                float4 xt[4], xs[4];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int j = 32 * jt + 8 * g4 + 4 * half;
+                    xt[g4] = *reinterpret_cast<const float4*>(me.t + j);
+                    xs[g4] = *reinterpret_cast<const float4*>(me.s + j);
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int j = 32 * jt + 8 * g4 + 4 * half;
+                    const float4 xv = mix4(xt[g4], xs[g4], me.al, true);
+                    *reinterpret_cast<float4*>(yrow + j) = make_float4(
+                        cA * xv.x + cB * accv[jt][4 * g4], cA * xv.y + cB * accv[jt][4 * g4 + 1],
+                        cA * xv.z + cB * accv[jt][4 * g4 + 2], cA * xv.w + cB * accv[jt][4 * g4 + 3]);
+                }
+            }
+            if (half == 0) {
+                yrow[h] = cA;
+                if (is_gap) acc_b2[0] += (double)cA; else acc_b2[1] += (double)cA;
+            }
+            float* urow = U + ro * (int64_t)a;
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int i0 = 32 * it + 8 * g4 + 4 * half;
+                    if (i0 < a) *reinterpret_cast<float4*>(urow + i0) = make_float4(
+                        mr[it][4 * g4] * w2s[i0], mr[it][4 * g4 + 1] * w2s[i0 + 1], mr[it][4 * g4 + 2] * w2s[i0 + 2], mr[it][4 * g4 + 3] * w2s[i0 + 3]);
+                }
+        }
+    }
+    // ---- block partials: the w2 terms are summed over the 32 row slots of a half-wave first
+    __shared__ double red[WAVES][2 * AMAX + 5];
+    {   // lane rl of a half holds the sums of unit register (tile rl / 16, register rl % 16) of that half
+        const int it = rl >> 4, q = rl & 15;
+        const int i = 32 * it + (q & 3) + 8 * (q >> 2) + 4 * half;
+        if (i < a) { red[wave][i] = (double)w2sum_gap; red[wave][AMAX + i] = (double)w2sum_gp; }
+    }
+    const double b20 = wave_sum_d_fwd(acc_b2[0]), b21 = wave_sum_d_fwd(acc_b2[1]), gps = wave_sum_d_fwd(acc_gp);
+    const double dss = wave_sum_d_fwd(acc_ds), dts = wave_sum_d_fwd(acc_dt);
+    if (lane == 0) {
+        red[wave][2 * AMAX + 0] = b20; red[wave][2 * AMAX + 1] = b21; red[wave][2 * AMAX + 2] = gps;
+        red[wave][2 * AMAX + 3] = dss; red[wave][2 * AMAX + 4] = dts;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 2 * a + 5) {
+        int slot;
+        if (t < a) slot = t;
+        else if (t == a) slot = 2 * AMAX + 0;
+        else if (t < 2 * a + 1) slot = AMAX + (t - a - 1);
+        else slot = 2 * AMAX + 1 + (t - (2 * a + 1));
+        double v = 0.0;
+        for (int w = 0; w < WAVES; ++w) v += red[w][slot];
+        part_rows[(int64_t)t * gridDim.x + blockIdx.x] = v;
+    }
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -350,16 +659,43 @@ extern "C" int gda_wgan_critic_f32(const float* es, int64_t n_s, const float* et
     const Critic C{W1, b1, w2, b2, h, a};
     const RowsIn R{es, n_s, et, n_t, idx_s, idx_t, alpha, n_i};
     const Drop dr{dropout_p, seed, step, site};
-    const size_t lds = lds_floats(h, a) * sizeof(float);
     const int64_t n_gap = n_s + n_t, m_gp = n_s + n_t + n_i;
     const int ldy = h + 4;
-    const bool wide = h > 128;
-    if (lds > 48 * 1024) {                         // the widest legal critic needs 66 KB of dynamic LDS
-        const void* fn = wide ? reinterpret_cast<const void*>(k_critic_rows<4>) : reinterpret_cast<const void*>(k_critic_rows<2>);
-        GDA_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const bool mfma = h % 32 == 0 && h >= 64 && a % 4 == 0 && ((uintptr_t)es | (uintptr_t)et) % 16 == 0;   // h >= 64: the U tile (64 units) shares the X tile's rows
+    int row_blocks = ROW_BLOCKS;
+    if (mfma) {
+        // 32 rows per wavefront: as many workgroups as there are groups of 4 row tiles (at most ROW_BLOCKS)
+        const int64_t tiles = gda_cdiv(n_gap, RT) + gda_cdiv(m_gp, RT);
+        const int64_t want = gda_cdiv(tiles, WAVES);
+        row_blocks = (int)(want < ROW_BLOCKS ? want : ROW_BLOCKS);
+        const size_t lds = lds_floats_mfma(h, a) * sizeof(float);
+#define GDA_CRITIC_MFMA(HT)                                                                                          \
+        {                                                                                                            \
+            GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_critic_rows_mfma<HT>),                   \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+            k_critic_rows_mfma<HT><<<row_blocks, TB, lds, stream>>>(C, R, dr, gp_weight, ws.U, ws.Y, ldy, ws.part_rows); \
+        }
+        switch (h / 32) {
+            case 1: GDA_CRITIC_MFMA(1) break;
+            case 2: GDA_CRITIC_MFMA(2) break;
+            case 3: GDA_CRITIC_MFMA(3) break;
+            case 4: GDA_CRITIC_MFMA(4) break;
+            case 5: GDA_CRITIC_MFMA(5) break;
+            case 6: GDA_CRITIC_MFMA(6) break;
+            case 7: GDA_CRITIC_MFMA(7) break;
+            default: GDA_CRITIC_MFMA(8) break;
+        }
+#undef GDA_CRITIC_MFMA
+    } else {
+        const size_t lds = lds_floats(h, a) * sizeof(float);
+        const bool wide = h > 128;
+        if (lds > 48 * 1024) {                     // the widest legal critic needs 66 KB of dynamic LDS
+            const void* fn = wide ? reinterpret_cast<const void*>(k_critic_rows<4>) : reinterpret_cast<const void*>(k_critic_rows<2>);
+            GDA_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (wide) k_critic_rows<4><<<ROW_BLOCKS, TB, lds, stream>>>(C, R, dr, gp_weight, ws.U, ws.Y, ldy, ws.part_rows);
+        else k_critic_rows<2><<<ROW_BLOCKS, TB, lds, stream>>>(C, R, dr, gp_weight, ws.U, ws.Y, ldy, ws.part_rows);
     }
-    if (wide) k_critic_rows<4><<<ROW_BLOCKS, TB, lds, stream>>>(C, R, dr, gp_weight, ws.U, ws.Y, ldy, ws.part_rows);
-    else k_critic_rows<2><<<ROW_BLOCKS, TB, lds, stream>>>(C, R, dr, gp_weight, ws.U, ws.Y, ldy, ws.part_rows);
     GDA_LAUNCH_CHECK();
     // gW1 | gb1 of the two row groups: U^T Y on the matrix cores (columns h+1 .. h+3 of Y pad the 16-byte row
     // stride: never written, they only reach columns of UtY that nobody reads)
@@ -368,7 +704,7 @@ extern "C" int gda_wgan_critic_f32(const float* es, int64_t n_s, const float* et
     st = gda_gemm_f32(GDA_GEMM_TN, a, ldy, m_gp, ws.U + n_gap * a, a, ws.Y + n_gap * (int64_t)ldy, ldy, ws.UtY_gp, ldy,
                       ws.gemm_ws, ws.gemm_bytes, stream_);
     if (st != GDA_OK) return st;
-    k_critic_final<<<16, TB, 0, stream>>>(C, R, gp_weight, ws.part_rows, ROW_BLOCKS, ws.UtY_gap, ws.UtY_gp, ldy,
+    k_critic_final<<<16, TB, 0, stream>>>(C, R, gp_weight, ws.part_rows, row_blocks, ws.UtY_gap, ws.UtY_gp, ldy,
                                          loss, gW1, gb1, gw2, gb2);
     GDA_LAUNCH_CHECK();
     return GDA_OK;

@@ -11,6 +11,8 @@ and step (it is deterministic) and shared by the 11 encoder passes; inside the c
 outputs are detached.  The reference back-propagates the critic loss into the encoder ten
 times per step and then discards those gradients (``optimizer.zero_grad()`` at :292 precedes
 the only encoder step), i.e. 10 x L wasted backward aggregations per domain."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -76,6 +78,25 @@ class AdaGCN(BaseGDA):
             self._interp_cache[key] = hit
         return hit
 
+    def _batched_encodes(self, h0, source_data, target_data):
+        return (self.mode == 'node' and h0.is_cuda and self.critic_steps > 1 and self.adagcn.encoder.gnn_type == 'gcn'
+                and all(getattr(d.edge_index, "_gda_static", False) for d in (source_data, target_data))
+                and os.environ.get("PYGDA_AMD_BATCHED_CRITIC_ENCODES", "1") == "1")
+
+    def _encode_copies(self, h0, data):
+        """``[critic_steps, n, hid]``: the encoder stack after its first conv on `critic_steps` stacked copies."""
+        from ..data import Data
+        S, n = self.critic_steps, h0.size(0)
+        cache = self.__dict__.setdefault("_copies_cache", {})
+        key = (data.edge_index.data_ptr(), S, n)
+        rep = cache.get(key)
+        if rep is None:
+            ei = data.edge_index
+            off = (torch.arange(S, device=ei.device) * n).repeat_interleave(ei.size(1))
+            rep = cache[key] = (ei, Data(x=None, edge_index=ei.repeat(1, S) + off, y=None))   # the entry keeps `ei` alive
+            rep[1].edge_index._gda_static = True
+        return self.adagcn.forward_from(h0.repeat(S, 1), rep[1]).view(S, n, -1)
+
     def _critic_update_fused(self, es, et):
         from ..hipgraph import host_rand
         from ..ops import wgan_critic_grads
@@ -98,10 +119,22 @@ class AdaGCN(BaseGDA):
         net = self.adagcn
         # the first conv of the encoder (projection + aggregation, nothing random) once per domain and step
         h0_s, h0_t = net.first_conv(source_data), net.first_conv(target_data)
-        for _ in range(self.critic_steps):                                            # :169-183
+        # The critic loop re-encodes both domains every step (:170-171) with an encoder that does not change inside
+        # the loop: its `critic_steps` passes differ by their dropout draws only, so they run as ONE pass over
+        # `critic_steps` stacked copies (block-diagonal graph, independent draws per copy): 5 launches per domain
+        # instead of 4 per critic step.
+        batched = self._batched_encodes(h0_s, source_data, target_data)
+        if batched:
             with torch.no_grad():
-                encoded_source = net.forward_from(h0_s.detach(), source_data)
-                encoded_target = net.forward_from(h0_t.detach(), target_data)
+                es_all = self._encode_copies(h0_s.detach(), source_data)
+                et_all = self._encode_copies(h0_t.detach(), target_data)
+        for k in range(self.critic_steps):                                            # :169-183
+            if batched:
+                encoded_source, encoded_target = es_all[k], et_all[k]
+            else:
+                with torch.no_grad():
+                    encoded_source = net.forward_from(h0_s.detach(), source_data)
+                    encoded_target = net.forward_from(h0_t.detach(), target_data)
             if self._fused_critic(encoded_source):
                 self._critic_update_fused(encoded_source, encoded_target)
                 continue

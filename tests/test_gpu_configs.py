@@ -385,6 +385,43 @@ def test_wgan_critic_fused_vs_autograd(ns, nt):
     assert bool((outs[0][1] != out[1]).any()) and bool(torch.isfinite(outs[0][1]).all())
 
 
+@pytest.mark.parametrize("h,a,ns,nt", [(128, 40, 9360, 5484), (64, 64, 300, 420), (256, 24, 500, 260), (96, 40, 257, 33)])
+def test_wgan_critic_mfma_rows_equal_readlane_rows(h, a, ns, nt):
+    """The matrix-core row kernel (32 rows per wavefront, h % 32 == 0) against the readlane row kernel (taken when the
+    encodings are not 16-byte aligned) on the same values WITH dropout: same keep-bits by construction, so loss and
+    all four gradients agree to rounding."""
+    from pygda_amd.ops import dropout_state, wgan_critic_grads
+    gen = torch.Generator().manual_seed(h + a)
+    es = torch.randn(ns, h, generator=gen).relu().to(DEV)
+    et = (torch.randn(nt, h, generator=gen) * 1.2 + 0.1).relu().to(DEV)
+    W1 = (torch.randn(a, h, generator=gen) * (2.0 / h ** 0.5)).to(DEV); b1 = (torch.randn(a, generator=gen) * 0.1).to(DEV)
+    W2 = (torch.randn(1, a, generator=gen) * 0.5).to(DEV); b2 = torch.zeros(1, device=DEV)
+    n_i = min(ns, nt)
+    idx_s = torch.randint(0, ns, (n_i,), generator=gen, dtype=torch.int32).to(DEV)
+    idx_t = torch.randint(0, nt, (n_i,), generator=gen, dtype=torch.int32).to(DEV)
+    alpha = torch.rand(n_i, 1, generator=gen).to(DEV)
+
+    def unaligned(t):                                                  # same values, 4-byte aligned storage
+        buf = torch.empty(t.numel() + 1, device=DEV)
+        v = buf[1:].view_as(t)
+        v.copy_(t)
+        assert v.data_ptr() % 16 == 4
+        return v
+
+    def run(e_s, e_t, p):
+        dropout_state.counter(e_s.device).fill_(9); dropout_state.site = 0
+        out = (torch.zeros(1, device=DEV), torch.zeros_like(W1), torch.zeros_like(b1), torch.zeros_like(W2), torch.zeros_like(b2))
+        wgan_critic_grads(e_s, e_t, idx_s, idx_t, alpha, W1, b1, W2, b2, p, 5.0, out)
+        return out
+
+    for p in (0.0, 0.3):
+        got, want = run(es, et, p), run(unaligned(es), unaligned(et), p)
+        close(got[0], want[0], rtol=1e-4, atol=1e-6)
+        for g_, w_ in zip(got[1:], want[1:]):
+            close(g_, w_, rtol=1e-3, atol=1e-5 * max(float(w_.abs().max()), 1e-3))
+    assert bool((run(es, et, 0.3)[1] != run(es, et, 0.0)[1]).any())
+
+
 def test_adagcn_fused_critic_trajectory_equals_composed(monkeypatch):
     """AdaGCN.fit for three epochs with the fused critic update against the composed (torch autograd) one: same
     host draws, dropout off -> same losses, accuracies and critic weights."""
