@@ -4,6 +4,7 @@ one aggregation, bias added afterwards."""
 import torch
 from torch import nn
 
+from .. import sparse_features
 from ..graph import CSRGraph, as_graph, build_csr
 from ..ops import propagate
 from .linear import glorot, zeros
@@ -45,7 +46,10 @@ class CachedGCNConv(nn.Module):
         return g
 
     def forward(self, x, edge_index, cache_name="default_cache", edge_weight=None):
-        x = torch.matmul(x, self.weight)                                        # :130
+        sf = sparse_features.lookup(x) if x.dim() == 2 and x.size(1) >= sparse_features.MIN_WIDTH else None
+        # :130 -- bag-of-words input features run as an SpMM over their CSR (the weight [in, out] is the gathered
+        # operand as stored); hidden activations as the dense product
+        x = sparse_features.sparse_matmul(sf, self.weight) if sf is not None else torch.matmul(x, self.weight)
         return propagate(x, self._graph(x, edge_index, cache_name, edge_weight), 1, self.bias)
 
     def __repr__(self):

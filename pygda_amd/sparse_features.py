@@ -123,6 +123,36 @@ class _SparseLinear(torch.autograd.Function):
         return gwt.t(), None, None, gb
 
 
+class _SparseMatmul(torch.autograd.Function):
+    """``y = X W`` for a weight stored ``[in, out]`` (CachedGCNConv / PPMIConv, cached_gcn_conv.py:130): the weight
+    IS the gathered operand -- no transposed copy either way; ``gW = X^T gy`` comes out in the weight's layout."""
+
+    @staticmethod
+    def forward(ctx, weight, sf):
+        g = sf.graph
+        w = weight.contiguous()
+        with profiler.region(f"sparse_projection[{sf.f}x{w.size(1)}]", 1,
+                             sf.nnz * 8 + (sf.n + 1) * 4 + 4 * (w.numel() + sf.n * w.size(1)), 2 * sf.nnz * w.size(1)):
+            y = _spmm(g.rowptr, g.colidx, g.val, sf.n, w, sf.n, g.split(False))
+        ctx.sf = sf
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        sf = ctx.sf
+        g = sf.graph
+        gy = gy.contiguous()
+        with profiler.region(f"sparse_projection_bwd[{sf.f}x{gy.size(1)}]", 1,
+                             sf.nnz * 8 + (sf.f + 1) * 4 + 4 * (gy.numel() + sf.f * gy.size(1)), 2 * sf.nnz * gy.size(1)):
+            gw = _spmm(g.t_rowptr, g.t_colidx, g.t_val, sf.f, gy, sf.f, g.split(True))       # [F, h]
+        return gw, None
+
+
+def sparse_matmul(sf, weight):
+    """``X @ weight`` with ``weight [in, out]``."""
+    return _SparseMatmul.apply(weight, sf)
+
+
 def sparse_linear(weight, sf, dropout=0.0, bias=None):
     """``X W^T (+ bias)``; with ``dropout > 0`` the product uses ``dropout(X)`` (mask drawn per call)."""
     if dropout > 0.0:

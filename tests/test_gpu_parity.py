@@ -1348,6 +1348,31 @@ def test_sparse_linear_bias_epilogue():
     exact(conv(d.x, d.edge_index, 0), out)
 
 
+def test_cached_gcn_conv_sparse_input_features():
+    """CachedGCNConv / PPMIConv layer 0 on registered sparse features (X W as an SpMM over the CSR of X, W [in, out]
+    used as stored) against the dense product: output and both gradients."""
+    from pygda_amd import sparse_features
+    gen = torch.Generator().manual_seed(12)
+    n = 900
+    xd = (torch.rand(n, 640, generator=gen) < 0.02).float()
+    d = Data(x=xd, edge_index=torch.randint(0, n, (2, 3000), generator=gen), y=torch.zeros(n, dtype=torch.long)).to(DEV)
+    assert sparse_features.lookup(d.x) is not None
+    conv = CachedGCNConv(640, 48).to(DEV)
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(48, generator=gen))
+    w = torch.randn(n, 48, generator=gen).to(DEV)
+    out = conv(d.x, d.edge_index)
+    gW, gb = torch.autograd.grad((out * w).sum(), [conv.weight, conv.bias])
+    dense = d.x.clone()                                                # same values, not registered: dense product
+    assert sparse_features.lookup(dense) is None
+    out_d = conv(dense, d.edge_index)
+    gW_d, gb_d = torch.autograd.grad((out_d * w).sum(), [conv.weight, conv.bias])
+    close(out, out_d, rtol=1e-5, atol=1e-5)
+    close(gW, gW_d, rtol=1e-4, atol=1e-5 * float(gW_d.abs().max()))
+    close(gb, gb_d, rtol=1e-5, atol=1e-5)
+    assert gW.is_contiguous() and gW.shape == conv.weight.shape
+
+
 def test_a2gnn_stacked_source_passes_match_two_passes():
     """feat_pair_from (one pass over stacked rows) against two feat_bottleneck_from passes: same values and same
     parameter gradients at dropout 0, at the cfg-A widths where the tall GEMM kernels run."""

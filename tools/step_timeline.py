@@ -5,7 +5,8 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'k_adam' in r['Kernel_Name']]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-a, b = idx[k], idx[k + 1]
+span = int(sys.argv[3]) if len(sys.argv) > 3 else 1        # optimiser launches per step (UDAGCN: 2 rounds)
+a, b = idx[k], idx[k + span]
 t0 = int(rows[a]['End_Timestamp']); qs = {}
 for r in rows[a + 1:b + 1]:
     q = r['Queue_Id']; qs.setdefault(q, len(qs))
