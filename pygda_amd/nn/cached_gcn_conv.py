@@ -7,7 +7,7 @@ from torch import nn
 from .. import sparse_features
 from ..graph import CSRGraph, as_graph, build_csr
 from ..ops import propagate
-from .linear import glorot, zeros
+from .linear import glorot, tall_matmul, tall_matmul_ok, zeros
 
 
 class CachedGCNConv(nn.Module):
@@ -49,7 +49,12 @@ class CachedGCNConv(nn.Module):
         sf = sparse_features.lookup(x) if x.dim() == 2 and x.size(1) >= sparse_features.MIN_WIDTH else None
         # :130 -- bag-of-words input features run as an SpMM over their CSR (the weight [in, out] is the gathered
         # operand as stored); hidden activations as the dense product
-        x = sparse_features.sparse_matmul(sf, self.weight) if sf is not None else torch.matmul(x, self.weight)
+        if sf is not None:
+            x = sparse_features.sparse_matmul(sf, self.weight)
+        elif tall_matmul_ok(x, self.weight):
+            x = tall_matmul(x, self.weight)                # 64x64-tile matrix-core kernels (csrc/gda_gemm.hip)
+        else:
+            x = torch.matmul(x, self.weight)
         return propagate(x, self._graph(x, edge_index, cache_name, edge_weight), 1, self.bias)
 
     def __repr__(self):

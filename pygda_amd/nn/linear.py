@@ -76,6 +76,35 @@ def tall_linear_bias(x, weight, bias):
     return _TallLinearBias.apply(x, weight, bias)
 
 
+class _TallMatmul(torch.autograd.Function):
+    """``y = x W`` for a weight stored ``[in, out]`` (CachedGCNConv, cached_gcn_conv.py:130) on the same kernels:
+    forward NN, data gradient ``gy W^T`` = NT, weight gradient ``x^T gy`` = TN in the weight's own layout."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        from ..ops import GEMM_NN, gemm
+        ctx.save_for_backward(x, weight)
+        return gemm(GEMM_NN, x, weight)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from ..ops import GEMM_NT, GEMM_TN, gemm
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gemm(GEMM_NT, gy, weight) if ctx.needs_input_grad[0] else None
+        gw = gemm(GEMM_TN, x, gy) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+def tall_matmul_ok(x, weight):
+    return (x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and 1024 <= x.size(0) <= TALL_GEMM_MAX_ROWS and weight.size(0) <= 256 and weight.size(1) <= 256)
+
+
+def tall_matmul(x, weight):
+    return _TallMatmul.apply(x, weight)
+
+
 class _BlasTallLinear(torch.autograd.Function):
     """Same contraction through the ROCm BLAS, for row counts where its 128x128 macro-tiles fill the
     chip (sampled sub-graphs of 10^5 rows and more: measured 20-30 % ahead of the 64x64-tile kernels

@@ -1373,6 +1373,26 @@ def test_cached_gcn_conv_sparse_input_features():
     assert gW.is_contiguous() and gW.shape == conv.weight.shape
 
 
+def test_cached_gcn_conv_hidden_layer_on_gemm_kernels():
+    """A hidden CachedGCNConv layer (dense x W, W [in, out]) at a size that takes the hand-written GEMM kernels,
+    against the float64 composition: output and both gradients."""
+    gen = torch.Generator().manual_seed(13)
+    n = 3000
+    ei = torch.randint(0, n, (2, 9000), generator=gen).to(DEV)
+    x = torch.randn(n, 128, generator=gen).to(DEV).requires_grad_()
+    conv = CachedGCNConv(128, 96).to(DEV)
+    w = torch.randn(n, 96, generator=gen).to(DEV)
+    out = conv(x, ei)
+    gx, gW = torch.autograd.grad((out * w).sum(), [x, conv.weight])
+    g_ei, g_w = O.gcn_norm(ei.cpu(), None, n, False, True, "row")
+    xd = x.detach().cpu().double().requires_grad_(); Wd = conv.weight.detach().cpu().double().requires_grad_()
+    want = O.propagate(g_ei, g_w.double(), xd @ Wd) + conv.bias.detach().cpu().double()
+    wx, wW = torch.autograd.grad((want * w.cpu().double()).sum(), [xd, Wd])
+    close(out, want.float(), rtol=1e-4, atol=1e-4)
+    close(gx, wx.float(), rtol=1e-4, atol=1e-4 * float(wx.abs().max()))
+    close(gW, wW.float(), rtol=1e-4, atol=1e-4 * float(wW.abs().max()))
+
+
 def test_a2gnn_stacked_source_passes_match_two_passes():
     """feat_pair_from (one pass over stacked rows) against two feat_bottleneck_from passes: same values and same
     parameter gradients at dropout 0, at the cfg-A widths where the tall GEMM kernels run."""
