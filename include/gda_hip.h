@@ -147,7 +147,7 @@ int gda_spmm_csr_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const f
 
 /* ------------------------------------------------------------------------------
  * K-step aggregation in ONE launch for graphs whose feature columns fit a CU's LDS
- * (n_rows <= gda_kstep_max_rows() = 16380; the citation-graph regime), csrc/gda_kstep.hip.
+ * (n_rows <= gda_kstep_max_rows() = 16320; the citation-graph regime), csrc/gda_kstep.hip.
  *
  * Replaces the same prop_nums loop (pygda/nn/prop_gcn_conv.py:208-210) as gda_spmm_csr_kstep_f32,
  * with the same results bit for bit (per-row sums in CSR order, separately rounded multiply and
@@ -159,6 +159,10 @@ int gda_spmm_csr_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const f
  * returns S (6, 8, 10 or 12 slots per thread), 0 when the graph is not eligible (too many rows /
  * a row longer than 4*S entries / more slots than one workgroup holds) -- callers then use
  * gda_spmm_csr_kstep_f32 --, or a negative status.  The plan is copied to the device by the caller.
+ * gda_kstep_plan_host_ex takes flags: bit 0 = bank-aware placement -- WHERE a node's word lives in LDS is
+ * chosen such that the 32 words a lane group gathers (or stores) in one instruction fall on different LDS
+ * banks as far as possible (the step loop is bound by exactly those gathers); the sums and their order do
+ * not change.  gda_kstep_plan_host = flags 1.
  *
  * gda_kstep_lds_f32: K >= 1 steps; x is row-major [n_rows, ldx] (x_colmajor = 0) or column-major
  * [d, ldx] (x_colmajor = 1: ldx >= round_up(n_rows, 4), 16-byte aligned columns), y likewise; bias ([d] or
@@ -172,6 +176,8 @@ int gda_kstep_max_rows(void);
 size_t gda_kstep_plan_bytes(int slots);
 int gda_kstep_plan_host(const int32_t* rowptr_host, const int32_t* colidx_host, const float* val_host,
                         int64_t n_rows, void* plan_host, size_t plan_bytes);
+int gda_kstep_plan_host_ex(const int32_t* rowptr_host, const int32_t* colidx_host, const float* val_host,
+                           int64_t n_rows, int flags, void* plan_host, size_t plan_bytes);
 int gda_kstep_lds_f32(const void* plan, int slots, int64_t n_rows, int64_t d, int K,
                       const float* x, int64_t ldx, int x_colmajor, float* y, int64_t ldy, int y_colmajor,
                       const float* bias, float* colsum, float* scratchT, gda_stream_t stream);

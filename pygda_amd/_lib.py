@@ -73,6 +73,7 @@ _SIGNATURES = {
     "gda_kstep_max_rows": (c_int, []),
     "gda_kstep_plan_bytes": (c_size_t, [c_int]),
     "gda_kstep_plan_host": (c_int, [_P, _P, _P, c_int64, _P, c_size_t]),
+    "gda_kstep_plan_host_ex": (c_int, [_P, _P, _P, c_int64, c_int, _P, c_size_t]),
     "gda_kstep_lds_f32": (c_int, [_P, c_int, c_int64, c_int64, c_int, _P, c_int64, c_int, _P, c_int64, c_int,
                                   _P, _P, _P, _P]),
     "gda_kstep_lds_colmajor_f32": (c_int, [_P, c_int, c_int64, c_int64, c_int, _P, c_int64, _P, c_int64, _P, _P, _P]),

@@ -1,5 +1,5 @@
 // K-step neighbour aggregation  y = A_hat^K x (+ bias)  in ONE launch for graphs whose feature
-// columns fit the LDS of a CU (the citation-graph regime: N <= 16380 nodes).
+// columns fit the LDS of a CU (the citation-graph regime: N <= 16320 nodes).
 //
 // Replaces the prop_nums loop of pygda/nn/prop_gcn_conv.py:208-210 (one PyG propagate per step) and
 // the K dependent launches gda_spmm_csr_kstep_f32 makes of it.  At N ~ 5-10 k nodes a step moves
@@ -28,7 +28,12 @@ namespace {
 constexpr int KS_TB = 1024;          // 16 wavefronts: 4 per SIMD, <= 128 VGPRs each
 constexpr int KS_L = 4;              // entries per slot
 constexpr int KS_OFFB = 65528;       // byte offset of the second LDS buffer: fits the 16-bit DS offset field
-constexpr int KS_MAX_ROWS = KS_OFFB / 4 - 2;
+constexpr int KS_MAX_ROWS = (KS_OFFB / 4 - 32) / 32 * 32;    // 16,320: 510 node words on each of the 32 banks
+constexpr int KS_BANKS = 32;         // ds_read_b32 / ds_write_b32: bank = (byte address / 4) mod 32, lanes 0-31 and 32-63 apart
+constexpr int KS_ZERO_W = 0;         // word 0 of each buffer reads as 0 (padding entries), word 1 takes the writes of
+constexpr int KS_DUMP_W = 1;         // slots that do not end a row; node words start at KS_NODE_W0
+constexpr int KS_NODE_W0 = KS_BANKS;
+constexpr int KS_POS_WORDS = (KS_MAX_ROWS + 2 + 3) / 4 * 4;      // the plan's node -> LDS address table (fixed size)
 
 // ds_read / ds_write at (LDS byte address held in a register) + (compile-time offset): the offset folds
 // into the instruction's 16-bit offset field, the register holds an absolute LDS address (the kernel adds
@@ -71,7 +76,7 @@ __device__ __forceinline__ void ks_step(const unsigned (&ea)[S * KS_L], const fl
 template <int S>
 __global__ void __launch_bounds__(KS_TB)
 k_kstep_lds(const int2* __restrict__ ent, const unsigned* __restrict__ outa, const unsigned* __restrict__ keepm,
-            int n_rows, int n_pad, int K, const float* __restrict__ xT, int64_t ldx, float* __restrict__ yT, int64_t ldy,
+            const unsigned* __restrict__ pos, int n_rows, int n_pad, int K, const float* __restrict__ xT, int64_t ldx, float* __restrict__ yT, int64_t ldy,
             const float* __restrict__ bias, float* __restrict__ colsum) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int R = S * KS_L;
@@ -79,21 +84,23 @@ k_kstep_lds(const int2* __restrict__ ent, const unsigned* __restrict__ outa, con
     const int t = threadIdx.x;
     float* bufA = reinterpret_cast<float*>(lds);
     float* bufB = reinterpret_cast<float*>(lds + KS_OFFB);
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     const float* xc = xT + (int64_t)c * ldx;
     float csum = 0.f;
     for (int i = t * 4; i < n_pad; i += KS_TB * 4) {
         const float4 v = *reinterpret_cast<const float4*>(xc + i);
-        *reinterpret_cast<float4*>(bufA + i) = v;
+        const uint4 p = *reinterpret_cast<const uint4*>(pos + i);      // node i lives at LDS byte address pos[i]
+        lds_st<0>(p.x + base, v.x); lds_st<0>(p.y + base, v.y); lds_st<0>(p.z + base, v.z); lds_st<0>(p.w + base, v.w);
         if (colsum) {                                        // column sum of the INPUT over the real rows
             csum += (i + 0 < n_rows ? v.x : 0.f); csum += (i + 1 < n_rows ? v.y : 0.f);
             csum += (i + 2 < n_rows ? v.z : 0.f); csum += (i + 3 < n_rows ? v.w : 0.f);
         }
     }
-    if (t < 2) { bufA[n_pad + t] = 0.f; bufB[n_pad + t] = 0.f; }        // the zero word (+ dump word) of each buffer
+    if (t < 1) { bufA[KS_ZERO_W] = 0.f; bufB[KS_ZERO_W] = 0.f; }        // the zero word of each buffer
     if (colsum) {      // fixed-order block reduction (wave butterflies, then 16 leaders through the spare LDS above both buffers)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) csum += __shfl_down(csum, off, 64);
-        float* red = reinterpret_cast<float*>(lds + KS_OFFB) + n_pad + 2;
+        float* red = reinterpret_cast<float*>(lds + 2 * KS_OFFB);
         if ((t & 63) == 0) red[t >> 6] = csum;
         __syncthreads();
         if (t == 0) {
@@ -107,7 +114,6 @@ k_kstep_lds(const int2* __restrict__ ent, const unsigned* __restrict__ outa, con
     float ew[R];
     const int w = t >> 6, lane = t & 63;
     const int2* ep = ent + ((size_t)w * R) * 64 + lane;
-    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
 #pragma unroll
     for (int j = 0; j < R; ++j) { const int2 e = ep[(size_t)j * 64]; ea[j] = (unsigned)e.x + base; ew[j] = __int_as_float(e.y);
         asm volatile("" : "+v"(ea[j])); }       // pin the sum in the register: no re-derivation from the symbol inside the loop
@@ -123,16 +129,18 @@ k_kstep_lds(const int2* __restrict__ ent, const unsigned* __restrict__ outa, con
         ks_step<S, KS_OFFB, 0>(ea, ew, oa, keep);
         __syncthreads();
     }
-    const float* res = bufA;
+    unsigned rbase = base;
     if (step < K) {
         ks_step<S, 0, KS_OFFB>(ea, ew, oa, keep);
         __syncthreads();
-        res = bufB;
+        rbase = base + KS_OFFB;
     }
     const float bv = bias ? bias[c] : 0.f;
     float* yc = yT + (int64_t)c * ldy;
     for (int i = t * 4; i < n_pad; i += KS_TB * 4) {
-        float4 v = *reinterpret_cast<const float4*>(res + i);
+        const uint4 p = *reinterpret_cast<const uint4*>(pos + i);
+        float4 v;
+        v.x = lds_ld<0>(p.x + rbase); v.y = lds_ld<0>(p.y + rbase); v.z = lds_ld<0>(p.z + rbase); v.w = lds_ld<0>(p.w + rbase);
         if (bias) { v.x = __fadd_rn(v.x, bv); v.y = __fadd_rn(v.y, bv); v.z = __fadd_rn(v.z, bv); v.w = __fadd_rn(v.w, bv); }
         *reinterpret_cast<float4*>(yc + i) = v;
     }
@@ -155,18 +163,157 @@ k_transpose(const float* __restrict__ in, int64_t ldi, float* __restrict__ out, 
 }
 
 template <int S>
-int ks_launch(const int2* ent, const unsigned* outa, const unsigned* keep, int n_rows, int n_pad, int d, int K,
-              const float* xT, int64_t ldx, float* yT, int64_t ldy, const float* bias, float* colsum, hipStream_t s) {
-    const size_t lds = (size_t)KS_OFFB + (size_t)(n_pad + 2 + KS_TB / 64) * 4;
+int ks_launch(const int2* ent, const unsigned* outa, const unsigned* keep, const unsigned* pos, int n_rows, int n_pad, int d,
+              int K, const float* xT, int64_t ldx, float* yT, int64_t ldy, const float* bias, float* colsum, hipStream_t s) {
+    const size_t lds = (size_t)2 * KS_OFFB + (size_t)(KS_TB / 64) * 4;       // both buffers in full + the column-sum scratch
     static bool configured = false;          // idempotent attribute; racing first calls set the same value
     if (!configured) {
         GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_kstep_lds<S>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
-    k_kstep_lds<S><<<(unsigned)d, KS_TB, lds, s>>>(ent, outa, keep, n_rows, n_pad, K, xT, ldx, yT, ldy, bias, colsum);
+    k_kstep_lds<S><<<(unsigned)d, KS_TB, lds, s>>>(ent, outa, keep, pos, n_rows, n_pad, K, xT, ldx, yT, ldy, bias, colsum);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
+}
+
+// ---- bank-aware node placement -------------------------------------------------------------------------
+// The step loop is bound by its LDS gathers: every wave instruction reads 2 x 32 unrelated words, and 32 random
+// words over 32 banks put ~3.4 distinct addresses on the busiest bank (measured: 1.6 us per step at the cfg-A
+// target graph, 2.7 LDS cycles per lane group where 1 is the floor).  WHERE a node's word lives in LDS is free
+// -- only the plan's addresses and the column's load / store go through the table -- so the nodes are assigned
+// to banks such that the nodes one lane group touches in one instruction (32 neighbours of a ds_read, 32 row
+// ends of a ds_write, 32 nodes of the column load / store) sit on different banks as far as possible: a greedy
+// pass in order of decreasing incidence, then local-search sweeps, on  sum_groups weight * (distinct addresses on
+// the group's busiest bank).  The sums are untouched (same entries, same order): results stay bit-identical.
+struct KsGroups {
+    std::vector<int> gptr{0}, gnode, gweight;
+    std::vector<unsigned char> gfix;         // bit 0: the zero word (bank of KS_ZERO_W) is read, bit 1: the dump word is written
+    void add(std::vector<int>& nodes, int weight, unsigned char fix) {
+        std::sort(nodes.begin(), nodes.end());
+        nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
+        if (nodes.size() + (fix ? 1 : 0) < 2) { nodes.clear(); return; }          // nothing can collide
+        gnode.insert(gnode.end(), nodes.begin(), nodes.end());
+        gptr.push_back((int)gnode.size());
+        gweight.push_back(weight);
+        gfix.push_back(fix);
+        nodes.clear();
+    }
+};
+
+void ks_place(int n, int S, const std::vector<int>& ent_node, const std::vector<int>& out_node, bool bank_aware,
+              std::vector<unsigned>& pos_word) {
+    pos_word.assign((size_t)n, 0u);
+    if (!bank_aware) {
+        for (int i = 0; i < n; ++i) pos_word[i] = (unsigned)(KS_NODE_W0 + i);
+        return;
+    }
+    const int R = S * KS_L, NB = KS_BANKS;
+    constexpr int W_STEP = 4, W_IO = 1;          // a step's groups run K times per launch, the column load / store once each
+    KsGroups G;
+    std::vector<int> tmp;
+    for (int w = 0; w < KS_TB / 64; ++w)
+        for (int j = 0; j < R; ++j)
+            for (int h = 0; h < 2; ++h) {
+                unsigned char fix = 0;
+                for (int l = 0; l < 32; ++l) {
+                    const int v = ent_node[((size_t)w * R + j) * 64 + h * 32 + l];
+                    if (v >= 0) tmp.push_back(v); else fix = 1;
+                }
+                G.add(tmp, W_STEP, fix);
+            }
+    for (int w = 0; w < KS_TB / 64; ++w)
+        for (int sl = 0; sl < S; ++sl)
+            for (int h = 0; h < 2; ++h) {
+                unsigned char fix = 0;
+                for (int l = 0; l < 32; ++l) {
+                    const int v = out_node[((size_t)w * S + sl) * 64 + h * 32 + l];
+                    if (v >= 0) tmp.push_back(v); else fix = 2;
+                }
+                G.add(tmp, W_STEP, fix);
+            }
+    for (int i0 = 0; i0 < n; i0 += 128)          // the column load / store: lane l of a 32-lane group holds nodes i0 + 4l .. 4l+3
+        for (int j = 0; j < 4; ++j) {
+            for (int l = 0; l < 32; ++l) if (i0 + 4 * l + j < n) tmp.push_back(i0 + 4 * l + j);
+            G.add(tmp, 2 * W_IO, 0);
+        }
+    const int ng = (int)G.gweight.size();
+    std::vector<int> iptr((size_t)n + 1, 0), inc(G.gnode.size());
+    for (int v : G.gnode) ++iptr[v + 1];
+    for (int i = 0; i < n; ++i) iptr[i + 1] += iptr[i];
+    {
+        std::vector<int> fill(iptr.begin(), iptr.end() - 1);
+        for (int g = 0; g < ng; ++g)
+            for (int k = G.gptr[g]; k < G.gptr[g + 1]; ++k) inc[fill[G.gnode[k]]++] = g;
+    }
+    std::vector<unsigned short> cnt((size_t)ng * NB, 0), gmax((size_t)ng, 0);
+    for (int g = 0; g < ng; ++g) {
+        if (G.gfix[g] & 1) cnt[(size_t)g * NB + KS_ZERO_W % NB] = 1;
+        if (G.gfix[g] & 2) cnt[(size_t)g * NB + KS_DUMP_W % NB] = 1;
+        gmax[g] = G.gfix[g] ? 1 : 0;
+    }
+    const int cap = (KS_OFFB / 4 - KS_NODE_W0) / NB;
+    std::vector<int> bank((size_t)n, -1), load(NB, 0);
+    auto put = [&](int v, int b) {
+        bank[v] = b; ++load[b];
+        for (int k = iptr[v]; k < iptr[v + 1]; ++k) {
+            const int g = inc[k];
+            const unsigned short c = ++cnt[(size_t)g * NB + b];
+            if (c > gmax[g]) gmax[g] = c;
+        }
+    };
+    auto take = [&](int v) {
+        const int b = bank[v];
+        --load[b];
+        for (int k = iptr[v]; k < iptr[v + 1]; ++k) {
+            const int g = inc[k];
+            const unsigned short c = cnt[(size_t)g * NB + b]--;
+            if (c == gmax[g]) gmax[g] = *std::max_element(cnt.begin() + (size_t)g * NB, cnt.begin() + (size_t)(g + 1) * NB);
+        }
+    };
+    // (growth of the groups' maxima, crowding of the bank inside the node's groups) of putting v on bank b
+    auto score = [&](int v, int b, int64_t& hard, int64_t& soft) {
+        hard = soft = 0;
+        for (int k = iptr[v]; k < iptr[v + 1]; ++k) {
+            const int g = inc[k];
+            const int c = cnt[(size_t)g * NB + b];
+            hard += (c + 1 > gmax[g]) ? G.gweight[g] : 0;
+            soft += (int64_t)c * G.gweight[g];
+        }
+    };
+    std::vector<int> order((size_t)n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::vector<int64_t> wsum((size_t)n, 0);
+    for (int v = 0; v < n; ++v) for (int k = iptr[v]; k < iptr[v + 1]; ++k) wsum[v] += G.gweight[inc[k]];
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wsum[a] > wsum[b]; });
+    for (int v : order) {
+        int best = -1; int64_t bh = 0, bs = 0;
+        for (int b = 0; b < NB; ++b) {
+            if (load[b] >= cap) continue;
+            int64_t h, sft; score(v, b, h, sft);
+            if (best < 0 || h < bh || (h == bh && (sft < bs || (sft == bs && load[b] < load[best])))) { best = b; bh = h; bs = sft; }
+        }
+        put(v, best);
+    }
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        int moved = 0;
+        for (int v = 0; v < n; ++v) {
+            if (iptr[v] == iptr[v + 1]) continue;
+            const int b0 = bank[v];
+            take(v);
+            int best = b0; int64_t bh, bs; score(v, b0, bh, bs);
+            for (int b = 0; b < NB; ++b) {
+                if (b == b0 || load[b] >= cap) continue;
+                int64_t h, sft; score(v, b, h, sft);
+                if (h < bh || (h == bh && sft < bs)) { best = b; bh = h; bs = sft; }
+            }
+            put(v, best);
+            moved += best != b0;
+        }
+        if (!moved) break;
+    }
+    std::vector<int> next(NB, 0);
+    for (int v = 0; v < n; ++v) pos_word[v] = (unsigned)(KS_NODE_W0 + bank[v] + NB * next[bank[v]]++);
 }
 
 }  // namespace
@@ -174,23 +321,25 @@ int ks_launch(const int2* ent, const unsigned* outa, const unsigned* keep, int n
 extern "C" int gda_kstep_max_rows(void) { return KS_MAX_ROWS; }
 
 extern "C" size_t gda_kstep_plan_bytes(int slots) {
-    return (size_t)KS_TB * slots * KS_L * sizeof(int2) + (size_t)KS_TB * slots * 4 + (size_t)KS_TB * 4;
+    return (size_t)KS_TB * slots * KS_L * sizeof(int2) + (size_t)KS_TB * slots * 4 + (size_t)KS_TB * 4 + (size_t)KS_POS_WORDS * 4;
 }
 
 // Compile a CSR (HOST arrays) into the register program.  Tries S = 6, 8, 10, 12 slots per thread and
 // writes the first that fits into `plan_host` (gda_kstep_plan_bytes(12) bytes are always enough):
-//   [ent: int2[16 waves][S*L][64]] [outa: u32[16][S][64]] [keep: u32[1024]]
+//   [ent: int2[16 waves][S*L][64]] [outa: u32[16][S][64]] [keep: u32[1024]] [pos: u32[KS_POS_WORDS]]
+// ent.x / outa / pos are LDS byte addresses inside one buffer: word 0 = the zero word, word 1 = the dump word,
+// node i at pos[i] (rows n_rows .. round_up(n_rows, 4) - 1 of the column park on the dump word).
+// flags bit 0: bank-aware placement of the nodes (ks_place); without it node i sits at word 32 + i.
 // Returns the S chosen (>0), 0 if the graph is not eligible (too many rows, a row longer than S*L entries,
 // or more slots than 1024 threads hold), <0 on invalid arguments.
-extern "C" int gda_kstep_plan_host(const int32_t* rowptr_host, const int32_t* colidx_host, const float* val_host,
-                                   int64_t n_rows, void* plan_host, size_t plan_bytes) {
+extern "C" int gda_kstep_plan_host_ex(const int32_t* rowptr_host, const int32_t* colidx_host, const float* val_host,
+                                      int64_t n_rows, int flags, void* plan_host, size_t plan_bytes) {
     if (n_rows < 0) return GDA_E_SIZE;
     if (n_rows == 0) return 0;
     if (!rowptr_host || !plan_host) return GDA_E_NULL;
     if (n_rows > KS_MAX_ROWS) return 0;
     const int n = (int)n_rows;
     const int n_pad = (n + 3) / 4 * 4;
-    const unsigned zero_addr = (unsigned)n_pad * 4u, dump_addr = zero_addr + 4u;
     int64_t total_slots = 0;
     int max_len = 0;
     for (int i = 0; i < n; ++i) {
@@ -204,12 +353,10 @@ extern "C" int gda_kstep_plan_host(const int32_t* rowptr_host, const int32_t* co
         if (max_len > S * KS_L || total_slots > (int64_t)S * KS_TB) continue;
         if (plan_bytes < gda_kstep_plan_bytes(S)) return GDA_E_WORKSPACE;
         const int R = S * KS_L;
-        int2* ent = static_cast<int2*>(plan_host);
-        unsigned* outa = reinterpret_cast<unsigned*>(ent + (size_t)KS_TB * R);
-        unsigned* keep = outa + (size_t)KS_TB * S;
-        for (size_t i = 0; i < (size_t)KS_TB * R; ++i) ent[i] = int2{(int)zero_addr, 0};
-        for (size_t i = 0; i < (size_t)KS_TB * S; ++i) outa[i] = dump_addr;
-        std::memset(keep, 0, (size_t)KS_TB * 4);
+        // pass 1: the program on node ids (-1 = zero word / dump word)
+        std::vector<int> ent_node((size_t)KS_TB * R, -1), out_node((size_t)KS_TB * S, -1);
+        std::vector<int> ent_w((size_t)KS_TB * R, 0);
+        std::vector<unsigned> keepv((size_t)KS_TB, 0u);
         int row = 0;
         int64_t placed = 0;
         for (int t = 0; t < KS_TB && row < n; ++t) {
@@ -226,20 +373,40 @@ extern "C" int gda_kstep_plan_host(const int32_t* rowptr_host, const int32_t* co
                     const int k = rowptr_host[row] + q;
                     const int32_t col = colidx_host[k];
                     if (col < 0 || col >= n) return GDA_E_SIZE;
-                    int vb;
-                    std::memcpy(&vb, &val_host[k], 4);
-                    ent[((size_t)w * R + (size_t)used * KS_L + q) * 64 + lane] = int2{(int)((unsigned)col * 4u), vb};
+                    const size_t at = ((size_t)w * R + (size_t)used * KS_L + q) * 64 + lane;
+                    ent_node[at] = col;
+                    std::memcpy(&ent_w[at], &val_host[k], 4);
                 }
-                for (int q = 0; q + 1 < need; ++q) keep[t] |= 1u << (used + q);
-                outa[((size_t)w * S + used + need - 1) * 64 + lane] = (unsigned)row * 4u;
+                for (int q = 0; q + 1 < need; ++q) keepv[t] |= 1u << (used + q);
+                out_node[((size_t)w * S + used + need - 1) * 64 + lane] = row;
                 used += need;
                 placed += need;
                 ++row;
             }
         }
-        if (row == n) return S;
+        if (row != n) continue;
+        // pass 2: where the nodes live, then the program on LDS byte addresses
+        std::vector<unsigned> pos_word;
+        ks_place(n, S, ent_node, out_node, (flags & 1) != 0, pos_word);
+        int2* ent = static_cast<int2*>(plan_host);
+        unsigned* outa = reinterpret_cast<unsigned*>(ent + (size_t)KS_TB * R);
+        unsigned* keep = outa + (size_t)KS_TB * S;
+        unsigned* pos = keep + KS_TB;
+        for (size_t i = 0; i < (size_t)KS_TB * R; ++i)
+            ent[i] = int2{(int)((ent_node[i] >= 0 ? pos_word[ent_node[i]] : (unsigned)KS_ZERO_W) * 4u), ent_w[i]};
+        for (size_t i = 0; i < (size_t)KS_TB * S; ++i)
+            outa[i] = (out_node[i] >= 0 ? pos_word[out_node[i]] : (unsigned)KS_DUMP_W) * 4u;
+        std::memcpy(keep, keepv.data(), (size_t)KS_TB * 4);
+        for (int i = 0; i < KS_POS_WORDS; ++i) pos[i] = (i < n ? pos_word[i] : (unsigned)KS_DUMP_W) * 4u;
+        (void)n_pad;
+        return S;
     }
     return 0;
+}
+
+extern "C" int gda_kstep_plan_host(const int32_t* rowptr_host, const int32_t* colidx_host, const float* val_host,
+                                   int64_t n_rows, void* plan_host, size_t plan_bytes) {
+    return gda_kstep_plan_host_ex(rowptr_host, colidx_host, val_host, n_rows, 1, plan_host, plan_bytes);
 }
 
 // Column-major entry point: xT, yT are [d, ld*] with ld* >= n_pad = round_up(n_rows, 4) and 16-byte aligned
@@ -258,13 +425,14 @@ extern "C" int gda_kstep_lds_colmajor_f32(const void* plan, int slots, int64_t n
     const int2* ent = static_cast<const int2*>(plan);
     const unsigned* outa = reinterpret_cast<const unsigned*>(ent + (size_t)KS_TB * R);
     const unsigned* keep = outa + (size_t)KS_TB * slots;
+    const unsigned* pos = keep + KS_TB;
     hipStream_t s = (hipStream_t)stream;
     const int n = (int)n_rows;
     switch (slots) {
-        case 6: return ks_launch<6>(ent, outa, keep, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
-        case 8: return ks_launch<8>(ent, outa, keep, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
-        case 10: return ks_launch<10>(ent, outa, keep, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
-        case 12: return ks_launch<12>(ent, outa, keep, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
+        case 6: return ks_launch<6>(ent, outa, keep, pos, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
+        case 8: return ks_launch<8>(ent, outa, keep, pos, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
+        case 10: return ks_launch<10>(ent, outa, keep, pos, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
+        case 12: return ks_launch<12>(ent, outa, keep, pos, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
         default: return GDA_E_UNSUPPORTED;
     }
 }

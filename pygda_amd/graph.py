@@ -96,7 +96,7 @@ class CSRGraph:
     def kstep_plan(self, transposed=False):
         """``(plan, slots)`` for the one-launch LDS-resident K-step kernel (csrc/gda_kstep.hip), compiled on
         the host from this CSR on first use (one device-to-host copy of the graph: static graphs only), or
-        None when the graph is not eligible (more than 16,380 nodes, a row beyond 48 entries, ...)."""
+        None when the graph is not eligible (more than 16,320 nodes, a row beyond 48 entries, ...)."""
         hit = self._t_kplan if transposed else self._kplan
         if hit is None:
             hit = _kstep_plan(self, transposed) or False
@@ -153,16 +153,17 @@ def _kstep_plan(g, transposed):
     va_h = va[:nnz].cpu().numpy()
     cap = L.gda_kstep_plan_bytes(12)
     buf = torch.empty(cap, dtype=torch.uint8)
-    slots = L.gda_kstep_plan_host(rp_h.ctypes.data, ci_h.ctypes.data if nnz else None,
-                                  va_h.ctypes.data if nnz else None, n, buf.data_ptr(), cap)
+    slots = L.gda_kstep_plan_host_ex(rp_h.ctypes.data, ci_h.ctypes.data if nnz else None,
+                                     va_h.ctypes.data if nnz else None, n, KSTEP_BANK_AWARE, buf.data_ptr(), cap)
     if slots < 0:
-        _lib.check(slots, "gda_kstep_plan_host")
+        _lib.check(slots, "gda_kstep_plan_host_ex")
     if slots == 0:
         return None
     return buf[:L.gda_kstep_plan_bytes(slots)].to(g.device), int(slots)
 
 
 KSTEP_LDS = os.environ.get("PYGDA_AMD_KSTEP_LDS", "1") == "1"
+KSTEP_BANK_AWARE = int(os.environ.get("PYGDA_AMD_KSTEP_BANKS", "1"))     # bank-aware node placement in LDS (gda_kstep.hip)
 KSTEP_LDS_MIN_K = int(os.environ.get("PYGDA_AMD_KSTEP_LDS_MIN_K", "3"))
 
 SQUARE_MAX_FILL = float(os.environ.get("PYGDA_AMD_SQUARE_MAX_FILL", "6"))

@@ -342,10 +342,46 @@ def test_mixup_base_foreign_edge_index_b(monkeypatch, layers):
             np.testing.assert_allclose(dict(net.named_parameters())[k].grad.numpy(), v, atol=1e-5, err_msg=k)
 
 
-def test_kstep_plan_is_the_csr_program():
-    """gda_kstep_plan_host (host side of csrc/gda_kstep.hip): emulate the per-lane register program it emits
-    on the CPU -- slots of 4 (LDS address, weight) entries, output address per slot, carry bits -- and compare
-    one step with the oracle's propagate, bit for bit; eligibility limits."""
+def _kstep_plan_views(buf, S):
+    import numpy as np
+    TB, R = 1024, S * 4
+    o1 = TB * R * 8
+    o2 = o1 + TB * S * 4
+    o3 = o2 + TB * 4
+    ent = buf[:o1].view(np.int32).reshape(16, R, 64, 2)
+    outa = buf[o1:o2].view(np.uint32).reshape(16, S, 64)
+    keep = buf[o2:o3].view(np.uint32)
+    pos = buf[o3:].view(np.uint32)
+    return ent, outa, keep, pos
+
+
+def _kstep_lds_cycles(ent, outa, pos, n, banks=32):
+    """LDS-array cycles of one step + one column load under MI355X_MICROARCH.md's ds_read_b32 / ds_write_b32 model:
+    per wave instruction two lane groups of 32, each costing the largest number of DISTINCT addresses on one bank."""
+    import numpy as np
+
+    def cost(addr):                                  # [..., 64] byte addresses
+        a = addr.reshape(-1, 2, 32) // 4
+        tot = 0
+        for grp in a.reshape(-1, 32):
+            u = np.unique(grp)
+            tot += np.bincount(u % banks, minlength=banks).max()
+        return int(tot)
+    n_pad = (n + 3) // 4 * 4
+    io = 0
+    for j in range(4):
+        lanes = pos[:n_pad].reshape(-1, 4)[:, j]
+        lanes = np.concatenate([lanes, np.full((-len(lanes)) % 64, 4, dtype=lanes.dtype)])
+        io += cost(lanes.reshape(-1, 64))
+    return cost(ent[..., 0].astype(np.int64)), cost(outa.astype(np.int64)), io
+
+
+@pytest.mark.parametrize("flags", [1, 0])
+def test_kstep_plan_is_the_csr_program(flags):
+    """gda_kstep_plan_host_ex (host side of csrc/gda_kstep.hip): emulate the per-lane register program it emits
+    on the CPU -- slots of 4 (LDS address, weight) entries, output address per slot, carry bits, the node -> LDS
+    address table the column is loaded and stored through -- and compare one step with the oracle's propagate,
+    bit for bit, with and without the bank-aware placement; eligibility limits."""
     import ctypes
     import numpy as np
     from pygda_amd import _lib
@@ -363,17 +399,22 @@ def test_kstep_plan_is_the_csr_program():
     col = src.astype(np.int32)
     cap = L.gda_kstep_plan_bytes(12)
     buf = np.zeros(cap, dtype=np.uint8)
-    S = L.gda_kstep_plan_host(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, n, buf.ctypes.data, cap)
+    S = L.gda_kstep_plan_host_ex(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, n, flags, buf.ctypes.data, cap)
     assert S in (6, 8, 10, 12)
-    TB, Lw, R = 1024, 4, S * 4
-    ent = buf[:TB * R * 8].view(np.int32).reshape(16, R, 64, 2)
-    outa = buf[TB * R * 8:TB * R * 8 + TB * S * 4].view(np.uint32).reshape(16, S, 64)
-    keep = buf[TB * R * 8 + TB * S * 4:TB * R * 8 + TB * S * 4 + TB * 4].view(np.uint32)
+    TB, Lw = 1024, 4
+    ent, outa, keep, pos = _kstep_plan_views(buf[:L.gda_kstep_plan_bytes(S)], S)
     n_pad = (n + 3) // 4 * 4
+    words = 65528 // 4
+    # the table: distinct words per node beyond the zero / dump words, inside one buffer; padding rows park on the dump word
+    assert len(np.unique(pos[:n])) == n and pos[:n].min() >= 8 and pos[:n].max() < words * 4 and (pos[:n] % 4 == 0).all()
+    assert (pos[n:n_pad] == 4).all()
+    if not flags:
+        assert (pos[:n] == (32 + np.arange(n)) * 4).all()
     x = rng.standard_normal(n).astype(np.float32)
-    cur = np.zeros(n_pad + 2, dtype=np.float32)
-    cur[:n] = x
-    nxt = np.full(n_pad + 2, np.nan, dtype=np.float32)
+    cur = np.full(words, np.nan, dtype=np.float32)
+    cur[0] = 0.0                                                 # the zero word
+    cur[pos[:n] // 4] = x                                        # the column load
+    nxt = np.full(words, np.nan, dtype=np.float32)
     for t in range(TB):
         wv, lane = t >> 6, t & 63
         acc = np.float32(0)
@@ -385,10 +426,11 @@ def test_kstep_plan_is_the_csr_program():
             if not (keep[t] >> s) & 1:
                 acc = np.float32(0)
     want = O.propagate(ei, w, torch.from_numpy(x).view(n, 1)).view(-1).numpy()
-    np.testing.assert_array_equal(nxt[:n], want)
+    np.testing.assert_array_equal(nxt[pos[:n] // 4], want)       # the column store
     # every row is written exactly once; the zero word is never an output
-    rows_written = outa[outa < n_pad * 4] // 4
-    assert sorted(rows_written.tolist()) == list(range(n))
+    rows_written = outa[outa != 4]
+    assert sorted(rows_written.tolist()) == sorted(pos[:n].tolist())
+    assert (outa != 0).all()
     # limits: a row longer than 48 entries, too many rows
     rp2 = np.array([0, 49], dtype=np.int32)
     c2, v2 = np.zeros(49, dtype=np.int32), np.ones(49, dtype=np.float32)
@@ -397,6 +439,37 @@ def test_kstep_plan_is_the_csr_program():
     rp3 = np.zeros(big + 1, dtype=np.int32)
     assert L.gda_kstep_plan_host(rp3.ctypes.data, None, None, big, buf.ctypes.data, cap) == 0
     assert L.gda_kstep_plan_host(None, None, None, 5, buf.ctypes.data, cap) == -1
+
+
+def test_kstep_bank_aware_placement_cuts_the_lds_conflicts():
+    """The step loop of csrc/gda_kstep.hip is bound by its LDS gathers; with node i at word 32 + i a lane group's 32
+    gathers put ~2.7 distinct addresses on the busiest bank at the cfg-A target graph's shape (random neighbours),
+    the bank-aware placement brings the gathers near the 1-per-group floor.  Model: MI355X_MICROARCH.md, LDS table."""
+    import numpy as np
+    from pygda_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    n, e = 5484, 8117
+    a, b = rng.integers(0, n, size=e), rng.integers(0, n, size=e)
+    srcs = np.concatenate([a, b, np.arange(n)])
+    dsts = np.concatenate([b, a, np.arange(n)])
+    order = np.argsort(dsts, kind="stable")
+    col = srcs[order].astype(np.int32)
+    rowptr = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(dsts, minlength=n), out=rowptr[1:])
+    val = np.ones(len(col), dtype=np.float32)
+    cap = L.gda_kstep_plan_bytes(12)
+    cyc = {}
+    for flags in (0, 1):
+        buf = np.zeros(cap, dtype=np.uint8)
+        S = L.gda_kstep_plan_host_ex(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, n, flags, buf.ctypes.data, cap)
+        assert S == 8
+        ent, outa, keep, pos = _kstep_plan_views(buf[:L.gda_kstep_plan_bytes(S)], S)
+        cyc[flags] = _kstep_lds_cycles(ent, outa, pos, n)
+    groups_rd, groups_wr = 16 * 32 * 2, 16 * 8 * 2
+    assert cyc[0][0] > 2.4 * groups_rd                           # the unplaced plan: ~2.7-way gathers
+    assert cyc[1][0] < 1.4 * groups_rd and cyc[1][1] < 1.5 * groups_wr, cyc
+    assert cyc[1][2] <= 1.5 * cyc[0][2], cyc                     # the column load / store stays near conflict-free
 
 
 def test_int32_limits_are_rejected_not_wrapped():

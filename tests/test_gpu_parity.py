@@ -1798,7 +1798,7 @@ def test_kstep_lds_bit_exact_vs_oracle(name, d, K):
 
 def test_kstep_lds_ragged_rows_and_fallback():
     """Empty rows (no self loops), rows spanning several 4-entry slots, non-finite features staying in their
-    rows; a row beyond 48 entries or more than 16,380 nodes is not eligible and takes the launch chain."""
+    rows; a row beyond 48 entries or more than 16,320 nodes is not eligible and takes the launch chain."""
     gen = torch.Generator().manual_seed(21)
     n, d, K = 2000, 64, 5
     ei = torch.randint(0, n, (2, 9000), generator=gen)
