@@ -418,6 +418,22 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     profiler.stop()
+    host_launch = None
+    if graphed and hasattr(_g, "_refill") and hasattr(_g, "_replay"):
+        # what the host pays per step: the refill (sample draws + H2D enqueue) and the hipGraphLaunch call itself,
+        # timed with an idle device after the timed region (replaying a forked graph enqueues its nodes one by one)
+        refill, replay = [], []
+        for _ in range(10):
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            _g._refill()
+            h1 = time.perf_counter()
+            _g._replay()
+            h2 = time.perf_counter()
+            refill.append(h1 - h0)
+            replay.append(h2 - h1)
+        torch.cuda.synchronize()
+        host_launch = {"refill_us": 1e6 * sorted(refill)[5], "graph_launch_call_us": 1e6 * sorted(replay)[5]}
     if graphed:
         # Per-kernel HIP-event timing cannot bracket launches inside a replayed graph, so the
         # roofline inputs are measured on the SAME kernels in an eager pass of the same K steps
@@ -492,6 +508,8 @@ def main():
             "roofline_dense_projection": {k: roof(k) for k in sorted(prof) if k.startswith("dense_projection")},
             "kernel_time_ms_per_step": {k: v["ms"] / args.steps for k, v in sorted(prof.items())},
         }
+        if host_launch is not None:
+            out["host_per_step"] = host_launch
         if world == 1 and not args.no_hbm_probe:
             # cfg-A's graphs are cache resident, so the HBM fraction above says little about the kernel:
             # the same aggregation kernel timed at configs[4]'s per-domain size, where HBM is the bound

@@ -421,6 +421,13 @@ int gda_sampler_sample(gda_sampler* s, const int64_t* seeds_host, int64_t n_seed
                        int64_t* n_nodes_out, int64_t* n_edges_out);
 int gda_sampler_fetch(const gda_sampler* s, int64_t* nodes_out, int64_t* esrc_out,
                       int64_t* edst_out);
+/* The GCN-normalised adjacency of the last sampled batch as the two CSRs of the aggregation kernels, built on
+ * the host where the structure is known: exactly the arrays gda_build_csr_norm(esrc, edst, NULL, n_edges,
+ * n_nodes, 1.0, add_self_loops = 1, normalize = 1, degree_side = 0) writes (gcn_norm with unit weights,
+ * pygda/nn/prop_gcn_conv.py:64-81), without the device sorts.  rowptr / t_rowptr: n_nodes + 1 entries;
+ * colidx / val / t_colidx / t_val: n_edges + n_nodes entries (HOST pointers). */
+int gda_sampler_csr_norm(const gda_sampler* s, int32_t* rowptr, int32_t* colidx, float* val,
+                         int32_t* t_rowptr, int32_t* t_colidx, float* t_val);
 
 /* ------------------------------------------------------------------------------
  * Host construction of the PPMI graph (HOST pointers).

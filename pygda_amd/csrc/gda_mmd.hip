@@ -29,6 +29,8 @@
 // All reductions are fixed-order (no atomics): results are run-to-run deterministic.
 #include "gda_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int TB = 256;
@@ -352,23 +354,32 @@ k_finalize(const double* __restrict__ kpartial, int tiles_per_t, int times, int6
 // LDS: the global loads of chunk c+1 are in flight while the 32 MFMAs of chunk c issue.
 // g is symmetric, so the A operand tile is read as g[j][i]: 16-byte loads along i, stored k-major,
 // and every MFMA operand fetch is a conflict-free ds_read_b32.
-constexpr int BI = 64;        // rows i per workgroup
+constexpr int BI = 64;        // rows i per workgroup (default variant)
 constexpr int BJ = 32;        // rows j per chunk (MFMA K = 2 per instruction)
 
-template <int KN>
-__global__ void __launch_bounds__(TB)
+// BI_ x 128 workgroup tile, BI_ / 32 * 2 wavefronts (64 rows: 4 waves, 128 rows: 8 waves -- the T chunk is then shared
+// by twice the rows: 0.25 KB of staging per row and chunk instead of 0.375, four waves per SIMD with two workgroups
+// per CU).  Dynamic LDS: [Gs 2 x BJ x BI_][Ts 2 x BJ x DC][rowsum BI_]; the row-sum partials reuse Gs afterwards.
+template <int KN, int BI_>
+__global__ void __launch_bounds__(BI_ * 4)
 k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* __restrict__ bandwidth,
       KParams kp, const float* __restrict__ grad_loss, float scale, int times, int nseg,
       float* __restrict__ part) {
     (void)bandwidth; (void)kp;
-    __shared__ __attribute__((aligned(16))) float Gs[2][BJ][BI];      // Gs[b][j][i] = g[i][j]
-    __shared__ __attribute__((aligned(16))) float Ts[2][BJ][DC];      // rows j of total, this column chunk
-    __shared__ float rs_part[16][BI];
-    __shared__ float rowsum[BI];
+    constexpr int TB_ = BI_ * 4;
+    constexpr int GC = BI_ / 4;                   // float4 per G row
+    constexpr int TQ = (BJ * DC / 4) / TB_;       // T float4 per thread and chunk
+    constexpr int TSTEP = TB_ / (DC / 4);         // rows between a thread's T pieces
+    static_assert(TB_ / GC == 16 && BJ == 32, "two G rows per thread");
+    extern __shared__ __attribute__((aligned(16))) char bwd_lds[];
+    float (*Gs)[BJ][BI_] = reinterpret_cast<float (*)[BJ][BI_]>(bwd_lds);                       // Gs[b][j][i] = g[i][j]
+    float (*Ts)[BJ][DC] = reinterpret_cast<float (*)[BJ][DC]>(bwd_lds + sizeof(float) * 2 * BJ * BI_);   // rows j of total
+    float* rowsum = reinterpret_cast<float*>(bwd_lds + sizeof(float) * 2 * BJ * (BI_ + DC));
+    float (*rs_part)[BI_] = reinterpret_cast<float (*)[BI_]>(bwd_lds);                          // [16][BI_], after the loop
     const int t = blockIdx.z;
     const int seg = blockIdx.y % nseg;
     const int64_t c0 = (int64_t)(blockIdx.y / nseg) * DC;
-    const int64_t i0 = (int64_t)blockIdx.x * BI;
+    const int64_t i0 = (int64_t)blockIdx.x * BI_;
     const int tid = threadIdx.x, wave = tid / 64, lane = tid % 64;
     const int ka = lane >> 5, la = lane & 31;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
@@ -376,9 +387,9 @@ k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* _
     const float* L = l2 + (int64_t)t * m * m;
     const bool g_vec = (m % 4 == 0);
 
-    // staging roles: G chunk = 32 rows x 16 float4 (2 per thread), T chunk = 32 rows x 32 float4 (4 per thread)
-    const int g_c4 = (tid % 16) * 4, g_r = tid / 16;       // rows g_r and g_r + 16
-    const int t_c4 = (tid % 32) * 4, t_r = tid / 32;       // rows t_r, +8, +16, +24
+    // staging roles: G chunk = 32 rows x GC float4 (2 per thread), T chunk = 32 rows x 32 float4 (TQ per thread)
+    const int g_c4 = (tid % GC) * 4, g_r = tid / GC;       // rows g_r and g_r + 16
+    const int t_c4 = (tid % 32) * 4, t_r = tid / 32;       // rows t_r, t_r + TSTEP, ...
     // the same pivot shift as the forward: sum_j g_ij (t_i - t_j) is unchanged by it, and the two
     // products it is computed from no longer carry the batch's common offset
     const float* pivot = row_ptr(R, t, 0);
@@ -390,7 +401,7 @@ k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* _
     float rs[4] = {0.f, 0.f, 0.f, 0.f};
 
     const int64_t nchunks = gda_cdiv_dev(m, BJ);
-    float4 gq[2], tq[4];
+    float4 gq[2], tq[TQ];
     auto fetch = [&](int64_t ch) {
         const int64_t j0 = ch * BJ;
 #pragma unroll
@@ -410,8 +421,8 @@ k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* _
             gq[q] = v;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t j = j0 + t_r + 8 * q;
+        for (int q = 0; q < TQ; ++q) {
+            const int64_t j = j0 + t_r + TSTEP * q;
             tq[q] = sub4(load4(j < m ? row_ptr(R, t, j) : nullptr, c0 + t_c4, d, R.vec4), pv, j < m);
         }
     };
@@ -422,7 +433,7 @@ k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* _
             rs[0] += gq[q].x; rs[1] += gq[q].y; rs[2] += gq[q].z; rs[3] += gq[q].w;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(&Ts[b][t_r + 8 * q][t_c4]) = tq[q];
+        for (int q = 0; q < TQ; ++q) *reinterpret_cast<float4*>(&Ts[b][t_r + TSTEP * q][t_c4]) = tq[q];
     };
 
     // this segment's chunks: seg, seg + nseg, ...
@@ -446,9 +457,9 @@ k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* _
 
     // row sums of g over this segment: 16 threads hold partials for the same 4 rows
 #pragma unroll
-    for (int e = 0; e < 4; ++e) rs_part[g_r][g_c4 + e] = rs[e];
+    for (int e = 0; e < 4; ++e) rs_part[g_r][g_c4 + e] = rs[e];        // Gs is free: the loop ended on a barrier
     __syncthreads();
-    if (tid < BI) {
+    if (tid < BI_) {
         float sres = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) sres += rs_part[k][tid];
@@ -525,7 +536,35 @@ k_bwd_scatter(const float* __restrict__ part, int64_t m, int64_t d, int nseg,
     }
 }
 
-constexpr int BWD_NSEG = 4;        // measured: 2 -> 141+5 us, 4 -> 97+7, 8 -> 102+10, 16 -> 119+18 (k_bwd + k_bwd_reduce)
+constexpr int BWD_NSEG = 4;        // 64-row tiles, measured: 2 -> 141+5 us, 4 -> 97+7, 8 -> 102+10, 16 -> 119+18 (k_bwd + k_bwd_reduce)
+constexpr int BWD_NSEG_MAX = 8;    // workspace bound for the segment count of any variant
+
+struct BwdVariant { int tile, nseg; };
+BwdVariant bwd_variant() {          // PYGDA_AMD_MMD_BWD_TILE (64 | 128), PYGDA_AMD_MMD_BWD_NSEG: experiment switches
+    static const BwdVariant v = [] {
+        BwdVariant r{64, BWD_NSEG};
+        if (const char* e = std::getenv("PYGDA_AMD_MMD_BWD_TILE")) r.tile = std::atoi(e) == 128 ? 128 : 64;
+        if (r.tile == 128) r.nseg = 6;
+        if (const char* e = std::getenv("PYGDA_AMD_MMD_BWD_NSEG")) { const int k = std::atoi(e); if (k >= 1 && k <= BWD_NSEG_MAX) r.nseg = k; }
+        return r;
+    }();
+    return v;
+}
+
+template <int KN, int BI_>
+int launch_bwd(dim3 grid, hipStream_t stream, Rows R, int64_t d, int64_t m, const float* l2, const float* bandwidth, KParams kp,
+               const float* grad_loss, float scale, int times, int nseg, float* part) {
+    const size_t lds = sizeof(float) * (2 * BJ * (BI_ + DC) + BI_);
+    static bool configured = false;
+    if (!configured) {
+        GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd<KN, BI_>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    k_bwd<KN, BI_><<<grid, BI_ * 4, lds, stream>>>(R, d, m, l2, bandwidth, kp, grad_loss, scale, times, nseg, part);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
 
 struct MmdWs { double* kpartial; double* part_s1; float* part_col; float* bwd_part; size_t total; };
 
@@ -542,7 +581,7 @@ MmdWs carve(void* base, int times, int64_t n, int64_t d) {
     w.kpartial = (double*)take(sizeof(double) * times * nt * nt);
     w.part_s1 = (double*)take(sizeof(double) * times * chunks);
     w.part_col = (float*)take(sizeof(float) * times * chunks * (d > 0 ? d : 1));
-    w.bwd_part = (float*)take(sizeof(float) * times * BWD_NSEG * m * (d > 0 ? d : 1));
+    w.bwd_part = (float*)take(sizeof(float) * times * BWD_NSEG_MAX * m * (d > 0 ? d : 1));
     w.total = off;
     return w;
 }
@@ -661,11 +700,17 @@ extern "C" int gda_mmd_bwd_ex_f32(const float* src, int64_t ld_src, const float*
     const Rows R = make_rows(src, ld_src, tgt, ld_tgt, src_idx, tgt_idx, n);
     const KParams kp{kernel_mul, kernel_num, 0.f};
     const int64_t ntiles = gda_cdiv(m, BJ);
-    const int nseg = (int)(ntiles < BWD_NSEG ? ntiles : BWD_NSEG);
-    const dim3 grid((unsigned)gda_cdiv(m, BI), (unsigned)(gda_cdiv(d, DC) * nseg), (unsigned)times);
-    if (kernel_num == 5) k_bwd<5><<<grid, TB, 0, stream>>>(R, d, m, l2_saved, bandwidth, kp, grad_loss, scale, times, nseg, ws.bwd_part);
-    else k_bwd<0><<<grid, TB, 0, stream>>>(R, d, m, l2_saved, bandwidth, kp, grad_loss, scale, times, nseg, ws.bwd_part);
-    GDA_LAUNCH_CHECK();
+    const BwdVariant var = bwd_variant();
+    const int nseg = (int)(ntiles < var.nseg ? ntiles : var.nseg);
+    const dim3 grid((unsigned)gda_cdiv(m, var.tile), (unsigned)(gda_cdiv(d, DC) * nseg), (unsigned)times);
+    if (var.tile == 128) {
+        st = kernel_num == 5 ? launch_bwd<5, 128>(grid, stream, R, d, m, l2_saved, bandwidth, kp, grad_loss, scale, times, nseg, ws.bwd_part)
+                             : launch_bwd<0, 128>(grid, stream, R, d, m, l2_saved, bandwidth, kp, grad_loss, scale, times, nseg, ws.bwd_part);
+    } else {
+        st = kernel_num == 5 ? launch_bwd<5, 64>(grid, stream, R, d, m, l2_saved, bandwidth, kp, grad_loss, scale, times, nseg, ws.bwd_part)
+                             : launch_bwd<0, 64>(grid, stream, R, d, m, l2_saved, bandwidth, kp, grad_loss, scale, times, nseg, ws.bwd_part);
+    }
+    if (st != GDA_OK) return st;
     if (scatter) {
         const int64_t most = n_src_rows > n_tgt_rows ? n_src_rows : n_tgt_rows;
         if (most > 0) {

@@ -12,6 +12,7 @@
 // The per-node draws come from a counter-based generator keyed on (seed, hop, node), so a
 // batch is reproducible and independent of traversal order.
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <new>
@@ -210,6 +211,56 @@ extern "C" int gda_sampler_fetch(const gda_sampler* s, int64_t* nodes_out, int64
         if (!esrc_out || !edst_out) return GDA_E_NULL;
         std::memcpy(esrc_out, s->esrc.data(), s->esrc.size() * sizeof(int64_t));
         std::memcpy(edst_out, s->edst.data(), s->edst.size() * sizeof(int64_t));
+    }
+    return GDA_OK;
+}
+
+
+// The normalised adjacency of the LAST sampled batch as the two CSRs the aggregation kernels consume -- built where
+// the structure is known instead of re-derived on the device.  gda_build_csr_norm (csrc/gda_graph.hip) gets the
+// relabelled edge list back from the host and spends two radix sorts, a scan and five small kernels per batch and
+// domain on it (0.5 ms of a 7.6 ms cfg-S step); the sampler already holds the edges grouped by destination.
+// Output = exactly what gda_build_csr_norm(esrc, edst, w = NULL, E, N = n_nodes, fill 1, add_self_loops = 1,
+// normalize = 1, degree_side = col) writes (pygda/nn/prop_gcn_conv.py:64-81, gcn_norm with unit weights):
+//   rows of the by-destination CSR: the kept (non-loop) edges into the node in edge order, then its self loop;
+//   rows of the by-source CSR: the kept edges out of the node in edge order, then its self loop;
+//   deg[i] = entries of by-destination row i, dis = 1 / sqrt(deg), val = (dis[src] * 1) * dis[dst];
+// arrays of n_nodes + 1 and n_edges + n_nodes entries (the capacity layout of the device builder; rowptr[n_nodes] =
+// number of stored entries).
+extern "C" int gda_sampler_csr_norm(const gda_sampler* s, int32_t* rowptr, int32_t* colidx, float* val,
+                                    int32_t* t_rowptr, int32_t* t_colidx, float* t_val) {
+    if (!s || !rowptr || !t_rowptr) return GDA_E_NULL;
+    const int64_t n = (int64_t)s->nodes.size(), E = (int64_t)s->esrc.size();
+    if (E + n >= INT32_MAX) return GDA_E_SIZE;
+    if (E + n > 0 && (!colidx || !val || !t_colidx || !t_val)) return GDA_E_NULL;
+    std::vector<int32_t> cnt_d((size_t)n + 1, 0), cnt_s((size_t)n + 1, 0);
+    for (int64_t e = 0; e < E; ++e) {
+        if (s->esrc[e] == s->edst[e]) continue;                       // add_remaining_self_loops: loops are re-appended
+        ++cnt_d[s->edst[e] + 1];
+        ++cnt_s[s->esrc[e] + 1];
+    }
+    rowptr[0] = t_rowptr[0] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        rowptr[i + 1] = rowptr[i] + cnt_d[i + 1] + 1;
+        t_rowptr[i + 1] = t_rowptr[i] + cnt_s[i + 1] + 1;
+    }
+    std::vector<float> dis((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const float deg = (float)(rowptr[i + 1] - rowptr[i]);             // a sum of ones: exact
+        dis[i] = 1.0f / std::sqrt(deg);
+    }
+    std::vector<int32_t> cur_d(rowptr, rowptr + n), cur_s(t_rowptr, t_rowptr + n);
+    for (int64_t e = 0; e < E; ++e) {
+        const int64_t u = s->esrc[e], v = s->edst[e];
+        if (u == v) continue;
+        const float w = (dis[u] * 1.0f) * dis[v];
+        colidx[cur_d[v]] = (int32_t)u; val[cur_d[v]++] = w;
+        t_colidx[cur_s[u]] = (int32_t)v; t_val[cur_s[u]++] = w;
+    }
+    for (int64_t i = 0; i < n; ++i) {                                     // the appended loops come last in their rows
+        const float w = (dis[i] * 1.0f) * dis[i];
+        colidx[cur_d[i]] = (int32_t)i; val[cur_d[i]] = w;
+        t_colidx[cur_s[i]] = (int32_t)i; t_val[cur_s[i]] = w;
     }
     return GDA_OK;
 }

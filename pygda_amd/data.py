@@ -153,13 +153,19 @@ class NeighborLoader:
             import queue
             import threading
             q, stop = queue.Queue(maxsize=self.prefetch), threading.Event()
+            packed = self.data.x.device.type == "cuda"      # ids, edges and the batch's CSR in one pinned block
 
             def producer():
                 try:
                     for b, seeds in enumerate(batches):
                         if stop.is_set():
                             return
-                        q.put((seeds, self._sampler.sample(seeds, self.num_neighbors, seed=seeds_of(b))))
+                        if packed:
+                            q.put((seeds, self._sampler.sample_packed(seeds, self.num_neighbors, seed=seeds_of(b),
+                                                                      csr=self._sampler.emit_csr(self.data),
+                                                                      device=self.data.x.device)))
+                        else:
+                            q.put((seeds, self._sampler.sample(seeds, self.num_neighbors, seed=seeds_of(b))))
                     q.put(None)
                 except BaseException as exc:        # surface sampler errors in the consumer
                     q.put(exc)
@@ -173,8 +179,11 @@ class NeighborLoader:
                         break
                     if isinstance(item, BaseException):
                         raise item
-                    seeds, (n_id, ei) = item
-                    yield self._sampler.assemble(self.data, seeds, n_id, ei)
+                    seeds, parts = item
+                    if packed:
+                        yield self._sampler.assemble_packed(self.data, seeds, parts)
+                    else:
+                        yield self._sampler.assemble(self.data, seeds, *parts)
             finally:
                 stop.set()
                 while th.is_alive():                 # unblock a producer waiting on a full queue

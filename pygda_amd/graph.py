@@ -296,6 +296,10 @@ def as_graph(edge_index, num_nodes, edge_weight=None, improved=False, add_self_l
     """``edge_index`` may already be a :class:`CSRGraph` (then it is used as is)."""
     if isinstance(edge_index, CSRGraph):
         return edge_index
+    pre = getattr(edge_index, "_gda_prebuilt", None)   # a sampled batch whose gcn_norm graph the sampler built (sampler.py)
+    if (pre is not None and edge_weight is None and not improved and (add_self_loops is True or add_self_loops == 1) and normalize
+            and degree_side == "col" and pre.num_nodes == int(num_nodes)):
+        return pre
     g = graph_cache.get(edge_index, num_nodes, edge_weight, improved, add_self_loops, normalize, degree_side)
     if getattr(edge_index, "_gda_static", False):      # tagged by the full-batch loader (pygda_amd/data.py)
         g.static = True

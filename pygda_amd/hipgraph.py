@@ -31,6 +31,20 @@ def host_rand(shape, device):
     return torch.rand(shape).to(device)
 
 
+def _col_major(p):
+    return p.dim() == 2 and not p.is_contiguous() and p.t().is_contiguous()
+
+
+def _mem_flat(g, p):
+    """``g`` (a gradient of ``p``) flattened in the memory order of ``p``."""
+    return g.t().reshape(-1) if _col_major(p) else g.reshape(-1)
+
+
+def _mem_view(flat, p):
+    """The inverse: a view of ``flat`` with the shape AND strides of ``p``."""
+    return flat.view(p.size(1), p.size(0)).t() if _col_major(p) else flat.view_as(p)
+
+
 class _RandSlot:
     def __init__(self, shape, dev):
         self.shape = shape
@@ -476,11 +490,12 @@ class GraphedStepDP:
             # step is ~30 us at these kernel sizes)
             grads = torch.autograd.grad([loss_ce, rows_s, rows_t], params, [one, g_rows_s, g_rows_t],
                                         allow_unused=True)
-            flat = torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1)
-                              for g, p in zip(grads, params)])
+            # every gradient in its parameter's MEMORY order (a weight stored gather-major, sparse_features.py, has
+            # transposed strides: flattening it logically would transpose it here and back again in front of Adam)
+            flat = torch.cat([_mem_flat(g if g is not None else torch.zeros_like(p), p) for g, p in zip(grads, params)])
         off = 0
         for p in params:                     # the optimiser reads static views of the reduced buffer
-            p.grad = flat[off:off + p.numel()].view_as(p)
+            p.grad = _mem_view(flat[off:off + p.numel()], p)
             off += p.numel()
         with torch.cuda.graph(g4, pool=pool, **mode):
             flat.div_(float(W))

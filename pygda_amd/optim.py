@@ -56,11 +56,18 @@ class Adam(torch.optim.Optimizer):
                     g = p.grad
                     if g.is_sparse or g.dtype != torch.float32:
                         raise _lib.GdaError("Adam: dense fp32 gradients only")
-                    if not p.is_contiguous():
-                        raise _lib.GdaError("Adam: parameters must be contiguous")
-                    g = g.contiguous()
+                    # the update is elementwise: any dense layout works as long as parameter, gradient and both
+                    # moments share it (a weight stored gather-major, pygda_amd/sparse_features.py: [out, in] with
+                    # transposed strides)
+                    if not (p.is_contiguous() or (p.dim() == 2 and p.t().is_contiguous())):
+                        raise _lib.GdaError("Adam: parameters must be dense (row- or column-major)")
+                    if g.stride() != p.stride():
+                        g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
                     keep.append(g)
                     st = self._state(p)
+                    for name in ("exp_avg", "exp_avg_sq"):
+                        if st[name].stride() != p.stride():          # state created before the weight was re-laid out
+                            st[name] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[name])
                     table[k] = _lib.AdamTensorStruct(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
                                                      st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), p.numel())
                 b1, b2 = group["betas"]

@@ -9,6 +9,7 @@ the same products in index order, the structural zeros skipped (same result up t
 summation order).  Registration happens where feature matrices enter the device
 (``Data.to``); lookups are by tensor identity, so hidden activations never pay a check.
 """
+import os
 import weakref
 
 import torch
@@ -94,8 +95,9 @@ class _SparseLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weight, sf, vals=None, bias=None):
-        # [F, h].  Sharing one transposed copy between the source and the target branch (formed before the streams
-        # fork) was measured and dropped: a kernel ahead of the fork costs the captured step 60-70 us
+        # [F, h]: no copy once the weight is stored gather-major (_store_gather_major).  Sharing one transposed copy
+        # between the source and the target branch (formed before the streams fork) was measured and dropped: a
+        # kernel ahead of the fork costs the captured step 60-70 us
         wt = weight.t().contiguous()
         g = sf.graph
         val, t_val = (g.val, g.t_val) if vals is None else vals
@@ -153,8 +155,29 @@ def sparse_matmul(sf, weight):
     return _SparseMatmul.apply(weight, sf)
 
 
+OWN_LAYOUT = os.environ.get("PYGDA_AMD_SPARSE_WT_LAYOUT", "1") == "1"
+
+
+def _store_gather_major(weight):
+    """Re-lay a leaf ``weight [out, in]`` out in ``[in, out]`` memory order -- same shape, same values, transposed
+    strides -- the first time it meets sparse input features: ``W^T`` is the operand the SpMM gathers rows of, and
+    the weight gradient ``X^T gy`` comes out ``[in, out]``.  With the reference's row-major storage every step paid
+    a transposed copy of the 867 k-element layer-0 weight per branch (6-8 us each, the first kernel of the target
+    branch) and a transposing copy of its gradient at the very end of the backward pass (9 us on the critical
+    path); stored gather-major, ``weight.t()`` is contiguous and the gradient meets autograd's layout contract as
+    it is.  Adam is elementwise, so the optimiser works on the raw memory (pygda_amd/optim.py); ``state_dict`` /
+    ``load_state_dict`` / ``.weight[i, j]`` see the same ``[out, in]`` tensor as before."""
+    if (OWN_LAYOUT and weight.dim() == 2 and weight.is_leaf and weight.is_contiguous() and weight.is_cuda
+            and min(weight.shape) > 1 and not torch.cuda.is_current_stream_capturing()):
+        with torch.no_grad():
+            weight.data = weight.data.t().contiguous().t()
+            if weight.grad is not None:
+                weight.grad = None
+
+
 def sparse_linear(weight, sf, dropout=0.0, bias=None):
     """``X W^T (+ bias)``; with ``dropout > 0`` the product uses ``dropout(X)`` (mask drawn per call)."""
+    _store_gather_major(weight)
     if dropout > 0.0:
         return _SparseLinear.apply(weight, sf, sf.dropped_values(dropout), bias)
     return _SparseLinear.apply(weight, sf, None, bias)

@@ -20,6 +20,7 @@ import pygda_amd
 from pygda_amd import ops
 from pygda_amd.data import Data
 from pygda_amd.graph import build_csr
+from pygda_amd.sampler import NeighborSampler
 from oracle import pygda_cpu as O
 from tests.conftest import T, load_golden
 from tests.test_gpu_parity import DEV, LOGIT_ATOL, REL, _no_dropout, _pair, close, exact

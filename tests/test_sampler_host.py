@@ -72,6 +72,38 @@ def test_fanout_bounds_and_no_replacement(fan):
     assert not (n3.numel() == n_id.numel() and torch.equal(s3, sub))
 
 
+@pytest.mark.parametrize("fan,loops", [([-1, -1], False), ([4, 3], False), ([5, 5], True), ([2], True)])
+def test_sampler_built_csr_is_gcn_norm_of_the_batch(fan, loops):
+    """gda_sampler_csr_norm: the normalised adjacency of a sampled batch built by the sampler -- rows by destination
+    and by source, edge order inside a row, the self loop last, w = dis[src] * dis[dst] -- against the oracle's
+    gcn_norm (prop_gcn_conv.py:64-81) of the batch's edge list, bit for bit; with and without self-loop edges in
+    the input graph (add_remaining_self_loops drops them and re-appends one per node)."""
+    from oracle import pygda_cpu as O
+    n, ei = 300, rand_graph(300, 2500, 7)
+    if loops:
+        ei = torch.cat([ei, torch.arange(0, n, 3).repeat(2, 1)], dim=1)[:, torch.randperm(ei.size(1) + n // 3 + (n % 3 > 0),
+                                                                                         generator=torch.Generator().manual_seed(1))]
+    S = NeighborSampler(ei, n)
+    n_id, sub, block = S.sample(torch.arange(10, 50), fan, seed=3, csr=True)
+    nb, ne = n_id.numel(), sub.size(1)
+    o = S._csr_offsets(nb, ne)
+    block = block.numpy()
+    cap = nb + ne
+    rowptr, t_rowptr = block[o[0]:o[0] + nb + 1], block[o[1]:o[1] + nb + 1]
+    colidx, t_colidx = block[o[2]:o[2] + cap], block[o[3]:o[3] + cap]
+    val, t_val = block[o[4]:o[4] + cap].view(np.float32), block[o[5]:o[5] + cap].view(np.float32)
+    nei, nw = O.gcn_norm(sub, None, nb)                    # kept edges in order, then one loop per node
+    nnz = nei.size(1)
+    assert rowptr[nb] == nnz and t_rowptr[nb] == nnz and all(o_ % 4 == 0 for o_ in o)
+    for key, other, rp, ci, va in ((1, 0, rowptr, colidx, val), (0, 1, t_rowptr, t_colidx, t_val)):
+        order = np.argsort(nei[key].numpy(), kind="stable")
+        want_rp = np.zeros(nb + 1, dtype=np.int64)
+        np.cumsum(np.bincount(nei[key].numpy(), minlength=nb), out=want_rp[1:])
+        np.testing.assert_array_equal(rp, want_rp)
+        np.testing.assert_array_equal(ci[:nnz], nei[other].numpy()[order])
+        np.testing.assert_array_equal(va[:nnz], nw.numpy()[order])
+
+
 def test_loader_batches_and_rank_sharding():
     n, ei = 300, rand_graph(300, 2000, 3)
     d = Data(x=torch.randn(n, 7), edge_index=ei, y=torch.arange(n) % 5)
