@@ -301,6 +301,32 @@ int gda_grl_disc_ce_bwd_f32(const float* feat_src, int64_t ld_src, int64_t n_src
 size_t gda_grl_disc_workspace_bytes(int64_t n_rows, int64_t h, int C);
 
 /* ------------------------------------------------------------------------------
+ * Gradient-reversal + TWO-LAYER domain discriminator + per-domain softmax cross-entropy, fused
+ * (csrc/gda_disc_mlp.hip).  Replaces UDAGCN's domain branch, pygda/models/udagcn.py:176-190 with the
+ * discriminator built at pygda/nn/udagcn_base.py:157-162:
+ *     D(x) = W2 dropout_p(relu(W1 GradReverse(x) + b1)) + b2,   W1 [a, h], b1 [a], W2 [2, a], b2 [2] (row-major)
+ *     losses[0] = mean over the n_s source rows of CE(D(x), 0),  losses[1] = mean over the n_t target rows of CE(D(x), 1),
+ *     losses[2] = their sum (what the reference adds to its loss; the two means also come back separately so that a
+ *     data-parallel caller can weight them by node counts).  h <= 128, a <= 64.  Dropout keep-bits: Philox keyed on (seed, *step, site + domain, row, unit) --
+ * forward and backward regenerate them, nothing of size [rows, a] is stored.
+ *   backward: grad_losses = upstream gradients (device): of the two means at [0] and [grad_stride] (grad_stride 1), or
+ *             of their sum (grad_stride 0); g_es / g_et (may be NULL) receive
+ *             -alpha * dD/dx (the reversal; alpha_dev != NULL: alpha read from the device), gW1 [a, h], gb1 [a],
+ *             gW2 [2, a], gb2 [2] the parameter gradients (fixed-order sums: deterministic).
+ * ---------------------------------------------------------------------------- */
+size_t gda_grl_mlp_ce_workspace_bytes(int64_t h, int64_t a);
+int gda_grl_mlp_ce_fwd_f32(const float* es, int64_t ld_s, int64_t n_s, const float* et, int64_t ld_t, int64_t n_t,
+                           int64_t h, int64_t a, const float* W1, const float* b1, const float* W2, const float* b2,
+                           float dropout_p, uint64_t seed, const int64_t* step, uint32_t site,
+                           float* losses, void* workspace, size_t workspace_bytes, gda_stream_t stream);
+int gda_grl_mlp_ce_bwd_f32(const float* es, int64_t ld_s, int64_t n_s, const float* et, int64_t ld_t, int64_t n_t,
+                           int64_t h, int64_t a, const float* W1, const float* b1, const float* W2, const float* b2,
+                           float dropout_p, uint64_t seed, const int64_t* step, uint32_t site,
+                           const float* grad_losses, int grad_stride, float alpha, const float* alpha_dev,
+                           float* g_es, float* g_et, float* gW1, float* gb1, float* gW2, float* gb2,
+                           void* workspace, size_t workspace_bytes, gda_stream_t stream);
+
+/* ------------------------------------------------------------------------------
  * Wasserstein critic update with gradient penalty (WGAN-GP), loss and parameter gradients in closed form
  * (csrc/gda_critic.hip).  Replaces the body of AdaGCN's critic loop, pygda/models/adagcn.py:169-183 with
  * gradient_penalty (:387-454), for the critic built at :264-270:

@@ -46,6 +46,12 @@ _SIGNATURES = {
                                    _P, _P, _P, c_float, _P, _P, _P, c_int64, _P, _P, _P, c_int64, _P,
                                    _P, c_size_t, _P]),
     "gda_grl_disc_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "gda_grl_mlp_ce_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "gda_grl_mlp_ce_fwd_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P,
+                                       c_float, ctypes.c_uint64, _P, ctypes.c_uint32, _P, _P, c_size_t, _P]),
+    "gda_grl_mlp_ce_bwd_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P,
+                                       c_float, ctypes.c_uint64, _P, ctypes.c_uint32, _P, c_int, c_float, _P,
+                                       _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gda_grl_disc_ce_fwd_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int,
                                         _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gda_grl_disc_ce_bwd_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int,

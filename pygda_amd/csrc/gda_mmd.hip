@@ -539,15 +539,22 @@ k_bwd_scatter(const float* __restrict__ part, int64_t m, int64_t d, int nseg,
 constexpr int BWD_NSEG = 4;        // 64-row tiles, measured: 2 -> 141+5 us, 4 -> 97+7, 8 -> 102+10, 16 -> 119+18 (k_bwd + k_bwd_reduce)
 constexpr int BWD_NSEG_MAX = 8;    // workspace bound for the segment count of any variant
 
+// Row tile and j-segment count of k_bwd.  Measured at the A2GNN shapes (times = 5, m = 2000, d = 128; k_bwd + the fold
+// behind it, us): 64 rows x 4 segments 102.6 + 6.7 (round 1's choice), 128 x 4 109.5 + 6.6, 128 x 5 93.4 + 7.6,
+// 128 x 6 83.0 + 8.4, 128 x 8 100.1 + 10.3 -- 16 row tiles x 6 segments x 5 resamples = 480 workgroups of 8 waves,
+// two per CU on 240 of the 256 CUs at once; the 128-row tile shares every staged T chunk between twice the rows.
+// PYGDA_AMD_MMD_BWD_TILE / PYGDA_AMD_MMD_BWD_NSEG override (experiments).
 struct BwdVariant { int tile, nseg; };
-BwdVariant bwd_variant() {          // PYGDA_AMD_MMD_BWD_TILE (64 | 128), PYGDA_AMD_MMD_BWD_NSEG: experiment switches
-    static const BwdVariant v = [] {
-        BwdVariant r{64, BWD_NSEG};
-        if (const char* e = std::getenv("PYGDA_AMD_MMD_BWD_TILE")) r.tile = std::atoi(e) == 128 ? 128 : 64;
-        if (r.tile == 128) r.nseg = 6;
+BwdVariant bwd_variant(int64_t m) {
+    static const BwdVariant env = [] {
+        BwdVariant r{0, 0};
+        if (const char* e = std::getenv("PYGDA_AMD_MMD_BWD_TILE")) r.tile = std::atoi(e) == 64 ? 64 : (std::atoi(e) == 128 ? 128 : 0);
         if (const char* e = std::getenv("PYGDA_AMD_MMD_BWD_NSEG")) { const int k = std::atoi(e); if (k >= 1 && k <= BWD_NSEG_MAX) r.nseg = k; }
         return r;
     }();
+    BwdVariant v = m >= 512 ? BwdVariant{128, 6} : BwdVariant{64, BWD_NSEG};
+    if (env.tile) { v.tile = env.tile; v.nseg = env.tile == 128 ? 6 : BWD_NSEG; }
+    if (env.nseg) v.nseg = env.nseg;
     return v;
 }
 
@@ -700,7 +707,7 @@ extern "C" int gda_mmd_bwd_ex_f32(const float* src, int64_t ld_src, const float*
     const Rows R = make_rows(src, ld_src, tgt, ld_tgt, src_idx, tgt_idx, n);
     const KParams kp{kernel_mul, kernel_num, 0.f};
     const int64_t ntiles = gda_cdiv(m, BJ);
-    const BwdVariant var = bwd_variant();
+    const BwdVariant var = bwd_variant(m);
     const int nseg = (int)(ntiles < var.nseg ? ntiles : var.nseg);
     const dim3 grid((unsigned)gda_cdiv(m, var.tile), (unsigned)(gda_cdiv(d, DC) * nseg), (unsigned)times);
     if (var.tile == 128) {

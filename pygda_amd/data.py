@@ -153,19 +153,14 @@ class NeighborLoader:
             import queue
             import threading
             q, stop = queue.Queue(maxsize=self.prefetch), threading.Event()
-            packed = self.data.x.device.type == "cuda"      # ids, edges and the batch's CSR in one pinned block
 
             def producer():
                 try:
                     for b, seeds in enumerate(batches):
                         if stop.is_set():
                             return
-                        if packed:
-                            q.put((seeds, self._sampler.sample_packed(seeds, self.num_neighbors, seed=seeds_of(b),
-                                                                      csr=self._sampler.emit_csr(self.data),
-                                                                      device=self.data.x.device)))
-                        else:
-                            q.put((seeds, self._sampler.sample(seeds, self.num_neighbors, seed=seeds_of(b))))
+                        q.put((seeds, self._sampler.sample(seeds, self.num_neighbors, seed=seeds_of(b),
+                                                           csr=self._sampler.emit_csr(self.data))))
                     q.put(None)
                 except BaseException as exc:        # surface sampler errors in the consumer
                     q.put(exc)
@@ -180,10 +175,7 @@ class NeighborLoader:
                     if isinstance(item, BaseException):
                         raise item
                     seeds, parts = item
-                    if packed:
-                        yield self._sampler.assemble_packed(self.data, seeds, parts)
-                    else:
-                        yield self._sampler.assemble(self.data, seeds, *parts)
+                    yield self._sampler.assemble(self.data, seeds, *parts)
             finally:
                 stop.set()
                 while th.is_alive():                 # unblock a producer waiting on a full queue

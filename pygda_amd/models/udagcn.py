@@ -14,6 +14,11 @@ from ..nn import GradReverse, UDAGCNBase
 from .base import BaseGDA
 
 
+import os
+
+FUSED_DOMAIN_MODEL = os.environ.get("PYGDA_AMD_FUSED_DOMAIN_MODEL", "1") == "1"
+
+
 class UDAGCN(BaseGDA):
     def __init__(self, in_dim, hid_dim, num_classes, mode='node', num_layers=2, dropout=0., act=F.relu,
                  ppmi=True, adv_dim=40, weight_decay=3e-3, lr=4e-3, epoch=300, device='cuda:0',
@@ -42,6 +47,30 @@ class UDAGCN(BaseGDA):
                 conv.cache_dict.pop(key, None)
         return key
 
+    def _domain_loss(self, net, encoded_source, encoded_target, alpha, ns, nt):
+        """``CE(domain_model(GRL(source)), 0) + CE(domain_model(GRL(target)), 1)`` (udagcn.py:176-190): on the GPU one
+        fused row kernel and one fold each way (ops.grl_mlp_ce) for the discriminator the reference builds
+        (Linear - ReLU - Dropout - Linear(., 2), udagcn_base.py:157-162); anything else, and the CPU, composes it."""
+        dm, gm = net.domain_model, self._gmean
+        from ..distributed import active
+        from ..ops import grl_mlp_ce, grl_mlp_ce_ok
+        if (FUSED_DOMAIN_MODEL and len(dm) == 4 and isinstance(dm[0], torch.nn.Linear) and isinstance(dm[1], torch.nn.ReLU)
+                and isinstance(dm[2], torch.nn.Dropout) and isinstance(dm[3], torch.nn.Linear)
+                and grl_mlp_ce_ok(encoded_source, dm[0].weight, dm[3].weight)):
+            p = dm[2].p if dm.training else 0.0
+            args = (encoded_source, encoded_target, dm[0].weight, dm[0].bias, dm[3].weight, dm[3].bias, alpha, p)
+            if active() and not getattr(self.source_loader, "full_batch", False):     # node-count weighted means
+                ls, lt = grl_mlp_ce(*args, pair=True)
+                return gm(ls, ns) + gm(lt, nt)
+            return grl_mlp_ce(*args)
+        dev = encoded_source.device
+        source_domain_preds = dm(GradReverse.apply(encoded_source, alpha))
+        target_domain_preds = dm(GradReverse.apply(encoded_target, alpha))
+        return gm(net.loss_func(source_domain_preds,
+                                torch.zeros(source_domain_preds.size(0), dtype=torch.long, device=dev)), ns) \
+            + gm(net.loss_func(target_domain_preds,
+                               torch.ones(target_domain_preds.size(0), dtype=torch.long, device=dev)), nt)
+
     def forward_model(self, source_data, target_data, alpha, epoch):
         net = self.udagcn
         encoded_source = net.encode(source_data, self._cache_key(source_data, "source"))
@@ -51,12 +80,7 @@ class UDAGCN(BaseGDA):
         ns, nt = encoded_source.size(0), encoded_target.size(0)
         loss = gm(net.loss_func(source_logits, source_data.y), ns)                           # :172
         dev = encoded_source.device
-        source_domain_preds = net.domain_model(GradReverse.apply(encoded_source, alpha))
-        target_domain_preds = net.domain_model(GradReverse.apply(encoded_target, alpha))
-        loss = loss + gm(net.loss_func(source_domain_preds,
-                                       torch.zeros(source_domain_preds.size(0), dtype=torch.long, device=dev)), ns) \
-                    + gm(net.loss_func(target_domain_preds,
-                                       torch.ones(target_domain_preds.size(0), dtype=torch.long, device=dev)), nt)
+        loss = loss + self._domain_loss(net, encoded_source, encoded_target, alpha, ns, nt)   # :176-190
         target_logits = net.cls_model(encoded_target)
         target_probs = torch.clamp(F.softmax(target_logits, dim=-1), min=1e-9, max=1.0)
         loss_entropy = gm(torch.mean(torch.sum(-target_probs * torch.log(target_probs), dim=-1)), nt)  # :193-197

@@ -642,6 +642,90 @@ def grl_disc_ce(source_feat, target_feat, weight, bias, alpha, labels=None):
     return _GrlDiscCE.apply(source_feat, target_feat, weight, bias, alpha, labels)
 
 
+# ------------------------------ GRL + two-layer discriminator + per-domain CE (fused) --
+def _grl_mlp_fwd(ctx, es, et, W1, b1, W2, b2, alpha, p):
+    es, et = _f32c(es, "source_feat"), _f32c(et, "target_feat")
+    W1, b1, W2, b2 = _f32c(W1, "W1"), _f32c(b1, "b1"), _f32c(W2, "W2"), _f32c(b2, "b2")
+    ns, nt, h, a = es.size(0), et.size(0), es.size(1), W1.size(0)
+    dev = es.device
+    st = dropout_state
+    if st.seed is None:
+        st.seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+    site = st.next_site()
+    st.next_site()                                   # two call sites: source rows, target rows
+    losses = torch.empty(3, dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    ws = _lib.workspace(L.gda_grl_mlp_ce_workspace_bytes(h, a), dev, "disc_mlp")
+    _lib.check(L.gda_grl_mlp_ce_fwd_f32(
+        _lib.ptr(es), h, ns, _lib.ptr(et), h, nt, h, a, _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
+        float(p), ctypes.c_uint64(st.seed), _lib.ptr(st.counter(dev)), ctypes.c_uint32(site),
+        _lib.ptr(losses), _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_grl_mlp_ce_fwd_f32")
+    ctx.save_for_backward(es, et, W1, b1, W2, b2, alpha if torch.is_tensor(alpha) else None)
+    ctx.alpha = None if torch.is_tensor(alpha) else float(alpha)
+    ctx.p, ctx.seed, ctx.site = float(p), st.seed, site
+    return losses
+
+
+def _grl_mlp_bwd(ctx, g, stride):
+    es, et, W1, b1, W2, b2, alpha_dev = ctx.saved_tensors
+    ns, nt, h, a = es.size(0), et.size(0), es.size(1), W1.size(0)
+    dev = es.device
+    ges = torch.empty_like(es) if ctx.needs_input_grad[0] else None
+    get = torch.empty_like(et) if ctx.needs_input_grad[1] else None
+    gW1, gb1, gW2, gb2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2), torch.empty_like(b2)
+    if alpha_dev is not None:
+        alpha_dev = alpha_dev.detach().reshape(1).to(torch.float32)
+    L = _lib.lib()
+    ws = _lib.workspace(L.gda_grl_mlp_ce_workspace_bytes(h, a), dev, "disc_mlp")
+    _lib.check(L.gda_grl_mlp_ce_bwd_f32(
+        _lib.ptr(es), h, ns, _lib.ptr(et), h, nt, h, a, _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
+        ctx.p, ctypes.c_uint64(ctx.seed), _lib.ptr(dropout_state.counter(dev)), ctypes.c_uint32(ctx.site),
+        _lib.ptr(g), stride, 0.0 if ctx.alpha is None else ctx.alpha, _lib.ptr(alpha_dev),
+        _lib.ptr(ges), _lib.ptr(get), _lib.ptr(gW1), _lib.ptr(gb1), _lib.ptr(gW2), _lib.ptr(gb2),
+        _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_grl_mlp_ce_bwd_f32")
+    return ges, get, gW1, gb1, gW2, gb2, None, None
+
+
+class _GrlMlpCESum(torch.autograd.Function):
+    """The two domain means added, as the reference adds them: one scalar out, one scalar gradient in."""
+
+    @staticmethod
+    def forward(ctx, es, et, W1, b1, W2, b2, alpha, p):
+        return _grl_mlp_fwd(ctx, es, et, W1, b1, W2, b2, alpha, p)[2]
+
+    @staticmethod
+    def backward(ctx, g):
+        return _grl_mlp_bwd(ctx, g.reshape(1).to(torch.float32).contiguous(), 0)
+
+
+class _GrlMlpCEPair(torch.autograd.Function):
+    """The two domain means separately (data-parallel callers weight them by node counts)."""
+
+    @staticmethod
+    def forward(ctx, es, et, W1, b1, W2, b2, alpha, p):
+        losses = _grl_mlp_fwd(ctx, es, et, W1, b1, W2, b2, alpha, p)
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, g_s, g_t):
+        return _grl_mlp_bwd(ctx, torch.stack([g_s.reshape(()).to(torch.float32), g_t.reshape(()).to(torch.float32)]), 1)
+
+
+def grl_mlp_ce_ok(es, W1, W2):
+    """Shapes the fused two-layer discriminator covers (csrc/gda_disc_mlp.hip)."""
+    return (es.is_cuda and es.dtype == torch.float32 and es.dim() == 2 and es.size(1) <= 128
+            and W1.size(0) <= 64 and W2.size(0) == 2)
+
+
+def grl_mlp_ce(source_feat, target_feat, W1, b1, W2, b2, alpha, dropout_p=0.0, pair=False):
+    """``CE(D(GradReverse(source)), 0).mean() + CE(D(GradReverse(target)), 1).mean()`` (``pair``: the two means as a
+    tuple) for the two-layer discriminator ``D = Linear(h, a) - ReLU - Dropout(p) - Linear(a, 2)`` of UDAGCN
+    (udagcn.py:176-190, udagcn_base.py:157-162), fused: one row kernel and one fold each way (include/gda_hip.h:
+    gda_grl_mlp_ce_fwd_f32 / _bwd_f32).  ``alpha`` may be a 0-dim device tensor (captured steps)."""
+    fn = _GrlMlpCEPair if pair else _GrlMlpCESum
+    return fn.apply(source_feat, target_feat, W1, b1, W2, b2, alpha, dropout_p)
+
+
 # ------------------------------------------- Wasserstein critic update (WGAN-GP), fused --
 def wgan_critic_grads(es, et, idx_s, idx_t, alpha, W1, b1, W2, b2, dropout_p, gp_weight, out):
     """Loss and parameter gradients of one critic update of AdaGCN (pygda/models/adagcn.py:169-183,387-454)

@@ -59,15 +59,17 @@ class NeighborSampler:
     def sample_batch(self, data, seeds, fanouts, seed=0):
         """A ``Data`` batch like PyG's: ``x``/``y`` sliced to the sampled nodes (seeds are the
         first ``batch_size`` rows), local ``edge_index``, ``n_id``, ``batch_size``."""
-        if data.x.device.type == "cuda":
-            return self.assemble_packed(data, seeds, self.sample_packed(seeds, fanouts, seed, csr=self.emit_csr(data)))
-        return self.assemble(data, seeds, *self.sample(seeds, fanouts, seed))
+        return self.assemble(data, seeds, *self.sample(seeds, fanouts, seed, csr=self.emit_csr(data)))
 
     @staticmethod
     def emit_csr(data):
-        """The host-built CSR rides along for batches assembled on the GPU (``PYGDA_AMD_SAMPLER_CSR=0``: off)."""
+        """``PYGDA_AMD_SAMPLER_CSR=1``: the batch's normalised CSR pair is built by the sampler (gda_sampler_csr_norm)
+        and rides along instead of being re-derived by the device ingestion.  Off by default: measured at cfg-S
+        (5 M nodes per domain, fan-out [15, 10], ~160 k-node batches) the device sorts it saves cost 0.5 ms per step,
+        the 6 MB of extra host-to-device traffic per batch more than that (8.6 -> 9.4 ms per step; shipping ids,
+        edges and CSR as one pinned block on a copy stream from the producer thread: 11.2 -> 13.4 ms)."""
         import os
-        return data.x.device.type == "cuda" and os.environ.get("PYGDA_AMD_SAMPLER_CSR", "1") == "1"
+        return data.x.device.type == "cuda" and os.environ.get("PYGDA_AMD_SAMPLER_CSR", "0") == "1"
 
     @staticmethod
     def _csr_offsets(n, e):
@@ -77,116 +79,33 @@ class NeighborSampler:
         rp, cap = r4(n + 1), r4(n + e)
         return [0, rp, 2 * rp, 2 * rp + cap, 2 * rp + 2 * cap, 2 * rp + 3 * cap, 2 * rp + 4 * cap]
 
-    # -- one pinned block per batch: ids, edges and the CSR cross PCIe in ONE asynchronous copy --------------
-    def _pinned(self, nbytes):
-        """A free pinned byte block of at least ``nbytes`` from this sampler's ring (blocks are recycled once the
-        copy that read them has completed; a pageable source would make every ``.to(device)`` a blocking staged
-        copy in the training thread: measured 3 ms per cfg-S step)."""
-        import threading
-        if not hasattr(self, "_ring"):
-            self._ring, self._ring_lock = [], threading.Lock()
-        with self._ring_lock:
-            for ent in self._ring:
-                if not ent["busy"] and ent["buf"].numel() >= nbytes and (ent["event"] is None or ent["event"].query()):
-                    ent["busy"] = True
-                    return ent
-            ent = dict(buf=torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory(), event=None, busy=True)
-            self._ring.append(ent)
-            if len(self._ring) > 16:              # sizes drifted upwards: drop the smallest idle block
-                idle = [x for x in self._ring if not x["busy"] and (x["event"] is None or x["event"].query())]
-                if idle:
-                    self._ring.remove(min(idle, key=lambda x: x["buf"].numel()))
-            return ent
-
-    def sample_packed(self, seeds, fanouts, seed=0, csr=True, device=None):
-        """Sample a batch straight into one pinned block: ``[n_id int64 | esrc int64 | edst int64 | CSR block]``
-        (the CSR part as in :meth:`sample`).  Runs on the loader's producer thread; with ``device`` the block is
-        shipped from there as well, on this sampler's copy stream -- the copy (9 MB per cfg-S batch) then runs
-        beside the previous step's kernels instead of in front of this step's on the training stream."""
-        seeds = np.ascontiguousarray(torch.as_tensor(seeds).cpu().numpy(), dtype=np.int64)
-        fan = np.ascontiguousarray(np.asarray(fanouts, dtype=np.int32))
-        nn_, ne_ = ctypes.c_int64(), ctypes.c_int64()
-        L = _lib.lib()
-        _lib.check(L.gda_sampler_sample(self._h, seeds.ctypes.data, seeds.size, fan.ctypes.data, fan.size,
-                                        ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), ctypes.byref(nn_),
-                                        ctypes.byref(ne_)), "gda_sampler_sample")
-        n, e = nn_.value, ne_.value
-        r16 = lambda v: (v + 15) // 16 * 16
-        o_nodes, o_edges = 0, r16(8 * n)
-        o_csr = o_edges + r16(16 * e)
-        co = self._csr_offsets(n, e)
-        total = o_csr + (4 * co[6] if csr else 0)
-        ent = self._pinned(max(total, 16))
-        base = ent["buf"].data_ptr()
-        _lib.check(L.gda_sampler_fetch(self._h, base + o_nodes, base + o_edges if e else None,
-                                       base + o_edges + 8 * e if e else None), "gda_sampler_fetch")
-        if csr:
-            at = lambda k: base + o_csr + 4 * co[k]
-            _lib.check(L.gda_sampler_csr_norm(self._h, at(0), at(2), at(4), at(1), at(3), at(5)), "gda_sampler_csr_norm")
-            nnz = int(ent["buf"][o_csr + 4 * n:o_csr + 4 * n + 4].view(torch.int32)[0])     # rowptr[n]
-        else:
-            nnz = None
-        pk = dict(ent=ent, n=n, e=e, total=total, o_nodes=o_nodes, o_edges=o_edges, o_csr=o_csr, csr=csr, nnz=nnz)
-        if device is not None:
-            self._ship(pk, torch.device(device))
-        return pk
-
-    def _ship(self, pk, dev):
-        """The one H2D copy of a packed batch, on the copy stream of the calling (producer) thread."""
-        if getattr(self, "_copy_stream", None) is None:
-            torch.cuda.set_device(dev)
-            self._copy_stream = torch.cuda.Stream(device=dev)
-        ent = pk["ent"]
-        with torch.cuda.stream(self._copy_stream):
-            pk["dev"] = ent["buf"][:max(pk["total"], 16)].to(dev, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-        pk["ready"] = ev
-        with self._ring_lock:
-            ent["event"], ent["busy"] = ev, False
-
-    def assemble_packed(self, data, seeds, pk):
-        """Device side of a packed batch: ONE asynchronous copy of the pinned block, typed views of its device
-        image, feature rows by the gather kernel."""
+    @classmethod
+    def _graph_from_block(cls, block, n, e, dev):
+        """``CSRGraph`` views of the device copy of a gda_sampler_csr_norm block (one H2D copy)."""
         from .graph import CSRGraph
-        from .ops import gather_rows
-        dev = data.x.device
-        ent, n, e = pk["ent"], pk["n"], pk["e"]
-        if "dev" in pk:                       # shipped by the producer on its copy stream
-            b = pk["dev"]
-            torch.cuda.current_stream().wait_event(pk["ready"])
-            b.record_stream(torch.cuda.current_stream())
-        else:
-            b = ent["buf"][:max(pk["total"], 16)].to(dev, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            with self._ring_lock:
-                ent["event"], ent["busy"] = ev, False
-        n_dev = b[pk["o_nodes"]:pk["o_nodes"] + 8 * n].view(torch.int64)
-        ei = b[pk["o_edges"]:pk["o_edges"] + 16 * e].view(torch.int64).view(2, e)
-        ei._gda_trusted = True                # relabelled ids are in range by construction: no validation sync
-        if pk["csr"]:                         # gcn_norm(edge_index) of this batch, ready made (graph.as_graph)
-            co, cap = self._csr_offsets(n, e), n + e
-            sizes = [n + 1, n + 1, cap, cap, cap, cap]
-            w = b[pk["o_csr"]:].view(torch.int32)
-            part = lambda k: w[co[k]:co[k] + max(sizes[k], 1)]
-            g = CSRGraph(n, cap, part(0), part(2), part(4).view(torch.float32), part(1), part(3), part(5).view(torch.float32))
-            g._nnz, g.transient = pk["nnz"], True
-            ei._gda_prebuilt = g
-        x = gather_rows(data.x, n_dev)
-        y = None if data.y is None else data.y[n_dev]
-        return Data(x=x, edge_index=ei, y=y, n_id=n_dev, batch_size=int(torch.as_tensor(seeds).numel()))
+        cap = n + e
+        b = block.to(dev, non_blocking=True)
+        o = cls._csr_offsets(n, e)
+        sizes = [n + 1, n + 1, cap, cap, cap, cap]
+        part = lambda k: b[o[k]:o[k] + max(sizes[k], 1)]
+        g = CSRGraph(n, cap, part(0), part(2), part(4).view(torch.float32), part(1), part(3), part(5).view(torch.float32))
+        g._nnz = int(block[n])                 # rowptr[n] on the host copy: no device read-back
+        g.transient = True
+        return g
 
-    def assemble(self, data, seeds, n_id, ei):
-        """A batch from host tensors (CPU data; or device data without the packed path)."""
+    def assemble(self, data, seeds, n_id, ei, csr_block=None):
+        """Device side of a batch: feature rows by the gather kernel, labels, ids."""
         dev = data.x.device
         if dev.type == "cuda":
             from .ops import gather_rows
             n_dev = n_id.to(dev, non_blocking=True)
             x = gather_rows(data.x, n_dev)
             y = None if data.y is None else data.y[n_dev]
+            n_edges = int(ei.size(1))
             ei = ei.to(dev, non_blocking=True)
             ei._gda_trusted = True            # relabelled ids are in range by construction: no validation sync
+            if csr_block is not None:         # gcn_norm(edge_index) of this batch, ready made (graph.as_graph)
+                ei._gda_prebuilt = self._graph_from_block(csr_block, int(n_id.numel()), n_edges, dev)
             return Data(x=x, edge_index=ei, y=y, n_id=n_dev,
                         batch_size=int(torch.as_tensor(seeds).numel()))
         return Data(x=data.x[n_id], edge_index=ei, y=None if data.y is None else data.y[n_id], n_id=n_id,

@@ -450,3 +450,73 @@ def test_adagcn_fused_critic_trajectory_equals_composed(monkeypatch):
     for a, b in zip(f_disc, c_disc):
         close(a, b, rtol=1e-3, atol=1e-5)
     close([x[0] for x in f_seen], g["adagcn/losses"], rtol=REL)
+
+
+# ---------------------------------------------------------------- fused two-layer domain discriminator (UDAGCN) --
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns,nt,h,a,alpha_kind", [(700, 333, 128, 40, "float"), (5, 1200, 64, 16, "tensor"),
+                                                    (257, 0, 100, 48, "float"), (9360, 5484, 128, 40, "tensor")])
+def test_grl_mlp_ce_fused_vs_composed(ns, nt, h, a, alpha_kind):
+    """ops.grl_mlp_ce (csrc/gda_disc_mlp.hip) against the composition the reference runs (udagcn.py:176-190 on the
+    discriminator of udagcn_base.py:157-162, dropout off): both domain means, the input gradients behind the reversal
+    and all four parameter gradients, for a float and a device-tensor alpha, ragged sizes and an empty domain."""
+    from pygda_amd.nn import GradReverse
+    gen = torch.Generator().manual_seed(ns + 7 * nt + h)
+    es = torch.randn(ns, h, generator=gen).to(DEV).requires_grad_()
+    et = (torch.randn(nt, h, generator=gen) + 0.3).to(DEV).requires_grad_()
+    dm = torch.nn.Sequential(torch.nn.Linear(h, a), torch.nn.ReLU(), torch.nn.Dropout(0.0), torch.nn.Linear(a, 2)).to(DEV)
+    alpha = 0.37 if alpha_kind == "float" else torch.tensor(0.37, device=DEV)
+    for pair in (False, True):
+        for t in (es, et, *dm.parameters()):
+            t.grad = None
+        out = ops.grl_mlp_ce(es, et, dm[0].weight, dm[0].bias, dm[3].weight, dm[3].bias, alpha, 0.0, pair=pair)
+        got = (out[0] * 1.5 + out[1] * 0.5) if pair else out
+        got.backward()
+        g_got = [t.grad.clone() if t.grad is not None else None for t in (es, et, *dm.parameters())]
+        for t in (es, et, *dm.parameters()):
+            t.grad = None
+        ce = torch.nn.CrossEntropyLoss()
+        ls = ce(dm(GradReverse.apply(es, alpha)), torch.zeros(ns, dtype=torch.long, device=DEV)) if ns else torch.zeros((), device=DEV)
+        lt = ce(dm(GradReverse.apply(et, alpha)), torch.ones(nt, dtype=torch.long, device=DEV)) if nt else torch.zeros((), device=DEV)
+        want = (ls * 1.5 + lt * 0.5) if pair else ls + lt
+        want.backward()
+        close(got, want, rtol=1e-5, atol=1e-6)
+        if pair:
+            close(out[0], ls, rtol=1e-5, atol=1e-6)
+            close(out[1], lt, rtol=1e-5, atol=1e-6)
+        for g, t in zip(g_got, (es, et, *dm.parameters())):
+            if t.grad is None:                     # empty domain: the composition never touched it
+                assert g is None or float(g.abs().sum()) == 0.0
+            else:
+                close(g, t.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_grl_mlp_ce_dropout_masks_are_consistent():
+    """With dropout on, forward and backward regenerate the same keep-bits (nothing [rows, a] is stored): the analytic
+    directional derivative equals a central difference of the loss under the SAME step counter; another step draws
+    another mask; run to run the kernels are deterministic."""
+    gen = torch.Generator().manual_seed(3)
+    ns, nt, h, a, p = 900, 700, 128, 40, 0.1
+    es = torch.randn(ns, h, generator=gen).to(DEV).requires_grad_()
+    et = torch.randn(nt, h, generator=gen).to(DEV).requires_grad_()
+    dm = torch.nn.Sequential(torch.nn.Linear(h, a), torch.nn.ReLU(), torch.nn.Dropout(p), torch.nn.Linear(a, 2)).to(DEV).double().float()
+    par = (dm[0].weight, dm[0].bias, dm[3].weight, dm[3].bias)
+    st = ops.dropout_state
+
+    def loss_at(e_s, e_t):
+        st.site = 0                                    # same call sites -> same masks while the step counter stands
+        return ops.grl_mlp_ce(e_s, e_t, *par, -1.0, p)
+    st.next_step(torch.device(DEV))
+    l0 = loss_at(es, et)
+    l0.backward()
+    assert float(l0) == float(loss_at(es, et))         # deterministic, same mask
+    d_s, d_t = torch.randn(ns, h, generator=gen).to(DEV), torch.randn(nt, h, generator=gen).to(DEV)
+    eps = 1e-2
+    with torch.no_grad():
+        fd = (loss_at(es + eps * d_s, et + eps * d_t).double() - loss_at(es - eps * d_s, et - eps * d_t).double()) / (2 * eps)
+    # alpha = -1: the reversal hands the true gradient through
+    an = (es.grad.double() * d_s).sum() + (et.grad.double() * d_t).sum()
+    close(an, fd, rtol=2e-2, atol=1e-4)
+    st.next_step(torch.device(DEV))
+    assert float(loss_at(es, et)) != float(l0)         # a new step draws a new mask
