@@ -106,7 +106,7 @@ class _DPSamples:
 class GraphedStep:
     """Captures ``loss, logits = step_fn(src, tgt)``, ``backward`` and ``optimizer.step()``."""
 
-    def __init__(self, step_fn, optimizer, src, tgt, warmup=3, dp=False, extra_optimizers=()):
+    def __init__(self, step_fn, optimizer, src, tgt, warmup=3, dp=False, extra_optimizers=(), unroll=1):
         """``dp``: data-parallel step with the library-owned RCCL communicator -- the gradient
         all-reduce and the MMD row all-gather are enqueued on the capturing stream like any kernel,
         so the whole step is still ONE graph."""
@@ -116,6 +116,12 @@ class GraphedStep:
         self._dp_idx = {}                 # (ns, nt, times, per) -> (dev_s, dev_t, pin_s, pin_t)
         self._samples = {}                # (ns, nt, times, n) -> (dev_s, dev_t, pin_s, pin_t)
         self._order = []
+        # `unroll` consecutive steps in ONE capture (each with its own sample block): between the last kernel of a
+        # replay and the first of the next the device idles 40-50 us on this runtime whatever the host does
+        # (DESIGN 4.7); a replay of U steps pays that once.  A one-step graph of the same step serves the remainder.
+        self.unroll = max(1, int(unroll)) if (type(self) is GraphedStep and not dp) else 1
+        self._sub = 0                     # sub-step being issued (selects the sample block)
+        self._fills = {}                  # sub-step -> refill callables, in call order
         self.graph = None
         self.warmup = warmup
         self.loss = self.logits = None
@@ -138,7 +144,7 @@ class GraphedStep:
         """Static device buffers: the row samples and the selection CSRs of their scatter -- ONE
         device block and two pinned host blocks (double-buffered), so a refill is one H2D copy and
         the host may prepare step e+1 while the copy of step e is still in flight."""
-        key = (ns, nt, times, n)
+        key = (ns, nt, times, n, self._sub)
         if key not in self._samples:
             dev = self.src.x.device
             shapes = [((times, n), torch.int64), ((times, n), torch.int64), ((ns + 1,), torch.int32),
@@ -151,7 +157,9 @@ class GraphedStep:
             self._samples[key] = dict(dev=dev_block, devv=self._carve(dev_block, shapes), pin=pin_blocks,
                                       pinv=[self._carve(b, shapes) for b in pin_blocks],
                                       done=[None, None], turn=0, ones=ones)
-            self._order.append(lambda key=key: self._fill_one(key))
+            fill = lambda key=key: self._fill_one(key)      # noqa: E731
+            self._order.append(fill)
+            self._fills.setdefault(self._sub, []).append(fill)
             self._fill_one(key)
         e = self._samples[key]
         d = e["devv"]
@@ -159,7 +167,7 @@ class GraphedStep:
 
     def _fill_one(self, key):
         from .ops import selection_csr_host
-        ns, nt, times, n = key
+        ns, nt, times, n = key[:4]
         e = self._samples[key]
         k = e["turn"]
         e["turn"] = 1 - k
@@ -198,10 +206,19 @@ class GraphedStep:
         return slot.dev
 
     def _refill(self):
+        """The refills of ONE step: sub-step 0's sample blocks, every host_rand slot, the data-parallel blocks."""
+        later = {id(f) for u, fs in self._fills.items() if u > 0 for f in fs}
         for fill in self._order:
-            fill()
+            if id(fill) not in later:
+                fill()
         for e in self._dp_idx.values():
             e.fill()
+
+    def _refill_multi(self):
+        """The refills of `unroll` consecutive steps, in step order (the CPU generator's order in eager mode)."""
+        for u in range(self.unroll):
+            for fill in self._fills.get(u, ()):
+                fill()
 
     def _run(self, with_stats=False):
         from .ops import dropout_state
@@ -256,12 +273,31 @@ class GraphedStep:
                 for _ in range(self.warmup):       # allocator warm-up + first sample buffers
                     self._refill()
                     self._run()
+                if self.unroll > 1 and (self._rand_slots or self.extra_optimizers or not self._fills):
+                    self.unroll = 1                # host_rand call sites / critics: one step per capture
+                for u in range(1, self.unroll):    # the further sub-steps' sample blocks are created (and filled) eagerly
+                    self._sub = u
+                    self._run()
+                self._sub = 0
             torch.cuda.current_stream().wait_stream(side)
             self._refill()
-            self.graph = torch.cuda.CUDAGraph()
             # thread_local: API calls of other threads (RCCL's watchdog polls events) must not
             # invalidate the capture
             self._stat_stream = torch.cuda.Stream()
+            self.graph_multi = None
+            if self.unroll > 1:
+                self.graph_multi = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_multi, capture_error_mode="thread_local"):
+                    per_step = []
+                    for u in range(self.unroll):
+                        self._sub = u
+                        self._run(with_stats=True)
+                        per_step.append(self.stats)
+                    self.stats_multi = torch.stack(per_step)   # [unroll, 2]: ONE small D2H per replay
+                self._sub = 0
+                self._multi_pins = [torch.zeros(self.unroll, 2, dtype=torch.float64).pin_memory() for _ in range(2)]
+                self._multi_events, self._multi_turn = [None, None], 0
+            self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 loss, logits = self._run(with_stats=True)      # an epoch then needs ONE small D2H
             self.loss, self.logits = loss.detach(), logits.detach()
@@ -304,10 +340,31 @@ class GraphedStep:
 
     def result(self, ticket):
         """(loss, source accuracy) of the step behind ``ticket`` (at most one newer launch may exist)."""
+        if isinstance(ticket, tuple):
+            return self.result_multi(ticket)[0]
         self._stat_events[ticket].synchronize()
         loss, correct = self._stat_pins[ticket].tolist()
         n = self.src.y.numel()
         return loss, (correct / n if n else 0.0)
+
+    def launch_multi(self):
+        """`unroll` steps in one replay; returns a ticket for result_multi()."""
+        self._refill_multi()
+        self.graph_multi.replay()
+        k = self._multi_turn
+        self._multi_turn = 1 - k
+        self._multi_pins[k].copy_(self.stats_multi, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._multi_events[k] = ev
+        return ("multi", k)
+
+    def result_multi(self, ticket):
+        """[(loss, source accuracy)] * unroll of the replay behind ``ticket``, in step order."""
+        k = ticket[1]
+        self._multi_events[k].synchronize()
+        n = self.src.y.numel()
+        return [(loss, (correct / n if n else 0.0)) for loss, correct in self._multi_pins[k].tolist()]
 
 
 class GraphedStepSplit(GraphedStep):

@@ -200,6 +200,8 @@ class A2GNN(BaseGDA):
         # the MMD branch never reads alpha/epoch; the adversarial branch reads the GRL alpha, which the
         # captured step receives as a 0-dim device tensor refreshed per epoch: both replay as a hipGraph
         self._graph_safe_step, self._graph_uses_scalars = True, bool(self.adv)
+        # the MMD step reads no per-epoch scalar: consecutive steps may share one capture (hipgraph.GraphedStep.unroll)
+        self._graph_unroll_ok = not self.adv and type(self) is A2GNN
         on_gpu = torch.device(self.device).type == "cuda"
         if on_gpu:           # torch.optim.Adam's update in one multi-tensor launch (pygda_amd/optim.py)
             from ..optim import Adam

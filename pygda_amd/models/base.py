@@ -133,17 +133,34 @@ class BaseGDA(ABC):
             if self.epoch_hook is not None:
                 self.epoch_hook(epoch, loss, acc, secs)
 
-        pending = None
-        for epoch in epochs:
-            if alpha_fn is not None and getattr(self, "_graph_uses_scalars", False):
-                self._g_alpha.fill_(float(alpha_fn(epoch)))
-                self._g_epoch.fill_(float(epoch))
-            ticket = graphed.launch()
+        def report_group(group, ticket):
+            if isinstance(ticket, tuple):                  # several steps behind one replay (GraphedStep.unroll)
+                for epoch, (loss, acc) in zip(group, graphed.result_multi(ticket)):
+                    secs = time.time() - start
+                    logger(epoch=epoch, loss=loss, source_train_acc=acc, time=secs, verbose=self.verbose, train=True)
+                    if self.epoch_hook is not None:
+                        self.epoch_hook(epoch, loss, acc, secs)
+            else:
+                report(group[0], ticket)
+
+        scalars = alpha_fn is not None and getattr(self, "_graph_uses_scalars", False)
+        unroll = 1 if scalars or getattr(graphed, "graph_multi", None) is None else graphed.unroll
+        epochs = list(epochs)
+        pending, i = None, 0
+        while i < len(epochs):
+            if unroll > 1 and len(epochs) - i >= unroll:
+                group, ticket = epochs[i:i + unroll], graphed.launch_multi()
+            else:
+                if scalars:
+                    self._g_alpha.fill_(float(alpha_fn(epochs[i])))
+                    self._g_epoch.fill_(float(epochs[i]))
+                group, ticket = epochs[i:i + 1], graphed.launch()
+            i += len(group)
             if pending is not None:
-                report(*pending)
-            pending = (epoch, ticket)
+                report_group(*pending)
+            pending = (group, ticket)
         if pending is not None:
-            report(*pending)
+            report_group(*pending)
 
     def _maybe_graphed_step(self, optimizer, step_fn, before_step, net):
         """A captured step when asked for and legal: one full-batch pair, single process, and a
@@ -209,8 +226,10 @@ class BaseGDA(ABC):
                     from ..hipgraph import GraphedStepSplit
                     graphed = GraphedStepSplit(split, self._g_alpha, scalar_step, optimizer, src, tgt).capture()
                 else:
+                    unroll = int(os.environ.get("PYGDA_AMD_GRAPH_UNROLL", "2")) if getattr(self, "_graph_unroll_ok", False) else 1
                     graphed = GraphedStep(scalar_step, optimizer, src, tgt,
-                                          extra_optimizers=getattr(self, "_graph_extra_optimizers", ())).capture()
+                                          extra_optimizers=getattr(self, "_graph_extra_optimizers", ()),
+                                          unroll=unroll).capture()
         except Exception as exc:       # anything a custom activation / exotic configuration may do under capture
             if self.use_hip_graph:     # explicitly requested: do not hide the failure
                 raise

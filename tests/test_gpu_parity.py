@@ -617,10 +617,13 @@ def test_sparse_input_projection_matches_dense():
 
 
 # ---------------------------------------------------------------- hipGraph capture --
-def test_hipgraph_step_matches_eager_trajectory():
+@pytest.mark.parametrize("unroll", [1, 2, 3])
+def test_hipgraph_step_matches_eager_trajectory(monkeypatch, unroll):
     """The captured step (forward + backward + Adam in one hipGraph) replays the same training
     trajectory as eager mode and as the reference: per-epoch losses and final logits against
-    the 3-epoch golden, warm-up steps rolled back."""
+    the 3-epoch golden, warm-up steps rolled back -- one step per capture, two steps per capture plus the one-step
+    graph for the remainder, and all three epochs in one replay."""
+    monkeypatch.setenv("PYGDA_AMD_GRAPH_UNROLL", str(unroll))
     g = load_golden("a2gnn_fit3_mmd")
     s, t = _pair(g)
     m = pygda_amd.models.A2GNN(24, 16, 5, num_layers=2, dropout=0.0, s_pnums=0, t_pnums=10, adv=False,
@@ -631,6 +634,7 @@ def test_hipgraph_step_matches_eager_trajectory():
     torch.manual_seed(int(g["seed"]))
     m.fit(s, t)
     assert getattr(m, "_graphed", None) is not None, "step was not captured"
+    assert m._graphed.unroll == unroll and (m._graphed.graph_multi is not None) == (unroll > 1)
     close([x[0] for x in seen], g["losses"], rtol=REL)
     close([x[1] for x in seen], g["accs"], rtol=0, atol=1e-12)
     logits, _ = m.predict(t)
