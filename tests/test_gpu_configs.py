@@ -511,12 +511,15 @@ def test_grl_mlp_ce_dropout_masks_are_consistent():
     l0 = loss_at(es, et)
     l0.backward()
     assert float(l0) == float(loss_at(es, et))         # deterministic, same mask
-    d_s, d_t = torch.randn(ns, h, generator=gen).to(DEV), torch.randn(nt, h, generator=gen).to(DEV)
-    eps = 1e-2
+    # move along the analytic gradient itself, at most 0.02 per element: the loss changes by ~|g|^2 * scale (far above
+    # fp32 noise), hardly any hidden unit crosses its ReLU kink, and the prediction is the squared gradient norm
+    gs, gt = es.grad.double(), et.grad.double()
+    scale = 0.02 / float(torch.maximum(gs.abs().max(), gt.abs().max()))
+    d_s, d_t = (gs * scale).float(), (gt * scale).float()
     with torch.no_grad():
-        fd = (loss_at(es + eps * d_s, et + eps * d_t).double() - loss_at(es - eps * d_s, et - eps * d_t).double()) / (2 * eps)
+        fd = (loss_at(es + d_s, et + d_t).double() - loss_at(es - d_s, et - d_t).double()) / 2
     # alpha = -1: the reversal hands the true gradient through
-    an = (es.grad.double() * d_s).sum() + (et.grad.double() * d_t).sum()
-    close(an, fd, rtol=2e-2, atol=1e-4)
+    an = ((gs * gs).sum() + (gt * gt).sum()) * scale
+    close(an, fd, rtol=2e-2, atol=0)
     st.next_step(torch.device(DEV))
     assert float(loss_at(es, et)) != float(l0)         # a new step draws a new mask
