@@ -327,6 +327,23 @@ int gda_grl_mlp_ce_bwd_f32(const float* es, int64_t ld_s, int64_t n_s, const flo
                            void* workspace, size_t workspace_bytes, gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
+ * DANE's LSGAN discriminator head (csrc/gda_disc_mlp.hip).  Replaces what follows the first layer of
+ * domain_discriminator = Linear(h, h) - ReLU - Linear(h, 1) (pygda/models/dane.py:241-247) in the LSGAN terms
+ * `(pre ** 2).mean()` / `((pre - 1) ** 2).mean()` (dane.py:339-350, 468-470) and their autograd graph, on
+ * Z = x W1^T + b1 ([rows, a] fp32, the first layer: a GEMM, gda_gemm_ex_f32):
+ *   forward : pre[r] = sum_k relu(Z[r,k]) w2[k] + b2,  loss[0] = mean_r (pre[r] - target)^2
+ *   backward: gZ[r,k] = 2 (pre[r] - target) / rows * grad_loss[0] * w2[k] * [Z[r,k] > 0],  gw2 [a], gb2 [1]
+ * (gW1, gb1 and the input gradient follow from gZ by gda_gemm_ex_f32).  a <= 256; fixed-order sums.
+ * ---------------------------------------------------------------------------- */
+size_t gda_lsgan_head_workspace_bytes(int64_t a);
+int gda_lsgan_head_fwd_f32(const float* Z, int64_t ldz, int64_t rows, int64_t a, const float* w2, const float* b2,
+                           float target, float* pre, float* loss, void* workspace, size_t workspace_bytes,
+                           gda_stream_t stream);
+int gda_lsgan_head_bwd_f32(const float* Z, int64_t ldz, int64_t rows, int64_t a, const float* w2, const float* pre,
+                           float target, const float* grad_loss, float* gZ, int64_t ldg, float* gw2, float* gb2,
+                           void* workspace, size_t workspace_bytes, gda_stream_t stream);
+
+/* ------------------------------------------------------------------------------
  * Wasserstein critic update with gradient penalty (WGAN-GP), loss and parameter gradients in closed form
  * (csrc/gda_critic.hip).  Replaces the body of AdaGCN's critic loop, pygda/models/adagcn.py:169-183 with
  * gradient_penalty (:387-454), for the critic built at :264-270:

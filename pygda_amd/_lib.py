@@ -47,6 +47,10 @@ _SIGNATURES = {
                                    _P, c_size_t, _P]),
     "gda_grl_disc_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "gda_grl_mlp_ce_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "gda_lsgan_head_workspace_bytes": (c_size_t, [c_int64]),
+    "gda_lsgan_head_fwd_f32": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_float, _P, _P, _P, c_size_t, _P]),
+    "gda_lsgan_head_bwd_f32": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, c_float, _P, _P, c_int64, _P, _P,
+                                       _P, c_size_t, _P]),
     "gda_grl_mlp_ce_fwd_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P,
                                        c_float, ctypes.c_uint64, _P, ctypes.c_uint32, _P, _P, c_size_t, _P]),
     "gda_grl_mlp_ce_bwd_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P,

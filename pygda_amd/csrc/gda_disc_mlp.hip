@@ -393,3 +393,156 @@ extern "C" int gda_grl_mlp_ce_bwd_f32(const float* es, int64_t ld_s, int64_t n_s
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// DANE's LSGAN discriminator head (pygda/models/dane.py:339-350,468-470: Linear(h, h) - ReLU - Linear(h, 1) on 8 x
+// sample_size sampled rows per domain, loss mean((D(x) - target)^2)).  The first layer is a [rows, h] x [h, h]
+// product -- GEMM-sized, it runs on the matrix-core kernels (csrc/gda_gemm.hip, bias in the epilogue); this is what
+// follows it, one pass each way over Z = x W1^T + b1 ([rows, a] fp32, HBM-bound: forward reads Z once, backward
+// reads Z and writes gZ):
+//   forward : pre[r] = sum_k relu(Z[r,k]) w2[k] + b2 ;  loss = mean_r (pre[r] - target)^2
+//   backward: dpre = 2 (pre - target) / rows * g ;  gZ[r,k] = dpre w2[k] [Z[r,k] > 0] ;  gw2[k] = sum_r dpre relu(Z[r,k]) ;
+//             gb2 = sum_r dpre          (fixed-order sums; gW1, gb1, gx follow from gZ by GEMMs)
+// One wavefront per row, lane l owns units l, l + 64, ... (a <= 256).
+namespace {
+
+constexpr int LS_UC = 4;             // units per lane
+constexpr int LS_BLOCKS = 256;
+
+__global__ void __launch_bounds__(TB)
+k_lsgan_fwd(const float* __restrict__ Z, int64_t ldz, int64_t rows, int a, const float* __restrict__ w2,
+            const float* __restrict__ b2, float target, float* __restrict__ pre, double* __restrict__ part) {
+    const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    float w[LS_UC];
+#pragma unroll
+    for (int c = 0; c < LS_UC; ++c) { const int k = c * 64 + lane; w[c] = k < a ? w2[k] : 0.f; }
+    const float bias = b2[0];
+    double acc = 0.0;
+    for (int64_t r = (int64_t)blockIdx.x * WAVES + wave; r < rows; r += (int64_t)gridDim.x * WAVES) {
+        const float* z = Z + r * ldz;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < LS_UC; ++c) { const int k = c * 64 + lane; if (k < a) s = fmaf(fmaxf(z[k], 0.f), w[c], s); }
+        const float p = wave_sum(s) + bias;
+        if (lane == 0) pre[r] = p;
+        acc += (double)((p - target) * (p - target));
+    }
+    __shared__ double red[WAVES];
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { double v = 0.0; for (int k = 0; k < WAVES; ++k) v += red[k]; part[blockIdx.x] = v; }
+}
+
+__global__ void k_lsgan_fwd_final(const double* __restrict__ part, int blocks, int64_t rows, float* __restrict__ loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < blocks; ++b) s += part[b];
+        loss[0] = (float)(s / (double)rows);
+    }
+}
+
+// pw2 [blocks][a], pb2 [blocks]
+__global__ void __launch_bounds__(TB)
+k_lsgan_bwd(const float* __restrict__ Z, int64_t ldz, int64_t rows, int a, const float* __restrict__ w2,
+            const float* __restrict__ pre, float target, const float* __restrict__ grad, float* __restrict__ gZ, int64_t ldg,
+            float* __restrict__ pw2, float* __restrict__ pb2) {
+    const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    float w[LS_UC], gw[LS_UC];
+#pragma unroll
+    for (int c = 0; c < LS_UC; ++c) { const int k = c * 64 + lane; w[c] = k < a ? w2[k] : 0.f; gw[c] = 0.f; }
+    const float sc = 2.f * grad[0] / (float)rows;
+    float gb = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * WAVES + wave; r < rows; r += (int64_t)gridDim.x * WAVES) {
+        const float* z = Z + r * ldz;
+        float* g = gZ + r * ldg;
+        const float dp = (pre[r] - target) * sc;
+        gb += dp;
+#pragma unroll
+        for (int c = 0; c < LS_UC; ++c) {
+            const int k = c * 64 + lane;
+            if (k < a) {
+                const float zv = z[k];
+                g[k] = zv > 0.f ? dp * w[c] : 0.f;
+                gw[c] = fmaf(dp, fmaxf(zv, 0.f), gw[c]);
+            }
+        }
+    }
+    __shared__ float sh[WAVES][64 * LS_UC + 1];
+#pragma unroll
+    for (int c = 0; c < LS_UC; ++c) sh[wave][c * 64 + lane] = gw[c];
+    if (lane == 0) sh[wave][64 * LS_UC] = gb;
+    __syncthreads();
+    for (int k = threadIdx.x; k < a; k += TB) {
+        float v = 0.f;
+        for (int q = 0; q < WAVES; ++q) v += sh[q][k];
+        pw2[(int64_t)blockIdx.x * a + k] = v;
+    }
+    if (threadIdx.x == 0) { float v = 0.f; for (int q = 0; q < WAVES; ++q) v += sh[q][64 * LS_UC]; pb2[blockIdx.x] = v; }
+}
+
+int ls_blocks(int64_t rows) {
+    int64_t nb = gda_cdiv(rows, (int64_t)WAVES * 8);
+    if (nb < 1) nb = 1;
+    if (nb > LS_BLOCKS) nb = LS_BLOCKS;
+    return (int)nb;
+}
+
+struct LsWs { double* part; float* pw2; float* pb2; size_t total; };
+
+LsWs ls_carve(void* base, int64_t a) {
+    LsWs w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void* p = base ? (void*)((char*)base + off) : nullptr;
+        off += gda_align_up(bytes, 256);
+        return p;
+    };
+    w.part = (double*)take(sizeof(double) * LS_BLOCKS);
+    w.pw2 = (float*)take(sizeof(float) * LS_BLOCKS * (a > 0 ? a : 1));
+    w.pb2 = (float*)take(sizeof(float) * LS_BLOCKS);
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t gda_lsgan_head_workspace_bytes(int64_t a) {
+    if (a <= 0) return 0;
+    return ls_carve(nullptr, a).total;
+}
+
+extern "C" int gda_lsgan_head_fwd_f32(const float* Z, int64_t ldz, int64_t rows, int64_t a, const float* w2, const float* b2,
+                                      float target, float* pre, float* loss, void* workspace, size_t workspace_bytes,
+                                      gda_stream_t stream_) {
+    if (rows <= 0 || a <= 0 || ldz < a) return GDA_E_SIZE;
+    if (a > 64 * LS_UC) return GDA_E_UNSUPPORTED;
+    if (!Z || !w2 || !b2 || !pre || !loss || !workspace) return GDA_E_NULL;
+    LsWs ws = ls_carve(workspace, a);
+    if (workspace_bytes < ws.total) return GDA_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nb = ls_blocks(rows);
+    k_lsgan_fwd<<<nb, TB, 0, stream>>>(Z, ldz, rows, (int)a, w2, b2, target, pre, ws.part);
+    GDA_LAUNCH_CHECK();
+    k_lsgan_fwd_final<<<1, 64, 0, stream>>>(ws.part, nb, rows, loss);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+extern "C" int gda_lsgan_head_bwd_f32(const float* Z, int64_t ldz, int64_t rows, int64_t a, const float* w2, const float* pre,
+                                      float target, const float* grad_loss, float* gZ, int64_t ldg, float* gw2, float* gb2,
+                                      void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    if (rows <= 0 || a <= 0 || ldz < a || ldg < a) return GDA_E_SIZE;
+    if (a > 64 * LS_UC) return GDA_E_UNSUPPORTED;
+    if (!Z || !w2 || !pre || !grad_loss || !gZ || !gw2 || !gb2 || !workspace) return GDA_E_NULL;
+    LsWs ws = ls_carve(workspace, a);
+    if (workspace_bytes < ws.total) return GDA_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nb = ls_blocks(rows);
+    k_lsgan_bwd<<<nb, TB, 0, stream>>>(Z, ldz, rows, (int)a, w2, pre, target, grad_loss, gZ, ldg, ws.pw2, ws.pb2);
+    GDA_LAUNCH_CHECK();
+    const Fold4 F{{ws.pw2, ws.pb2, nullptr, nullptr}, {gw2, gb2, nullptr, nullptr}, {a, 1, 0, 0}};
+    k_fold4<<<(unsigned)gda_cdiv(a + 1, 256), 256, 0, stream>>>(F, nb);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}

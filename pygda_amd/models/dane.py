@@ -17,6 +17,11 @@ from ..nn import GNNBase
 from .base import BaseGDA
 
 
+import os
+
+FUSED_LSGAN = os.environ.get("PYGDA_AMD_FUSED_LSGAN", "1") == "1"
+
+
 class DANE(BaseGDA):
     def __init__(self, in_dim, hid_dim, num_classes, num_layers, mode='node', dropout=0., gnn='gcn', k=5,
                  train_mode='unsup', tgt_rate=0.05, act=F.relu, weight_decay=1e-5, lr=0.001, epoch=200,
@@ -42,6 +47,23 @@ class DANE(BaseGDA):
         i_t = self._draw(et.shape[0], 8 * self.sample_size, True)
         return self.domain_discriminator(es[i_s]), self.domain_discriminator(et[i_t])
 
+    def _lsgan_loss(self, es, et, target_s, target_t):
+        """``((D(es[i_s]) - target_s) ** 2).mean() + ((D(et[i_t]) - target_t) ** 2).mean()`` over 8 x sample_size
+        sampled rows per domain (:339-350 with targets (0, 1), :468-470 with (1, 0)); the draws are the reference's.
+        On the GPU the discriminator the trainer builds (Linear - ReLU - Linear(., 1)) runs as one GEMM plus the fused
+        LSGAN head per domain (ops.lsgan_head); anything else composes it."""
+        i_s = self._draw(es.shape[0], 8 * self.sample_size, True)
+        i_t = self._draw(et.shape[0], 8 * self.sample_size, True)
+        xs, xt = es[i_s], et[i_t]
+        D = self.domain_discriminator
+        from ..ops import lsgan_head, lsgan_head_ok
+        if (FUSED_LSGAN and len(D) == 3 and isinstance(D[0], nn.Linear) and isinstance(D[1], nn.ReLU)
+                and isinstance(D[2], nn.Linear) and lsgan_head_ok(xs, D[0].weight, D[2].weight)
+                and lsgan_head_ok(xt, D[0].weight, D[2].weight)):
+            par = (D[0].weight, D[0].bias, D[2].weight, D[2].bias)
+            return lsgan_head(xs, *par, target_s) + lsgan_head(xt, *par, target_t)
+        return ((D(xs) - target_s) ** 2).mean() + ((D(xt) - target_t) ** 2).mean()
+
     def forward_model(self, source_data, target_data):
         for _ in range(5):
             discriminator_loss = self.train_d(source_data, target_data)
@@ -55,9 +77,8 @@ class DANE(BaseGDA):
         with torch.no_grad():
             es = self.gnn.feat_bottleneck(source_data.x, source_data.edge_index)
             et = self.gnn.feat_bottleneck(target_data.x, target_data.edge_index)
-        pre_s, pre_t = self._lsgan_rows(es, et)
         self.d_optimizer.zero_grad()
-        loss = (pre_s ** 2).mean() + ((pre_t - 1) ** 2).mean()
+        loss = self._lsgan_loss(es, et, 0.0, 1.0)
         loss.backward()
         self.d_optimizer.step()
         return loss.item()
@@ -92,8 +113,7 @@ class DANE(BaseGDA):
         out_s = self.gnn.feat_classifier(es, source_data.edge_index)
         et = self.gnn.feat_bottleneck(target_data.x, target_data.edge_index)
         out_t = self.gnn.feat_classifier(et, target_data.edge_index)
-        pre_s, pre_t = self._lsgan_rows(es, et)
-        l_adv = (pre_t ** 2).mean() + ((pre_s - 1) ** 2).mean()
+        l_adv = self._lsgan_loss(es, et, 1.0, 0.0)
         edges_s, edges_t = self._pick_edges(source_data), self._pick_edges(target_data)   # draw order of :480-487
         l_gcn = self.L_GCN(es, *edges_s, self.k) + self.L_GCN(et, *edges_t, self.k)
         l_ce = F.cross_entropy(out_s, source_data.y)

@@ -726,6 +726,59 @@ def grl_mlp_ce(source_feat, target_feat, W1, b1, W2, b2, alpha, dropout_p=0.0, p
     return fn.apply(source_feat, target_feat, W1, b1, W2, b2, alpha, dropout_p)
 
 
+# ------------------------------------------------------ LSGAN discriminator head (DANE) --
+class _LsganHead(torch.autograd.Function):
+    """``mean((Linear(h, 1)(relu(x W1^T + b1)) - target) ** 2)``: first layer on the matrix-core kernels (bias in the
+    epilogue), everything after it in one pass each way over Z (gda_lsgan_head_fwd/bwd_f32); gW1 / gb1 / gx from gZ
+    by the TN (column sums as a by-product) and NN kernels."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, target):
+        x, W1, b1 = _f32c(x, "rows"), _f32c(W1, "W1"), _f32c(b1, "b1")
+        w2, b2 = _f32c(W2, "W2").reshape(-1), _f32c(b2, "b2").reshape(-1)
+        rows, a = x.size(0), W1.size(0)
+        Z = gemm(GEMM_NT, x, W1, bias=b1)
+        pre = torch.empty(rows, dtype=torch.float32, device=x.device)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        L = _lib.lib()
+        ws = _lib.workspace(L.gda_lsgan_head_workspace_bytes(a), x.device, "lsgan")
+        _lib.check(L.gda_lsgan_head_fwd_f32(_lib.ptr(Z), a, rows, a, _lib.ptr(w2), _lib.ptr(b2), float(target), _lib.ptr(pre),
+                                            _lib.ptr(loss), _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_lsgan_head_fwd_f32")
+        ctx.save_for_backward(x, W1, Z, w2, pre)
+        ctx.target, ctx.w2_shape, ctx.b2_shape = float(target), W2.shape, b2.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W1, Z, w2, pre = ctx.saved_tensors
+        rows, a = Z.shape
+        gZ = torch.empty_like(Z)
+        gw2 = torch.empty(a, dtype=torch.float32, device=Z.device)
+        gb2 = torch.empty(1, dtype=torch.float32, device=Z.device)
+        g = g.reshape(1).to(torch.float32).contiguous()
+        L = _lib.lib()
+        ws = _lib.workspace(L.gda_lsgan_head_workspace_bytes(a), Z.device, "lsgan")
+        _lib.check(L.gda_lsgan_head_bwd_f32(_lib.ptr(Z), a, rows, a, _lib.ptr(w2), _lib.ptr(pre), ctx.target, _lib.ptr(g),
+                                            _lib.ptr(gZ), a, _lib.ptr(gw2), _lib.ptr(gb2), _lib.ptr(ws), ws.numel(),
+                                            _lib.stream()), "gda_lsgan_head_bwd_f32")
+        gx = gemm(GEMM_NN, gZ, W1) if ctx.needs_input_grad[0] else None
+        gb1 = torch.empty(a, dtype=torch.float32, device=Z.device)
+        gW1 = gemm(GEMM_TN, gZ, x, colsum=gb1)
+        return gx, gW1, gb1, gw2.reshape(ctx.w2_shape), gb2.reshape(ctx.b2_shape), None
+
+
+def lsgan_head_ok(x, W1, W2):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= x.size(0) <= 200_000
+            and W1.size(0) <= 256 and W1.size(1) <= 256 and W2.size(0) == 1)
+
+
+def lsgan_head(x, W1, b1, W2, b2, target):
+    """``((D(x) - target) ** 2).mean()`` for DANE's ``D = Linear(h, a) - ReLU - Linear(a, 1)`` (dane.py:241-247,
+    339-350, 468-470): one GEMM, one row pass and one fold forward; one row pass, one fold and the GEMMs of the first
+    layer backward."""
+    return _LsganHead.apply(x, W1, b1, W2, b2, target)
+
+
 # ------------------------------------------- Wasserstein critic update (WGAN-GP), fused --
 def wgan_critic_grads(es, et, idx_s, idx_t, alpha, W1, b1, W2, b2, dropout_p, gp_weight, out):
     """Loss and parameter gradients of one critic update of AdaGCN (pygda/models/adagcn.py:169-183,387-454)

@@ -523,3 +523,25 @@ def test_grl_mlp_ce_dropout_masks_are_consistent():
     close(an, fd, rtol=2e-2, atol=0)
     st.next_step(torch.device(DEV))
     assert float(loss_at(es, et)) != float(l0)         # a new step draws a new mask
+
+
+# ------------------------------------------------------------------------ LSGAN discriminator head (DANE) --
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,h,a,target", [(43872, 128, 128, 1.0), (193, 16, 16, 0.0), (5000, 100, 72, 1.0)])
+def test_lsgan_head_fused_vs_composed(rows, h, a, target):
+    """ops.lsgan_head (first layer on the matrix-core kernels + csrc/gda_disc_mlp.hip's LSGAN head) against the
+    composition DANE runs (dane.py:339-350, 468-470): loss, input gradient and the four parameter gradients, at DANE's
+    cfg-A row count (8 x 5,484 sampled rows), a fixture-sized and a ragged case."""
+    gen = torch.Generator().manual_seed(rows + h)
+    x = torch.randn(rows, h, generator=gen).to(DEV).requires_grad_()
+    D = torch.nn.Sequential(torch.nn.Linear(h, a), torch.nn.ReLU(), torch.nn.Linear(a, 1)).to(DEV)
+    got = ops.lsgan_head(x, D[0].weight, D[0].bias, D[2].weight, D[2].bias, target)
+    (got * 0.7).backward()
+    g_got = [t.grad.clone() for t in (x, *D.parameters())]
+    for t in (x, *D.parameters()):
+        t.grad = None
+    want = ((D(x) - target) ** 2).mean()
+    (want * 0.7).backward()
+    close(got, want, rtol=1e-5, atol=1e-6)
+    for g, t in zip(g_got, (x, *D.parameters())):
+        close(g, t.grad, rtol=2e-4, atol=2e-5)      # sums over up to 43,872 rows in another order
