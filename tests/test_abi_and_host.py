@@ -492,3 +492,73 @@ def test_int32_limits_are_rejected_not_wrapped():
     assert L.gda_gemm_f32(0, -1, 4, 4, one, 4, one, 4, one, 4, None, 0, None) == -2
     with pytest.raises(_lib.GdaError):
         _lib.check(-2, "size check")
+
+
+def test_graphed_epoch_loop_groups_and_reports_in_order():
+    """The epoch loop over a captured step (models/base.py::_graphed_epochs) with several steps per replay: replays of
+    `unroll` epochs while enough remain, the one-step graph for the remainder, every epoch logged exactly once and in
+    order, one launch ahead of the read-back -- host logic, on a stand-in for hipgraph.GraphedStep."""
+    from pygda_amd.models.base import BaseGDA
+
+    class FakeGraphed:
+        def __init__(self, unroll):
+            self.unroll, self.graph_multi, self.calls, self.step = unroll, (object() if unroll > 1 else None), [], 0
+
+        def launch(self):
+            self.calls.append(("one", self.step))
+            self.step += 1
+            return len(self.calls) - 1
+
+        def launch_multi(self):
+            self.calls.append(("multi", self.step))
+            self.step += self.unroll
+            return ("multi", len(self.calls) - 1)
+
+        def result(self, ticket):
+            kind, first = self.calls[ticket]
+            assert kind == "one"
+            return float(first), 0.5
+
+        def result_multi(self, ticket):
+            kind, first = self.calls[ticket[1]]
+            assert kind == "multi"
+            return [(float(first + u), 0.5) for u in range(self.unroll)]
+
+    class T(BaseGDA):
+        def __init__(self):
+            self.verbose, self.epoch_hook = 0, None
+
+        init_model = forward_model = fit = process_graph = predict = lambda self, *a, **k: None
+
+    for unroll, n in [(1, 5), (2, 5), (2, 6), (3, 7), (4, 3)]:
+        t, g, seen = T(), FakeGraphed(unroll), []
+        t.epoch_hook = lambda e, loss, acc, secs: seen.append((e, loss))
+        t._graphed_epochs(g, range(10, 10 + n), 0.0)
+        assert seen == [(10 + i, float(i)) for i in range(n)], (unroll, n, seen)      # epoch i is step i, in order
+        multi = [c for c in g.calls if c[0] == "multi"]
+        assert len(multi) == (n // unroll if unroll > 1 else 0) and len(g.calls) - len(multi) == (n % unroll if unroll > 1 else n)
+    # per-epoch device scalars (adversarial branch): one step per replay whatever the capture holds
+    t, g, fills = T(), FakeGraphed(2), []
+
+    class Scalar:
+        def fill_(self, v):
+            fills.append(v)
+    t._graph_uses_scalars, t._g_alpha, t._g_epoch = True, Scalar(), Scalar()
+    t._graphed_epochs(g, range(3), 0.0, alpha_fn=lambda e: 0.1 * e)
+    assert [c[0] for c in g.calls] == ["one"] * 3 and fills == [0.0, 0.0, 0.1, 1.0, 0.2, 2.0]
+
+
+def test_memory_order_flat_gradients_roundtrip():
+    """hipgraph._mem_flat / _mem_view: the data-parallel step's flat gradient buffer holds every gradient in its
+    parameter's MEMORY order, so a weight stored gather-major (transposed strides, sparse_features.py) is neither
+    transposed into the buffer nor back out of it."""
+    from pygda_amd.hipgraph import _col_major, _mem_flat, _mem_view
+    p_row = torch.randn(3, 5)
+    p_col = torch.randn(3, 5).t().contiguous().t()                 # shape [3, 5], strides (1, 3)
+    assert not _col_major(p_row) and _col_major(p_col) and not _col_major(torch.randn(7))
+    for p in (p_row, p_col, torch.randn(7)):
+        g = torch.randn_like(p)
+        flat = _mem_flat(g, p)
+        v = _mem_view(flat, p)
+        assert flat.dim() == 1 and v.shape == p.shape and v.stride() == p.stride() and torch.equal(v, g)
+        assert v.data_ptr() == flat.data_ptr()                     # a view: Adam reads the reduced buffer in place
