@@ -562,3 +562,46 @@ def test_memory_order_flat_gradients_roundtrip():
         v = _mem_view(flat, p)
         assert flat.dim() == 1 and v.shape == p.shape and v.stride() == p.stride() and torch.equal(v, g)
         assert v.data_ptr() == flat.data_ptr()                     # a view: Adam reads the reduced buffer in place
+
+
+def test_ctypes_signatures_match_the_header():
+    """Every prototype of include/gda_hip.h against the ctypes table the Python layer binds with (pygda_amd/_lib.py):
+    same number of parameters, integer / floating / pointer kinds in the same positions, same kind of return value -- a
+    drifted binding would otherwise pass garbage across the ABI without any diagnostic."""
+    import ctypes
+    header = open(os.path.join(ROOT, "include", "gda_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = re.findall(r"^\s*([A-Za-z_][\w\s\*]*?)\b(gda_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.M)
+    assert len(protos) >= 60
+
+    def kind_of_c(decl):
+        d = decl.strip()
+        if d in ("void", ""):
+            return None
+        if "*" in d or re.search(r"\b(gda_stream_t|gda_comm_t)\b", d):      # the header's void* handle typedefs
+            return "ptr"
+        if re.search(r"\b(float|double)\b", d):
+            return "flt"
+        return "int"
+
+    def kind_of_ct(t):
+        if t is None:
+            return None
+        if t in (ctypes.c_float, ctypes.c_double):
+            return "flt"
+        if (t in (ctypes.c_void_p, ctypes.c_char_p) or getattr(t, "_type_", None) == "P"
+                or issubclass(t, (ctypes._Pointer, ctypes.Structure))):
+            return "ptr"
+        return "int"
+
+    checked = 0
+    for ret, name, params in protos:
+        sig = _lib._SIGNATURES.get(name)
+        assert sig is not None, f"{name}: declared in the header, missing from _lib._SIGNATURES"
+        want = [k for k in (kind_of_c(p) for p in params.split(",")) if k is not None]
+        got = [kind_of_ct(t) for t in sig[1]]
+        assert len(want) == len(got), f"{name}: header has {len(want)} parameters, ctypes table {len(got)}"
+        assert want == got, f"{name}: parameter kinds differ: header {want}, ctypes {got}"
+        assert kind_of_c(ret.replace("const", "")) == kind_of_ct(sig[0]), f"{name}: return kind"
+        checked += 1
+    assert checked == len(protos)
