@@ -28,21 +28,32 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
 FP32_MFMA_PEAK_TF = 157.3      # v_mfma_f32_32x32x2_f32 dense peak
+LDS_READ_B32_PEAK_GBS = 128 * 256 * 2.4   # ds_read_b32: 128 B/clk/CU (MI355X_MICROARCH.md, LDS table) x 256 CUs x 2.4 GHz
 
 
-def make_cfg_a(seed=200, ns=9360, es=15556, nt=5484, et=8117, feat=6775, classes=5, density=0.01):
+def make_cfg_a(seed=200, ns=9360, es=15556, nt=5484, et=8117, feat=6775, classes=5, density=0.01,
+               degrees="uniform", zipf=0.8):
     """Shape-identical stand-in for CitationDataset ACMv9 -> DBLPv7 (the files are not in the
     reference checkout, data/README.md links Google Drive only): E distinct undirected pairs
     symmetrised, x ~ Bernoulli(0.01) float32 [N, 6775], y uniform in {0..4}; seed 200 is the
-    benchmark scripts' (unused) default seed (benchmark/node/a2gnn.py:23)."""
+    benchmark scripts' (unused) default seed (benchmark/node/a2gnn.py:23).
+    ``degrees='powerlaw'``: same N and E, endpoints drawn with probability ~ rank^-zipf (a Chung-Lu graph on Zipf
+    weights): a few hubs with several hundred neighbours over a majority of degree-1/2 nodes, which is what real
+    citation graphs look like and what uniform pairs (maximum degree ~12) do not exercise."""
     from pygda_amd.data import Data
     g = torch.Generator().manual_seed(seed)
 
     def graph(n, e):
         keys = torch.empty(0, dtype=torch.int64)
+        if degrees == "powerlaw":
+            wgt = torch.arange(1, n + 1, dtype=torch.float64).pow(-zipf)[torch.randperm(n, generator=g)]
         while keys.numel() < e:
-            a = torch.randint(0, n, (2 * e,), generator=g)
-            b = torch.randint(0, n, (2 * e,), generator=g)
+            if degrees == "powerlaw":
+                a = torch.multinomial(wgt, 2 * e, replacement=True, generator=g)
+                b = torch.multinomial(wgt, 2 * e, replacement=True, generator=g)
+            else:
+                a = torch.randint(0, n, (2 * e,), generator=g)
+                b = torch.randint(0, n, (2 * e,), generator=g)
             lo, hi = torch.minimum(a, b), torch.maximum(a, b)
             k = (lo * n + hi)[lo != hi]
             keys = torch.unique(torch.cat([keys, k]))
@@ -72,6 +83,12 @@ def pmc_traffic(prefix="k_spmm<32, 4", pattern="*_rocprof_summary.json"):
             if k.startswith(prefix):
                 return v["traffic_bytes"], os.path.basename(f)
     return None, None
+
+
+def max_row(g):
+    """Longest row of the normalised adjacency (self loop included)."""
+    rp = g.rowptr[:g.num_nodes + 1]
+    return int((rp[1:] - rp[:-1]).max()) if g.num_nodes else 0
 
 
 def edges_per_step(nnz_s, nnz_t, L, s_p, t_p):
@@ -170,10 +187,11 @@ def make_cfg_s(nodes, avg_degree, feat, classes, seed, device):
     return Data(x=x, edge_index=ei, y=y)
 
 
-def run_cfg_s(args, world, rank, dev):
-    """Sampled mini-batch A2GNN on the synthetic large graphs (configs[4]): the native host sampler
+def run_cfg_s(args, world, rank, dev, cpu_base=True):
+    """Sampled mini-batch A2GNN on the synthetic large graphs (configs[4]): the neighbour sampler
     (prefetching), the row-gather kernel, per-batch graph ingestion, and -- with N ranks -- disjoint
-    seed shards, all-gathered MMD rows and one flat gradient all-reduce per step."""
+    seed shards, all-gathered MMD rows and one flat gradient all-reduce per step.  Returns the JSON
+    object on rank 0 (None elsewhere)."""
     import torch.distributed as dist
     from pygda_amd import ops
     from pygda_amd.models import A2GNN
@@ -289,6 +307,7 @@ def run_cfg_s(args, world, rank, dev):
                                    f"L=2, s_pnums=0, t_pnums=10, NeighborLoader fan-out {fan}, {args.batch} seeds per GPU "
                                    "per step, MMD domain loss",
                        "edges_aggregated_per_step": edges / args.steps, "final_loss": float(loss),
+                       "sampler": model.source_loader.sampler_description(),
                        "parallelism": "single GPU" if world == 1 else
                        f"dp{world}: disjoint seed mini-batches per rank, graph + features replicated, all-gathered "
                        "global-batch MMD rows, one flat RCCL gradient all-reduce per step"},
@@ -297,7 +316,7 @@ def run_cfg_s(args, world, rank, dev):
                                                     "the timed region"),
             "roofline_dense_projection": {k: roof(k) for k in sorted(prof) if k.startswith("dense_projection")},
             "kernel_time_ms_per_step": {k: v["ms"] / prof_steps for k, v in sorted(prof.items())}}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and cpu_base and not args.no_cpu_baseline:
             # the oracle's training step on ONE sampled batch pair of this run (its sub-graphs, its features)
             sb, tb = last["s"], last["t"]
             from pygda_amd.data import Data
@@ -309,81 +328,81 @@ def run_cfg_s(args, world, rank, dev):
             out["cpu_baseline"] = cpu_baseline(cs, ct, hp, edges_per_step(nnz_s, nnz_t, hp["L"], hp["s_pnums"],
                                                                          hp["t_pnums"]),
                                                what=f"cfg-S sampled batch pair ({cs.x.size(0)} + {ct.x.size(0)} nodes)")
-        print(json.dumps(out))
+        return out
+    return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-hbm-probe", action="store_true",
-                    help="skip the 5 M-node / 100 M-edge aggregation timed after the cfg-A region (roofline_hbm_regime)")
-    ap.add_argument("--adv", action="store_true", help="adversarial branch instead of MMD")
-    ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
-    ap.add_argument("--workload", default="cfgA", choices=["cfgA", "cfgS"],
-                    help="cfgA (default): BASELINE.json configs[1]; cfgS: sampled mini-batches on configs[4]-style graphs")
-    ap.add_argument("--nodes", type=int, default=5_000_000, help="cfgS: nodes per domain")
-    ap.add_argument("--avg-degree", type=int, default=20)
-    ap.add_argument("--feat", type=int, default=256)
-    ap.add_argument("--batch", type=int, default=1024, help="cfgS: seeds per GPU per step")
-    ap.add_argument("--fanout", default="15,10")
-    ap.add_argument("--force-dp", action="store_true",
-                    help="run the data-parallel code path (RCCL exchange steps) on a 1-rank group")
-    ap.add_argument("--rccl-direct", action="store_true",
-                    help="collectives through the C ABI's own RCCL communicator (gda_allreduce_f32 / "
-                         "gda_allgather_f32): the whole data-parallel step is then ONE hipGraph")
-    args = ap.parse_args()
+def relaunch(args):
+    """``python bench.py --gpus N`` without a launcher's environment: start the N ranks here, through the same
+    ``python -m torch.distributed.run`` command line the driver uses, and hand its exit code back.  A node with
+    fewer than N GPUs is an error -- never a silent 1-rank run that prints ``n_gpus: 1``."""
+    import socket
+    import subprocess
+    if not args.launch_check or torch.cuda.is_available():
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible on this node; refusing "
+                             "to run fewer ranks than requested")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
-    torch.cuda.set_device(local)
-    dev = f"cuda:{local}"
+
+def init_group(args, world, rank, dev):
+    """RCCL (``nccl``) process group of exactly ``--gpus`` ranks; gloo only for ``--launch-check`` on a box
+    without GPUs.  RCCL prints a version banner through C stdio on stdout when the communicator comes up; stdout
+    is kept for the ONE JSON line, so fd 1 is routed to stderr until the banner has been flushed."""
+    import ctypes
     import torch.distributed as dist
-    if world > 1 or args.force_dp:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29517")
-            os.environ["PYGDA_AMD_FORCE_DP"] = "1"
-        if args.rccl_direct:
-            os.environ["PYGDA_AMD_RCCL_DIRECT"] = "1"
-        # RCCL prints a version banner through C stdio on stdout when the communicator comes up; keep
-        # stdout for the ONE JSON line: route fd 1 to stderr until the banner has been flushed
-        import ctypes
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ["PYGDA_AMD_FORCE_DP"] = "1"
+    if args.rccl_direct:
+        os.environ["PYGDA_AMD_RCCL_DIRECT"] = "1"
+    gpu = torch.cuda.is_available()
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if gpu:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
-            warm = torch.ones(1, device=dev)
-            dist.all_reduce(warm)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+        warm = torch.ones(1, device=dev if gpu else "cpu")
+        dist.all_reduce(warm)
+        if gpu:
             torch.cuda.synchronize()
-            if os.environ.get("PYGDA_AMD_RCCL_DIRECT") == "1":
-                from pygda_amd import distributed as _D
-                _D.direct().all_reduce_(warm)
-                torch.cuda.synchronize()
-        finally:
-            ctypes.CDLL(None).fflush(None)
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
+        if float(warm) != float(world):
+            raise SystemExit(f"bench.py: all-reduce over the group summed to {float(warm)}, expected {world}")
+        if gpu and os.environ.get("PYGDA_AMD_RCCL_DIRECT") == "1":
+            from pygda_amd import distributed as _D
+            _D.direct().all_reduce_(warm)
+            torch.cuda.synchronize()
+    finally:
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
 
+
+def run_cfg_a(args, world, rank, dev, side=False):
+    """cfg-A (BASELINE.json configs[1]): full-batch A2GNN on the ACMv9 -> DBLPv7 shapes.  With ``side`` (the N > 1
+    run, where cfg-A is one full-batch REPLICA per GPU) only a short labelled summary is returned."""
+    import torch.distributed as dist
     from pygda_amd import profiler
     from pygda_amd.models import A2GNN
-
-    if args.workload == "cfgS":
-        run_cfg_s(args, world, rank, dev)
-        if dist.is_initialized():
-            dist.destroy_process_group()
-        return
-
     # hyper-parameters of benchmark/node/run_citation.sh:92 (A2GNN, ACMv9 -> DBLPv7)
     hp = dict(hid=128, classes=5, L=2, lr=0.01, wd=0.005, dropout=0.5, s_pnums=0, t_pnums=10, weight=10)
-    src, tgt = make_cfg_a(seed=200)
+    src, tgt = make_cfg_a(seed=200, degrees=args.graph)
     total_epochs = args.warmup + args.steps
     model = A2GNN(src.x.size(1), hp["hid"], hp["classes"], num_layers=hp["L"], lr=hp["lr"],
                   weight_decay=hp["wd"], epoch=total_epochs, dropout=hp["dropout"], s_pnums=hp["s_pnums"],
@@ -410,6 +429,7 @@ def main():
                            "dp-whole" if getattr(_g, "dp", False) else "single")
     from pygda_amd import ops as _ops
     _ops.aggregated_edges = 0
+    _ops.kstep_paths = {}
     sync()
     if not graphed:
         profiler.start()
@@ -418,6 +438,27 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     profiler.stop()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    executed = _ops.aggregated_edges // args.steps     # aggregations actually launched per step x nnz
+    execution = (({"dp": "four hipGraph segments with eager RCCL collectives between them",
+                   "dp-whole": "hipGraph replay of the whole data-parallel step, RCCL collectives captured "
+                               "(library-owned communicator)"}
+                  .get(getattr(model, "_graphed_kind", "single"), "hipGraph replay of the captured step"))
+                 if graphed else "eager launches")
+    kstep_paths = dict(getattr(_ops, "kstep_paths", {}) or {})
+    if side:
+        if rank != 0:
+            return None
+        return {"what": f"cfg-A as {world} full-batch REPLICAS (one per GPU: cfg-A has one batch per epoch, SURVEY "
+                        "8e 'replicas only'), independent dropout draws, global-batch MMD over all-gathered sample "
+                        "rows, one flat RCCL gradient all-reduce per step.  The job finishes epochs at "
+                        "epochs_per_sec whatever N is: this is the cost of the exchange steps, not a speed-up",
+                "ms_per_step": 1e3 * dt / args.steps, "epochs_per_sec": args.steps / dt,
+                "edges_aggregated_per_sec_per_replica": executed * args.steps / dt, "replicas": world,
+                "execution": execution, "graph": args.graph}
     host_launch = None
     if graphed and hasattr(_g, "_refill") and hasattr(_g, "_replay"):
         # what the host pays per step: the refill (sample draws + H2D enqueue) and the hipGraphLaunch call itself,
@@ -443,81 +484,182 @@ def main():
         model._train_epochs(*state, epochs=range(total_epochs, total_epochs + args.steps))
         sync()
         profiler.stop()
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     prof = profiler.summary()
-    executed = _ops.aggregated_edges // args.steps     # aggregations actually launched per step x nnz
+    if rank != 0:
+        return None
+    ms = 1e3 * dt / args.steps
+
+    def roof(name):
+        r = prof[name]
+        secs = r["ms"] * 1e-3
+        if name.startswith("spmm") or name.startswith("kstep_lds"):
+            ach = r["bytes"] / secs / 1e9
+            out = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": ach / HBM_PEAK_GBS, "launches": r["launches"],
+                   "avg_launch_us": r["avg_us"], "algorithmic_bytes_per_launch": r["bytes"] / r["launches"]}
+            if name.startswith("kstep_lds"):
+                # one launch = K aggregations whose operands never leave LDS: `achieved` is SURVEY 8(d)'s
+                # algorithmic bytes of the K aggregations it stands for over its duration ("HBM bytes the K
+                # launches would have moved"), NOT a bandwidth the memory system delivered -- the kernel's own
+                # HBM traffic is the plan + one read and one write of the activations (`hbm_bytes_per_launch`),
+                # its bound is the LDS gather rate (`lds`)
+                out["traffic"], out["traffic_source"] = pmc_traffic("k_kstep_lds", "r[0-9]*_rocprof_summary.json")
+                out["achieved_is"] = "algorithmic-equivalent (K aggregations per launch), see DESIGN 4.1b"
+                if r.get("hbm_bytes"):
+                    out["hbm_bytes_per_launch"] = r["hbm_bytes"] / r["launches"]
+                    out["hbm_frac_real"] = r["hbm_bytes"] / secs / 1e9 / HBM_PEAK_GBS
+                if r.get("lds_bytes"):
+                    lds = r["lds_bytes"] / secs / 1e9
+                    out["lds"] = {"gathered_GBs": lds, "peak_GBs": LDS_READ_B32_PEAK_GBS,
+                                  "frac": lds / LDS_READ_B32_PEAK_GBS,
+                                  "what": "4 B x slot-program entries (padding included) x columns x K per launch, "
+                                          "against the chip's ds_read_b32 rate (128 B/clk/CU x 256 CUs x 2.4 GHz, "
+                                          "MI355X_MICROARCH.md, LDS table)"}
+            else:
+                out["traffic"], out["traffic_source"] = pmc_traffic() if "d=128" in name else (None, None)
+            return out
+        ach = r["flops"] / secs / 1e12
+        return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None, "launches": r["launches"],
+                "avg_launch_us": r["avg_us"]}
+
+    cands = [k for k in prof if k.startswith("spmm") or k.startswith("kstep_lds") or k.startswith("dense")]
+    dominant = max(cands, key=lambda k: prof[k]["ms"])
+    agg = max((k for k in prof if k.startswith("spmm") or k.startswith("kstep_lds")), key=lambda k: prof[k]["ms"])
+    graph_note = ("shape-identical stand-in graphs" if args.graph == "uniform" else
+                  "stand-in graphs with the same N / E and Zipf (power-law) degrees")
+    out = {
+        "metric": "edges_aggregated_per_sec", "value": executed * args.steps / dt, "unit": "edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"cfg-A: A2GNN ACMv9->DBLPv7 ({graph_note}, "
+                               "Ns=9360/Es=15556, Nt=5484/Et=8117, F=6775), nhid=128, L=2, s_pnums=0, "
+                               "t_pnums=10, weight=10, dropout=0.5, full batch, "
+                               + ("adversarial" if args.adv else "MMD") + " domain loss",
+                   "edges_aggregated_per_step": executed,
+                   "edges_aggregated_per_step_reference_equivalent": edges,
+                   "note": "value counts the aggregations EXECUTED; layer 0 is evaluated once per domain and "
+                           "shared by the two passes the reference runs separately (identical values), so a "
+                           "step executes fewer aggregations than the reference's step",
+                   "nnz_source": nnz_s, "nnz_target": nnz_t, "graph": args.graph,
+                   "max_row_source": max_row(as_graph(src_d.edge_index, src_d.num_nodes)),
+                   "max_row_target": max_row(as_graph(tgt_d.edge_index, tgt_d.num_nodes)),
+                   "execution": execution, "kstep_aggregation_path": kstep_paths,
+                   "parallelism": "single GPU" if world == 1 else f"{world} replicas"},
+        "epochs_per_sec": args.steps / dt,
+        "reference_equivalent_edges_per_sec": edges * args.steps / dt,
+        "roofline": dict(roof(dominant), timing="HIP events on the launch stream, " + (
+            "eager pass of the same K steps after the timed hipGraph region" if graphed else "timed region")),
+        "roofline_aggregation": roof(agg),
+        # BASELINE.json also asks for the MFMA utilisation of the dense projection: the hidden-layer
+        # products on the hand-written matrix-core kernels (layer 0 is a sparse projection here)
+        "roofline_dense_projection": {k: roof(k) for k in sorted(prof) if k.startswith("dense_projection")},
+        "kernel_time_ms_per_step": {k: v["ms"] / args.steps for k, v in sorted(prof.items())},
+    }
+    if host_launch is not None:
+        out["host_per_step"] = host_launch
+    del model, state
+    torch.cuda.empty_cache()
+    if world == 1 and not args.no_hbm_probe:
+        # cfg-A's graphs are cache resident, so the HBM fraction above says little about the kernel:
+        # the same aggregation kernel timed at configs[4]'s per-domain size, where HBM is the bound
+        out["roofline_hbm_regime"] = hbm_regime_probe(dev)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(src, tgt, hp, edges)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-probe", action="store_true",
+                    help="skip the 5 M-node / 100 M-edge aggregation timed after the cfg-A region (roofline_hbm_regime)")
+    ap.add_argument("--adv", action="store_true", help="adversarial branch instead of MMD")
+    ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
+    ap.add_argument("--workload", default=None, choices=["cfgA", "cfgS"],
+                    help="cfgA: BASELINE.json configs[1] (default at --gpus 1); cfgS: sampled mini-batches on "
+                         "configs[4]-style graphs, seed shards per rank (default at --gpus N > 1, where cfg-A -- one "
+                         "batch per epoch -- can only run as replicas: SURVEY 8e)")
+    ap.add_argument("--graph", default="uniform", choices=["uniform", "powerlaw"],
+                    help="cfgA stand-in graphs: uniform random pairs, or the same N / E with Zipf degrees (hubs of "
+                         "several hundred neighbours, as real citation graphs have)")
+    ap.add_argument("--nodes", type=int, default=5_000_000, help="cfgS: nodes per domain")
+    ap.add_argument("--avg-degree", type=int, default=20)
+    ap.add_argument("--feat", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=1024, help="cfgS: seeds per GPU per step")
+    ap.add_argument("--fanout", default="15,10")
+    ap.add_argument("--no-side-lines", action="store_true",
+                    help="skip the second workload's labelled side object (N = 1: cfg-S on one GPU, the base point "
+                         "of the scaling curve; N > 1: cfg-A replicas)")
+    ap.add_argument("--side-steps", type=int, default=10)
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the data-parallel code path (RCCL exchange steps) on a 1-rank group")
+    ap.add_argument("--rccl-direct", action="store_true",
+                    help="collectives through the C ABI's own RCCL communicator (gda_allreduce_f32 / "
+                         "gda_allgather_f32): the whole data-parallel step is then ONE hipGraph")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="bring up the --gpus ranks, check the group's size with one all-reduce, print it and exit "
+                         "(gloo when the box has no GPU: the CPU test of the launcher)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(relaunch(args))          # start the ranks ourselves; each re-enters main() with the env set
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}")
+    gpu = torch.cuda.is_available()
+    if not gpu and not args.launch_check:
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    if gpu:
+        if torch.cuda.device_count() <= local:
+            raise SystemExit(f"bench.py: rank {rank} wants GPU {local}, {torch.cuda.device_count()} visible")
+        torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    import torch.distributed as dist
+    if world > 1 or args.force_dp:
+        init_group(args, world, rank, dev)
+    if args.launch_check:
+        if rank == 0:
+            print(json.dumps({"launch_check": "ok", "n_gpus": dist.get_world_size() if dist.is_initialized() else 1,
+                              "backend": dist.get_backend() if dist.is_initialized() else None}))
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
+
+    workload = args.workload or ("cfgA" if world == 1 else "cfgS")
+    side_args = argparse.Namespace(**vars(args))
+    side_args.steps, side_args.warmup = min(args.steps, args.side_steps), min(args.warmup, 3)
+    if workload == "cfgS":
+        out = run_cfg_s(args, world, rank, dev)
+        if world > 1 and not args.no_side_lines:
+            side = run_cfg_a(side_args, world, rank, dev, side=True)
+            if rank == 0:
+                out["cfgA_replicas"] = side
+    else:
+        out = run_cfg_a(args, world, rank, dev)
+        if world == 1 and not args.no_side_lines and not args.force_dp:
+            # the base point of the 1/2/4/8 scaling curve: the sampled workload the N > 1 lines report, on one GPU
+            side = run_cfg_s(side_args, world, rank, dev, cpu_base=False)
+            out["scaling_reference"] = {
+                "what": "cfg-S on this one GPU: `bench.py --gpus N` (N > 1) reports cfg-S (seed shards per rank, "
+                        "weak scaling); divide its value by N x this value for the scaling efficiency",
+                "value": side["value"], "unit": side["unit"], "ms_per_step": side["ms_per_step"],
+                "steps": side["steps"], "workload": side["config"]["workload"],
+                "sampler": side["config"].get("sampler"),
+                "roofline": side["roofline"], "roofline_dense_projection": side["roofline_dense_projection"]}
+        elif world > 1 and rank == 0:
+            out["config"]["parallelism"] = (f"{world} full-batch replicas (explicit --workload cfgA; value is ONE "
+                                            "replica's rate, the job's epoch rate is epochs_per_sec)")
     if rank == 0:
-        ms = 1e3 * dt / args.steps
-
-        def roof(name):
-            r = prof[name]
-            secs = r["ms"] * 1e-3
-            if name.startswith("spmm") or name.startswith("kstep_lds"):
-                ach = r["bytes"] / secs / 1e9
-                if name.startswith("kstep_lds"):     # one launch = K aggregations whose operands never leave LDS
-                    traffic, src_file = pmc_traffic("k_kstep_lds", "r2*_rocprof_summary.json")
-                else:
-                    traffic, src_file = pmc_traffic() if "d=128" in name else (None, None)
-                return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src_file,
-                        "launches": r["launches"],
-                        "avg_launch_us": r["avg_us"], "algorithmic_bytes_per_launch": r["bytes"] / r["launches"]}
-            ach = r["flops"] / secs / 1e12
-            return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None, "launches": r["launches"],
-                    "avg_launch_us": r["avg_us"]}
-
-        cands = [k for k in prof if k.startswith("spmm") or k.startswith("kstep_lds") or k.startswith("dense")]
-        dominant = max(cands, key=lambda k: prof[k]["ms"])
-        agg = max((k for k in prof if k.startswith("spmm") or k.startswith("kstep_lds")), key=lambda k: prof[k]["ms"])
-        out = {
-            "metric": "edges_aggregated_per_sec", "value": world * executed * args.steps / dt, "unit": "edges/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "cfg-A: A2GNN ACMv9->DBLPv7 (shape-identical stand-in graphs, "
-                                   "Ns=9360/Es=15556, Nt=5484/Et=8117, F=6775), nhid=128, L=2, s_pnums=0, "
-                                   "t_pnums=10, weight=10, dropout=0.5, full batch, "
-                                   + ("adversarial" if args.adv else "MMD") + " domain loss",
-                       "edges_aggregated_per_step": executed,
-                       "edges_aggregated_per_step_reference_equivalent": edges,
-                       "note": "value counts the aggregations EXECUTED; layer 0 is evaluated once per domain and "
-                               "shared by the two passes the reference runs separately (identical values), so a "
-                               "step executes fewer aggregations than the reference's step",
-                       "nnz_source": nnz_s, "nnz_target": nnz_t,
-                       "execution": ({"dp": "four hipGraph segments with eager RCCL collectives between them",
-                                      "dp-whole": "hipGraph replay of the whole data-parallel step, RCCL collectives "
-                                                  "captured (library-owned communicator)"}
-                                     .get(getattr(model, "_graphed_kind", "single"),
-                                          "hipGraph replay of the captured step")) if graphed else "eager launches",
-                       "parallelism": "single GPU" if world == 1 else
-                       f"dp{world}: one full-batch replica per GPU (cfg-A has one batch per epoch), "
-                       "independent dropout draws, global-batch MMD over all-gathered sample rows, "
-                       "one flat RCCL gradient all-reduce per step"},
-            "epochs_per_sec": world * args.steps / dt,
-            "reference_equivalent_edges_per_sec": world * edges * args.steps / dt,
-            "roofline": dict(roof(dominant), timing="HIP events on the launch stream, " + (
-                "eager pass of the same K steps after the timed hipGraph region" if graphed else "timed region")),
-            "roofline_aggregation": roof(agg),
-            # BASELINE.json also asks for the MFMA utilisation of the dense projection: the hidden-layer
-            # products on the hand-written matrix-core kernels (layer 0 is a sparse projection here)
-            "roofline_dense_projection": {k: roof(k) for k in sorted(prof) if k.startswith("dense_projection")},
-            "kernel_time_ms_per_step": {k: v["ms"] / args.steps for k, v in sorted(prof.items())},
-        }
-        if host_launch is not None:
-            out["host_per_step"] = host_launch
-        if world == 1 and not args.no_hbm_probe:
-            # cfg-A's graphs are cache resident, so the HBM fraction above says little about the kernel:
-            # the same aggregation kernel timed at configs[4]'s per-domain size, where HBM is the bound
-            del model, state
-            torch.cuda.empty_cache()
-            out["roofline_hbm_regime"] = hbm_regime_probe(dev)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(src, tgt, hp, edges)
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -126,6 +126,14 @@ class NeighborLoader:
     def __len__(self):
         return 1 if self.full_batch else len(self._batches())
 
+    def sampler_description(self):
+        """Which sampler assembles the batches (bench.py: config.sampler)."""
+        if self.full_batch:
+            return "none (full batch)"
+        if self._sampler is None:
+            return "not started"
+        return self._sampler.description()
+
     def __iter__(self):
         if self.full_batch:
             self.data._static_graph = True        # the same graph every step: operators derived from it

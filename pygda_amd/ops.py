@@ -124,6 +124,13 @@ def gemm(mode, a, b, bias=None, colsum=None):
 aggregated_edges = 0     # running count of nnz(A_hat) over every aggregation launched (bench bookkeeping;
                          # only maintained while the profiler is on: it costs a cached-nnz lookup)
 aggregation_log = None   # or a list: (graph, K) per aggregation call, nnz resolved later (no sync in the loop)
+kstep_paths = None       # or a dict: which kernel ran the K >= 3 aggregation calls ("lds-one-launch" / "launch-chain"),
+                         # counted per call while the profiler is on (bench.py: config.kstep_aggregation_path)
+
+
+def _note_path(name, K):
+    if kstep_paths is not None and profiler.enabled and K >= 3:
+        kstep_paths[name] = kstep_paths.get(name, 0) + 1
 
 
 def _launch_kstep(graph, x, K, bias, transposed, y, tmp, counts_as=None):
@@ -134,6 +141,7 @@ def _launch_kstep(graph, x, K, bias, transposed, y, tmp, counts_as=None):
     n, d = x.shape
     L = _lib.lib()
     book_graph, book_steps = counts_as if counts_as is not None else (graph, int(K))
+    _note_path("launch-chain", int(K))
     if aggregation_log is not None:
         aggregation_log.append((book_graph, book_steps))
     if profiler.enabled:      # algorithmic bytes per launch: nnz*(4+4) + (N+1)*4 + 2*N*d*4
@@ -163,8 +171,14 @@ def _launch_kstep_lds(graph, plan, slots, x, K, bias, transposed, y, x_colmajor=
     if profiler.enabled:
         global aggregated_edges
         aggregated_edges += int(K) * graph.nnz
+        _note_path("lds-one-launch", int(K))
+        # `bytes`: SURVEY 8(d)'s algorithmic bytes of the K aggregations the launch stands for; `hbm_bytes`: what the
+        # kernel itself moves (the plan per workgroup + one read and one write of the activations); `lds_bytes`:
+        # the words its step loops gather out of LDS (slot-program entries incl. padding x columns x K)
         ctx = profiler.region(f"kstep_lds_f32[d={d},K={int(K)}]", 1,
-                              K * (graph.nnz * 8 + (n + 1) * 4 + 2 * n * d * 4), K * 2 * graph.nnz * d)
+                              K * (graph.nnz * 8 + (n + 1) * 4 + 2 * n * d * 4), K * 2 * graph.nnz * d,
+                              hbm_bytes=plan.numel() + 2 * n * d * 4,
+                              lds_bytes=4 * 1024 * slots * 4 * d * int(K))
     else:
         ctx = profiler.region("", 0)
     n_pad = (n + 3) // 4 * 4

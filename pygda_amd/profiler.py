@@ -10,7 +10,7 @@ from contextlib import contextmanager
 import torch
 
 enabled = False
-_records = defaultdict(list)       # name -> [(start, end, launches, bytes, flops)]
+_records = defaultdict(list)       # name -> [(start, end, launches, bytes, flops, extra)]
 
 
 def start():
@@ -25,7 +25,9 @@ def stop():
 
 
 @contextmanager
-def region(name, launches=1, nbytes=0, flops=0):
+def region(name, launches=1, nbytes=0, flops=0, **extra):
+    """``extra``: further per-call byte counts of the kernel family (summed by :func:`summary`), e.g. the bytes a
+    kernel really moves over HBM next to the algorithmic bytes it stands for."""
     if not enabled:
         yield
         return
@@ -35,7 +37,7 @@ def region(name, launches=1, nbytes=0, flops=0):
         yield
     finally:
         e.record()
-        _records[name].append((s, e, launches, nbytes, flops))
+        _records[name].append((s, e, launches, nbytes, flops, extra))
 
 
 def summary():
@@ -47,4 +49,7 @@ def summary():
         out[name] = dict(calls=len(recs), launches=launches, ms=ms,
                          avg_us=1e3 * ms / max(launches, 1),
                          bytes=sum(r[3] for r in recs), flops=sum(r[4] for r in recs))
+        for r in recs:
+            for k, v in r[5].items():
+                out[name][k] = out[name].get(k, 0) + v
     return out

@@ -10,6 +10,23 @@ from . import _lib
 from .data import Data
 
 
+def default_threads():
+    """Worker threads of ONE host sampler.  A rank runs two loaders (source and target) that prefetch at the same
+    time, and a node runs LOCAL_WORLD_SIZE ranks: the host's hardware threads (this process's affinity mask) are
+    divided by both, capped at 16 -- 8 ranks x 2 loaders x 8 threads on a 128-thread host, not 256 threads
+    (``PYGDA_AMD_SAMPLER_THREADS`` overrides)."""
+    import os
+    env = os.environ.get("PYGDA_AMD_SAMPLER_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = os.cpu_count() or 2
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    return max(1, min(16, cpus // (2 * local_world)))
+
+
 class NeighborSampler:
     def __init__(self, edge_index, num_nodes, threads=None):
         ei = edge_index.detach().cpu().contiguous()
@@ -20,10 +37,8 @@ class NeighborSampler:
         L = _lib.lib()
         _lib.check(L.gda_sampler_create(self._src.ctypes.data, self._dst.ctypes.data, self._src.size,
                                         self.num_nodes, ctypes.byref(self._h)), "gda_sampler_create")
-        if threads is None:
-            import os
-            threads = max(1, min(16, (os.cpu_count() or 2) // 2))
-        _lib.check(L.gda_sampler_set_threads(self._h, int(threads)), "gda_sampler_set_threads")
+        self.threads = default_threads() if threads is None else int(threads)
+        _lib.check(L.gda_sampler_set_threads(self._h, self.threads), "gda_sampler_set_threads")
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -55,6 +70,9 @@ class NeighborSampler:
         at = lambda k: block[o[k]:].ctypes.data
         _lib.check(L.gda_sampler_csr_norm(self._h, at(0), at(2), at(4), at(1), at(3), at(5)), "gda_sampler_csr_norm")
         return torch.from_numpy(nodes), torch.from_numpy(ei), torch.from_numpy(block)
+
+    def description(self):
+        return f"native host sampler (csrc/gda_sampler.cpp), {self.threads} worker threads per loader"
 
     def sample_batch(self, data, seeds, fanouts, seed=0):
         """A ``Data`` batch like PyG's: ``x``/``y`` sliced to the sampled nodes (seeds are the

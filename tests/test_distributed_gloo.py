@@ -133,3 +133,54 @@ def test_two_rank_a2gnn_step_equals_concatenated_batch(adv):
     assert abs(results[1]["loss"] - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
     for k, g in ref_grads.items():
         assert torch.allclose(results[0]["grads"][k], g, rtol=1e-4, atol=1e-6), (k, (results[0]["grads"][k] - g).abs().max())
+
+
+# ---- bench.py's launcher: `--gpus N` must mean N ranks, or an error ------------------------------------------
+def _bench(*argv, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR",
+                                                             "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], capture_output=True, text=True,
+                          timeout=timeout, env=env, cwd=root)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the CPU form of the launcher test (gloo)")
+def test_bench_spawns_the_ranks_it_is_asked_for():
+    """VERDICT round 2, missing item 4: `python bench.py --gpus 2` without a launcher's environment used to run ONE
+    rank and print n_gpus: 1.  It now starts the ranks itself (same torch.distributed.run command line the driver
+    uses) and checks the group's size with an all-reduce; --launch-check stops there (gloo on a box without GPUs)."""
+    import json
+    r = _bench("--gpus", "2", "--launch-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    assert out == {"launch_check": "ok", "n_gpus": 2, "backend": "gloo"}
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="needs a box with fewer GPUs than asked for")
+def test_bench_refuses_to_run_fewer_ranks_than_requested():
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert "n_gpus" not in r.stdout                       # no JSON line claiming a result
+    assert "refusing" in r.stderr or "needs an MI355X" in r.stderr
+    # a launcher whose world size disagrees with --gpus is an error as well
+    r = _bench("--gpus", "4", "--launch-check", env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_sampler_threads_divide_by_the_local_world_size(monkeypatch):
+    from pygda_amd import sampler
+    monkeypatch.delenv("PYGDA_AMD_SAMPLER_THREADS", raising=False)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(128)), raising=False)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    assert sampler.default_threads() == 16
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert sampler.default_threads() == 8                  # 8 ranks x 2 loaders x 8 = the host's 128 threads
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(8)), raising=False)
+    assert sampler.default_threads() == 1
+    monkeypatch.setenv("PYGDA_AMD_SAMPLER_THREADS", "3")
+    assert sampler.default_threads() == 3
