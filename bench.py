@@ -442,14 +442,25 @@ def run_cfg_a(args, world, rank, dev, side=False):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    executed = _ops.aggregated_edges // args.steps     # aggregations actually launched per step x nnz
     execution = (({"dp": "four hipGraph segments with eager RCCL collectives between them",
                    "dp-whole": "hipGraph replay of the whole data-parallel step, RCCL collectives captured "
                                "(library-owned communicator)"}
                   .get(getattr(model, "_graphed_kind", "single"), "hipGraph replay of the captured step"))
                  if graphed else "eager launches")
-    kstep_paths = dict(getattr(_ops, "kstep_paths", {}) or {})
+    def executed_edges():
+        """Aggregations actually launched per step x nnz.  The bookkeeping (ops.aggregated_edges, ops.kstep_paths)
+        runs with the profiler: eager steps inside the timed region, or the eager pass after a replayed one."""
+        if _ops.aggregated_edges == 0:          # captured steps, no eager pass yet: one bookkeeping step
+            model.use_hip_graph, model._graphed = False, None
+            profiler.start()
+            model._train_epochs(*state, epochs=range(total_epochs, total_epochs + 1))
+            sync()
+            profiler.stop()
+            return _ops.aggregated_edges
+        return _ops.aggregated_edges // args.steps
+
     if side:
+        executed = executed_edges()
         if rank != 0:
             return None
         return {"what": f"cfg-A as {world} full-batch REPLICAS (one per GPU: cfg-A has one batch per epoch, SURVEY "
@@ -486,6 +497,8 @@ def run_cfg_a(args, world, rank, dev, side=False):
         profiler.stop()
 
     prof = profiler.summary()
+    executed = executed_edges()
+    kstep_paths = {k: v // args.steps for k, v in (getattr(_ops, "kstep_paths", {}) or {}).items()}
     if rank != 0:
         return None
     ms = 1e3 * dt / args.steps
@@ -511,11 +524,16 @@ def run_cfg_a(args, world, rank, dev, side=False):
                     out["hbm_frac_real"] = r["hbm_bytes"] / secs / 1e9 / HBM_PEAK_GBS
                 if r.get("lds_bytes"):
                     lds = r["lds_bytes"] / secs / 1e9
+                    cols = int(name.split("d=")[1].split(",")[0])
+                    active = min(cols, 256) / 256.0          # one workgroup (= one CU) per feature column
                     out["lds"] = {"gathered_GBs": lds, "peak_GBs": LDS_READ_B32_PEAK_GBS,
                                   "frac": lds / LDS_READ_B32_PEAK_GBS,
-                                  "what": "4 B x slot-program entries (padding included) x columns x K per launch, "
-                                          "against the chip's ds_read_b32 rate (128 B/clk/CU x 256 CUs x 2.4 GHz, "
-                                          "MI355X_MICROARCH.md, LDS table)"}
+                                  "frac_of_the_cus_it_occupies": lds / (LDS_READ_B32_PEAK_GBS * active),
+                                  "what": "4 B x slot-program entries (padding included) x columns x K per launch over "
+                                          "the WHOLE launch (plan load and column I/O included), against the chip's "
+                                          "ds_read_b32 rate (128 B/clk/CU x 256 CUs x 2.4 GHz, MI355X_MICROARCH.md, LDS "
+                                          f"table); the launch has {cols} workgroups, one per feature column, so it "
+                                          f"occupies {min(cols, 256)} of the 256 CUs"}
             else:
                 out["traffic"], out["traffic_source"] = pmc_traffic() if "d=128" in name else (None, None)
             return out

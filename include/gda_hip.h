@@ -153,12 +153,18 @@ int gda_spmm_csr_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const f
  * with the same results bit for bit (per-row sums in CSR order, separately rounded multiply and
  * add): A_hat^K x is independent per feature column, so a workgroup keeps one column of all rows in
  * LDS across the K steps and the graph is compiled once into a per-lane register program.
+ * On a graph with a row of more than 48 entries (power-law hubs) the rows longer than 4*S entries are cut into
+ * segments of 4*S entries whose sequential
+ * sums are added as a fixed balanced tree by a second phase of each step: deterministic, within fp32
+ * summation tolerance of the sequential order (the rows of up to 4*S entries stay bit-exact).
  *
  * gda_kstep_plan_host compiles a CSR given as HOST arrays into `plan_host` (caller-owned host
- * memory of gda_kstep_plan_bytes(12) bytes; the first gda_kstep_plan_bytes(S) are meaningful) and
- * returns S (6, 8, 10 or 12 slots per thread), 0 when the graph is not eligible (too many rows /
- * a row longer than 4*S entries / more slots than one workgroup holds) -- callers then use
- * gda_spmm_csr_kstep_f32 --, or a negative status.  The plan is copied to the device by the caller.
+ * memory of gda_kstep_plan_bytes(12) bytes; the first gda_kstep_plan_bytes(slots) are meaningful) and
+ * returns `slots` = S | hub_waves << 8 (S = 6, 8, 10 or 12 slots per thread; hub_waves = 0 for a graph
+ * without long rows) -- the value the launch entry points take --, 0 when the graph is not eligible (too
+ * many rows / a row longer than 64 segments / more slots than one workgroup holds / nodes + segments beyond
+ * the 16320 words of an LDS buffer) -- callers then use gda_spmm_csr_kstep_f32 --, or a negative status.
+ * The plan is copied to the device by the caller.
  * gda_kstep_plan_host_ex takes flags: bit 0 = bank-aware placement -- WHERE a node's word lives in LDS is
  * chosen such that the 32 words a lane group gathers (or stores) in one instruction fall on different LDS
  * banks as far as possible (the step loop is bound by exactly those gathers); the sums and their order do

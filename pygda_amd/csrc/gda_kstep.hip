@@ -16,6 +16,15 @@
 //   * activations cross the kernel in column-major [d, ldT] (contiguous per column): the row-major
 //     wrapper below transposes through 64x64 LDS tiles before and after.
 //
+//   * long rows (power-law hubs: real citation graphs have nodes with hundreds of neighbours) do not fit one
+//     lane's S*L entries.  Such a row is cut into segments of S*L entries; a segment is an ordinary program row
+//     whose sum lands in a PARTIAL word (an extra word of the ping-pong buffer) instead of the node's word, and
+//     a second phase per step -- one more workgroup barrier, executed only when the plan has hubs, and only by
+//     the few waves that hold combine lanes -- adds a hub's partials with a fixed-shape butterfly inside an
+//     aligned lane group of one wave and stores the node's word.  Rows of up to S*L entries keep the sequential
+//     CSR-order chain (bit-exact against the CPU scatter-add); a hub row's sum is its segments' sequential sums
+//     added as a balanced tree: deterministic, and within fp32 summation tolerance of the sequential order.
+//
 // Bound: LDS gather rate / VALU issue of one CU per column (not HBM: the working set never leaves LDS).
 #include "gda_common.h"
 
@@ -34,6 +43,8 @@ constexpr int KS_ZERO_W = 0;         // word 0 of each buffer reads as 0 (paddin
 constexpr int KS_DUMP_W = 1;         // slots that do not end a row; node words start at KS_NODE_W0
 constexpr int KS_NODE_W0 = KS_BANKS;
 constexpr int KS_POS_WORDS = (KS_MAX_ROWS + 2 + 3) / 4 * 4;      // the plan's node -> LDS address table (fixed size)
+constexpr int KS_MAX_PARTS = 64;     // segments of one hub row: its combine group is a lane group of ONE wave
+constexpr int KS_RED_BYTES = (KS_TB / 64) * 4;                     // column-sum scratch above the two buffers
 
 // ds_read / ds_write at (LDS byte address held in a register) + (compile-time offset): the offset folds
 // into the instruction's 16-bit offset field, the register holds an absolute LDS address (the kernel adds
@@ -73,10 +84,35 @@ __device__ __forceinline__ void ks_step(const unsigned (&ea)[S * KS_L], const fl
     }
 }
 
+// Phase 2 of a step on a graph with hub rows.  Lane t of the first `hub_waves` waves owns one table entry
+// {x = LDS address of a partial word (or of the zero word), y = (group size - 1) << 24 | LDS address of the hub
+// node's word in the lane that leads a group (0: none)}.  A hub's P partials sit in an aligned group of
+// G = pow2ceil(P) lanes (padding lanes read the zero word); the butterfly adds lane + off for off = 1, 2, .. G/2,
+// so the group's first lane ends with ((p0 + p1) + (p2 + p3)) + ... -- a fixed tree, the same on every launch.
+// Everything it needs is re-derived from the thread id behind an opaque copy, so that the compiler keeps none of it
+// (six shuffle addresses, the table pointer) in registers across the step loop: the slot program owns the VGPRs.
+template <int WR>
+__device__ __forceinline__ void ks_combine(const uint2* hubtab, unsigned base) {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const uint2 h = hubtab[t];
+    float v = lds_ld<WR>(h.x);
+    const unsigned gm = h.y >> 24;
+#pragma unroll
+    for (int off = 1; off < KS_MAX_PARTS; off <<= 1) {
+        // lane + off (mod 64: a wrapped lane only ever feeds lanes whose value no group uses)
+        const float o = __int_as_float(__builtin_amdgcn_ds_bpermute(((t + off) & 63) << 2, __float_as_int(v)));
+        v = (gm & (unsigned)off) ? __fadd_rn(v, o) : v;
+    }
+    const unsigned out = h.y & 0xffffffu;
+    if (out) lds_st<WR>(out + base, v);
+}
+
 template <int S>
 __global__ void __launch_bounds__(KS_TB)
 k_kstep_lds(const int2* __restrict__ ent, const unsigned* __restrict__ outa, const unsigned* __restrict__ keepm,
-            const unsigned* __restrict__ pos, int n_rows, int n_pad, int K, const float* __restrict__ xT, int64_t ldx, float* __restrict__ yT, int64_t ldy,
+            const unsigned* __restrict__ pos, const uint2* __restrict__ hubp, int hub_waves,
+            int n_rows, int n_pad, int K, const float* __restrict__ xT, int64_t ldx, float* __restrict__ yT, int64_t ldy,
             const float* __restrict__ bias, float* __restrict__ colsum) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int R = S * KS_L;
@@ -121,18 +157,24 @@ k_kstep_lds(const int2* __restrict__ ent, const unsigned* __restrict__ outa, con
 #pragma unroll
     for (int s = 0; s < S; ++s) { oa[s] = op[(size_t)s * 64] + base; asm volatile("" : "+v"(oa[s])); }
     const unsigned keep = keepm[t];
+    uint2* hubtab = reinterpret_cast<uint2*>(lds + 2 * KS_OFFB + KS_RED_BYTES);
+    if (t < hub_waves * 64) { uint2 h = hubp[t]; h.x += base; hubtab[t] = h; }
+    const int wu = __builtin_amdgcn_readfirstlane(w);          // the wave's index as a scalar
     __syncthreads();
     int step = 0;
     for (; step + 2 <= K; step += 2) {
         ks_step<S, 0, KS_OFFB>(ea, ew, oa, keep);
         __syncthreads();
+        if (hub_waves) { if (wu < hub_waves) ks_combine<KS_OFFB>(hubtab, base); __syncthreads(); }
         ks_step<S, KS_OFFB, 0>(ea, ew, oa, keep);
         __syncthreads();
+        if (hub_waves) { if (wu < hub_waves) ks_combine<0>(hubtab, base); __syncthreads(); }
     }
     unsigned rbase = base;
     if (step < K) {
         ks_step<S, 0, KS_OFFB>(ea, ew, oa, keep);
         __syncthreads();
+        if (hub_waves) { if (wu < hub_waves) ks_combine<KS_OFFB>(hubtab, base); __syncthreads(); }
         rbase = base + KS_OFFB;
     }
     const float bv = bias ? bias[c] : 0.f;
@@ -163,16 +205,18 @@ k_transpose(const float* __restrict__ in, int64_t ldi, float* __restrict__ out, 
 }
 
 template <int S>
-int ks_launch(const int2* ent, const unsigned* outa, const unsigned* keep, const unsigned* pos, int n_rows, int n_pad, int d,
+int ks_launch(const int2* ent, const unsigned* outa, const unsigned* keep, const unsigned* pos, const uint2* hubp, int hub_waves,
+              int n_rows, int n_pad, int d,
               int K, const float* xT, int64_t ldx, float* yT, int64_t ldy, const float* bias, float* colsum, hipStream_t s) {
-    const size_t lds = (size_t)2 * KS_OFFB + (size_t)(KS_TB / 64) * 4;       // both buffers in full + the column-sum scratch
+    // both buffers in full + the column-sum scratch + the combine table of the hub waves
+    const size_t lds = (size_t)2 * KS_OFFB + (size_t)KS_RED_BYTES + (size_t)hub_waves * 64 * sizeof(uint2);
     static bool configured = false;          // idempotent attribute; racing first calls set the same value
     if (!configured) {
         GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_kstep_lds<S>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
-    k_kstep_lds<S><<<(unsigned)d, KS_TB, lds, s>>>(ent, outa, keep, pos, n_rows, n_pad, K, xT, ldx, yT, ldy, bias, colsum);
+    k_kstep_lds<S><<<(unsigned)d, KS_TB, lds, s>>>(ent, outa, keep, pos, hubp, hub_waves, n_rows, n_pad, K, xT, ldx, yT, ldy, bias, colsum);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
@@ -201,7 +245,10 @@ struct KsGroups {
     }
 };
 
-void ks_place(int n, int S, const std::vector<int>& ent_node, const std::vector<int>& out_node, bool bank_aware,
+// `n` counts the graph's nodes AND the partial words of its hub rows (virtual nodes n_rows ..); `hub_read` /
+// `hub_write` are the combine phase's per-lane partial reads and group-leader stores (-1: zero word / none).
+void ks_place(int n, int n_rows, int S, const std::vector<int>& ent_node, const std::vector<int>& out_node,
+              const std::vector<int>& hub_read, const std::vector<int>& hub_write, bool bank_aware,
               std::vector<unsigned>& pos_word) {
     pos_word.assign((size_t)n, 0u);
     if (!bank_aware) {
@@ -232,9 +279,16 @@ void ks_place(int n, int S, const std::vector<int>& ent_node, const std::vector<
                 }
                 G.add(tmp, W_STEP, fix);
             }
-    for (int i0 = 0; i0 < n; i0 += 128)          // the column load / store: lane l of a 32-lane group holds nodes i0 + 4l .. 4l+3
+    for (size_t g0 = 0; g0 + 32 <= hub_read.size(); g0 += 32) {      // the combine phase: one read per lane, leaders store
+        unsigned char fix = 0;
+        for (int l = 0; l < 32; ++l) { const int v = hub_read[g0 + l]; if (v >= 0) tmp.push_back(v); else fix = 1; }
+        G.add(tmp, W_STEP, fix);
+        for (int l = 0; l < 32; ++l) { const int v = hub_write[g0 + l]; if (v >= 0) tmp.push_back(v); }
+        G.add(tmp, W_STEP, 0);
+    }
+    for (int i0 = 0; i0 < n_rows; i0 += 128)     // the column load / store: lane l of a 32-lane group holds nodes i0 + 4l .. 4l+3
         for (int j = 0; j < 4; ++j) {
-            for (int l = 0; l < 32; ++l) if (i0 + 4 * l + j < n) tmp.push_back(i0 + 4 * l + j);
+            for (int l = 0; l < 32; ++l) if (i0 + 4 * l + j < n_rows) tmp.push_back(i0 + 4 * l + j);
             G.add(tmp, 2 * W_IO, 0);
         }
     const int ng = (int)G.gweight.size();
@@ -321,17 +375,24 @@ void ks_place(int n, int S, const std::vector<int>& ent_node, const std::vector<
 extern "C" int gda_kstep_max_rows(void) { return KS_MAX_ROWS; }
 
 extern "C" size_t gda_kstep_plan_bytes(int slots) {
-    return (size_t)KS_TB * slots * KS_L * sizeof(int2) + (size_t)KS_TB * slots * 4 + (size_t)KS_TB * 4 + (size_t)KS_POS_WORDS * 4;
+    const int S = slots & 0xff;
+    return (size_t)KS_TB * S * KS_L * sizeof(int2) + (size_t)KS_TB * S * 4 + (size_t)KS_TB * 4 + (size_t)KS_POS_WORDS * 4 +
+           (size_t)KS_TB * sizeof(uint2);
 }
 
 // Compile a CSR (HOST arrays) into the register program.  Tries S = 6, 8, 10, 12 slots per thread and
 // writes the first that fits into `plan_host` (gda_kstep_plan_bytes(12) bytes are always enough):
-//   [ent: int2[16 waves][S*L][64]] [outa: u32[16][S][64]] [keep: u32[1024]] [pos: u32[KS_POS_WORDS]]
-// ent.x / outa / pos are LDS byte addresses inside one buffer: word 0 = the zero word, word 1 = the dump word,
+//   [ent: int2[16 waves][S*L][64]] [outa: u32[16][S][64]] [keep: u32[1024]] [pos: u32[KS_POS_WORDS]] [hub: uint2[1024]]
+// ent.x / outa / pos / hub are LDS byte addresses inside one buffer: word 0 = the zero word, word 1 = the dump word,
 // node i at pos[i] (rows n_rows .. round_up(n_rows, 4) - 1 of the column park on the dump word).
+// A row of more than S*L entries is cut into segments of S*L entries (program rows whose sums land in partial
+// words -- extra words of the buffer, placed like nodes); hub[t] = {partial word read by combine lane t, (group
+// size - 1) << 24 | word of the hub node stored by the group's first lane} (see ks_combine).
 // flags bit 0: bank-aware placement of the nodes (ks_place); without it node i sits at word 32 + i.
-// Returns the S chosen (>0), 0 if the graph is not eligible (too many rows, a row longer than S*L entries,
-// or more slots than 1024 threads hold), <0 on invalid arguments.
+// Returns S | hub_waves << 8 (> 0; hub_waves = leading waves that hold combine lanes, 0 for a graph without long
+// rows) -- the value the launch entry points take as `slots` --, 0 if the graph is not eligible (too many rows,
+// a row longer than 64 segments, more slots than 1024 threads hold, more words than a buffer holds), < 0 on
+// invalid arguments.
 extern "C" int gda_kstep_plan_host_ex(const int32_t* rowptr_host, const int32_t* colidx_host, const float* val_host,
                                       int64_t n_rows, int flags, void* plan_host, size_t plan_bytes) {
     if (n_rows < 0) return GDA_E_SIZE;
@@ -339,67 +400,124 @@ extern "C" int gda_kstep_plan_host_ex(const int32_t* rowptr_host, const int32_t*
     if (!rowptr_host || !plan_host) return GDA_E_NULL;
     if (n_rows > KS_MAX_ROWS) return 0;
     const int n = (int)n_rows;
-    const int n_pad = (n + 3) / 4 * 4;
-    int64_t total_slots = 0;
-    int max_len = 0;
-    for (int i = 0; i < n; ++i) {
-        const int len = rowptr_host[i + 1] - rowptr_host[i];
-        if (len < 0) return GDA_E_SIZE;
-        max_len = std::max(max_len, len);
-        total_slots += std::max((len + KS_L - 1) / KS_L, 1);
-    }
+    for (int i = 0; i < n; ++i)
+        if (rowptr_host[i + 1] < rowptr_host[i]) return GDA_E_SIZE;
     if (rowptr_host[n] > 0 && (!colidx_host || !val_host)) return GDA_E_NULL;
+    for (int64_t k = 0; k < rowptr_host[n]; ++k)
+        if (colidx_host[k] < 0 || colidx_host[k] >= n) return GDA_E_SIZE;
+    struct VRow { int beg, len, out; };          // entries [beg, beg + len) of the CSR; out = node id or n + partial id
+    struct Hub { int row, first, parts, group; };
+    int max_len = 0;
+    for (int i = 0; i < n; ++i) max_len = std::max(max_len, rowptr_host[i + 1] - rowptr_host[i]);
+    // a graph whose rows all fit one lane at the largest S keeps every row whole (bit-exact sums): segments are for
+    // graphs that have a row no S can hold
+    const bool segments = max_len > 12 * KS_L;
     for (int S : {6, 8, 10, 12}) {
-        if (max_len > S * KS_L || total_slots > (int64_t)S * KS_TB) continue;
-        if (plan_bytes < gda_kstep_plan_bytes(S)) return GDA_E_WORKSPACE;
         const int R = S * KS_L;
+        if (!segments && max_len > R) continue;
+        // the program's rows: short rows as they are, long rows as segments of R entries
+        std::vector<VRow> vrows;
+        std::vector<Hub> hubs;
+        vrows.reserve((size_t)n);
+        int n_parts = 0;
+        bool ok = true;
+        int64_t total_slots = 0;
+        for (int i = 0; i < n && ok; ++i) {
+            const int beg = rowptr_host[i], len = rowptr_host[i + 1] - beg;
+            if (len <= R) {
+                vrows.push_back({beg, len, i});
+                total_slots += std::max((len + KS_L - 1) / KS_L, 1);
+                continue;
+            }
+            const int parts = (len + R - 1) / R;
+            if (parts > KS_MAX_PARTS) { ok = false; break; }
+            int group = 1;
+            while (group < parts) group <<= 1;
+            hubs.push_back({i, n_parts, parts, group});
+            for (int j = 0; j < parts; ++j) {
+                const int sl = std::min(R, len - j * R);
+                vrows.push_back({beg + j * R, sl, n + n_parts + j});
+                total_slots += (sl + KS_L - 1) / KS_L;
+            }
+            n_parts += parts;
+        }
+        if (!ok) return 0;                       // a longer segment only comes with a larger S: 12 * 4 * 64 entries is the limit
+        const int n_total = n + n_parts;
+        if (n_total > KS_MAX_ROWS || total_slots > (int64_t)S * KS_TB) continue;
+        // combine lanes: groups in order of decreasing size pack the 64-lane waves without gaps
+        std::stable_sort(hubs.begin(), hubs.end(), [](const Hub& a, const Hub& b) { return a.group > b.group; });
+        int64_t lanes = 0;
+        for (const Hub& h : hubs) lanes += h.group;
+        if (lanes > KS_TB) continue;
+        const int hub_waves = (int)((lanes + 63) / 64);
+        if (plan_bytes < gda_kstep_plan_bytes(S)) return GDA_E_WORKSPACE;
         // pass 1: the program on node ids (-1 = zero word / dump word)
         std::vector<int> ent_node((size_t)KS_TB * R, -1), out_node((size_t)KS_TB * S, -1);
         std::vector<int> ent_w((size_t)KS_TB * R, 0);
         std::vector<unsigned> keepv((size_t)KS_TB, 0u);
-        int row = 0;
+        size_t row = 0;
         int64_t placed = 0;
-        for (int t = 0; t < KS_TB && row < n; ++t) {
+        for (int t = 0; t < KS_TB && row < vrows.size(); ++t) {
             // even spread of the slots over the threads (prefix target), never beyond S per thread
             const int64_t target = (total_slots * (t + 1) + KS_TB - 1) / KS_TB;
             const int w = t >> 6, lane = t & 63;
             int used = 0;
-            while (row < n) {
-                const int len = rowptr_host[row + 1] - rowptr_host[row];
-                const int need = std::max((len + KS_L - 1) / KS_L, 1);
+            while (row < vrows.size()) {
+                const VRow& vr = vrows[row];
+                const int need = std::max((vr.len + KS_L - 1) / KS_L, 1);
                 if (used + need > S) break;
                 if (used > 0 && placed + need > target) break;
-                for (int q = 0; q < len; ++q) {
-                    const int k = rowptr_host[row] + q;
-                    const int32_t col = colidx_host[k];
-                    if (col < 0 || col >= n) return GDA_E_SIZE;
+                for (int q = 0; q < vr.len; ++q) {
+                    const int k = vr.beg + q;
                     const size_t at = ((size_t)w * R + (size_t)used * KS_L + q) * 64 + lane;
-                    ent_node[at] = col;
+                    ent_node[at] = colidx_host[k];
                     std::memcpy(&ent_w[at], &val_host[k], 4);
                 }
                 for (int q = 0; q + 1 < need; ++q) keepv[t] |= 1u << (used + q);
-                out_node[((size_t)w * S + used + need - 1) * 64 + lane] = row;
+                out_node[((size_t)w * S + used + need - 1) * 64 + lane] = vr.out;
                 used += need;
                 placed += need;
                 ++row;
             }
         }
-        if (row != n) continue;
-        // pass 2: where the nodes live, then the program on LDS byte addresses
+        if (row != vrows.size()) continue;
+        std::vector<int> hub_read((size_t)hub_waves * 64, -1), hub_write((size_t)hub_waves * 64, -1);
+        std::vector<unsigned> hub_mask((size_t)hub_waves * 64, 0u);
+        {
+            int at = 0;
+            for (const Hub& h : hubs) {
+                for (int j = 0; j < h.group; ++j) {
+                    if (j < h.parts) hub_read[(size_t)at + j] = n + h.first + j;
+                    hub_mask[(size_t)at + j] = (unsigned)(h.group - 1);
+                }
+                hub_write[(size_t)at] = h.row;
+                at += h.group;
+            }
+        }
+        // pass 2: where the nodes and the partial words live, then the program on LDS byte addresses
         std::vector<unsigned> pos_word;
-        ks_place(n, S, ent_node, out_node, (flags & 1) != 0, pos_word);
+        ks_place(n_total, n, S, ent_node, out_node, hub_read, hub_write, (flags & 1) != 0, pos_word);
         int2* ent = static_cast<int2*>(plan_host);
         unsigned* outa = reinterpret_cast<unsigned*>(ent + (size_t)KS_TB * R);
         unsigned* keep = outa + (size_t)KS_TB * S;
         unsigned* pos = keep + KS_TB;
+        uint2* hub = reinterpret_cast<uint2*>(pos + KS_POS_WORDS);
         for (size_t i = 0; i < (size_t)KS_TB * R; ++i)
             ent[i] = int2{(int)((ent_node[i] >= 0 ? pos_word[ent_node[i]] : (unsigned)KS_ZERO_W) * 4u), ent_w[i]};
         for (size_t i = 0; i < (size_t)KS_TB * S; ++i)
             outa[i] = (out_node[i] >= 0 ? pos_word[out_node[i]] : (unsigned)KS_DUMP_W) * 4u;
         std::memcpy(keep, keepv.data(), (size_t)KS_TB * 4);
         for (int i = 0; i < KS_POS_WORDS; ++i) pos[i] = (i < n ? pos_word[i] : (unsigned)KS_DUMP_W) * 4u;
-        (void)n_pad;
-        return S;
+        for (int t = 0; t < KS_TB; ++t) {
+            uint2 h{(unsigned)KS_ZERO_W * 4u, 0u};
+            if (t < hub_waves * 64) {
+                if (hub_read[t] >= 0) h.x = pos_word[hub_read[t]] * 4u;
+                h.y = hub_mask[t] << 24;
+                if (hub_write[t] >= 0) h.y |= pos_word[hub_write[t]] * 4u;       // < 2^17: node words start at word 32, never 0
+            }
+            hub[t] = h;
+        }
+        return S | (hub_waves << 8);
     }
     return 0;
 }
@@ -421,18 +539,21 @@ extern "C" int gda_kstep_lds_colmajor_f32(const void* plan, int slots, int64_t n
     if (!plan || !xT || !yT) return GDA_E_NULL;
     const int n_pad = ((int)n_rows + 3) / 4 * 4;
     if (ldx < n_pad || ldy < n_pad || ldx % 4 || ldy % 4 || ((uintptr_t)xT % 16) || ((uintptr_t)yT % 16)) return GDA_E_SIZE;
-    const int R = slots * KS_L;
+    const int S = slots & 0xff, hub_waves = (slots >> 8) & 0xff;       // the value gda_kstep_plan_host returned
+    if (slots < 0 || (slots >> 16) || hub_waves > KS_TB / 64) return GDA_E_SIZE;
+    const int R = S * KS_L;
     const int2* ent = static_cast<const int2*>(plan);
     const unsigned* outa = reinterpret_cast<const unsigned*>(ent + (size_t)KS_TB * R);
-    const unsigned* keep = outa + (size_t)KS_TB * slots;
+    const unsigned* keep = outa + (size_t)KS_TB * S;
     const unsigned* pos = keep + KS_TB;
+    const uint2* hub = reinterpret_cast<const uint2*>(pos + KS_POS_WORDS);
     hipStream_t s = (hipStream_t)stream;
     const int n = (int)n_rows;
-    switch (slots) {
-        case 6: return ks_launch<6>(ent, outa, keep, pos, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
-        case 8: return ks_launch<8>(ent, outa, keep, pos, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
-        case 10: return ks_launch<10>(ent, outa, keep, pos, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
-        case 12: return ks_launch<12>(ent, outa, keep, pos, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
+    switch (S) {
+        case 6: return ks_launch<6>(ent, outa, keep, pos, hub, hub_waves, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
+        case 8: return ks_launch<8>(ent, outa, keep, pos, hub, hub_waves, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
+        case 10: return ks_launch<10>(ent, outa, keep, pos, hub, hub_waves, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
+        case 12: return ks_launch<12>(ent, outa, keep, pos, hub, hub_waves, n, n_pad, (int)d, K, xT, ldx, yT, ldy, bias, colsum, s);
         default: return GDA_E_UNSUPPORTED;
     }
 }

@@ -168,7 +168,7 @@ extern "C" int gda_sampler_sample(gda_sampler* s, const int64_t* seeds_host, int
         parallel_for(nf, s->workers, [&](int64_t fb, int64_t fe, int) {
             std::vector<int64_t> scratch;
             for (int64_t f = fb; f < fe; ++f) {
-                if (f + 8 < fe) __builtin_prefetch(&s->in_src[s->in_ptr[s->nodes[frontier_begin + f + 8]]]);
+                if (f + 8 < fe) __builtin_prefetch(s->in_src.data() + s->in_ptr[s->nodes[frontier_begin + f + 8]]);
                 const int64_t v = s->nodes[frontier_begin + f];
                 const int64_t b = s->in_ptr[v], deg = s->in_ptr[v + 1] - b;
                 int64_t* out = s->picks.data() + s->pick_off[f];

@@ -132,14 +132,19 @@ class _GlobalMean(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mean_local, n_local):
+        if int(n_local) == 0:      # a rank without rows: its "mean" is 0/0; it contributes nothing and receives nothing
+            mean_local = torch.zeros_like(mean_local)
         buf = torch.stack([mean_local.detach().to(torch.float32).reshape(()) * float(n_local),
                            torch.tensor(float(n_local), dtype=torch.float32, device=mean_local.device)])
         _all_reduce_sum(buf)
         ctx.scale = buf.new_tensor(float(n_local) * dist.get_world_size()) / buf[1]
+        ctx.empty = int(n_local) == 0
         return (buf[0] / buf[1]).to(mean_local.dtype).reshape(mean_local.shape)
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.empty:              # never NaN * 0: the upstream mean of zero rows may carry a NaN gradient path
+            return torch.zeros_like(g), None
         return g * ctx.scale.to(g.dtype), None
 
 

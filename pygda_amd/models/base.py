@@ -226,7 +226,14 @@ class BaseGDA(ABC):
                     from ..hipgraph import GraphedStepSplit
                     graphed = GraphedStepSplit(split, self._g_alpha, scalar_step, optimizer, src, tgt).capture()
                 else:
-                    unroll = int(os.environ.get("PYGDA_AMD_GRAPH_UNROLL", "2")) if getattr(self, "_graph_unroll_ok", False) else 1
+                    # several steps per replay: the weights are already U-1 steps (plus the pipelining lag) past
+                    # the epoch a log line reports.  A hook may want to look at the MODEL of that epoch (evaluate,
+                    # checkpoint), so a trainer with an epoch_hook replays one step at a time unless the
+                    # environment variable asks for more explicitly; hooks should consume the numbers they are
+                    # handed -- with pipelined epochs the model is always at least one launch ahead of them
+                    env_unroll = os.environ.get("PYGDA_AMD_GRAPH_UNROLL")
+                    unroll = int(env_unroll or ("1" if self.epoch_hook is not None else "2")) \
+                        if getattr(self, "_graph_unroll_ok", False) else 1
                     graphed = GraphedStep(scalar_step, optimizer, src, tgt,
                                           extra_optimizers=getattr(self, "_graph_extra_optimizers", ()),
                                           unroll=unroll).capture()

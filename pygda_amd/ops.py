@@ -34,7 +34,8 @@ class _SoftmaxNLL(torch.autograd.Function):
                                                 _lib.ptr(stats), _lib.ptr(ws), ws.numel(), _lib.stream()),
                    "gda_softmax_nll_fwd_ex_f32")
         global _ce_stats
-        _ce_stats = (logits.data_ptr(), labels.data_ptr(), n, stats)
+        _ce_stats = (logits, labels, n, stats)       # the tensors themselves are held: while the entry lives their
+                                                     # storage cannot be handed to another tensor
         ctx.save_for_backward(x, labels)
         return loss.reshape(())
 
@@ -56,8 +57,10 @@ def ce_stats_for(logits, labels):
     """``[loss, number of correct argmax predictions]`` (float64, device) left by the LAST softmax_nll call if it
     was made on exactly these logits and labels, else None.  Lets a trainer's epoch log line (loss, source
     micro-F1) ride on the loss kernel instead of an argmax / compare / sum / cast / stack chain."""
-    hit = _ce_stats
-    if hit is not None and hit[0] == logits.data_ptr() and hit[1] == labels.data_ptr() and hit[2] == logits.size(0):
+    global _ce_stats
+    hit, _ce_stats = _ce_stats, None              # consumed by the first look-up: a later loss computed some other
+    if (hit is not None and hit[2] == logits.size(0) and hit[0].shape == logits.shape       # way never sees it
+            and hit[0].data_ptr() == logits.data_ptr() and hit[1].data_ptr() == labels.data_ptr()):
         return hit[3]
     return None
 
@@ -178,7 +181,7 @@ def _launch_kstep_lds(graph, plan, slots, x, K, bias, transposed, y, x_colmajor=
         ctx = profiler.region(f"kstep_lds_f32[d={d},K={int(K)}]", 1,
                               K * (graph.nnz * 8 + (n + 1) * 4 + 2 * n * d * 4), K * 2 * graph.nnz * d,
                               hbm_bytes=plan.numel() + 2 * n * d * 4,
-                              lds_bytes=4 * 1024 * slots * 4 * d * int(K))
+                              lds_bytes=4 * 1024 * (slots & 0xff) * 4 * d * int(K))
     else:
         ctx = profiler.region("", 0)
     n_pad = (n + 3) // 4 * 4

