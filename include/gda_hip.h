@@ -479,6 +479,39 @@ int gda_sampler_csr_norm(const gda_sampler* s, int32_t* rowptr, int32_t* colidx,
                          int32_t* t_rowptr, int32_t* t_colidx, float* t_val);
 
 /* ------------------------------------------------------------------------------
+ * Device neighbour sampler (csrc/gda_dsampler.hip; DEVICE pointers, fan-outs on the host).
+ *
+ * The same NeighborLoader call sites (pygda/models/a2gnn.py:260-277) with the graph resident in HBM: the same
+ * contract as the host sampler above and, bit for bit, the same batches (same counter-based generator keyed on
+ * (seed, hop, node), same discovery order) -- plus the batch's GCN-normalised CSR pair exactly as
+ * gda_build_csr_norm(esrc, edst, NULL, n_edges, n_nodes, 1.0, 1, 1, 0) would write it, without its two sorts.
+ * Stateless: the caller owns every array.
+ *
+ * gda_dsampler_build_graph: in-neighbour lists (in_ptr int64 [N+1], in_src int32 [E], edge order kept inside a
+ *   list) from a COO edge list; status = device int32[2] {edges with an endpoint outside [0, N), largest in-degree}.
+ * gda_dsampler_caps: node_cap / edge_cap of a batch of n_seeds seeds (every output array is sized by them);
+ *   GDA_E_UNSUPPORTED for a fan-out of 0 or above 64, or a batch beyond the int32 range (use the host sampler).
+ * gda_dsampler_sample: nodes int64 [node_cap] (global ids, seeds first), esrc / edst int64 [edge_cap] (local ids),
+ *   rowptr / t_rowptr int32 [node_cap + 1], colidx / val / t_colidx / t_val [edge_cap + node_cap] (all six NULL:
+ *   no CSR), counts = device int64[4] {n_nodes, n_edges, nnz, status: 0 ok / 1 capacity exceeded / 2 seed out of
+ *   range}; rowptr[i] == nnz for i >= n_nodes.  All launches are capacity sized; nothing returns to the host.
+ * ---------------------------------------------------------------------------- */
+size_t gda_dsampler_graph_workspace_bytes(int64_t E, int64_t N);
+int gda_dsampler_build_graph(const int64_t* src, const int64_t* dst, int64_t E, int64_t N,
+                             int64_t* in_ptr, int32_t* in_src, int32_t* status,
+                             void* workspace, size_t workspace_bytes, gda_stream_t stream);
+int gda_dsampler_caps(int64_t n_seeds, const int32_t* fanouts_host, int L, int64_t max_in_degree, int64_t E,
+                      int64_t N, int64_t* node_cap, int64_t* edge_cap);
+size_t gda_dsampler_workspace_bytes(int64_t n_seeds, const int32_t* fanouts_host, int L, int64_t max_in_degree,
+                                    int64_t E, int64_t N);
+int gda_dsampler_sample(const int64_t* in_ptr, const int32_t* in_src, int64_t N, int64_t E, int64_t max_in_degree,
+                        const int64_t* seeds, int64_t n_seeds, const int32_t* fanouts_host, int L, uint64_t rng_seed,
+                        int64_t* nodes, int64_t* esrc, int64_t* edst,
+                        int32_t* rowptr, int32_t* colidx, float* val,
+                        int32_t* t_rowptr, int32_t* t_colidx, float* t_val,
+                        int64_t* counts, void* workspace, size_t workspace_bytes, gda_stream_t stream);
+
+/* ------------------------------------------------------------------------------
  * Host construction of the PPMI graph (HOST pointers).
  *
  * Replaces the Python random-walk loop of PPMIConv.norm (pygda/nn/ppmi_conv.py:98-172):

@@ -70,6 +70,12 @@ _SIGNATURES = {
                                    ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
     "gda_sampler_fetch": (c_int, [_P, _P, _P, _P]),
     "gda_sampler_csr_norm": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "gda_dsampler_graph_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "gda_dsampler_build_graph": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, _P, c_size_t, _P]),
+    "gda_dsampler_caps": (c_int, [c_int64, _P, c_int, c_int64, c_int64, c_int64, _P, _P]),
+    "gda_dsampler_workspace_bytes": (c_size_t, [c_int64, _P, c_int, c_int64, c_int64, c_int64]),
+    "gda_dsampler_sample": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int, ctypes.c_uint64,
+                                    _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gda_selection_csr_host": (c_int, [_P, c_int, c_int64, c_int64, c_int64, c_int64, _P, _P]),
     "gda_ppmi_build_host": (c_int, [_P, _P, c_int64, c_int64, c_int, c_int, ctypes.c_uint64,
                                     ctypes.POINTER(c_void_p)]),

@@ -141,9 +141,9 @@ class NeighborLoader:
                 self.data.edge_index._gda_static = True
             yield self.data
             return
-        from .sampler import NeighborSampler
+        from .sampler import NeighborSampler, DeviceNeighborSampler
         if self._sampler is None:
-            self._sampler = NeighborSampler(self.data.edge_index, self.data.num_nodes)
+            self._sampler = self._make_sampler()
         # the epoch counter advances when iteration STARTS: ``zip(source_loader, target_loader)`` never
         # resumes the second generator after the first one is exhausted, so a bump after the last yield
         # would leave the target loader on epoch 0 (same neighbourhoods and shuffle every epoch)
@@ -151,7 +151,9 @@ class NeighborLoader:
         self._epoch += 1
         batches = self._batches(epoch)
         seeds_of = lambda b: hash((self.seed, epoch, b, self.rank)) & 0x7FFFFFFF
-        if self.prefetch <= 0:
+        if isinstance(self._sampler, DeviceNeighborSampler):
+            yield from self._device_batches(batches, seeds_of)
+        elif self.prefetch <= 0:
             for b, seeds in enumerate(batches):
                 yield self._sampler.sample_batch(self.data, seeds, self.num_neighbors, seed=seeds_of(b))
         else:
@@ -191,6 +193,69 @@ class NeighborLoader:
                         q.get_nowait()
                     except queue.Empty:
                         th.join(timeout=0.01)
+
+
+    def _make_sampler(self):
+        """The device sampler when the graph and the features live on the GPU and the fan-outs allow it (1..64, or
+        -1 within its workspace budget); the native host sampler otherwise (``PYGDA_AMD_DEVICE_SAMPLER=0`` forces it)."""
+        import os
+        from .sampler import NeighborSampler, DeviceNeighborSampler
+        ei = self.data.edge_index
+        if (ei.is_cuda and self.data.x is not None and self.data.x.is_cuda
+                and os.environ.get("PYGDA_AMD_DEVICE_SAMPLER", "1") == "1"):
+            ds = DeviceNeighborSampler(ei, self.data.num_nodes)
+            if ds.supports(self.batch_size, self.num_neighbors):
+                return ds
+        return NeighborSampler(ei, self.data.num_nodes)
+
+    def _device_batches(self, batches, seeds_of):
+        """Batches from the device sampler.  With prefetching, a producer thread enqueues batch b+1.. on a side
+        stream and waits for their sizes there, so the training stream never waits for a size read-back; the
+        consumer orders itself behind the side stream with an event and gathers the feature rows."""
+        S = self._sampler
+        if self.prefetch <= 0:
+            for b, seeds in enumerate(batches):
+                yield S.assemble(self.data, S.enqueue(seeds, self.num_neighbors, seed=seeds_of(b)))
+            return
+        import queue
+        import threading
+        dev = self.data.x.device
+        if getattr(self, "_samp_stream", None) is None:
+            self._samp_stream = torch.cuda.Stream(device=dev)
+        side = self._samp_stream
+        side.wait_stream(torch.cuda.current_stream())       # the graph / features may have just been produced
+        q, stop = queue.Queue(maxsize=self.prefetch), threading.Event()
+
+        def producer():
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(side):
+                    for b, seeds in enumerate(batches):
+                        if stop.is_set():
+                            return
+                        p = S.enqueue(seeds, self.num_neighbors, seed=seeds_of(b))
+                        q.put((p, p.wait()))
+                q.put(None)
+            except BaseException as exc:
+                q.put(exc)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield S.assemble(self.data, *item)
+        finally:
+            stop.set()
+            while th.is_alive():
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    th.join(timeout=0.01)
 
 
 class DataLoader:

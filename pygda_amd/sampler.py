@@ -128,3 +128,141 @@ class NeighborSampler:
                         batch_size=int(torch.as_tensor(seeds).numel()))
         return Data(x=data.x[n_id], edge_index=ei, y=None if data.y is None else data.y[n_id], n_id=n_id,
                     batch_size=int(torch.as_tensor(seeds).numel()))
+
+
+class _PendingBatch:
+    """A batch the device sampler has enqueued: capacity-sized device arrays + the event after which the four
+    counts ({n_nodes, n_edges, nnz, status}) are on the host."""
+    __slots__ = ("nodes", "ei", "csr", "counts_host", "event", "n_seeds", "stream")
+
+    def wait(self):
+        self.event.synchronize()
+        n, e, nnz, status = (int(v) for v in self.counts_host.tolist())
+        if status == 2:
+            raise _lib.GdaError("gda_dsampler_sample: a seed lies outside [0, num_nodes)")
+        if status != 0:
+            raise _lib.GdaError("gda_dsampler_sample: a capacity bound was exceeded (internal error)")
+        return n, e, nnz
+
+
+class DeviceNeighborSampler:
+    """Python face of the device neighbour sampler (csrc/gda_dsampler.hip): the graph's in-neighbour lists live in
+    HBM, a batch (global ids, local edge list, GCN-normalised CSR pair) is built by a few dozen small launches on
+    the caller's stream -- the same batches as :class:`NeighborSampler`, bit for bit, with no host work beyond the
+    enqueue and one 32-byte read-back of the sizes."""
+
+    MAX_WORKSPACE = int(float(__import__("os").environ.get("PYGDA_AMD_DSAMPLER_MAX_WS_GB", "4")) * 2 ** 30)
+
+    def __init__(self, edge_index, num_nodes):
+        _lib.require_gpu_tensor(edge_index, "edge_index", torch.int64)
+        L = _lib.lib()
+        dev = edge_index.device
+        self.device, self.num_nodes, self.num_edges = dev, int(num_nodes), int(edge_index.size(1))
+        N, E = self.num_nodes, self.num_edges
+        need = L.gda_dsampler_graph_workspace_bytes(E, N)
+        if need == 0:
+            raise _lib.GdaError("device sampler: graph beyond the int32 index range")
+        self.in_ptr = torch.empty(N + 1, dtype=torch.int64, device=dev)
+        self.in_src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        status = torch.empty(2, dtype=torch.int32, device=dev)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        src, dst = edge_index[0].contiguous(), edge_index[1].contiguous()
+        _lib.check(L.gda_dsampler_build_graph(_lib.ptr(src), _lib.ptr(dst), E, N, _lib.ptr(self.in_ptr),
+                                              _lib.ptr(self.in_src), _lib.ptr(status), _lib.ptr(ws), ws.numel(),
+                                              _lib.stream()), "gda_dsampler_build_graph")
+        bad, self.max_in_degree = (int(v) for v in status.tolist())       # one sync per graph
+        del ws
+        if bad:
+            raise IndexError(f"edge_index values must lie in [0, {N}): {bad} edges do not")
+        self._ws = {}
+
+    def _caps(self, n_seeds, fanouts):
+        fan = np.ascontiguousarray(np.asarray(fanouts, dtype=np.int32))
+        nc, ec = ctypes.c_int64(), ctypes.c_int64()
+        L = _lib.lib()
+        st = L.gda_dsampler_caps(int(n_seeds), fan.ctypes.data, fan.size, self.max_in_degree, self.num_edges,
+                                 self.num_nodes, ctypes.byref(nc), ctypes.byref(ec))
+        if st != 0:
+            return None
+        need = L.gda_dsampler_workspace_bytes(int(n_seeds), fan.ctypes.data, fan.size, self.max_in_degree,
+                                              self.num_edges, self.num_nodes)
+        return fan, nc.value, ec.value, need
+
+    def supports(self, n_seeds, fanouts):
+        """Fan-outs 1..64 (or -1 when the whole-neighbourhood bound still fits the workspace budget)."""
+        caps = self._caps(n_seeds, fanouts)
+        return caps is not None and 0 < caps[3] <= self.MAX_WORKSPACE
+
+    def description(self):
+        return "device sampler (csrc/gda_dsampler.hip): in-neighbour lists in HBM, no host sampling threads"
+
+    def enqueue(self, seeds, fanouts, seed=0, csr=True):
+        """Launch the batch on the CURRENT stream; returns a :class:`_PendingBatch`."""
+        caps = self._caps(int(torch.as_tensor(seeds).numel()), fanouts)
+        if caps is None:
+            raise _lib.GdaError(f"device sampler: fan-outs {list(fanouts)} are not supported (0, or above 64)")
+        fan, ncap, ecap, need = caps
+        dev = self.device
+        stream = torch.cuda.current_stream()
+        ws = self._ws.get(stream.cuda_stream)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[stream.cuda_stream] = torch.empty(need, dtype=torch.uint8, device=dev)
+        seeds_d = torch.as_tensor(seeds).to(dev, torch.int64, non_blocking=True).contiguous()
+        i64, i32, f32 = (dict(dtype=t, device=dev) for t in (torch.int64, torch.int32, torch.float32))
+        p = _PendingBatch()
+        p.n_seeds, p.stream = int(seeds_d.numel()), stream
+        p.nodes = torch.empty(ncap, **i64)
+        p.ei = torch.empty(2, ecap, **i64)
+        if csr:
+            cap = ecap + ncap
+            p.csr = (torch.empty(ncap + 1, **i32), torch.empty(cap, **i32), torch.empty(cap, **f32),
+                     torch.empty(ncap + 1, **i32), torch.empty(cap, **i32), torch.empty(cap, **f32))
+        else:
+            p.csr = (None,) * 6
+        counts = torch.empty(4, **i64)
+        L = _lib.lib()
+        _lib.check(L.gda_dsampler_sample(_lib.ptr(self.in_ptr), _lib.ptr(self.in_src), self.num_nodes, self.num_edges,
+                                         self.max_in_degree, _lib.ptr(seeds_d), p.n_seeds, fan.ctypes.data, fan.size,
+                                         ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _lib.ptr(p.nodes),
+                                         _lib.ptr(p.ei[0]), _lib.ptr(p.ei[1]), *(_lib.ptr(t) for t in p.csr),
+                                         _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream()),
+                   "gda_dsampler_sample")
+        p.counts_host = torch.empty(4, dtype=torch.int64, pin_memory=True)
+        p.counts_host.copy_(counts, non_blocking=True)
+        p.event = torch.cuda.Event()
+        p.event.record(stream)
+        return p
+
+    def sample(self, seeds, fanouts, seed=0):
+        """-> (n_id, edge_index) on the device, like :meth:`NeighborSampler.sample` (tests)."""
+        p = self.enqueue(seeds, fanouts, seed, csr=False)
+        n, e, _ = p.wait()
+        return p.nodes[:n], p.ei[:, :e]
+
+    def graph_of(self, p, n, e, nnz):
+        """:class:`CSRGraph` views of a pending batch's CSR pair (what ``as_graph(edge_index, n)`` would build)."""
+        from .graph import CSRGraph
+        rp, ci, va, trp, tci, tva = p.csr
+        g = CSRGraph(n, n + e, rp[:n + 1], ci, va, trp[:n + 1], tci, tva)
+        g._nnz = nnz
+        g.transient = True
+        return g
+
+    def assemble(self, data, p, sizes=None):
+        """Consumer side (training stream): order behind the sampler's stream, gather the feature rows."""
+        n, e, nnz = sizes if sizes is not None else p.wait()
+        cur = torch.cuda.current_stream()
+        if p.stream != cur:
+            cur.wait_event(p.event)
+            for t in (p.nodes, p.ei, *p.csr):
+                if t is not None:
+                    t.record_stream(cur)          # allocated on the sampler's stream, consumed on this one
+        from .ops import gather_rows
+        n_id = p.nodes[:n]
+        ei = p.ei[:, :e]
+        ei._gda_trusted = True
+        if p.csr[0] is not None:
+            ei._gda_prebuilt = self.graph_of(p, n, e, nnz)
+        x = gather_rows(data.x, n_id)
+        y = None if data.y is None else data.y[n_id]
+        return Data(x=x, edge_index=ei, y=y, n_id=n_id, batch_size=p.n_seeds)

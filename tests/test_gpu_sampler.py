@@ -1,0 +1,154 @@
+"""GPU: the device neighbour sampler (csrc/gda_dsampler.hip) against the native host sampler it must reproduce bit
+for bit (same counter-based draws keyed on (seed, hop, node), same discovery order), its CSR pair against the device
+ingestion of the batch's edge list, and the loader path built on it (missing item 2;
+pygda/models/a2gnn.py:260-277 is the call site both samplers stand in for)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from pygda_amd import _lib
+from pygda_amd.data import Data, NeighborLoader
+from pygda_amd.graph import build_csr
+from pygda_amd.sampler import DeviceNeighborSampler, NeighborSampler
+from tests.test_gpu_parity import DEV, exact
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(n, e, seed, loops=False, multi=False):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    if loops:
+        ei = torch.cat([ei, torch.arange(0, n, 3).repeat(2, 1)], dim=1)
+    if multi:
+        ei = torch.cat([ei, ei[:, : e // 10]], dim=1)
+    return ei[:, torch.randperm(ei.size(1), generator=g)]
+
+
+def test_device_batches_match_the_pinned_digests():
+    """The digests of tests/test_sampler_host.py::test_sampled_batches_are_pinned, produced on the device."""
+    g = torch.Generator().manual_seed(123)
+    n, e = 5000, 60000
+    ei = torch.randint(0, n, (2, e), generator=g)
+    seeds = torch.randint(0, n, (64,), generator=g)
+    want = {((15, 10), 1): (3753, 7042, "0026048238023cad6cc2052ad5c720a8e8f9dec0"),
+            ((4, 4, 4), 2): (3007, 4486, "205d423fb5cad5a1dbd575f9ee688653b2170a5c"),
+            ((-1,), 3): (762, 770, "b3cee7c84ca0624bcfc695d4731097d8592e3cb3")}
+    S = DeviceNeighborSampler(ei.to(DEV), n)
+    assert S.max_in_degree == int(torch.bincount(ei[1], minlength=n).max())
+    for (fan, seed), (nn, ne, digest) in want.items():
+        assert S.supports(seeds.numel(), list(fan))
+        n_id, sub = S.sample(seeds, list(fan), seed=seed)
+        assert (n_id.numel(), sub.size(1)) == (nn, ne)
+        got = hashlib.sha1(n_id.cpu().numpy().tobytes() + sub.cpu().contiguous().numpy().tobytes()).hexdigest()
+        assert got == digest, (fan, seed)
+
+
+@pytest.mark.parametrize("fan", [[15, 10], [3, 2, 2], [-1, -1], [2, -1], [-1, 3], [1], [64, 1]])
+@pytest.mark.parametrize("variant", ["plain", "loops+multi"])
+def test_device_sampler_equals_host_sampler(fan, variant):
+    """Same nodes in the same order, same edges in the same order -- on graphs with self-loop edges, repeated edges,
+    isolated nodes and hubs, seeds with duplicates -- and the CSR pair equals what the device ingestion builds from
+    the batch's edge list, bit for bit (structure and weights, both orientations)."""
+    n = 3000
+    ei = _graph(n, 30000, 5, loops=variant != "plain", multi=variant != "plain")
+    ei = torch.cat([ei, torch.stack([torch.randint(0, n, (400,), generator=torch.Generator().manual_seed(2)),
+                                     torch.full((400,), 17)])], dim=1)          # a hub: 400 extra in-neighbours of node 17
+    ei = ei[:, ei[1] % 11 != 5]                                                  # nodes without in-neighbours
+    H = NeighborSampler(ei, n, threads=2)
+    D = DeviceNeighborSampler(ei.to(DEV), n)
+    g = torch.Generator().manual_seed(9)
+    for trial in range(3):
+        seeds = torch.randint(0, n, (97,), generator=g)
+        if trial == 1:
+            seeds = torch.cat([seeds, seeds[:13], torch.tensor([17, 17])])       # duplicates among the seeds
+        hn, he = H.sample(seeds, fan, seed=100 + trial)
+        p = D.enqueue(seeds, fan, seed=100 + trial)
+        nn, ne, nnz = p.wait()
+        exact(p.nodes[:nn], hn)
+        exact(p.ei[:, :ne], he)
+        G = build_csr(he.to(DEV), nn)
+        assert nnz == G.nnz
+        rp, ci, va, trp, tci, tva = p.csr
+        exact(rp[:nn + 1], G.rowptr[:nn + 1]); exact(trp[:nn + 1], G.t_rowptr[:nn + 1])
+        exact(ci[:nnz], G.colidx[:nnz]); exact(tci[:nnz], G.t_colidx[:nnz])
+        exact(va[:nnz].view(torch.int32), G.val[:nnz].view(torch.int32))
+        exact(tva[:nnz].view(torch.int32), G.t_val[:nnz].view(torch.int32))
+    # reproducible for a seed, different for another (when the fan-out leaves a choice)
+    a = D.sample(seeds, fan, seed=7); b = D.sample(seeds, fan, seed=7); c = D.sample(seeds, fan, seed=8)
+    exact(a[0], b[0]); exact(a[1], b[1])
+    if any(0 < k < 20 for k in fan):
+        assert a[1].shape != c[1].shape or not torch.equal(a[1], c[1])
+
+
+def test_device_sampler_rejects_what_it_cannot_do():
+    ei = _graph(50, 400, 1)
+    D = DeviceNeighborSampler(ei.to(DEV), 50)
+    assert not D.supports(8, [0]) and not D.supports(8, [65]) and D.supports(8, [64, -1])
+    with pytest.raises(_lib.GdaError):
+        D.sample(torch.tensor([3, 50]), [2])                                     # a seed outside the graph
+    with pytest.raises(IndexError):
+        DeviceNeighborSampler(torch.tensor([[0, 51], [1, 2]], device=DEV), 50)
+    # no edges at all: every batch is its seeds
+    Z = DeviceNeighborSampler(torch.empty(2, 0, dtype=torch.int64, device=DEV), 10)
+    n_id, sub = Z.sample(torch.tensor([4, 2, 4]), [3, 3])
+    exact(n_id, [4, 2]); assert sub.size(1) == 0
+
+
+@pytest.mark.parametrize("prefetch", [0, 2])
+def test_loader_on_the_device_sampler_equals_the_host_loader(monkeypatch, prefetch):
+    """NeighborLoader over GPU-resident data: batches (x, y, n_id, edge_index, batch_size) equal those of the host
+    sampler path, in order, with and without the prefetching producer thread; the batch carries the prebuilt
+    normalised graph, which equals the ingestion of its edge list."""
+    from pygda_amd.graph import as_graph
+    n = 4000
+    ei = _graph(n, 50000, 3, loops=True)
+    g = torch.Generator().manual_seed(0)
+    d = Data(x=torch.randn(n, 24, generator=g), edge_index=ei, y=torch.randint(0, 5, (n,), generator=g)).to(DEV)
+    kw = dict(batch_size=256, input_nodes=torch.randperm(n, generator=g)[:1500], device=DEV, prefetch=prefetch)
+    dev_loader = NeighborLoader(d, [6, 4], **kw)
+    dev_batches = list(dev_loader)
+    assert "device sampler" in dev_loader.sampler_description()
+    monkeypatch.setenv("PYGDA_AMD_DEVICE_SAMPLER", "0")
+    host_loader = NeighborLoader(d, [6, 4], **kw)
+    host_batches = list(host_loader)
+    assert "host sampler" in host_loader.sampler_description()
+    assert len(dev_batches) == len(host_batches) == 6
+    for a, b in zip(dev_batches, host_batches):
+        assert a.batch_size == b.batch_size
+        exact(a.n_id, b.n_id); exact(a.edge_index, b.edge_index); exact(a.x, b.x); exact(a.y, b.y)
+        ga = as_graph(a.edge_index, a.x.size(0))
+        assert ga is a.edge_index._gda_prebuilt and ga.transient
+        gb = build_csr(b.edge_index.contiguous(), b.x.size(0))
+        assert ga.nnz == gb.nnz
+        exact(ga.rowptr, gb.rowptr); exact(ga.colidx[:ga.nnz], gb.colidx[:gb.nnz])
+        exact(ga.val[:ga.nnz].view(torch.int32), gb.val[:gb.nnz].view(torch.int32))
+        exact(ga.t_colidx[:ga.nnz], gb.t_colidx[:gb.nnz])
+    # a second epoch draws different neighbourhoods (the epoch enters the RNG seed), same seeds
+    again = list(dev_loader)
+    exact(again[0].n_id[:256], dev_batches[0].n_id[:256])
+    assert again[0].n_id.numel() != dev_batches[0].n_id.numel() or not torch.equal(again[0].n_id, dev_batches[0].n_id)
+
+
+def test_sampled_training_no_longer_depends_on_host_sampler_threads():
+    """cfg-S style training through the trainer: the loaders pick the device sampler, the step trains."""
+    import pygda_amd
+    from bench import make_cfg_s
+    N = 200_000
+    src, tgt = make_cfg_s(N, 20, 64, 5, 200, DEV), make_cfg_s(N, 20, 64, 5, 201, DEV)
+    m = pygda_amd.models.A2GNN(64, 32, 5, num_layers=2, dropout=0.5, s_pnums=0, t_pnums=10, weight=10, lr=0.005,
+                               device=DEV, epoch=1, verbose=0, batch_size=512, num_neigh=[15, 10])
+    net, optimizer, step, alpha = m._prepare(src, tgt)
+    m.source_loader.input_nodes = m.source_loader.input_nodes[:4 * 512]
+    m.target_loader.input_nodes = m.target_loader.input_nodes[:4 * 512]
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+    torch.manual_seed(1)
+    m._train_epochs(net, optimizer, step, alpha)
+    assert "device sampler" in m.source_loader.sampler_description()
+    assert len(seen) == 1 and np.isfinite(seen[0][0])
+    logits, labels = m.predict(tgt)
+    assert logits.shape == (4 * 512, 5) and bool(torch.isfinite(logits).all())
+    exact(labels, tgt.y[:4 * 512])
