@@ -449,6 +449,17 @@ int gda_gather_rows_f32(const float* x, int64_t ldx, int64_t d, const int64_t* i
                         int64_t n_out, float* out, int64_t ldo, gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
+ * Graph-level readout (mode='graph'): PyG's global_mean_pool(x, batch) as pygda/nn/a2gnn_base.py:140-141 calls
+ * it on the collated batch of a DataLoader -- `batch` sorted, graph g = rows seg_ptr[g] .. seg_ptr[g+1].
+ * out[g] = (rows added in node order) / max(count, 1); backward gx[i] = gout[batch[i]] / max(count, 1).
+ * seg_ptr int64 [G+1], batch int64 [n] (device).
+ * ---------------------------------------------------------------------------- */
+int gda_segment_mean_fwd_f32(const float* x, int64_t ldx, const int64_t* seg_ptr, int64_t G, int64_t d,
+                             float* out, int64_t ldo, gda_stream_t stream);
+int gda_segment_mean_bwd_f32(const float* gout, int64_t ldg, const int64_t* seg_ptr, const int64_t* batch,
+                             int64_t n, int64_t d, float* gx, int64_t ldx, gda_stream_t stream);
+
+/* ------------------------------------------------------------------------------
  * Host neighbour sampler (mini-batch assembly; HOST pointers throughout).
  *
  * Replaces the C++ sampler behind PyG's NeighborLoader as pygda's trainers construct it

@@ -266,17 +266,39 @@ class Graph:
         self.x, self.edge_index, self.y = x, edge_index, y
 
 
+def global_mean_pool(x: Tensor, batch: Tensor, size: Optional[int] = None) -> Tensor:
+    """PyG ``global_mean_pool`` (a2gnn_base.py:141 on a DataLoader's collated batch): per-graph sum of the node rows
+    (scatter in node order) divided by the node count, clamped at 1."""
+    n = int(batch.max()) + 1 if size is None else size
+    total = torch.zeros(n, x.size(1), dtype=x.dtype).index_add_(0, batch, x)
+    count = torch.zeros(n, dtype=x.dtype).index_add_(0, batch, torch.ones(batch.numel(), dtype=x.dtype))
+    return total / count.clamp(min=1).view(-1, 1)
+
+
+def collate_graphs(graphs) -> "Graph":
+    """PyG ``Batch.from_data_list`` for the attributes graph mode reads (a2gnn.py:278-286 DataLoader batches):
+    ``x`` / ``y`` concatenated in list order, ``edge_index`` shifted by the nodes before each graph, ``batch``."""
+    counts = torch.tensor([g.x.size(0) for g in graphs], dtype=torch.long)
+    offs = (torch.cumsum(counts, 0) - counts).tolist()
+    out = Graph(torch.cat([g.x for g in graphs], 0),
+                torch.cat([g.edge_index + o for g, o in zip(graphs, offs)], 1),
+                torch.cat([g.y.reshape(-1) for g in graphs], 0))
+    out.batch = torch.repeat_interleave(torch.arange(len(graphs)), counts)
+    out.num_graphs = len(graphs)
+    return out
+
+
 class A2GNNBase(nn.Module):
-    """a2gnn_base.py:11-203 (node mode)."""
+    """a2gnn_base.py:11-203 (``mode='node'``; ``mode='graph'``: mean readout per graph :140-141, linear classifier)."""
 
     def __init__(self, in_dim, hid_dim, num_classes, num_layers=1, adv=False,
-                 dropout=0.1, act=F.relu):
+                 dropout=0.1, act=F.relu, mode="node"):
         super().__init__()
-        self.dropout, self.act, self.adv = dropout, act, adv
+        self.dropout, self.act, self.adv, self.mode = dropout, act, adv, mode
         self.convs = nn.ModuleList([PropGCNConv(in_dim, hid_dim)])
         for _ in range(num_layers - 1):
             self.convs.append(PropGCNConv(hid_dim, hid_dim))
-        self.cls = PropGCNConv(hid_dim, num_classes)
+        self.cls = PropGCNConv(hid_dim, num_classes) if mode == "node" else nn.Linear(hid_dim, num_classes)
         if adv:
             self.domain_discriminator = nn.Linear(hid_dim, 2)
 
@@ -285,17 +307,20 @@ class A2GNNBase(nn.Module):
             x = conv(x, edge_index, prop_nums)
             x = self.act(x)
             x = F.dropout(x, p=self.dropout, training=self.training)
+        if self.mode == "graph":                                             # :140-141
+            x = global_mean_pool(x, batch)
         return x
 
     def feat_classifier(self, x, edge_index, batch=None, prop_nums=1):       # :145-176
-        return self.cls(x, edge_index, prop_nums)
+        return self.cls(x, edge_index, prop_nums) if self.mode == "node" else self.cls(x)
 
     def domain_classifier(self, x, alpha):                                   # :178-203
         return self.domain_discriminator(grad_reverse(x, alpha))
 
     def forward(self, data, prop_nums):                                      # :72-104
-        x = self.feat_bottleneck(data.x, data.edge_index, None, prop_nums)
-        return self.feat_classifier(x, data.edge_index, None, 1)
+        batch = None if self.mode == "node" else data.batch
+        x = self.feat_bottleneck(data.x, data.edge_index, batch, prop_nums)
+        return self.feat_classifier(x, data.edge_index, batch, 1)
 
 
 def a2gnn_forward_model(net: A2GNNBase, src: Graph, tgt: Graph, alpha: float,
@@ -305,8 +330,9 @@ def a2gnn_forward_model(net: A2GNNBase, src: Graph, tgt: Graph, alpha: float,
     target forward (:211) is returned but not part of the loss."""
     source_logits = net(src, s_pnums)                                        # :181
     loss = F.nll_loss(F.log_softmax(source_logits, dim=1), src.y)            # :182
-    sf = net.feat_bottleneck(src.x, src.edge_index, None, s_pnums)           # :192
-    tf = net.feat_bottleneck(tgt.x, tgt.edge_index, None, t_pnums)           # :193
+    sb, tb = getattr(src, "batch", None), getattr(tgt, "batch", None)        # :186-190 (None in node mode)
+    sf = net.feat_bottleneck(src.x, src.edge_index, sb, s_pnums)             # :192
+    tf = net.feat_bottleneck(tgt.x, tgt.edge_index, tb, t_pnums)             # :193
     if adv:                                                                  # :196-205
         sd = net.domain_classifier(sf, alpha)
         td = net.domain_classifier(tf, alpha)

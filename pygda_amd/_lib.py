@@ -63,6 +63,8 @@ _SIGNATURES = {
     "gda_relu_dropout_fwd_f32": (c_int, [_P, _P, c_int64, c_float, ctypes.c_uint64, _P, ctypes.c_uint32, _P]),
     "gda_relu_dropout_bwd_f32": (c_int, [_P, _P, _P, c_int64, c_float, _P]),
     "gda_gather_rows_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P]),
+    "gda_segment_mean_fwd_f32": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, c_int64, _P]),
+    "gda_segment_mean_bwd_f32": (c_int, [_P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, _P]),
     "gda_sampler_create": (c_int, [_P, _P, c_int64, c_int64, ctypes.POINTER(c_void_p)]),
     "gda_sampler_destroy": (None, [_P]),
     "gda_sampler_set_threads": (c_int, [_P, c_int]),

@@ -24,6 +24,37 @@ k_gather(const float* __restrict__ x, int64_t ldx, int d, const int64_t* __restr
     }
 }
 
+// Graph-level readout  out[g, :] = (sum of x[seg[g] .. seg[g+1], :]) / max(seg[g+1] - seg[g], 1)  -- PyG's
+// global_mean_pool(x, batch) for the sorted `batch` vector a DataLoader produces (pygda/nn/a2gnn_base.py:140-141):
+// the rows of a graph are added in node order (the CPU scatter's order), then divided by the node count.
+// One thread per (graph, column): a graph of the TU datasets has tens of nodes; reads are coalesced across columns.
+__global__ void __launch_bounds__(TB)
+k_segment_mean_fwd(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ seg, int64_t G, int d,
+                   float* __restrict__ out, int64_t ldo) {
+    const int64_t s = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (s >= G * d) return;
+    const int64_t g = s / d;
+    const int c = (int)(s % d);
+    const int64_t b = seg[g], e = seg[g + 1];
+    float acc = 0.f;
+    for (int64_t r = b; r < e; ++r) acc = __fadd_rn(acc, x[r * ldx + c]);
+    const float cnt = (float)(e - b > 1 ? e - b : 1);
+    out[g * ldo + c] = __fdiv_rn(acc, cnt);
+}
+
+// gx[i, :] = gout[batch[i], :] / max(count(batch[i]), 1)
+__global__ void __launch_bounds__(TB)
+k_segment_mean_bwd(const float* __restrict__ gout, int64_t ldg, const int64_t* __restrict__ seg,
+                   const int64_t* __restrict__ batch, int64_t n, int d, float* __restrict__ gx, int64_t ldx) {
+    const int64_t s = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (s >= n * d) return;
+    const int64_t i = s / d;
+    const int c = (int)(s % d);
+    const int64_t g = batch[i];
+    const int64_t m = seg[g + 1] - seg[g];
+    gx[i * ldx + c] = __fdiv_rn(gout[g * ldg + c], (float)(m > 1 ? m : 1));
+}
+
 }  // namespace
 
 extern "C" int gda_abi_version(void) { return 1; }
@@ -56,6 +87,26 @@ extern "C" int gda_gather_rows_f32(const float* x, int64_t ldx, int64_t d, const
     if (grid > 256 * 16) grid = 256 * 16;                     // grid-stride beyond 16 workgroups per CU
     if (v4) k_gather<4><<<(unsigned)grid, TB, 0, stream>>>(x, ldx, (int)d, idx, n_out, out, ldo);
     else k_gather<1><<<(unsigned)grid, TB, 0, stream>>>(x, ldx, (int)d, idx, n_out, out, ldo);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+extern "C" int gda_segment_mean_fwd_f32(const float* x, int64_t ldx, const int64_t* seg_ptr, int64_t G, int64_t d,
+                                        float* out, int64_t ldo, gda_stream_t stream_) {
+    if (G < 0 || d < 0 || d >= INT32_MAX || ldx < d || ldo < d) return GDA_E_SIZE;
+    if (G == 0 || d == 0) return GDA_OK;
+    if (!x || !seg_ptr || !out) return GDA_E_NULL;
+    k_segment_mean_fwd<<<(unsigned)gda_cdiv(G * d, TB), TB, 0, (hipStream_t)stream_>>>(x, ldx, seg_ptr, G, (int)d, out, ldo);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+extern "C" int gda_segment_mean_bwd_f32(const float* gout, int64_t ldg, const int64_t* seg_ptr, const int64_t* batch,
+                                        int64_t n, int64_t d, float* gx, int64_t ldx, gda_stream_t stream_) {
+    if (n < 0 || d < 0 || d >= INT32_MAX || ldx < d || ldg < d) return GDA_E_SIZE;
+    if (n == 0 || d == 0) return GDA_OK;
+    if (!gout || !seg_ptr || !batch || !gx) return GDA_E_NULL;
+    k_segment_mean_bwd<<<(unsigned)gda_cdiv(n * d, TB), TB, 0, (hipStream_t)stream_>>>(gout, ldg, seg_ptr, batch, n, (int)d, gx, ldx);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }

@@ -4,6 +4,7 @@ pygda/models/a2gnn.py:254-286).  Full-batch loading hands out the graph itself (
 the device after the first ``.to``); fan-out sampling is done by the native host sampler
 (pygda_amd/sampler.py)."""
 import torch
+import torch.utils.data
 
 
 class Data:
@@ -258,9 +259,46 @@ class NeighborLoader:
                     th.join(timeout=0.01)
 
 
-class DataLoader:
-    """Graph-level mini-batching (``mode='graph'``) is outside this build's scope."""
+def collate_graphs(graphs):
+    """PyG's ``Batch.from_data_list`` for what pygda's graph mode reads: ``x`` / ``y`` concatenated in list order,
+    ``edge_index`` with every graph's node ids shifted by the nodes before it, ``batch`` = graph index per node
+    (sorted by construction), ``num_graphs``."""
+    counts = torch.tensor([g.x.size(0) for g in graphs], dtype=torch.long)
+    offs = (torch.cumsum(counts, 0) - counts).tolist()
+    ei = [g.edge_index + o for g, o in zip(graphs, offs)]
+    b = Data(x=torch.cat([g.x for g in graphs], dim=0),
+             edge_index=torch.cat(ei, dim=1) if ei else torch.empty(2, 0, dtype=torch.long),
+             y=torch.cat([g.y.reshape(-1) for g in graphs], dim=0),
+             batch=torch.repeat_interleave(torch.arange(len(graphs)), counts), num_graphs=len(graphs))
+    return b
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("graph-classification mode (mode='graph') is out of scope; "
-                                  "see DESIGN.md, section 'Out of scope'")
+
+class _GraphBatch(Data):
+    """A collated batch: ``.to(device)`` tags the device copy of ``batch`` as sorted and with its graph count, so
+    the readout needs no device check and no read-back."""
+
+    def to(self, device, non_blocking=False):
+        hit = super().to(device, non_blocking)
+        if hit.batch is not None:
+            hit.batch._gda_sorted = True
+            hit.batch._gda_num_graphs = self.num_graphs
+        return hit
+
+
+def _collate(graphs):
+    b = collate_graphs(graphs)
+    out = _GraphBatch(**{k: getattr(b, k) for k in ("x", "edge_index", "y", "batch", "num_graphs")})
+    out.batch._gda_sorted = True
+    out.batch._gda_num_graphs = out.num_graphs
+    return out
+
+
+class DataLoader(torch.utils.data.DataLoader):
+    """``torch_geometric.loader.DataLoader(dataset, batch_size, shuffle)`` as a2gnn.py:278-286 builds it: torch's own
+    loader (its shuffling draws -- the iterator's base seed, then the sampler's seed -- come from the default CPU
+    generator exactly as with PyG, whose DataLoader is the same class) with the collation above.  ``dataset``: any
+    sequence of ``Data``-like graphs (``x``, ``edge_index``, ``y`` with one label per graph)."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=False, **kwargs):
+        kwargs.pop("collate_fn", None)
+        super().__init__(dataset, batch_size=batch_size, shuffle=shuffle, collate_fn=_collate, **kwargs)

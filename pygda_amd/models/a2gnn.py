@@ -82,6 +82,12 @@ class A2GNN(BaseGDA):
 
     def _domain_loss(self, loss, source_features, target_features, alpha):
         net = self.a2gnn
+        if self.adv and self.mode != 'node':
+            # the reference sizes its domain labels by NODE counts (:199-203) while the pooled features have one row
+            # per graph: F.cross_entropy raises ValueError there -- the same error, named
+            raise ValueError(f"Expected input batch_size ({source_features.size(0) + target_features.size(0)}) to match "
+                             "target batch_size (the node count): adv=True is not defined for mode='graph' in pygda "
+                             "(a2gnn.py:199-204)")
         if self.adv:                                                                     # :196-205, fused
             disc = net.domain_discriminator
             dom = grl_disc_ce(source_features, target_features, disc.weight, disc.bias, alpha)
@@ -193,13 +199,21 @@ class A2GNN(BaseGDA):
 
     def _prepare(self, source_data, target_data):
         """Everything fit() does before its epoch loop (a2gnn.py:254-296)."""
-        if self.mode != 'node':
-            raise NotImplementedError("mode='graph' is out of scope (DESIGN.md)")
-        self._node_loaders(source_data, target_data)
+        if self.mode == 'node':
+            self._node_loaders(source_data, target_data)
+        elif self.mode == 'graph':                                                         # :278-286
+            from ..data import DataLoader
+            bs_s = len(source_data) if self.batch_size == 0 else self.batch_size
+            bs_t = len(target_data) if self.batch_size == 0 else self.batch_size
+            self.source_loader = DataLoader(source_data, batch_size=bs_s, shuffle=True)
+            self.target_loader = DataLoader(target_data, batch_size=bs_t, shuffle=True)
+        else:
+            assert self.mode in ('graph', 'node'), 'Invalid train mode'                  # :288
         self.a2gnn = self.init_model(**self.kwargs)
         # the MMD branch never reads alpha/epoch; the adversarial branch reads the GRL alpha, which the
         # captured step receives as a 0-dim device tensor refreshed per epoch: both replay as a hipGraph
-        self._graph_safe_step, self._graph_uses_scalars = True, bool(self.adv)
+        # (graph mode re-collates a shuffled batch every epoch: nothing static to capture)
+        self._graph_safe_step, self._graph_uses_scalars = self.mode == 'node', bool(self.adv)
         # the MMD step reads no per-epoch scalar: consecutive steps may share one capture (hipgraph.GraphedStep.unroll)
         self._graph_unroll_ok = not self.adv and type(self) is A2GNN
         on_gpu = torch.device(self.device).type == "cuda"

@@ -9,12 +9,13 @@ from .reverse_layer import GradReverse
 
 
 def global_mean_pool(x, batch, size=None):
-    """Per-graph mean of node rows (graph mode only; plain torch, off the hot path)."""
-    import torch
-    n = int(batch.max()) + 1 if size is None else size
-    out = torch.zeros(n, x.size(1), dtype=x.dtype, device=x.device).index_add_(0, batch, x)
-    cnt = torch.zeros(n, dtype=x.dtype, device=x.device).index_add_(0, batch, torch.ones_like(batch, dtype=x.dtype))
-    return out / cnt.clamp(min=1).unsqueeze(1)
+    """PyG's ``global_mean_pool`` as a2gnn_base.py:141 calls it on a collated batch: per-graph mean of the node
+    rows (``gda_segment_mean_fwd/bwd_f32``); ``size`` defaults to the loader's ``num_graphs`` when the batch
+    vector carries it."""
+    from ..ops import segment_mean
+    if size is None:
+        size = getattr(batch, "_gda_num_graphs", None)
+    return segment_mean(x, batch, size)
 
 
 class A2GNNBase(nn.Module):

@@ -837,6 +837,53 @@ def gather_rows(x, idx):
     return out
 
 
+# ---------------------------------------------------------- graph-level readout --
+class _SegmentMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, seg_ptr, batch):
+        x = _f32c(x, "x")
+        G, d = seg_ptr.numel() - 1, x.size(1)
+        out = torch.empty(G, d, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().gda_segment_mean_fwd_f32(_lib.ptr(x), d, _lib.ptr(seg_ptr), G, d, _lib.ptr(out), d,
+                                                       _lib.stream()), "gda_segment_mean_fwd_f32")
+        ctx.save_for_backward(seg_ptr, batch)
+        ctx.n = x.size(0)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        seg_ptr, batch = ctx.saved_tensors
+        gout = gout.contiguous()
+        d = gout.size(1)
+        gx = torch.empty(ctx.n, d, dtype=torch.float32, device=gout.device)
+        _lib.check(_lib.lib().gda_segment_mean_bwd_f32(_lib.ptr(gout), d, _lib.ptr(seg_ptr), _lib.ptr(batch), ctx.n, d,
+                                                       _lib.ptr(gx), d, _lib.stream()), "gda_segment_mean_bwd_f32")
+        return gx, None, None
+
+
+def segment_ptr(batch, size=None):
+    """``seg_ptr [G+1]`` of a SORTED graph-index vector (what a DataLoader's collation produces), cached on the
+    tensor; an unsorted vector is rejected (one device check per vector): the readout kernel walks contiguous rows."""
+    hit = getattr(batch, "_gda_seg_ptr", None)
+    if hit is not None and (size is None or hit.numel() - 1 == size):
+        return hit
+    _lib.require_gpu_tensor(batch, "batch", torch.int64)
+    if batch.numel() > 1 and not getattr(batch, "_gda_sorted", False) and bool((batch[1:] < batch[:-1]).any()):
+        raise ValueError("global_mean_pool: `batch` must be sorted (nodes of a graph contiguous), as PyG's DataLoader "
+                         "collates it")
+    G = (int(batch[-1]) + 1 if batch.numel() else 0) if size is None else int(size)
+    seg = torch.zeros(G + 1, dtype=torch.int64, device=batch.device)
+    if batch.numel():
+        seg[1:] = torch.cumsum(torch.bincount(batch, minlength=G), 0)
+    batch._gda_seg_ptr = seg
+    return seg
+
+
+def segment_mean(x, batch, size=None):
+    """``global_mean_pool(x, batch)`` (pygda/nn/a2gnn_base.py:141) for a sorted ``batch``."""
+    return _SegmentMean.apply(x, segment_ptr(batch, size), batch.contiguous())
+
+
 # ------------------------------------------------------------ ReLU + dropout (fused) --
 class _DropoutState:
     """Device step counter + per-step call-site numbering for the fused activation's generator."""

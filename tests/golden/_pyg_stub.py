@@ -31,6 +31,12 @@ boundary" (the MMD / GradReverse / Attention goldens do not go through it).
  9. (dgsda_base.py only) ``get_laplacian(normalization='sym')`` removes self loops, takes the
     degree over ``row`` and returns ``-D^-1/2 W D^-1/2`` followed by N diagonal ones;
     ``add_self_loops`` appends N loops with the fill value.
+11. (graph mode only) ``torch_geometric.loader.DataLoader(dataset, batch_size, shuffle)`` is torch's own
+    ``DataLoader`` (real: its RNG draws -- the iterator's base seed, then the RandomSampler's seed, both from the
+    default CPU generator -- are the installed torch's) with PyG's collation: ``x`` / ``y`` concatenated in list
+    order, ``edge_index`` concatenated with every graph's node ids shifted by the nodes before it, ``batch`` =
+    graph index per node, ``num_graphs``.  ``global_mean_pool(x, batch)`` = per-graph sum (index_add in node
+    order) divided by the node count (clamped at 1).
 10. (reweight_gnn.py / strurw.py only) ``MessagePassing(aggr='mean', flow='target_to_source')``:
     messages from ``x[edge_index[1]]`` averaged at ``edge_index[0]`` over the number of messages;
     ``update`` receives the propagate kwargs it names; ``to_dense_adj`` sums duplicate edges;
@@ -43,6 +49,7 @@ import types
 from typing import Optional, Tuple
 
 import torch
+import torch.utils.data
 from torch import Tensor
 
 
@@ -333,9 +340,21 @@ class NeighborLoader:
         return 1
 
 
-class DataLoader:
-    def __init__(self, *a, **k):
-        raise NotImplementedError('graph mode is out of scope')
+def collate_graphs(graphs):
+    """PyG ``Batch.from_data_list`` for the attributes pygda's graph mode reads (assumption 11)."""
+    counts = torch.tensor([g.x.size(0) for g in graphs], dtype=torch.long)
+    offs = torch.cumsum(counts, 0) - counts
+    b = Data(x=torch.cat([g.x for g in graphs], dim=0),
+             edge_index=torch.cat([g.edge_index + o for g, o in zip(graphs, offs.tolist())], dim=1),
+             y=torch.cat([g.y.reshape(-1) for g in graphs], dim=0))
+    b.batch = torch.repeat_interleave(torch.arange(len(graphs)), counts)
+    b.num_graphs = len(graphs)
+    return b
+
+
+class DataLoader(torch.utils.data.DataLoader):
+    def __init__(self, dataset, batch_size=1, shuffle=False, **kw):
+        super().__init__(dataset, batch_size=batch_size, shuffle=shuffle, collate_fn=collate_graphs, **kw)
 
 
 def install():

@@ -763,6 +763,83 @@ def fx_strurw_mixup(ref):
 FIXTURES["strurw_mixup"] = fx_strurw_mixup
 
 
+def _graph_dataset(seed, count, f=10, c=3):
+    """A list of small graphs (4-14 nodes, undirected, a few isolated nodes), one label per graph: the shape of the
+    TU datasets ``benchmark/graph/a2gnn.py`` feeds ``A2GNN(mode='graph')``."""
+    stub = _pyg_stub
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(count):
+        n = int(torch.randint(4, 15, (1,), generator=g))
+        e = int(torch.randint(n, 3 * n, (1,), generator=g))
+        ei = torch.randint(0, n - 1, (2, e), generator=g)            # node n-1 isolated
+        ei = torch.cat([ei, ei.flip(0)], dim=1)
+        out.append(stub.Data(x=torch.randn(n, f, generator=g), edge_index=ei,
+                             y=torch.randint(0, c, (1,), generator=g)))
+    return out
+
+
+def _dataset_arrays(prefix, graphs):
+    arrs = {f"{prefix}/count": np.int64(len(graphs))}
+    for i, gr in enumerate(graphs):
+        arrs[f"{prefix}/{i}/x"], arrs[f"{prefix}/{i}/ei"], arrs[f"{prefix}/{i}/y"] = np_(gr.x), np_(gr.edge_index), np_(gr.y)
+    return arrs
+
+
+def fx_a2gnn_graph(ref):
+    """``A2GNN(mode='graph')`` (a2gnn_base.py:140-141 global_mean_pool, linear classifier; a2gnn.py:278-286
+    DataLoader(shuffle=True)): forward_model on one collated batch pair (loss, logits, every gradient, MMD and
+    adversarial), and a 3-epoch fit()/predict() from a fixed seed -- the shuffles and the MMD draws all come from the
+    default CPU generator, in the installed torch's DataLoader order."""
+    stub = _pyg_stub
+    src, tgt = _graph_dataset(71, 14), _graph_dataset(72, 11)
+    base = dict(_dataset_arrays("src", src), **_dataset_arrays("tgt", tgt))
+    # adv=True cannot run in graph mode in the reference: its domain labels are sized by NODE counts (a2gnn.py:199-203)
+    # while the pooled features have one row per graph -> F.cross_entropy raises ValueError
+    for adv in (False,):
+        m = ref.A2GNN(10, 16, 3, mode='graph', num_layers=2, dropout=0.0, s_pnums=0, t_pnums=5, adv=adv,
+                      weight=0.5, device="cpu", epoch=3, verbose=0)
+        torch.manual_seed(61)
+        m.a2gnn = m.init_model()
+        m.a2gnn.train()
+        sb, tb = stub.collate_graphs(src), stub.collate_graphs(tgt)
+        torch.manual_seed(62)
+        loss, sl, tl = m.forward_model(sb, tb, 0.4)
+        loss.backward()
+        arrs = dict(base, loss=np_(loss), src_logits=np_(sl), tgt_logits=np_(tl), alpha=np.float64(0.4),
+                    mmd_seed=np.int64(62), init_seed=np.int64(61),
+                    pooled_src=np_(m.a2gnn.feat_bottleneck(sb.x, sb.edge_index, sb.batch, 0)))
+        arrs.update(sd_arrays(m.a2gnn)); arrs.update(grads(m.a2gnn))
+        save("a2gnn_graph_forward_adv" if adv else "a2gnn_graph_forward_mmd", **arrs)
+    import pygda.models.a2gnn as a2mod
+    losses, accs = [], []
+    orig = a2mod.logger
+    a2mod.logger = lambda **kw: (losses.append(kw["loss"]), accs.append(kw["source_train_acc"]))
+    try:
+        for batch_size in (0, 6):
+            losses.clear(); accs.clear()
+            m = ref.A2GNN(10, 16, 3, mode='graph', num_layers=2, dropout=0.0, s_pnums=0, t_pnums=5, adv=False,
+                          weight=0.5, lr=0.01, weight_decay=0.001, device="cpu", epoch=3, verbose=0,
+                          batch_size=batch_size)
+            torch.manual_seed(63)
+            m.fit(src, tgt)
+            rng_after_fit = torch.get_rng_state()
+            # predict() draws a shuffle too (the stored loaders are shuffle=True); with several batches the reference
+            # keeps only the last one (a2gnn.py:402-409), so the full-batch run is the one predict() is recorded for
+            arrs = dict(base, seed=np.int64(63), losses=np.array(losses, dtype=np.float64),
+                        accs=np.array(accs, dtype=np.float64), batch_size=np.int64(batch_size))
+            if batch_size == 0:
+                logits, labels = m.predict(tgt)
+                arrs.update(tgt_logits=np_(logits), tgt_labels=np_(labels))
+            arrs.update(sd_arrays(m.a2gnn, "final/"))
+            save(f"a2gnn_graph_fit3_b{batch_size}", **arrs)
+    finally:
+        a2mod.logger = orig
+
+
+FIXTURES["a2gnn_graph"] = fx_a2gnn_graph
+
+
 def main(argv):
     ref = load_reference()
     for name in (argv or list(FIXTURES)):

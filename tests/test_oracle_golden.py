@@ -149,6 +149,62 @@ def test_a2gnn_fit_trajectory(adv):
         eq(net(tgt, 10), g["tgt_logits"]); eq(net(src, 0), g["src_logits"])
 
 
+def _graph_dataset(g, prefix):
+    return [O.Graph(T(g[f"{prefix}/{i}/x"]), T(g[f"{prefix}/{i}/ei"]), T(g[f"{prefix}/{i}/y"]))
+            for i in range(int(g[f"{prefix}/count"]))]
+
+
+def test_a2gnn_graph_mode_forward_model():
+    """mode='graph' (a2gnn_base.py:140-141 readout, linear classifier): loss, logits, pooled features and every
+    gradient of one forward_model over the collated datasets, against the reference run through the stub."""
+    g = load_golden("a2gnn_graph_forward_mmd")
+    src, tgt = O.collate_graphs(_graph_dataset(g, "src")), O.collate_graphs(_graph_dataset(g, "tgt"))
+    torch.manual_seed(int(g["init_seed"]))
+    net = O.A2GNNBase(10, 16, 3, num_layers=2, dropout=0.0, mode="graph")
+    for k, v in sub(g, "param/").items():
+        eq(net.state_dict()[k], v)
+    net.train()
+    eq(net.feat_bottleneck(src.x, src.edge_index, src.batch, 0), g["pooled_src"])
+    torch.manual_seed(int(g["mmd_seed"]))
+    loss, sl, tl = O.a2gnn_forward_model(net, src, tgt, float(g["alpha"]), 0, 5, False, 0.5)
+    loss.backward()
+    eq(loss, g["loss"]); eq(sl, g["src_logits"]); eq(tl, g["tgt_logits"])
+    for k, v in sub(g, "grad/").items():
+        eq(dict(net.named_parameters())[k].grad, v)
+
+
+@pytest.mark.parametrize("batch_size", [0, 6])
+def test_a2gnn_graph_mode_fit_trajectory(batch_size):
+    """Three epochs of a2gnn.py:300-336 over DataLoader(shuffle=True) batches (:278-286): torch's own loader draws the
+    shuffles from the default CPU generator between the MMD draws; full batch and three / two batches of six."""
+    import torch.utils.data as tud
+    g = load_golden(f"a2gnn_graph_fit3_b{batch_size}")
+    src, tgt = _graph_dataset(g, "src"), _graph_dataset(g, "tgt")
+    torch.manual_seed(int(g["seed"]))
+    mk = lambda ds: tud.DataLoader(ds, batch_size=batch_size or len(ds), shuffle=True, collate_fn=O.collate_graphs)
+    sl_, tl_ = mk(src), mk(tgt)
+    net = O.A2GNNBase(10, 16, 3, num_layers=2, dropout=0.0, mode="graph")
+    opt = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=0.001)
+    losses, accs = [], []
+    for epoch in range(3):
+        tot, logits, labels = 0.0, [], []
+        for sb, tb in zip(sl_, tl_):
+            val, s_logits = O.a2gnn_train_step(net, opt, sb, tb, 0.0, 0, 5, False, 0.5)
+            tot += val
+            logits.append(s_logits.detach()); labels.append(sb.y)
+        losses.append(tot)
+        accs.append(float((torch.cat(logits).argmax(1) == torch.cat(labels)).float().mean()))
+    eq(np.array(losses), g["losses"])
+    np.testing.assert_allclose(accs, g["accs"], atol=1e-12)
+    for k, v in sub(g, "final/").items():
+        eq(net.state_dict()[k], v)
+    if batch_size == 0:
+        net.eval()
+        with torch.no_grad():
+            for tb in tl_:
+                eq(net(tb, 5), g["tgt_logits"]); eq(tb.y, g["tgt_labels"])
+
+
 @pytest.mark.parametrize("disc", ["JS", "MMD"])
 def test_grade_forward_model(disc):
     g = load_golden(f"grade_forward_{disc.lower()}")
