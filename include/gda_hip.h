@@ -670,6 +670,17 @@ int gda_gemm_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int6
 int gda_gemm_ex_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                     const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, float* colsum,
                     void* workspace, size_t workspace_bytes, gda_stream_t stream);
+/* The same products for the shapes of sampled sub-graphs (10^5 .. 10^7 rows against a weight whose extents are 128 or
+ * 256; pygda/nn/prop_gcn_conv.py:205 on a NeighborLoader batch): the weight lives in registers as ready MFMA operands,
+ * only the tall operand streams through LDS (NT / NN), and the weight gradient (TN) reads both operands along their
+ * rows with the whole output of a row slab in accumulators (csrc/gda_gemm.hip, "tall products").
+ *   NT / NN: N in {128, 256}, K in {128, 256}, A 16-byte aligned with lda % 4 == 0;
+ *   TN: M == 128 (the output rows = columns of A), N in {128, 256}, K = the node count; colsum as in gda_gemm_ex_f32.
+ * GDA_E_UNSUPPORTED outside that envelope -- callers then use gda_gemm_ex_f32, which takes any shape. */
+size_t gda_gemm_tall_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K);
+int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                      const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, float* colsum,
+                      void* workspace, size_t workspace_bytes, gda_stream_t stream);
 
 
 /* C = A * A of a CSR operator on the host (threaded, deterministic order), for STATIC full-batch

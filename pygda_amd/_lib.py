@@ -128,6 +128,9 @@ _SIGNATURES = {
                              _P, c_size_t, _P]),
     "gda_gemm_ex_f32": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, _P,
                                 _P, c_size_t, _P]),
+    "gda_gemm_tall_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64]),
+    "gda_gemm_tall_f32": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, _P,
+                                  _P, c_size_t, _P]),
     "gda_adam_multi_f32": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, c_float, _P]),
     "gda_rccl_load": (c_int, [ctypes.c_char_p]),
     "gda_comm_unique_id": (c_int, [_P, c_size_t]),

@@ -168,38 +168,53 @@ __global__ void k_ds_setm(DsCnt* __restrict__ cnt, const int32_t* __restrict__ p
     cnt->m = m;
 }
 
-// nodes with more in-neighbours than the fan-out: k distinct positions by the host sampler's partial Fisher-Yates,
-// on a sparse map of the touched positions, then in list order
-__global__ void k_ds_pick_rng(const int64_t* __restrict__ in_ptr, const int32_t* __restrict__ in_src,
-                              const int64_t* __restrict__ nodes, const DsCnt* __restrict__ cnt, int k, int hop, uint64_t rng_seed,
-                              const int32_t* __restrict__ pick_off, int64_t pcap, int32_t* __restrict__ cand) {
-    const int64_t f = (int64_t)blockIdx.x * DS_TB + threadIdx.x;
+// nodes with more in-neighbours than the fan-out: k distinct positions by the host sampler's partial Fisher-Yates
+// (scratch[j] <-> scratch[j + below(deg - j)] for j < k over scratch = identity), then in list order.  The array is
+// never materialised: positions < k live in a dense k-entry table, the touched positions >= k (at most k) in a small
+// key / value list -- 3 k words per lane, in LDS (lane-interleaved: conflict-free), one wave per workgroup.
+constexpr int DS_PICK_TB = 64;
+
+__global__ void __launch_bounds__(DS_PICK_TB)
+k_ds_pick_rng(const int64_t* __restrict__ in_ptr, const int32_t* __restrict__ in_src,
+              const int64_t* __restrict__ nodes, const DsCnt* __restrict__ cnt, int k, int hop, uint64_t rng_seed,
+              const int32_t* __restrict__ pick_off, int64_t pcap, int32_t* __restrict__ cand) {
+    extern __shared__ int32_t ds_sm[];
+    const int lane = threadIdx.x;
+    const int64_t f = (int64_t)blockIdx.x * DS_PICK_TB + lane;
     if (f >= cnt->fe - cnt->fb) return;
     const int64_t v = nodes[cnt->fb + f];
     const int64_t b = in_ptr[v], deg = in_ptr[v + 1] - b;
     if (k < 0 || deg <= k) return;
-    int32_t key[2 * DS_MAXK], val[2 * DS_MAXK];
+    int32_t* dense = ds_sm + lane;                           // entry j at dense[j * 64]
+    int32_t* skey = ds_sm + (size_t)k * DS_PICK_TB + lane;
+    int32_t* sval = ds_sm + (size_t)2 * k * DS_PICK_TB + lane;
+    for (int j = 0; j < k; ++j) dense[j * DS_PICK_TB] = j;
     int used = 0;
     SplitMix rng(rng_seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(hop + 1)) ^ (0x9E3779B97F4A7C15ull * (uint64_t)(v + 1)));
     for (int j = 0; j < k; ++j) {
         const int32_t r = (int32_t)(j + (int64_t)rng.below((uint64_t)(deg - j)));
-        int ij = -1, ir = -1;
-        for (int t = 0; t < used; ++t) { if (key[t] == j) ij = t; if (key[t] == r) ir = t; }
-        const int32_t aj = ij >= 0 ? val[ij] : j, ar = ir >= 0 ? val[ir] : r;
-        if (ij >= 0) val[ij] = ar; else { key[used] = j; val[used] = ar; ++used; }
-        if (r != j) { if (ir >= 0) val[ir] = aj; else { key[used] = r; val[used] = aj; ++used; } }
+        const int32_t aj = dense[j * DS_PICK_TB];
+        int32_t ar;
+        if (r < k) {
+            ar = dense[r * DS_PICK_TB];
+            dense[r * DS_PICK_TB] = aj;
+        } else {
+            int ir = -1;
+            for (int t = 0; t < used; ++t) if (skey[t * DS_PICK_TB] == r) ir = t;
+            if (ir >= 0) { ar = sval[ir * DS_PICK_TB]; sval[ir * DS_PICK_TB] = aj; }
+            else { ar = r; skey[used * DS_PICK_TB] = r; sval[used * DS_PICK_TB] = aj; ++used; }
+        }
+        dense[j * DS_PICK_TB] = ar;
     }
-    int32_t pos[DS_MAXK];
-    for (int j = 0; j < k; ++j) {
-        int32_t a = j;
-        for (int t = 0; t < used; ++t) if (key[t] == j) a = val[t];
-        int i = j;                                   // insertion sort: the kept edges stay in edge order
-        while (i > 0 && pos[i - 1] > a) { pos[i] = pos[i - 1]; --i; }
-        pos[i] = a;
+    for (int j = 1; j < k; ++j) {                             // insertion sort: the kept edges stay in edge order
+        const int32_t a = dense[j * DS_PICK_TB];
+        int i = j;
+        while (i > 0 && dense[(i - 1) * DS_PICK_TB] > a) { dense[i * DS_PICK_TB] = dense[(i - 1) * DS_PICK_TB]; --i; }
+        dense[i * DS_PICK_TB] = a;
     }
     const int64_t o = pick_off[f];
     for (int j = 0; j < k; ++j)
-        if (o + j < pcap) cand[o + j] = in_src[b + pos[j]];
+        if (o + j < pcap) cand[o + j] = in_src[b + dense[j * DS_PICK_TB]];
 }
 
 // per pick: its frontier node (binary search in the offsets); nodes that keep all their neighbours copy them here
@@ -485,7 +500,9 @@ extern "C" int gda_dsampler_sample(const int64_t* in_ptr, const int32_t* in_src,
         k_ds_count<<<ds_grid(fcap + 1), DS_TB, 0, s>>>(in_ptr, nodes, w.cnt, k, fcap, w.c);
         GDA_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(w.cub, w.cub_bytes, w.c, w.pick_off, (int)(fcap + 1), s));
         k_ds_setm<<<1, 1, 0, s>>>(w.cnt, w.pick_off, fcap, pcap);
-        if (k >= 0) k_ds_pick_rng<<<ds_grid(fcap), DS_TB, 0, s>>>(in_ptr, in_src, nodes, w.cnt, k, hop, rng_seed, w.pick_off, pcap, w.cand);
+        if (k >= 0)
+            k_ds_pick_rng<<<(unsigned)gda_cdiv(fcap, DS_PICK_TB), DS_PICK_TB, (size_t)3 * k * DS_PICK_TB * sizeof(int32_t), s>>>(
+                in_ptr, in_src, nodes, w.cnt, k, hop, rng_seed, w.pick_off, pcap, w.cand);
         k_ds_pick_copy<<<ds_grid(pcap), DS_TB, 0, s>>>(in_ptr, in_src, nodes, w.cnt, k, w.pick_off, w.cand, w.dst_of);
         GDA_LAUNCH_CHECK();
         st = discover(pcap, 1);

@@ -191,6 +191,199 @@ k_slab_sum(const float* __restrict__ partial, int slabs, int64_t M, int64_t N, f
     }
 }
 
+// ---- tall products at 10^5 .. 10^7 rows (sampled sub-graphs of the cfg-S regime) -------------------------------------
+// Above ~50 k rows the 64 x 64-tile kernel above loses to the BLAS's 128 x 128 macro-tiles by 20-35 %: both operands go
+// through LDS for a single 32 x 32 accumulator per wave.  At these shapes one operand is a WEIGHT of at most 256 x 256:
+// it fits the register file of a workgroup.
+//
+// k_tall_fwd (NT forward  y = x W^T,  NN dgrad  gx = gy W): a persistent workgroup of 4 waves owns 128 output columns,
+// wave w the 32 columns [32 w, 32 w + 32); its slice of the weight -- every reduction pair x 32 columns -- lives in
+// KP registers per lane as ready MFMA B operands for the whole kernel.  Only the tall operand moves: 128-row tiles
+// in 32-deep chunks through a double-buffered, row-padded LDS image (row stride 33 words: the A-operand fetch
+// "32 consecutive rows at one k" and the staging stores are both conflict-free), one barrier per chunk, the next
+// chunk's global loads in flight under the current chunk's 64 MFMAs per wave (4 row sub-tiles x 16 pairs), the pipeline
+// running on across tile boundaries.  Per MFMA: ONE ds_read_b32 (the 64 x 64-tile kernel: two, the 2 x 2-tile probe of
+// round 2: one, plus the weight's staging).
+//
+// k_tall_wgrad (TN  gW = gy^T x, reduction over the rows): both operands are consumed along their rows -- lane (c, kk)
+// of the A operand is gy[m + kk][n0 + c], of the B operand x[m + kk][32 t + c] -- so 32-row chunks of gy and x are
+// staged in LDS exactly as they lie in memory (16-byte loads and stores, no transposition; the operand fetch "one row,
+// 32 consecutive columns" is conflict-free), double-buffered, and the whole 128 x K' output of a row slab stays in
+// accumulators: 8 waves, wave w = output rows [32 (w & 3), +32) x one half of the K' columns.  One workgroup per slab
+// (256 slabs at 10^5 rows), slab partials summed in slab order by k_slab_sum (deterministic), the bias gradient
+// (column sums of gy) as a by-product of the A operand registers.  (First version: operands straight from global
+// memory, 9 dword loads per 8 MFMAs and wave: 160 us at 150 k x 256 x 128; staged: 117; 8 waves: 101; the BLAS: 89.)
+//
+// Measured (tools/gemm_bench.py, profiles/r3_gemm_bench.jsonl; fraction of the 157.3 TF fp32 MFMA peak; a register-only
+// MFMA loop reaches 95-99 % of it on this part, tools/ubench/mfma_peak.hip): forward 59-63 %, data gradient 59-63 %,
+// weight gradient 52-65 % between 150 k and 300 k rows -- the BLAS 57-72 / 55-63 / 63-69 %; ahead of it at 300 k rows
+// (forward, data gradient), 5-15 % behind at 150 k.  By the counters (rocprofv3 --pmc, profiles/r3_gemm_pmc.txt) the
+// forward kernel's matrix pipe is busy 64 % of the time; its one wave per SIMD is parked at the chunk barrier / waitcnt
+// 13 % and issuing LDS reads and register moves 16 % of the time.
+constexpr int TALL_BM = 128, TALL_LDA = 33;
+constexpr int TALL_TB = 512;          // k_tall_wgrad: 8 waves (2 per SIMD; its accumulators are half the forward kernel's):
+                                      // 117 -> 101 us at 150 k x 256 x 128.  The forward kernel stays at 4 waves: with the weight
+                                      // slice, 4 accumulators and the operand prefetch a wave needs > 256 registers, and two
+                                      // workgroups per CU spill (measured: 119 us with 8 waves against 106 with 4)
+
+template <int KP, bool BT>
+__global__ void __launch_bounds__(TB, 1)
+k_tall_fwd(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
+           int64_t ldc, int64_t M, const float* __restrict__ bias) {
+    constexpr int NC = KP / 16;                       // 32-deep chunks of the reduction
+    static_assert(NC % 2 == 0, "the buffer index of a chunk is its parity");
+    __shared__ float As[2][TALL_BM * TALL_LDA];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ka = lane >> 5, la = lane & 31;
+    const int64_t j0 = (int64_t)blockIdx.y * 128 + 32 * wave;
+    float breg[KP];
+#pragma unroll
+    for (int p = 0; p < KP; ++p)
+        breg[p] = BT ? B[(int64_t)(2 * p + ka) * ldb + j0 + la] : B[(j0 + la) * ldb + 2 * p + ka];
+    const float bv = bias ? bias[j0 + la] : 0.f;
+    const int64_t ntiles = (M + TALL_BM - 1) / TALL_BM;
+    const int sr = tid >> 3, sk = (tid & 7) * 4;      // staging role: rows sr + 32 q, k piece sk .. sk + 3
+    float4 v[4];
+    int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+#define TF_FETCH(TILE, CH)                                                                             \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+        int64_t r = (TILE) * TALL_BM + sr + 32 * q;                                                   \
+        r = r < M ? r : M - 1;      /* rows past the end: any valid address; their outputs are not stored */ \
+        v[q] = *reinterpret_cast<const float4*>(A + r * lda + (CH) * 32 + sk);                        \
+    }
+#define TF_STASH(BUF)                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+        float* d = &As[BUF][(sr + 32 * q) * TALL_LDA + sk];                                           \
+        d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w;                                   \
+    }
+    TF_FETCH(tile, 0)
+    TF_STASH(0)
+    __syncthreads();
+    const float* ar = &As[0][la * TALL_LDA + ka];
+    for (; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ms][r] = 0.f;
+        const bool more_tiles = tile + gridDim.x < ntiles;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bool next = c + 1 < NC || more_tiles;
+            if (next) { TF_FETCH(c + 1 < NC ? tile : tile + gridDim.x, c + 1 < NC ? c + 1 : 0) }
+            __builtin_amdgcn_sched_barrier(0);        // the loads go out before the chunk's MFMAs, not between them
+            const float* a = ar + (c & 1) * (TALL_BM * TALL_LDA);
+#pragma unroll
+            for (int kp = 0; kp < 16; ++kp) {
+#pragma unroll
+                for (int ms = 0; ms < 4; ++ms)
+                    acc[ms] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms * 32 * TALL_LDA + 2 * kp], breg[c * 16 + kp], acc[ms], 0, 0, 0);
+                if (kp == 7) {                        // mid-chunk: the other image is free since the last barrier
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (next) { TF_STASH((c + 1) & 1) }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t i = tile * TALL_BM + 32 * ms + (r & 3) + 8 * (r >> 2) + 4 * ka;
+                if (i < M) C[i * ldc + j0 + la] = acc[ms][r] + bv;
+            }
+    }
+#undef TF_FETCH
+#undef TF_STASH
+}
+
+template <int NT8>
+__global__ void __launch_bounds__(TALL_TB, 1)
+k_tall_wgrad(const float* __restrict__ G, int64_t ldg, const float* __restrict__ X, int64_t ldx, float* __restrict__ P,
+             float* __restrict__ CS, int64_t M, int64_t rows_per_slab) {
+    constexpr int XC = 32 * NT8, RC = 32;             // x columns; rows per chunk
+    constexpr int HT = NT8 / 2;                       // column tiles per wave (the two waves of a row group split them)
+    constexpr int XQ = RC * XC / 4 / TALL_TB, GQ = RC * 128 / 4 / TALL_TB;      // 16-byte pieces per thread and chunk
+    extern __shared__ __attribute__((aligned(16))) float tw_lds[];
+    float* Xs = tw_lds;                               // [2][RC][XC]  rows as they lie in memory: the B-operand fetch
+    float* Gs = tw_lds + 2 * RC * XC;                 // [2][RC][128] "one row, 32 consecutive columns" is conflict-free
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ka = lane >> 5, la = lane & 31;
+    const int n0 = 32 * (wave & 3), t0 = HT * (wave >> 2);
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab, r1 = min(M, r0 + rows_per_slab);
+    f32x16 acc[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float csum = 0.f;
+    float4 vx[XQ], vg[GQ];
+    // (macros, not lambdas: with the staging arrays captured by reference the compiler kept them in scratch memory)
+#define TW_FETCH(M0)                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < XQ; ++q) {                                                       \
+        const int idx = tid + TALL_TB * q, row = idx / (XC / 4), c4 = idx % (XC / 4);                      \
+        int64_t r = (M0) + row;                                                                            \
+        r = r < r1 ? r : r1 - 1;              /* past the slab: the last row, with gy as zero */           \
+        vx[q] = *reinterpret_cast<const float4*>(X + r * ldx + 4 * c4);                                    \
+    }                                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < GQ; ++q) {                                                       \
+        const int idx = tid + TALL_TB * q, row = idx / 32, c4 = idx % 32;                                  \
+        const int64_t r = (M0) + row;                                                                      \
+        const bool in = r < r1;                                                                            \
+        float4 g = *reinterpret_cast<const float4*>(G + (in ? r : r1 - 1) * ldg + 4 * c4);                 \
+        g.x = in ? g.x : 0.f; g.y = in ? g.y : 0.f; g.z = in ? g.z : 0.f; g.w = in ? g.w : 0.f;            \
+        vg[q] = g;                                                                                         \
+    }
+#define TW_STASH(BUF)                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < XQ; ++q)                                                         \
+        *reinterpret_cast<float4*>(Xs + (BUF) * RC * XC + 4 * (tid + TALL_TB * q)) = vx[q];                \
+    _Pragma("unroll") for (int q = 0; q < GQ; ++q)                                                         \
+        *reinterpret_cast<float4*>(Gs + (BUF) * RC * 128 + 4 * (tid + TALL_TB * q)) = vg[q];
+    if (r0 < r1) {
+        TW_FETCH(r0)
+        TW_STASH(0)
+        __syncthreads();
+        const float* xb = Xs + ka * XC + 32 * t0 + la;
+        const float* gb = Gs + ka * 128 + n0 + la;
+        int buf = 0;
+        for (int64_t m0 = r0; m0 < r1; m0 += RC) {
+            TW_FETCH(m0 + RC)                         // unconditional: the loads go out before the chunk's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            const float* xs = xb + buf * RC * XC;
+            const float* gs = gb + buf * RC * 128;
+#pragma unroll
+            for (int p = 0; p < RC / 2; ++p) {
+                const float a = gs[2 * p * 128];
+                csum += a;
+#pragma unroll
+                for (int t = 0; t < HT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs[2 * p * XC + 32 * t], acc[t], 0, 0, 0);
+                if (p == RC / 4 - 1) {                // mid-chunk: the other image is free since the last barrier
+                    __builtin_amdgcn_sched_barrier(0);
+                    TW_STASH(buf ^ 1)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+#undef TW_FETCH
+#undef TW_STASH
+    float* out = P + (int64_t)blockIdx.x * 128 * XC;
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            out[(int64_t)(n0 + (r & 3) + 8 * (r >> 2) + 4 * ka) * XC + 32 * (t0 + t) + la] = acc[t][r];
+    if (CS && t0 == 0) {                               // rows m + 0 and m + 1 of every pair sit in the two lane halves
+        const float other = __shfl_down(csum, 32, 64);
+        if (ka == 0) CS[(int64_t)blockIdx.x * 128 + n0 + la] = csum + other;
+    }
+}
+
 bool vec_ok(const float* p, int64_t ld) { return ld % 4 == 0 && ((uintptr_t)p & 15) == 0; }
 
 int slabs_for(int64_t K) {
@@ -272,6 +465,69 @@ extern "C" int gda_gemm_ex_f32(int mode, int64_t M, int64_t N, int64_t K, const 
         GDA_GEMM_LAUNCH(false, true, dim3((unsigned)gy, (unsigned)gx, 1), C, ldc, K);
     }
 #undef GDA_GEMM_LAUNCH
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+// ---- tall entry point ------------------------------------------------------------------------------------------------
+// Same products as gda_gemm_ex_f32 for the shapes of sampled sub-graphs: M (the node count) large, the weight at most
+// 256 x 256 with both extents multiples of 128 resp. 32:
+//   NT  C[M, N] = A[M, K] B[N, K]^T (+ bias[N])   N in {128, 256}, K in {128, 256}
+//   NN  C[M, N] = A[M, K] B[K, N]                 N in {128, 256}, K in {128, 256}
+//   TN  C[128, N] = A[Mrows, 128]^T B[Mrows, N]   (mode TN: M = 128 output rows, K = the tall reduction), N in {128, 256};
+//       colsum[128] = column sums of A.  Workspace: gda_gemm_tall_workspace_bytes.
+// GDA_E_UNSUPPORTED outside that envelope (callers use gda_gemm_ex_f32).
+extern "C" size_t gda_gemm_tall_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
+    if (mode != GDA_GEMM_TN || M != 128 || (N != 128 && N != 256) || K <= 0) return 0;
+    const int64_t slabs = min((int64_t)256, gda_cdiv(K, 64));
+    return (size_t)slabs * 128 * (size_t)(N + 1) * sizeof(float);
+}
+
+extern "C" int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                                 const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, float* colsum,
+                                 void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    if (mode != GDA_GEMM_NT && mode != GDA_GEMM_NN && mode != GDA_GEMM_TN) return GDA_E_UNSUPPORTED;
+    if (M <= 0 || N <= 0 || K <= 0 || ldc < N) return GDA_E_SIZE;
+    if (!A || !B || !C) return GDA_E_NULL;
+    if (C == A || C == B) return GDA_E_ALIAS;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (mode == GDA_GEMM_TN) {
+        if (bias) return GDA_E_UNSUPPORTED;
+        if (M != 128 || (N != 128 && N != 256) || lda < 128 || ldb < N) return GDA_E_UNSUPPORTED;
+        const int64_t slabs = min((int64_t)256, gda_cdiv(K, 64));
+        const int64_t rows = gda_cdiv(gda_cdiv(K, slabs), 8) * 8;
+        if (!workspace || workspace_bytes < gda_gemm_tall_workspace_bytes(mode, M, N, K)) return GDA_E_WORKSPACE;
+        float* part = (float*)workspace;
+        float* cs_part = part + (size_t)slabs * 128 * N;
+        if (lda % 4 || ldb % 4 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return GDA_E_UNSUPPORTED;
+        const size_t lds = (size_t)2 * 32 * (N + 128) * sizeof(float);           // both images of x and gy chunks
+        static bool configured = false;              // idempotent attribute; racing first calls set the same value
+        if (!configured) {
+            GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tall_wgrad<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tall_wgrad<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            configured = true;
+        }
+        if (N == 128) k_tall_wgrad<4><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, B, ldb, part, colsum ? cs_part : nullptr, K, rows);
+        else k_tall_wgrad<8><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, B, ldb, part, colsum ? cs_part : nullptr, K, rows);
+        GDA_LAUNCH_CHECK();
+        k_slab_sum<<<(unsigned)gda_cdiv(128 * N + (colsum ? 128 : 0), SS_OUT), TB, 0, stream>>>(
+            part, (int)slabs, 128, N, C, ldc, cs_part, colsum);
+        GDA_LAUNCH_CHECK();
+        return GDA_OK;
+    }
+    if (colsum) return GDA_E_UNSUPPORTED;
+    if ((N != 128 && N != 256) || (K != 128 && K != 256) || lda < K || lda % 4 || ((uintptr_t)A & 15)) return GDA_E_UNSUPPORTED;
+    if (mode == GDA_GEMM_NT ? ldb < K : ldb < N) return GDA_E_SIZE;
+    if (bias && mode != GDA_GEMM_NT) return GDA_E_UNSUPPORTED;
+    const int64_t ntiles = gda_cdiv(M, TALL_BM);
+    const dim3 grid((unsigned)min(ntiles, (int64_t)256), (unsigned)(N / 128));
+    if (mode == GDA_GEMM_NT) {
+        if (K == 128) k_tall_fwd<64, false><<<grid, TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
+        else k_tall_fwd<128, false><<<grid, TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
+    } else {
+        if (K == 128) k_tall_fwd<64, true><<<grid, TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
+        else k_tall_fwd<128, true><<<grid, TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
+    }
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }

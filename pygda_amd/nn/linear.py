@@ -1,8 +1,9 @@
 """PyG-style ``Linear`` (weight ``[out, in]``, glorot) used inside the conv layers.
 
-The dense hidden x weight contraction is a plain fp32 GEMM: it goes to the ROCm BLAS
-(hipBLASLt / rocBLAS fp32 MFMA kernels) through ``F.linear``; everything sparse or fused
-around it is ours.
+The dense hidden x weight contraction of a node matrix (1024 rows and more, weight extents up to 256) runs on the
+hand-written fp32 matrix-core kernels of csrc/gda_gemm.hip -- 64 x 64 tiles at citation size, the weight-in-registers
+kernels for sampled sub-graphs of 10^5 rows and more; other shapes (tiny row counts, wide weights) go through
+``F.linear``.
 """
 import math
 
@@ -98,41 +99,11 @@ class _TallMatmul(torch.autograd.Function):
 
 def tall_matmul_ok(x, weight):
     return (x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
-            and 1024 <= x.size(0) <= TALL_GEMM_MAX_ROWS and weight.size(0) <= 256 and weight.size(1) <= 256)
+            and 1024 <= x.size(0) and weight.size(0) <= 256 and weight.size(1) <= 256)
 
 
 def tall_matmul(x, weight):
     return _TallMatmul.apply(x, weight)
-
-
-class _BlasTallLinear(torch.autograd.Function):
-    """Same contraction through the ROCm BLAS, for row counts where its 128x128 macro-tiles fill the
-    chip (sampled sub-graphs of 10^5 rows and more: measured 20-30 % ahead of the 64x64-tile kernels
-    there, tools/gemm_bench.py).  The weight gradient is cut into 32 row slabs (one batched GEMM + a
-    sum): the BLAS otherwise runs it as a single no-split-K tile."""
-    SLABS = 32
-
-    @staticmethod
-    def forward(ctx, x, weight):
-        ctx.save_for_backward(x, weight)
-        return F.linear(x, weight)
-
-    @staticmethod
-    def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
-        gx = gy @ weight if ctx.needs_input_grad[0] else None
-        gw = None
-        if ctx.needs_input_grad[1]:
-            n, s = x.size(0), _BlasTallLinear.SLABS
-            rows = (n // s) * s
-            gw = torch.bmm(gy[:rows].reshape(s, n // s, gy.size(1)).transpose(1, 2),
-                           x[:rows].reshape(s, n // s, x.size(1))).sum(0)
-            if rows < n:
-                gw = gw + gy[rows:].t() @ x[rows:]
-        return gx, gw
-
-
-TALL_GEMM_MAX_ROWS = 50_000      # above: BLAS (see _BlasTallLinear)
 
 
 class Linear(nn.Module):
@@ -157,7 +128,7 @@ class Linear(nn.Module):
             return False
         if x.size(1) >= sparse_features.MIN_WIDTH and sparse_features.lookup(x) is not None:
             return False
-        return 1024 <= x.size(0) <= TALL_GEMM_MAX_ROWS and self.in_channels <= 256 and self.out_channels <= 256
+        return 1024 <= x.size(0) and self.in_channels <= 256 and self.out_channels <= 256
 
     def forward(self, x):
         if self.bias is None and x.dim() == 2 and x.size(1) >= sparse_features.MIN_WIDTH:
@@ -166,9 +137,7 @@ class Linear(nn.Module):
                 return sparse_features.sparse_linear(self.weight, sf)
         if (self.bias is None and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and x.size(0) >= 1024
                 and self.in_channels <= 256 and self.out_channels <= 256):
-            if x.size(0) > TALL_GEMM_MAX_ROWS:
-                return _BlasTallLinear.apply(x, self.weight)
-            return _TallLinear.apply(x, self.weight)
+            return _TallLinear.apply(x, self.weight)          # every row count: ops.gemm picks the kernel by shape
         if profiler.enabled:
             n = x.numel() // x.size(-1)
             with profiler.region(f"dense_projection[{self.in_channels}x{self.out_channels}]", 1,

@@ -96,8 +96,19 @@ def gemm_raw(mode, M, N, K, a, lda, b, ldb, c, ldc, name="dense_projection"):
     return c
 
 
+TALL_ROWS = int(_os.environ.get("PYGDA_AMD_TALL_GEMM_ROWS", "32768"))    # node counts from here on: the tall kernels
+
+
+def _tall_shape(mode, M, N, K, a, b):
+    """The envelope of gda_gemm_tall_f32 (csrc/gda_gemm.hip): sampled sub-graphs (10^5 rows and more) against a weight
+    whose extents are 128 or 256."""
+    if mode == GEMM_TN:          # gW = gy^T x: `a` = gy [rows, 128], reduction over the rows
+        return M == 128 and N in (128, 256) and K >= TALL_ROWS
+    return M >= TALL_ROWS and N in (128, 256) and K in (128, 256) and a.data_ptr() % 16 == 0
+
+
 def gemm(mode, a, b, bias=None, colsum=None):
-    """fp32 product on the matrix cores (include/gda_hip.h: gda_gemm_ex_f32), no autograd.
+    """fp32 product on the matrix cores (include/gda_hip.h: gda_gemm_ex_f32 / gda_gemm_tall_f32), no autograd.
     NT: ``a [M,K] @ b [N,K]^T`` (+ ``bias [N]`` in the epilogue); NN: ``a [M,K] @ b [K,N]``;
     TN: ``a [K,M]^T @ b [K,N]`` (``colsum [M]`` receives ``a.sum(0)``, the bias gradient beside the weight's)."""
     a, b = _f32c(a, "a"), _f32c(b, "b")
@@ -111,15 +122,16 @@ def gemm(mode, a, b, bias=None, colsum=None):
         raise ValueError(f"inner dimensions differ: {tuple(a.shape)} x {tuple(b.shape)} (mode {mode})")
     c = torch.empty(M, N, dtype=torch.float32, device=a.device)
     L = _lib.lib()
-    need = L.gda_gemm_workspace_bytes(mode, M, N, K)
+    tall = _tall_shape(mode, M, N, K, a, b)
+    need = (L.gda_gemm_tall_workspace_bytes if tall else L.gda_gemm_workspace_bytes)(mode, M, N, K)
     ws = _lib.workspace(need, a.device, "gemm") if need else None
     name = ("dense_projection", "dense_projection_dgrad", "dense_projection_wgrad")[mode]
     with profiler.region(f"{name}[{K}x{N}]" if mode != GEMM_TN else f"{name}[{M}x{N}]", 1,
                          4 * (a.numel() + b.numel() + c.numel()), 2 * M * N * K):
-        _lib.check(L.gda_gemm_ex_f32(mode, M, N, K, _lib.ptr(a), a.size(1), _lib.ptr(b), b.size(1), _lib.ptr(c), N,
-                                     _lib.ptr(bias), _lib.ptr(colsum),
-                                     _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream()),
-                   "gda_gemm_ex_f32")
+        fn, what = (L.gda_gemm_tall_f32, "gda_gemm_tall_f32") if tall else (L.gda_gemm_ex_f32, "gda_gemm_ex_f32")
+        _lib.check(fn(mode, M, N, K, _lib.ptr(a), a.size(1), _lib.ptr(b), b.size(1), _lib.ptr(c), N,
+                      _lib.ptr(bias), _lib.ptr(colsum), _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream()),
+                   what)
     return c
 
 
@@ -498,6 +510,61 @@ class _MMD(torch.autograd.Function):
             gs = _scatter_rows(grad_rows, src_idx, 0, n, ctx.feat_rows[0])
             gt = _scatter_rows(grad_rows, tgt_idx, n, n, ctx.feat_rows[1])
         return (gs if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None) + tail
+
+
+class _PinnedRing:
+    """A few pinned host blocks handed out in turn, each guarded by the event of the copy that last left it: what a
+    step ships to the device (MMD row samples + their selection CSRs, ~1.4 MB at cfg-S) goes as ONE asynchronous
+    copy.  ``tensor.to(device)`` from pageable memory is synchronous -- the host waits for the stream to drain
+    first -- which serialised the eager sampled-training loop against the GPU (six such copies per step: 1.2 ms)."""
+
+    def __init__(self, slots=4):
+        self.slots, self.turn = [None] * slots, 0
+
+    def take(self, nbytes):
+        i = self.turn
+        self.turn = (i + 1) % len(self.slots)
+        hit = self.slots[i]
+        if hit is not None and hit[1] is not None:
+            hit[1].synchronize()                       # the copy out of this block (several steps ago) has finished
+        if hit is None or hit[0].numel() < nbytes:
+            hit = [torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8).pin_memory(), None]
+            self.slots[i] = hit
+        return i, hit[0]
+
+    def sent(self, i, stream):
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self.slots[i][1] = ev
+
+
+_pinned_ring = _PinnedRing()
+
+
+def mmd_samples_to_device(source_sample, target_sample, ns, nt, dev):
+    """The two ``[times, n]`` CPU row-sample tensors of an MMD call and the selection CSRs of their gradient scatter
+    -> ``(idx_s, idx_t, sel)`` on the device through one pinned block and one non-blocking copy."""
+    times, n = source_sample.shape
+    m = 2 * n
+    a16 = lambda v: (v + 15) // 16 * 16
+    sizes = [8 * times * n, 8 * times * n, 4 * (ns + 1), 4 * times * n, 4 * (nt + 1), 4 * times * n]
+    offs = [0]
+    for sz in sizes:
+        offs.append(offs[-1] + a16(sz))
+    slot, host = _pinned_ring.take(offs[-1])
+    view = lambda k, dt, cnt: host[offs[k]:offs[k] + sizes[k]].view(dt)[:cnt]
+    view(0, torch.int64, times * n).copy_(source_sample.reshape(-1))
+    view(1, torch.int64, times * n).copy_(target_sample.reshape(-1))
+    selection_csr_host(source_sample, ns, 0, m, out=(view(2, torch.int32, ns + 1), view(3, torch.int32, times * n)))
+    selection_csr_host(target_sample, nt, n, m, out=(view(4, torch.int32, nt + 1), view(5, torch.int32, times * n)))
+    block = torch.empty(offs[-1], dtype=torch.uint8, device=dev)
+    block.copy_(host[:offs[-1]], non_blocking=True)
+    _pinned_ring.sent(slot, torch.cuda.current_stream())
+    dview = lambda k, dt, cnt: block[offs[k]:offs[k] + sizes[k]].view(dt)[:cnt]
+    sel = (dview(2, torch.int32, ns + 1), dview(3, torch.int32, times * n),
+           dview(4, torch.int32, nt + 1), dview(5, torch.int32, times * n),
+           torch.ones(times * n, dtype=torch.float32, device=dev))
+    return dview(0, torch.int64, times * n).view(times, n), dview(1, torch.int64, times * n).view(times, n), sel
 
 
 def selection_csr_host(idx, num_feat_rows, offset, m, out=None):

@@ -69,10 +69,6 @@ def MMD(source_feat, target_feat, sampling_num=1000, times=5, *, scale=1.0, add=
         return mmd_loss(source_feat, target_feat, s_idx, t_idx, sel=sel, scale=scale, add=add)
     source_sample = torch.randint(source_feat.size(0), (times, sampling_num))
     target_sample = torch.randint(target_feat.size(0), (times, sampling_num))
-    m = 2 * sampling_num
-    sel = [t.to(dev, non_blocking=True) for t in
-           (*selection_csr_host(source_sample, source_feat.size(0), 0, m),
-            *selection_csr_host(target_sample, target_feat.size(0), sampling_num, m))]
-    sel.append(torch.ones(times * sampling_num, dtype=torch.float32, device=dev))
-    return mmd_loss(source_feat, target_feat, source_sample.to(dev, non_blocking=True),
-                    target_sample.to(dev, non_blocking=True), sel=tuple(sel), scale=scale, add=add)
+    from ..ops import mmd_samples_to_device
+    s_idx, t_idx, sel = mmd_samples_to_device(source_sample, target_sample, source_feat.size(0), target_feat.size(0), dev)
+    return mmd_loss(source_feat, target_feat, s_idx, t_idx, sel=sel, scale=scale, add=add)

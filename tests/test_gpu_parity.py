@@ -1159,6 +1159,63 @@ def test_tall_gemm_vs_fp64(M, N, K):
     exact(ops.gemm(ops.GEMM_TN, gyd, ad), ops.gemm(ops.GEMM_TN, gyd, ad))      # split-K is deterministic
 
 
+@pytest.mark.parametrize("M,N,K", [(33_000, 128, 128), (40_001, 128, 256), (65_536, 256, 128), (150_037, 128, 256),
+                                   (33_333, 256, 256)])
+def test_tall_gemm_weight_in_registers_vs_fp64(M, N, K):
+    """The kernels for sampled sub-graphs (csrc/gda_gemm.hip, "tall products": weight held in registers as MFMA
+    operands, the tall operand streamed; weight gradient with both operands read along their rows): NT (+ bias),
+    NN, TN (+ column sums) against fp64 at row counts that are not multiples of the 128-row tile, with fewer tiles
+    than persistent workgroups and with more; the deterministic slab sum; same answers as the 64 x 64-tile kernels
+    to fp32 summation order."""
+    from pygda_amd import _lib
+    assert ops._tall_shape(ops.GEMM_NT, M, N, K, torch.empty(1, device=DEV), None)
+    gen = torch.Generator().manual_seed(M % 1000 + N + K)
+    a = torch.randn(M, K, generator=gen)
+    w = torch.randn(N, K, generator=gen)
+    bias = torch.randn(N, generator=gen)
+    ad, wd = a.to(DEV), w.to(DEV)
+    tol = lambda want, depth: 2e-6 * float(want.abs().max()) * max(1.0, (depth / 128) ** 0.5)
+    want = a.double() @ w.double().t()
+    close(ops.gemm(ops.GEMM_NT, ad, wd), want, rtol=0, atol=tol(want, K))
+    close(ops.gemm(ops.GEMM_NT, ad, wd, bias=bias.to(DEV)), want + bias.double(), rtol=0, atol=tol(want, K))
+    wt = w.t().contiguous()                                  # NN: b is [K, N]
+    close(ops.gemm(ops.GEMM_NN, ad, wt.to(DEV)), want, rtol=0, atol=tol(want, K))
+    if N == 128:                                             # TN: gy [M, 128], x [M, K] -> gW [128, K]
+        gy = torch.randn(M, 128, generator=gen)
+        gyd = gy.to(DEV)
+        wantw = gy.double().t() @ a.double()
+        cs = torch.empty(128, device=DEV)
+        got = ops.gemm(ops.GEMM_TN, gyd, ad, colsum=cs)
+        close(got, wantw, rtol=0, atol=tol(wantw, M))
+        close(cs, gy.double().sum(0), rtol=0, atol=tol(gy.double().sum(0), M) + 1e-4)
+        exact(got, ops.gemm(ops.GEMM_TN, gyd, ad))           # slab partials summed in a fixed order
+    # the envelope: other shapes are refused by the tall entry point and served by the general one
+    L = _lib.lib()
+    c = torch.empty(M, 96, device=DEV)
+    st = L.gda_gemm_tall_f32(ops.GEMM_NT, M, 96, K, _lib.ptr(ad), K, _lib.ptr(wd), K, _lib.ptr(c), 96, None, None, None, 0,
+                             _lib.stream())
+    assert st == -4                                          # GDA_E_UNSUPPORTED
+    w96 = torch.randn(96, K, generator=gen)
+    want96 = a.double() @ w96.double().t()
+    close(ops.gemm(ops.GEMM_NT, ad, w96.to(DEV)), want96, rtol=0, atol=tol(want96, K))
+
+
+def test_linear_layer_at_sampled_batch_size_with_autograd():
+    """A hidden layer at 60 k rows (the BLAS's territory until round 3): forward, data and weight gradient on the
+    hand-written kernels against the torch composition."""
+    lin = pygda_amd.nn.Linear(256, 128, bias=False).to(DEV)
+    x = torch.randn(60_013, 256, device=DEV, requires_grad=True)
+    y = lin(x)
+    (y * y).sum().backward()
+    xr = x.detach().clone().requires_grad_()
+    wr = lin.weight.detach().clone().requires_grad_()
+    yr = F.linear(xr, wr)
+    (yr * yr).sum().backward()
+    close(y, yr, rtol=1e-4, atol=1e-4)
+    close(x.grad, xr.grad, rtol=1e-4, atol=1e-3)
+    close(lin.weight.grad, wr.grad, rtol=1e-4, atol=1e-4 * float(wr.grad.abs().max()))
+
+
 def test_linear_layer_uses_tall_gemm_with_autograd():
     lin = pygda_amd.nn.Linear(128, 128, bias=False).to(DEV)
     x = torch.randn(3000, 128, device=DEV, requires_grad=True)

@@ -29,11 +29,14 @@ def blas_wgrad(gy, x, s=32):
     return gw if rows == n else gw + gy[rows:].t() @ x[rows:]
 
 
-for n in (5484, 9360, 30000, 75000, 150000, 300000):
+for n in (9360, 40000, 75000, 150000, 157000, 300000):
     for k in (128, 256):
         x = torch.randn(n, k, device=dev); w = torch.randn(128, k, device=dev); gy = torch.randn(n, 128, device=dev)
         out = dict(N=n, K=k, out=128,
                    fwd_ours=t(lambda: ops.gemm(ops.GEMM_NT, x, w)), fwd_blas=t(lambda: F.linear(x, w)),
                    dgrad_ours=t(lambda: ops.gemm(ops.GEMM_NN, gy, w)), dgrad_blas=t(lambda: gy @ w),
                    wgrad_ours=t(lambda: ops.gemm(ops.GEMM_TN, gy, x)), wgrad_blas=t(lambda: blas_wgrad(gy, x)))
-        print(json.dumps({a: (round(b, 1) if isinstance(b, float) else b) for a, b in out.items()}))
+        gf = 2.0 * n * k * 128 / 1e3            # MFLOP per product -> TF = gf / us / 1e3
+        out.update(fwd_ours_frac=gf / out["fwd_ours"] / 1e3 / 157.3, dgrad_ours_frac=gf / out["dgrad_ours"] / 1e3 / 157.3,
+                   wgrad_ours_frac=gf / out["wgrad_ours"] / 1e3 / 157.3, fwd_blas_frac=gf / out["fwd_blas"] / 1e3 / 157.3)
+        print(json.dumps({a: (round(b, 3 if a.endswith("frac") else 1) if isinstance(b, float) else b) for a, b in out.items()}), flush=True)

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--bench")
     ap.add_argument("--out", default="profiles")
     ap.add_argument("--cmd", default=None, help="the profiled command, for the record")
+    ap.add_argument("--lds", help="directory of a `--pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES ...` pass")
+    ap.add_argument("--lds-kernel", default="k_kstep_lds", help="kernel name prefix the LDS section reports")
     ap.add_argument("--largest-grid", action="store_true",
                     help="PMC: per kernel keep only the dispatches with the largest grid (a sweep's biggest case)")
     a = ap.parse_args()
@@ -103,6 +105,31 @@ def main():
                 ours[k] = dict(fetch_kib=fe, write_kib=wr, traffic_bytes=traffic, wide_correction=wide)
         result["pmc"] = ours
         lines.append("")
+    if a.lds:
+        f = find(a.lds, "counter_collection.csv")
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if k.startswith(a.lds_kernel):
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if agg:
+            lines += ["## LDS counters per launch (separate `--pmc` pass; SQ counters are summed over the chip's SQs)", "",
+                      "`SQ_LDS_IDX_ACTIVE` = LDS-array cycles spent on indexed (ds_read / ds_write) operations, "
+                      "`SQ_LDS_BANK_CONFLICT` = the part of them that are bank-conflict replays "
+                      "(MI355X_MICROARCH.md, LDS section): conflict fraction = BANK_CONFLICT / IDX_ACTIVE.", "",
+                      "| kernel | launches | counter | avg per launch |", "|---|---|---|---|"]
+            lds = {}
+            for k, cs in agg.items():
+                lds[k] = {}
+                for c, v in sorted(cs.items()):
+                    lines.append(f"| `{k}` | {len(v)} | {c} | {sum(v)/len(v):.4g} |")
+                    lds[k][c] = dict(launches=len(v), avg=sum(v) / len(v))
+                if "SQ_LDS_IDX_ACTIVE" in cs and "SQ_LDS_BANK_CONFLICT" in cs:
+                    act, conf = sum(cs["SQ_LDS_IDX_ACTIVE"]), sum(cs["SQ_LDS_BANK_CONFLICT"])
+                    lds[k]["bank_conflict_fraction"] = conf / act if act else None
+                    lines.append(f"| `{k}` | | bank-conflict fraction of the LDS-array cycles | {conf / act if act else 0:.4f} |")
+            result["lds"] = lds
+            lines.append("")
     open(os.path.join(a.out, f"{a.tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
     json.dump(result, open(os.path.join(a.out, f"{a.tag}_rocprof_summary.json"), "w"), indent=1)
     print("\n".join(lines[:60]))
