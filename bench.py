@@ -287,11 +287,17 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
             secs = r["ms"] * 1e-3
             if name.startswith("spmm") or name.startswith("kstep_lds"):
                 ach = r["bytes"] / secs / 1e9
-                traffic, src_file = pmc_traffic("k_spmm<32, 4", "r2_cfgS*_summary.json") if "d=128" in name else (None, None)
-                return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src_file,
-                        "launches": r["launches"], "avg_launch_us": r["avg_us"],
-                        "algorithmic_bytes_per_launch": r["bytes"] / r["launches"]}
+                kern = "k_spmm_range<32, 4" if name.startswith("spmm_interior") else "k_spmm<32, 4"
+                traffic, src_file = pmc_traffic(kern, "r[0-9]*_cfgS*_summary.json") if "d=128" in name else (None, None)
+                out = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src_file,
+                       "launches": r["launches"], "avg_launch_us": r["avg_us"],
+                       "algorithmic_bytes_per_launch": r["bytes"] / r["launches"]}
+                if r.get("alg_equiv_bytes"):
+                    out["bytes_are"] = ("what the interior-rows K-step itself moves (gather model: K steps over the rows "
+                                        "that can change + one pass over the leaves), NOT K full aggregations")
+                    out["k_full_aggregations_equivalent_GBs"] = r["alg_equiv_bytes"] / secs / 1e9
+                return out
             ach = r["flops"] / secs / 1e12
             return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None, "launches": r["launches"],

@@ -145,6 +145,19 @@ int gda_spmm_csr_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const f
                            float* y, int64_t ldy, float* tmp, const float* bias,
                            gda_stream_t stream);
 
+/* K aggregation steps on a sampled sub-graph (a NeighborLoader batch, pygda/models/a2gnn.py:260-277, numbered seeds
+ * first then in discovery order): the nodes found in the last hop are never expanded, so rows [n_int, n_rows) of the
+ * normalised adjacency hold their unit self loop only and K steps leave them unchanged.  Only rows [0, n_int) are
+ * recomputed per step (transposed = 0: leaf columns are read from x; same values as gda_spmm_csr_kstep_f32, signed
+ * zeros aside); the transposed operator (backward) runs its K steps on the interior rows, sums their inputs in `sacc`
+ * and finishes the leaves in one pass, y_L = x_L + A_IL^T (h_0 + ... + h_{K-1}) -- K full steps up to fp32 summation
+ * order.  Rows must be short (<= 128 entries: no hub splitting here; sampled batches hold fan-out + 1 per row).
+ * x, y: [n_rows, d] contiguous; tmp [n_int, d] (K > 1), sacc [n_int, d] (transposed). */
+int gda_spmm_csr_interior_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                                    int64_t n_rows, int64_t n_int, int64_t d, int K, int transposed,
+                                    const float* x, float* y, float* tmp, float* sacc, const float* bias,
+                                    gda_stream_t stream);
+
 /* ------------------------------------------------------------------------------
  * K-step aggregation in ONE launch for graphs whose feature columns fit a CU's LDS
  * (n_rows <= gda_kstep_max_rows() = 16320; the citation-graph regime), csrc/gda_kstep.hip.
@@ -504,8 +517,9 @@ int gda_sampler_csr_norm(const gda_sampler* s, int32_t* rowptr, int32_t* colidx,
  *   GDA_E_UNSUPPORTED for a fan-out of 0 or above 64, or a batch beyond the int32 range (use the host sampler).
  * gda_dsampler_sample: nodes int64 [node_cap] (global ids, seeds first), esrc / edst int64 [edge_cap] (local ids),
  *   rowptr / t_rowptr int32 [node_cap + 1], colidx / val / t_colidx / t_val [edge_cap + node_cap] (all six NULL:
- *   no CSR), counts = device int64[4] {n_nodes, n_edges, nnz, status: 0 ok / 1 capacity exceeded / 2 seed out of
- *   range}; rowptr[i] == nnz for i >= n_nodes.  All launches are capacity sized; nothing returns to the host.
+ *   no CSR), counts = device int64[5] {n_nodes, n_edges, nnz, status: 0 ok / 1 capacity exceeded / 2 seed out of
+ *   range, n_interior: nodes before the last hop's discoveries -- the rows from there on are never expanded and hold
+ *   their self loop only (gda_spmm_csr_interior_kstep_f32)}; rowptr[i] == nnz for i >= n_nodes.  All launches are capacity sized; nothing returns to the host.
  * ---------------------------------------------------------------------------- */
 size_t gda_dsampler_graph_workspace_bytes(int64_t E, int64_t N);
 int gda_dsampler_build_graph(const int64_t* src, const int64_t* dst, int64_t E, int64_t N,

@@ -29,6 +29,7 @@ _SIGNATURES = {
     "gda_spmm_csr_f32": (c_int, [_P, _P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P]),
     "gda_spmm_csr_kstep_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P, c_int64,
                                        _P, _P, _P]),
+    "gda_spmm_csr_interior_kstep_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "gda_row_split_workspace_bytes": (c_size_t, [c_int64]),
     "gda_row_split_build": (c_int, [_P, c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gda_spmm_csr_split_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P, c_int64,

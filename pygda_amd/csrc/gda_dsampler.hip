@@ -298,6 +298,7 @@ __global__ void k_ds_fill_t(const DsCnt* __restrict__ cnt, const int32_t* __rest
 
 __global__ void k_ds_counts_out(const DsCnt* __restrict__ cnt, int64_t* __restrict__ out) {
     out[0] = cnt->n_nodes; out[1] = cnt->n_edges; out[2] = cnt->nnz; out[3] = cnt->overflow;
+    out[4] = cnt->fb;          // nodes before the last hop's discoveries: rows [fb, n_nodes) are never expanded
 }
 
 inline unsigned ds_grid(int64_t n) { return (unsigned)gda_cdiv(n > 0 ? n : 1, DS_TB); }
@@ -453,8 +454,9 @@ extern "C" size_t gda_dsampler_workspace_bytes(int64_t n_seeds, const int32_t* f
 
 // One batch.  Device arrays: nodes [node_cap] int64 (global ids, seeds first), esrc / edst [edge_cap] int64 (local
 // ids), the CSR pair in the capacity layout of gda_build_csr_norm for N = node_cap, E = edge_cap (rowptr [node_cap+1],
-// colidx / val [edge_cap + node_cap]; all six NULL: no CSR), counts int64[4] = {n_nodes, n_edges, nnz, status}
-// (status 0 = ok, 1 = a capacity was exceeded, 2 = a seed outside [0, N)).  rowptr[i] for i >= n_nodes equals nnz.
+// colidx / val [edge_cap + node_cap]; all six NULL: no CSR), counts int64[5] = {n_nodes, n_edges, nnz, status,
+// n_interior} (status 0 = ok, 1 = a capacity was exceeded, 2 = a seed outside [0, N); n_interior = nodes before the last
+// hop's discoveries: the rows from there on hold their self loop only).  rowptr[i] for i >= n_nodes equals nnz.
 extern "C" int gda_dsampler_sample(const int64_t* in_ptr, const int32_t* in_src, int64_t N, int64_t E, int64_t max_in_degree,
                                    const int64_t* seeds, int64_t n_seeds, const int32_t* fanouts_host, int L, uint64_t rng_seed,
                                    int64_t* nodes, int64_t* esrc, int64_t* edst,

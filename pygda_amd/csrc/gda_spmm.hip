@@ -202,6 +202,140 @@ k_long_reduce(RowSplit sp, int d, float* __restrict__ y, int64_t ldy, const floa
     }
 }
 
+// ---- sampled sub-graphs: the rows that can change ---------------------------------------------------------------
+// A NeighborLoader batch numbers its nodes seeds first, then in discovery order, and the nodes found in the LAST hop
+// are never expanded: rows [n_int, n) of the normalised adjacency hold their self loop only (weight exactly 1), ~90 %
+// of a fan-out [15, 10] batch.  K aggregation steps leave those rows unchanged, so only rows [0, n_int) are
+// recomputed per step; and in the transposed operator (backward) the interior rows never read a leaf.  This kernel is
+// the plain row walk of k_spmm (same accumulation order, separately rounded multiply and add) on a row RANGE, with two
+// gather sources split at a column index -- columns < col_split come from `xa`, the others from `xb` -- and an
+// optional running sum of the step inputs (sacc_mode 1: sacc[row] = xa[row]; 2: sacc[row] += xa[row]), which the
+// backward pass needs once at the end:  (A^T)^K g  restricted to the leaves is  g_L + A_IL^T (h_0 + ... + h_{K-1}).
+// Rows of a sampled batch hold at most fan-out + 1 entries: no hub handling here.
+template <int G, int VEC>
+__global__ void __launch_bounds__(TB)
+k_spmm_range(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ val,
+             int64_t row0, int64_t n_rows, int d, const float* __restrict__ xa, int64_t lda,
+             const float* __restrict__ xb, int64_t ldb, int32_t col_split, float* __restrict__ y, int64_t ldy,
+             const float* __restrict__ bias, float* __restrict__ sacc, int sacc_mode) {
+    constexpr int ROWS_PER_BLOCK = TB / G;
+    const int lane_in_group = threadIdx.x % G;
+    const int64_t row = row0 + (int64_t)blockIdx.x * ROWS_PER_BLOCK + threadIdx.x / G;
+    const bool live = row < row0 + n_rows;
+    int32_t start = 0, end = 0;
+    if (live) { start = rowptr[row]; end = rowptr[row + 1]; }
+    for (int c0 = 0; c0 < d; c0 += G * VEC) {
+        const int c = c0 + lane_in_group * VEC;
+        const bool col_ok = c < d;
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
+        for (int32_t base = start; base < end; base += G) {
+            const int32_t k = base + lane_in_group;
+            const int32_t my_col = k < end ? colidx[k] : 0;
+            const float my_val = k < end ? val[k] : 0.0f;
+            const int cnt = min((int32_t)G, end - base);
+            int e = 0;
+            for (; e + UNROLL <= cnt; e += UNROLL) {
+                float xv[UNROLL][VEC];
+                float w[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int32_t cu = __shfl(my_col, e + u, G);
+                    w[u] = __shfl(my_val, e + u, G);
+                    const float* src = cu < col_split ? xa + (int64_t)cu * lda : xb + (int64_t)cu * ldb;
+                    if (col_ok) vload<VEC>(xv[u], src + c);
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        acc[v] = __fadd_rn(acc[v], __fmul_rn(w[u], col_ok ? xv[u][v] : 0.0f));
+            }
+            for (; e < cnt; ++e) {
+                const int32_t cu = __shfl(my_col, e, G);
+                const float w = __shfl(my_val, e, G);
+                const float* src = cu < col_split ? xa + (int64_t)cu * lda : xb + (int64_t)cu * ldb;
+                float xv[VEC];
+                if (col_ok) {
+                    vload<VEC>(xv, src + c);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] = __fadd_rn(acc[v], __fmul_rn(w, xv[v]));
+                }
+            }
+        }
+        if (live && col_ok) {
+            if (sacc_mode) {                              // running sum of the step inputs (own row: no race)
+                float own[VEC], run[VEC];
+                vload<VEC>(own, xa + row * lda + c);
+                if (sacc_mode == 2) {
+                    vload<VEC>(run, sacc + row * (int64_t)d + c);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) own[v] = __fadd_rn(run[v], own[v]);
+                }
+                vstore<VEC>(sacc + row * (int64_t)d + c, own);
+            }
+            if (bias) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = __fadd_rn(acc[v], bias[c + v]);
+            }
+            vstore<VEC>(y + row * ldy + c, acc);
+        }
+    }
+}
+
+// y[row] = x[row] (+ bias) for rows [row0, row0 + n_rows): the leaf rows of a forward K-step
+__global__ void __launch_bounds__(TB)
+k_rows_copy_bias(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy, int64_t row0, int64_t n_rows,
+                 int d, const float* __restrict__ bias) {
+    const int64_t total = n_rows * d;
+    for (int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x; k < total; k += (int64_t)gridDim.x * TB) {
+        const int64_t r = row0 + k / d;
+        const int c = (int)(k % d);
+        // 0 + 1 * x: what the self-loop row computes (a negative zero becomes +0, like there)
+        float v = __fadd_rn(0.0f, __fmul_rn(1.0f, x[r * ldx + c]));
+        if (bias) v = __fadd_rn(v, bias[c]);
+        y[r * ldy + c] = v;
+    }
+}
+
+template <int G, int VEC>
+int launch_range(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t row0, int64_t n_rows, int d,
+                 const float* xa, int64_t lda, const float* xb, int64_t ldb, int32_t col_split, float* y, int64_t ldy,
+                 const float* bias, float* sacc, int sacc_mode, hipStream_t s) {
+    if (n_rows <= 0) return GDA_OK;
+    constexpr int ROWS_PER_BLOCK = TB / G;
+    const int64_t blocks = gda_cdiv(n_rows, ROWS_PER_BLOCK);
+    if (blocks > INT32_MAX) return GDA_E_SIZE;
+    k_spmm_range<G, VEC><<<(unsigned)blocks, TB, 0, s>>>(rowptr, colidx, val, row0, n_rows, d, xa, lda, xb, ldb, col_split,
+                                                         y, ldy, bias, sacc, sacc_mode);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+int dispatch_range(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t row0, int64_t n_rows, int64_t d,
+                   const float* xa, int64_t lda, const float* xb, int64_t ldb, int32_t col_split, float* y, int64_t ldy,
+                   const float* bias, float* sacc, int sacc_mode, hipStream_t s) {
+    const bool a16 = (d % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)xa % 16 == 0) &&
+                     ((uintptr_t)xb % 16 == 0) && ((uintptr_t)y % 16 == 0) && (!sacc || (uintptr_t)sacc % 16 == 0);
+    const int di = (int)d;
+#define GO(G, V) return launch_range<G, V>(rowptr, colidx, val, row0, n_rows, di, xa, lda, xb, ldb, col_split, y, ldy, bias, sacc, sacc_mode, s)
+    if (a16) {
+        const int64_t lanes = d / 4;
+        if (lanes >= 64) GO(64, 4);
+        if (lanes > 16) GO(32, 4);
+        if (lanes > 8) GO(16, 4);
+        if (lanes > 4) GO(8, 4);
+        GO(4, 4);
+    }
+    if (d > 32) GO(64, 1);
+    if (d > 16) GO(32, 1);
+    if (d > 8) GO(16, 1);
+    if (d > 4) GO(8, 1);
+    GO(4, 1);
+#undef GO
+}
+
 template <int G, int VEC>
 int launch(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n_rows, int d,
            const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias, const RowSplit& sp,
@@ -343,4 +477,47 @@ extern "C" int gda_spmm_csr_axpby_f32(const int32_t* rowptr, const int32_t* coli
     const RowSplit sp = make_split(split);
     const Epilogue ep{alpha, beta, gamma, gamma_dev, z, ldz};
     return dispatch(rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, nullptr, sp, (hipStream_t)stream, &ep);
+}
+
+// K aggregation steps on a sampled sub-graph whose rows [n_int, n_rows) hold their unit self loop only (the nodes a
+// NeighborLoader batch discovered in its last hop; csrc/gda_dsampler.hip reports n_int).
+//   transposed = 0 (rows by destination):  y = A^K x (+ bias): K steps over rows [0, n_int) -- gathers of leaf columns
+//     read x itself -- and one copy of the leaf rows.  Same values as gda_spmm_csr_kstep_f32 (signed zeros aside).
+//   transposed = 1 (rows by source; the backward pass):  y = (A^T)^K x: K steps over the interior rows (they read interior
+//     columns only), their inputs summed on the way, then ONE pass over the leaf rows  y_L = x_L + A_IL^T (h_0 + .. + h_{K-1}).
+//     Same result as K full steps up to fp32 summation order (the leaves' sums are re-associated).
+// tmp: [n_int, d] (K > 1); sacc: [n_int, d] (transposed only).  x, y contiguous rows (ld = d).
+extern "C" int gda_spmm_csr_interior_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                                               int64_t n_rows, int64_t n_int, int64_t d, int K, int transposed,
+                                               const float* x, float* y, float* tmp, float* sacc, const float* bias,
+                                               gda_stream_t stream) {
+    if (K < 1 || n_int < 0 || n_int > n_rows) return GDA_E_SIZE;
+    int st = check(rowptr, colidx, val, n_rows, d, x, d, y, d);
+    if (st != GDA_OK || n_rows == 0 || d == 0) return st;
+    if ((K > 1 && n_int > 0 && !tmp) || (transposed && n_int > 0 && !sacc)) return GDA_E_NULL;
+    if (tmp && (tmp == y || (const float*)tmp == x)) return GDA_E_ALIAS;
+    if (transposed && bias) return GDA_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int32_t split = (int32_t)n_int;
+    const float* in = x;
+    for (int j = 1; j <= K && n_int > 0; ++j) {          // step j writes y when K - j is even
+        float* out = ((K - j) % 2 == 0) ? y : tmp;
+        // forward: leaf columns always come from x; transposed: interior rows have no leaf columns at all
+        const int r = dispatch_range(rowptr, colidx, val, 0, n_int, d, in, d, x, d, split, out, d,
+                                     (j == K && !transposed) ? bias : nullptr, transposed ? sacc : nullptr,
+                                     transposed ? (j == 1 ? 1 : 2) : 0, s);
+        if (r != GDA_OK) return r;
+        in = out;
+    }
+    const int64_t n_leaf = n_rows - n_int;
+    if (n_leaf == 0) return GDA_OK;
+    if (!transposed) {
+        int64_t g = gda_cdiv(n_leaf * d, TB);
+        if (g > 256 * 16) g = 256 * 16;
+        k_rows_copy_bias<<<(unsigned)g, TB, 0, s>>>(x, d, y, d, n_int, n_leaf, (int)d, bias);
+        GDA_LAUNCH_CHECK();
+        return GDA_OK;
+    }
+    // leaves of the transposed operator: interior columns read the summed step inputs, the self loop reads x
+    return dispatch_range(rowptr, colidx, val, n_int, n_leaf, d, n_int > 0 ? sacc : x, d, x, d, split, y, d, nullptr, nullptr, 0, s);
 }

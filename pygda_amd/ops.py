@@ -148,9 +148,50 @@ def _note_path(name, K):
         kstep_paths[name] = kstep_paths.get(name, 0) + 1
 
 
+INTERIOR_KSTEP = _os.environ.get("PYGDA_AMD_INTERIOR_KSTEP", "1") == "1"
+
+
+def _launch_kstep_interior(graph, x, K, bias, transposed, y):
+    """K steps on a sampled batch whose rows ``[n_interior, n)`` hold their unit self loop only: the interior rows are
+    recomputed per step, the leaves are finished in one pass (csrc/gda_spmm.hip, "sampled sub-graphs")."""
+    rp, ci, va = (graph.t_rowptr, graph.t_colidx, graph.t_val) if transposed else (graph.rowptr, graph.colidx, graph.val)
+    n, d = x.shape
+    n_int = graph.n_interior
+    L = _lib.lib()
+    if aggregation_log is not None:
+        aggregation_log.append((graph, int(K)))
+    _note_path("interior-rows", int(K))
+    if profiler.enabled:
+        # `bytes`: what the call itself moves (gather model: every stored entry reads a d-wide row) -- forward K
+        # interior steps + one copy of the leaf rows; transposed K interior steps (few entries: bounded by their rows'
+        # inputs, outputs and running sums) + one pass over every entry for the leaves.  `alg_equiv_bytes`: SURVEY
+        # 8(d)'s algorithmic bytes of the K full aggregations the call stands for.
+        global aggregated_edges
+        aggregated_edges += int(K) * graph.nnz
+        nnz, n_leaf, row = graph.nnz, n - n_int, 4 * d
+        if transposed:
+            real = K * (4 * n_int * row) + nnz * (8 + row) + 2 * n_leaf * row
+        else:
+            real = K * (nnz * (8 + row) + n_int * row + (n_int + 1) * 4) + 2 * n_leaf * row
+        ctx = profiler.region(f"spmm_interior_f32[d={d}]", K + 1, real, K * 2 * nnz * d,
+                              alg_equiv_bytes=K * (nnz * 8 + (n + 1) * 4 + 2 * n * d * 4))
+    else:
+        ctx = profiler.region("", 0)
+    tmp = torch.empty(n_int, d, dtype=torch.float32, device=x.device) if K > 1 and n_int else None
+    sacc = torch.empty(n_int, d, dtype=torch.float32, device=x.device) if transposed and n_int else None
+    with ctx:
+        _lib.check(L.gda_spmm_csr_interior_kstep_f32(_lib.ptr(rp), _lib.ptr(ci), _lib.ptr(va), n, n_int, d, int(K),
+                                                     int(bool(transposed)), _lib.ptr(x), _lib.ptr(y), _lib.ptr(tmp),
+                                                     _lib.ptr(sacc), _lib.ptr(bias), _lib.stream()),
+                   "gda_spmm_csr_interior_kstep_f32")
+
+
 def _launch_kstep(graph, x, K, bias, transposed, y, tmp, counts_as=None):
     """``counts_as = (graph, steps)``: what the launches stand for in the edges-aggregated bookkeeping
     (a launch of the cached A*A counts as two aggregations over the edges of A, not over its own)."""
+    if (INTERIOR_KSTEP and counts_as is None and graph.n_interior is not None and 2 * graph.n_interior <= x.size(0)
+            and x.is_contiguous() and (bias is None or not transposed)):
+        return _launch_kstep_interior(graph, x, K, bias, transposed, y)
     rp, ci, va = (graph.t_rowptr, graph.t_colidx, graph.t_val) if transposed else \
                  (graph.rowptr, graph.colidx, graph.val)
     n, d = x.shape
@@ -243,7 +284,8 @@ def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
             _launch_kstep_lds(graph, hit[0], hit[1], x, K, b, transposed, y)
             return y
     if sq is None:
-        _launch_kstep(graph, x, K, b, transposed, y, torch.empty_like(x) if K > 1 else None)
+        interior = INTERIOR_KSTEP and graph.n_interior is not None and 2 * graph.n_interior <= x.size(0)
+        _launch_kstep(graph, x, K, b, transposed, y, torch.empty_like(x) if K > 1 and not interior else None)
         return y
     pairs, single = K // 2, K % 2
     if single:

@@ -131,18 +131,18 @@ class NeighborSampler:
 
 
 class _PendingBatch:
-    """A batch the device sampler has enqueued: capacity-sized device arrays + the event after which the four
-    counts ({n_nodes, n_edges, nnz, status}) are on the host."""
-    __slots__ = ("nodes", "ei", "csr", "counts_host", "event", "n_seeds", "stream")
+    """A batch the device sampler has enqueued: capacity-sized device arrays + the event after which the five
+    counts ({n_nodes, n_edges, nnz, status, n_interior}) are on the host."""
+    __slots__ = ("nodes", "ei", "csr", "counts_host", "event", "n_seeds", "stream", "short_rows")
 
     def wait(self):
         self.event.synchronize()
-        n, e, nnz, status = (int(v) for v in self.counts_host.tolist())
+        n, e, nnz, status, n_int = (int(v) for v in self.counts_host.tolist())
         if status == 2:
             raise _lib.GdaError("gda_dsampler_sample: a seed lies outside [0, num_nodes)")
         if status != 0:
             raise _lib.GdaError("gda_dsampler_sample: a capacity bound was exceeded (internal error)")
-        return n, e, nnz
+        return n, e, nnz, n_int
 
 
 class DeviceNeighborSampler:
@@ -211,6 +211,7 @@ class DeviceNeighborSampler:
         i64, i32, f32 = (dict(dtype=t, device=dev) for t in (torch.int64, torch.int32, torch.float32))
         p = _PendingBatch()
         p.n_seeds, p.stream = int(seeds_d.numel()), stream
+        p.short_rows = bool(fan.size) and int(fan.min()) > 0        # every row holds at most fan-out + 1 entries
         p.nodes = torch.empty(ncap, **i64)
         p.ei = torch.empty(2, ecap, **i64)
         if csr:
@@ -219,7 +220,7 @@ class DeviceNeighborSampler:
                      torch.empty(ncap + 1, **i32), torch.empty(cap, **i32), torch.empty(cap, **f32))
         else:
             p.csr = (None,) * 6
-        counts = torch.empty(4, **i64)
+        counts = torch.empty(5, **i64)
         L = _lib.lib()
         _lib.check(L.gda_dsampler_sample(_lib.ptr(self.in_ptr), _lib.ptr(self.in_src), self.num_nodes, self.num_edges,
                                          self.max_in_degree, _lib.ptr(seeds_d), p.n_seeds, fan.ctypes.data, fan.size,
@@ -227,7 +228,7 @@ class DeviceNeighborSampler:
                                          _lib.ptr(p.ei[0]), _lib.ptr(p.ei[1]), *(_lib.ptr(t) for t in p.csr),
                                          _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream()),
                    "gda_dsampler_sample")
-        p.counts_host = torch.empty(4, dtype=torch.int64, pin_memory=True)
+        p.counts_host = torch.empty(5, dtype=torch.int64, pin_memory=True)
         p.counts_host.copy_(counts, non_blocking=True)
         p.event = torch.cuda.Event()
         p.event.record(stream)
@@ -236,21 +237,23 @@ class DeviceNeighborSampler:
     def sample(self, seeds, fanouts, seed=0):
         """-> (n_id, edge_index) on the device, like :meth:`NeighborSampler.sample` (tests)."""
         p = self.enqueue(seeds, fanouts, seed, csr=False)
-        n, e, _ = p.wait()
+        n, e, _, _ = p.wait()
         return p.nodes[:n], p.ei[:, :e]
 
-    def graph_of(self, p, n, e, nnz):
+    def graph_of(self, p, n, e, nnz, n_int=None):
         """:class:`CSRGraph` views of a pending batch's CSR pair (what ``as_graph(edge_index, n)`` would build)."""
         from .graph import CSRGraph
         rp, ci, va, trp, tci, tva = p.csr
         g = CSRGraph(n, n + e, rp[:n + 1], ci, va, trp[:n + 1], tci, tva)
         g._nnz = nnz
         g.transient = True
+        if n_int is not None and p.short_rows:      # rows [n_int, n): the last hop's discoveries, self loop only
+            g.n_interior = int(n_int)
         return g
 
     def assemble(self, data, p, sizes=None):
         """Consumer side (training stream): order behind the sampler's stream, gather the feature rows."""
-        n, e, nnz = sizes if sizes is not None else p.wait()
+        n, e, nnz, n_int = sizes if sizes is not None else p.wait()
         cur = torch.cuda.current_stream()
         if p.stream != cur:
             cur.wait_event(p.event)
@@ -262,7 +265,7 @@ class DeviceNeighborSampler:
         ei = p.ei[:, :e]
         ei._gda_trusted = True
         if p.csr[0] is not None:
-            ei._gda_prebuilt = self.graph_of(p, n, e, nnz)
+            ei._gda_prebuilt = self.graph_of(p, n, e, nnz, n_int)
         x = gather_rows(data.x, n_id)
         y = None if data.y is None else data.y[n_id]
         return Data(x=x, edge_index=ei, y=y, n_id=n_id, batch_size=p.n_seeds)

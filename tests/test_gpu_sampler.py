@@ -66,7 +66,8 @@ def test_device_sampler_equals_host_sampler(fan, variant):
             seeds = torch.cat([seeds, seeds[:13], torch.tensor([17, 17])])       # duplicates among the seeds
         hn, he = H.sample(seeds, fan, seed=100 + trial)
         p = D.enqueue(seeds, fan, seed=100 + trial)
-        nn, ne, nnz = p.wait()
+        nn, ne, nnz, n_int = p.wait()
+        assert 0 < n_int <= nn
         exact(p.nodes[:nn], hn)
         exact(p.ei[:, :ne], he)
         G = build_csr(he.to(DEV), nn)
@@ -130,6 +131,43 @@ def test_loader_on_the_device_sampler_equals_the_host_loader(monkeypatch, prefet
     again = list(dev_loader)
     exact(again[0].n_id[:256], dev_batches[0].n_id[:256])
     assert again[0].n_id.numel() != dev_batches[0].n_id.numel() or not torch.equal(again[0].n_id, dev_batches[0].n_id)
+
+
+@pytest.mark.parametrize("K,d", [(1, 128), (3, 5), (10, 128), (4, 36)])
+def test_interior_rows_kstep_on_sampled_batches(monkeypatch, K, d):
+    """A sampled batch's last-hop discoveries are never expanded: their rows hold a unit self loop only.  K steps that
+    recompute the interior rows only (gda_spmm_csr_interior_kstep_f32) equal K full steps -- forward bit for bit
+    (signed zeros aside), transposed (backward) to fp32 summation order -- with and without the bias, and through
+    autograd."""
+    from pygda_amd import ops
+    from pygda_amd.graph import as_graph
+    n = 20000
+    ei = _graph(n, 300000, 11, loops=True)
+    g = torch.Generator().manual_seed(K * 7 + d)
+    data = Data(x=torch.randn(n, 16, generator=g), edge_index=ei, y=torch.zeros(n, dtype=torch.long)).to(DEV)
+    loader = NeighborLoader(data, [7, 5], batch_size=300, input_nodes=torch.randperm(n, generator=g)[:600], device=DEV)
+    for batch in loader:
+        G = as_graph(batch.edge_index, batch.x.size(0))
+        nb = batch.x.size(0)
+        assert G.n_interior is not None and 300 <= G.n_interior < nb // 2
+        # rows from n_interior on: exactly their self loop, weight 1
+        rp = G.rowptr[:nb + 1].cpu()
+        assert bool((rp[G.n_interior + 1:] - rp[G.n_interior:-1] == 1).all())
+        x = torch.randn(nb, d, generator=g).to(DEV)
+        bias = torch.randn(d, generator=g).to(DEV)
+        gy = torch.randn(nb, d, generator=g).to(DEV)
+        got = ops.spmm_kstep(G, x, K, bias)
+        got_t = ops.spmm_kstep(G, gy, K, None, transposed=True)
+        xa = x.clone().requires_grad_()
+        ops.propagate(xa, G, K, bias).backward(gy)
+        monkeypatch.setattr(ops, "INTERIOR_KSTEP", False)
+        want = ops.spmm_kstep(G, x, K, bias)
+        want_t = ops.spmm_kstep(G, gy, K, None, transposed=True)
+        monkeypatch.setattr(ops, "INTERIOR_KSTEP", True)
+        exact(got, want)
+        scale = float(want_t.abs().max())
+        np.testing.assert_allclose(got_t.cpu().numpy(), want_t.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)
+        np.testing.assert_allclose(xa.grad.cpu().numpy(), want_t.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)
 
 
 def test_sampled_training_no_longer_depends_on_host_sampler_threads():

@@ -49,7 +49,7 @@ def case(name, n, ei, d=128):
     for w in (64, 32, 16, 8):
         us = timed(lambda: slab_spmm(G, x, y, w))
         out[f"slab{w}_us"] = round(us, 1)
-        assert torch.equal(y, ref), w
+        assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4), w      # (hub rows: chunked in `plain`, sequential in the slabs)
     print(json.dumps(out), flush=True)
     del G, x, y, ref
     torch.cuda.empty_cache()
