@@ -570,7 +570,10 @@ class _PinnedRing:
         if hit is not None and hit[1] is not None:
             hit[1].synchronize()                       # the copy out of this block (several steps ago) has finished
         if hit is None or hit[0].numel() < nbytes:
-            hit = [torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8).pin_memory(), None]
+            cap = 1 << 16
+            while cap < nbytes + nbytes // 2:          # headroom: batches differ in size, pinning is expensive (~50 ms)
+                cap <<= 1
+            hit = [torch.empty(cap, dtype=torch.uint8).pin_memory(), None]
             self.slots[i] = hit
         return i, hit[0]
 

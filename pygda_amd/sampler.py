@@ -228,11 +228,21 @@ class DeviceNeighborSampler:
                                          _lib.ptr(p.ei[0]), _lib.ptr(p.ei[1]), *(_lib.ptr(t) for t in p.csr),
                                          _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream()),
                    "gda_dsampler_sample")
-        p.counts_host = torch.empty(5, dtype=torch.int64, pin_memory=True)
+        p.counts_host = self._pinned_counts()
         p.counts_host.copy_(counts, non_blocking=True)
         p.event = torch.cuda.Event()
         p.event.record(stream)
         return p
+
+    def _pinned_counts(self):
+        """A 5-word pinned landing pad for a batch's counts, from a ring of 64 (a batch's counts are read long before
+        the ring comes round; pinning a fresh block per batch costs a host allocation each time)."""
+        ring = getattr(self, "_count_ring", None)
+        if ring is None:
+            ring = self._count_ring = [torch.empty(64, 5, dtype=torch.int64).pin_memory(), 0]
+        i = ring[1]
+        ring[1] = (i + 1) % 64
+        return ring[0][i]
 
     def sample(self, seeds, fanouts, seed=0):
         """-> (n_id, edge_index) on the device, like :meth:`NeighborSampler.sample` (tests)."""
