@@ -196,14 +196,13 @@ k_slab_sum(const float* __restrict__ partial, int slabs, int64_t M, int64_t N, f
 // through LDS for a single 32 x 32 accumulator per wave.  At these shapes one operand is a WEIGHT of at most 256 x 256:
 // it fits the register file of a workgroup.
 //
-// k_tall_fwd (NT forward  y = x W^T,  NN dgrad  gx = gy W): a persistent workgroup of 4 waves owns 128 output columns,
-// wave w the 32 columns [32 w, 32 w + 32); its slice of the weight -- every reduction pair x 32 columns -- lives in
-// KP registers per lane as ready MFMA B operands for the whole kernel.  Only the tall operand moves: 128-row tiles
-// in 32-deep chunks through a double-buffered, row-padded LDS image (row stride 33 words: the A-operand fetch
-// "32 consecutive rows at one k" and the staging stores are both conflict-free), one barrier per chunk, the next
-// chunk's global loads in flight under the current chunk's 64 MFMAs per wave (4 row sub-tiles x 16 pairs), the pipeline
-// running on across tile boundaries.  Per MFMA: ONE ds_read_b32 (the 64 x 64-tile kernel: two, the 2 x 2-tile probe of
-// round 2: one, plus the weight's staging).
+// k_tall_fwd16 (NT forward  y = x W^T,  NN dgrad  gx = gy W): a persistent workgroup of 8 waves owns 128 output columns,
+// wave w the 16 columns [16 w, 16 w + 16); its slice of the weight -- every group of 4 reduction indices x 16 columns --
+// lives in K/4 registers per lane as ready MFMA B operands for the whole kernel.  Only the tall operand moves: 128-row
+// tiles in 32-deep chunks through a double-buffered, row-padded LDS image, one barrier per chunk, the next chunk's
+// global loads issued before the current chunk's 64 MFMAs per wave (8 row sub-tiles x 8 k-groups) and stored
+// mid-chunk, the pipeline running on across tile boundaries.  Per MFMA: ONE ds_read_b32 (the 64 x 64-tile kernel: two,
+// the 2 x 2-tile probe of round 2: one, plus the weight's staging).
 //
 // k_tall_wgrad (TN  gW = gy^T x, reduction over the rows): both operands are consumed along their rows -- lane (c, kk)
 // of the A operand is gy[m + kk][n0 + c], of the B operand x[m + kk][32 t + c] -- so 32-row chunks of gy and x are
@@ -215,71 +214,81 @@ k_slab_sum(const float* __restrict__ partial, int slabs, int64_t M, int64_t N, f
 // memory, 9 dword loads per 8 MFMAs and wave: 160 us at 150 k x 256 x 128; staged: 117; 8 waves: 101; the BLAS: 89.)
 //
 // Measured (tools/gemm_bench.py, profiles/r3_gemm_bench.jsonl; fraction of the 157.3 TF fp32 MFMA peak; a register-only
-// MFMA loop reaches 95-99 % of it on this part, tools/ubench/mfma_peak.hip): forward 59-63 %, data gradient 59-63 %,
-// weight gradient 52-65 % between 150 k and 300 k rows -- the BLAS 57-72 / 55-63 / 63-69 %; ahead of it at 300 k rows
-// (forward, data gradient), 5-15 % behind at 150 k.  By the counters (rocprofv3 --pmc, profiles/r3_gemm_pmc.txt) the
-// forward kernel's matrix pipe is busy 64 % of the time; its one wave per SIMD is parked at the chunk barrier / waitcnt
-// 13 % and issuing LDS reads and register moves 16 % of the time.
-constexpr int TALL_BM = 128, TALL_LDA = 33;
+// MFMA loop reaches 95-99 % of it on this part, tools/ubench/mfma_peak.hip): forward 54-67 %, data gradient 59-62 %,
+// weight gradient 51-66 % between 150 k and 300 k rows -- the BLAS 49-69 / 48-62 / 63-70 %; ahead of it at 300 k rows
+// (forward, data gradient), 3-12 % behind at 150 k.  By the counters on the first (32x32x2, one wave per SIMD) forward
+// kernel (rocprofv3 --pmc, profiles/r3_gemm_pmc.txt) the matrix pipe was busy 64 % of the time, its wave parked at the
+// chunk barrier / waitcnt 13 % and issuing LDS reads and register moves 16 % of the time.  Tried on the 16x16x4 kernel
+// and dropped: contiguous row ranges per workgroup with a partial last tile + loads two chunks ahead (117 us at
+// 150 k x 256 x 128 against 100 for the round-robin tiles with loads one chunk ahead).
+constexpr int TALL_BM = 128;
 constexpr int TALL_TB = 512;          // k_tall_wgrad: 8 waves (2 per SIMD; its accumulators are half the forward kernel's):
                                       // 117 -> 101 us at 150 k x 256 x 128.  The forward kernel stays at 4 waves: with the weight
                                       // slice, 4 accumulators and the operand prefetch a wave needs > 256 registers, and two
                                       // workgroups per CU spill (measured: 119 us with 8 waves against 106 with 4)
 
-template <int KP, bool BT>
-__global__ void __launch_bounds__(TB, 1)
-k_tall_fwd(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
-           int64_t ldc, int64_t M, const float* __restrict__ bias) {
-    constexpr int NC = KP / 16;                       // 32-deep chunks of the reduction
+// k_tall_fwd16 runs on v_mfma_f32_16x16x4_f32: a wave owns 16 output columns, so its weight slice is K/4 registers
+// (64 at K = 256) and a 16-row sub-tile's accumulator 4 -- 8 waves = TWO per SIMD fit the register file.  (First
+// version on v_mfma_f32_32x32x2_f32, 4 waves x 32 columns: K/2 weight registers + 64 accumulators = one wave per SIMD,
+// whose matrix pipe idles while it issues LDS reads and waits: 106 us at 150 k x 256 x 128 against 100 for this one.)
+// LDS image row-major with row stride 34 words: the A-operand fetch (16 rows x 2 k per 32-lane group) is conflict-free.
+constexpr int TALL_LDA16 = 34;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int KQ, bool BT>
+__global__ void __launch_bounds__(TALL_TB, 1)
+k_tall_fwd16(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
+             int64_t ldc, int64_t M, const float* __restrict__ bias) {
+    constexpr int NC = KQ / 8;                        // 32-deep chunks of the reduction (8 k-groups of 4)
     static_assert(NC % 2 == 0, "the buffer index of a chunk is its parity");
-    __shared__ float As[2][TALL_BM * TALL_LDA];
+    __shared__ __attribute__((aligned(16))) float As[2][TALL_BM * TALL_LDA16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int ka = lane >> 5, la = lane & 31;
-    const int64_t j0 = (int64_t)blockIdx.y * 128 + 32 * wave;
-    float breg[KP];
+    const int kk = lane >> 4, lc = lane & 15;         // operand layouts: A[row = lc][k = kk], B[k = kk][col = lc]
+    const int64_t j0 = (int64_t)blockIdx.y * 128 + 16 * wave;
+    float breg[KQ];
 #pragma unroll
-    for (int p = 0; p < KP; ++p)
-        breg[p] = BT ? B[(int64_t)(2 * p + ka) * ldb + j0 + la] : B[(j0 + la) * ldb + 2 * p + ka];
-    const float bv = bias ? bias[j0 + la] : 0.f;
+    for (int q = 0; q < KQ; ++q)
+        breg[q] = BT ? B[(int64_t)(4 * q + kk) * ldb + j0 + lc] : B[(j0 + lc) * ldb + 4 * q + kk];
+    const float bv = bias ? bias[j0 + lc] : 0.f;
     const int64_t ntiles = (M + TALL_BM - 1) / TALL_BM;
-    const int sr = tid >> 3, sk = (tid & 7) * 4;      // staging role: rows sr + 32 q, k piece sk .. sk + 3
-    float4 v[4];
+    const int sr = tid >> 3, sk = (tid & 7) * 4;      // staging role: rows sr, sr + 64; k piece sk .. sk + 3
+    float4 v[2];
     int64_t tile = blockIdx.x;
     if (tile >= ntiles) return;
 #define TF_FETCH(TILE, CH)                                                                             \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
-        int64_t r = (TILE) * TALL_BM + sr + 32 * q;                                                   \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                   \
+        int64_t r = (TILE) * TALL_BM + sr + 64 * q;                                                   \
         r = r < M ? r : M - 1;      /* rows past the end: any valid address; their outputs are not stored */ \
         v[q] = *reinterpret_cast<const float4*>(A + r * lda + (CH) * 32 + sk);                        \
     }
 #define TF_STASH(BUF)                                                                                 \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
-        float* d = &As[BUF][(sr + 32 * q) * TALL_LDA + sk];                                           \
-        d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w;                                   \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                   \
+        float2* d = reinterpret_cast<float2*>(&As[BUF][(sr + 64 * q) * TALL_LDA16 + sk]);             \
+        d[0] = make_float2(v[q].x, v[q].y); d[1] = make_float2(v[q].z, v[q].w);                       \
     }
     TF_FETCH(tile, 0)
     TF_STASH(0)
     __syncthreads();
-    const float* ar = &As[0][la * TALL_LDA + ka];
+    const float* ar = &As[0][lc * TALL_LDA16 + kk];
     for (; tile < ntiles; tile += gridDim.x) {
-        f32x16 acc[4];
+        f32x4 acc[8];
 #pragma unroll
-        for (int ms = 0; ms < 4; ++ms)
+        for (int ms = 0; ms < 8; ++ms)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ms][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[ms][r] = 0.f;
         const bool more_tiles = tile + gridDim.x < ntiles;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const bool next = c + 1 < NC || more_tiles;
             if (next) { TF_FETCH(c + 1 < NC ? tile : tile + gridDim.x, c + 1 < NC ? c + 1 : 0) }
             __builtin_amdgcn_sched_barrier(0);        // the loads go out before the chunk's MFMAs, not between them
-            const float* a = ar + (c & 1) * (TALL_BM * TALL_LDA);
+            const float* a = ar + (c & 1) * (TALL_BM * TALL_LDA16);
 #pragma unroll
-            for (int kp = 0; kp < 16; ++kp) {
+            for (int q = 0; q < 8; ++q) {
 #pragma unroll
-                for (int ms = 0; ms < 4; ++ms)
-                    acc[ms] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms * 32 * TALL_LDA + 2 * kp], breg[c * 16 + kp], acc[ms], 0, 0, 0);
-                if (kp == 7) {                        // mid-chunk: the other image is free since the last barrier
+                for (int ms = 0; ms < 8; ++ms)
+                    acc[ms] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ms * 16 * TALL_LDA16 + 4 * q], breg[c * 8 + q], acc[ms], 0, 0, 0);
+                if (q == 3) {                         // mid-chunk: the other image is free since the last barrier
                     __builtin_amdgcn_sched_barrier(0);
                     if (next) { TF_STASH((c + 1) & 1) }
                     __builtin_amdgcn_sched_barrier(0);
@@ -288,11 +297,11 @@ k_tall_fwd(const float* __restrict__ A, int64_t lda, const float* __restrict__ B
             __syncthreads();
         }
 #pragma unroll
-        for (int ms = 0; ms < 4; ++ms)
+        for (int ms = 0; ms < 8; ++ms)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t i = tile * TALL_BM + 32 * ms + (r & 3) + 8 * (r >> 2) + 4 * ka;
-                if (i < M) C[i * ldc + j0 + la] = acc[ms][r] + bv;
+            for (int r = 0; r < 4; ++r) {             // C/D layout of the 16x16 MFMA: column lane % 16, rows 4 (lane / 16) + r
+                const int64_t i = tile * TALL_BM + 16 * ms + 4 * kk + r;
+                if (i < M) C[i * ldc + j0 + lc] = acc[ms][r] + bv;
             }
     }
 #undef TF_FETCH
@@ -522,11 +531,11 @@ extern "C" int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, cons
     const int64_t ntiles = gda_cdiv(M, TALL_BM);
     const dim3 grid((unsigned)min(ntiles, (int64_t)256), (unsigned)(N / 128));
     if (mode == GDA_GEMM_NT) {
-        if (K == 128) k_tall_fwd<64, false><<<grid, TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
-        else k_tall_fwd<128, false><<<grid, TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
+        if (K == 128) k_tall_fwd16<32, false><<<grid, TALL_TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
+        else k_tall_fwd16<64, false><<<grid, TALL_TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
     } else {
-        if (K == 128) k_tall_fwd<64, true><<<grid, TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
-        else k_tall_fwd<128, true><<<grid, TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
+        if (K == 128) k_tall_fwd16<32, true><<<grid, TALL_TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
+        else k_tall_fwd16<64, true><<<grid, TALL_TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
     }
     GDA_LAUNCH_CHECK();
     return GDA_OK;
