@@ -165,12 +165,52 @@ def hbm_regime_probe(device, nodes=5_000_000, avg_degree=20, d=128, iters=5):
     traffic, src_file = pmc_traffic("k_spmm<32, 4", "r2_spmm5m*_summary.json")
     del G, x, y, ei
     torch.cuda.empty_cache()
-    return {"kernel": f"spmm_csr_f32[d={d}] (k_spmm<32,4>), N={nodes}, nnz={nnz}", "bound": "hbm",
-            "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": src_file, "avg_launch_us": us, "launches": iters,
-            "algorithmic_bytes_per_launch": alg, "gather_model_bytes_per_launch": gather,
-            "gather_model_GBs": gather / us / 1e3, "gather_model_frac": gather / us / 1e3 / HBM_PEAK_GBS,
-            "timing": "HIP events on the launch stream, same process, after the timed region"}
+    out = {"kernel": f"spmm_csr_f32[d={d}] (k_spmm<32,4>), N={nodes}, nnz={nnz}", "bound": "hbm",
+           "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBS,
+           "traffic": traffic, "traffic_source": src_file, "avg_launch_us": us, "launches": iters,
+           "algorithmic_bytes_per_launch": alg, "gather_model_bytes_per_launch": gather,
+           "gather_model_GBs": gather / us / 1e3, "gather_model_frac": gather / us / 1e3 / HBM_PEAK_GBS,
+           "timing": "HIP events on the launch stream, same process, after the timed region"}
+    out["rmat_2^22"] = rmat_probe(device, d, iters)
+    return out
+
+
+def rmat_probe(device, d=128, iters=5):
+    """The same full-graph aggregation on a power-law graph (R-MAT a, b, c = 0.57, 0.19, 0.19; 2^22 nodes, 32 M edges
+    symmetrised), as generated and after a degree-sorted relabelling (hubs first: the rows most rows gather share
+    cache lines and pages) -- the locality option a uniform graph has no use for."""
+    from pygda_amd import ops
+    from pygda_amd.graph import build_csr
+    from tools.spmm_sweep import rmat_edges
+    gen = torch.Generator(device=device).manual_seed(200)
+    n = 1 << 22
+    ei = rmat_edges(22, 32_000_000, gen)
+    ei = torch.cat([ei, ei.flip(0)], dim=1)
+    res = {}
+    for name in ("as_generated", "degree_sorted"):
+        if name == "degree_sorted":
+            order = torch.argsort(torch.bincount(ei[1], minlength=n), descending=True)
+            new_id = torch.empty_like(order)
+            new_id[order] = torch.arange(n, device=device)
+            ei = new_id[ei]
+            del order, new_id
+        G = build_csr(ei, n, validate=False)
+        x = torch.randn(n, d, device=device, generator=gen)
+        for _ in range(2):
+            ops.spmm_kstep(G, x, 1)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(iters):
+            ops.spmm_kstep(G, x, 1)
+        e.record()
+        torch.cuda.synchronize()
+        us = s.elapsed_time(e) * 1e3 / iters
+        alg = G.nnz * 8 + (n + 1) * 4 + 2 * n * d * 4
+        res[name] = {"avg_launch_us": us, "nnz": G.nnz, "algorithmic_GBs": alg / us / 1e3, "frac": alg / us / 1e3 / HBM_PEAK_GBS}
+        del G, x
+        torch.cuda.empty_cache()
+    return res
 
 
 def make_cfg_s(nodes, avg_degree, feat, classes, seed, device):
