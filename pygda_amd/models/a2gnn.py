@@ -69,11 +69,12 @@ class A2GNN(BaseGDA):
         loss = self._gmean(source_ce(source_logits, source_data.y), source_logits.size(0))   # :182, fused
         return loss, source_logits, source_features
 
-    def _target_branch(self, target_data, fork):
+    def _target_branch(self, target_data, fork, h0_t=None):
         """Target feature pass (:193); the loss-unused logits pass (:211) forked from its layer 0."""
         net = self.a2gnn
         tb = None if self.mode == 'node' else target_data.batch
-        h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
+        if h0_t is None:
+            h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
         pending = None
         if self.compute_target_logits and fork:
             pending = self._target_logits_async(net, target_data, h0_t)
