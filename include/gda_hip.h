@@ -692,6 +692,14 @@ int gda_gemm_ex_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, i
  *   TN: M == 128 (the output rows = columns of A), N in {128, 256}, K = the node count; colsum as in gda_gemm_ex_f32.
  * GDA_E_UNSUPPORTED outside that envelope -- callers then use gda_gemm_ex_f32, which takes any shape. */
 size_t gda_gemm_tall_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K);
+/* ... and for the classifier projection h -> C (C <= 8 classes, `self.cls` of a2gnn_base.py:62 / grade_base.py:66) at
+ * 10^5 rows, where a matrix-core tile is 92 % padding: memory-bound vector kernels, fixed-order sums.
+ *   NT: N <= 8, K in {32, 64, 128, 256} (+ bias);  NN: K <= 8, N in {32, .., 256};  TN: M <= 8, N in {32, .., 256}
+ *   (colsum as in gda_gemm_ex_f32).  GDA_E_UNSUPPORTED outside. */
+size_t gda_gemm_skinny_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K);
+int gda_gemm_skinny_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                        const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, float* colsum,
+                        void* workspace, size_t workspace_bytes, gda_stream_t stream);
 int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                       const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, float* colsum,
                       void* workspace, size_t workspace_bytes, gda_stream_t stream);

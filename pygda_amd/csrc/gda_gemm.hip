@@ -393,6 +393,123 @@ k_tall_wgrad(const float* __restrict__ G, int64_t ldg, const float* __restrict__
     }
 }
 
+// ---- skinny products: the classifier projection h -> C (C <= 8 classes) at 10^5 rows ---------------------------------
+// On the 64 x 64-tile kernel 92 % of such a product's matrix-core work is padding (5 of 64 columns) and its weight
+// gradient ran 179 us per cfg-S step; the products are memory-bound streams (read x once / write gx once), so they run on
+// the vector ALUs: W (<= 8 x 256) in LDS or registers, 16-byte coalesced accesses of the node matrix, fixed-order sums.
+constexpr int SK_N = 8;
+
+// y[M, N] = x[M, K] W[N, K]^T (+ bias): 8 lanes per row, lane j covers the 16-byte pieces j, j + 8, ... of the row
+__global__ void __launch_bounds__(TB)
+k_skinny_fwd(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
+             float* __restrict__ Y, int64_t ldy, int64_t M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) float Ws[SK_N * 256];
+    for (int i = threadIdx.x; i < N * K; i += TB) Ws[i] = W[(int64_t)(i / K) * ldw + i % K];
+    __syncthreads();
+    const int j = threadIdx.x & 7;
+    const int pieces = K / 4;
+    for (int64_t row = (int64_t)blockIdx.x * (TB / 8) + (threadIdx.x >> 3); row < M; row += (int64_t)gridDim.x * (TB / 8)) {
+        float acc[SK_N];
+#pragma unroll
+        for (int n = 0; n < SK_N; ++n) acc[n] = 0.f;
+        for (int p = j; p < pieces; p += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(X + row * ldx + 4 * p);
+#pragma unroll
+            for (int n = 0; n < SK_N; ++n)
+                if (n < N) {
+                    const float4 w = *reinterpret_cast<const float4*>(Ws + n * K + 4 * p);
+                    acc[n] = fmaf(v.x, w.x, acc[n]); acc[n] = fmaf(v.y, w.y, acc[n]);
+                    acc[n] = fmaf(v.z, w.z, acc[n]); acc[n] = fmaf(v.w, w.w, acc[n]);
+                }
+        }
+#pragma unroll
+        for (int n = 0; n < SK_N; ++n) {                   // butterfly over the row's 8 lanes: every lane ends with the sum
+            acc[n] += __shfl_xor(acc[n], 1, 8);
+            acc[n] += __shfl_xor(acc[n], 2, 8);
+            acc[n] += __shfl_xor(acc[n], 4, 8);
+        }
+        float out = 0.f;
+#pragma unroll
+        for (int n = 0; n < SK_N; ++n) out = (j == n) ? acc[n] : out;
+        if (j < N) Y[row * ldy + j] = out + (bias ? bias[j] : 0.f);
+    }
+}
+
+// gx[M, K] = gy[M, N] W[N, K]: K / 4 lanes per row, a 16-byte piece each
+__global__ void __launch_bounds__(TB)
+k_skinny_dgrad(const float* __restrict__ GY, int64_t ldg, const float* __restrict__ W, int64_t ldw, float* __restrict__ GX,
+               int64_t ldx, int64_t M, int N, int K) {
+    const int pieces = K / 4, p = threadIdx.x % pieces, rows_per_block = TB / pieces;
+    float4 w[SK_N];
+#pragma unroll
+    for (int n = 0; n < SK_N; ++n)
+        w[n] = n < N ? *reinterpret_cast<const float4*>(W + (int64_t)n * ldw + 4 * p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t row = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / pieces; row < M;
+         row += (int64_t)gridDim.x * rows_per_block) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int n = 0; n < SK_N; ++n)
+            if (n < N) {
+                const float g = GY[row * ldg + n];
+                o.x = fmaf(g, w[n].x, o.x); o.y = fmaf(g, w[n].y, o.y); o.z = fmaf(g, w[n].z, o.z); o.w = fmaf(g, w[n].w, o.w);
+            }
+        *reinterpret_cast<float4*>(GX + row * ldx + 4 * p) = o;
+    }
+}
+
+// slab partial of gW[N, K] = gy^T x and of colsum(gy): K / 4 lanes across a row, TB / (K / 4) row lanes, rows in order
+__global__ void __launch_bounds__(TB)
+k_skinny_wgrad(const float* __restrict__ GY, int64_t ldg, const float* __restrict__ X, int64_t ldx, float* __restrict__ P,
+               float* __restrict__ CS, int64_t M, int64_t rows_per_slab, int N, int K) {
+    __shared__ float red[TB * 4];
+    const int pieces = K / 4, p = threadIdx.x % pieces, rl = threadIdx.x / pieces, rlanes = TB / pieces;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab, r1 = min(M, r0 + rows_per_slab);
+    float4 acc[SK_N];
+    float cs[SK_N];
+#pragma unroll
+    for (int n = 0; n < SK_N; ++n) { acc[n] = make_float4(0.f, 0.f, 0.f, 0.f); cs[n] = 0.f; }
+    for (int64_t row = r0 + rl; row < r1; row += rlanes) {
+        const float4 v = *reinterpret_cast<const float4*>(X + row * ldx + 4 * p);
+#pragma unroll
+        for (int n = 0; n < SK_N; ++n)
+            if (n < N) {
+                const float g = GY[row * ldg + n];
+                acc[n].x = fmaf(g, v.x, acc[n].x); acc[n].y = fmaf(g, v.y, acc[n].y);
+                acc[n].z = fmaf(g, v.z, acc[n].z); acc[n].w = fmaf(g, v.w, acc[n].w);
+                cs[n] += g;
+            }
+    }
+    // the row lanes' partials are added in row-lane order through LDS (one class at a time)
+    float* out = P + (int64_t)blockIdx.x * N * K;
+    for (int n = 0; n < N; ++n) {
+        __syncthreads();
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        float c = 0.f;
+#pragma unroll
+        for (int q = 0; q < SK_N; ++q) if (q == n) { a = acc[q]; c = cs[q]; }
+        *reinterpret_cast<float4*>(red + 4 * threadIdx.x) = a;
+        __syncthreads();
+        if (rl == 0) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r = 0; r < rlanes; ++r) {
+                const float4 u = *reinterpret_cast<const float4*>(red + 4 * (r * pieces + p));
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            *reinterpret_cast<float4*>(out + (int64_t)n * K + 4 * p) = t;
+        }
+        if (CS) {
+            __syncthreads();
+            if (p == 0) red[rl] = c;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float t = 0.f;
+                for (int r = 0; r < rlanes; ++r) t += red[r];
+                CS[(int64_t)blockIdx.x * N + n] = t;
+            }
+        }
+    }
+}
+
 bool vec_ok(const float* p, int64_t ld) { return ld % 4 == 0 && ((uintptr_t)p & 15) == 0; }
 
 int slabs_for(int64_t K) {
@@ -536,6 +653,55 @@ extern "C" int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, cons
     } else {
         if (K == 128) k_tall_fwd16<32, true><<<grid, TALL_TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
         else k_tall_fwd16<64, true><<<grid, TALL_TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
+    }
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+// ---- skinny entry point ----------------------------------------------------------------------------------------------
+// The classifier projection's three products (at most 8 classes against a width of 32 / 64 / 128 / 256):
+//   NT  C[M, N] = A[M, K] B[N, K]^T (+ bias)     N <= 8, K in {32, 64, 128, 256}
+//   NN  C[M, N] = A[M, K] B[K, N]                K <= 8, N in {32, 64, 128, 256}      (data gradient)
+//   TN  C[M, N] = A[rows, M]^T B[rows, N]        M <= 8, N in {32, 64, 128, 256}, K = rows; colsum[M] = A's column sums
+// 16-byte aligned operands with leading dimensions % 4 == 0 where rows are read in 16-byte pieces.
+// GDA_E_UNSUPPORTED outside that envelope.
+static int64_t skinny_slabs(int64_t rows) { return min((int64_t)512, max((int64_t)1, rows / 256)); }
+
+extern "C" size_t gda_gemm_skinny_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
+    if (mode != GDA_GEMM_TN || M <= 0 || M > SK_N || K <= 0) return 0;
+    return (size_t)skinny_slabs(K) * (size_t)M * (size_t)(N + 1) * sizeof(float);
+}
+
+extern "C" int gda_gemm_skinny_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                                   const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, float* colsum,
+                                   void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    if (M <= 0 || N <= 0 || K <= 0 || ldc < N) return GDA_E_SIZE;
+    if (!A || !B || !C) return GDA_E_NULL;
+    if (C == A || C == B) return GDA_E_ALIAS;
+    hipStream_t stream = (hipStream_t)stream_;
+    auto wide_ok = [](int64_t w) { return w == 32 || w == 64 || w == 128 || w == 256; };
+    auto al = [](const float* p, int64_t ld) { return ld % 4 == 0 && ((uintptr_t)p & 15) == 0; };
+    if (mode == GDA_GEMM_NT) {
+        if (N > SK_N || !wide_ok(K) || colsum || !al(A, lda) || lda < K || ldb < K) return GDA_E_UNSUPPORTED;
+        const int64_t blocks = min(gda_cdiv(M, TB / 8), (int64_t)256 * 16);
+        k_skinny_fwd<<<(unsigned)blocks, TB, 0, stream>>>(A, lda, B, ldb, bias, C, ldc, M, (int)N, (int)K);
+    } else if (mode == GDA_GEMM_NN) {
+        if (K > SK_N || !wide_ok(N) || bias || colsum || !al(B, ldb) || !al(C, ldc) || lda < K || ldb < N) return GDA_E_UNSUPPORTED;
+        const int64_t rpb = TB / (N / 4);
+        const int64_t blocks = min(gda_cdiv(M, rpb), (int64_t)256 * 16);
+        k_skinny_dgrad<<<(unsigned)blocks, TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, (int)K, (int)N);
+    } else if (mode == GDA_GEMM_TN) {
+        if (M > SK_N || !wide_ok(N) || bias || !al(B, ldb) || lda < M || ldb < N) return GDA_E_UNSUPPORTED;
+        const int64_t slabs = skinny_slabs(K);
+        const int64_t rows = gda_cdiv(K, slabs);
+        if (!workspace || workspace_bytes < gda_gemm_skinny_workspace_bytes(mode, M, N, K)) return GDA_E_WORKSPACE;
+        float* part = (float*)workspace;
+        float* cs_part = part + (size_t)slabs * M * N;
+        k_skinny_wgrad<<<(unsigned)slabs, TB, 0, stream>>>(A, lda, B, ldb, part, colsum ? cs_part : nullptr, K, rows, (int)M, (int)N);
+        GDA_LAUNCH_CHECK();
+        k_slab_sum<<<(unsigned)gda_cdiv(M * N + (colsum ? M : 0), SS_OUT), TB, 0, stream>>>(part, (int)slabs, M, N, C, ldc, cs_part, colsum);
+    } else {
+        return GDA_E_UNSUPPORTED;
     }
     GDA_LAUNCH_CHECK();
     return GDA_OK;

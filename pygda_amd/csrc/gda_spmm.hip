@@ -17,6 +17,8 @@
 // HBM bound: algorithmic bytes per call = nnz*8 + (N+1)*4 + 2*N*d*4.
 #include "gda_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int TB = 256;           // 4 wavefronts per workgroup
@@ -92,7 +94,11 @@ __device__ __forceinline__ void apply_epilogue(float (&acc)[VEC], const Epilogue
     }
 }
 
-template <int G, int VEC, bool EPI>
+// STG: the (col, val) tile of a lane group is staged in LDS (one ds_write_b64 per lane, one ds_read_b64 per neighbour,
+// a broadcast inside the group) instead of being broadcast with two cross-lane shuffles per neighbour -- the
+// "LDS staging of per-wavefront neighbour tiles" of the path's specification.  Same values in the same order.
+// Measured against the shuffle form (tools/spmm_sweep.py with PYGDA_AMD_SPMM_LDS=1, profiles/r3_spmm_lds_vs_shuffle.jsonl).
+template <int G, int VEC, bool EPI, bool STG = false>
 __global__ void __launch_bounds__(TB)
 k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
        const float* __restrict__ val, int64_t n_rows, int d,
@@ -100,6 +106,8 @@ k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
        const float* __restrict__ bias, RowSplit sp, unsigned row_blocks, Epilogue ep) {
     constexpr int ROWS_PER_BLOCK = TB / G;
     const int lane_in_group = threadIdx.x % G;
+    __shared__ int2 stg_tile[STG ? TB : 1];                // STG: one (col, val bits) pair per lane
+    const int stg_base = threadIdx.x - lane_in_group;       // the group's first slot (groups never straddle a wave)
     const bool chunk_mode = blockIdx.x >= row_blocks;       // block-uniform
     int64_t row;                                             // output row (or chunk id in chunk mode)
     bool live;
@@ -140,14 +148,16 @@ k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
             const int32_t my_col = k < end ? colidx[k] : 0;
             const float my_val = k < end ? val[k] : 0.0f;
             const int cnt = min((int32_t)G, end - base);
+            if constexpr (STG) stg_tile[threadIdx.x] = make_int2(my_col, __float_as_int(my_val));   // same wave reads it back
             int e = 0;
             for (; e + UNROLL <= cnt; e += UNROLL) {
                 float xv[UNROLL][VEC];
                 float w[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
-                    const int32_t cu = __shfl(my_col, e + u, G);
-                    w[u] = __shfl(my_val, e + u, G);
+                    int32_t cu;
+                    if constexpr (STG) { const int2 p = stg_tile[stg_base + e + u]; cu = p.x; w[u] = __int_as_float(p.y); }
+                    else { cu = __shfl(my_col, e + u, G); w[u] = __shfl(my_val, e + u, G); }
                     if (col_ok) vload<VEC>(xv[u], x + (int64_t)cu * ldx + c);
                 }
 #pragma unroll
@@ -157,8 +167,9 @@ k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                         acc[v] = __fadd_rn(acc[v], __fmul_rn(w[u], col_ok ? xv[u][v] : 0.0f));
             }
             for (; e < cnt; ++e) {
-                const int32_t cu = __shfl(my_col, e, G);
-                const float w = __shfl(my_val, e, G);
+                int32_t cu; float w;
+                if constexpr (STG) { const int2 p = stg_tile[stg_base + e]; cu = p.x; w = __int_as_float(p.y); }
+                else { cu = __shfl(my_col, e, G); w = __shfl(my_val, e, G); }
                 float xv[VEC];
                 if (col_ok) {
                     vload<VEC>(xv, x + (int64_t)cu * ldx + c);
@@ -344,9 +355,13 @@ int launch(const int32_t* rowptr, const int32_t* colidx, const float* val, int64
     const int64_t row_blocks = gda_cdiv(n_rows, ROWS_PER_BLOCK);
     const int64_t chunk_blocks = sp.n_chunks > 0 ? gda_cdiv(sp.n_chunks, ROWS_PER_BLOCK) : 0;
     if (row_blocks + chunk_blocks > INT32_MAX) return GDA_E_SIZE;
+    static const bool staged = getenv("PYGDA_AMD_SPMM_LDS") != nullptr;     // measured alternative (see k_spmm): off by default
     if (ep)
         k_spmm<G, VEC, true><<<(unsigned)(row_blocks + chunk_blocks), TB, 0, s>>>(
             rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, bias, sp, (unsigned)row_blocks, *ep);
+    else if (staged)
+        k_spmm<G, VEC, false, true><<<(unsigned)(row_blocks + chunk_blocks), TB, 0, s>>>(
+            rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, bias, sp, (unsigned)row_blocks, Epilogue{});
     else
         k_spmm<G, VEC, false><<<(unsigned)(row_blocks + chunk_blocks), TB, 0, s>>>(
             rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, bias, sp, (unsigned)row_blocks, Epilogue{});

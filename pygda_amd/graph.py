@@ -55,7 +55,7 @@ class RowSplit:
         if self.n_long == 0:
             return None
         need = self.n_chunks * d
-        key = torch.cuda.current_stream().cuda_stream
+        key = torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
         buf = self._scratch.get(key)
         if buf is None or buf.numel() < need:
             buf = self._scratch[key] = torch.empty(need, dtype=torch.float32, device=self.long_rows.device)

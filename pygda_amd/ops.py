@@ -107,6 +107,17 @@ def _tall_shape(mode, M, N, K, a, b):
     return M >= TALL_ROWS and N in (128, 256) and K in (128, 256) and a.data_ptr() % 16 == 0
 
 
+def _skinny_shape(mode, M, N, K, a, b, c_ld):
+    """The envelope of gda_gemm_skinny_f32: the classifier projection (at most 8 classes) at sampled-batch row counts."""
+    wide = (32, 64, 128, 256)
+    al = lambda t: t.data_ptr() % 16 == 0
+    if mode == GEMM_NT:
+        return M >= TALL_ROWS and N <= 8 and K in wide and al(a)
+    if mode == GEMM_NN:
+        return M >= TALL_ROWS and K <= 8 and N in wide and al(b)
+    return K >= TALL_ROWS and M <= 8 and N in wide and al(b)
+
+
 def gemm(mode, a, b, bias=None, colsum=None):
     """fp32 product on the matrix cores (include/gda_hip.h: gda_gemm_ex_f32 / gda_gemm_tall_f32), no autograd.
     NT: ``a [M,K] @ b [N,K]^T`` (+ ``bias [N]`` in the epilogue); NN: ``a [M,K] @ b [K,N]``;
@@ -123,12 +134,15 @@ def gemm(mode, a, b, bias=None, colsum=None):
     c = torch.empty(M, N, dtype=torch.float32, device=a.device)
     L = _lib.lib()
     tall = _tall_shape(mode, M, N, K, a, b)
-    need = (L.gda_gemm_tall_workspace_bytes if tall else L.gda_gemm_workspace_bytes)(mode, M, N, K)
+    skinny = not tall and _skinny_shape(mode, M, N, K, a, b, N)
+    need = (L.gda_gemm_tall_workspace_bytes if tall else L.gda_gemm_skinny_workspace_bytes if skinny
+            else L.gda_gemm_workspace_bytes)(mode, M, N, K)
     ws = _lib.workspace(need, a.device, "gemm") if need else None
     name = ("dense_projection", "dense_projection_dgrad", "dense_projection_wgrad")[mode]
     with profiler.region(f"{name}[{K}x{N}]" if mode != GEMM_TN else f"{name}[{M}x{N}]", 1,
                          4 * (a.numel() + b.numel() + c.numel()), 2 * M * N * K):
-        fn, what = (L.gda_gemm_tall_f32, "gda_gemm_tall_f32") if tall else (L.gda_gemm_ex_f32, "gda_gemm_ex_f32")
+        fn, what = ((L.gda_gemm_tall_f32, "gda_gemm_tall_f32") if tall else
+                    (L.gda_gemm_skinny_f32, "gda_gemm_skinny_f32") if skinny else (L.gda_gemm_ex_f32, "gda_gemm_ex_f32"))
         _lib.check(fn(mode, M, N, K, _lib.ptr(a), a.size(1), _lib.ptr(b), b.size(1), _lib.ptr(c), N,
                       _lib.ptr(bias), _lib.ptr(colsum), _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream()),
                    what)

@@ -5,7 +5,6 @@ launches, their summed duration on the launch stream, and the algorithmic bytes 
 they moved -- the inputs of the roofline line.  Events are recorded on the stream the
 kernels are launched on (torch's current stream, which is what the C ABI is handed)."""
 from collections import defaultdict
-from contextlib import contextmanager
 
 import torch
 
@@ -24,20 +23,42 @@ def stop():
     enabled = False
 
 
-@contextmanager
-def region(name, launches=1, nbytes=0, flops=0, **extra):
-    """``extra``: further per-call byte counts of the kernel family (summed by :func:`summary`), e.g. the bytes a
-    kernel really moves over HBM next to the algorithmic bytes it stands for."""
-    if not enabled:
-        yield
-        return
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    try:
-        yield
-    finally:
+class _Null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+class _Region:
+    __slots__ = ("name", "launches", "nbytes", "flops", "extra", "s")
+
+    def __init__(self, name, launches, nbytes, flops, extra):
+        self.name, self.launches, self.nbytes, self.flops, self.extra = name, launches, nbytes, flops, extra
+
+    def __enter__(self):
+        self.s = torch.cuda.Event(enable_timing=True)
+        self.s.record()
+
+    def __exit__(self, *exc):
+        e = torch.cuda.Event(enable_timing=True)
         e.record()
-        _records[name].append((s, e, launches, nbytes, flops, extra))
+        _records[self.name].append((self.s, e, self.launches, self.nbytes, self.flops, self.extra))
+        return False
+
+
+_NULL = _Null()
+
+
+def region(name, launches=1, nbytes=0, flops=0, **extra):
+    """Context manager bracketing a kernel family's launches with HIP events (a shared no-op object while the
+    profiler is off: the call sites sit on the eager training loop's host path).  ``extra``: further per-call byte
+    counts of the kernel family (summed by :func:`summary`), e.g. the bytes a kernel really moves over HBM next to
+    the algorithmic bytes it stands for."""
+    if not enabled:
+        return _NULL
+    return _Region(name, launches, nbytes, flops, extra)
 
 
 def summary():

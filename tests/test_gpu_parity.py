@@ -1200,6 +1200,30 @@ def test_tall_gemm_weight_in_registers_vs_fp64(M, N, K):
     close(ops.gemm(ops.GEMM_NT, ad, w96.to(DEV)), want96, rtol=0, atol=tol(want96, K))
 
 
+@pytest.mark.parametrize("M,C,K", [(33_000, 5, 128), (70_001, 2, 256), (40_000, 8, 64), (157_013, 5, 128)])
+def test_skinny_classifier_gemm_vs_fp64(M, C, K):
+    """The classifier projection h -> C (at most 8 classes) at sampled-batch row counts on the vector kernels
+    (gda_gemm_skinny_f32): forward (+ bias), data gradient, weight gradient (+ column sums) against fp64; the
+    weight gradient's slab sum is deterministic."""
+    assert ops._skinny_shape(ops.GEMM_NT, M, C, K, torch.empty(4, device=DEV), None, C)
+    gen = torch.Generator().manual_seed(M % 977 + C + K)
+    x, w = torch.randn(M, K, generator=gen), torch.randn(C, K, generator=gen)
+    gy, bias = torch.randn(M, C, generator=gen), torch.randn(C, generator=gen)
+    xd, wd, gyd = x.to(DEV), w.to(DEV), gy.to(DEV)
+    want = x.double() @ w.double().t()
+    close(ops.gemm(ops.GEMM_NT, xd, wd), want, rtol=0, atol=2e-6 * float(want.abs().max()) * (K / 128) ** 0.5)
+    close(ops.gemm(ops.GEMM_NT, xd, wd, bias=bias.to(DEV)), want + bias.double(), rtol=0,
+          atol=2e-6 * float(want.abs().max()) * (K / 128) ** 0.5)
+    wantx = gy.double() @ w.double()
+    close(ops.gemm(ops.GEMM_NN, gyd, wd), wantx, rtol=0, atol=2e-6 * float(wantx.abs().max()))
+    wantw = gy.double().t() @ x.double()
+    cs = torch.empty(C, device=DEV)
+    got = ops.gemm(ops.GEMM_TN, gyd, xd, colsum=cs)
+    close(got, wantw, rtol=0, atol=3e-6 * float(wantw.abs().max()) * (M / 128) ** 0.5)
+    close(cs, gy.double().sum(0), rtol=0, atol=1e-3)
+    exact(got, ops.gemm(ops.GEMM_TN, gyd, xd))
+
+
 def test_linear_layer_at_sampled_batch_size_with_autograd():
     """A hidden layer at 60 k rows (the BLAS's territory until round 3): forward, data and weight gradient on the
     hand-written kernels against the torch composition."""
