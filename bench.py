@@ -73,7 +73,12 @@ def pmc_traffic(prefix="k_spmm<32, 4", pattern="*_rocprof_summary.json"):
     and --pmc WRITE_SIZE runs of this same command, 2 x FETCH + WRITE per the gfx950 correction).
     PMC counters cannot be collected from inside the timed run; None if no summary is present."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=os.path.getmtime)
+    import re
+
+    def rnd(f):          # newest ROUND first (file times do not survive a checkout)
+        m = re.match(r"r(\d+)", os.path.basename(f))
+        return (int(m.group(1)) if m else -1, os.path.basename(f))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=rnd)
     for f in reversed(files):
         try:
             pmc = json.load(open(f)).get("pmc", {})
@@ -334,8 +339,9 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                        "launches": r["launches"], "avg_launch_us": r["avg_us"],
                        "algorithmic_bytes_per_launch": r["bytes"] / r["launches"]}
                 if r.get("alg_equiv_bytes"):
-                    out["bytes_are"] = ("what the interior-rows K-step itself moves (gather model: K steps over the rows "
-                                        "that can change + one pass over the leaves), NOT K full aggregations")
+                    out["bytes_are"] = ("what the interior-rows K-step itself has to move (K steps over the rows that can "
+                                        "change, every distinct row read once per step, + one pass over the leaves), NOT "
+                                        "K full aggregations; `launches` = K interior steps + the leaf pass")
                     out["k_full_aggregations_equivalent_GBs"] = r["alg_equiv_bytes"] / secs / 1e9
                 return out
             ach = r["flops"] / secs / 1e12
@@ -549,6 +555,9 @@ def run_cfg_a(args, world, rank, dev, side=False):
         return None
     ms = 1e3 * dt / args.steps
 
+    # committed PMC passes of this same command (profiles/, made by tools/profile_r3.sh)
+    prof_pattern = "r[0-9]*_cfgA" + ("_powerlaw" if args.graph == "powerlaw" else "") + "_rocprof_summary.json"
+
     def roof(name):
         r = prof[name]
         secs = r["ms"] * 1e-3
@@ -563,7 +572,7 @@ def run_cfg_a(args, world, rank, dev, side=False):
                 # launches would have moved"), NOT a bandwidth the memory system delivered -- the kernel's own
                 # HBM traffic is the plan + one read and one write of the activations (`hbm_bytes_per_launch`),
                 # its bound is the LDS gather rate (`lds`)
-                out["traffic"], out["traffic_source"] = pmc_traffic("k_kstep_lds", "r[0-9]*_rocprof_summary.json")
+                out["traffic"], out["traffic_source"] = pmc_traffic("k_kstep_lds", prof_pattern)
                 out["achieved_is"] = "algorithmic-equivalent (K aggregations per launch), see DESIGN 4.1b"
                 if r.get("hbm_bytes"):
                     out["hbm_bytes_per_launch"] = r["hbm_bytes"] / r["launches"]
@@ -581,7 +590,7 @@ def run_cfg_a(args, world, rank, dev, side=False):
                                           f"table); the launch has {cols} workgroups, one per feature column, so it "
                                           f"occupies {min(cols, 256)} of the 256 CUs"}
             else:
-                out["traffic"], out["traffic_source"] = pmc_traffic() if "d=128" in name else (None, None)
+                out["traffic"], out["traffic_source"] = pmc_traffic("k_spmm<32, 4", prof_pattern) if "d=128" in name else (None, None)
             return out
         ach = r["flops"] / secs / 1e12
         return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",

@@ -176,17 +176,18 @@ def _launch_kstep_interior(graph, x, K, bias, transposed, y):
         aggregation_log.append((graph, int(K)))
     _note_path("interior-rows", int(K))
     if profiler.enabled:
-        # `bytes`: what the call itself moves (gather model: every stored entry reads a d-wide row) -- forward K
-        # interior steps + one copy of the leaf rows; transposed K interior steps (few entries: bounded by their rows'
-        # inputs, outputs and running sums) + one pass over every entry for the leaves.  `alg_equiv_bytes`: SURVEY
-        # 8(d)'s algorithmic bytes of the K full aggregations the call stands for.
+        # `bytes`: what the call itself has to move -- forward K interior steps + one copy of the leaf rows; transposed K
+        # interior steps + one pass over every entry for the leaves.  `alg_equiv_bytes`: SURVEY 8(d)'s algorithmic
+        # bytes of the K full aggregations the call stands for.
         global aggregated_edges
         aggregated_edges += int(K) * graph.nnz
         nnz, n_leaf, row = graph.nnz, n - n_int, 4 * d
+        # compulsory bytes: a step reads every distinct row its entries name at most once (<= n rows; the transposed
+        # interior steps name interior rows only), the index arrays, and writes its own rows
         if transposed:
-            real = K * (4 * n_int * row) + nnz * (8 + row) + 2 * n_leaf * row
+            real = K * (3 * n_int * row) + nnz * 8 + n_int * row + 2 * n_leaf * row
         else:
-            real = K * (nnz * (8 + row) + n_int * row + (n_int + 1) * 4) + 2 * n_leaf * row
+            real = K * (nnz * 8 + min(nnz, n) * row + n_int * row + (n_int + 1) * 4) + 2 * n_leaf * row
         ctx = profiler.region(f"spmm_interior_f32[d={d}]", K + 1, real, K * 2 * nnz * d,
                               alg_equiv_bytes=K * (nnz * 8 + (n + 1) * 4 + 2 * n * d * 4))
     else:

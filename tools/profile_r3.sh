@@ -22,5 +22,10 @@ python tools/summarize_rocprof.py --tag r3_cfgA --stats $O/prof_r3_cfgA --fetch 
 python tools/summarize_rocprof.py --tag r3_cfgA_powerlaw --stats $O/prof_r3_cfgA_powerlaw --fetch $O/pmcf_r3_cfgA_powerlaw --write $O/pmcw_r3_cfgA_powerlaw --bench $O/prof_r3_cfgA_powerlaw_out.txt --cmd "$AP" --out $O > /dev/null
 python tools/summarize_rocprof.py --tag r3_cfgS --stats $O/prof_r3_cfgS --fetch $O/pmcf_r3_cfgS --write $O/pmcw_r3_cfgS --bench $O/prof_r3_cfgS_out.txt --cmd "$C" --out $O > /dev/null
 python tools/step_timeline.py $O/prof_r3_cfgA 20 2 > $O/r3_cfgA_timeline.txt 2>&1
-rm -rf $O/prof_r3_* $O/pmcf_r3_*/ $O/pmcw_r3_*/ $O/pmcl_r3_*/ 2>/dev/null
+rm -rf $O/prof_r3_*/ $O/pmcf_r3_*/ $O/pmcw_r3_*/ $O/pmcl_r3_*/ 2>/dev/null
+ls -la $O/r3_*
+timeout 300 python tools/gemm_bench.py > $O/r3_gemm_bench.jsonl 2> $O/r3_gemm_bench.err
+python bench.py > $O/r3_bench.json 2> $O/r3_bench.err
+python bench.py --graph powerlaw --no-side-lines --no-hbm-probe --no-cpu-baseline > $O/r3_bench_powerlaw.json 2> $O/r3_bench_powerlaw.err
+python bench.py --workload cfgS > $O/r3_bench_cfgS_5M.json 2> $O/r3_bench_cfgS_5M.err
 ls -la $O/r3_*

@@ -97,7 +97,8 @@ def main():
         for k, v in sorted(pmc.items(), key=lambda kv: -(kv[1].get("FETCH_SIZE", {}).get("avg_kib", 0) *
                                                          kv[1].get("FETCH_SIZE", {}).get("launches", 0)))[:25]:
             fe, wr = v.get("FETCH_SIZE", {}).get("avg_kib", 0.0), v.get("WRITE_SIZE", {}).get("avg_kib", 0.0)
-            wide = (k.startswith("k_spmm<") and k.split(",")[1].strip().startswith("4")) or k.startswith("k_kstep_lds")
+            wide = ((k.startswith("k_spmm<") or k.startswith("k_spmm_range<")) and k.split(",")[1].strip().startswith("4")) \
+                or k.startswith("k_kstep_lds") or k.startswith("k_tall")
             traffic = ((2 if wide else 1) * fe + wr) * 1024
             n = v.get("FETCH_SIZE", v.get("WRITE_SIZE"))["launches"]
             lines.append(f"| `{k}` | {n} | {fe:.1f} | {wr:.1f} | {traffic/1e6:.3f} |")
