@@ -601,11 +601,13 @@ class _PinnedRing:
 _pinned_ring = _PinnedRing()
 
 
-def mmd_samples_to_device(source_sample, target_sample, ns, nt, dev):
+def mmd_samples_to_device(source_sample, target_sample, ns, nt, dev, stacked=True):
     """The two ``[times, n]`` CPU row-sample tensors of an MMD call and the selection CSRs of their gradient scatter
-    -> ``(idx_s, idx_t, sel)`` on the device through one pinned block and one non-blocking copy."""
+    -> ``(idx_s, idx_t, sel)`` on the device through one pinned block and one non-blocking copy.  ``stacked``: the
+    gradient buffer holds source and target rows side by side (``[times, 2n, d]``, the single-process loss);
+    otherwise each domain scatters out of its own ``[times, n, d]`` buffer (the data-parallel row exchange)."""
     times, n = source_sample.shape
-    m = 2 * n
+    m = 2 * n if stacked else n
     a16 = lambda v: (v + 15) // 16 * 16
     sizes = [8 * times * n, 8 * times * n, 4 * (ns + 1), 4 * times * n, 4 * (nt + 1), 4 * times * n]
     offs = [0]
@@ -616,7 +618,8 @@ def mmd_samples_to_device(source_sample, target_sample, ns, nt, dev):
     view(0, torch.int64, times * n).copy_(source_sample.reshape(-1))
     view(1, torch.int64, times * n).copy_(target_sample.reshape(-1))
     selection_csr_host(source_sample, ns, 0, m, out=(view(2, torch.int32, ns + 1), view(3, torch.int32, times * n)))
-    selection_csr_host(target_sample, nt, n, m, out=(view(4, torch.int32, nt + 1), view(5, torch.int32, times * n)))
+    selection_csr_host(target_sample, nt, n if stacked else 0, m,
+                       out=(view(4, torch.int32, nt + 1), view(5, torch.int32, times * n)))
     block = torch.empty(offs[-1], dtype=torch.uint8, device=dev)
     block.copy_(host[:offs[-1]], non_blocking=True)
     _pinned_ring.sent(slot, torch.cuda.current_stream())

@@ -52,10 +52,15 @@ def MMD(source_feat, target_feat, sampling_num=1000, times=5, *, scale=1.0, add=
             s_idx, t_idx, sel_s, sel_t = dp_index_provider(ns, nt, times, per)
         else:
             s_cpu, t_cpu = torch.randint(ns, (times, per)), torch.randint(nt, (times, per))
-            ones = torch.ones(times * per, dtype=torch.float32, device=dev)
-            sel_s = tuple(t.to(dev, non_blocking=True) for t in selection_csr_host(s_cpu, ns, 0, per)) + (ones,)
-            sel_t = tuple(t.to(dev, non_blocking=True) for t in selection_csr_host(t_cpu, nt, 0, per)) + (ones,)
-            s_idx, t_idx = s_cpu.to(dev, non_blocking=True), t_cpu.to(dev, non_blocking=True)
+            if dev.type == "cuda":      # one pinned block, one asynchronous copy (pageable .to() calls drain the stream)
+                from ..ops import mmd_samples_to_device
+                s_idx, t_idx, sel = mmd_samples_to_device(s_cpu, t_cpu, ns, nt, dev, stacked=False)
+                sel_s, sel_t = (sel[0], sel[1], sel[4]), (sel[2], sel[3], sel[4])
+            else:
+                ones = torch.ones(times * per, dtype=torch.float32, device=dev)
+                sel_s = tuple(t.to(dev) for t in selection_csr_host(s_cpu, ns, 0, per)) + (ones,)
+                sel_t = tuple(t.to(dev) for t in selection_csr_host(t_cpu, nt, 0, per)) + (ones,)
+                s_idx, t_idx = s_cpu.to(dev), t_cpu.to(dev)
         s_rows = distributed.all_gather_rows(sample_rows(source_feat, s_idx, sel_s))    # [W, times, per, d]
         t_rows = distributed.all_gather_rows(sample_rows(target_feat, t_idx, sel_t))
         d = source_feat.size(1)
