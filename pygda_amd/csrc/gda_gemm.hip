@@ -231,17 +231,22 @@ constexpr int TALL_TB = 512;          // k_tall_wgrad: 8 waves (2 per SIMD; its 
 // (64 at K = 256) and a 16-row sub-tile's accumulator 4 -- 8 waves = TWO per SIMD fit the register file.  (First
 // version on v_mfma_f32_32x32x2_f32, 4 waves x 32 columns: K/2 weight registers + 64 accumulators = one wave per SIMD,
 // whose matrix pipe idles while it issues LDS reads and waits: 106 us at 150 k x 256 x 128 against 100 for this one.)
-// LDS image row-major with row stride 34 words: the A-operand fetch (16 rows x 2 k per 32-lane group) is conflict-free.
-constexpr int TALL_LDA16 = 34;
+// LDS image row-major with a row stride == 2 mod 32 words: the A-operand fetch (16 rows x 2 k per 32-lane group) is
+// conflict-free.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-template <int KQ, bool BT>
+template <int KQ, bool BT, int CQ /* k-groups of 4 per chunk: 8 (32-deep) or 16 (64-deep: half the barriers) */>
 __global__ void __launch_bounds__(TALL_TB, 1)
 k_tall_fwd16(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
              int64_t ldc, int64_t M, const float* __restrict__ bias) {
-    constexpr int NC = KQ / 8;                        // 32-deep chunks of the reduction (8 k-groups of 4)
+    constexpr int NC = KQ / CQ;                       // chunks of the reduction
+    constexpr int CK = 4 * CQ;                        // reduction depth of a chunk
+    constexpr int LD = CK + 2;                        // row stride of the LDS image (== 2 mod 32: conflict-free fetches)
+    constexpr int PQ = TALL_BM * CK / 4 / TALL_TB;    // 16-byte pieces per thread and chunk
+    constexpr int RSTEP = TALL_TB / (CK / 4);         // rows between a thread's pieces
     static_assert(NC % 2 == 0, "the buffer index of a chunk is its parity");
-    __shared__ __attribute__((aligned(16))) float As[2][TALL_BM * TALL_LDA16];
+    extern __shared__ __attribute__((aligned(16))) float tf_lds[];
+    float* As = tf_lds;                               // [2][TALL_BM * LD]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int kk = lane >> 4, lc = lane & 15;         // operand layouts: A[row = lc][k = kk], B[k = kk][col = lc]
     const int64_t j0 = (int64_t)blockIdx.y * 128 + 16 * wave;
@@ -251,25 +256,25 @@ k_tall_fwd16(const float* __restrict__ A, int64_t lda, const float* __restrict__
         breg[q] = BT ? B[(int64_t)(4 * q + kk) * ldb + j0 + lc] : B[(j0 + lc) * ldb + 4 * q + kk];
     const float bv = bias ? bias[j0 + lc] : 0.f;
     const int64_t ntiles = (M + TALL_BM - 1) / TALL_BM;
-    const int sr = tid >> 3, sk = (tid & 7) * 4;      // staging role: rows sr, sr + 64; k piece sk .. sk + 3
-    float4 v[2];
+    const int sr = tid / (CK / 4), sk = (tid % (CK / 4)) * 4;      // staging role: rows sr + RSTEP q; k piece sk .. sk + 3
+    float4 v[PQ];
     int64_t tile = blockIdx.x;
     if (tile >= ntiles) return;
 #define TF_FETCH(TILE, CH)                                                                             \
-    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                   \
-        int64_t r = (TILE) * TALL_BM + sr + 64 * q;                                                   \
+    _Pragma("unroll") for (int q = 0; q < PQ; ++q) {                                                  \
+        int64_t r = (TILE) * TALL_BM + sr + RSTEP * q;                                                \
         r = r < M ? r : M - 1;      /* rows past the end: any valid address; their outputs are not stored */ \
-        v[q] = *reinterpret_cast<const float4*>(A + r * lda + (CH) * 32 + sk);                        \
+        v[q] = *reinterpret_cast<const float4*>(A + r * lda + (CH) * CK + sk);                        \
     }
 #define TF_STASH(BUF)                                                                                 \
-    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                   \
-        float2* d = reinterpret_cast<float2*>(&As[BUF][(sr + 64 * q) * TALL_LDA16 + sk]);             \
+    _Pragma("unroll") for (int q = 0; q < PQ; ++q) {                                                  \
+        float2* d = reinterpret_cast<float2*>(As + (BUF) * TALL_BM * LD + (sr + RSTEP * q) * LD + sk); \
         d[0] = make_float2(v[q].x, v[q].y); d[1] = make_float2(v[q].z, v[q].w);                       \
     }
     TF_FETCH(tile, 0)
     TF_STASH(0)
     __syncthreads();
-    const float* ar = &As[0][lc * TALL_LDA16 + kk];
+    const float* ar = As + lc * LD + kk;
     for (; tile < ntiles; tile += gridDim.x) {
         f32x4 acc[8];
 #pragma unroll
@@ -282,13 +287,13 @@ k_tall_fwd16(const float* __restrict__ A, int64_t lda, const float* __restrict__
             const bool next = c + 1 < NC || more_tiles;
             if (next) { TF_FETCH(c + 1 < NC ? tile : tile + gridDim.x, c + 1 < NC ? c + 1 : 0) }
             __builtin_amdgcn_sched_barrier(0);        // the loads go out before the chunk's MFMAs, not between them
-            const float* a = ar + (c & 1) * (TALL_BM * TALL_LDA16);
+            const float* a = ar + (c & 1) * (TALL_BM * LD);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < CQ; ++q) {
 #pragma unroll
                 for (int ms = 0; ms < 8; ++ms)
-                    acc[ms] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ms * 16 * TALL_LDA16 + 4 * q], breg[c * 8 + q], acc[ms], 0, 0, 0);
-                if (q == 3) {                         // mid-chunk: the other image is free since the last barrier
+                    acc[ms] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ms * 16 * LD + 4 * q], breg[c * CQ + q], acc[ms], 0, 0, 0);
+                if (q == CQ / 2 - 1) {                // mid-chunk: the other image is free since the last barrier
                     __builtin_amdgcn_sched_barrier(0);
                     if (next) { TF_STASH((c + 1) & 1) }
                     __builtin_amdgcn_sched_barrier(0);
@@ -647,13 +652,25 @@ extern "C" int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, cons
     if (bias && mode != GDA_GEMM_NT) return GDA_E_UNSUPPORTED;
     const int64_t ntiles = gda_cdiv(M, TALL_BM);
     const dim3 grid((unsigned)min(ntiles, (int64_t)256), (unsigned)(N / 128));
+    // 64-deep chunks (one barrier per 128 MFMAs of a wave; 32-deep: 186 -> 183 us forward, 201 -> 187 us data gradient
+    // at 300 k x 256 x 128)
+#define TF_LAUNCH(KQ_, BT_)                                                                                   \
+    do {                                                                                                      \
+        const size_t lds = (size_t)2 * TALL_BM * (4 * 16 + 2) * sizeof(float);                                \
+        static bool configured = false;              /* idempotent attribute; racing first calls set the same value */ \
+        if (!configured) {                                                                                    \
+            GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tall_fwd16<KQ_, BT_, 16>),        \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));         \
+            configured = true;                                                                                \
+        }                                                                                                     \
+        k_tall_fwd16<KQ_, BT_, 16><<<grid, TALL_TB, lds, stream>>>(A, lda, B, ldb, C, ldc, M, bias);          \
+    } while (0)
     if (mode == GDA_GEMM_NT) {
-        if (K == 128) k_tall_fwd16<32, false><<<grid, TALL_TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
-        else k_tall_fwd16<64, false><<<grid, TALL_TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
+        if (K == 128) TF_LAUNCH(32, false); else TF_LAUNCH(64, false);
     } else {
-        if (K == 128) k_tall_fwd16<32, true><<<grid, TALL_TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
-        else k_tall_fwd16<64, true><<<grid, TALL_TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, bias);
+        if (K == 128) TF_LAUNCH(32, true); else TF_LAUNCH(64, true);
     }
+#undef TF_LAUNCH
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
