@@ -50,6 +50,90 @@ def test_argument_validation_without_gpu():
     assert L.gda_gather_rows_f32(None, 4, 8, None, 3, None, 8, None) == -2                    # ldx < d
 
 
+def test_round3_entry_points_validate_before_touching_a_device():
+    """The entry points added in round 3: capacity maths of the device sampler (host-only), envelopes of the tall /
+    skinny GEMMs and of the interior-rows K-step, argument errors of the graph-mode readout."""
+    import ctypes
+    import numpy as np
+    L = _lib.lib()
+    one = ctypes.c_void_p(1)                                   # non-NULL dummies: validation comes first
+    fan = np.array([15, 10], dtype=np.int32)
+    nc, ec = ctypes.c_int64(), ctypes.c_int64()
+    assert L.gda_dsampler_caps(1024, fan.ctypes.data, 2, 400, 100_000_000, 5_000_000, ctypes.byref(nc), ctypes.byref(ec)) == 0
+    assert (nc.value, ec.value) == (1024 * (1 + 15 + 150), 1024 * (15 + 150))      # seeds x (1 + k1 + k1 k2), picks
+    assert L.gda_dsampler_workspace_bytes(1024, fan.ctypes.data, 2, 400, 100_000_000, 5_000_000) > 0
+    small = np.array([15, 10], dtype=np.int32)
+    assert L.gda_dsampler_caps(64, small.ctypes.data, 2, 3, 500, 200, ctypes.byref(nc), ctypes.byref(ec)) == 0
+    assert nc.value == 200 and ec.value == 64 * 3 + 500       # bounded by the graph: in-degree <= 3, E = 500 edges (in-lists are disjoint), N = 200 nodes
+    for bad in ([0, 5], [65], [4, 0]):                         # fan-out 0 or above 64: the host sampler's business
+        b = np.array(bad, dtype=np.int32)
+        assert L.gda_dsampler_caps(8, b.ctypes.data, len(bad), 10, 100, 50, ctypes.byref(nc), ctypes.byref(ec)) == -4
+        assert L.gda_dsampler_workspace_bytes(8, b.ctypes.data, len(bad), 10, 100, 50) == 0
+    allk = np.array([-1, -1], dtype=np.int32)                  # whole neighbourhoods: bounded by the edge count
+    assert L.gda_dsampler_caps(8, allk.ctypes.data, 2, 10, 100, 50, ctypes.byref(nc), ctypes.byref(ec)) == 0
+    assert nc.value == 50 and ec.value == 80 + 100
+    assert L.gda_dsampler_sample(None, None, 10, 5, 2, None, 1, fan.ctypes.data, 2, 0, None, None, None, None, None, None,
+                                 None, None, None, None, None, 0, None) == -1
+    assert L.gda_dsampler_build_graph(one, one, 2 ** 31, 10, one, one, one, one, 1 << 40, None) == -2      # int32 edge count
+    # GEMM envelopes: refused shapes are the general kernel's business
+    assert L.gda_gemm_tall_f32(0, 100_000, 96, 128, one, 128, one, 128, ctypes.c_void_p(2), 96, None, None, None, 0, None) == -4
+    assert L.gda_gemm_tall_f32(0, 100_000, 128, 100, one, 100, one, 100, ctypes.c_void_p(2), 128, None, None, None, 0, None) == -4
+    assert L.gda_gemm_tall_f32(2, 64, 128, 100_000, one, 64, one, 128, ctypes.c_void_p(2), 128, None, None, None, 0, None) == -4
+    assert L.gda_gemm_tall_workspace_bytes(2, 128, 256, 150_000) == 256 * 128 * 257 * 4
+    assert L.gda_gemm_tall_workspace_bytes(0, 150_000, 128, 256) == 0
+    assert L.gda_gemm_skinny_f32(0, 100_000, 9, 128, one, 128, one, 128, ctypes.c_void_p(2), 9, None, None, None, 0, None) == -4
+    assert L.gda_gemm_skinny_f32(0, 100_000, 5, 100, one, 100, one, 100, ctypes.c_void_p(2), 5, None, None, None, 0, None) == -4
+    assert L.gda_gemm_skinny_f32(2, 5, 128, 100_000, one, 5, ctypes.c_void_p(16), 128, ctypes.c_void_p(2), 128, None, None,
+                                 None, 0, None) == -3          # the slab partials need a workspace
+    assert L.gda_gemm_skinny_workspace_bytes(2, 5, 128, 100_000) == (100_000 // 256) * 5 * 129 * 4
+    # interior-rows K-step / graph-mode readout
+    assert L.gda_spmm_csr_interior_kstep_f32(one, one, one, 10, 11, 4, 2, 0, one, ctypes.c_void_p(2), one, None, None, None) == -2
+    assert L.gda_spmm_csr_interior_kstep_f32(one, one, one, 10, 4, 4, 2, 0, one, ctypes.c_void_p(2), None, None, None, None) == -1
+    assert L.gda_spmm_csr_interior_kstep_f32(one, one, one, 10, 4, 4, 0, 0, one, ctypes.c_void_p(2), one, None, None, None) == -2
+    assert L.gda_segment_mean_fwd_f32(None, 4, None, 3, 4, None, 4, None) == -1
+    assert L.gda_segment_mean_fwd_f32(one, 2, one, 3, 4, one, 4, None) == -2                   # ldx < d
+    assert L.gda_segment_mean_bwd_f32(one, 4, one, None, 5, 4, one, 4, None) == -1
+
+
+def test_graph_mode_collation_and_loader_on_the_host():
+    """PyG's Batch.from_data_list for what graph mode reads, and torch's own DataLoader underneath: the shuffles are
+    the installed torch's draws from the default generator (a2gnn.py:278-286 relies on exactly that)."""
+    import torch.utils.data as tud
+    from pygda_amd.data import DataLoader, collate_graphs
+    from oracle import pygda_cpu as O
+    g = torch.Generator().manual_seed(4)
+    ds = [Data(x=torch.randn(3 + i, 4, generator=g), edge_index=torch.randint(0, 3 + i, (2, 5 + i), generator=g),
+               y=torch.tensor([i % 3])) for i in range(7)]
+    b = collate_graphs(ds)
+    ob = O.collate_graphs([O.Graph(d.x, d.edge_index, d.y) for d in ds])
+    for k in ("x", "edge_index", "y", "batch"):
+        assert torch.equal(getattr(b, k), getattr(ob, k))
+    assert b.num_graphs == 7 and b.batch.tolist() == sum(([i] * (3 + i) for i in range(7)), [])
+    assert int(b.edge_index[:, 5:11].min()) >= 3            # the second graph's edges are shifted by the first's nodes
+    torch.manual_seed(3)
+    mine = [bb.y.tolist() for bb in DataLoader(ds, batch_size=3, shuffle=True)]
+    torch.manual_seed(3)
+    ref = [bb.y.tolist() for bb in tud.DataLoader(ds, batch_size=3, shuffle=True, collate_fn=collate_graphs)]
+    assert mine == ref and [len(m) for m in mine] == [3, 3, 1]
+    one = next(iter(DataLoader(ds, batch_size=7)))
+    assert one.batch._gda_sorted and one.batch._gda_num_graphs == 7 and one.y.tolist() == [0, 1, 2, 0, 1, 2, 0]
+
+
+def test_bench_reads_the_pmc_summary_of_its_round(tmp_path, monkeypatch):
+    """bench.py's `traffic` comes from the committed PMC passes: the newest ROUND's summary of the same command."""
+    import json
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    for rnd, val in (("r2", 1.0), ("r10", 3.0), ("r3", 2.0)):
+        (prof / f"{rnd}_cfgA_rocprof_summary.json").write_text(json.dumps({"pmc": {"k_kstep_lds<8>(x)": {"traffic_bytes": val}}}))
+    (prof / "r11_cfgA_powerlaw_rocprof_summary.json").write_text(json.dumps({"pmc": {"k_kstep_lds<10>(x)": {"traffic_bytes": 9.0}}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.pmc_traffic("k_kstep_lds", "r[0-9]*_cfgA_rocprof_summary.json") == (3.0, "r10_cfgA_rocprof_summary.json")
+    assert bench.pmc_traffic("k_kstep_lds", "r[0-9]*_cfgA_powerlaw_rocprof_summary.json")[0] == 9.0
+    assert bench.pmc_traffic("k_nothing", "r[0-9]*_cfgA_rocprof_summary.json") == (None, None)
+
+
 def test_product_path_has_no_cpu_fallback():
     x = torch.randn(4, 8)
     ei = torch.tensor([[0, 1], [1, 0]])
