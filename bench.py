@@ -358,7 +358,7 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                                    f"{args.nodes * args.avg_degree} directed edges per domain, F={args.feat}, nhid=128, "
                                    f"L=2, s_pnums=0, t_pnums=10, NeighborLoader fan-out {fan}, {args.batch} seeds per GPU "
                                    "per step, MMD domain loss",
-                       "edges_aggregated_per_step": edges / args.steps, "final_loss": float(loss),
+                       "edges_aggregated_per_step": edges / args.steps, "final_loss": float(loss.detach()),
                        "sampler": model.source_loader.sampler_description(),
                        "parallelism": "single GPU" if world == 1 else
                        f"dp{world}: disjoint seed mini-batches per rank, graph + features replicated, all-gathered "
@@ -390,7 +390,7 @@ def relaunch(args):
     fewer than N GPUs is an error -- never a silent 1-rank run that prints ``n_gpus: 1``."""
     import socket
     import subprocess
-    if not args.launch_check or torch.cuda.is_available():
+    if (not args.launch_check or torch.cuda.is_available()) and not args.share_gpus:
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if have < args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible on this node; refusing "
@@ -424,7 +424,7 @@ def init_group(args, world, rank, dev):
     saved_fd = os.dup(1)
     os.dup2(2, 1)
     try:
-        if gpu:
+        if gpu and not args.share_gpus:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -675,6 +675,10 @@ def main():
     ap.add_argument("--rccl-direct", action="store_true",
                     help="collectives through the C ABI's own RCCL communicator (gda_allreduce_f32 / "
                          "gda_allgather_f32): the whole data-parallel step is then ONE hipGraph")
+    ap.add_argument("--share-gpus", action="store_true",
+                    help="FUNCTIONAL check of the N-rank path on a node with fewer than N GPUs: rank r takes GPU "
+                         "r mod (GPUs visible), the group is gloo (RCCL refuses two ranks on one device).  The line "
+                         "says so (`functional_check`) and is not a measurement")
     ap.add_argument("--launch-check", action="store_true",
                     help="bring up the --gpus ranks, check the group's size with one all-reduce, print it and exit "
                          "(gloo when the box has no GPU: the CPU test of the launcher)")
@@ -693,6 +697,8 @@ def main():
     if not gpu and not args.launch_check:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     if gpu:
+        if args.share_gpus:
+            local %= torch.cuda.device_count()
         if torch.cuda.device_count() <= local:
             raise SystemExit(f"bench.py: rank {rank} wants GPU {local}, {torch.cuda.device_count()} visible")
         torch.cuda.set_device(local)
@@ -714,7 +720,10 @@ def main():
     if workload == "cfgS":
         out = run_cfg_s(args, world, rank, dev)
         if world > 1 and not args.no_side_lines:
-            side = run_cfg_a(side_args, world, rank, dev, side=True)
+            try:                          # a labelled side object must not cost the scaling line
+                side = run_cfg_a(side_args, world, rank, dev, side=True)
+            except Exception as exc:      # noqa: BLE001 -- reported in the line, rank-local
+                side = {"error": f"{type(exc).__name__}: {exc}"[:400]}
             if rank == 0:
                 out["cfgA_replicas"] = side
     else:
@@ -733,6 +742,9 @@ def main():
             out["config"]["parallelism"] = (f"{world} full-batch replicas (explicit --workload cfgA; value is ONE "
                                             "replica's rate, the job's epoch rate is epochs_per_sec)")
     if rank == 0:
+        if args.share_gpus:
+            out["functional_check"] = (f"{world} ranks on {torch.cuda.device_count()} GPU(s) over gloo (--share-gpus): "
+                                       "the N-rank code path end to end, NOT a measurement")
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -583,7 +583,9 @@ class GraphedStepDP:
         self._refill()
         g1.replay()
         with torch.no_grad():
-            dist.all_gather_into_tensor(self.gath, self._rows_st)
+            # flat views: RCCL takes any output of W x the input's size; gloo (CPU tests, bench --share-gpus) chunks
+            # the output along dim 0 and wants each chunk in the input's shape
+            dist.all_gather_into_tensor(self.gath.view(-1), self._rows_st.view(-1))
         g2.replay()
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
         g4.replay()

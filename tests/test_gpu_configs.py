@@ -10,6 +10,7 @@
 
 Tolerances as in tests/test_gpu_parity.py (1e-4 on logits, 1e-4 relative on losses).
 """
+import os
 import socket
 
 import numpy as np
@@ -190,6 +191,30 @@ def test_two_rank_a2gnn_step_equals_concatenated_batch_gpu(adv):
     for k, gr in ref_grads.items():
         scale = max(float(gr.abs().max()), 1e-3)
         close(results[0]["grads"][k], gr, rtol=1e-3, atol=1e-4 * scale)
+
+
+def test_bench_two_rank_path_end_to_end_on_one_gpu():
+    """`bench.py --gpus 2` as the driver launches it, except that the two ranks share this GPU over gloo
+    (`--share-gpus`): the launcher, seed shards per rank on the device sampler, the all-gathered MMD rows and the
+    averaged gradients of the cfg-S line, and the cfg-A replicas' segmented hipGraph step with its two eager
+    collectives -- end to end, W = 2 (a 1-rank group cannot tell a stacked gather from a concatenated one)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpus", "--steps", "3", "--warmup", "1",
+           "--nodes", "200000", "--side-steps", "3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "functional_check" in line
+    assert line["config"]["parallelism"].startswith("dp2") and np.isfinite(line["config"]["final_loss"])
+    assert line["value"] > 0 and line["config"]["edges_aggregated_per_step"] > 0
+    side = line["cfgA_replicas"]
+    assert "error" not in side, side
+    assert side["replicas"] == 2 and side["ms_per_step"] > 0 and side["epochs_per_sec"] > 0
+    assert side["execution"].startswith("four hipGraph segments")
 
 
 # -------------------------------------------------- configs[4]: cfg-S scale on one GPU --
