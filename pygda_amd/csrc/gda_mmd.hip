@@ -58,6 +58,11 @@ __device__ __forceinline__ const float* row_ptr(const Rows& R, int t, int64_t r)
     return R.tgt + g * R.ld_tgt;
 }
 
+// rows stacked [times, n, d] per domain (no index): the address is arithmetic only
+__device__ __forceinline__ const float* row_direct(const Rows& R, int t, int64_t r) {
+    return r < R.n ? R.src + ((int64_t)t * R.n + r) * R.ld_src : R.tgt + ((int64_t)t * R.n + (r - R.n)) * R.ld_tgt;
+}
+
 // four consecutive features k..k+3 of a row, zero beyond d / for a missing row
 __device__ __forceinline__ float4 load4(const float* __restrict__ p, int64_t k, int64_t d, bool vec4) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -359,13 +364,19 @@ constexpr int BJ = 32;        // rows j per chunk (MFMA K = 2 per instruction)
 
 // BI_ x 128 workgroup tile, BI_ / 32 * 2 wavefronts (64 rows: 4 waves, 128 rows: 8 waves -- the T chunk is then shared
 // by twice the rows: 0.25 KB of staging per row and chunk instead of 0.375, four waves per SIMD with two workgroups
-// per CU).  Dynamic LDS: [Gs 2 x BJ x BI_][Ts 2 x BJ x DC][rowsum BI_]; the row-sum partials reuse Gs afterwards.
-template <int KN, int BI_>
-__global__ void __launch_bounds__(BI_ * 4)
-k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* __restrict__ bandwidth,
-      KParams kp, const float* __restrict__ grad_loss, float scale, int times, int nseg,
-      float* __restrict__ part) {
-    (void)bandwidth; (void)kp;
+// per CU).  Dynamic LDS: [Gs 2 x BJ x BI_][Ts 2 x BJ x DC][rowsum BI_].
+//
+// FAST (m % 4 == 0, 16-byte aligned rows, d a multiple of the 128-column block: every A2GNN call): the staging loads
+// are branch-free -- row / column indices clamped into the matrix, out-of-range pieces zeroed when they are written
+// to LDS -- and nothing consumes them before the chunk's MFMAs have been issued (the pivot shift happens on the way
+// into LDS), so a chunk's global loads really are in flight under the previous chunk's matrix work; the generic
+// variant keeps the guarded loads.  Both read a chunk's MFMA operands from LDS ahead of the MFMAs that use them
+// (round 3: with read -> wait -> two MFMAs the loop ran at 56 % of the matrix pipe with no global load in it,
+// 69 us of the kernel's 82).
+template <bool FAST, int BI_>
+__global__ void __launch_bounds__(BI_ * 4, BI_ == 128 ? 4 : 3)
+k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* __restrict__ grad_loss, float scale,
+      int times, int nseg, float* __restrict__ part) {
     constexpr int TB_ = BI_ * 4;
     constexpr int GC = BI_ / 4;                   // float4 per G row
     constexpr int TQ = (BJ * DC / 4) / TB_;       // T float4 per thread and chunk
@@ -375,7 +386,6 @@ k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* _
     float (*Gs)[BJ][BI_] = reinterpret_cast<float (*)[BJ][BI_]>(bwd_lds);                       // Gs[b][j][i] = g[i][j]
     float (*Ts)[BJ][DC] = reinterpret_cast<float (*)[BJ][DC]>(bwd_lds + sizeof(float) * 2 * BJ * BI_);   // rows j of total
     float* rowsum = reinterpret_cast<float*>(bwd_lds + sizeof(float) * 2 * BJ * (BI_ + DC));
-    float (*rs_part)[BI_] = reinterpret_cast<float (*)[BI_]>(bwd_lds);                          // [16][BI_], after the loop
     const int t = blockIdx.z;
     const int seg = blockIdx.y % nseg;
     const int64_t c0 = (int64_t)(blockIdx.y / nseg) * DC;
@@ -398,78 +408,151 @@ k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* _
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    float rsum = 0.f;                             // sum over this lane's j (j = ka mod 2) of g[wr + la][j]
 
     const int64_t nchunks = gda_cdiv_dev(m, BJ);
-    float4 gq[2], tq[TQ];
-    auto fetch = [&](int64_t ch) {
-        const int64_t j0 = ch * BJ;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int64_t j = j0 + g_r + 16 * q, i = i0 + g_c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < m) {
-                const float* p = L + j * m + i;
-                if (g_vec && i + 3 < m) v = *reinterpret_cast<const float4*>(p);
-                else {
-                    if (i + 0 < m) v.x = p[0];
-                    if (i + 1 < m) v.y = p[1];
-                    if (i + 2 < m) v.z = p[2];
-                    if (i + 3 < m) v.w = p[3];
-                }
-            }
-            gq[q] = v;
+    // Two register sets of staged pieces: the loads of chunk k + 3 are issued when chunk k + 1 has been written to
+    // LDS, and are consumed two chunks of matrix work later -- the G tiles (80 MB per call) come from the Infinity
+    // Cache / HBM at 2-3 us under load, more than one chunk's MFMAs cover (one set, one chunk ahead: 73 us; the
+    // loads alone 42, the MFMA loop alone 36).
+    float4 gq0[2], tq0[TQ], gq1[2], tq1[TQ];
+#define BW_FETCH(GQ, TQV, CH)                                                                                     \
+    {                                                                                                             \
+        const int64_t j0_ = (CH) * BJ;                                                                            \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                           \
+            const int64_t j = j0_ + g_r + 16 * q, i = i0 + g_c4;                                                  \
+            if constexpr (FAST) {                                                                                 \
+                GQ[q] = *reinterpret_cast<const float4*>(L + (j < m ? j : m - 1) * m + (i < m ? i : m - 4));      \
+            } else {                                                                                              \
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+                if (j < m) {                                                                                      \
+                    const float* p = L + j * m + i;                                                               \
+                    if (g_vec && i + 3 < m) v = *reinterpret_cast<const float4*>(p);                              \
+                    else {                                                                                        \
+                        if (i + 0 < m) v.x = p[0];                                                                \
+                        if (i + 1 < m) v.y = p[1];                                                                \
+                        if (i + 2 < m) v.z = p[2];                                                                \
+                        if (i + 3 < m) v.w = p[3];                                                                \
+                    }                                                                                             \
+                }                                                                                                 \
+                GQ[q] = v;                                                                                        \
+            }                                                                                                     \
+        }                                                                                                         \
+        _Pragma("unroll") for (int q = 0; q < TQ; ++q) {                                                          \
+            const int64_t j = j0_ + t_r + TSTEP * q;                                                              \
+            if constexpr (FAST) TQV[q] = *reinterpret_cast<const float4*>(row_direct(R, t, j < m ? j : m - 1) + c0 + t_c4); \
+            else TQV[q] = sub4(load4(j < m ? row_ptr(R, t, j) : nullptr, c0 + t_c4, d, R.vec4), pv, j < m);       \
+        }                                                                                                         \
+    }
+#define BW_STASH(GQ, TQV, B, CH)                                                                                  \
+    {                                                                                                             \
+        const int64_t j0_ = (CH) * BJ;                                                                            \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                           \
+            float4 v = GQ[q];                                                                                     \
+            if constexpr (FAST) {                                                                                 \
+                const bool ok = j0_ + g_r + 16 * q < m && i0 + g_c4 < m;                                          \
+                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;           \
+            }                                                                                                     \
+            *reinterpret_cast<float4*>(&Gs[B][g_r + 16 * q][g_c4]) = v;                                           \
+        }                                                                                                         \
+        _Pragma("unroll") for (int q = 0; q < TQ; ++q) {                                                          \
+            float4 v = TQV[q];                                                                                    \
+            if constexpr (FAST) {                                                                                 \
+                const bool ok = j0_ + t_r + TSTEP * q < m;                                                        \
+                v.x = ok ? v.x - pv.x : 0.f; v.y = ok ? v.y - pv.y : 0.f;                                         \
+                v.z = ok ? v.z - pv.z : 0.f; v.w = ok ? v.w - pv.w : 0.f;                                         \
+            }                                                                                                     \
+            *reinterpret_cast<float4*>(&Ts[B][t_r + TSTEP * q][t_c4]) = v;                                        \
+        }                                                                                                         \
+    }
+    // operands of group g + 1 (4 k-pairs: 12 LDS words per lane) are read while the 8 MFMAs of group g issue;
+    // the scheduling barriers keep the compiler from sinking every read to just in front of its MFMA again
+#define BW_LOAD(g)                                                                                   \
+        _Pragma("unroll") for (int u = 4 * (g); u < 4 * (g) + 4; ++u) {                              \
+            av[u] = Gs[buf][2 * u + ka][wr + la];                                                    \
+            b0[u] = Ts[buf][2 * u + ka][wc + la];                                                    \
+            b1[u] = Ts[buf][2 * u + ka][wc + 32 + la];                                               \
         }
-#pragma unroll
-        for (int q = 0; q < TQ; ++q) {
-            const int64_t j = j0 + t_r + TSTEP * q;
-            tq[q] = sub4(load4(j < m ? row_ptr(R, t, j) : nullptr, c0 + t_c4, d, R.vec4), pv, j < m);
+#define BW_MFMA(g)                                                                                   \
+        _Pragma("unroll") for (int u = 4 * (g); u < 4 * (g) + 4; ++u) {                              \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b0[u], acc0, 0, 0, 0);                \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b1[u], acc1, 0, 0, 0);                \
+            rsum += av[u];                                                                           \
         }
-    };
-    auto stash = [&](int b) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            *reinterpret_cast<float4*>(&Gs[b][g_r + 16 * q][g_c4]) = gq[q];
-            rs[0] += gq[q].x; rs[1] += gq[q].y; rs[2] += gq[q].z; rs[3] += gq[q].w;
-        }
-#pragma unroll
-        for (int q = 0; q < TQ; ++q) *reinterpret_cast<float4*>(&Ts[b][t_r + TSTEP * q][t_c4]) = tq[q];
-    };
+#define BW_COMPUTE()                                                                                 \
+    {                                                                                                \
+        float av[BJ / 2], b0[BJ / 2], b1[BJ / 2];                                                    \
+        BW_LOAD(0) __builtin_amdgcn_sched_barrier(0);                                                \
+        BW_LOAD(1) BW_MFMA(0) __builtin_amdgcn_sched_barrier(0);                                     \
+        BW_LOAD(2) BW_MFMA(1) __builtin_amdgcn_sched_barrier(0);                                     \
+        BW_LOAD(3) BW_MFMA(2) __builtin_amdgcn_sched_barrier(0);                                     \
+        BW_MFMA(3)                                                                                   \
+    }
 
-    // this segment's chunks: seg, seg + nseg, ...
+    // this segment's chunks: seg, seg + nseg, ...; chunk k + 1 waits in set (k mod 2) while chunk k is multiplied
     int64_t ch = seg;
+    const int64_t step = nseg;
     int buf = 0;
-    if (ch < nchunks) { fetch(ch); stash(0); }
+    if (ch < nchunks) BW_FETCH(gq1, tq1, ch)
+    if (ch + step < nchunks) BW_FETCH(gq0, tq0, ch + step)
+    if (ch < nchunks) BW_STASH(gq1, tq1, 0, ch)
+    if (ch + 2 * step < nchunks) BW_FETCH(gq1, tq1, ch + 2 * step)
     __syncthreads();
-    for (; ch < nchunks; ch += nseg) {
-        const bool more = ch + nseg < nchunks;
-        if (more) fetch(ch + nseg);                        // in flight during the MFMAs below
-#pragma unroll
-        for (int kk = 0; kk < BJ; kk += 2) {
-            const float av = Gs[buf][kk + ka][wr + la];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Ts[buf][kk + ka][wc + la], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Ts[buf][kk + ka][wc + 32 + la], acc1, 0, 0, 0);
-        }
-        if (more) stash(buf ^ 1);
+    while (ch < nchunks) {
+        BW_COMPUTE()
+        if (ch + step < nchunks) BW_STASH(gq0, tq0, buf ^ 1, ch + step)
+        if (ch + 3 * step < nchunks) BW_FETCH(gq0, tq0, ch + 3 * step)
         __syncthreads();
         buf ^= 1;
+        ch += step;
+        if (ch >= nchunks) break;
+        BW_COMPUTE()
+        if (ch + step < nchunks) BW_STASH(gq1, tq1, buf ^ 1, ch + step)
+        if (ch + 3 * step < nchunks) BW_FETCH(gq1, tq1, ch + 3 * step)
+        __syncthreads();
+        buf ^= 1;
+        ch += step;
     }
+#undef BW_FETCH
+#undef BW_STASH
+#undef BW_LOAD
+#undef BW_MFMA
+#undef BW_COMPUTE
 
-    // row sums of g over this segment: 16 threads hold partials for the same 4 rows
-#pragma unroll
-    for (int e = 0; e < 4; ++e) rs_part[g_r][g_c4 + e] = rs[e];        // Gs is free: the loop ended on a barrier
-    __syncthreads();
-    if (tid < BI_) {
-        float sres = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) sres += rs_part[k][tid];
-        rowsum[tid] = sres;
-    }
+    // row sums of g over this segment: the A operands a wave walked ARE its 32 rows' entries -- the two lane halves
+    // (even / odd j) added, in a fixed order
+    rsum += __shfl_xor(rsum, 32, 64);
+    if ((wave & 1) == 0 && lane < 32) rowsum[wr + la] = rsum;
     __syncthreads();
 
     // epilogue: part[t][seg][i][c] = c * (rowsum[i] * total[i][c] - acc)   (factor 4 in the reduce)
     const float coef = grad_loss[0] * scale / ((float)n * (float)n) / (float)times;
     float* out = part + (((int64_t)t * nseg + seg) * m) * d;
+    if constexpr (FAST) {
+        // the 32 row values a lane needs are 32 INDEPENDENT loads (row index clamped, no branch around them): one
+        // memory round trip for the lot.  Guarded one by one -- load, wait, store, next -- they were ~30 us of the
+        // kernel: every workgroup reaches its epilogue at the same time (the grid is one round of workgroups)
+        const float pv0 = pivot[c0 + wc + la], pv1 = pivot[c0 + wc + 32 + la];
+        float tiv[2][16];
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t i = i0 + wr + (r & 3) + 8 * (r >> 2) + 4 * ka;
+                tiv[half][r] = row_direct(R, t, i < m ? i : m - 1)[c0 + wc + 32 * half + la];
+            }
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = wr + (r & 3) + 8 * (r >> 2) + 4 * ka;     // C/D layout of the 32x32 MFMA
+                const int64_t i = i0 + il;
+                const float ti = tiv[half][r] - (half == 0 ? pv0 : pv1);
+                const float a = half == 0 ? acc0[r] : acc1[r];
+                if (i < m) out[i * d + c0 + wc + 32 * half + la] = coef * fmaf(rowsum[il], ti, -a);
+            }
+        return;
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int64_t c = c0 + wc + 32 * half + la;
@@ -586,17 +669,17 @@ BwdVariant bwd_variant(int64_t m) {
     return v;
 }
 
-template <int KN, int BI_>
-int launch_bwd(dim3 grid, hipStream_t stream, Rows R, int64_t d, int64_t m, const float* l2, const float* bandwidth, KParams kp,
-               const float* grad_loss, float scale, int times, int nseg, float* part) {
+template <bool FAST, int BI_>
+int launch_bwd(dim3 grid, hipStream_t stream, Rows R, int64_t d, int64_t m, const float* l2, const float* grad_loss, float scale,
+               int times, int nseg, float* part) {
     const size_t lds = sizeof(float) * (2 * BJ * (BI_ + DC) + BI_);
     static bool configured = false;
     if (!configured) {
-        GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd<KN, BI_>),
+        GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd<FAST, BI_>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    k_bwd<KN, BI_><<<grid, BI_ * 4, lds, stream>>>(R, d, m, l2, bandwidth, kp, grad_loss, scale, times, nseg, part);
+    k_bwd<FAST, BI_><<<grid, BI_ * 4, lds, stream>>>(R, d, m, l2, grad_loss, scale, times, nseg, part);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
@@ -738,13 +821,15 @@ extern "C" int gda_mmd_bwd_ex_f32(const float* src, int64_t ld_src, const float*
     const BwdVariant var = bwd_variant(m);
     const int nseg = (int)(ntiles < var.nseg ? ntiles : var.nseg);
     const dim3 grid((unsigned)gda_cdiv(m, var.tile), (unsigned)(gda_cdiv(d, DC) * nseg), (unsigned)times);
-    if (var.tile == 128) {
-        st = kernel_num == 5 ? launch_bwd<5, 128>(grid, stream, R, d, m, l2_saved, bandwidth, kp, grad_loss, scale, times, nseg, ws.bwd_part)
-                             : launch_bwd<0, 128>(grid, stream, R, d, m, l2_saved, bandwidth, kp, grad_loss, scale, times, nseg, ws.bwd_part);
-    } else {
-        st = kernel_num == 5 ? launch_bwd<5, 64>(grid, stream, R, d, m, l2_saved, bandwidth, kp, grad_loss, scale, times, nseg, ws.bwd_part)
-                             : launch_bwd<0, 64>(grid, stream, R, d, m, l2_saved, bandwidth, kp, grad_loss, scale, times, nseg, ws.bwd_part);
-    }
+    // branch-free staging (see k_bwd): whole 16-byte pieces everywhere
+    const bool fast = R.vec4 && !R.src_idx && m % 4 == 0 && m >= 4 && d % DC == 0 && ((uintptr_t)l2_saved % 16 == 0);
+    (void)kp;
+    if (var.tile == 128)
+        st = fast ? launch_bwd<true, 128>(grid, stream, R, d, m, l2_saved, grad_loss, scale, times, nseg, ws.bwd_part)
+                  : launch_bwd<false, 128>(grid, stream, R, d, m, l2_saved, grad_loss, scale, times, nseg, ws.bwd_part);
+    else
+        st = fast ? launch_bwd<true, 64>(grid, stream, R, d, m, l2_saved, grad_loss, scale, times, nseg, ws.bwd_part)
+                  : launch_bwd<false, 64>(grid, stream, R, d, m, l2_saved, grad_loss, scale, times, nseg, ws.bwd_part);
     if (st != GDA_OK) return st;
     if (scatter) {
         const int64_t most = n_src_rows > n_tgt_rows ? n_src_rows : n_tgt_rows;
