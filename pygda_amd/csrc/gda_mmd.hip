@@ -36,7 +36,8 @@ namespace {
 constexpr int TB = 256;
 constexpr int TILE = 64;      // rows/cols of the pair tile per workgroup
 constexpr int DK = 32;        // feature chunk staged in LDS per iteration (forward)
-constexpr int LDT = TILE + 4; // padded LDS leading dimension, keeps 16-byte row alignment
+constexpr int LDT = TILE + 1; // padded LDS leading dimension: 4 * LDT = 4 (mod 32), so the staging writes of a wave -- eight
+                              // k-quads x eight rows, four words each -- fall on 32 different banks (TILE + 4: four-way conflicts)
 constexpr int DC = 128;       // feature columns per workgroup in the backward kernel
 constexpr int MAXQ = 8;       // kernel_num upper bound
 
@@ -105,9 +106,11 @@ constexpr int SR = 16;        // rows per k_rowstats workgroup (4 per thread: in
 // chunk (t, blockIdx.x): s1 = sum over its rows of |t_i - p|^2, col[c] = sum over its rows of (t_i - p)[c]
 __global__ void __launch_bounds__(TB)
 k_rowstats(Rows R, int64_t d, int64_t m, double* __restrict__ part_s1, float* __restrict__ part_col,
-           float* __restrict__ rows_src, float* __restrict__ rows_tgt) {
+           float* __restrict__ rows_src, float* __restrict__ rows_tgt, float* __restrict__ norms) {
     __shared__ double red[TB / 64];
     __shared__ float colsh[TB / 64][64];
+    extern __shared__ float rs_tile[];                    // [SR][d + 1] shifted rows, only when `norms` is asked for
+    const int64_t ldt = d + 1;
     const int t = blockIdx.y;
     const int64_t r0 = (int64_t)blockIdx.x * SR;
     const int lane = threadIdx.x % 64, rg = threadIdx.x / 64;
@@ -128,6 +131,7 @@ k_rowstats(Rows R, int64_t d, int64_t m, double* __restrict__ part_s1, float* __
                     const float v = raw - pv;
                     s1 = fmaf(v, v, s1);
                     col += v;
+                    if (norms) rs_tile[rr * ldt + c] = v;
                 }
             }
         }
@@ -135,6 +139,15 @@ k_rowstats(Rows R, int64_t d, int64_t m, double* __restrict__ part_s1, float* __
         __syncthreads();
         if (rg == 0 && c < d) out[c] = (colsh[0][lane] + colsh[1][lane]) + (colsh[2][lane] + colsh[3][lane]);
         __syncthreads();
+    }
+    // |t_i - p|^2 per row as ONE k-ascending fmaf chain: the chain the fp32 MFMA of k_pairdist builds for the dot
+    // products, so for identical rows (sampling is with replacement) dot == norm bit for bit and their distance is
+    // exactly 0, as in the reference's difference form.  (The last barrier of the column loop ordered the tile.)
+    if (norms && threadIdx.x < SR && r0 + threadIdx.x < m) {
+        const float* row = rs_tile + threadIdx.x * ldt;
+        float acc = 0.f;
+        for (int64_t k = 0; k < d; ++k) acc = fmaf(row[k], row[k], acc);
+        norms[(int64_t)t * m + r0 + threadIdx.x] = acc;
     }
     const double s = block_sum((double)s1, red);
     if (threadIdx.x == 0) part_s1[(int64_t)t * gridDim.x + blockIdx.x] = s;
@@ -194,10 +207,13 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // the MFMA accumulator's natural 16-byte direction (four consecutive i per lane) -- and counts twice in the
 // block sums.  SQ: kernel_mul == 2 with five kernels (every pygda call): the five exponentials
 // exp(-L2 / (bw 2^q)) are one __expf and four squarings (e_q = e_{q+1}^2).
-template <int KN, bool SQ>
+// FAST (rows stacked without an index, 16-byte aligned, d a multiple of the 32-feature chunk, row norms left by
+// k_rowstats): the staging loads are branch-free (row index clamped, the piece zeroed on its way into LDS), those of
+// chunk k + 1 are issued before chunk k's MFMAs, and no thread walks a norm chain between the barrier and the MFMAs.
+template <int KN, bool SQ, bool FAST>
 __global__ void __launch_bounds__(TB)
 k_pairdist(Rows R, int64_t d, int64_t m, int nt, const float* __restrict__ bandwidth, KParams kp,
-           float* __restrict__ l2, double* __restrict__ partial) {
+           float* __restrict__ l2, double* __restrict__ partial, const float* __restrict__ norms) {
     __shared__ __attribute__((aligned(16))) float As[DK][LDT];   // As[k][row i of the tile]
     __shared__ __attribute__((aligned(16))) float Bs[DK][LDT];   // Bs[k][row j of the tile]
     __shared__ float nA[TILE], nB[TILE];                          // |t_i|^2, |t_j|^2 of the tile rows
@@ -241,6 +257,49 @@ k_pairdist(Rows R, int64_t d, int64_t m, int nt, const float* __restrict__ bandw
     float (*Sn)[LDT] = tid < TILE ? As : Bs;
     const int nrow = tid & (TILE - 1);
 
+    if constexpr (FAST) {
+        const bool oka[2] = {i0 + lr < m, i0 + lr + 32 < m}, okb[2] = {j0 + lr < m, j0 + lr + 32 < m};
+        const float* qa[2]; const float* qb[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t ri = i0 + lr + 32 * q, rj = j0 + lr + 32 * q;
+            qa[q] = row_direct(R, t, ri < m ? ri : m - 1) + kq;
+            qb[q] = row_direct(R, t, rj < m ? rj : m - 1) + kq;
+        }
+        if (tid < TILE) nA[tid] = i0 + tid < m ? norms[(int64_t)t * m + i0 + tid] : 0.f;
+        else if (tid < 2 * TILE) nB[tid - TILE] = j0 + tid - TILE < m ? norms[(int64_t)t * m + j0 + tid - TILE] : 0.f;
+        float4 va[2], vb[2], pv;
+        pv = *reinterpret_cast<const float4*>(pivot + kq);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            va[q] = *reinterpret_cast<const float4*>(qa[q]);
+            vb[q] = *reinterpret_cast<const float4*>(qb[q]);
+        }
+        for (int64_t k0 = 0; k0 < d; k0 += DK) {
+            __syncthreads();                                   // the previous chunk's MFMAs have read their operands
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = lr + 32 * q;
+                As[kq + 0][r] = oka[q] ? va[q].x - pv.x : 0.f; As[kq + 1][r] = oka[q] ? va[q].y - pv.y : 0.f;
+                As[kq + 2][r] = oka[q] ? va[q].z - pv.z : 0.f; As[kq + 3][r] = oka[q] ? va[q].w - pv.w : 0.f;
+                Bs[kq + 0][r] = okb[q] ? vb[q].x - pv.x : 0.f; Bs[kq + 1][r] = okb[q] ? vb[q].y - pv.y : 0.f;
+                Bs[kq + 2][r] = okb[q] ? vb[q].z - pv.z : 0.f; Bs[kq + 3][r] = okb[q] ? vb[q].w - pv.w : 0.f;
+            }
+            if (k0 + DK < d) {                                 // next chunk: in flight under this chunk's MFMAs
+                pv = *reinterpret_cast<const float4*>(pivot + k0 + DK + kq);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    va[q] = *reinterpret_cast<const float4*>(qa[q] + k0 + DK);
+                    vb[q] = *reinterpret_cast<const float4*>(qb[q] + k0 + DK);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < DK; kk += 2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + ka][wi + la], Bs[kk + ka][wj + la], acc, 0, 0, 0);
+        }
+        __syncthreads();
+    } else {
     // single-buffered on purpose: at 17 KB of LDS nine workgroups share a CU and hide each
     // other's staging; a double-buffered variant (35 KB, four workgroups) measured 8 % slower
     for (int64_t k0 = 0; k0 < d; k0 += DK) {
@@ -270,6 +329,7 @@ k_pairdist(Rows R, int64_t d, int64_t m, int nt, const float* __restrict__ bandw
     if (tid < TILE) nA[nrow] = nacc;
     else if (tid < 2 * TILE) nB[nrow] = nacc;
     __syncthreads();
+    }
 
     // Epilogue: the distances never leave the registers.  K = sum_q exp(L2 * (-1/bw_q)) feeds the signed block
     // sums of the loss; what is stored is the backward's weight g[i,j] = +-sum_q exp(.) * (-1/bw_q) = dK/dL2,
@@ -684,7 +744,7 @@ int launch_bwd(dim3 grid, hipStream_t stream, Rows R, int64_t d, int64_t m, cons
     return GDA_OK;
 }
 
-struct MmdWs { double* kpartial; double* part_s1; float* part_col; float* bwd_part; size_t total; };
+struct MmdWs { double* kpartial; double* part_s1; float* part_col; float* bwd_part; float* norms; size_t total; };
 
 MmdWs carve(void* base, int times, int64_t n, int64_t d) {
     const int64_t m = 2 * n, nt = gda_cdiv(m, TILE);
@@ -700,6 +760,7 @@ MmdWs carve(void* base, int times, int64_t n, int64_t d) {
     w.part_s1 = (double*)take(sizeof(double) * times * chunks);
     w.part_col = (float*)take(sizeof(float) * times * chunks * (d > 0 ? d : 1));
     w.bwd_part = (float*)take(sizeof(float) * times * BWD_NSEG_MAX * m * (d > 0 ? d : 1));
+    w.norms = (float*)take(sizeof(float) * times * m);
     w.total = off;
     return w;
 }
@@ -766,19 +827,36 @@ extern "C" int gda_mmd_fwd_gather_f32(const float* src, int64_t ld_src, const fl
     const KParams kp{kernel_mul, kernel_num, fix_sigma};
     const unsigned chunks = (unsigned)gda_cdiv(m, SR);
     Rows R = make_rows(src, ld_src, tgt, ld_tgt, src_idx, tgt_idx, n);
-    k_rowstats<<<dim3(chunks, (unsigned)times), TB, 0, stream>>>(R, d, m, ws.part_s1, ws.part_col, rows_src, rows_tgt);
+    // the branch-free k_pairdist: rows without an index after this kernel (stacked as given, or gathered by it),
+    // whole 32-feature chunks of 16-byte pieces, and a row tile of k_rowstats that fits its LDS
+    const bool fast = (rows_src || !src_idx) && d % DK == 0 && d <= 2048 && m >= 1 &&
+                      (rows_src ? (d % 4 == 0 && (uintptr_t)rows_src % 16 == 0 && (uintptr_t)rows_tgt % 16 == 0) : R.vec4) &&
+                      kernel_num == 5 && kernel_mul == 2.0f;
+    const size_t rs_lds = fast ? sizeof(float) * SR * (size_t)(d + 1) : 0;
+    if (fast && rs_lds > 48 * 1024) {
+        static bool configured = false;
+        if (!configured) {
+            GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowstats), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)(sizeof(float) * SR * 2049)));
+            configured = true;
+        }
+    }
+    k_rowstats<<<dim3(chunks, (unsigned)times), TB, rs_lds, stream>>>(R, d, m, ws.part_s1, ws.part_col, rows_src, rows_tgt,
+                                                                    fast ? ws.norms : nullptr);
     GDA_LAUNCH_CHECK();
     if (rows_src) R = make_rows(rows_src, d, rows_tgt, d, nullptr, nullptr, n);      // gathered: no index from here on
     k_bandwidth<<<(unsigned)times, TB, 0, stream>>>(ws.part_s1, ws.part_col, (int)chunks, d, m, kp, bandwidth);
     GDA_LAUNCH_CHECK();
     const unsigned ntri = nt * (nt + 1) / 2;
     const dim3 grid(ntri, 1, (unsigned)times);
-    if (kernel_num == 5 && kernel_mul == 2.0f)
-        k_pairdist<5, true><<<grid, TB, 0, stream>>>(R, d, m, (int)nt, bandwidth, kp, l2_saved, ws.kpartial);
+    if (fast)
+        k_pairdist<5, true, true><<<grid, TB, 0, stream>>>(R, d, m, (int)nt, bandwidth, kp, l2_saved, ws.kpartial, ws.norms);
+    else if (kernel_num == 5 && kernel_mul == 2.0f)
+        k_pairdist<5, true, false><<<grid, TB, 0, stream>>>(R, d, m, (int)nt, bandwidth, kp, l2_saved, ws.kpartial, nullptr);
     else if (kernel_num == 5)
-        k_pairdist<5, false><<<grid, TB, 0, stream>>>(R, d, m, (int)nt, bandwidth, kp, l2_saved, ws.kpartial);
+        k_pairdist<5, false, false><<<grid, TB, 0, stream>>>(R, d, m, (int)nt, bandwidth, kp, l2_saved, ws.kpartial, nullptr);
     else
-        k_pairdist<0, false><<<grid, TB, 0, stream>>>(R, d, m, (int)nt, bandwidth, kp, l2_saved, ws.kpartial);
+        k_pairdist<0, false, false><<<grid, TB, 0, stream>>>(R, d, m, (int)nt, bandwidth, kp, l2_saved, ws.kpartial, nullptr);
     GDA_LAUNCH_CHECK();
     k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, (int)ntri, times, n, scale, add, loss);
     GDA_LAUNCH_CHECK();
