@@ -154,32 +154,52 @@ k_rowstats(Rows R, int64_t d, int64_t m, double* __restrict__ part_s1, float* __
 }
 
 // bandwidth[t] = (sum_ij L2 + 1e-6) / (m^2 - m) / kernel_mul^(kernel_num/2)     (mmd.py:50-51)
-__global__ void __launch_bounds__(TB)
+// One workgroup of 1024 threads per resample: a column's chunk partials are summed by EIGHT threads (chunks g, g + 8,
+// ..., eight loads in flight each) whose double sums are added in group order -- a 125-deep chain of loads per
+// column took 8 us on the step's critical path with 128 threads doing it alone.
+constexpr int BW_TB = 1024, BW_G = 8, BW_C = BW_TB / BW_G;
+__global__ void __launch_bounds__(BW_TB)
 k_bandwidth(const double* __restrict__ part_s1, const float* __restrict__ part_col, int chunks, int64_t d,
             int64_t m, KParams kp, float* __restrict__ bandwidth) {
-    __shared__ double red[TB / 64];
-    const int t = blockIdx.x;
+    __shared__ double colpart[BW_G][BW_C];
+    __shared__ double red[2][BW_TB / 64];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int g = tid / BW_C, cl = tid % BW_C;
     double s2 = 0.0;
-    for (int64_t c = threadIdx.x; c < d; c += TB) {
+    for (int64_t c0 = 0; c0 < d; c0 += BW_C) {
+        const int64_t c = c0 + cl;
         double cs = 0.0;
-        const float* pc = part_col + (int64_t)t * chunks * d + c;
-        int k = 0;
-        for (; k + 8 <= chunks; k += 8) {                  // eight loads in flight, summed in chunk order
-            float v[8];
+        if (c < d) {
+            const float* pc = part_col + (int64_t)t * chunks * d + c;
+            int k = g;
+            for (; k + 7 * BW_G < chunks; k += 8 * BW_G) {     // eight loads in flight, summed in chunk order
+                float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = pc[(int64_t)(k + u) * d];
+                for (int u = 0; u < 8; ++u) v[u] = pc[(int64_t)(k + u * BW_G) * d];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) cs += (double)v[u];
+                for (int u = 0; u < 8; ++u) cs += (double)v[u];
+            }
+            for (; k < chunks; k += BW_G) cs += (double)pc[(int64_t)k * d];
         }
-        for (; k < chunks; ++k) cs += (double)pc[(int64_t)k * d];
-        s2 += cs * cs;
+        colpart[g][cl] = cs;
+        __syncthreads();
+        if (g == 0 && c < d) {
+            double tot = 0.0;
+#pragma unroll
+            for (int u = 0; u < BW_G; ++u) tot += colpart[u][cl];
+            s2 += tot * tot;
+        }
+        __syncthreads();
     }
     double s1 = 0.0;
-    for (int k = threadIdx.x; k < chunks; k += TB) s1 += part_s1[(int64_t)t * chunks + k];
-    const double S2 = block_sum(s2, red);
+    for (int k = tid; k < chunks; k += BW_TB) s1 += part_s1[(int64_t)t * chunks + k];
+    // both sums through one fixed-order tree: wave shuffles, then the 16 wave leaders
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+    if (tid % 64 == 0) { red[0][tid / 64] = s1; red[1][tid / 64] = s2; }
     __syncthreads();
-    const double S1 = block_sum(s1, red);
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
+        double S1 = 0.0, S2 = 0.0;
+        for (int w = 0; w < BW_TB / 64; ++w) { S1 += red[0][w]; S2 += red[1][w]; }
         float bw;
         if (kp.fix_sigma > 0.f) bw = kp.fix_sigma;
         else {
@@ -394,14 +414,34 @@ k_pairdist(Rows R, int64_t d, int64_t m, int nt, const float* __restrict__ bandw
 __global__ void __launch_bounds__(TB)
 k_finalize(const double* __restrict__ kpartial, int tiles_per_t, int times, int64_t n,
            float scale, const float* __restrict__ add, float* __restrict__ loss) {
-    __shared__ double red[TB / 64];
+    // every resample's tile sums in ONE pass: per-thread partials of all resamples, one shuffle tree over the lot, one
+    // barrier (a block sum per resample, one after the other, was 5 x 1.3 us in front of the backward pass)
+    constexpr int MAXT = 8;
+    __shared__ double red[TB / 64][MAXT];
     float total = 0.f;
-    for (int t = 0; t < times; ++t) {
-        double v = 0.0;
-        for (int k = threadIdx.x; k < tiles_per_t; k += TB) v += kpartial[(int64_t)t * tiles_per_t + k];
-        const double s = block_sum(v, red);
-        if (threadIdx.x == 0) total += (float)(s / ((double)n * (double)n));            // mmd.py:106 mean
+    for (int t0 = 0; t0 < times; t0 += MAXT) {
+        const int nt_ = times - t0 < MAXT ? times - t0 : MAXT;
+        double v[MAXT];
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) {
+            v[u] = 0.0;
+            if (u < nt_)
+                for (int k = threadIdx.x; k < tiles_per_t; k += TB) v[u] += kpartial[(int64_t)(t0 + u) * tiles_per_t + k];
+        }
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u)
+            for (int off = 32; off > 0; off >>= 1) v[u] += __shfl_down(v[u], off, 64);
         __syncthreads();
+        if (threadIdx.x % 64 == 0)
+#pragma unroll
+            for (int u = 0; u < MAXT; ++u) red[threadIdx.x / 64][u] = v[u];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int u = 0; u < nt_; ++u) {
+                double sres = 0.0;
+                for (int w = 0; w < TB / 64; ++w) sres += red[w][u];
+                total += (float)(sres / ((double)n * (double)n));            // mmd.py:106 mean
+            }
     }
     if (threadIdx.x == 0) {                            // mmd.py:157; `add + scale * mmd` in one go when asked for
         const float v = total / (float)times;
@@ -845,7 +885,7 @@ extern "C" int gda_mmd_fwd_gather_f32(const float* src, int64_t ld_src, const fl
                                                                     fast ? ws.norms : nullptr);
     GDA_LAUNCH_CHECK();
     if (rows_src) R = make_rows(rows_src, d, rows_tgt, d, nullptr, nullptr, n);      // gathered: no index from here on
-    k_bandwidth<<<(unsigned)times, TB, 0, stream>>>(ws.part_s1, ws.part_col, (int)chunks, d, m, kp, bandwidth);
+    k_bandwidth<<<(unsigned)times, BW_TB, 0, stream>>>(ws.part_s1, ws.part_col, (int)chunks, d, m, kp, bandwidth);
     GDA_LAUNCH_CHECK();
     const unsigned ntri = nt * (nt + 1) / 2;
     const dim3 grid(ntri, 1, (unsigned)times);

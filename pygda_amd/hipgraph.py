@@ -103,6 +103,17 @@ class _DPSamples:
         return d[0], d[1], (d[2], d[3], self.ones), (d[4], d[5], self.ones)
 
 
+class LossTerms(tuple):
+    """The step's loss as its independent terms (each a 0-dim tensor with its own autograd history) instead of their
+    sum.  A captured step hands this to :class:`GraphedStep`, which seeds every term with a constant 1 in ONE engine
+    run and forms the reported total on its statistics branch: the addition of the terms, the fill of the backward
+    seed and -- with them -- the loss value's own reduction kernels leave the chain between the domain loss's forward
+    and backward kernels (``loss = ce + mmd; loss.backward()`` put three glue launches there)."""
+
+
+defer_total = False        # set by GraphedStep around its step function: trainers may then return LossTerms
+
+
 class GraphedStep:
     """Captures ``loss, logits = step_fn(src, tgt)``, ``backward`` and ``optimizer.step()``."""
 
@@ -224,7 +235,20 @@ class GraphedStep:
         from .ops import dropout_state
         self._rand_cursor = 0
         dropout_state.next_step(self.src.x.device)        # device counter: bumped by every replay too
-        loss, logits = self.step_fn(self.src, self.tgt)
+        global defer_total
+        defer_total = type(self) is GraphedStep and not self.dp
+        try:
+            loss, logits = self.step_fn(self.src, self.tgt)
+        finally:
+            defer_total = False
+        terms = loss if isinstance(loss, LossTerms) else None
+        if terms is not None:
+            if getattr(self, "_one", None) is None:
+                self._one = torch.ones((), dtype=torch.float32, device=self.src.x.device)
+            if not with_stats:                                    # warm-up runs: the total on the main stream
+                loss = terms[0].detach()
+                for extra in terms[1:]:
+                    loss = loss + extra.detach()
         if with_stats:
             # per-epoch numbers of the reference's loop (loss, source micro-F1 = accuracy): two doubles
             # produced inside the graph, on a side branch that runs beside the backward pass
@@ -233,6 +257,10 @@ class GraphedStep:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 from .ops import ce_stats_for
+                if terms is not None:                             # the reported total: same fp32 sum as `a + b` in eager mode
+                    loss = terms[0].detach()
+                    for extra in terms[1:]:
+                        loss = loss + extra.detach()
                 by_product = ce_stats_for(logits, self.src.y)     # the loss kernel counted the correct rows already
                 if by_product is not None:
                     by_product[0:1].copy_(loss.detach().reshape(1))   # slot 0: the TOTAL loss of the step
@@ -243,7 +271,10 @@ class GraphedStep:
             for t in (loss, logits):
                 t.record_stream(side)
         self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        if terms is not None:
+            torch.autograd.backward(list(terms), [self._one.reshape(t.shape) for t in terms])
+        else:
+            loss.backward()
         if self.dp:
             from .distributed import allreduce_grads
             allreduce_grads(p for g in self.optimizer.param_groups for p in g["params"])
@@ -416,6 +447,10 @@ class GraphedStepSplit(GraphedStep):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 from .ops import ce_stats_for
+                if terms is not None:                             # the reported total: same fp32 sum as `a + b` in eager mode
+                    loss = terms[0].detach()
+                    for extra in terms[1:]:
+                        loss = loss + extra.detach()
                 by_product = ce_stats_for(logits, self.src.y)     # the loss kernel counted the correct rows already
                 if by_product is not None:
                     by_product[0:1].copy_(loss.detach().reshape(1))   # slot 0: the TOTAL loss of the step

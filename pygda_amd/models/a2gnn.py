@@ -95,7 +95,11 @@ class A2GNN(BaseGDA):
             return loss + self.weight * self._gmean(dom, source_features.size(0) + target_features.size(0))
         # the weight rides inside the loss kernels; the CE term is added OUTSIDE on purpose: as an input of the MMD node
         # its gradient would only be released after the MMD's backward kernels, serialising the CE path behind them
-        return loss + MMD(source_features, target_features, scale=self.weight)            # :206-209
+        mmd = MMD(source_features, target_features, scale=self.weight)                  # :206-209
+        from .. import hipgraph
+        if hipgraph.defer_total and type(self) is A2GNN:
+            return hipgraph.LossTerms((loss, mmd))       # summed beside the backward pass (hipgraph.LossTerms)
+        return loss + mmd
 
     def _split_graph_parts(self):
         """The step as three captures (pygda_amd/hipgraph.py::GraphedStepSplit): source forward and target
