@@ -144,6 +144,13 @@ int gda_spmm_csr_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const f
                            int64_t n_rows, int64_t d, int K, const float* x, int64_t ldx,
                            float* y, int64_t ldy, float* tmp, const float* bias,
                            gda_stream_t stream);
+/* One step with the result written TRANSPOSED: yT[c * ldyT + i] = (A x)[i][c] (+ bias[c]), ldyT >= n_rows -- the same
+ * row walk and sums as gda_spmm_csr_f32 (no hub-row split: callers with rows beyond the split threshold use
+ * gda_spmm_csr_split_f32 + gda_transpose_f32).  The projection of sparse input features (pygda/nn/prop_gcn_conv.py:205
+ * on a bag-of-words matrix) hands its result to gda_kstep_lds_colmajor_f32 in that kernel's own layout. */
+int gda_spmm_csr_tout_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                          int64_t n_rows, int64_t d, const float* x, int64_t ldx,
+                          float* yT, int64_t ldyT, const float* bias, gda_stream_t stream);
 
 /* K aggregation steps on a sampled sub-graph (a NeighborLoader batch, pygda/models/a2gnn.py:260-277, numbered seeds
  * first then in discovery order): the nodes found in the last hop are never expanded, so rows [n_int, n_rows) of the

@@ -27,6 +27,7 @@ _SIGNATURES = {
                                 _P, _P, _P, _P, _P]),
     "gda_csr_to_coo": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P]),
     "gda_spmm_csr_f32": (c_int, [_P, _P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P]),
+    "gda_spmm_csr_tout_f32": (c_int, [_P, _P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P]),
     "gda_spmm_csr_kstep_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P, c_int64,
                                        _P, _P, _P]),
     "gda_spmm_csr_interior_kstep_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),

@@ -98,7 +98,9 @@ __device__ __forceinline__ void apply_epilogue(float (&acc)[VEC], const Epilogue
 // a broadcast inside the group) instead of being broadcast with two cross-lane shuffles per neighbour -- the
 // "LDS staging of per-wavefront neighbour tiles" of the path's specification.  Same values in the same order.
 // Measured against the shuffle form (tools/spmm_sweep.py with PYGDA_AMD_SPMM_LDS=1, profiles/r3_spmm_lds_vs_shuffle.jsonl).
-template <int G, int VEC, bool EPI, bool STG = false>
+// TOUT: y is written TRANSPOSED, yT[c * ldy + row] (ldy >= n_rows) -- the column-major hand-over to the LDS-resident
+// K-step kernel (gda_kstep.hip) for a projection of sparse input features: no transpose launch between the two.
+template <int G, int VEC, bool EPI, bool STG = false, bool TOUT = false>
 __global__ void __launch_bounds__(TB)
 k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
        const float* __restrict__ val, int64_t n_rows, int d,
@@ -186,7 +188,12 @@ k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) acc[v] = __fadd_rn(acc[v], bias[c + v]);
             }
-            vstore<VEC>(y + row * ldy + c, acc);
+            if constexpr (TOUT) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) y[(int64_t)(c + v) * ldy + row] = acc[v];
+            } else {
+                vstore<VEC>(y + row * ldy + c, acc);
+            }
         }
     }
 }
@@ -412,6 +419,17 @@ int dispatch(const int32_t* rowptr, const int32_t* colidx, const float* val, int
 #undef GO
 }
 
+template <int G, int VEC>
+int launch_tout(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n_rows, int d,
+                const float* x, int64_t ldx, float* yT, int64_t ldyT, const float* bias, hipStream_t s) {
+    const int64_t row_blocks = gda_cdiv(n_rows, TB / G);
+    if (row_blocks > INT32_MAX) return GDA_E_SIZE;
+    k_spmm<G, VEC, false, false, true><<<(unsigned)row_blocks, TB, 0, s>>>(
+        rowptr, colidx, val, n_rows, d, x, ldx, yT, ldyT, bias, RowSplit{}, (unsigned)row_blocks, Epilogue{});
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
 int check(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n_rows, int64_t d,
           const float* x, int64_t ldx, float* y, int64_t ldy) {
     if (n_rows < 0 || d < 0 || n_rows >= INT32_MAX || d >= INT32_MAX || ldx < d || ldy < d) return GDA_E_SIZE;
@@ -446,6 +464,33 @@ extern "C" int gda_spmm_csr_f32(const int32_t* rowptr, const int32_t* colidx, co
                                 float* y, int64_t ldy, const float* bias, gda_stream_t stream) {
     return gda_spmm_csr_split_f32(rowptr, colidx, val, n_rows, d, 1, x, ldx, y, ldy, nullptr, bias, nullptr,
                                   stream);
+}
+
+extern "C" int gda_spmm_csr_tout_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                                     int64_t n_rows, int64_t d, const float* x, int64_t ldx,
+                                     float* yT, int64_t ldyT, const float* bias, gda_stream_t stream) {
+    if (n_rows < 0 || d < 0 || n_rows >= INT32_MAX || d >= INT32_MAX || ldx < d || ldyT < n_rows) return GDA_E_SIZE;
+    if (n_rows == 0 || d == 0) return GDA_OK;
+    if (!rowptr || !x || !yT) return GDA_E_NULL;
+    if ((const float*)yT == x) return GDA_E_ALIAS;
+    hipStream_t s = (hipStream_t)stream;
+    const int di = (int)d;
+    const bool a16 = (d % 4 == 0) && (ldx % 4 == 0) && ((uintptr_t)x % 16 == 0);
+#define GO(G, V) return launch_tout<G, V>(rowptr, colidx, val, n_rows, di, x, ldx, yT, ldyT, bias, s)
+    if (a16) {
+        const int64_t lanes = d / 4;
+        if (lanes >= 64) GO(64, 4);
+        if (lanes > 16) GO(32, 4);
+        if (lanes > 8) GO(16, 4);
+        if (lanes > 4) GO(8, 4);
+        GO(4, 4);
+    }
+    if (d > 32) GO(64, 1);
+    if (d > 16) GO(32, 1);
+    if (d > 8) GO(16, 1);
+    if (d > 4) GO(8, 1);
+    GO(4, 1);
+#undef GO
 }
 
 extern "C" int gda_spmm_csr_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,

@@ -14,6 +14,9 @@ from ..graph import CSRGraph, as_graph, build_csr
 from ..ops import propagate
 from .linear import Linear, zeros
 
+import os
+SPARSE_COLMAJOR = os.environ.get("PYGDA_AMD_SPARSE_COLMAJOR", "1") == "1"
+
 
 def gcn_norm(edge_index, edge_weight=None, num_nodes=None, improved=False, add_self_loops=True,
              dtype=None):
@@ -78,6 +81,17 @@ class PropGCNConv(nn.Module):
             if (self.out_channels % 4 == 0 and lds_kstep_plan(g, prop_nums, False) is not None
                     and lds_kstep_plan(g, prop_nums, True) is not None):
                 return propagate(tall_linear_colmajor(x, self.lin.weight), g, prop_nums, self.bias)
+        if (colmajor_out and prop_nums > 0 and x.dim() == 2 and x.size(1) >= sparse_features.MIN_WIDTH
+                and self.out_channels % 4 == 0 and SPARSE_COLMAJOR):
+            # sparse input features: the SpMM that projects them writes the K-step kernel's layout itself
+            sf = sparse_features.lookup(x)
+            if sf is not None:
+                from ..ops import lds_kstep_plan
+                g = self._graph(x, edge_index, edge_weight)
+                if lds_kstep_plan(g, prop_nums, False) is not None and lds_kstep_plan(g, prop_nums, True) is not None:
+                    hT = sparse_features.sparse_linear_colmajor(self.lin.weight, sf)
+                    if hT is not None:
+                        return propagate(hT, g, prop_nums, self.bias)
         if prop_nums <= 0 and self.bias is not None and self.lin.tall_gemm_ok(x):
             from .linear import tall_linear_bias               # projection + bias (and both gradients) in the GEMMs
             return tall_linear_bias(x, self.lin.weight, self.bias)

@@ -125,6 +125,55 @@ class _SparseLinear(torch.autograd.Function):
         return gwt.t(), None, None, gb
 
 
+class _SparseLinearT(torch.autograd.Function):
+    """``(X W^T)^T`` as ``[out, round_up(n, 4)]``: the layer-0 projection of sparse features handed to the LDS-resident
+    K-step kernel in that kernel's column-major layout (``gda_spmm_csr_tout_f32``) -- same sums as :class:`_SparseLinear`,
+    no transpose launch between projection and aggregation.  Backward takes the column-major gradient."""
+
+    @staticmethod
+    def forward(ctx, weight, sf):
+        wt = weight.t().contiguous()
+        g = sf.graph
+        h, n = weight.size(0), sf.n
+        n_pad = (n + 3) // 4 * 4
+        yT = torch.empty(h, n_pad, dtype=torch.float32, device=wt.device)
+        if n_pad != n:
+            yT[:, n:].zero_()
+        L = _lib.lib()
+        with profiler.region(f"sparse_projection[{sf.f}x{h}]", 1,
+                             sf.nnz * 8 + (sf.n + 1) * 4 + 4 * (wt.numel() + sf.n * h), 2 * sf.nnz * h):
+            _lib.check(L.gda_spmm_csr_tout_f32(_lib.ptr(g.rowptr), _lib.ptr(g.colidx), _lib.ptr(g.val), n, h,
+                                               _lib.ptr(wt), h, _lib.ptr(yT), n_pad, None, _lib.stream()),
+                       "gda_spmm_csr_tout_f32")
+        ctx.sf = sf
+        return yT
+
+    @staticmethod
+    def backward(ctx, gT):
+        sf = ctx.sf
+        g = sf.graph
+        gT = gT.contiguous()
+        h, n_pad = gT.shape
+        gy = torch.empty(sf.n, h, dtype=torch.float32, device=gT.device)   # [n, h]: the transposed SpMM gathers whole rows
+        _lib.check(_lib.lib().gda_transpose_f32(_lib.ptr(gT), n_pad, _lib.ptr(gy), h, h, sf.n, _lib.stream()),
+                   "gda_transpose_f32")
+        with profiler.region(f"sparse_projection_bwd[{sf.f}x{gy.size(1)}]", 1,
+                             sf.nnz * 8 + (sf.f + 1) * 4 + 4 * (gy.numel() + sf.f * gy.size(1)),
+                             2 * sf.nnz * gy.size(1)):
+            gwt = _spmm(g.t_rowptr, g.t_colidx, g.t_val, sf.f, gy, sf.f, g.split(True))   # [F, h]
+        return gwt.t(), None
+
+
+def sparse_linear_colmajor(weight, sf):
+    """``X W^T`` as a :class:`~pygda_amd.ops.ColMajor`, or None when the feature matrix has rows beyond the hub-row
+    split threshold (those take the split kernel and a transpose)."""
+    from .ops import ColMajor
+    if sf.graph.split(False).struct(weight.size(0)) is not None:
+        return None
+    _store_gather_major(weight)
+    return ColMajor(_SparseLinearT.apply(weight, sf), sf.n)
+
+
 class _SparseMatmul(torch.autograd.Function):
     """``y = X W`` for a weight stored ``[in, out]`` (CachedGCNConv / PPMIConv, cached_gcn_conv.py:130): the weight
     IS the gathered operand -- no transposed copy either way; ``gW = X^T gy`` comes out in the weight's layout."""

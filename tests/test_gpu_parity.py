@@ -616,6 +616,40 @@ def test_sparse_input_projection_matches_dense():
     assert sparse_features.lookup(dense.x) is None
 
 
+def test_sparse_projection_hands_the_kstep_kernel_its_own_layout(monkeypatch):
+    """Layer 0 on sparse input features in front of the LDS-resident K-step kernel: the SpMM that projects them writes
+    the column-major layout itself (gda_spmm_csr_tout_f32) -- same sums, so the conv's output, the weight gradient and
+    the bias gradient are BIT-identical to the row-major projection + transpose path."""
+    from pygda_amd import sparse_features
+    from pygda_amd.graph import as_graph
+    from pygda_amd.nn import prop_gcn_conv as P
+    gen = torch.Generator().manual_seed(14)
+    n, f, h, K = 1001, 900, 64, 5                     # n % 4 != 0: padded columns of the hand-over
+    x = (torch.rand(n, f, generator=gen) < 0.03).float() * torch.randn(n, f, generator=gen)
+    d = Data(x=x, edge_index=torch.randint(0, n, (2, 4000), generator=gen), y=torch.zeros(n, dtype=torch.long)).to(DEV)
+    assert sparse_features.lookup(d.x) is not None
+    G = as_graph(d.edge_index, n)
+    G.static = True
+    assert G.kstep_plan(False) is not None and G.kstep_plan(True) is not None
+    torch.manual_seed(1)
+    conv = pygda_amd.nn.PropGCNConv(f, h).to(DEV)
+    with torch.no_grad():
+        conv.bias.uniform_(-0.5, 0.5)
+    gy = torch.randn(n, h, generator=gen).to(DEV)
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(P, "SPARSE_COLMAJOR", flag)
+        out = conv.forward_colmajor(d.x, G, K)
+        assert isinstance(out, ops.ColMajor)
+        dense = out.t[:, :n].t()
+        gw, gb = torch.autograd.grad((dense * gy).sum(), [conv.lin.weight, conv.bias])
+        res[flag] = (dense.detach().clone(), gw.clone(), gb.clone())
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    ref = conv(d.x, G, K)                              # plain forward: row-major all the way
+    assert torch.equal(res[True][0], ref.detach())
+
+
 # ---------------------------------------------------------------- hipGraph capture --
 @pytest.mark.parametrize("unroll", [1, 2, 3])
 def test_hipgraph_step_matches_eager_trajectory(monkeypatch, unroll):
