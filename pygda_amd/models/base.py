@@ -79,6 +79,7 @@ class BaseGDA(ABC):
         ``(loss, source_logits)``; the optimiser step happens here.  ``epochs`` (default
         ``range(self.epoch)``) lets a harness run the same loop in slices."""
         start = time.time()
+        _freeze_gc()
         if not getattr(self, "_dp_synced", None) is net:      # data-parallel: one set of initial weights
             from ..distributed import broadcast_parameters
             broadcast_parameters(net)
@@ -282,6 +283,25 @@ class BaseGDA(ABC):
                 outs.append(out if k is None else out[:k])
                 labs.append(batch.y if k is None else batch.y[:k])
         return torch.cat(outs), torch.cat(labs)
+
+
+_gc_frozen = False
+
+
+def _freeze_gc():
+    """Once per process, before the first training loop: collect, then move everything alive -- the interpreter, torch
+    and its ~10^6 functions, types and modules -- into the cyclic collector's permanent generation.  A full collection
+    otherwise walks all of it: 70 ms on the GPU box = twenty sampled-training steps lost whenever generation 2 comes
+    up (measured: steps of 3.1 ms with one of 71 ms and one of 9.5 ms per ~100; none with the collector off).  Objects
+    created afterwards are collected as usual.  ``PYGDA_AMD_GC_FREEZE=0`` leaves the collector alone."""
+    global _gc_frozen
+    import gc
+    import os
+    if _gc_frozen or os.environ.get("PYGDA_AMD_GC_FREEZE", "1") != "1":
+        return
+    gc.collect()
+    gc.freeze()
+    _gc_frozen = True
 
 
 def _dist_info():

@@ -60,12 +60,20 @@ def inject_oracle():
         return torch.nn.functional.cross_entropy(z, y)
 
     import pygda_amd.models.a2gnn as A
+    saved = [(A, "grl_disc_ce", A.grl_disc_ce), (P.PropGCNConv, "_graph", P.PropGCNConv._graph),
+             (P, "propagate", P.propagate), (M, "sample_rows", M.sample_rows), (M, "mmd_loss_rows", M.mmd_loss_rows),
+             (M, "mmd_loss", M.mmd_loss)]
     A.grl_disc_ce = grl_disc_ce
     P.PropGCNConv._graph = _graph
     P.propagate = propagate
     M.sample_rows = lambda feat, idx, sel=None: feat[idx]
     M.mmd_loss_rows = mmd_rows
     M.mmd_loss = lambda sf, tf, si, ti, *a, **k: mmd_rows(sf[si], tf[ti])
+
+    def restore():               # the parent (pytest) process goes on to other tests: the product layer back in place
+        for obj, name, val in saved:
+            setattr(obj, name, val)
+    return restore
 
 
 def _trainer(device, adv):
@@ -135,8 +143,15 @@ def run_ranks(world, device, adv, oracle, timeout=600):
 def concatenated_reference(results, device, adv, oracle):
     """The same objective on ONE process: union batch, concatenated row samples."""
     from pygda_amd.data import Data
-    if oracle:
-        inject_oracle()
+    restore = inject_oracle() if oracle else None
+    try:
+        return _concatenated_reference(results, device, adv, Data)
+    finally:
+        if restore is not None:
+            restore()
+
+
+def _concatenated_reference(results, device, adv, Data):
     world = len(results)
 
     def union(key):

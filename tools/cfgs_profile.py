@@ -18,6 +18,9 @@ from pygda_amd.models import A2GNN  # noqa: E402
 from pygda_amd.models.base import _allreduce_grads  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+if os.environ.get("PYGDA_AMD_NOGC") == "1":          # is a slow step the cyclic collector?
+    import gc
+    gc.disable()
 dev = "cuda:0"
 N, B, fan = 5_000_000, 1024, [15, 10]
 src = bench.make_cfg_s(N, 20, 256, 5, 200, dev)
