@@ -650,7 +650,9 @@ def run_cfg_a(args, world, rank, dev, side=False):
         # the same aggregation kernel timed at configs[4]'s per-domain size, where HBM is the bound
         out["roofline_hbm_regime"] = hbm_regime_probe(dev)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(src, tgt, hp, edges)
+        # LAST thing of the process (main() calls it after the side line): ~27 s of all host cores, whose after-effects
+        # -- spinning worker threads, page-cache and allocator churn -- the host-bound cfg-S side line should not meet
+        out["_cpu_baseline_thunk"] = lambda: cpu_baseline(src, tgt, hp, edges)
     return out
 
 
@@ -751,6 +753,9 @@ def main():
         elif world > 1 and rank == 0:
             out["config"]["parallelism"] = (f"{world} full-batch replicas (explicit --workload cfgA; value is ONE "
                                             "replica's rate, the job's epoch rate is epochs_per_sec)")
+        thunk = out.pop("_cpu_baseline_thunk", None) if isinstance(out, dict) else None
+        if thunk is not None:
+            out["cpu_baseline"] = thunk()
     if rank == 0:
         if args.share_gpus:
             out["functional_check"] = (f"{world} ranks on {torch.cuda.device_count()} GPU(s) over gloo (--share-gpus): "
