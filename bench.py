@@ -286,11 +286,14 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
     sync()
     gc.disable()                 # a generation-2 pass of the cyclic collector is milliseconds; the steps are 3 ms
     t0 = time.perf_counter()
+    marks = []
     for _ in range(args.steps):
         loss = one_step()
+        marks.append(time.perf_counter())
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
+    host_ms = [1e3 * (b - a) for a, b in zip([t0] + marks[:-1], marks)]        # host time per step (enqueue side)
     log, ops.aggregation_log = ops.aggregation_log, None
     edges = sum(g.nnz * k for g, k in log)
     # roofline inputs: a short pass of the same steps with HIP events around every kernel family (the timed
@@ -363,6 +366,7 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                                    f"L=2, s_pnums=0, t_pnums=10, NeighborLoader fan-out {fan}, {args.batch} seeds per GPU "
                                    "per step, MMD domain loss",
                        "edges_aggregated_per_step": edges / args.steps, "final_loss": float(loss.detach()),
+                       "host_ms_per_step_max_median": [max(host_ms), sorted(host_ms)[len(host_ms) // 2]],
                        "sampler": model.source_loader.sampler_description(),
                        "parallelism": "single GPU" if world == 1 else
                        f"dp{world}: disjoint seed mini-batches per rank, graph + features replicated, all-gathered "
