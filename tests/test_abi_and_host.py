@@ -134,6 +134,37 @@ def test_bench_reads_the_pmc_summary_of_its_round(tmp_path, monkeypatch):
     assert bench.pmc_traffic("k_nothing", "r[0-9]*_cfgA_rocprof_summary.json") == (None, None)
 
 
+def test_fit_freezes_the_collector_once(monkeypatch):
+    """models/base.py::_freeze_gc: one collect + freeze per process (a generation-2 pass over the interpreter and torch
+    is tens of milliseconds = many sampled steps), left alone when PYGDA_AMD_GC_FREEZE=0."""
+    import gc
+    from pygda_amd.models import base as B
+    monkeypatch.setattr(B, "_gc_frozen", False)
+    monkeypatch.setenv("PYGDA_AMD_GC_FREEZE", "0")
+    before = gc.get_freeze_count()
+    B._freeze_gc()
+    assert gc.get_freeze_count() == before and B._gc_frozen is False
+    monkeypatch.setenv("PYGDA_AMD_GC_FREEZE", "1")
+    try:
+        B._freeze_gc()
+        frozen = gc.get_freeze_count()
+        assert frozen > before and B._gc_frozen is True
+        junk = [[] for _ in range(1000)]
+        B._freeze_gc()                                     # second call: nothing more is frozen
+        assert gc.get_freeze_count() == frozen and len(junk) == 1000
+    finally:
+        gc.unfreeze()                                      # the test process goes on collecting as usual
+
+
+def test_loss_terms_is_a_plain_tuple_of_its_terms():
+    from pygda_amd import hipgraph
+    a, b = torch.tensor(1.5, requires_grad=True), torch.tensor(2.0, requires_grad=True)
+    terms = hipgraph.LossTerms((a * 2, b * 3))
+    assert isinstance(terms, tuple) and len(terms) == 2 and hipgraph.defer_total is False
+    torch.autograd.backward(list(terms), [torch.ones(()) for _ in terms])      # what GraphedStep does with them
+    assert float(a.grad) == 2.0 and float(b.grad) == 3.0
+
+
 def test_product_path_has_no_cpu_fallback():
     x = torch.randn(4, 8)
     ei = torch.tensor([[0, 1], [1, 0]])
