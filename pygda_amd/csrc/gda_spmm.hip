@@ -235,7 +235,13 @@ __global__ void __launch_bounds__(TB)
 k_spmm_range(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ val,
              int64_t row0, int64_t n_rows, int d, const float* __restrict__ xa, int64_t lda,
              const float* __restrict__ xb, int64_t ldb, int32_t col_split, float* __restrict__ y, int64_t ldy,
-             const float* __restrict__ bias, float* __restrict__ sacc, int sacc_mode) {
+             const float* __restrict__ bias, float* __restrict__ sacc, int sacc_mode, int src_mode,
+             const float* __restrict__ cadd) {
+    // src_mode 0: every entry (columns < col_split from xa, the others from xb); 1: only the entries at or beyond
+    // col_split (from xb); 2: only the entries below it (from xa), and `cadd[row]` is added to the row's sum -- the
+    // forward K-step of a sampled batch forms the leaves' contribution c = A_IL x_L ONCE (mode 1) and then iterates
+    // y_I <- A_II y_I + c (mode 2): a step gathers the few interior neighbours instead of every neighbour.  A skipped
+    // entry contributes w * 0 at its place in the chain.
     constexpr int ROWS_PER_BLOCK = TB / G;
     const int lane_in_group = threadIdx.x % G;
     const int64_t row = row0 + (int64_t)blockIdx.x * ROWS_PER_BLOCK + threadIdx.x / G;
@@ -262,20 +268,26 @@ k_spmm_range(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col
                     const int32_t cu = __shfl(my_col, e + u, G);
                     w[u] = __shfl(my_val, e + u, G);
                     const float* src = cu < col_split ? xa + (int64_t)cu * lda : xb + (int64_t)cu * ldb;
-                    if (col_ok) vload<VEC>(xv[u], src + c);
+                    const bool take = src_mode == 0 || (src_mode == 1) == (cu >= col_split);
+                    if (col_ok && take) vload<VEC>(xv[u], src + c);
+                    else {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) xv[u][v] = 0.0f;
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
                     for (int v = 0; v < VEC; ++v)
-                        acc[v] = __fadd_rn(acc[v], __fmul_rn(w[u], col_ok ? xv[u][v] : 0.0f));
+                        acc[v] = __fadd_rn(acc[v], __fmul_rn(w[u], xv[u][v]));
             }
             for (; e < cnt; ++e) {
                 const int32_t cu = __shfl(my_col, e, G);
                 const float w = __shfl(my_val, e, G);
                 const float* src = cu < col_split ? xa + (int64_t)cu * lda : xb + (int64_t)cu * ldb;
+                const bool take = src_mode == 0 || (src_mode == 1) == (cu >= col_split);
                 float xv[VEC];
-                if (col_ok) {
+                if (col_ok && take) {
                     vload<VEC>(xv, src + c);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) acc[v] = __fadd_rn(acc[v], __fmul_rn(w, xv[v]));
@@ -292,6 +304,12 @@ k_spmm_range(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col
                     for (int v = 0; v < VEC; ++v) own[v] = __fadd_rn(run[v], own[v]);
                 }
                 vstore<VEC>(sacc + row * (int64_t)d + c, own);
+            }
+            if (cadd) {
+                float cv[VEC];
+                vload<VEC>(cv, cadd + row * (int64_t)d + c);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = __fadd_rn(acc[v], cv[v]);
             }
             if (bias) {
 #pragma unroll
@@ -320,24 +338,25 @@ k_rows_copy_bias(const float* __restrict__ x, int64_t ldx, float* __restrict__ y
 template <int G, int VEC>
 int launch_range(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t row0, int64_t n_rows, int d,
                  const float* xa, int64_t lda, const float* xb, int64_t ldb, int32_t col_split, float* y, int64_t ldy,
-                 const float* bias, float* sacc, int sacc_mode, hipStream_t s) {
+                 const float* bias, float* sacc, int sacc_mode, hipStream_t s, int src_mode = 0, const float* cadd = nullptr) {
     if (n_rows <= 0) return GDA_OK;
     constexpr int ROWS_PER_BLOCK = TB / G;
     const int64_t blocks = gda_cdiv(n_rows, ROWS_PER_BLOCK);
     if (blocks > INT32_MAX) return GDA_E_SIZE;
     k_spmm_range<G, VEC><<<(unsigned)blocks, TB, 0, s>>>(rowptr, colidx, val, row0, n_rows, d, xa, lda, xb, ldb, col_split,
-                                                         y, ldy, bias, sacc, sacc_mode);
+                                                         y, ldy, bias, sacc, sacc_mode, src_mode, cadd);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
 
 int dispatch_range(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t row0, int64_t n_rows, int64_t d,
                    const float* xa, int64_t lda, const float* xb, int64_t ldb, int32_t col_split, float* y, int64_t ldy,
-                   const float* bias, float* sacc, int sacc_mode, hipStream_t s) {
+                   const float* bias, float* sacc, int sacc_mode, hipStream_t s, int src_mode = 0, const float* cadd = nullptr) {
     const bool a16 = (d % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)xa % 16 == 0) &&
-                     ((uintptr_t)xb % 16 == 0) && ((uintptr_t)y % 16 == 0) && (!sacc || (uintptr_t)sacc % 16 == 0);
+                     ((uintptr_t)xb % 16 == 0) && ((uintptr_t)y % 16 == 0) && (!sacc || (uintptr_t)sacc % 16 == 0) &&
+                     (!cadd || (uintptr_t)cadd % 16 == 0);
     const int di = (int)d;
-#define GO(G, V) return launch_range<G, V>(rowptr, colidx, val, row0, n_rows, di, xa, lda, xb, ldb, col_split, y, ldy, bias, sacc, sacc_mode, s)
+#define GO(G, V) return launch_range<G, V>(rowptr, colidx, val, row0, n_rows, di, xa, lda, xb, ldb, col_split, y, ldy, bias, sacc, sacc_mode, s, src_mode, cadd)
     if (a16) {
         const int64_t lanes = d / 4;
         if (lanes >= 64) GO(64, 4);
@@ -543,10 +562,12 @@ extern "C" int gda_spmm_csr_axpby_f32(const int32_t* rowptr, const int32_t* coli
 // NeighborLoader batch discovered in its last hop; csrc/gda_dsampler.hip reports n_int).
 //   transposed = 0 (rows by destination):  y = A^K x (+ bias): K steps over rows [0, n_int) -- gathers of leaf columns
 //     read x itself -- and one copy of the leaf rows.  Same values as gda_spmm_csr_kstep_f32 (signed zeros aside).
+//     With `sacc` given and K >= 2 the leaf columns' contribution (the same in every step) is formed once and a step
+//     gathers interior columns only: same result up to fp32 summation order (a row's leaf entries are summed apart).
 //   transposed = 1 (rows by source; the backward pass):  y = (A^T)^K x: K steps over the interior rows (they read interior
 //     columns only), their inputs summed on the way, then ONE pass over the leaf rows  y_L = x_L + A_IL^T (h_0 + .. + h_{K-1}).
 //     Same result as K full steps up to fp32 summation order (the leaves' sums are re-associated).
-// tmp: [n_int, d] (K > 1); sacc: [n_int, d] (transposed only).  x, y contiguous rows (ld = d).
+// tmp: [n_int, d] (K > 1); sacc: [n_int, d] (transposed: required; forward: optional, see above).  x, y contiguous rows (ld = d).
 extern "C" int gda_spmm_csr_interior_kstep_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
                                                int64_t n_rows, int64_t n_int, int64_t d, int K, int transposed,
                                                const float* x, float* y, float* tmp, float* sacc, const float* bias,
@@ -560,12 +581,21 @@ extern "C" int gda_spmm_csr_interior_kstep_f32(const int32_t* rowptr, const int3
     hipStream_t s = (hipStream_t)stream;
     const int32_t split = (int32_t)n_int;
     const float* in = x;
+    // forward with a scratch and K >= 2: the leaf columns read x in EVERY step and x does not change -- their
+    // contribution c = A_IL x_L is formed once into `sacc`, the steps gather interior columns only
+    const bool hoist = !transposed && K >= 2 && n_int > 0 && sacc != nullptr;
+    if (hoist) {
+        const int r = dispatch_range(rowptr, colidx, val, 0, n_int, d, x, d, x, d, split, sacc, d, nullptr, nullptr, 0, s, 1, nullptr);
+        if (r != GDA_OK) return r;
+    }
     for (int j = 1; j <= K && n_int > 0; ++j) {          // step j writes y when K - j is even
         float* out = ((K - j) % 2 == 0) ? y : tmp;
         // forward: leaf columns always come from x; transposed: interior rows have no leaf columns at all
-        const int r = dispatch_range(rowptr, colidx, val, 0, n_int, d, in, d, x, d, split, out, d,
-                                     (j == K && !transposed) ? bias : nullptr, transposed ? sacc : nullptr,
-                                     transposed ? (j == 1 ? 1 : 2) : 0, s);
+        const int r = hoist
+            ? dispatch_range(rowptr, colidx, val, 0, n_int, d, in, d, x, d, split, out, d, j == K ? bias : nullptr, nullptr, 0, s, 2, sacc)
+            : dispatch_range(rowptr, colidx, val, 0, n_int, d, in, d, x, d, split, out, d,
+                             (j == K && !transposed) ? bias : nullptr, transposed ? sacc : nullptr,
+                             transposed ? (j == 1 ? 1 : 2) : 0, s);
         if (r != GDA_OK) return r;
         in = out;
     }

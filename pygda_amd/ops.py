@@ -165,6 +165,9 @@ def _note_path(name, K):
 INTERIOR_KSTEP = _os.environ.get("PYGDA_AMD_INTERIOR_KSTEP", "1") == "1"
 
 
+INTERIOR_HOIST = _os.environ.get("PYGDA_AMD_INTERIOR_HOIST", "1") == "1"
+
+
 def _launch_kstep_interior(graph, x, K, bias, transposed, y):
     """K steps on a sampled batch whose rows ``[n_interior, n)`` hold their unit self loop only: the interior rows are
     recomputed per step, the leaves are finished in one pass (csrc/gda_spmm.hip, "sampled sub-graphs")."""
@@ -184,16 +187,22 @@ def _launch_kstep_interior(graph, x, K, bias, transposed, y):
         nnz, n_leaf, row = graph.nnz, n - n_int, 4 * d
         # compulsory bytes: a step reads every distinct row its entries name at most once (<= n rows; the transposed
         # interior steps name interior rows only), the index arrays, and writes its own rows
+        hoist = INTERIOR_HOIST and not transposed and K >= 2 and n_int > 0
         if transposed:
             real = K * (3 * n_int * row) + nnz * 8 + n_int * row + 2 * n_leaf * row
+        elif hoist:       # one pass over the leaf columns, then K steps that gather interior rows and add the constant
+            real = (nnz * 8 + min(nnz, n) * row + n_int * row) + K * (nnz * 8 + 3 * n_int * row + (n_int + 1) * 4) \
+                + 2 * n_leaf * row
         else:
             real = K * (nnz * 8 + min(nnz, n) * row + n_int * row + (n_int + 1) * 4) + 2 * n_leaf * row
-        ctx = profiler.region(f"spmm_interior_f32[d={d}]", K + 1, real, K * 2 * nnz * d,
+        ctx = profiler.region(f"spmm_interior_f32[d={d}]", K + (2 if hoist else 1), real, K * 2 * nnz * d,
                               alg_equiv_bytes=K * (nnz * 8 + (n + 1) * 4 + 2 * n * d * 4))
     else:
         ctx = profiler.region("", 0)
     tmp = torch.empty(n_int, d, dtype=torch.float32, device=x.device) if K > 1 and n_int else None
-    sacc = torch.empty(n_int, d, dtype=torch.float32, device=x.device) if transposed and n_int else None
+    # transposed: the running sum of the step inputs; forward (K >= 2): the leaf columns' contribution, formed once
+    want_sacc = transposed or (INTERIOR_HOIST and K >= 2)
+    sacc = torch.empty(n_int, d, dtype=torch.float32, device=x.device) if want_sacc and n_int else None
     with ctx:
         _lib.check(L.gda_spmm_csr_interior_kstep_f32(_lib.ptr(rp), _lib.ptr(ci), _lib.ptr(va), n, n_int, d, int(K),
                                                      int(bool(transposed)), _lib.ptr(x), _lib.ptr(y), _lib.ptr(tmp),

@@ -137,8 +137,9 @@ def test_loader_on_the_device_sampler_equals_the_host_loader(monkeypatch, prefet
 def test_interior_rows_kstep_on_sampled_batches(monkeypatch, K, d):
     """A sampled batch's last-hop discoveries are never expanded: their rows hold a unit self loop only.  K steps that
     recompute the interior rows only (gda_spmm_csr_interior_kstep_f32) equal K full steps -- forward bit for bit
-    (signed zeros aside), transposed (backward) to fp32 summation order -- with and without the bias, and through
-    autograd."""
+    (signed zeros aside) for K = 1 and whenever the leaf columns are gathered per step, to fp32 summation order when
+    their contribution is formed once (K >= 2, the default); transposed (backward) to fp32 summation order -- with and
+    without the bias, and through autograd."""
     from pygda_amd import ops
     from pygda_amd.graph import as_graph
     n = 20000
@@ -164,7 +165,13 @@ def test_interior_rows_kstep_on_sampled_batches(monkeypatch, K, d):
         want = ops.spmm_kstep(G, x, K, bias)
         want_t = ops.spmm_kstep(G, gy, K, None, transposed=True)
         monkeypatch.setattr(ops, "INTERIOR_KSTEP", True)
-        exact(got, want)
+        if K >= 2:       # the leaf columns' contribution is formed once and added per step: re-associated row sums
+            np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=2e-6 * float(want.abs().max()))
+            monkeypatch.setattr(ops, "INTERIOR_HOIST", False)
+            exact(ops.spmm_kstep(G, x, K, bias), want)          # without the hoist: the full steps' sums bit for bit
+            monkeypatch.setattr(ops, "INTERIOR_HOIST", True)
+        else:
+            exact(got, want)
         scale = float(want_t.abs().max())
         np.testing.assert_allclose(got_t.cpu().numpy(), want_t.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)
         np.testing.assert_allclose(xa.grad.cpu().numpy(), want_t.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)
