@@ -285,6 +285,8 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
     ops.aggregation_log = []
     sync()
     gc.disable()                 # a generation-2 pass of the cyclic collector is milliseconds; the steps are 3 ms
+    ms0 = torch.cuda.memory_stats(dev)
+    allocs0 = ms0.get("num_device_alloc", 0)
     t0 = time.perf_counter()
     marks = []
     for _ in range(args.steps):
@@ -294,6 +296,13 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
     dt = time.perf_counter() - t0
     gc.enable()
     host_ms = [1e3 * (b - a) for a, b in zip([t0] + marks[:-1], marks)]        # host time per step (enqueue side)
+    ms1 = torch.cuda.memory_stats(dev)
+    device_allocs = ms1.get("num_device_alloc", 0) - allocs0   # hipMalloc calls inside the region
+    if os.environ.get("PYGDA_AMD_BENCH_ALLOC_DEBUG") == "1":
+        sys.stderr.write("alloc debug: " + json.dumps({k: ms1.get(k, 0) - ms0.get(k, 0) for k in (
+            "num_device_alloc", "num_device_free", "num_alloc_retries", "reserved_bytes.all.current",
+            "allocated_bytes.all.peak", "allocation.all.allocated", "segment.all.allocated", "num_sync_all_streams")})
+            + f" reserved now {ms1.get('reserved_bytes.all.current', 0) / 2**30:.1f} GiB\n")
     log, ops.aggregation_log = ops.aggregation_log, None
     edges = sum(g.nnz * k for g, k in log)
     # roofline inputs: a short pass of the same steps with HIP events around every kernel family (the timed
@@ -367,6 +376,7 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                                    "per step, MMD domain loss",
                        "edges_aggregated_per_step": edges / args.steps, "final_loss": float(loss.detach()),
                        "host_ms_per_step_max_median": [max(host_ms), sorted(host_ms)[len(host_ms) // 2]],
+                       "hipMalloc_calls_in_timed_region": device_allocs,
                        "sampler": model.source_loader.sampler_description(),
                        "parallelism": "single GPU" if world == 1 else
                        f"dp{world}: disjoint seed mini-batches per rank, graph + features replicated, all-gathered "

@@ -152,7 +152,23 @@ def gemm(mode, a, b, bias=None, colsum=None):
 # --------------------------------------------------------------------------- SpMM --
 aggregated_edges = 0     # running count of nnz(A_hat) over every aggregation launched (bench bookkeeping;
                          # only maintained while the profiler is on: it costs a cached-nnz lookup)
-aggregation_log = None   # or a list: (graph, K) per aggregation call, nnz resolved later (no sync in the loop)
+aggregation_log = None   # or a list: (graph or _Nnz, K) per aggregation call, nnz resolved later (no sync in the loop)
+
+
+class _Nnz:
+    """What the log keeps of a graph whose entry count is already known on the host (every batch of the device
+    sampler): the number, not the graph -- a logged graph object pins its batch's CSR buffers for as long as the log
+    lives, ~13 MB per sampled step that the caching allocator then has to hipMalloc afresh (1.7 device allocations per
+    step inside bench.py's timed cfg-S region, one of them now and then 30 ms long)."""
+    __slots__ = ("nnz",)
+
+    def __init__(self, nnz):
+        self.nnz = nnz
+
+
+def _logged(graph):
+    return _Nnz(graph._nnz) if getattr(graph, "_nnz", None) is not None and getattr(graph, "transient", False) else graph
+
 kstep_paths = None       # or a dict: which kernel ran the K >= 3 aggregation calls ("lds-one-launch" / "launch-chain"),
                          # counted per call while the profiler is on (bench.py: config.kstep_aggregation_path)
 
@@ -176,7 +192,7 @@ def _launch_kstep_interior(graph, x, K, bias, transposed, y):
     n_int = graph.n_interior
     L = _lib.lib()
     if aggregation_log is not None:
-        aggregation_log.append((graph, int(K)))
+        aggregation_log.append((_logged(graph), int(K)))
     _note_path("interior-rows", int(K))
     if profiler.enabled:
         # `bytes`: what the call itself has to move -- forward K interior steps + one copy of the leaf rows; transposed K
@@ -223,7 +239,7 @@ def _launch_kstep(graph, x, K, bias, transposed, y, tmp, counts_as=None):
     book_graph, book_steps = counts_as if counts_as is not None else (graph, int(K))
     _note_path("launch-chain", int(K))
     if aggregation_log is not None:
-        aggregation_log.append((book_graph, book_steps))
+        aggregation_log.append((_logged(book_graph), book_steps))
     if profiler.enabled:      # algorithmic bytes per launch: nnz*(4+4) + (N+1)*4 + 2*N*d*4
         global aggregated_edges
         aggregated_edges += book_steps * book_graph.nnz
@@ -1332,7 +1348,7 @@ def spmm_axpby(graph: CSRGraph, x, alpha, beta, z=None, gamma=1.0, gamma_dev=Non
             raise ValueError("out must be a contiguous fp32 tensor of the shape of x on its device")
     L = _lib.lib()
     if aggregation_log is not None:
-        aggregation_log.append((graph, 1))
+        aggregation_log.append((_logged(graph), 1))
     if profiler.enabled:
         global aggregated_edges
         aggregated_edges += graph.nnz
