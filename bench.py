@@ -742,7 +742,8 @@ def main():
 
     workload = args.workload or ("cfgA" if world == 1 else "cfgS")
     side_args = argparse.Namespace(**vars(args))
-    side_args.steps, side_args.warmup = args.side_steps if args.steps >= 20 else min(args.steps, args.side_steps), min(args.warmup, 5)
+    side_args.steps = args.side_steps if args.steps >= 20 else min(args.steps, args.side_steps)
+    side_args.warmup = max(args.warmup, 10) if args.steps >= 20 else min(args.warmup, 5)     # a fresh allocator pool: see DESIGN 5
     if workload == "cfgS":
         out = run_cfg_s(args, world, rank, dev)
         if world > 1 and not args.no_side_lines:
