@@ -134,10 +134,12 @@ class _GlobalMean(torch.autograd.Function):
     def forward(ctx, mean_local, n_local):
         if int(n_local) == 0:      # a rank without rows: its "mean" is 0/0; it contributes nothing and receives nothing
             mean_local = torch.zeros_like(mean_local)
+        # (the row count enters as a fill and as scalar kernel arguments: a tensor made from a host number is a
+        # pageable H2D copy, i.e. a stream synchronisation per call, and this runs once per data-parallel step)
         buf = torch.stack([mean_local.detach().to(torch.float32).reshape(()) * float(n_local),
-                           torch.tensor(float(n_local), dtype=torch.float32, device=mean_local.device)])
+                           torch.full((), float(n_local), dtype=torch.float32, device=mean_local.device)])
         _all_reduce_sum(buf)
-        ctx.scale = buf.new_tensor(float(n_local) * dist.get_world_size()) / buf[1]
+        ctx.scale = (float(n_local) * dist.get_world_size()) / buf[1]
         ctx.empty = int(n_local) == 0
         return (buf[0] / buf[1]).to(mean_local.dtype).reshape(mean_local.shape)
 

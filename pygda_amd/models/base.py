@@ -90,7 +90,7 @@ class BaseGDA(ABC):
         if graphed is not None and hasattr(graphed, "launch"):
             return self._graphed_epochs(graphed, range(self.epoch) if epochs is None else epochs, start, alpha_fn)
         for epoch in (range(self.epoch) if epochs is None else epochs):
-            epoch_loss, logits, labels = 0.0, [], []
+            epoch_loss, logits, labels, dev_loss = 0.0, [], [], None
             alpha = alpha_fn(epoch)
             if graphed is not None:
                 loss, source_logits = graphed()
@@ -111,9 +111,13 @@ class BaseGDA(ABC):
                 loss.backward()
                 _allreduce_grads(optimizer)
                 optimizer.step()
-                epoch_loss += loss.item()
+                # the reference adds loss.item() per batch (a2gnn.py:327): a host sync per step, with which the host can
+                # never run ahead of the device.  Same doubles, summed on the device in step order, read once per epoch
+                dev_loss = loss.detach().double() if dev_loss is None else dev_loss + loss.detach().double()
                 logits.append(source_logits.detach())
                 labels.append(src.y)
+            if dev_loss is not None:
+                epoch_loss += dev_loss.item()
             preds = torch.cat(logits).argmax(dim=1)
             acc = eval_micro_f1(torch.cat(labels), preds)
             secs = time.time() - start
