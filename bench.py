@@ -256,6 +256,9 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                   weight=hp["weight"], device=dev, batch_size=args.batch, num_neigh=fan, verbose=0)
     torch.manual_seed(1234 + rank)
     net, optimizer, step_fn, alpha_fn = model._prepare(src, tgt)
+    if world > 1:                # replicas of ONE model (fit() does this in its epoch loop; the generators stay per rank)
+        from pygda_amd.distributed import broadcast_parameters
+        broadcast_parameters(net)
     kw = dict(rank=rank, world_size=world, device=dev)
     model.source_loader = NeighborLoader(src, fan, batch_size=args.batch, input_nodes=seeds_s, **kw)
     model.target_loader = NeighborLoader(tgt, fan, batch_size=args.batch, input_nodes=seeds_t, **kw)
