@@ -576,6 +576,34 @@ def run_cfg_a(args, world, rank, dev, side=False):
         return None
     ms = 1e3 * dt / args.steps
 
+    def kstep_alone():
+        """The one-launch K-step kernel of the target graph, 30 launches back to back between two HIP events on the
+        launch stream: its duration without the event pair and the neighbours of the per-launch bracket above
+        (rocprofv3's in-graph average of the same kernel is the figure to compare with)."""
+        try:
+            g = as_graph(tgt_d.edge_index, tgt_d.num_nodes)
+            g.static = True                      # the full-batch graph of this run (the loader tags its own copy)
+            hit = _ops.lds_kstep_plan(g, hp["t_pnums"], False)
+            if hit is None:
+                return None
+            plan, slots = hit
+            n, d = g.num_nodes, hp["hid"]
+            n_pad = (n + 3) // 4 * 4
+            xT = torch.randn(d, n_pad, device=dev)
+            yT = torch.empty_like(xT)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for rep in range(33):
+                if rep == 3:
+                    e0.record()
+                _ops._launch_kstep_lds(g, plan, slots, xT, hp["t_pnums"], None, False, yT, x_colmajor=True, y_colmajor=True)
+            e1.record()
+            torch.cuda.synchronize()
+            return 1e3 * e0.elapsed_time(e1) / 30
+        except Exception:                     # noqa: BLE001 -- a side figure must not cost the line
+            return None
+
+    alone_us = kstep_alone()
+
     # committed PMC passes of this same command (profiles/, made by tools/profile_r3.sh)
     prof_pattern = "r[0-9]*_cfgA" + ("_powerlaw" if args.graph == "powerlaw" else "") + "_rocprof_summary.json"
 
@@ -595,6 +623,9 @@ def run_cfg_a(args, world, rank, dev, side=False):
                 # its bound is the LDS gather rate (`lds`)
                 out["traffic"], out["traffic_source"] = pmc_traffic("k_kstep_lds", prof_pattern)
                 out["achieved_is"] = "algorithmic-equivalent (K aggregations per launch), see DESIGN 4.1b"
+                if alone_us:
+                    out["back_to_back_launch_us"] = alone_us
+                    out["frac_back_to_back"] = r["bytes"] / r["launches"] / (alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS
                 if r.get("hbm_bytes"):
                     out["hbm_bytes_per_launch"] = r["hbm_bytes"] / r["launches"]
                     out["hbm_frac_real"] = r["hbm_bytes"] / secs / 1e9 / HBM_PEAK_GBS
