@@ -90,6 +90,11 @@ def test_round3_entry_points_validate_before_touching_a_device():
     assert L.gda_spmm_csr_interior_kstep_f32(one, one, one, 10, 11, 4, 2, 0, one, ctypes.c_void_p(2), one, None, None, None) == -2
     assert L.gda_spmm_csr_interior_kstep_f32(one, one, one, 10, 4, 4, 2, 0, one, ctypes.c_void_p(2), None, None, None, None) == -1
     assert L.gda_spmm_csr_interior_kstep_f32(one, one, one, 10, 4, 4, 0, 0, one, ctypes.c_void_p(2), one, None, None, None) == -2
+    # transposed-output step: the leading dimension of yT counts ROWS
+    assert L.gda_spmm_csr_tout_f32(one, one, one, 10, 4, one, 4, ctypes.c_void_p(2), 9, None, None) == -2
+    assert L.gda_spmm_csr_tout_f32(one, one, one, 10, 4, one, 3, ctypes.c_void_p(2), 12, None, None) == -2
+    assert L.gda_spmm_csr_tout_f32(None, one, one, 10, 4, one, 4, ctypes.c_void_p(2), 12, None, None) == -1
+    assert L.gda_spmm_csr_tout_f32(one, one, one, 0, 4, one, 4, ctypes.c_void_p(2), 12, None, None) == 0      # nothing to do
     assert L.gda_segment_mean_fwd_f32(None, 4, None, 3, 4, None, 4, None) == -1
     assert L.gda_segment_mean_fwd_f32(one, 2, one, 3, 4, one, 4, None) == -2                   # ldx < d
     assert L.gda_segment_mean_bwd_f32(one, 4, one, None, 5, 4, one, 4, None) == -1
