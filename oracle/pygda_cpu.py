@@ -345,12 +345,12 @@ def a2gnn_forward_model(net: A2GNNBase, src: Graph, tgt: Graph, alpha: float,
 
 
 class GRADEBase(nn.Module):
-    """grade_base.py:9-202 (node mode)."""
+    """grade_base.py:9-202 (``mode='graph'``: every layer's output and the last one mean-pooled per graph, :150-157)."""
 
     def __init__(self, in_dim, hid_dim, num_classes, num_layers=1, dropout=0.1,
-                 act=F.relu, disc="JS"):
+                 act=F.relu, disc="JS", mode="node"):
         super().__init__()
-        self.dropout, self.act, self.num_classes = dropout, act, num_classes
+        self.dropout, self.act, self.num_classes, self.mode = dropout, act, num_classes, mode
         self.convs = nn.ModuleList([GCNConv(in_dim, hid_dim)])
         for _ in range(num_layers - 1):
             self.convs.append(GCNConv(hid_dim, hid_dim))
@@ -364,7 +364,9 @@ class GRADEBase(nn.Module):
             x = conv(x, data.edge_index)
             x = self.act(x)
             x = F.dropout(x, p=self.dropout, training=self.training)
-            feats.append(x)
+            feats.append(x if self.mode == "node" else global_mean_pool(x, data.batch))       # :150-153
+        if self.mode == "graph":                                                               # :155-156
+            x = global_mean_pool(x, data.batch)
         x = self.cls(x)
         feats.append(x)
         return x, torch.cat(feats, dim=1)
@@ -378,10 +380,12 @@ def grade_forward_model(net: GRADEBase, src: Graph, tgt: Graph, alpha: float,
     loss = F.nll_loss(F.log_softmax(s_logits, dim=1), src.y)
     if disc == "JS":                                                         # :169-176
         preds = net.discriminator(grad_reverse(torch.cat([s_feats, t_feats], 0), alpha))
-        lab = torch.tensor([0] * src.x.size(0) + [1] * tgt.x.size(0))
+        # node mode: one label per node (:171-172); graph mode: len(batch) = its number of graphs (:173-174)
+        ns, nt = (src.x.size(0), tgt.x.size(0)) if net.mode == "node" else (src.num_graphs, tgt.num_graphs)
+        lab = torch.tensor([0] * ns + [1] * nt)
         dom = F.cross_entropy(preds, lab)
     elif disc == "MMD":                                                      # :177-182
-        m = min(src.x.size(0), tgt.x.size(0))
+        m = min(src.x.size(0), tgt.x.size(0)) if net.mode == "node" else min(src.num_graphs, tgt.num_graphs)
         dom = MMD(s_feats[:m], t_feats[:m], chunk_rows=mmd_chunk_rows, samples=mmd_samples)
     else:
         raise NotImplementedError(disc)
@@ -580,15 +584,25 @@ class UDAGCNBase(nn.Module):
 
 
 def udagcn_forward_model(net: UDAGCNBase, src: Graph, tgt: Graph, alpha: float, epoch: int,
-                         epochs: int):
-    """udagcn.py:131-201."""
+                         epochs: int, mode: str = "node"):
+    """udagcn.py:131-201.  ``mode='graph'`` (:168-170): embeddings mean-pooled per graph; the adjacency caches are
+    emptied first -- the reference never invalidates them (cached_gcn_conv.py:132-136) and would aggregate every
+    shuffled batch after the first over the first batch's edges (tests/golden/make_golden.py::fx_graph_trainers
+    records the reference with the caches emptied the same way)."""
+    if mode == "graph":
+        for enc in (net.encoder, getattr(net, "ppmi_encoder", None)):
+            for conv in (() if enc is None else enc.conv_layers):
+                conv.cache_dict.clear()
     es, et = net.encode(src, "source"), net.encode(tgt, "target")
+    if mode == "graph":
+        es, et = global_mean_pool(es, src.batch), global_mean_pool(et, tgt.batch)
     s_logits = net.cls_model(es)
     loss = net.loss_func(s_logits, src.y)                                            # :172
     sd = net.domain_model(grad_reverse(es, alpha))
     td = net.domain_model(grad_reverse(et, alpha))
-    loss = loss + net.loss_func(sd, torch.zeros(sd.size(0), dtype=torch.long)) \
-                + net.loss_func(td, torch.ones(td.size(0), dtype=torch.long))        # :177-190
+    loss_grl = net.loss_func(sd, torch.zeros(sd.size(0), dtype=torch.long)) \
+        + net.loss_func(td, torch.ones(td.size(0), dtype=torch.long))               # :177-189
+    loss = loss + loss_grl                                                           # :190 (cls + (src + tgt))
     t_logits = net.cls_model(et)
     p = torch.clamp(F.softmax(t_logits, dim=-1), min=1e-9, max=1.0)
     ent = torch.mean(torch.sum(-p * torch.log(p), dim=-1))                           # :193-197
@@ -980,14 +994,16 @@ class AdaGCNBase(nn.Module):
     """adagcn_base.py:99-181 (node mode).  The ctor's ``dropout`` never reaches the stack
     (:145 builds GNN without it, so its default 0.1 at :39 always applies)."""
 
-    def __init__(self, in_dim, hid_dim, num_classes, num_layers=3, act=F.relu, dropout_p=0.1):
+    def __init__(self, in_dim, hid_dim, num_classes, num_layers=3, act=F.relu, dropout_p=0.1, mode="node"):
         super().__init__()
         self.encoder = _AdaGNN(in_dim, hid_dim, num_layers, act, dropout_p)
         self.cls_model = nn.Sequential(nn.Linear(hid_dim, num_classes))
         self.loss_func = nn.CrossEntropyLoss()
+        self.mode = mode
 
     def forward(self, data):
-        return self.encoder(data.x, data.edge_index)
+        x = self.encoder(data.x, data.edge_index)
+        return global_mean_pool(x, data.batch) if self.mode == "graph" else x      # adagcn_base.py:93-94
 
 
 def adagcn_gradient_penalty(disc: nn.Module, es: Tensor, et: Tensor) -> Tensor:
@@ -1099,16 +1115,16 @@ class GATConv(nn.Module):
 
 
 class GNNBase(nn.Module):
-    """gnn_base.py:11-203 (node mode)."""
+    """gnn_base.py:11-203 (``mode='graph'``: mean readout per graph :133-134, linear classifier :97-98, :200-203)."""
 
-    def __init__(self, in_dim, hid_dim, num_classes, num_layers=1, dropout=0.1, act=F.relu, gnn="gcn"):
+    def __init__(self, in_dim, hid_dim, num_classes, num_layers=1, dropout=0.1, act=F.relu, gnn="gcn", mode="node"):
         super().__init__()
-        self.dropout, self.act = dropout, act
+        self.dropout, self.act, self.mode = dropout, act, mode
         mk = {"gcn": GCNConv, "sage": SAGEConv, "gat": GATConv,
               "gin": lambda a, b: GINConv(nn.Sequential(nn.Linear(a, b)))}[gnn]
         dims = [in_dim] + [hid_dim] * num_layers
         self.convs = nn.ModuleList(mk(dims[i], dims[i + 1]) for i in range(num_layers))
-        self.cls = mk(hid_dim, num_classes)
+        self.cls = mk(hid_dim, num_classes) if mode == "node" else nn.Linear(hid_dim, num_classes)
 
     def feat_bottleneck(self, x, edge_index, edge_weight=None):                 # :139-171
         for i, conv in enumerate(self.convs):
@@ -1118,10 +1134,12 @@ class GNNBase(nn.Module):
         return x
 
     def feat_classifier(self, x, edge_index, edge_weight=None):                 # :173-203
-        return self.cls(x, edge_index, edge_weight)
+        return self.cls(x, edge_index, edge_weight) if self.mode == "node" else self.cls(x)
 
-    def forward(self, x, edge_index, edge_weight=None):                          # :97-137
+    def forward(self, x, edge_index, edge_weight=None, batch=None):              # :97-137
         x = self.feat_bottleneck(x, edge_index, edge_weight)
+        if self.mode == "graph":
+            x = global_mean_pool(x, batch)
         return F.log_softmax(self.feat_classifier(x, edge_index, edge_weight), dim=1)
 
 
@@ -1138,12 +1156,18 @@ def dane_l_gcn(embedding, nodes_weight, idx_u, idx_v, k, sample_size):
 
 def dane_forward_model(gnn: GNNBase, disc: nn.Module, g_opt, d_opt, src: Graph, tgt: Graph, k: int,
                        sample_size: int):
-    """dane.py:145-180 + train_d :301-355 + train_g :426-516 (node mode, train_mode='unsup')."""
+    """dane.py:145-180 + train_d :301-355 + train_g :426-516 (train_mode='unsup').  Graph mode (``gnn.mode``): the
+    embeddings are mean-pooled per graph (:323-331, :448-456) and the skip-gram term is absent (:492-493)."""
+    graph = gnn.mode == "graph"
+
+    def embed(d):
+        e = gnn.feat_bottleneck(d.x, d.edge_index)
+        return global_mean_pool(e, d.batch) if graph else e
+
     d_loss = 0.0
     for _ in range(5):
         gnn.eval()
-        es = gnn.feat_bottleneck(src.x, src.edge_index)
-        et = gnn.feat_bottleneck(tgt.x, tgt.edge_index)
+        es, et = embed(src), embed(tgt)
         i_s = torch.multinomial(torch.ones(es.shape[0]), 8 * sample_size, replacement=True)
         i_t = torch.multinomial(torch.ones(et.shape[0]), 8 * sample_size, replacement=True)
         d_opt.zero_grad()
@@ -1152,20 +1176,24 @@ def dane_forward_model(gnn: GNNBase, disc: nn.Module, g_opt, d_opt, src: Graph, 
         d_opt.step()
         d_loss = loss.item()
     gnn.train()
-    es = gnn.feat_bottleneck(src.x, src.edge_index)
+    es = embed(src)
     out_s = gnn.feat_classifier(es, src.edge_index)
-    et = gnn.feat_bottleneck(tgt.x, tgt.edge_index)
+    et = embed(tgt)
     i_s = torch.multinomial(torch.ones(es.shape[0]), 8 * sample_size, replacement=True)
     i_t = torch.multinomial(torch.ones(et.shape[0]), 8 * sample_size, replacement=True)
     l_adv = (disc(et[i_t]) ** 2).mean() + ((disc(es[i_s]) - 1) ** 2).mean()
-    e_s = torch.multinomial(torch.ones(src.edge_index.shape[1]), sample_size, replacement=False)
-    e_t = torch.multinomial(torch.ones(tgt.edge_index.shape[1]), sample_size, replacement=False)
-    w_s = torch.pow(torch.unique(src.edge_index[0], return_counts=True)[1], 0.75)
-    w_t = torch.pow(torch.unique(tgt.edge_index[0], return_counts=True)[1], 0.75)
-    l_gcn = dane_l_gcn(es, w_s, src.edge_index[0][e_s], src.edge_index[1][e_s], k, sample_size) + \
-        dane_l_gcn(et, w_t, tgt.edge_index[0][e_t], tgt.edge_index[1][e_t], k, sample_size)
+    if graph:
+        l_gcn = 0
+    else:
+        e_s = torch.multinomial(torch.ones(src.edge_index.shape[1]), sample_size, replacement=False)
+        e_t = torch.multinomial(torch.ones(tgt.edge_index.shape[1]), sample_size, replacement=False)
+        w_s = torch.pow(torch.unique(src.edge_index[0], return_counts=True)[1], 0.75)
+        w_t = torch.pow(torch.unique(tgt.edge_index[0], return_counts=True)[1], 0.75)
+        l_gcn = dane_l_gcn(es, w_s, src.edge_index[0][e_s], src.edge_index[1][e_s], k, sample_size) + \
+            dane_l_gcn(et, w_t, tgt.edge_index[0][e_t], tgt.edge_index[1][e_t], k, sample_size)
     loss = l_gcn + F.cross_entropy(out_s, src.y) + l_adv * 0.1
     g_opt.zero_grad()
     loss.backward()
     g_opt.step()
-    return d_loss + loss.item(), gnn(src.x, src.edge_index), gnn(tgt.x, tgt.edge_index)
+    kw_s, kw_t = (dict(batch=src.batch), dict(batch=tgt.batch)) if graph else ({}, {})
+    return d_loss + loss.item(), gnn(src.x, src.edge_index, **kw_s), gnn(tgt.x, tgt.edge_index, **kw_t)

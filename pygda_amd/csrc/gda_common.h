@@ -19,6 +19,22 @@
         if (_e != hipSuccess) return (int)_e;          \
     } while (0)
 
+// Opt a kernel into more than 64 KB of dynamic LDS.  The attribute is per DEVICE: the flag word holds one bit per device
+// ordinal (a process that drives a second GPU configures the kernel there too); racing first calls set the same value.
+#include <atomic>
+#define GDA_LDS_ATTR_ONCE(func, bytes)                                                                         \
+    do {                                                                                                       \
+        static std::atomic<uint64_t> _done{0};                                                                 \
+        int _dev = 0;                                                                                          \
+        GDA_HIP_TRY(hipGetDevice(&_dev));                                                                      \
+        const uint64_t _bit = 1ull << (_dev & 63);                                                             \
+        if (!(_done.load(std::memory_order_relaxed) & _bit)) {                                                 \
+            GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(func),                               \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));        \
+            _done.fetch_or(_bit, std::memory_order_relaxed);                                                   \
+        }                                                                                                      \
+    } while (0)
+
 static inline size_t gda_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static inline int64_t gda_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

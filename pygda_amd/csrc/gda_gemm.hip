@@ -632,12 +632,8 @@ extern "C" int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, cons
         float* cs_part = part + (size_t)slabs * 128 * N;
         if (lda % 4 || ldb % 4 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return GDA_E_UNSUPPORTED;
         const size_t lds = (size_t)2 * 32 * (N + 128) * sizeof(float);           // both images of x and gy chunks
-        static bool configured = false;              // idempotent attribute; racing first calls set the same value
-        if (!configured) {
-            GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tall_wgrad<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tall_wgrad<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            configured = true;
-        }
+        GDA_LDS_ATTR_ONCE(k_tall_wgrad<4>, 160 * 1024);
+        GDA_LDS_ATTR_ONCE(k_tall_wgrad<8>, 160 * 1024);
         if (N == 128) k_tall_wgrad<4><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, B, ldb, part, colsum ? cs_part : nullptr, K, rows);
         else k_tall_wgrad<8><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, B, ldb, part, colsum ? cs_part : nullptr, K, rows);
         GDA_LAUNCH_CHECK();
@@ -657,12 +653,7 @@ extern "C" int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, cons
 #define TF_LAUNCH(KQ_, BT_)                                                                                   \
     do {                                                                                                      \
         const size_t lds = (size_t)2 * TALL_BM * (4 * 16 + 2) * sizeof(float);                                \
-        static bool configured = false;              /* idempotent attribute; racing first calls set the same value */ \
-        if (!configured) {                                                                                    \
-            GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tall_fwd16<KQ_, BT_, 16>),        \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));         \
-            configured = true;                                                                                \
-        }                                                                                                     \
+        GDA_LDS_ATTR_ONCE((k_tall_fwd16<KQ_, BT_, 16>), 160 * 1024);                                          \
         k_tall_fwd16<KQ_, BT_, 16><<<grid, TALL_TB, lds, stream>>>(A, lda, B, ldb, C, ldc, M, bias);          \
     } while (0)
     if (mode == GDA_GEMM_NT) {

@@ -210,12 +210,7 @@ int ks_launch(const int2* ent, const unsigned* outa, const unsigned* keep, const
               int K, const float* xT, int64_t ldx, float* yT, int64_t ldy, const float* bias, float* colsum, hipStream_t s) {
     // both buffers in full + the column-sum scratch + the combine table of the hub waves
     const size_t lds = (size_t)2 * KS_OFFB + (size_t)KS_RED_BYTES + (size_t)hub_waves * 64 * sizeof(uint2);
-    static bool configured = false;          // idempotent attribute; racing first calls set the same value
-    if (!configured) {
-        GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_kstep_lds<S>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
+    GDA_LDS_ATTR_ONCE(k_kstep_lds<S>, 160 * 1024);
     k_kstep_lds<S><<<(unsigned)d, KS_TB, lds, s>>>(ent, outa, keep, pos, hubp, hub_waves, n_rows, n_pad, K, xT, ldx, yT, ldy, bias, colsum);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
@@ -441,7 +436,10 @@ extern "C" int gda_kstep_plan_host_ex(const int32_t* rowptr_host, const int32_t*
             }
             n_parts += parts;
         }
-        if (!ok) return 0;                       // a longer segment only comes with a larger S: 12 * 4 * 64 entries is the limit
+        if (!ok) {                               // a longer segment comes with a larger S: 12 * 4 * 64 entries is the limit
+            if (S < 12) continue;
+            return 0;
+        }
         const int n_total = n + n_parts;
         if (n_total > KS_MAX_ROWS || total_slots > (int64_t)S * KS_TB) continue;
         // combine lanes: groups in order of decreasing size pack the 64-lane waves without gaps

@@ -773,12 +773,7 @@ template <bool FAST, int BI_>
 int launch_bwd(dim3 grid, hipStream_t stream, Rows R, int64_t d, int64_t m, const float* l2, const float* grad_loss, float scale,
                int times, int nseg, float* part) {
     const size_t lds = sizeof(float) * (2 * BJ * (BI_ + DC) + BI_);
-    static bool configured = false;
-    if (!configured) {
-        GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd<FAST, BI_>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
-    }
+    GDA_LDS_ATTR_ONCE((k_bwd<FAST, BI_>), lds);
     k_bwd<FAST, BI_><<<grid, BI_ * 4, lds, stream>>>(R, d, m, l2, grad_loss, scale, times, nseg, part);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
@@ -874,12 +869,7 @@ extern "C" int gda_mmd_fwd_gather_f32(const float* src, int64_t ld_src, const fl
                       kernel_num == 5 && kernel_mul == 2.0f;
     const size_t rs_lds = fast ? sizeof(float) * SR * (size_t)(d + 1) : 0;
     if (fast && rs_lds > 48 * 1024) {
-        static bool configured = false;
-        if (!configured) {
-            GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowstats), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)(sizeof(float) * SR * 2049)));
-            configured = true;
-        }
+        GDA_LDS_ATTR_ONCE(k_rowstats, sizeof(float) * SR * 2049);
     }
     k_rowstats<<<dim3(chunks, (unsigned)times), TB, rs_lds, stream>>>(R, d, m, ws.part_s1, ws.part_col, rows_src, rows_tgt,
                                                                     fast ? ws.norms : nullptr);

@@ -204,16 +204,7 @@ class A2GNN(BaseGDA):
 
     def _prepare(self, source_data, target_data):
         """Everything fit() does before its epoch loop (a2gnn.py:254-296)."""
-        if self.mode == 'node':
-            self._node_loaders(source_data, target_data)
-        elif self.mode == 'graph':                                                         # :278-286
-            from ..data import DataLoader
-            bs_s = len(source_data) if self.batch_size == 0 else self.batch_size
-            bs_t = len(target_data) if self.batch_size == 0 else self.batch_size
-            self.source_loader = DataLoader(source_data, batch_size=bs_s, shuffle=True)
-            self.target_loader = DataLoader(target_data, batch_size=bs_t, shuffle=True)
-        else:
-            assert self.mode in ('graph', 'node'), 'Invalid train mode'                  # :288
+        self._loaders(source_data, target_data)                                          # :254-288
         self.a2gnn = self.init_model(**self.kwargs)
         # the MMD branch never reads alpha/epoch; the adversarial branch reads the GRL alpha, which the
         # captured step receives as a 0-dim device tensor refreshed per epoch: both replay as a hipGraph

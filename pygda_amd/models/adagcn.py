@@ -153,9 +153,9 @@ class AdaGCN(BaseGDA):
         return cls_loss + dis_loss * self.domain_weight, source_logits, target_logits
 
     def _prepare(self, source_data, target_data):
-        if self.mode != 'node':
-            raise NotImplementedError("mode='graph' is out of scope (DESIGN.md)")
-        self._node_loaders(source_data, target_data)
+        # mode='graph' (adagcn.py:244-252, adagcn_base.py:93-94): shuffled DataLoader batches, the encoder's output
+        # mean-pooled per graph -- critic, gradient penalty and classifier then see one row per graph
+        self._loaders(source_data, target_data)
         self.adagcn = self.init_model(**self.kwargs)
         on_gpu = torch.device(self.device).type == "cuda"
         if on_gpu:       # torch.optim.Adam's rule in one capturable launch (pygda_amd/optim.py)
@@ -168,7 +168,7 @@ class AdaGCN(BaseGDA):
         self.c_optimizer = Adam(self.discriminator.parameters(), lr=self.lr, weight_decay=self.weight_decay)
         # no per-epoch scalar enters the step, its host draws go through hipgraph.host_rand and the critic's
         # optimiser is rolled back with the encoder's: the step (10 critic updates + encoder update) replays
-        self._graph_safe_step = True
+        self._graph_safe_step = self.mode == 'node'      # graph mode re-collates a shuffled batch every epoch
         self._graph_extra_optimizers = [self.c_optimizer]
         self._dp_aux_modules = [self.discriminator]      # broadcast from rank 0 with the encoder
 

@@ -74,6 +74,25 @@ class BaseGDA(ABC):
         self.source_loader = NeighborLoader(source_data, self.num_neigh, batch_size=sb, **kw)
         self.target_loader = NeighborLoader(target_data, self.num_neigh, batch_size=tb, **kw)
 
+    def _graph_loaders(self, source_data, target_data):
+        """``mode='graph'`` (a2gnn.py:278-286, the same block in grade.py:244-252, udagcn.py:248-256, adagcn.py:244-252,
+        dane.py:219-229): ``DataLoader(dataset, batch_size, shuffle=True)`` over a list of graphs, every graph of the
+        domain in one batch when ``batch_size == 0``."""
+        from ..data import DataLoader
+        bs_s = len(source_data) if self.batch_size == 0 else self.batch_size
+        bs_t = len(target_data) if self.batch_size == 0 else self.batch_size
+        self.source_loader = DataLoader(source_data, batch_size=bs_s, shuffle=True)
+        self.target_loader = DataLoader(target_data, batch_size=bs_t, shuffle=True)
+
+    def _loaders(self, source_data, target_data):
+        mode = getattr(self, "mode", "node")
+        if mode == 'node':
+            self._node_loaders(source_data, target_data)
+        elif mode == 'graph':
+            self._graph_loaders(source_data, target_data)
+        else:
+            assert mode in ('graph', 'node'), 'Invalid train mode'
+
     def _train_epochs(self, net, optimizer, step_fn, alpha_fn, before_step=None, epochs=None):
         """The epoch loop of a2gnn.py:298-336: ``step_fn(src, tgt, alpha, epoch)`` returns
         ``(loss, source_logits)``; the optimiser step happens here.  ``epochs`` (default

@@ -1,4 +1,5 @@
-"""``DANE`` trainer (pygda/models/dane.py:21-621), node mode: shared GNN encoder trained as an
+"""``DANE`` trainer (pygda/models/dane.py:21-621), node mode and graph mode (pooled embeddings, no skip-gram
+term, linear classifier -- :171-176, 219-229, 323-331, 448-456, 492-493): shared GNN encoder trained as an
 LSGAN generator (5 discriminator updates per generator update) with a skip-gram edge loss
 (degree^0.75 negative sampling) and source cross-entropy.
 
@@ -14,6 +15,7 @@ import torch.nn.functional as F
 
 from ..data import to_undirected
 from ..nn import GNNBase
+from ..nn.a2gnn_base import global_mean_pool
 from .base import BaseGDA
 
 
@@ -68,15 +70,20 @@ class DANE(BaseGDA):
         for _ in range(5):
             discriminator_loss = self.train_d(source_data, target_data)
         generator_loss = self.train_g(source_data, target_data)
-        source_logits = self.gnn(source_data.x, source_data.edge_index)
-        target_logits = self.gnn(target_data.x, target_data.edge_index)
+        graph = self.mode == 'graph'                                                    # :171-176
+        source_logits = self.gnn(source_data.x, source_data.edge_index, batch=source_data.batch if graph else None)
+        target_logits = self.gnn(target_data.x, target_data.edge_index, batch=target_data.batch if graph else None)
         return discriminator_loss + generator_loss, source_logits, target_logits
+
+    def _embed(self, data):
+        """Encoder output; graph mode: mean-pooled per graph (:323-331, :448-456)."""
+        e = self.gnn.feat_bottleneck(data.x, data.edge_index)
+        return global_mean_pool(e, data.batch) if self.mode == 'graph' else e
 
     def train_d(self, source_data, target_data):                                        # :301-355
         self.gnn.eval()
         with torch.no_grad():
-            es = self.gnn.feat_bottleneck(source_data.x, source_data.edge_index)
-            et = self.gnn.feat_bottleneck(target_data.x, target_data.edge_index)
+            es, et = self._embed(source_data), self._embed(target_data)
         self.d_optimizer.zero_grad()
         loss = self._lsgan_loss(es, et, 0.0, 1.0)
         loss.backward()
@@ -109,13 +116,16 @@ class DANE(BaseGDA):
 
     def train_g(self, source_data, target_data):                                        # :426-516
         self.gnn.train()
-        es = self.gnn.feat_bottleneck(source_data.x, source_data.edge_index)
+        es = self._embed(source_data)
         out_s = self.gnn.feat_classifier(es, source_data.edge_index)
-        et = self.gnn.feat_bottleneck(target_data.x, target_data.edge_index)
+        et = self._embed(target_data)
         out_t = self.gnn.feat_classifier(et, target_data.edge_index)
         l_adv = self._lsgan_loss(es, et, 1.0, 0.0)
-        edges_s, edges_t = self._pick_edges(source_data), self._pick_edges(target_data)   # draw order of :480-487
-        l_gcn = self.L_GCN(es, *edges_s, self.k) + self.L_GCN(et, *edges_t, self.k)
+        if self.mode == 'node':
+            edges_s, edges_t = self._pick_edges(source_data), self._pick_edges(target_data)   # draw order of :480-487
+            l_gcn = self.L_GCN(es, *edges_s, self.k) + self.L_GCN(et, *edges_t, self.k)
+        else:
+            l_gcn = 0                                                                   # :492-493: no skip-gram term
         l_ce = F.cross_entropy(out_s, source_data.y)
         if self.train_mode == 'semi':
             n_t = et.shape[0]
@@ -135,13 +145,14 @@ class DANE(BaseGDA):
         import time
         from ..metrics import eval_micro_f1
         from ..utils import logger
-        if self.mode != 'node':
-            raise NotImplementedError("mode='graph' is out of scope (DESIGN.md)")
-        for d in (source_data, target_data):                                            # :192-196
-            if not d.is_undirected():
-                d.edge_index = to_undirected(d.edge_index, d.num_nodes)
-        self.sample_size = min(source_data.x.shape[0], target_data.x.shape[0])
-        self._node_loaders(source_data, target_data)
+        if self.mode == 'node':
+            for d in (source_data, target_data):                                        # :203-207
+                if not d.is_undirected():
+                    d.edge_index = to_undirected(d.edge_index, d.num_nodes)
+            self.sample_size = min(source_data.x.shape[0], target_data.x.shape[0])
+        elif self.mode == 'graph':
+            self.sample_size = min(len(source_data), len(target_data))                  # :220: number of graphs
+        self._loaders(source_data, target_data)
         self.gnn = self.init_model(**self.kwargs)
         self.domain_discriminator = nn.Sequential(nn.Linear(self.hid_dim, self.hid_dim), nn.ReLU(),
                                                   nn.Linear(self.hid_dim, 1)).to(self.device)
@@ -169,4 +180,5 @@ class DANE(BaseGDA):
     def predict(self, data, source=False):
         self.gnn.eval()
         loader = self.source_loader if source else self.target_loader
-        return self._predict_loader(loader, lambda b: self.gnn(b.x, b.edge_index))
+        graph = self.mode == 'graph'                                                    # :561-564
+        return self._predict_loader(loader, lambda b: self.gnn(b.x, b.edge_index, batch=b.batch if graph else None))

@@ -37,7 +37,10 @@ class GRADE(BaseGDA):
         if self.disc == 'JS':                                                      # :169-176
             domain_loss = grl_disc_ce(source_feats, target_feats, lin.weight, lin.bias, alpha)
         elif self.disc == 'MMD':                                                   # :177-182
-            mind = min(source_data.x.size(0), target_data.x.size(0))
+            # graph mode: len(batch) in the reference = the number of graphs (PyG's Batch.__len__); the pooled feature
+            # matrix has one row per graph, so the row counts say the same
+            mind = min(source_feats.size(0), target_feats.size(0)) if self.mode == 'graph' else \
+                min(source_data.x.size(0), target_data.x.size(0))
             domain_loss = MMD(source_feats[:mind], target_feats[:mind])
         elif self.disc == 'C':                                                     # :183-193
             ratio = 8
@@ -47,9 +50,7 @@ class GRADE(BaseGDA):
         return loss + domain_loss * self.weight, source_logits, target_logits
 
     def fit(self, source_data, target_data):
-        if self.mode != 'node':
-            raise NotImplementedError("mode='graph' is out of scope (DESIGN.md)")
-        self._node_loaders(source_data, target_data)
+        self._loaders(source_data, target_data)                                    # :219-252
         self.grade = self.init_model(**self.kwargs)
         if torch.device(self.device).type == "cuda":       # one capturable multi-tensor launch (pygda_amd/optim.py)
             from ..optim import Adam
@@ -57,7 +58,8 @@ class GRADE(BaseGDA):
             Adam = torch.optim.Adam
         optimizer = Adam(self.grade.parameters(), lr=self.lr, weight_decay=self.weight_decay)
         # the step replays as a hipGraph: its only per-epoch scalar, the GRL alpha, is a device tensor there
-        self._graph_safe_step, self._graph_uses_scalars = True, self.disc != 'MMD'
+        # (graph mode re-collates a shuffled batch every epoch: nothing static to capture)
+        self._graph_safe_step, self._graph_uses_scalars = self.mode == 'node', self.disc != 'MMD'
 
         def step(src, tgt, alpha, epoch):
             loss, source_logits, _ = self.forward_model(src, tgt, alpha)

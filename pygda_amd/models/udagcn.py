@@ -4,13 +4,20 @@ CE per domain (MLP discriminator) + annealed target entropy, over the dual-view 
 The reference's per-name adjacency cache is never invalidated (cached_gcn_conv.py:132-136),
 so with ``batch_size > 0`` it would silently reuse batch #1's edges for every later batch.
 Here mini-batches key the cache per batch (SURVEY §3.4 hazard); full-batch runs use the
-reference's keys "source"/"target" unchanged."""
+reference's keys "source"/"target" unchanged.
+
+``mode='graph'`` (udagcn.py:168-170, 248-256, 360-377): node embeddings are mean-pooled per graph before the
+classifier, the discriminator and the entropy term.  Its loaders shuffle (``DataLoader(..., shuffle=True)``), so
+in the reference EVERY batch after the first meets the first batch's cached adjacency -- other graphs' edges
+applied to this batch's nodes, or an index error when the node counts differ.  Graph-mode batches are keyed per
+batch here as well (the goldens are recorded from the reference with its caches emptied before every step)."""
 import itertools
 
 import torch
 import torch.nn.functional as F
 
 from ..nn import GradReverse, UDAGCNBase
+from ..nn.a2gnn_base import global_mean_pool
 from .base import BaseGDA
 
 
@@ -39,7 +46,7 @@ class UDAGCN(BaseGDA):
         entries are dropped from every conv layer before the batch is encoded -- the graphs of a batch
         live for that batch only (no growth with the number of steps, no host sync for a key, no stale
         hit when two batches happen to agree in their first seed and sizes)."""
-        if getattr(data, "n_id", None) is None:
+        if getattr(data, "n_id", None) is None and self.mode == 'node':
             return name
         key = name + ":minibatch"
         for enc in (self.udagcn.encoder, getattr(self.udagcn, "ppmi_encoder", None)):
@@ -75,6 +82,9 @@ class UDAGCN(BaseGDA):
         net = self.udagcn
         encoded_source = net.encode(source_data, self._cache_key(source_data, "source"))
         encoded_target = net.encode(target_data, self._cache_key(target_data, "target"))
+        if self.mode == 'graph':                                                              # :168-170
+            encoded_source = global_mean_pool(encoded_source, source_data.batch)
+            encoded_target = global_mean_pool(encoded_target, target_data.batch)
         source_logits = net.cls_model(encoded_source)
         gm = self._gmean
         ns, nt = encoded_source.size(0), encoded_target.size(0)
@@ -87,9 +97,7 @@ class UDAGCN(BaseGDA):
         return loss + loss_entropy * (epoch / self.epoch * 0.01), source_logits, target_logits
 
     def _prepare(self, source_data, target_data):
-        if self.mode != 'node':
-            raise NotImplementedError("mode='graph' is out of scope (DESIGN.md)")
-        self._node_loaders(source_data, target_data)
+        self._loaders(source_data, target_data)                                              # :224-258
         self.udagcn = self.init_model(**self.kwargs)
         params = itertools.chain(*[m.parameters() for m in self.udagcn.models])            # :262-268
         # the shared conv Parameters are listed twice (encoder + ppmi_encoder), as in the reference; its CPU
@@ -103,7 +111,7 @@ class UDAGCN(BaseGDA):
             optimizer = Adam(list(params), lr=self.lr, weight_decay=self.weight_decay)
             # the step's per-epoch scalars (GRL alpha, entropy weight) reach the kernels as 0-dim device tensors
             # refreshed before every replay: the full-batch step replays as a hipGraph
-            self._graph_safe_step, self._graph_uses_scalars = True, True
+            self._graph_safe_step, self._graph_uses_scalars = self.mode == 'node', True
         else:
             optimizer = torch.optim.Adam(params, lr=self.lr, weight_decay=self.weight_decay, foreach=False)
 
@@ -127,5 +135,8 @@ class UDAGCN(BaseGDA):
         for m in self.udagcn.models:
             m.eval()
         loader, name = (self.source_loader, 'source') if source else (self.target_loader, 'target')
-        return self._predict_loader(
-            loader, lambda b: self.udagcn.cls_model(self.udagcn.encode(b, self._cache_key(b, name))))
+        def forward(b):                                                                       # :356-378
+            enc = self.udagcn.encode(b, self._cache_key(b, name))
+            return self.udagcn.cls_model(global_mean_pool(enc, b.batch) if self.mode == 'graph' else enc)
+
+        return self._predict_loader(loader, forward)

@@ -1,6 +1,7 @@
 """torch.autograd wrappers over the C ABI (include/gda_hip.h).  PyTorch supplies device
 memory, the stream and autograd plumbing; every numeric kernel named here is ours."""
 import ctypes
+import weakref
 
 import os as _os
 
@@ -34,8 +35,10 @@ class _SoftmaxNLL(torch.autograd.Function):
                                                 _lib.ptr(stats), _lib.ptr(ws), ws.numel(), _lib.stream()),
                    "gda_softmax_nll_fwd_ex_f32")
         global _ce_stats
-        _ce_stats = (logits, labels, n, stats)       # the tensors themselves are held: while the entry lives their
-                                                     # storage cannot be handed to another tensor
+        # weak references + version counters: the entry pins neither the [rows, C] logits nor the labels of a sampled
+        # batch (the eager loop never looks it up), and a tensor that died -- whose storage may since have been handed
+        # to another one -- or was written to can never match
+        _ce_stats = (weakref.ref(logits), weakref.ref(labels), n, stats, logits._version, labels._version)
         ctx.save_for_backward(x, labels)
         return loss.reshape(())
 
@@ -59,8 +62,12 @@ def ce_stats_for(logits, labels):
     micro-F1) ride on the loss kernel instead of an argmax / compare / sum / cast / stack chain."""
     global _ce_stats
     hit, _ce_stats = _ce_stats, None              # consumed by the first look-up: a later loss computed some other
-    if (hit is not None and hit[2] == logits.size(0) and hit[0].shape == logits.shape       # way never sees it
-            and hit[0].data_ptr() == logits.data_ptr() and hit[1].data_ptr() == labels.data_ptr()):
+    if hit is None:                                                                         # way never sees it
+        return None
+    lg, lb = hit[0](), hit[1]()
+    if (lg is not None and lb is not None and hit[2] == logits.size(0) and lg.shape == logits.shape
+            and lg.data_ptr() == logits.data_ptr() and lb.data_ptr() == labels.data_ptr()
+            and lg._version == hit[4] and lb._version == hit[5]):
         return hit[3]
     return None
 
@@ -102,8 +109,8 @@ TALL_ROWS = int(_os.environ.get("PYGDA_AMD_TALL_GEMM_ROWS", "32768"))    # node 
 def _tall_shape(mode, M, N, K, a, b):
     """The envelope of gda_gemm_tall_f32 (csrc/gda_gemm.hip): sampled sub-graphs (10^5 rows and more) against a weight
     whose extents are 128 or 256."""
-    if mode == GEMM_TN:          # gW = gy^T x: `a` = gy [rows, 128], reduction over the rows
-        return M == 128 and N in (128, 256) and K >= TALL_ROWS
+    if mode == GEMM_TN:          # gW = gy^T x: `a` = gy [rows, 128], reduction over the rows; 16-byte row loads of both
+        return (M == 128 and N in (128, 256) and K >= TALL_ROWS and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
     return M >= TALL_ROWS and N in (128, 256) and K in (128, 256) and a.data_ptr() % 16 == 0
 
 
@@ -226,12 +233,20 @@ def _launch_kstep_interior(graph, x, K, bias, transposed, y):
                    "gda_spmm_csr_interior_kstep_f32")
 
 
+def _takes_interior_path(graph, x, bias, transposed, counts_as=None):
+    """The ONE predicate for "these K steps run on the interior-rows kernel" (it needs no ping-pong buffer):
+    used by the launcher and by every caller that decides whether to allocate one."""
+    return bool(INTERIOR_KSTEP and counts_as is None and graph.n_interior is not None
+                and 2 * graph.n_interior <= x.size(0) and x.is_contiguous() and (bias is None or not transposed))
+
+
 def _launch_kstep(graph, x, K, bias, transposed, y, tmp, counts_as=None):
     """``counts_as = (graph, steps)``: what the launches stand for in the edges-aggregated bookkeeping
     (a launch of the cached A*A counts as two aggregations over the edges of A, not over its own)."""
-    if (INTERIOR_KSTEP and counts_as is None and graph.n_interior is not None and 2 * graph.n_interior <= x.size(0)
-            and x.is_contiguous() and (bias is None or not transposed)):
+    if _takes_interior_path(graph, x, bias, transposed, counts_as):
         return _launch_kstep_interior(graph, x, K, bias, transposed, y)
+    if tmp is None and K > 1:          # a caller that expected the interior path (which needs no ping-pong buffer)
+        tmp = torch.empty_like(x)
     rp, ci, va = (graph.t_rowptr, graph.t_colidx, graph.t_val) if transposed else \
                  (graph.rowptr, graph.colidx, graph.val)
     n, d = x.shape
@@ -324,7 +339,7 @@ def spmm_kstep(graph: CSRGraph, x, K=1, bias=None, transposed=False):
             _launch_kstep_lds(graph, hit[0], hit[1], x, K, b, transposed, y)
             return y
     if sq is None:
-        interior = INTERIOR_KSTEP and graph.n_interior is not None and 2 * graph.n_interior <= x.size(0)
+        interior = _takes_interior_path(graph, x, b, transposed)
         _launch_kstep(graph, x, K, b, transposed, y, torch.empty_like(x) if K > 1 and not interior else None)
         return y
     pairs, single = K // 2, K % 2

@@ -37,6 +37,8 @@ boundary" (the MMD / GradReverse / Attention goldens do not go through it).
     order, ``edge_index`` concatenated with every graph's node ids shifted by the nodes before it, ``batch`` =
     graph index per node, ``num_graphs``.  ``global_mean_pool(x, batch)`` = per-graph sum (index_add in node
     order) divided by the node count (clamped at 1).
+12. (graph mode of grade.py / dane.py only) ``len(batch)`` of a collated ``Batch`` = its number of graphs (PyG's
+    ``Batch.__len__`` returns ``num_graphs``): grade.py:174,180 size the domain labels / the MMD rows by it.
 10. (reweight_gnn.py / strurw.py only) ``MessagePassing(aggr='mean', flow='target_to_source')``:
     messages from ``x[edge_index[1]]`` averaged at ``edge_index[0]`` over the number of messages;
     ``update`` receives the propagate kwargs it names; ``to_dense_adj`` sums duplicate edges;
@@ -340,11 +342,18 @@ class NeighborLoader:
         return 1
 
 
+class Batch(Data):
+    """A collated batch: ``len()`` = number of graphs (assumption 12)."""
+
+    def __len__(self):
+        return self.num_graphs
+
+
 def collate_graphs(graphs):
     """PyG ``Batch.from_data_list`` for the attributes pygda's graph mode reads (assumption 11)."""
     counts = torch.tensor([g.x.size(0) for g in graphs], dtype=torch.long)
     offs = torch.cumsum(counts, 0) - counts
-    b = Data(x=torch.cat([g.x for g in graphs], dim=0),
+    b = Batch(x=torch.cat([g.x for g in graphs], dim=0),
              edge_index=torch.cat([g.edge_index + o for g, o in zip(graphs, offs.tolist())], dim=1),
              y=torch.cat([g.y.reshape(-1) for g in graphs], dim=0))
     b.batch = torch.repeat_interleave(torch.arange(len(graphs)), counts)

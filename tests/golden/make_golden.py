@@ -840,6 +840,118 @@ def fx_a2gnn_graph(ref):
 FIXTURES["a2gnn_graph"] = fx_a2gnn_graph
 
 
+def fx_graph_trainers(ref):
+    """``mode='graph'`` of the other trainers on the path: GRADE (grade.py:244-252, grade_base.py:154-157:
+    every layer's output mean-pooled per graph; JS and MMD), UDAGCN without the PPMI view (udagcn.py:168-170, 248-256,
+    360-377), AdaGCN (adagcn.py:244-252, adagcn_base.py:93-94) and DANE (dane.py:171-176, 219-229, 323-331, 448-456,
+    492-493).  Per trainer: one ``forward_model`` on the collated datasets, and 3-epoch ``fit()`` runs with one batch
+    per domain and with mini-batches of six graphs (DataLoader(shuffle=True): the shuffles' draws sit between the
+    trainers' own CPU-generator draws); ``predict()`` for the one-batch run (with several batches the reference keeps
+    only the last one).  Every Dropout constructed during the run has p = 0.
+
+    UDAGCN: ``CachedGCNConv`` never invalidates its per-name adjacency cache (cached_gcn_conv.py:132-136), so in graph
+    mode every batch after the first would be aggregated over the FIRST batch's edges (other graphs; an index error
+    when the node counts differ).  The recording empties the cache entry before every conv call -- the behaviour the
+    product implements (pygda_amd/models/udagcn.py) and documents as a deviation."""
+    import torch.nn as nn
+    stub = _pyg_stub
+    src, tgt = _graph_dataset(171, 13), _graph_dataset(172, 10)
+    base = dict(_dataset_arrays("src", src), **_dataset_arrays("tgt", tgt))
+    import pygda.nn.cached_gcn_conv as ccmod
+    import pygda.models.grade as gmod
+    import pygda.models.udagcn as umod
+    import pygda.models.adagcn as amod
+    import pygda.models.dane as dmod
+    orig_init = nn.Dropout.__init__
+    orig_fwd = ccmod.CachedGCNConv.forward
+
+    def fwd_uncached(self, x, edge_index, cache_name="default_cache", edge_weight=None):
+        self.cache_dict.pop(cache_name, None)
+        return orig_fwd(self, x, edge_index, cache_name, edge_weight)
+
+    nn.Dropout.__init__ = lambda self, p=0.5, inplace=False: orig_init(self, 0.0, inplace)
+    ccmod.CachedGCNConv.forward = fwd_uncached
+    makers = {
+        "grade_js": (gmod, lambda **k: ref.GRADE(10, 8, 3, mode='graph', num_layers=2, dropout=0.0, disc="JS", weight=0.5,
+                                                 lr=0.01, weight_decay=0.001, device="cpu", epoch=3, verbose=0, **k), "grade"),
+        "grade_mmd": (gmod, lambda **k: ref.GRADE(10, 8, 3, mode='graph', num_layers=2, dropout=0.0, disc="MMD", weight=0.5,
+                                                  lr=0.01, weight_decay=0.001, device="cpu", epoch=3, verbose=0, **k), "grade"),
+        "udagcn": (umod, lambda **k: ref.UDAGCN(10, 8, 3, mode='graph', num_layers=2, ppmi=False, adv_dim=6, lr=0.01,
+                                                weight_decay=0.003, device="cpu", epoch=3, verbose=0, **k), "udagcn"),
+        "adagcn": (amod, lambda **k: ref.AdaGCN(10, 8, 3, mode='graph', num_layers=2, adv_dim=6, gp_weight=5,
+                                                domain_weight=1, lr=0.01, weight_decay=0.001, device="cpu", epoch=3,
+                                                verbose=0, **k), "adagcn"),
+        "dane": (dmod, lambda **k: ref.DANE(10, 8, 3, num_layers=2, mode='graph', dropout=0.0, gnn="gcn", k=5, lr=0.01,
+                                            weight_decay=1e-5, device="cpu", epoch=3, verbose=0, **k), "gnn"),
+    }
+    try:
+        arrs = dict(base)
+        for tag, (mod, make, attr) in makers.items():
+            # ---- one forward_model on the collated datasets
+            m = make()
+            torch.manual_seed(181)
+            net = m.init_model()
+            setattr(m, attr, net)
+            sb, tb = stub.collate_graphs(src), stub.collate_graphs(tgt)
+            arrs.update(sd_arrays(net, f"{tag}/param/"))
+            if tag == "adagcn":
+                m.discriminator = nn.Sequential(nn.Linear(8, 6), nn.ReLU(), nn.Dropout(0.1), nn.Linear(6, 1), nn.Sigmoid())
+                arrs.update(sd_arrays(m.discriminator, f"{tag}/disc0/"))
+                m.c_optimizer = torch.optim.Adam(m.discriminator.parameters(), lr=0.01, weight_decay=0.001)
+            if tag == "dane":
+                m.domain_discriminator = nn.Sequential(nn.Linear(8, 8), nn.ReLU(), nn.Linear(8, 1))
+                m.sample_size = min(len(src), len(tgt))
+                arrs.update(sd_arrays(m.domain_discriminator, f"{tag}/disc0/"))
+                m.g_optimizer = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=1e-5)
+                m.d_optimizer = torch.optim.Adam(m.domain_discriminator.parameters(), lr=0.01, weight_decay=1e-5)
+            net.train()
+            for sub_ in getattr(net, "models", []):
+                sub_.train()
+            torch.manual_seed(182)
+            if tag.startswith("grade"):
+                loss, sl, tl = m.forward_model(sb, tb, 0.4)
+            elif tag == "udagcn":
+                loss, sl, tl = m.forward_model(sb, tb, 0.05, 2)
+            else:
+                loss, sl, tl = m.forward_model(sb, tb)
+            if tag == "dane":          # forward_model already stepped both optimisers; the loss is a float
+                arrs.update(sd_arrays(net, f"{tag}/param1/")); arrs.update(sd_arrays(m.domain_discriminator, f"{tag}/disc1/"))
+                arrs[f"{tag}/loss"] = np.float64(loss)
+            else:
+                net.zero_grad()
+                loss.backward()
+                arrs.update(grads(net, f"{tag}/grad/"))
+                arrs[f"{tag}/loss"] = np_(loss)
+                if tag == "adagcn":
+                    arrs.update(sd_arrays(m.discriminator, f"{tag}/disc10/"))
+            arrs[f"{tag}/src_logits"], arrs[f"{tag}/tgt_logits"] = np_(sl), np_(tl)
+            # ---- 3-epoch fit(): one batch per domain, and mini-batches of six graphs
+            for batch_size in (0, 6):
+                losses, accs = [], []
+                orig = mod.logger
+                mod.logger = lambda **kw_: (losses.append(float(kw_["loss"])), accs.append(kw_["source_train_acc"]))
+                try:
+                    m = make(batch_size=batch_size)
+                    torch.manual_seed(183)
+                    m.fit(src, tgt)
+                    if batch_size == 0:
+                        logits, labels = m.predict(tgt)
+                        arrs[f"{tag}/fit0/tgt_logits"], arrs[f"{tag}/fit0/tgt_labels"] = np_(logits), np_(labels)
+                finally:
+                    mod.logger = orig
+                arrs[f"{tag}/fit{batch_size}/losses"] = np.array(losses, dtype=np.float64)
+                arrs[f"{tag}/fit{batch_size}/accs"] = np.array(accs, dtype=np.float64)
+                arrs.update(sd_arrays(getattr(m, attr), f"{tag}/fit{batch_size}/final/"))
+        arrs.update(init_seed=np.int64(181), draw_seed=np.int64(182), fit_seed=np.int64(183))
+        save("graph_trainers", **arrs)
+    finally:
+        nn.Dropout.__init__ = orig_init
+        ccmod.CachedGCNConv.forward = orig_fwd
+
+
+FIXTURES["graph_trainers"] = fx_graph_trainers
+
+
 def main(argv):
     ref = load_reference()
     for name in (argv or list(FIXTURES)):

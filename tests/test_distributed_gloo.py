@@ -135,6 +135,34 @@ def test_two_rank_a2gnn_step_equals_concatenated_batch(adv):
         assert torch.allclose(results[0]["grads"][k], g, rtol=1e-4, atol=1e-6), (k, (results[0]["grads"][k] - g).abs().max())
 
 
+@pytest.mark.parametrize("kind", ["udagcn", "adagcn"])
+def test_two_rank_udagcn_adagcn_step_equals_concatenated_batch(kind):
+    """BASELINE.json configs[3] shards UDAGCN / AdaGCN mini-batches over ranks.  UDAGCN (udagcn.py:165-199): source CE,
+    two gradient-reversed domain CEs and the entropy term are four means over sub-graphs of different sizes; AdaGCN
+    (adagcn.py:169-198, 387-454): ten critic updates -- Wasserstein gap of two global means + gradient penalty as a
+    mean over every rank's rows, critic gradients averaged before each Adam step -- then CE + |gap|.  Two ranks ==
+    one process on the union batch: loss, every encoder gradient, and for AdaGCN the critic after its ten steps."""
+    from tests import dp_equality as E
+    results = E.run_ranks(2, "cpu", kind, oracle=True)
+    for k, v in results[0]["state"].items():
+        assert torch.equal(v, results[1]["state"][k]), k
+    assert results[0]["grads"] and set(results[0]["grads"]) == set(results[1]["grads"])
+    for k, v in results[0]["grads"].items():
+        assert torch.equal(v, results[1]["grads"][k]), k
+    ref_loss, ref_grads, (ns, nt, extra) = E.concatenated_reference(results, "cpu", kind, oracle=True)
+    assert ns[0] != ns[1] or nt[0] != nt[1]                        # the count weighting is exercised
+    for r in results:
+        assert abs(r["loss"] - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (r["loss"], ref_loss)
+    assert set(ref_grads) == set(results[0]["grads"])
+    for k, g in ref_grads.items():
+        assert torch.allclose(results[0]["grads"][k], g, rtol=1e-4, atol=1e-6), (k, (results[0]["grads"][k] - g).abs().max())
+    if kind == "adagcn":
+        for k, v in extra["disc10"].items():                       # replica critics identical, and equal to the union's
+            assert torch.equal(results[0]["disc10"][k], results[1]["disc10"][k]), k
+            assert not torch.equal(results[0]["disc10"][k], results[0]["disc0"][k]), k      # it did train
+            assert torch.allclose(results[0]["disc10"][k], v, rtol=1e-4, atol=1e-5), (k, (results[0]["disc10"][k] - v).abs().max())
+
+
 # ---- bench.py's launcher: `--gpus N` must mean N ranks, or an error ------------------------------------------
 def _bench(*argv, env_extra=None, timeout=300):
     import subprocess

@@ -193,6 +193,34 @@ def test_two_rank_a2gnn_step_equals_concatenated_batch_gpu(adv):
         close(results[0]["grads"][k], gr, rtol=1e-3, atol=1e-4 * scale)
 
 
+@pytest.mark.parametrize("kind", ["udagcn", "adagcn"])
+def test_two_rank_udagcn_adagcn_step_equals_concatenated_batch_gpu(kind):
+    """configs[3] (UDAGCN / AdaGCN sharded over ranks), the exchange step on the HIP kernels: two processes on this
+    GPU over gloo -- UDAGCN's fused GRL + two-layer discriminator kernel handing back per-domain means that are
+    weighted by node counts, AdaGCN's critic loop with its global means and averaged critic gradients -- against one
+    process on the union batch (pygda/models/udagcn.py:165-199, adagcn.py:169-198, 387-454)."""
+    from tests import dp_equality as E
+    results = E.run_ranks(2, DEV, kind, oracle=False)
+    for k, v in results[0]["state"].items():
+        assert torch.equal(v, results[1]["state"][k]), k
+    assert results[0]["grads"] and set(results[0]["grads"]) == set(results[1]["grads"])
+    for k, v in results[0]["grads"].items():
+        assert torch.equal(v, results[1]["grads"][k]), k
+    ref_loss, ref_grads, (ns, nt, extra) = E.concatenated_reference(results, DEV, kind, oracle=False)
+    assert ns[0] != ns[1] or nt[0] != nt[1]
+    for r in results:
+        assert abs(r["loss"] - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss)), (r["loss"], ref_loss)
+    assert set(ref_grads) == set(results[0]["grads"])
+    for k, gr in ref_grads.items():
+        scale = max(float(gr.abs().max()), 1e-3)
+        close(results[0]["grads"][k], gr, rtol=1e-3, atol=1e-4 * scale)
+    if kind == "adagcn":
+        for k, v in extra["disc10"].items():
+            assert torch.equal(results[0]["disc10"][k], results[1]["disc10"][k]), k
+            assert not torch.equal(results[0]["disc10"][k], results[0]["disc0"][k]), k
+            close(results[0]["disc10"][k], v, rtol=1e-3, atol=1e-4)
+
+
 def test_bench_two_rank_path_end_to_end_on_one_gpu():
     """`bench.py --gpus 2` as the driver launches it, except that the two ranks share this GPU over gloo
     (`--share-gpus`): the launcher, seed shards per rank on the device sampler, the all-gathered MMD rows and the

@@ -41,6 +41,33 @@ def _rel_l2(a, b):
     return float((a - b).norm() / max(float(b.norm()), 1e-30))
 
 
+def _check_grads(net, ora, rel=1e-4):
+    """Every parameter gradient of the product against the oracle's: relative L2 per tensor, the element-wise bound of
+    tests/test_gpu_parity.py, and sign agreement of every entry that is not noise-sized (a sign error in a small
+    gradient hides in an absolute bound).  Returns the number of tensors compared."""
+    named = dict(ora.named_parameters())
+    checked = 0
+    top = max(float(q.grad.abs().max()) for q in named.values() if q.grad is not None)
+    for k, p in net.named_parameters():
+        v = named[k].grad
+        if v is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        if float(v.abs().max()) <= 1e-7 * top:
+            # a gradient that is zero in exact arithmetic (the bias of UDAGCN's view attention: softmax over the views
+            # ignores a shift common to both) is rounding residue on both sides, ~1e-11 here: nothing to compare
+            assert float(p.grad.abs().max()) <= 1e-6 * top, k
+            checked += 1
+            continue
+        assert _rel_l2(p.grad, v) <= rel, (k, _rel_l2(p.grad, v))
+        close(p.grad, v, rtol=1e-3, atol=1e-4 * max(float(v.abs().max()), 1e-3))
+        big = v.abs() > 1e-3 * float(v.abs().max())
+        assert bool((torch.sign(p.grad.detach().cpu()[big]) == torch.sign(v[big])).all()), k
+        checked += 1
+    return checked
+
+
 def _model(feat, dropout=0.0, epoch=3, **kw):
     return pygda_amd.models.A2GNN(feat, 128, 5, dropout=dropout, device=DEV, epoch=epoch, verbose=0, **HP, **kw)
 
@@ -71,22 +98,7 @@ def test_cfg_a_full_size_training_step_vs_oracle(graph):
     close(tl, wtl, rtol=0, atol=LOGIT_ATOL)
     exact(sl.argmax(1), wsl.argmax(1))
     exact(tl.argmax(1), wtl.argmax(1))
-    named = dict(ora.named_parameters())
-    checked = 0
-    for k, p in m.a2gnn.named_parameters():
-        v = named[k].grad
-        if v is None:
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
-            continue
-        assert p.grad is not None, k
-        assert _rel_l2(p.grad, v) <= 1e-4, (k, _rel_l2(p.grad, v))
-        close(p.grad, v, rtol=1e-3, atol=1e-4 * max(float(v.abs().max()), 1e-3))
-        # a sign error in a small-magnitude gradient hides in an absolute bound: the signs of every entry that is
-        # not noise-sized must agree
-        big = v.abs() > 1e-3 * float(v.abs().max())
-        assert bool((torch.sign(p.grad.detach().cpu()[big]) == torch.sign(v[big])).all()), k
-        checked += 1
-    assert checked >= 6                # 3 convs x (weight, bias)
+    assert _check_grads(m.a2gnn, ora) >= 6                # 3 convs x (weight, bias)
 
 
 def _fit(src, tgt, use_hip_graph, seed=5):
@@ -173,3 +185,152 @@ def test_cfg_s_full_size_aggregation_properties():
     # the symmetric graph's normalised operator is symmetric: forward and transposed CSR give the same product
     z = torch.randn(n, 8, generator=gen, device=DEV)
     close(ops.spmm_kstep(G, z, 1), ops.spmm_kstep(G, z, 1, None, transposed=True), rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[3]: UDAGCN / AdaGCN, ACMv9 -> Citationv1 (benchmark/node/run_citation.sh:109-110: nhid 128, num_layers 2;
+# UDAGCN lr 1e-4, weight_decay 1e-3, 400 epochs; AdaGCN lr 0.01, weight_decay 0.01, 400 epochs) at the datasets' own
+# sizes (Ns = 9,360 / Es = 15,556, Nt = 8,935 / Et = 15,098 undirected pairs, F = 6,775), dropout 0, one training step
+# against the oracle: loss 1e-4 relative, logits 1e-4 absolute, labels identical, every parameter gradient.
+# ---------------------------------------------------------------------------------------------------------------------
+def _cfg_c():
+    from bench import make_cfg_a
+    return make_cfg_a(seed=203, ns=9360, es=15556, nt=8935, et=15098)
+
+
+def _no_dropout(*modules):
+    for module in modules:
+        for m in module.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+            for d in getattr(m, "dropout_layers", []):     # UDAGCN keeps its Dropout(0.1) modules in a plain list
+                d.p = 0.0
+
+
+@pytest.mark.parametrize("ppmi", [False, True])
+def test_udagcn_full_size_step_vs_oracle(ppmi, monkeypatch):
+    """pygda/models/udagcn.py:131-201 at the size of configs[3].  With the PPMI view the random-walk graphs are the
+    ones the DEVICE builder produced in this very forward pass (the reference's np.random walk stream cannot be
+    replayed): their RAW weighted edge lists are recorded on the way and handed to the oracle, which adds the self
+    loops and applies the source-degree normalisation itself (ppmi_conv.py:171-184, float64) -- so the ingestion of
+    the PPMI graph, both aggregation stacks on shared weights, the attention fusion, the fused GRL + two-layer
+    discriminator + CE kernels and the entropy term are all on the checked path."""
+    src, tgt = _cfg_c()
+    feat = src.x.size(1)
+    m = pygda_amd.models.UDAGCN(feat, 128, 5, num_layers=2, ppmi=ppmi, adv_dim=40, lr=1e-4, weight_decay=1e-3,
+                                epoch=400, device=DEV, verbose=0, use_hip_graph=False)
+    recorded = []
+    if ppmi:
+        import pygda_amd.nn.ppmi_conv as PC
+        real = PC.ppmi_edges
+
+        def spy(edge_index, num_nodes, path_len=5, **kw):
+            ei, w = real(edge_index, num_nodes, path_len, **kw)
+            recorded.append((ei.detach().cpu(), w.detach().cpu(), int(path_len)))
+            return ei, w
+        monkeypatch.setattr(PC, "ppmi_edges", spy)
+    torch.manual_seed(11); np.random.seed(11)
+    m.udagcn = m.init_model()
+    _no_dropout(m.udagcn)
+    for mod in m.udagcn.models:
+        mod.train()
+    ora = O.UDAGCNBase(feat, 128, 5, num_layers=2, ppmi=ppmi, adv_dim=40, dropout_p=0.0)
+    ora.load_state_dict({k: v.detach().cpu() for k, v in m.udagcn.state_dict().items()})
+    ora.train()
+    alpha, epoch = 0.05, 37                       # the schedule's value from epoch 19 on (udagcn.py: min((e+1)/epochs, 0.05))
+    loss, sl, tl = m.forward_model(src.to(DEV), tgt.to(DEV), alpha, epoch)
+    loss.backward()
+    if ppmi:
+        # call order of the product's forward: source layers 0..L-1, then target layers 0..L-1 (each PPMIConv walks
+        # its own graph, ppmi_conv.py:132-136 caches per layer)
+        assert len(recorded) == 4 and all(r[2] == 10 for r in recorded)
+        it = iter(recorded)
+        for name, n in (("source", src.num_nodes), ("target", tgt.num_nodes)):
+            for conv in ora.ppmi_encoder.conv_layers:
+                ei, w, _ = next(it)
+                assert ei.size(1) > 4 * n                 # a real random-walk graph, not a degenerate one
+                ei2, w2 = O.add_remaining_self_loops(ei, w.double(), 1, n)
+                row, col = ei2
+                deg = torch.zeros(n, dtype=torch.float64).index_add_(0, row, w2)
+                dis = deg.pow(-0.5)
+                dis[dis == float("inf")] = 0
+                conv.cache_dict[name] = (ei2, (dis[row] * w2 * dis[col]).float())
+    want, wsl, wtl = O.udagcn_forward_model(ora, O.Graph(src.x, src.edge_index, src.y),
+                                            O.Graph(tgt.x, tgt.edge_index, tgt.y), alpha, epoch, 400)
+    want.backward()
+    close(loss, want, rtol=REL)
+    close(sl, wsl, rtol=0, atol=LOGIT_ATOL)
+    close(tl, wtl, rtol=0, atol=LOGIT_ATOL)
+    exact(sl.argmax(1), wsl.argmax(1))
+    exact(tl.argmax(1), wtl.argmax(1))
+    # encoder convs (shared by both views) 2 x (weight, bias), classifier 2, discriminator 4 (+ attention 2 with ppmi)
+    assert _check_grads(m.udagcn, ora) >= (12 if ppmi else 10)
+
+
+def test_adagcn_full_size_step_vs_oracle():
+    """pygda/models/adagcn.py:138-198, 387-454 at the size of configs[3], in the two stages the step consists of.
+
+    (1) The whole ``forward_model``: ten critic updates (Wasserstein gap + gradient penalty on CPU-generator
+    interpolation weights, Adam on the critic), then the encoder loss.  Loss and logits hold the 1e-4 bounds.  The
+    critic after ten Adam steps is compared at relative L2 1e-3 and the encoder gradients of this stage at 5e-3:
+    Adam's first steps move every weight by ~lr * sign(gradient), so entries whose gradient is summation-order noise
+    end up to 2 lr apart between ANY two fp32 evaluations (measured on the first run of this test: critic within 1e-3,
+    the encoder gradient -- linear in the critic's weights through |E D(s) - E D(t)| -- 1.3e-3 apart on the layer-0
+    bias while every tensor of the critic-free UDAGCN step above held 1e-4).
+    (2) The encoder objective GIVEN the critic: the oracle's ten-step critic is loaded into the product's and both
+    evaluate the encoder loss with no further critic update (``critic_steps = 0``): loss, logits, labels and every
+    parameter gradient at the 1e-4 bounds of this file."""
+    src, tgt = _cfg_c()
+    feat = src.x.size(1)
+    m = pygda_amd.models.AdaGCN(feat, 128, 5, num_layers=2, adv_dim=40, gp_weight=5, domain_weight=1, lr=0.01,
+                                weight_decay=0.01, epoch=400, device=DEV, verbose=0, use_hip_graph=False)
+    torch.manual_seed(11)
+    net, _, _, _ = m._prepare(src, tgt)            # loaders, encoder, the critic and its optimiser (adagcn.py:254-275)
+    _no_dropout(net, m.discriminator)
+    net.train(); m.discriminator.train()
+    ora = O.AdaGCNBase(feat, 128, 5, num_layers=2, dropout_p=0.0)
+    ora.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    ora.train()
+    odisc = torch.nn.Sequential(torch.nn.Linear(128, 40), torch.nn.ReLU(), torch.nn.Dropout(0.0),
+                                torch.nn.Linear(40, 1), torch.nn.Sigmoid())
+    odisc.load_state_dict({k: v.detach().cpu() for k, v in m.discriminator.state_dict().items()})
+    c_opt = torch.optim.Adam(odisc.parameters(), lr=0.01, weight_decay=0.01)
+    (s,), (t,) = list(m.source_loader), list(m.target_loader)
+    s, t = s.to(DEV), t.to(DEV)
+    Gs, Gt = O.Graph(src.x, src.edge_index, src.y), O.Graph(tgt.x, tgt.edge_index, tgt.y)
+    # ---- stage 1: the whole step
+    torch.manual_seed(77)                          # the interpolation weights of the ten gradient penalties
+    loss, sl, tl = m.forward_model(s, t)
+    net.zero_grad()
+    loss.backward()
+    torch.manual_seed(77)
+    want, wsl, wtl = O.adagcn_forward_model(ora, odisc, c_opt, Gs, Gt, 5, 1, 10)
+    ora.zero_grad()
+    want.backward()
+    before = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    for k, v in odisc.state_dict().items():
+        got = m.discriminator.state_dict()[k]
+        assert _rel_l2(got, v) <= 1e-3, (k, _rel_l2(got, v))
+    close(loss, want, rtol=REL)
+    close(sl, wsl, rtol=0, atol=LOGIT_ATOL)
+    close(tl, wtl, rtol=0, atol=LOGIT_ATOL)
+    exact(sl.argmax(1), wsl.argmax(1))
+    exact(tl.argmax(1), wtl.argmax(1))
+    assert _check_grads(net, ora, rel=5e-3) >= 6   # 2 convs x (weight, bias) + classifier
+    for k, v in net.state_dict().items():          # forward_model trains the critic only
+        exact(v, before[k])
+    # ---- stage 2: the encoder objective given the (oracle's) critic
+    m.discriminator.load_state_dict({k: v.to(DEV) for k, v in odisc.state_dict().items()})
+    m.critic_steps = 0
+    loss, sl, tl = m.forward_model(s, t)
+    net.zero_grad()
+    loss.backward()
+    want, wsl, wtl = O.adagcn_forward_model(ora, odisc, c_opt, Gs, Gt, 5, 1, 0)
+    ora.zero_grad()
+    want.backward()
+    close(loss, want, rtol=REL)
+    close(sl, wsl, rtol=0, atol=LOGIT_ATOL)
+    close(tl, wtl, rtol=0, atol=LOGIT_ATOL)
+    exact(sl.argmax(1), wsl.argmax(1))
+    exact(tl.argmax(1), wtl.argmax(1))
+    assert _check_grads(net, ora) >= 6

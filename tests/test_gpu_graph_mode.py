@@ -110,3 +110,111 @@ def test_a2gnn_graph_mode_fit_predict_golden(batch_size):
         close(logits, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
         exact(labels, g["tgt_labels"])
         exact(logits.argmax(1), g["tgt_logits"].argmax(1))
+
+
+# ---- mode='graph' of GRADE / UDAGCN / AdaGCN / DANE (tests/golden/graph_trainers.npz) ------------------
+def _gt_trainer(tag, **kw):
+    M = pygda_amd.models
+    common = dict(device=DEV, epoch=3, verbose=0, **kw)
+    if tag == "grade_js":
+        return M.GRADE(10, 8, 3, mode='graph', num_layers=2, dropout=0.0, disc="JS", weight=0.5, lr=0.01,
+                       weight_decay=0.001, **common), "grade"
+    if tag == "grade_mmd":
+        return M.GRADE(10, 8, 3, mode='graph', num_layers=2, dropout=0.0, disc="MMD", weight=0.5, lr=0.01,
+                       weight_decay=0.001, **common), "grade"
+    if tag == "udagcn":
+        return M.UDAGCN(10, 8, 3, mode='graph', num_layers=2, ppmi=False, adv_dim=6, lr=0.01, weight_decay=0.003,
+                        **common), "udagcn"
+    if tag == "adagcn":
+        return M.AdaGCN(10, 8, 3, mode='graph', num_layers=2, adv_dim=6, gp_weight=5, domain_weight=1, lr=0.01,
+                        weight_decay=0.001, **common), "adagcn"
+    return M.DANE(10, 8, 3, num_layers=2, mode='graph', dropout=0.0, gnn="gcn", k=5, lr=0.01, weight_decay=1e-5,
+                  **common), "gnn"
+
+
+def _zero_dropouts(monkeypatch):
+    import torch.nn as nn
+    orig = nn.Dropout.__init__
+    monkeypatch.setattr(nn.Dropout, "__init__", lambda self, p=0.5, inplace=False: orig(self, 0.0, inplace))
+
+
+@pytest.mark.parametrize("tag", ["grade_js", "grade_mmd", "udagcn", "adagcn", "dane"])
+def test_graph_mode_forward_model_golden(monkeypatch, tag):
+    """One ``forward_model`` on the collated datasets against the reference's own files run in graph mode (grade.py,
+    grade_base.py:150-157; udagcn.py:168-170; adagcn.py + adagcn_base.py:93-94; dane.py:171-176, 323-331, 448-456,
+    492-493): loss, logits, every gradient; for AdaGCN / DANE the critic / discriminator (and DANE's encoder) after
+    their own Adam steps."""
+    import torch.nn as nn
+    _zero_dropouts(monkeypatch)
+    g = load_golden("graph_trainers")
+    sb, tb = collate_graphs(_dataset(g, "src")).to(DEV), collate_graphs(_dataset(g, "tgt")).to(DEV)
+    m, attr = _gt_trainer(tag)
+    torch.manual_seed(int(g["init_seed"]))
+    net = m.init_model()
+    setattr(m, attr, net)
+    for k, v in sub(g, f"{tag}/param/").items():
+        exact(net.state_dict()[k], v)
+    net.train()
+    for mod in getattr(net, "models", []):
+        mod.train()
+    if tag == "adagcn":
+        m.discriminator = nn.Sequential(nn.Linear(8, 6), nn.ReLU(), nn.Dropout(0.1), nn.Linear(6, 1), nn.Sigmoid()).to(DEV)
+        m.discriminator.load_state_dict({k: T(v) for k, v in sub(g, f"{tag}/disc0/").items()})
+        m.c_optimizer = torch.optim.Adam(m.discriminator.parameters(), lr=0.01, weight_decay=0.001)
+    if tag == "dane":
+        m.domain_discriminator = nn.Sequential(nn.Linear(8, 8), nn.ReLU(), nn.Linear(8, 1)).to(DEV)
+        m.domain_discriminator.load_state_dict({k: T(v) for k, v in sub(g, f"{tag}/disc0/").items()})
+        m.sample_size = min(int(g["src/count"]), int(g["tgt/count"]))
+        m.g_optimizer = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=1e-5)
+        m.d_optimizer = torch.optim.Adam(m.domain_discriminator.parameters(), lr=0.01, weight_decay=1e-5)
+    torch.manual_seed(int(g["draw_seed"]))
+    if tag.startswith("grade"):
+        loss, sl, tl = m.forward_model(sb, tb, 0.4)
+    elif tag == "udagcn":
+        loss, sl, tl = m.forward_model(sb, tb, 0.05, 2)
+    else:
+        loss, sl, tl = m.forward_model(sb, tb)
+    assert sl.shape == (int(g["src/count"]), 3) and tl.shape == (int(g["tgt/count"]), 3)      # one row per graph
+    close(sl, g[f"{tag}/src_logits"], rtol=0, atol=LOGIT_ATOL); close(tl, g[f"{tag}/tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    close(float(loss), float(g[f"{tag}/loss"]), rtol=REL)
+    if tag == "dane":
+        for k, v in sub(g, f"{tag}/param1/").items():
+            close(net.state_dict()[k], v, rtol=1e-3, atol=2e-4)
+        for k, v in sub(g, f"{tag}/disc1/").items():
+            close(m.domain_discriminator.state_dict()[k], v, rtol=1e-3, atol=2e-4)
+        return
+    net.zero_grad()
+    loss.backward()
+    params = dict(net.named_parameters())
+    want = sub(g, f"{tag}/grad/")
+    assert want
+    for k, v in want.items():
+        close(params[k].grad, v, rtol=1e-3, atol=1e-4 * max(np.abs(v).max(), 1e-3))
+    if tag == "adagcn":
+        for k, v in sub(g, f"{tag}/disc10/").items():
+            close(m.discriminator.state_dict()[k], v, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("batch_size", [0, 6])
+@pytest.mark.parametrize("tag", ["grade_js", "grade_mmd", "udagcn", "adagcn", "dane"])
+def test_graph_mode_fit_predict_golden(monkeypatch, tag, batch_size):
+    """fit() for three epochs from the reference's seed over shuffled DataLoader batches (one batch per domain, and
+    mini-batches of six graphs), then predict() for the one-batch run."""
+    _zero_dropouts(monkeypatch)
+    g = load_golden("graph_trainers")
+    src, tgt = _dataset(g, "src"), _dataset(g, "tgt")
+    m, attr = _gt_trainer(tag, batch_size=batch_size)
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append((float(loss), acc))
+    torch.manual_seed(int(g["fit_seed"]))
+    m.fit(src, tgt)
+    close([x[0] for x in seen], g[f"{tag}/fit{batch_size}/losses"], rtol=REL)
+    close([x[1] for x in seen], g[f"{tag}/fit{batch_size}/accs"], rtol=0, atol=1e-12)
+    net = getattr(m, attr)
+    for k, v in sub(g, f"{tag}/fit{batch_size}/final/").items():
+        close(net.state_dict()[k], v, rtol=1e-3, atol=2e-4)
+    if batch_size == 0:
+        logits, labels = m.predict(tgt)          # draws the loader's next shuffle, like the reference's predict()
+        close(logits, g[f"{tag}/fit0/tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+        exact(labels, g[f"{tag}/fit0/tgt_labels"])
+        exact(logits.argmax(1), g[f"{tag}/fit0/tgt_logits"].argmax(1))

@@ -330,6 +330,28 @@ def test_a2gnn_fit_predict_golden(adv):
     close(slogits, g["src_logits"], rtol=0, atol=LOGIT_ATOL)
 
 
+def test_a2gnn_fit_golden_as_three_graphs(monkeypatch):
+    """PYGDA_AMD_SPLIT_GRAPHS=1 (hipgraph.GraphedStepSplit: source forward | target forward | loss + backward + Adam as
+    three captures; opt-in) against the same 3-epoch golden -- the path had no test and its statistics
+    branch referred to an undefined name."""
+    monkeypatch.setenv("PYGDA_AMD_SPLIT_GRAPHS", "1")
+    g = load_golden("a2gnn_fit3_mmd")
+    s, t = _pair(g)
+    m = pygda_amd.models.A2GNN(24, 16, 5, num_layers=2, dropout=0.0, s_pnums=0, t_pnums=10, weight=10, lr=0.01,
+                               weight_decay=0.005, device=DEV, epoch=3, verbose=0, use_hip_graph=True)
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+    torch.manual_seed(int(g["seed"]))
+    m.fit(s, t)
+    from pygda_amd.hipgraph import GraphedStepSplit
+    assert isinstance(getattr(m, "_graphed", None), GraphedStepSplit), "the three-graph path did not run"
+    close([x[0] for x in seen], g["losses"], rtol=REL)
+    close([x[1] for x in seen], g["accs"], rtol=0, atol=1e-12)
+    logits, labels = m.predict(t)
+    close(logits, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    exact(logits.argmax(1), g["tgt_logits"].argmax(1))
+
+
 @pytest.mark.parametrize("disc", ["JS", "MMD"])
 def test_grade_forward_model_golden(disc):
     g = load_golden(f"grade_forward_{disc.lower()}")

@@ -719,3 +719,153 @@ def test_grade_and_adagcn_fit_trajectories():
     enc.eval()
     with torch.no_grad():
         eq(enc.cls_model(enc(tgt)), g["adagcn/tgt_logits"], tol=1e-5)
+
+
+# ---- mode='graph' of GRADE / UDAGCN / AdaGCN / DANE (tests/golden/graph_trainers.npz: the reference's own files in
+# ---- graph mode through the stub; UDAGCN recorded with its adjacency caches emptied before every conv call) ----------
+GT_KW = dict(grade_js=dict(disc="JS"), grade_mmd=dict(disc="MMD"))
+
+
+def _gt_make(tag):
+    """``(net, aux, forward)``: the oracle's network for ``tag`` as fit() builds it (init draws in the reference's
+    order), auxiliary critic / discriminator, and ``forward(src_batch, tgt_batch, epoch) -> (loss, source logits)``."""
+    if tag.startswith("grade"):
+        net = O.GRADEBase(10, 8, 3, num_layers=2, dropout=0.0, mode="graph", **GT_KW[tag])
+
+        def forward(sb, tb, epoch, epochs=3):
+            alpha = 2 / (1 + np.exp(-10 * epoch / epochs)) - 1                          # grade.py:260
+            loss, sl, _ = O.grade_forward_model(net, sb, tb, alpha, GT_KW[tag]["disc"], 0.5)
+            return loss, sl
+        return net, None, forward
+    if tag == "udagcn":
+        net = O.UDAGCNBase(10, 8, 3, num_layers=2, ppmi=False, adv_dim=6, dropout_p=0.0)
+
+        def forward(sb, tb, epoch, epochs=3):
+            alpha = min((epoch + 1) / epochs, 0.05)                                     # udagcn.py:277
+            loss, sl, _ = O.udagcn_forward_model(net, sb, tb, alpha, epoch, epochs, mode="graph")
+            return loss, sl
+        return net, None, forward
+    if tag == "adagcn":
+        net = O.AdaGCNBase(10, 8, 3, num_layers=2, dropout_p=0.0, mode="graph")
+        return net, None, None
+    net = O.GNNBase(10, 8, 3, num_layers=2, dropout=0.0, gnn="gcn", mode="graph")
+    return net, None, None
+
+
+@pytest.mark.parametrize("tag", ["grade_js", "grade_mmd", "udagcn", "adagcn", "dane"])
+def test_graph_mode_forward_model(tag):
+    g = load_golden("graph_trainers")
+    src, tgt = O.collate_graphs(_graph_dataset(g, "src")), O.collate_graphs(_graph_dataset(g, "tgt"))
+    torch.manual_seed(int(g["init_seed"]))
+    net, _, forward = _gt_make(tag)
+    for k, v in sub(g, f"{tag}/param/").items():
+        eq(net.state_dict()[k], v)
+    net.train()
+    if tag == "adagcn":
+        disc = torch.nn.Sequential(torch.nn.Linear(8, 6), torch.nn.ReLU(), torch.nn.Dropout(0.0), torch.nn.Linear(6, 1),
+                                   torch.nn.Sigmoid())
+        for k, v in sub(g, f"{tag}/disc0/").items():
+            eq(disc.state_dict()[k], v)
+        c_opt = torch.optim.Adam(disc.parameters(), lr=0.01, weight_decay=0.001)
+        torch.manual_seed(int(g["draw_seed"]))
+        loss, sl, tl = O.adagcn_forward_model(net, disc, c_opt, src, tgt, 5, 1)
+        net.zero_grad(); loss.backward()
+        for k, v in sub(g, f"{tag}/disc10/").items():
+            eq(disc.state_dict()[k], v)
+    elif tag == "dane":
+        disc = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))
+        for k, v in sub(g, f"{tag}/disc0/").items():
+            eq(disc.state_dict()[k], v)
+        g_opt = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=1e-5)
+        d_opt = torch.optim.Adam(disc.parameters(), lr=0.01, weight_decay=1e-5)
+        torch.manual_seed(int(g["draw_seed"]))
+        loss, sl, tl = O.dane_forward_model(net, disc, g_opt, d_opt, src, tgt, 5, min(int(g["src/count"]), int(g["tgt/count"])))
+        eq(np.float64(loss), g[f"{tag}/loss"])
+        for k, v in sub(g, f"{tag}/param1/").items():
+            eq(net.state_dict()[k], v)
+        for k, v in sub(g, f"{tag}/disc1/").items():
+            eq(disc.state_dict()[k], v)
+    else:
+        torch.manual_seed(int(g["draw_seed"]))
+        if tag == "udagcn":
+            loss, sl, tl = O.udagcn_forward_model(net, src, tgt, 0.05, 2, 3, mode="graph")
+        else:
+            loss, sl, tl = O.grade_forward_model(net, src, tgt, 0.4, GT_KW[tag]["disc"], 0.5)
+        loss.backward()
+    if tag != "dane":
+        eq(loss, g[f"{tag}/loss"])
+        named = dict(net.named_parameters())
+        got = sub(g, f"{tag}/grad/")
+        assert got
+        for k, v in got.items():
+            eq(named[k].grad, v)
+    eq(sl, g[f"{tag}/src_logits"]); eq(tl, g[f"{tag}/tgt_logits"])
+
+
+@pytest.mark.parametrize("batch_size", [0, 6])
+@pytest.mark.parametrize("tag", ["grade_js", "grade_mmd", "udagcn", "adagcn", "dane"])
+def test_graph_mode_fit_trajectory(tag, batch_size):
+    """Three epochs of the trainers' loops (grade.py:254-300, udagcn.py:272-320, adagcn.py:277-330, dane.py:252-290)
+    over shuffled DataLoader batches; the loaders' draws and the trainers' own CPU-generator draws interleave exactly
+    as in the reference."""
+    import torch.utils.data as tud
+    g = load_golden("graph_trainers")
+    src, tgt = _graph_dataset(g, "src"), _graph_dataset(g, "tgt")
+    torch.manual_seed(int(g["fit_seed"]))
+    mk = lambda ds: tud.DataLoader(ds, batch_size=batch_size or len(ds), shuffle=True, collate_fn=O.collate_graphs)
+    sl_, tl_ = mk(src), mk(tgt)
+    net, _, forward = _gt_make(tag)
+    wd = {"udagcn": 0.003, "dane": 1e-5}.get(tag, 0.001)
+    if tag == "udagcn":           # udagcn.py:262-268: parameters of encoder, cls_model, domain_model
+        import itertools
+        params = itertools.chain(net.encoder.parameters(), net.cls_model.parameters(), net.domain_model.parameters())
+        opt = torch.optim.Adam(params, lr=0.01, weight_decay=wd)
+    else:
+        opt = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=wd)
+    if tag == "adagcn":           # adagcn.py:264-275
+        disc = torch.nn.Sequential(torch.nn.Linear(8, 6), torch.nn.ReLU(), torch.nn.Dropout(0.0), torch.nn.Linear(6, 1),
+                                   torch.nn.Sigmoid())
+        c_opt = torch.optim.Adam(disc.parameters(), lr=0.01, weight_decay=wd)
+    if tag == "dane":             # dane.py:235-250
+        disc = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))
+        d_opt = torch.optim.Adam(disc.parameters(), lr=0.01, weight_decay=wd)
+        sample = min(len(src), len(tgt))
+    losses, accs = [], []
+    for epoch in range(3):
+        tot, logits, labels = 0.0, [], []
+        for sb, tb in zip(sl_, tl_):
+            net.train()
+            if tag == "dane":
+                val, s_logits, _ = O.dane_forward_model(net, disc, opt, d_opt, sb, tb, 5, sample)
+                tot += val
+            else:
+                if tag == "adagcn":
+                    loss, s_logits, _ = O.adagcn_forward_model(net, disc, c_opt, sb, tb, 5, 1)
+                else:
+                    loss, s_logits = forward(sb, tb, epoch)
+                tot += loss.item()
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            logits.append(s_logits.detach()); labels.append(sb.y)
+        losses.append(tot)
+        accs.append(float((torch.cat(logits).argmax(1) == torch.cat(labels)).float().mean()))
+    eq(np.array(losses), g[f"{tag}/fit{batch_size}/losses"])
+    np.testing.assert_allclose(accs, g[f"{tag}/fit{batch_size}/accs"], atol=1e-12)
+    for k, v in sub(g, f"{tag}/fit{batch_size}/final/").items():
+        eq(net.state_dict()[k], v)
+    if batch_size == 0:
+        net.eval()
+        with torch.no_grad():
+            for tb in tl_:
+                if tag.startswith("grade"):
+                    out = net(tb)[0]
+                elif tag == "udagcn":
+                    for conv in net.encoder.conv_layers:
+                        conv.cache_dict.clear()
+                    out = net.cls_model(O.global_mean_pool(net.encode(tb, "target"), tb.batch))
+                elif tag == "adagcn":
+                    out = net.cls_model(net(tb))
+                else:
+                    out = net(tb.x, tb.edge_index, batch=tb.batch)
+                eq(out, g[f"{tag}/fit0/tgt_logits"]); eq(tb.y, g[f"{tag}/fit0/tgt_labels"])
