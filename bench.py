@@ -215,11 +215,8 @@ def rmat_probe(device, d=128, iters=5):
     res = {}
     for name in ("as_generated", "degree_sorted"):
         if name == "degree_sorted":
-            order = torch.argsort(torch.bincount(ei[1], minlength=n), descending=True)
-            new_id = torch.empty_like(order)
-            new_id[order] = torch.arange(n, device=device)
-            ei = new_id[ei]
-            del order, new_id
+            from pygda_amd.data import degree_order
+            ei = degree_order(ei, n)[ei]
         G = build_csr(ei, n, validate=False)
         x = torch.randn(n, d, device=device, generator=gen)
         for _ in range(2):
@@ -467,8 +464,11 @@ def init_group(args, world, rank, dev):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ["PYGDA_AMD_FORCE_DP"] = "1"
-    if args.rccl_direct:
+    if args.rccl_direct:           # + the whole data-parallel step captured WITH its collectives (1-rank validated only)
         os.environ["PYGDA_AMD_RCCL_DIRECT"] = "1"
+        os.environ["PYGDA_AMD_RCCL_CAPTURE"] = "1"
+    if args.no_rccl_direct:
+        os.environ["PYGDA_AMD_RCCL_DIRECT"] = "0"
     gpu = torch.cuda.is_available()
     sys.stdout.flush()
     saved_fd = os.dup(1)
@@ -486,9 +486,22 @@ def init_group(args, world, rank, dev):
             torch.cuda.synchronize()
         if float(warm) != float(world):
             raise SystemExit(f"bench.py: all-reduce over the group summed to {float(warm)}, expected {world}")
-        if gpu and os.environ.get("PYGDA_AMD_RCCL_DIRECT") == "1":
+        # who is there: an all-gather of the ranks (the line prints it as rccl_ranks_seen)
+        mine = torch.tensor([rank], device=dev if gpu else "cpu", dtype=torch.int64)
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        args._ranks_seen = sorted(int(v) for v in torch.cat(seen).cpu())
+        if args._ranks_seen != list(range(world)):
+            raise SystemExit(f"bench.py: the group's ranks are {args._ranks_seen}, expected 0..{world - 1}")
+        args._collectives = "torch.distributed ProcessGroup (" + dist.get_backend() + ")"
+        if gpu and dist.get_backend() == "nccl":
+            # the library-owned RCCL communicator is the default for the exchange steps; it is kept only if EVERY rank
+            # built it and passed its self-test (pygda_amd/distributed.py), else all ranks stay on the ProcessGroup
             from pygda_amd import distributed as _D
-            _D.direct().all_reduce_(warm)
+            if _D.direct_agreed() is not None:
+                args._collectives = "library-owned RCCL communicator (gda_comm_*: enqueues on the training stream)"
+            elif _D._direct_failed:
+                args._collectives += "; library-owned communicator declined: " + _D._direct_failed
             torch.cuda.synchronize()
     finally:
         ctypes.CDLL(None).fflush(None)
@@ -818,6 +831,8 @@ def main():
     ap.add_argument("--side-steps", type=int, default=30)
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel code path (RCCL exchange steps) on a 1-rank group")
+    ap.add_argument("--no-rccl-direct", action="store_true",
+                    help="collectives through torch.distributed's ProcessGroup instead of the library-owned RCCL communicator")
     ap.add_argument("--rccl-direct", action="store_true",
                     help="collectives through the C ABI's own RCCL communicator (gda_allreduce_f32 / "
                          "gda_allgather_f32): the whole data-parallel step is then ONE hipGraph")
@@ -892,6 +907,9 @@ def main():
         if thunk is not None:
             out["cpu_baseline"] = thunk()
     if rank == 0:
+        if getattr(args, "_ranks_seen", None) is not None:
+            out["rccl_ranks_seen"] = args._ranks_seen            # all-gather of the ranks over the group (init_group)
+            out["collectives"] = args._collectives
         if args.share_gpus:
             out["functional_check"] = (f"{world} ranks on {torch.cuda.device_count()} GPU(s) over gloo (--share-gpus): "
                                        "the N-rank code path end to end, NOT a measurement")

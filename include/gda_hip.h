@@ -255,7 +255,8 @@ int gda_gat_bwd_f32(const int32_t* rowptr, const int32_t* colidx,
  *   bandwidth   [times] fp32 (device, saved for backward; gradient does not flow
  *               through it -- mmd.py:50 uses .data)
  *   l2_saved    [times, 2n, 2n] fp32 (device; produced by fwd, consumed by bwd -- on return it
- *               holds d K / d L2 with the block signs applied, not the distances themselves)
+ *               holds d K / d L2 with the block signs applied, not the distances themselves;
+ *               opaque to the caller)
  * Backward: grad_rows [times, 2n, d] = d loss / d total rows, scaled by *grad_loss.
  * The caller scatters them onto feature rows (a CSR SpMM with the selection matrix).
  * ---------------------------------------------------------------------------- */
@@ -291,6 +292,17 @@ int gda_mmd_fwd_gather_f32(const float* src, int64_t ld_src, const float* tgt, i
                            float scale, const float* add, float* rows_src, float* rows_tgt,
                            float* loss, float* bandwidth, float* l2_saved,
                            void* workspace, size_t workspace_bytes, gda_stream_t stream);
+/* The forward in two calls, so that the loss VALUE leaves the path between the pair-weight kernel and the backward
+ * kernel (the backward needs the weights in l2_saved, not the value): _partial runs everything but the final
+ * reduction and leaves the per-tile block sums in `workspace`; _finalize (same times / n / d / workspace, any stream
+ * ordered behind the first call) turns them into `loss = add[0] + scale * mmd`.  Together = gda_mmd_fwd_gather_f32. */
+int gda_mmd_fwd_partial_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
+                            int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
+                            int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
+                            float* rows_src, float* rows_tgt, float* bandwidth, float* l2_saved,
+                            void* workspace, size_t workspace_bytes, gda_stream_t stream);
+int gda_mmd_finalize_f32(int times, int64_t n, int64_t d, float scale, const float* add, float* loss,
+                         const void* workspace, size_t workspace_bytes, gda_stream_t stream);
 int gda_mmd_bwd_ex_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
                        int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
                        int times, int64_t n, float kernel_mul, int kernel_num,
@@ -662,6 +674,17 @@ typedef struct gda_adam_tensor {
 } gda_adam_tensor;
 int gda_adam_multi_f32(const gda_adam_tensor* tensors /* HOST array */, int n_tensors, float lr, float beta1,
                        float beta2, float eps, float weight_decay, gda_stream_t stream);
+/* The same update in TWO calls, so that the counter bump leaves the tail of the step (it sat between the last
+ * gradient kernel and the update, 8 us + a launch gap on the critical path of a replayed step):
+ *   gda_step_bump          at the START of a training step: `*counter += 1` (the device step counter the fused
+ *                          dropout kernels key their Philox streams on; may be NULL) and `*steps[k] += 1` for the
+ *                          n_steps Adam step counters (device floats; HOST array of device pointers, n_steps <=
+ *                          GDA_ADAM_MAX_TENSORS) -- one launch;
+ *   gda_adam_multi_ex_f32  flags & GDA_ADAM_STEPS_BUMPED: the step counters already hold t (no increment launch). */
+#define GDA_ADAM_STEPS_BUMPED 1
+int gda_step_bump(int64_t* counter, float* const* steps /* HOST array */, int n_steps, gda_stream_t stream);
+int gda_adam_multi_ex_f32(const gda_adam_tensor* tensors /* HOST array */, int n_tensors, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, int flags, gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
  * Tall-skinny fp32 GEMMs on the matrix cores: the dense projection of the hidden / classifier

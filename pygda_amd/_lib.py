@@ -44,6 +44,9 @@ _SIGNATURES = {
                                    c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gda_mmd_fwd_gather_f32": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, _P, c_int, c_int64, c_float, c_int, c_float,
                                        c_float, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gda_mmd_fwd_partial_f32": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, _P, c_int, c_int64, c_float, c_int, c_float,
+                                        _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gda_mmd_finalize_f32": (c_int, [c_int, c_int64, c_int64, c_float, _P, _P, _P, c_size_t, _P]),
     "gda_mmd_bwd_ex_f32": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, _P, c_int, c_int64, c_float, c_int,
                                    _P, _P, _P, c_float, _P, _P, _P, c_int64, _P, _P, _P, c_int64, _P,
                                    _P, c_size_t, _P]),
@@ -137,6 +140,8 @@ _SIGNATURES = {
     "gda_gemm_tall_f32": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, _P,
                                   _P, c_size_t, _P]),
     "gda_adam_multi_f32": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, c_float, _P]),
+    "gda_adam_multi_ex_f32": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
+    "gda_step_bump": (c_int, [_P, _P, c_int, _P]),
     "gda_rccl_load": (c_int, [ctypes.c_char_p]),
     "gda_comm_unique_id": (c_int, [_P, c_size_t]),
     "gda_comm_init_rank": (c_int, [_P, c_size_t, c_int, c_int, ctypes.POINTER(c_void_p)]),

@@ -65,10 +65,44 @@ __global__ void k_step_inc(AdamTable t) {
     if ((int)threadIdx.x < t.n) *t.step[threadIdx.x] += 1.0f;
 }
 
+struct BumpTable {
+    float* step[GDA_ADAM_MAX_TENSORS];
+    int64_t* counter;
+    int n;
+};
+__global__ void k_step_bump(BumpTable t) {
+    if ((int)threadIdx.x < t.n) *t.step[threadIdx.x] += 1.0f;
+    if (threadIdx.x == 63 && t.counter) *t.counter += 1;
+}
+
 }  // namespace
+
+extern "C" int gda_step_bump(int64_t* counter, float* const* steps, int n_steps, gda_stream_t stream_) {
+    if (n_steps < 0 || n_steps > GDA_ADAM_MAX_TENSORS) return GDA_E_SIZE;
+    if (n_steps > 0 && !steps) return GDA_E_NULL;
+    if (n_steps == 0 && !counter) return GDA_OK;
+    BumpTable t;
+    t.n = n_steps;
+    t.counter = counter;
+    for (int k = 0; k < n_steps; ++k) {
+        if (!steps[k]) return GDA_E_NULL;
+        for (int j = 0; j < k; ++j)
+            if (steps[j] == steps[k]) return GDA_E_UNSUPPORTED;       // one increment per counter and launch
+        t.step[k] = steps[k];
+    }
+    k_step_bump<<<1, 64, 0, (hipStream_t)stream_>>>(t);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
 
 extern "C" int gda_adam_multi_f32(const gda_adam_tensor* tensors, int n_tensors, float lr, float beta1,
                                   float beta2, float eps, float weight_decay, gda_stream_t stream_) {
+    return gda_adam_multi_ex_f32(tensors, n_tensors, lr, beta1, beta2, eps, weight_decay, 0, stream_);
+}
+
+extern "C" int gda_adam_multi_ex_f32(const gda_adam_tensor* tensors, int n_tensors, float lr, float beta1,
+                                     float beta2, float eps, float weight_decay, int flags, gda_stream_t stream_) {
+    if (flags & ~GDA_ADAM_STEPS_BUMPED) return GDA_E_UNSUPPORTED;
     if (n_tensors < 0 || n_tensors > GDA_ADAM_MAX_TENSORS) return GDA_E_SIZE;
     if (n_tensors == 0) return GDA_OK;
     if (!tensors) return GDA_E_NULL;
@@ -90,8 +124,10 @@ extern "C" int gda_adam_multi_f32(const gda_adam_tensor* tensors, int n_tensors,
     if (items >= INT32_MAX) return GDA_E_SIZE;
     hipStream_t stream = (hipStream_t)stream_;
     if (items == 0) return GDA_OK;
-    k_step_inc<<<1, 64, 0, stream>>>(t);
-    GDA_LAUNCH_CHECK();
+    if (!(flags & GDA_ADAM_STEPS_BUMPED)) {
+        k_step_inc<<<1, 64, 0, stream>>>(t);
+        GDA_LAUNCH_CHECK();
+    }
     k_adam<<<(unsigned)items, TB, 0, stream>>>(t, lr, beta1, beta2, eps, weight_decay);
     GDA_LAUNCH_CHECK();
     return GDA_OK;

@@ -78,6 +78,37 @@ class Data:
         return f"Data({info})"
 
 
+def degree_order(edge_index, num_nodes):
+    """``new_id [N]``: the relabelling that numbers the nodes by decreasing in-degree (ties in id order).  On a power-law
+    graph the rows most rows gather then share cache lines and pages: the full-graph aggregation of an R-MAT 2^22 graph
+    runs 6.8 -> 5.2 ms with it (`roofline_hbm_regime.rmat_2^22`); a uniform graph has nothing to gain."""
+    deg = torch.bincount(edge_index[1], minlength=num_nodes)
+    order = torch.argsort(deg, descending=True, stable=True)          # order[k] = old id of the k-th node
+    new_id = torch.empty_like(order)
+    new_id[order] = torch.arange(num_nodes, device=order.device)
+    return new_id
+
+
+def relabel(data, new_id):
+    """The same graph with node ``i`` renamed ``new_id[i]`` (features, labels, every per-node attribute and the edge
+    list follow): an isomorphic ``Data``, so training on it is training on the original; ``out[new_id]`` maps a
+    per-node result of the relabelled graph back to the original numbering."""
+    n = data.num_nodes
+    inv = torch.empty_like(new_id)
+    inv[new_id] = torch.arange(n, device=new_id.device)
+    out = {}
+    for k, v in data.__dict__.items():
+        if k.startswith("_") or v is None:
+            continue
+        if k == "edge_index":
+            out[k] = new_id[v]
+        elif torch.is_tensor(v) and v.dim() >= 1 and v.size(0) == n:
+            out[k] = v[inv]
+        else:
+            out[k] = v
+    return Data(**out)
+
+
 def to_undirected(edge_index, num_nodes=None):
     """Symmetrise and de-duplicate an edge list (what benchmark/node/a2gnn.py:92-97 applies)."""
     n = int(edge_index.max()) + 1 if num_nodes is None else num_nodes

@@ -18,7 +18,7 @@ class _DirectComm:
     """RCCL communicator owned by libgda_hip.so (include/gda_hip.h: gda_comm_*): the two exchange
     steps become plain enqueues on the current stream -- no ProcessGroup work objects, no watchdog
     events -- which is what lets a whole data-parallel step be captured into ONE hipGraph.
-    Opt-in (``PYGDA_AMD_RCCL_DIRECT=1``); the rendezvous (shipping the 128-byte id) still rides on
+    Default for ``nccl`` groups (:func:`direct`); the rendezvous (shipping the 128-byte id) still rides on
     the torch.distributed group the launcher set up."""
 
     def __init__(self):
@@ -51,16 +51,80 @@ class _DirectComm:
 
 
 _direct = None
+_direct_failed = None       # why the library-owned communicator was given up for this process (str), or None
+
+
+def _self_test(comm, timeout_s=20.0):
+    """One all-reduce and one all-gather on the fresh communicator, checked against what they must return; polled with
+    a deadline so that a communicator that never completes costs the process `timeout_s`, not the run."""
+    import time
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    x = torch.full((257,), float(rank + 1), dtype=torch.float32, device=dev)
+    g = torch.empty(world, 3, dtype=torch.float32, device=dev)
+    comm.all_reduce_(x)
+    comm.all_gather(g, torch.full((3,), float(rank), dtype=torch.float32, device=dev))
+    ev = torch.cuda.Event()
+    ev.record()
+    t0 = time.time()
+    while not ev.query():
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError(f"self-test collectives did not complete within {timeout_s:.0f} s")
+        time.sleep(0.001)
+    want = world * (world + 1) / 2.0
+    if not bool((x == want).all()):
+        raise RuntimeError(f"all-reduce self-test: got {float(x[0])}, expected {want}")
+    if not bool((g == torch.arange(world, dtype=torch.float32, device=dev).view(-1, 1)).all()):
+        raise RuntimeError("all-gather self-test: rank order of the gathered blocks is wrong")
 
 
 def direct():
-    """The library-owned communicator, or None (default: collectives go through torch.distributed)."""
-    global _direct
-    if os.environ.get("PYGDA_AMD_RCCL_DIRECT") != "1" or not active() or dist.get_backend() != "nccl":
+    """The library-owned RCCL communicator (csrc/gda_comm.cpp): the DEFAULT for the exchange steps of an ``nccl``
+    group since round 4 -- plain enqueues on the caller's stream, no ProcessGroup work objects, no per-collective
+    host bookkeeping.  It is built on first use (unique id shipped over the torch.distributed group) and must pass a
+    self-test (all-reduce + all-gather against known answers, with a deadline); ANY failure -- librccl symbols not
+    found, communicator init, wrong answer, timeout -- is reported once and every collective of this process then goes
+    through torch.distributed's ProcessGroup (same RCCL underneath), which stays the fallback.
+    ``PYGDA_AMD_RCCL_DIRECT=0`` switches it off.  gloo groups (CPU tests, ranks sharing a GPU) never use it."""
+    global _direct, _direct_failed
+    if (os.environ.get("PYGDA_AMD_RCCL_DIRECT", "1") == "0" or _direct_failed is not None or not active()
+            or dist.get_backend() != "nccl"):
         return None
     if _direct is None:
-        _direct = _DirectComm()
+        try:
+            comm = _DirectComm()
+            _self_test(comm)
+            _direct = comm
+        except Exception as exc:                     # noqa: BLE001 -- anything: the ProcessGroup path is complete
+            _direct_failed = f"{type(exc).__name__}: {exc}"
+            import warnings
+            warnings.warn("library-owned RCCL communicator unavailable (" + _direct_failed +
+                          "); collectives go through torch.distributed")
+            return None
+        # every rank must agree (a rank on the ProcessGroup path and a rank on the communicator would deadlock):
+        # the agreement itself rides on the ProcessGroup
     return _direct
+
+
+def direct_agreed():
+    """Collective: build the communicator on every rank and keep it only if EVERY rank succeeded (one rank falling back
+    alone would leave its peers waiting in a collective it never joins).  Call once, at start-up, from all ranks."""
+    global _direct, _direct_failed
+    if not active() or dist.get_backend() != "nccl":
+        return None
+    ok = torch.tensor([1.0 if direct() is not None else 0.0], device=torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok) < 1.0 and _direct is not None:
+        _direct_failed = "another rank could not build its communicator"
+        _direct = None
+    return _direct
+
+
+def capture_collectives():
+    """Whether a data-parallel step may be captured WITH its collectives into one hipGraph (opt-in,
+    ``PYGDA_AMD_RCCL_CAPTURE=1``: validated on a 1-rank group only -- no multi-GPU node was available to any round --
+    so N > 1 runs keep the collectives eager between captured segments unless asked otherwise)."""
+    return os.environ.get("PYGDA_AMD_RCCL_CAPTURE") == "1" and direct() is not None
 
 
 def shutdown_direct():

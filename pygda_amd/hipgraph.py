@@ -112,6 +112,7 @@ class LossTerms(tuple):
 
 
 defer_total = False        # set by GraphedStep around its step function: trainers may then return LossTerms
+BUMP_AT_START = __import__("os").environ.get("PYGDA_AMD_BUMP_AT_START", "1") == "1"
 
 
 class GraphedStep:
@@ -234,7 +235,13 @@ class GraphedStep:
     def _run(self, with_stats=False):
         from .ops import dropout_state
         self._rand_cursor = 0
-        dropout_state.next_step(self.src.x.device)        # device counter: bumped by every replay too
+        # device step counter of the dropout kernels (bumped by every replay too) and, in the same launch when the
+        # optimiser allows it, Adam's step counters: their increment then no longer sits in front of the update
+        bump = getattr(self.optimizer, "bump_steps", None) if BUMP_AT_START and not self.extra_optimizers else None
+        if bump is not None and bump(dropout_state.counter(self.src.x.device)):
+            dropout_state.site = 0
+        else:
+            dropout_state.next_step(self.src.x.device)
         global defer_total
         defer_total = type(self) is GraphedStep and not self.dp
         try:
@@ -242,10 +249,15 @@ class GraphedStep:
         finally:
             defer_total = False
         terms = loss if isinstance(loss, LossTerms) else None
+        from .ops import take_pending_streams
+        tails = take_pending_streams()        # operators that left their loss value's last kernel on a side stream
         if terms is not None:
             if getattr(self, "_one", None) is None:
                 self._one = torch.ones((), dtype=torch.float32, device=self.src.x.device)
             if not with_stats:                                    # warm-up runs: the total on the main stream
+                for s_ in tails:
+                    torch.cuda.current_stream().wait_stream(s_)
+                tails = []
                 loss = terms[0].detach()
                 for extra in terms[1:]:
                     loss = loss + extra.detach()
@@ -255,6 +267,9 @@ class GraphedStep:
             main = torch.cuda.current_stream()
             side = self._stat_stream
             side.wait_stream(main)
+            for s_ in tails:                                      # e.g. the MMD's final reduction
+                side.wait_stream(s_)
+            tails = []
             with torch.cuda.stream(side):
                 from .ops import ce_stats_for
                 if terms is not None:                             # the reported total: same fp32 sum as `a + b` in eager mode
@@ -270,6 +285,8 @@ class GraphedStep:
                     self.stats = torch.stack([loss.detach().double(), correct.double()])
             for t in (loss, logits):
                 t.record_stream(side)
+        for s_ in tails:                      # nobody took them (no LossTerms, no statistics branch): the main stream does
+            torch.cuda.current_stream().wait_stream(s_)
         self.optimizer.zero_grad(set_to_none=True)
         if terms is not None:
             torch.autograd.backward(list(terms), [self._one.reshape(t.shape) for t in terms])

@@ -95,9 +95,10 @@ class A2GNN(BaseGDA):
             return loss + self.weight * self._gmean(dom, source_features.size(0) + target_features.size(0))
         # the weight rides inside the loss kernels; the CE term is added OUTSIDE on purpose: as an input of the MMD node
         # its gradient would only be released after the MMD's backward kernels, serialising the CE path behind them
-        mmd = MMD(source_features, target_features, scale=self.weight)                  # :206-209
         from .. import hipgraph
-        if hipgraph.defer_total and type(self) is A2GNN:
+        terms = hipgraph.defer_total and type(self) is A2GNN
+        mmd = MMD(source_features, target_features, scale=self.weight, defer_value=terms)       # :206-209
+        if terms:
             return hipgraph.LossTerms((loss, mmd))       # summed beside the backward pass (hipgraph.LossTerms)
         return loss + mmd
 

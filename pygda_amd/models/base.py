@@ -100,7 +100,8 @@ class BaseGDA(ABC):
         start = time.time()
         _freeze_gc()
         if not getattr(self, "_dp_synced", None) is net:      # data-parallel: one set of initial weights
-            from ..distributed import broadcast_parameters
+            from ..distributed import broadcast_parameters, direct_agreed
+            direct_agreed()           # nccl groups: all ranks on the library-owned RCCL communicator, or all on the ProcessGroup
             broadcast_parameters(net)
             for aux in getattr(self, "_dp_aux_modules", ()):      # critics / discriminators with their own optimiser
                 broadcast_parameters(aux)
@@ -200,9 +201,9 @@ class BaseGDA(ABC):
         from ..distributed import active
         if not torch.cuda.is_available():
             return None
-        from ..distributed import direct
+        from ..distributed import capture_collectives
         dp = active()
-        whole = dp and direct() is not None           # library-owned RCCL communicator: collectives capture
+        whole = dp and capture_collectives()          # library-owned RCCL communicator: collectives capture (opt-in)
         parts = self._dp_graph_parts() if (dp and not whole and hasattr(self, "_dp_graph_parts")) else None
         if dp and not whole and parts is None:
             return None       # RCCL collectives abort under stream capture on this stack (ROCm 7.0 /

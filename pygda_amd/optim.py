@@ -4,6 +4,8 @@ weight_decay)`` (pygda/models/a2gnn.py:290-294); torch's fused implementation ch
 65536 elements, which leaves a model with one 867k-element weight and a few small ones on ~20
 workgroups (42 us per step at cfg-A).  Same update rule, 2048-element work items, device-resident
 step counters (hipGraph-capturable by construction)."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -27,12 +29,37 @@ class Adam(torch.optim.Optimizer):
         return st
 
     @torch.no_grad()
+    def bump_steps(self, counter=None):
+        """START of a training step (captured steps: pygda_amd/hipgraph.py): increment every parameter's Adam step
+        counter -- and ``counter``, the device step counter of the fused dropout kernels -- in ONE launch; the
+        following :meth:`step` then launches the update alone.  The bump used to sit between the last gradient kernel
+        and the update (8 us + a launch gap at the end of every replayed step).  Returns False, having done nothing,
+        when the optimiser's shape does not allow it (a Parameter listed twice -- UDAGCN -- is updated in two rounds
+        with two increments; more tensors than one launch takes)."""
+        params = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        if len({id(p) for p in params}) != len(params) or not 0 < len(params) <= MAX_TENSORS:
+            return False
+        ptrs = (ctypes.c_void_p * len(params))(*[self._state(p)["step"].data_ptr() for p in params])
+        _lib.check(_lib.lib().gda_step_bump(None if counter is None else counter.data_ptr(), ptrs, len(params),
+                                            _lib.stream()), "gda_step_bump")
+        self._bumped = {id(p) for p in params}
+        return True
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
+        bumped, self._bumped = getattr(self, "_bumped", None), None
+        if bumped is not None:
+            # counters incremented by bump_steps(): torch steps only the parameters that HAVE a gradient, so one that
+            # was bumped and has none gets its increment taken back (a plain device op: captured with the step)
+            for group in self.param_groups:
+                for p in group["params"]:
+                    if id(p) in bumped and p.grad is None:
+                        self._state(p)["step"].sub_(1.0)
         for group in self.param_groups:
             # A Parameter listed twice (UDAGCN / SpecReg hand the optimiser the conv weights their two
             # encoders share twice, pygda/models/udagcn.py:262-268) is updated twice per step, one update after
@@ -71,7 +98,8 @@ class Adam(torch.optim.Optimizer):
                     table[k] = _lib.AdamTensorStruct(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
                                                      st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), p.numel())
                 b1, b2 = group["betas"]
-                _lib.check(L.gda_adam_multi_f32(table, len(chunk), float(group["lr"]), float(b1), float(b2),
-                                                float(group["eps"]), float(group["weight_decay"]), _lib.stream()),
-                           "gda_adam_multi_f32")
+                _lib.check(L.gda_adam_multi_ex_f32(table, len(chunk), float(group["lr"]), float(b1), float(b2),
+                                                   float(group["eps"]), float(group["weight_decay"]),
+                                                   1 if bumped is not None else 0, _lib.stream()),
+                           "gda_adam_multi_ex_f32")
         return loss

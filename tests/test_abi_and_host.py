@@ -180,6 +180,24 @@ def test_product_path_has_no_cpu_fallback():
         pygda_amd.utils.get_MMD(torch.randn(4, 3), torch.randn(4, 3))
 
 
+def test_round4_entry_points_validate_before_touching_a_device():
+    """gda_step_bump / gda_adam_multi_ex_f32 (round 4: the step-counter bump at the start of a step)."""
+    import ctypes
+    L = _lib.lib()
+    one, two = ctypes.c_void_p(8), ctypes.c_void_p(16)
+    assert L.gda_step_bump(None, None, 0, None) == 0                               # nothing to do
+    assert L.gda_step_bump(None, None, 3, None) == -1                              # NULL table
+    assert L.gda_step_bump(None, None, -1, None) == -2 and L.gda_step_bump(None, None, 49, None) == -2
+    arr = (ctypes.c_void_p * 2)(one, one)
+    assert L.gda_step_bump(None, arr, 2, None) == -4          # the same counter twice
+    arr = (ctypes.c_void_p * 2)(one, None)
+    assert L.gda_step_bump(None, arr, 2, None) == -1
+    table = (_lib.AdamTensorStruct * 1)()
+    assert L.gda_adam_multi_ex_f32(table, 1, 0.1, 0.9, 0.999, 1e-8, 0.0, 2, None) == -4   # flag
+    assert L.gda_adam_multi_ex_f32(table, 0, 0.1, 0.9, 0.999, 1e-8, 0.0, 1, None) == 0
+    assert L.gda_adam_multi_ex_f32(None, 2, 0.1, 0.9, 0.999, 1e-8, 0.0, 1, None) == -1
+
+
 def test_basegda_num_neigh_validation():
     m = A2GNN(8, 4, 3, num_layers=2, num_neigh=[15, 10], device="cpu")
     assert m.num_neigh == [15, 10]
@@ -839,3 +857,27 @@ def test_ctypes_signatures_match_the_header():
         assert kind_of_c(ret.replace("const", "")) == kind_of_ct(sig[0]), f"{name}: return kind"
         checked += 1
     assert checked == len(protos)
+
+
+def test_degree_order_relabelling_is_an_isomorphism():
+    """data.degree_order / data.relabel (the locality option for power-law full-graph propagation): hubs get the
+    smallest ids, and the oracle's aggregation on the relabelled graph is the original's, row for row."""
+    import torch
+    from oracle import pygda_cpu as O
+    from pygda_amd.data import Data, degree_order, relabel
+    g = torch.Generator().manual_seed(5)
+    n = 60
+    w = torch.arange(1, n + 1, dtype=torch.float64).pow(-1.0)
+    ei = torch.stack([torch.multinomial(w, 400, True, generator=g), torch.multinomial(w, 400, True, generator=g)])
+    d = Data(x=torch.randn(n, 7, generator=g), edge_index=ei, y=torch.randint(0, 3, (n,), generator=g))
+    new_id = degree_order(ei, n)
+    assert sorted(new_id.tolist()) == list(range(n))
+    deg = torch.bincount(ei[1], minlength=n)
+    by_new = torch.empty(n, dtype=torch.long)
+    by_new[new_id] = deg
+    assert bool((by_new[:-1] >= by_new[1:]).all())                    # decreasing in-degree
+    r = relabel(d, new_id)
+    assert torch.equal(r.x[new_id], d.x) and torch.equal(r.y[new_id], d.y)
+    a = O.propagate(*O.gcn_norm(d.edge_index, None, n), d.x)
+    b = O.propagate(*O.gcn_norm(r.edge_index, None, n), r.x)
+    assert torch.allclose(b[new_id], a, atol=1e-6)

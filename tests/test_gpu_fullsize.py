@@ -41,7 +41,7 @@ def _rel_l2(a, b):
     return float((a - b).norm() / max(float(b.norm()), 1e-30))
 
 
-def _check_grads(net, ora, rel=1e-4):
+def _check_grads(net, ora, rel=1e-4, elem=1e-4):
     """Every parameter gradient of the product against the oracle's: relative L2 per tensor, the element-wise bound of
     tests/test_gpu_parity.py, and sign agreement of every entry that is not noise-sized (a sign error in a small
     gradient hides in an absolute bound).  Returns the number of tensors compared."""
@@ -61,8 +61,8 @@ def _check_grads(net, ora, rel=1e-4):
             checked += 1
             continue
         assert _rel_l2(p.grad, v) <= rel, (k, _rel_l2(p.grad, v))
-        close(p.grad, v, rtol=1e-3, atol=1e-4 * max(float(v.abs().max()), 1e-3))
-        big = v.abs() > 1e-3 * float(v.abs().max())
+        close(p.grad, v, rtol=1e-3, atol=elem * max(float(v.abs().max()), 1e-3))
+        big = v.abs() > max(1e-3, 10 * elem) * float(v.abs().max())
         assert bool((torch.sign(p.grad.detach().cpu()[big]) == torch.sign(v[big])).all()), k
         checked += 1
     return checked
@@ -316,7 +316,7 @@ def test_adagcn_full_size_step_vs_oracle():
     close(tl, wtl, rtol=0, atol=LOGIT_ATOL)
     exact(sl.argmax(1), wsl.argmax(1))
     exact(tl.argmax(1), wtl.argmax(1))
-    assert _check_grads(net, ora, rel=5e-3) >= 6   # 2 convs x (weight, bias) + classifier
+    assert _check_grads(net, ora, rel=5e-3, elem=5e-3) >= 6   # 2 convs x (weight, bias) + classifier
     for k, v in net.state_dict().items():          # forward_model trains the critic only
         exact(v, before[k])
     # ---- stage 2: the encoder objective given the (oracle's) critic

@@ -814,7 +814,8 @@ def test_dp_direct_rccl_single_rank(monkeypatch, graphed):
     try:
         monkeypatch.setenv("PYGDA_AMD_FORCE_DP", "1")
         monkeypatch.setenv("PYGDA_AMD_RCCL_DIRECT", "1")
-        assert D.direct() is not None
+        monkeypatch.setenv("PYGDA_AMD_RCCL_CAPTURE", "1")           # the whole step incl. its collectives in one graph
+        assert D.direct_agreed() is not None and D.direct() is not None
         x = torch.arange(12, dtype=torch.float32, device=DEV)
         D.direct().all_reduce_(x)                                   # 1 rank: identity
         exact(x, np.arange(12, dtype=np.float32))
