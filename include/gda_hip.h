@@ -292,17 +292,6 @@ int gda_mmd_fwd_gather_f32(const float* src, int64_t ld_src, const float* tgt, i
                            float scale, const float* add, float* rows_src, float* rows_tgt,
                            float* loss, float* bandwidth, float* l2_saved,
                            void* workspace, size_t workspace_bytes, gda_stream_t stream);
-/* The forward in two calls, so that the loss VALUE leaves the path between the pair-weight kernel and the backward
- * kernel (the backward needs the weights in l2_saved, not the value): _partial runs everything but the final
- * reduction and leaves the per-tile block sums in `workspace`; _finalize (same times / n / d / workspace, any stream
- * ordered behind the first call) turns them into `loss = add[0] + scale * mmd`.  Together = gda_mmd_fwd_gather_f32. */
-int gda_mmd_fwd_partial_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
-                            int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
-                            int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
-                            float* rows_src, float* rows_tgt, float* bandwidth, float* l2_saved,
-                            void* workspace, size_t workspace_bytes, gda_stream_t stream);
-int gda_mmd_finalize_f32(int times, int64_t n, int64_t d, float scale, const float* add, float* loss,
-                         const void* workspace, size_t workspace_bytes, gda_stream_t stream);
 int gda_mmd_bwd_ex_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
                        int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
                        int times, int64_t n, float kernel_mul, int kernel_num,

@@ -44,9 +44,6 @@ _SIGNATURES = {
                                    c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gda_mmd_fwd_gather_f32": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, _P, c_int, c_int64, c_float, c_int, c_float,
                                        c_float, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
-    "gda_mmd_fwd_partial_f32": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, _P, c_int, c_int64, c_float, c_int, c_float,
-                                        _P, _P, _P, _P, _P, c_size_t, _P]),
-    "gda_mmd_finalize_f32": (c_int, [c_int, c_int64, c_int64, c_float, _P, _P, _P, c_size_t, _P]),
     "gda_mmd_bwd_ex_f32": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, _P, c_int, c_int64, c_float, c_int,
                                    _P, _P, _P, c_float, _P, _P, _P, c_int64, _P, _P, _P, c_int64, _P,
                                    _P, c_size_t, _P]),

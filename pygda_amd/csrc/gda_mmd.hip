@@ -843,57 +843,15 @@ extern "C" int gda_mmd_fwd_ex_f32(const float* src, int64_t ld_src, const float*
                                   workspace_bytes, stream_);
 }
 
-namespace {
-int mmd_forward(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
-                int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
-                int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
-                float scale, const float* add, float* rows_src, float* rows_tgt,
-                float* loss, float* bandwidth, float* l2_saved,
-                void* workspace, size_t workspace_bytes, gda_stream_t stream_, bool finalize);
-}
-
 extern "C" int gda_mmd_fwd_gather_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
                                       int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
                                       int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
                                       float scale, const float* add, float* rows_src, float* rows_tgt,
                                       float* loss, float* bandwidth, float* l2_saved,
                                       void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
-    if (!loss) return GDA_E_NULL;
-    return mmd_forward(src, ld_src, tgt, ld_tgt, d, src_idx, tgt_idx, times, n, kernel_mul, kernel_num, fix_sigma, scale,
-                       add, rows_src, rows_tgt, loss, bandwidth, l2_saved, workspace, workspace_bytes, stream_, true);
-}
-
-extern "C" int gda_mmd_fwd_partial_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
-                                       int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
-                                       int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
-                                       float* rows_src, float* rows_tgt, float* bandwidth, float* l2_saved,
-                                       void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
-    return mmd_forward(src, ld_src, tgt, ld_tgt, d, src_idx, tgt_idx, times, n, kernel_mul, kernel_num, fix_sigma, 1.0f,
-                       nullptr, rows_src, rows_tgt, nullptr, bandwidth, l2_saved, workspace, workspace_bytes, stream_, false);
-}
-
-extern "C" int gda_mmd_finalize_f32(int times, int64_t n, int64_t d, float scale, const float* add, float* loss,
-                                    const void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
-    if (times <= 0 || n <= 0 || d <= 0) return GDA_E_SIZE;
-    if (!loss || !workspace) return GDA_E_NULL;
-    MmdWs ws = carve(const_cast<void*>(workspace), times, n, d);
-    if (workspace_bytes < ws.total) return GDA_E_WORKSPACE;
-    const unsigned nt = (unsigned)gda_cdiv(2 * n, TILE);
-    k_finalize<<<1, TB, 0, (hipStream_t)stream_>>>(ws.kpartial, (int)(nt * (nt + 1) / 2), times, n, scale, add, loss);
-    GDA_LAUNCH_CHECK();
-    return GDA_OK;
-}
-
-namespace {
-int mmd_forward(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
-                int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
-                int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
-                float scale, const float* add, float* rows_src, float* rows_tgt,
-                float* loss, float* bandwidth, float* l2_saved,
-                void* workspace, size_t workspace_bytes, gda_stream_t stream_, bool finalize) {
     int st = check_common(src, ld_src, tgt, ld_tgt, d, src_idx, tgt_idx, times, n, kernel_num);
     if (st != GDA_OK) return st;
-    if ((finalize && !loss) || !bandwidth || !l2_saved || !workspace) return GDA_E_NULL;
+    if (!loss || !bandwidth || !l2_saved || !workspace) return GDA_E_NULL;
     if ((rows_src == nullptr) != (rows_tgt == nullptr) || (rows_src && !src_idx)) return GDA_E_NULL;
     if (rows_src && (rows_src == src || rows_tgt == tgt)) return GDA_E_ALIAS;
     MmdWs ws = carve(workspace, times, n, d);
@@ -930,13 +888,10 @@ int mmd_forward(const float* src, int64_t ld_src, const float* tgt, int64_t ld_t
     else
         k_pairdist<0, false, false><<<grid, TB, 0, stream>>>(R, d, m, (int)nt, bandwidth, kp, l2_saved, ws.kpartial, nullptr);
     GDA_LAUNCH_CHECK();
-    if (finalize) {
-        k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, (int)ntri, times, n, scale, add, loss);
-        GDA_LAUNCH_CHECK();
-    }
+    k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, (int)ntri, times, n, scale, add, loss);
+    GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
-}  // namespace
 
 extern "C" int gda_mmd_bwd_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
                                int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,

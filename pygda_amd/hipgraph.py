@@ -249,15 +249,10 @@ class GraphedStep:
         finally:
             defer_total = False
         terms = loss if isinstance(loss, LossTerms) else None
-        from .ops import take_pending_streams
-        tails = take_pending_streams()        # operators that left their loss value's last kernel on a side stream
         if terms is not None:
             if getattr(self, "_one", None) is None:
                 self._one = torch.ones((), dtype=torch.float32, device=self.src.x.device)
             if not with_stats:                                    # warm-up runs: the total on the main stream
-                for s_ in tails:
-                    torch.cuda.current_stream().wait_stream(s_)
-                tails = []
                 loss = terms[0].detach()
                 for extra in terms[1:]:
                     loss = loss + extra.detach()
@@ -267,9 +262,6 @@ class GraphedStep:
             main = torch.cuda.current_stream()
             side = self._stat_stream
             side.wait_stream(main)
-            for s_ in tails:                                      # e.g. the MMD's final reduction
-                side.wait_stream(s_)
-            tails = []
             with torch.cuda.stream(side):
                 from .ops import ce_stats_for
                 if terms is not None:                             # the reported total: same fp32 sum as `a + b` in eager mode
@@ -285,8 +277,6 @@ class GraphedStep:
                     self.stats = torch.stack([loss.detach().double(), correct.double()])
             for t in (loss, logits):
                 t.record_stream(side)
-        for s_ in tails:                      # nobody took them (no LossTerms, no statistics branch): the main stream does
-            torch.cuda.current_stream().wait_stream(s_)
         self.optimizer.zero_grad(set_to_none=True)
         if terms is not None:
             torch.autograd.backward(list(terms), [self._one.reshape(t.shape) for t in terms])

@@ -31,6 +31,9 @@ class A2GNN(BaseGDA):
         import os
         self.overlap_streams = os.environ.get("PYGDA_AMD_OVERLAP", "1") == "1"
         self.split_graphs = os.environ.get("PYGDA_AMD_SPLIT_GRAPHS", "0") == "1"   # measured slower: opt-in
+        # sampled mini-batches: the source branch (s_pnums = 0: projections and activations, chip-filling kernels) beside
+        # the target branch (K-step launches over ~17 k interior rows: latency-sized) on two streams
+        self.overlap_sampled = os.environ.get("PYGDA_AMD_SAMPLED_OVERLAP", "0") == "1"
 
     def init_model(self, **kwargs):
         return A2GNNBase(in_dim=self.in_dim, hid_dim=self.hid_dim, num_classes=self.num_classes,
@@ -95,10 +98,9 @@ class A2GNN(BaseGDA):
             return loss + self.weight * self._gmean(dom, source_features.size(0) + target_features.size(0))
         # the weight rides inside the loss kernels; the CE term is added OUTSIDE on purpose: as an input of the MMD node
         # its gradient would only be released after the MMD's backward kernels, serialising the CE path behind them
+        mmd = MMD(source_features, target_features, scale=self.weight)                  # :206-209
         from .. import hipgraph
-        terms = hipgraph.defer_total and type(self) is A2GNN
-        mmd = MMD(source_features, target_features, scale=self.weight, defer_value=terms)       # :206-209
-        if terms:
+        if hipgraph.defer_total and type(self) is A2GNN:
             return hipgraph.LossTerms((loss, mmd))       # summed beside the backward pass (hipgraph.LossTerms)
         return loss + mmd
 
@@ -141,8 +143,8 @@ class A2GNN(BaseGDA):
         # under capture).  Autograd runs every backward node on its forward stream, so the backward
         # pass splits the same way.  Sampled mini-batches ingest new graphs every step on the main
         # stream and keep the single-stream order.
-        fork = (node and source_data.x.is_cuda and self.overlap_streams
-                and getattr(target_data, "n_id", None) is None and getattr(source_data, "n_id", None) is None)
+        sampled = getattr(target_data, "n_id", None) is not None or getattr(source_data, "n_id", None) is not None
+        fork = node and source_data.x.is_cuda and self.overlap_streams and (not sampled or self.overlap_sampled)
         main = torch.cuda.current_stream() if fork else None
         if fork:
             src_stream = getattr(self, "_src_stream", None)

@@ -522,32 +522,12 @@ def lds_colmajor_ok(x, graph, K):
 # ---------------------------------------------------------------------------- MMD --
 MMD_INDEX_IN_KERNEL = _os.environ.get("PYGDA_AMD_MMD_INDEX", "0") == "1"     # sampled rows read through their index inside the kernels (no gather pass)
 MMD_SCATTER_FUSED = _os.environ.get("PYGDA_AMD_MMD_SCATTER", "1") == "1"
-MMD_FINALIZE_ASIDE = _os.environ.get("PYGDA_AMD_MMD_FINALIZE_ASIDE", "1") == "1"
-
-_side_streams = {}
-_pending_streams = []     # side streams holding work whose RESULT nobody on the main stream has waited for yet
-
-
-def _side_stream(dev, tag):
-    key = (str(dev), tag)
-    st = _side_streams.get(key)
-    if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=dev)
-    return st
-
-
-def take_pending_streams():
-    """Side streams on which an operator left the tail of its work (today: the MMD's final reduction in a captured
-    step).  The caller -- the stream that reads those results -- must ``wait_stream`` each of them."""
-    out = list(_pending_streams)
-    _pending_streams.clear()
-    return out
 
 
 class _MMD(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, tgt, src_idx, tgt_idx, times, n, kernel_mul, kernel_num, fix_sigma, sel=None, scale=1.0,
-                add=None, defer_value=False):
+                add=None):
         """``(add +) scale * MMD``: the trainer's loss line ``loss = CE + MMD(...) * weight`` (a2gnn.py:207-209)
         without elementwise glue kernels around the loss kernels."""
         ctx.sel, ctx.scale, ctx.has_add = sel, float(scale), add is not None
@@ -572,30 +552,12 @@ class _MMD(torch.autograd.Function):
         L = _lib.lib()
         ws = _lib.workspace(L.gda_mmd_workspace_bytes(times, n, d), dev, "mmd")
         addc = None if add is None else add.detach().to(torch.float32).reshape(1).contiguous()
-        if MMD_FINALIZE_ASIDE and defer_value and add is None:
-            # A captured step that seeds its loss terms separately (hipgraph.LossTerms) never reads the loss VALUE on the
-            # main stream: the backward kernel needs the pair weights only.  The final reduction (7 us + a launch gap
-            # between the pair-weight kernel and the backward kernel of a replayed cfg-A step) therefore runs on a side
-            # stream; whoever reads the value (the step's statistics branch) orders itself behind it
-            # (take_pending_streams).
-            _lib.check(L.gda_mmd_fwd_partial_f32(
+        with profiler.region("mmd_fwd", 4, 0, times * (3 * m * m * d // 2 + 12 * m * m)):
+            _lib.check(L.gda_mmd_fwd_gather_f32(
                 _lib.ptr(src), d, _lib.ptr(tgt), d, d, _lib.ptr(idx_s), _lib.ptr(idx_t), times, n, float(kernel_mul),
-                int(kernel_num), float(fix_sigma) if fix_sigma else 0.0, _lib.ptr(rows_s), _lib.ptr(rows_t),
-                _lib.ptr(bw), _lib.ptr(l2), _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_mmd_fwd_partial_f32")
-            main, side = torch.cuda.current_stream(), _side_stream(dev, "mmd_finalize")
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                _lib.check(L.gda_mmd_finalize_f32(times, n, d, float(scale), None, _lib.ptr(loss), _lib.ptr(ws),
-                                                  ws.numel(), _lib.stream()), "gda_mmd_finalize_f32")
-            loss.record_stream(side)
-            _pending_streams.append(side)
-        else:
-            with profiler.region("mmd_fwd", 4, 0, times * (3 * m * m * d // 2 + 12 * m * m)):
-                _lib.check(L.gda_mmd_fwd_gather_f32(
-                    _lib.ptr(src), d, _lib.ptr(tgt), d, d, _lib.ptr(idx_s), _lib.ptr(idx_t), times, n, float(kernel_mul),
-                    int(kernel_num), float(fix_sigma) if fix_sigma else 0.0, float(scale), _lib.ptr(addc),
-                    _lib.ptr(rows_s), _lib.ptr(rows_t), _lib.ptr(loss), _lib.ptr(bw), _lib.ptr(l2), _lib.ptr(ws), ws.numel(),
-                    _lib.stream()), "gda_mmd_fwd_gather_f32")
+                int(kernel_num), float(fix_sigma) if fix_sigma else 0.0, float(scale), _lib.ptr(addc),
+                _lib.ptr(rows_s), _lib.ptr(rows_t), _lib.ptr(loss), _lib.ptr(bw), _lib.ptr(l2), _lib.ptr(ws), ws.numel(),
+                _lib.stream()), "gda_mmd_fwd_gather_f32")
         if rows_s is not None:
             src, tgt = rows_s, rows_t
         ctx.save_for_backward(src, tgt, src_idx, tgt_idx, bw, l2)
@@ -613,7 +575,7 @@ class _MMD(torch.autograd.Function):
         ws = _lib.workspace(L.gda_mmd_workspace_bytes(times, n, d), dev, "mmd")
         idx_s, idx_t = (src_idx, tgt_idx) if ctx.in_kernel else (None, None)
         g_add = gl if ctx.has_add else None
-        tail = (None,) * 9 + (g_add, None)
+        tail = (None,) * 9 + (g_add,)
         if src_idx is not None and ctx.sel is not None and MMD_SCATTER_FUSED:
             # row gradients summed straight onto the sampled feature rows (segment reduce + scatter in one kernel)
             s_rp, s_ci, t_rp, t_ci, _ones = ctx.sel
@@ -795,7 +757,7 @@ def mmd_loss_rows(source_rows, target_rows, kernel_mul=2.0, kernel_num=5, fix_si
 
 
 def mmd_loss(source_feat, target_feat, src_idx=None, tgt_idx=None, kernel_mul=2.0, kernel_num=5,
-             fix_sigma=None, sel=None, scale=1.0, add=None, defer_value=False):
+             fix_sigma=None, sel=None, scale=1.0, add=None):
     """Sampled multi-kernel MMD (mmd.py:57-159).  ``src_idx/tgt_idx``: ``[times, n]`` int64
     device tensors of row samples, or both ``None`` for get_MMD on the rows as given."""
     if (src_idx is None) != (tgt_idx is None):
@@ -814,7 +776,7 @@ def mmd_loss(source_feat, target_feat, src_idx=None, tgt_idx=None, kernel_mul=2.
         times, n = src_idx.shape
         src_idx, tgt_idx = src_idx.contiguous(), tgt_idx.contiguous()
     return _MMD.apply(source_feat, target_feat, src_idx, tgt_idx, int(times), int(n), kernel_mul,
-                      kernel_num, fix_sigma, sel, scale, add, bool(defer_value))
+                      kernel_num, fix_sigma, sel, scale, add)
 
 
 # ------------------------------------------------- GRL + discriminator + CE (fused) --

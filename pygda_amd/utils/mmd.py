@@ -32,11 +32,9 @@ sample_provider = None
 dp_index_provider = None       # data-parallel branch: (n_src, n_tgt, times, per) -> (idx_s, idx_t, sel_s, sel_t)
 
 
-def MMD(source_feat, target_feat, sampling_num=1000, times=5, *, scale=1.0, add=None, defer_value=False):
+def MMD(source_feat, target_feat, sampling_num=1000, times=5, *, scale=1.0, add=None):
     """``scale`` / ``add`` (keyword-only, not in the reference): return ``add + scale * MMD`` from the loss
     kernels themselves -- the trainers' ``loss = CE + MMD(...) * weight`` line without glue kernels.
-    ``defer_value`` (captured steps that hand their loss over as separate terms, hipgraph.LossTerms): the loss VALUE
-    may be finished on a side stream (ops.take_pending_streams); the caller must not read it on the current stream.
 
     Average of ``times`` MMDs over ``sampling_num`` rows drawn with replacement per
     domain (mmd.py:109-159).  The draws come from the CPU default generator exactly as in
@@ -73,7 +71,7 @@ def MMD(source_feat, target_feat, sampling_num=1000, times=5, *, scale=1.0, add=
         return out if add is None else add + out
     if sample_provider is not None:
         s_idx, t_idx, sel = sample_provider(source_feat.size(0), target_feat.size(0), times, sampling_num)
-        return mmd_loss(source_feat, target_feat, s_idx, t_idx, sel=sel, scale=scale, add=add, defer_value=defer_value)
+        return mmd_loss(source_feat, target_feat, s_idx, t_idx, sel=sel, scale=scale, add=add)
     source_sample = torch.randint(source_feat.size(0), (times, sampling_num))
     target_sample = torch.randint(target_feat.size(0), (times, sampling_num))
     from ..ops import mmd_samples_to_device
