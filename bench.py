@@ -375,6 +375,16 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src_file,
                        "launches": r["launches"], "avg_launch_us": r["avg_us"],
                        "algorithmic_bytes_per_launch": r["bytes"] / r["launches"]}
+                if name.startswith("spmm_interior") and "d=128" in name:
+                    # the committed rocprofv3 averages of the two kernels behind this region price the same launches
+                    ru, _, rf = rocprof_kernel("k_spmm_range<32, 4", "r[0-9]*_cfgS*_summary.json")
+                    cu, _, _ = rocprof_kernel("k_rows_copy_bias", "r[0-9]*_cfgS*_summary.json")
+                    if ru and cu:
+                        copies = r.get("copy_launches", 0)
+                        rp_secs = (ru * (r["launches"] - copies) + cu * copies) * 1e-6
+                        out["rocprof"] = {"k_spmm_range_avg_us": ru, "k_rows_copy_bias_avg_us": cu, "source": rf,
+                                          "region_us_from_rocprof": rp_secs * 1e6, "region_us_live": secs * 1e6,
+                                          "frac_rocprof": r["bytes"] / rp_secs / 1e9 / HBM_PEAK_GBS}
                 if r.get("alg_equiv_bytes"):
                     out["bytes_are"] = ("what the interior-rows K-step itself has to move (K steps over the rows that can "
                                         "change, every distinct row read once per step, + one pass over the leaves), NOT "

@@ -122,6 +122,21 @@ k_kstep_lds(const int2* __restrict__ ent, const unsigned* __restrict__ outa, con
     float* bufB = reinterpret_cast<float*>(lds + KS_OFFB);
     const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     const float* xc = xT + (int64_t)c * ldx;
+    // The slot program first: 2 R + S + 1 independent loads per lane (262 KB per workgroup at S = 8, L2-resident: every
+    // workgroup reads the same plan) are in flight while the column is loaded and placed -- they used to be issued
+    // behind the column's stores and the column-sum barrier, and the K = 0 cost of a launch was 7.8 us.
+    unsigned ea[R], oa[S];
+    float ew[R];
+    const int w = t >> 6, lane = t & 63;
+    {
+        const int2* ep = ent + ((size_t)w * R) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < R; ++j) { const int2 e = ep[(size_t)j * 64]; ea[j] = (unsigned)e.x + base; ew[j] = __int_as_float(e.y); }
+        const unsigned* op = outa + ((size_t)w * S) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) oa[s] = op[(size_t)s * 64] + base;
+    }
+    const unsigned keep = keepm[t];
     float csum = 0.f;
     for (int i = t * 4; i < n_pad; i += KS_TB * 4) {
         const float4 v = *reinterpret_cast<const float4*>(xc + i);
@@ -146,17 +161,10 @@ k_kstep_lds(const int2* __restrict__ ent, const unsigned* __restrict__ outa, con
             colsum[c] = sres;
         }
     }
-    unsigned ea[R], oa[S];
-    float ew[R];
-    const int w = t >> 6, lane = t & 63;
-    const int2* ep = ent + ((size_t)w * R) * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < R; ++j) { const int2 e = ep[(size_t)j * 64]; ea[j] = (unsigned)e.x + base; ew[j] = __int_as_float(e.y);
-        asm volatile("" : "+v"(ea[j])); }       // pin the sum in the register: no re-derivation from the symbol inside the loop
-    const unsigned* op = outa + ((size_t)w * S) * 64 + lane;
+    for (int j = 0; j < R; ++j) asm volatile("" : "+v"(ea[j]));   // pin the sums in registers: no re-derivation from the symbol inside the loop
 #pragma unroll
-    for (int s = 0; s < S; ++s) { oa[s] = op[(size_t)s * 64] + base; asm volatile("" : "+v"(oa[s])); }
-    const unsigned keep = keepm[t];
+    for (int s = 0; s < S; ++s) asm volatile("" : "+v"(oa[s]));
     uint2* hubtab = reinterpret_cast<uint2*>(lds + 2 * KS_OFFB + KS_RED_BYTES);
     if (t < hub_waves * 64) { uint2 h = hubp[t]; h.x += base; hubtab[t] = h; }
     const int wu = __builtin_amdgcn_readfirstlane(w);          // the wave's index as a scalar

@@ -218,8 +218,11 @@ def _launch_kstep_interior(graph, x, K, bias, transposed, y):
                 + 2 * n_leaf * row
         else:
             real = K * (nnz * 8 + min(nnz, n) * row + n_int * row + (n_int + 1) * 4) + 2 * n_leaf * row
+        # launches: forward = K (+ 1 with the hoisted leaf term) of k_spmm_range + ONE k_rows_copy_bias; transposed = K + 1
+        # of k_spmm_range (`copy_launches` lets the bench price the call with rocprofv3's per-kernel averages)
         ctx = profiler.region(f"spmm_interior_f32[d={d}]", K + (2 if hoist else 1), real, K * 2 * nnz * d,
-                              alg_equiv_bytes=K * (nnz * 8 + (n + 1) * 4 + 2 * n * d * 4))
+                              alg_equiv_bytes=K * (nnz * 8 + (n + 1) * 4 + 2 * n * d * 4),
+                              copy_launches=0 if transposed else 1)
     else:
         ctx = profiler.region("", 0)
     tmp = torch.empty(n_int, d, dtype=torch.float32, device=x.device) if K > 1 and n_int else None
