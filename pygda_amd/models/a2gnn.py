@@ -32,8 +32,10 @@ class A2GNN(BaseGDA):
         self.overlap_streams = os.environ.get("PYGDA_AMD_OVERLAP", "1") == "1"
         self.split_graphs = os.environ.get("PYGDA_AMD_SPLIT_GRAPHS", "0") == "1"   # measured slower: opt-in
         # sampled mini-batches: the source branch (s_pnums = 0: projections and activations, chip-filling kernels) beside
-        # the target branch (K-step launches over ~17 k interior rows: latency-sized) on two streams
-        self.overlap_sampled = os.environ.get("PYGDA_AMD_SAMPLED_OVERLAP", "0") == "1"
+        # the target branch (K-step launches over ~17 k interior rows: latency-sized) on two streams -- cfg-S, 40 steps,
+        # three runs each on one box: 2.88 / 2.98 / 2.92 ms/step against 3.10 / 3.11 / 4.11 on one stream
+        # (profiles/r4_stream_experiments.txt); eager launches, so none of the forked-graph scheduling of DESIGN 4.7
+        self.overlap_sampled = os.environ.get("PYGDA_AMD_SAMPLED_OVERLAP", "1") == "1"
 
     def init_model(self, **kwargs):
         return A2GNNBase(in_dim=self.in_dim, hid_dim=self.hid_dim, num_classes=self.num_classes,
@@ -170,6 +172,12 @@ class A2GNN(BaseGDA):
         evaluated once per domain and shared by the passes that the reference runs separately
         (source: logits :181 and features :192; target: features :193 and logits :211) -- same
         values, 10 aggregations and two layer-0 projections fewer per step."""
+        if (not self.adv and self.mode == 'node' and source_data.x.is_cuda
+                and (getattr(source_data, "n_id", None) is not None or getattr(target_data, "n_id", None) is not None)):
+            # sampled mini-batches (eager, host-bound): the MMD's draws + selection CSRs + staging copy are prepared on
+            # a helper thread beside the forward passes (utils.mmd.prefetch_samples: same draws, same order)
+            from ..utils.mmd import prefetch_samples
+            prefetch_samples(source_data.x.size(0), target_data.x.size(0), source_data.x.device)
         loss, source_logits, source_features, target_features, h0_t, pending, (sb, tb) = \
             self._branches(source_data, target_data)
         net = self.a2gnn

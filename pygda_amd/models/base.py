@@ -274,6 +274,8 @@ class BaseGDA(ABC):
                     p.copy_(v)
                     p.grad = None
                 for o in (optimizer, *extra):
+                    if hasattr(o, "_bumped"):
+                        o._bumped = None      # a bump whose step() never came (optim.Adam.bump_steps) must not leak into eager steps
                     for st in o.state.values():
                         for v in st.values():
                             if torch.is_tensor(v):

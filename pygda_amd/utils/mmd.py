@@ -32,6 +32,60 @@ sample_provider = None
 dp_index_provider = None       # data-parallel branch: (n_src, n_tgt, times, per) -> (idx_s, idx_t, sel_s, sel_t)
 
 
+# ---- the draws of the NEXT MMD() call, prepared beside the forward pass (eager sampled training) --------------------
+# MMD() draws its row samples from the CPU generator, builds the selection CSRs of their gradient scatter (a counting
+# sort over the batch's ~1.6e5 rows per domain) and ships 1.4 MB through a pinned block: 0.43 ms of host time per
+# cfg-S step, on the thread that also has to enqueue the step's ~60 launches -- and with the two branches on two
+# streams the step is host-bound.  A trainer that knows the row counts early (the batches' node counts, at the top of
+# forward_model) calls prefetch_samples(): a helper thread makes the SAME draws (nothing else reads the CPU generator
+# between the two points), the native counting sort and the staging copy release the GIL, and MMD() takes the finished
+# block.  Any mismatch (other counts, another device, a call in between) falls back to drawing in place.
+_prefetched = None
+PREFETCH = __import__("os").environ.get("PYGDA_AMD_MMD_PREFETCH", "1") == "1"
+
+
+def prefetch_samples(ns, nt, dev, sampling_num=1000, times=5):
+    global _prefetched
+    if (not PREFETCH or _prefetched is not None or distributed.active() or sample_provider is not None
+            or torch.device(dev).type != "cuda"):
+        return
+    import threading
+    stream = torch.cuda.current_stream(dev)
+    box = {}
+
+    def work():
+        try:
+            with torch.cuda.device(dev), torch.cuda.stream(stream):
+                s_cpu = torch.randint(ns, (times, sampling_num))
+                t_cpu = torch.randint(nt, (times, sampling_num))
+                from ..ops import mmd_samples_to_device
+                box["out"] = mmd_samples_to_device(s_cpu, t_cpu, ns, nt, torch.device(dev))
+        except BaseException as exc:          # surfaced by the consumer
+            box["err"] = exc
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    _prefetched = (ns, nt, times, sampling_num, str(torch.device(dev)), th, box)
+
+
+def _take_prefetched(ns, nt, times, sampling_num, dev):
+    global _prefetched
+    hit, _prefetched = _prefetched, None
+    if hit is None:
+        return None
+    hit[5].join()
+    if "err" in hit[6]:
+        raise hit[6]["err"]
+    if hit[:5] != (ns, nt, times, sampling_num, str(torch.device(dev))):
+        # left over from a forward pass that never reached its MMD() (an exception in between): its draws are spent,
+        # this call makes its own
+        import warnings
+        warnings.warn("MMD(): discarding row samples prefetched for another call "
+                      f"({hit[:4]} against {(ns, nt, times, sampling_num)})")
+        return None
+    return hit[6]["out"]
+
+
 def MMD(source_feat, target_feat, sampling_num=1000, times=5, *, scale=1.0, add=None):
     """``scale`` / ``add`` (keyword-only, not in the reference): return ``add + scale * MMD`` from the loss
     kernels themselves -- the trainers' ``loss = CE + MMD(...) * weight`` line without glue kernels.
@@ -71,6 +125,10 @@ def MMD(source_feat, target_feat, sampling_num=1000, times=5, *, scale=1.0, add=
         return out if add is None else add + out
     if sample_provider is not None:
         s_idx, t_idx, sel = sample_provider(source_feat.size(0), target_feat.size(0), times, sampling_num)
+        return mmd_loss(source_feat, target_feat, s_idx, t_idx, sel=sel, scale=scale, add=add)
+    ready = _take_prefetched(source_feat.size(0), target_feat.size(0), times, sampling_num, dev)
+    if ready is not None:
+        s_idx, t_idx, sel = ready
         return mmd_loss(source_feat, target_feat, s_idx, t_idx, sel=sel, scale=scale, add=add)
     source_sample = torch.randint(source_feat.size(0), (times, sampling_num))
     target_sample = torch.randint(target_feat.size(0), (times, sampling_num))

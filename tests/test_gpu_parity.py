@@ -1199,6 +1199,38 @@ def test_fused_adam_matches_torch_adam():
     assert float(o1.state[ours[3]]["step"]) == 3.0 and float(o1.state[ours[0]]["step"]) == 6.0
 
 
+def test_adam_step_counters_bumped_at_the_start_of_the_step():
+    """optim.Adam.bump_steps (gda_step_bump + gda_adam_multi_ex_f32, the captured step's order): the counters -- and
+    the dropout step counter handed in -- are incremented in one launch BEFORE the gradients exist, the update then
+    runs alone: bit-identical parameters, moments and counters to the plain step() over six steps, including a
+    parameter that ends some steps without a gradient (its increment is taken back) and one that never requires one."""
+    from pygda_amd.optim import Adam
+    gen = torch.Generator().manual_seed(9)
+    shapes = [(300, 128), (128,), (5,), (7, 3)]
+    init = [torch.randn(s, generator=gen) for s in shapes]
+    a = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    b = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    frozen_a, frozen_b = torch.nn.Parameter(torch.ones(4, device=DEV), requires_grad=False), torch.nn.Parameter(torch.ones(4, device=DEV), requires_grad=False)
+    oa, ob = Adam(a + [frozen_a], lr=0.01, weight_decay=0.005), Adam(b + [frozen_b], lr=0.01, weight_decay=0.005)
+    counter = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for step in range(6):
+        assert oa.bump_steps(counter) is True
+        for k in range(len(shapes)):
+            g = None if (k == 2 and step % 2 == 1) else torch.randn(shapes[k], generator=gen).to(DEV)
+            a[k].grad = g
+            b[k].grad = None if g is None else g.clone()
+        oa.step(); ob.step()
+    assert int(counter) == 6
+    for x, y in zip(a, b):
+        exact(x, y)
+        for key in ("step", "exp_avg", "exp_avg_sq"):
+            exact(oa.state[x][key], ob.state[y][key])
+    assert float(oa.state[a[2]]["step"]) == 3.0 and float(oa.state[a[0]]["step"]) == 6.0
+    # an optimiser that lists a Parameter twice (UDAGCN) keeps the in-step increment
+    dup = torch.nn.Parameter(torch.ones(8, device=DEV))
+    assert Adam([dup, dup], lr=0.01).bump_steps() is False
+
+
 @pytest.mark.parametrize("M,N,K", [(9360, 128, 128), (5484, 5, 128), (1000, 130, 70), (77, 3, 5), (20000, 64, 256),
                                    (4_400_000, 8, 16)])          # > 65535 row tiles: rows ride on grid.x
 def test_tall_gemm_vs_fp64(M, N, K):
