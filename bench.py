@@ -655,18 +655,23 @@ def run_cfg_a(args, world, rank, dev, side=False):
             n_pad = (n + 3) // 4 * 4
             xT = torch.randn(d, n_pad, device=dev)
             yT = torch.empty_like(xT)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for rep in range(33):
-                if rep == 3:
-                    e0.record()
-                _ops._launch_kstep_lds(g, plan, slots, xT, hp["t_pnums"], None, False, yT, x_colmajor=True, y_colmajor=True)
-            e1.record()
-            torch.cuda.synchronize()
-            return 1e3 * e0.elapsed_time(e1) / 30
+            from pygda_amd import _lib as _L
+            out = []
+            for K_ in (hp["t_pnums"], 0):      # K = 0: plan load + column load / store only (the launch's fixed cost)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for rep in range(33):
+                    if rep == 3:
+                        e0.record()
+                    _L.check(_L.lib().gda_kstep_lds_colmajor_f32(_L.ptr(plan), slots, n, d, K_, _L.ptr(xT), n_pad, _L.ptr(yT),
+                                                                 n_pad, None, None, _L.stream()), "gda_kstep_lds_colmajor_f32")
+                e1.record()
+                torch.cuda.synchronize()
+                out.append(1e3 * e0.elapsed_time(e1) / 30)
+            return tuple(out)
         except Exception:                     # noqa: BLE001 -- a side figure must not cost the line
-            return None
+            return None, None
 
-    alone_us = kstep_alone()
+    alone_us, fixed_us = kstep_alone()
 
     # committed PMC passes of this same command (profiles/, made by tools/profile_r3.sh)
     prof_pattern = "r[0-9]*_cfgA" + ("_powerlaw" if args.graph == "powerlaw" else "") + "_rocprof_summary.json"
@@ -702,6 +707,11 @@ def run_cfg_a(args, world, rank, dev, side=False):
                    "frac_back_to_back": (per_launch / (alone_us * 1e-6) / 1e9 / peak) if alone_us else None,
                    "lds_bytes_gathered_per_launch": per_launch, "launches": r["launches"],
                    "cus_occupied": cus, "frac_of_whole_chip": ach / LDS_READ_B32_PEAK_GBS}
+            if alone_us and fixed_us and alone_us > fixed_us:
+                # where the launch's time goes: K = 0 launches cost `fixed_us` (the slot program, 262 KB per workgroup,
+                # and the column in / out); the rest is the K step loops, whose LDS gather rate is the kernel's bound
+                out["back_to_back_launch_us_K0"] = fixed_us
+                out["frac_in_step_loops_back_to_back"] = per_launch / ((alone_us - fixed_us) * 1e-6) / 1e9 / peak
             out["traffic"], out["traffic_source"] = pmc_traffic("k_kstep_lds", prof_pattern)
             if r.get("hbm_bytes"):
                 out["hbm_bytes_per_launch"] = r["hbm_bytes"] / r["launches"]

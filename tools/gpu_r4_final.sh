@@ -3,5 +3,6 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
-python -m pytest tests -m gpu -q 2>&1 | tail -25 > $O/r4_final_tests.txt
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error|Error|FAILED" > $O/r4_final_tests.txt
 bash tools/profile_r4.sh > $O/r4_profile_session.log 2>&1
+python -c "import __graft_entry__ as g; g.smoke()" > $O/r4_smoke.txt 2>&1
