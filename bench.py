@@ -326,6 +326,14 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
             + f" reserved now {ms1.get('reserved_bytes.all.current', 0) / 2**30:.1f} GiB\n")
     log, ops.aggregation_log = ops.aggregation_log, None
     edges = sum(g.nnz * k for g, k in log)
+    if args.profile_run:
+        if rank != 0:
+            return None
+        return {"metric": "edges_aggregated_per_sec", "value": edges / dt, "unit": "edges/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "profile_run": True}
+    # the HIP-event pass below brackets kernel families on their launch stream: with the two branches on two streams an
+    # event pair also spans the other stream's kernels, so this pass runs the step on ONE stream
+    model.overlap_sampled = False
     # roofline inputs: a short pass of the same steps with HIP events around every kernel family (the timed
     # region above runs without them)
     from pygda_amd import profiler
@@ -595,6 +603,13 @@ def run_cfg_a(args, world, rank, dev, side=False):
                 "ms_per_step": 1e3 * dt / args.steps, "epochs_per_sec": args.steps / dt,
                 "edges_aggregated_per_sec_per_replica": executed * args.steps / dt, "replicas": world,
                 "execution": execution, "graph": args.graph}
+    if args.profile_run:
+        if rank != 0:
+            return None
+        return {"metric": "edges_aggregated_per_sec", "value": edges * args.steps / dt, "unit": "edges/s", "n_gpus": world,
+                "value_counts": "reference-equivalent edges (the executed count needs the eager bookkeeping pass this run skips)",
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "profile_run": True,
+                "execution": execution, "graph": args.graph}
     host_launch = None
     if graphed and hasattr(_g, "_refill") and hasattr(_g, "_replay"):
         # what the host pays per step: the refill (sample draws + H2D enqueue) and the hipGraphLaunch call itself,
@@ -851,6 +866,9 @@ def main():
     ap.add_argument("--side-steps", type=int, default=30)
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel code path (RCCL exchange steps) on a 1-rank group")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="for runs under rocprofv3: stop after the timed region (no eager HIP-event pass, no back-to-back "
+                         "kernel probes), so that the profiler's per-kernel averages are those of the replayed steps")
     ap.add_argument("--no-rccl-direct", action="store_true",
                     help="collectives through torch.distributed's ProcessGroup instead of the library-owned RCCL communicator")
     ap.add_argument("--rccl-direct", action="store_true",

@@ -212,3 +212,34 @@ def test_sampler_threads_divide_by_the_local_world_size(monkeypatch):
     assert sampler.default_threads() == 1
     monkeypatch.setenv("PYGDA_AMD_SAMPLER_THREADS", "3")
     assert sampler.default_threads() == 3
+
+
+def test_direct_communicator_falls_back_when_it_cannot_be_built(monkeypatch):
+    """distributed.direct(): the library-owned RCCL communicator is the default for nccl groups, but ANY failure to
+    build it (no librccl symbols, init error, failed self-test) is reported once and leaves every collective on the
+    torch.distributed ProcessGroup -- no second attempt, no exception into the training loop."""
+    import warnings
+    from pygda_amd import distributed as D
+    calls = []
+
+    def boom():
+        calls.append(1)
+        raise RuntimeError("librccl symbols not found")
+
+    monkeypatch.setattr(D, "active", lambda: True)
+    monkeypatch.setattr(D.dist, "get_backend", lambda *a, **k: "nccl")
+    monkeypatch.setattr(D, "_DirectComm", boom)
+    monkeypatch.setattr(D, "_direct", None)
+    monkeypatch.setattr(D, "_direct_failed", None)
+    monkeypatch.delenv("PYGDA_AMD_RCCL_DIRECT", raising=False)
+    with pytest.warns(UserWarning, match="library-owned RCCL communicator unavailable"):
+        assert D.direct() is None
+    assert "librccl symbols not found" in D._direct_failed and calls == [1]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert D.direct() is None and D.capture_collectives() is False      # remembered: silent, no retry
+    assert calls == [1]
+    # switched off by the environment: never even attempted
+    monkeypatch.setattr(D, "_direct_failed", None)
+    monkeypatch.setenv("PYGDA_AMD_RCCL_DIRECT", "0")
+    assert D.direct() is None and calls == [1]

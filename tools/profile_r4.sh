@@ -5,9 +5,9 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
-A="python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-hbm-probe --no-side-lines"
-AP="python bench.py --graph powerlaw --steps 40 --warmup 5 --no-cpu-baseline --no-hbm-probe --no-side-lines"
-C="python bench.py --workload cfgS --steps 30 --warmup 5 --no-cpu-baseline"
+A="python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-hbm-probe --no-side-lines --profile-run"
+AP="python bench.py --graph powerlaw --steps 40 --warmup 5 --no-cpu-baseline --no-hbm-probe --no-side-lines --profile-run"
+C="python bench.py --workload cfgS --steps 30 --warmup 5 --no-cpu-baseline --profile-run"
 prof() {   # tag cmd...
   tag=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- "$@" > $O/prof_${tag}_out.txt 2> $O/prof_${tag}.err
