@@ -231,7 +231,9 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // k_rowstats): the staging loads are branch-free (row index clamped, the piece zeroed on its way into LDS), those of
 // chunk k + 1 are issued before chunk k's MFMAs, and no thread walks a norm chain between the barrier and the MFMAs.
 template <int KN, bool SQ, bool FAST>
-__global__ void __launch_bounds__(TB)
+// round 4: asked for eight workgroups per CU the compiler fits the kernel into 63 registers, accumulators included, without a
+// spill (unhinted: 80 + 16 = five waves per SIMD) -- this kernel lives on occupancy (see the 128-tile experiment)
+__global__ void __launch_bounds__(TB, 8)
 k_pairdist(Rows R, int64_t d, int64_t m, int nt, const float* __restrict__ bandwidth, KParams kp,
            float* __restrict__ l2, double* __restrict__ partial, const float* __restrict__ norms) {
     __shared__ __attribute__((aligned(16))) float As[DK][LDT];   // As[k][row i of the tile]
