@@ -643,6 +643,24 @@ int gda_allgather_f32(const float* send, float* recv, int64_t count_per_rank, gd
                       gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
+ * View attention of UDAGCN's dual-view encoder (pygda/nn/attention.py:51-54):
+ *   stacked = stack(inputs, dim=1); weights = softmax(dense_weight(stacked), dim=1); out = sum(stacked * weights, dim=1)
+ * fused: s_k = x_k . w + b, a = softmax_k(s), out = sum_k a_k x_k, one pass each way, no [N, K, h] temporary.
+ *   x     HOST array of n_views (2..4) device pointers, view k = [n, h] rows with leading dimension ld[k]
+ *   w [h], b [1]   dense_weight.weight / .bias (device);  att [n, n_views] receives the weights (kept for backward)
+ * Backward: gx[k] ([n, h] contiguous, or NULL for a view that needs no gradient), gw [h], gb [1]; fixed-order sums
+ * (scratch from gda_attention_workspace_bytes).  h % 4 == 0, h <= 512, 16-byte aligned rows, else GDA_E_UNSUPPORTED.
+ * ---------------------------------------------------------------------------- */
+size_t gda_attention_workspace_bytes(int64_t n, int64_t h);
+int gda_attention_fuse_fwd_f32(int n_views, const float* const* x /* HOST array */, const int64_t* ld /* HOST array */,
+                               int64_t n, int64_t h, const float* w, const float* b, float* out, int64_t ldo,
+                               float* att, gda_stream_t stream);
+int gda_attention_fuse_bwd_f32(int n_views, const float* const* x /* HOST array */, const int64_t* ld /* HOST array */,
+                               int64_t n, int64_t h, const float* w, const float* att, const float* gout, int64_t ldg,
+                               float* const* gx /* HOST array */, float* gw, float* gb,
+                               void* workspace, size_t workspace_bytes, gda_stream_t stream);
+
+/* ------------------------------------------------------------------------------
  * Step epilogue: the Adam update.
  *
  * gda_adam_multi_f32: one torch.optim.Adam step (amsgrad off, maximize off) over up to

@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgda_hip.so")
-SOURCES = ["gda_graph.hip", "gda_spmm.hip", "gda_kstep.hip", "gda_mmd.hip", "gda_disc.hip", "gda_disc_mlp.hip", "gda_critic.hip", "gda_mixup.hip", "gda_misc.hip", "gda_gat.hip", "gda_act.hip",
+SOURCES = ["gda_graph.hip", "gda_spmm.hip", "gda_kstep.hip", "gda_mmd.hip", "gda_disc.hip", "gda_disc_mlp.hip", "gda_critic.hip", "gda_mixup.hip", "gda_misc.hip", "gda_gat.hip", "gda_act.hip", "gda_attention.hip",
            "gda_laplacian.hip", "gda_optim.hip", "gda_gemm.hip", "gda_ce.hip", "gda_ppmi_dev.hip", "gda_dsampler.hip", "gda_sampler.cpp", "gda_ppmi.cpp", "gda_smooth.cpp", "gda_comm.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wno-unused-result", "-Wno-unused-value"]

@@ -136,6 +136,9 @@ _SIGNATURES = {
     "gda_gemm_tall_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64]),
     "gda_gemm_tall_f32": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, _P,
                                   _P, c_size_t, _P]),
+    "gda_attention_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "gda_attention_fuse_fwd_f32": (c_int, [c_int, _P, _P, c_int64, c_int64, _P, _P, _P, c_int64, _P, _P]),
+    "gda_attention_fuse_bwd_f32": (c_int, [c_int, _P, _P, c_int64, c_int64, _P, _P, _P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "gda_adam_multi_f32": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, c_float, _P]),
     "gda_adam_multi_ex_f32": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
     "gda_step_bump": (c_int, [_P, _P, c_int, _P]),

@@ -1436,3 +1436,58 @@ class _BernFilter(torch.autograd.Function):
 
 def bern_filter(x, temp, graph: CSRGraph, coefs):
     return _BernFilter.apply(x, temp, graph, coefs)
+
+
+# ------------------------------------------------- view attention (UDAGCN's dual-view encoder) --
+class _AttentionFuse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, b, *views):
+        L = _lib.lib()
+        xs = [_f32c(v, "view") for v in views]
+        n, h = xs[0].shape
+        K = len(xs)
+        w1 = _f32c(w, "dense_weight.weight").reshape(-1)
+        b1 = _f32c(b, "dense_weight.bias").reshape(-1)
+        out = torch.empty(n, h, dtype=torch.float32, device=xs[0].device)
+        att = torch.empty(n, K, dtype=torch.float32, device=xs[0].device)
+        ptrs = (ctypes.c_void_p * K)(*[x.data_ptr() for x in xs])
+        lds = (ctypes.c_int64 * K)(*[h] * K)
+        _lib.check(L.gda_attention_fuse_fwd_f32(K, ptrs, lds, n, h, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(out), h,
+                                                _lib.ptr(att), _lib.stream()), "gda_attention_fuse_fwd_f32")
+        ctx.save_for_backward(w1, att, *xs)
+        ctx.w_shape, ctx.b_shape = w.shape, b.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        w1, att, *xs = ctx.saved_tensors
+        n, h = xs[0].shape
+        K = len(xs)
+        g = _f32c(g, "grad")
+        gxs = [torch.empty_like(x) if ctx.needs_input_grad[2 + k] else None for k, x in enumerate(xs)]
+        gw = torch.empty(h, dtype=torch.float32, device=g.device)
+        gb = torch.empty(1, dtype=torch.float32, device=g.device)
+        ws = _lib.workspace(L.gda_attention_workspace_bytes(n, h), g.device, "attention")
+        ptrs = (ctypes.c_void_p * K)(*[x.data_ptr() for x in xs])
+        gptrs = (ctypes.c_void_p * K)(*[None if t is None else t.data_ptr() for t in gxs])
+        lds = (ctypes.c_int64 * K)(*[h] * K)
+        _lib.check(L.gda_attention_fuse_bwd_f32(K, ptrs, lds, n, h, _lib.ptr(w1), _lib.ptr(att), _lib.ptr(g), h, gptrs,
+                                                _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), ws.numel() if ws is not None else 0,
+                                                _lib.stream()), "gda_attention_fuse_bwd_f32")
+        return (gw.view(ctx.w_shape), gb.view(ctx.b_shape), *gxs)
+
+
+def attention_fuse_ok(views, w):
+    """Shapes the fused view-attention kernels cover (csrc/gda_attention.hip)."""
+    if not (2 <= len(views) <= 4):
+        return False
+    v0 = views[0]
+    return (all(torch.is_tensor(v) and v.is_cuda and v.dtype == torch.float32 and v.dim() == 2 and v.shape == v0.shape
+                for v in views) and v0.size(1) % 4 == 0 and 0 < v0.size(1) <= 512 and w.numel() == v0.size(1))
+
+
+def attention_fuse(views, w, b):
+    """``sum(stack(views, 1) * softmax(Linear(h, 1)(stack(views, 1)), 1), 1)`` (pygda/nn/attention.py:51-54), fused."""
+    return _AttentionFuse.apply(w, b, *views)
+

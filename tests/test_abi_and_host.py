@@ -192,6 +192,17 @@ def test_round4_entry_points_validate_before_touching_a_device():
     assert L.gda_step_bump(None, arr, 2, None) == -4          # the same counter twice
     arr = (ctypes.c_void_p * 2)(one, None)
     assert L.gda_step_bump(None, arr, 2, None) == -1
+    # fused view attention (csrc/gda_attention.hip)
+    two = (ctypes.c_void_p * 2)(ctypes.c_void_p(16), ctypes.c_void_p(32))
+    ld = (ctypes.c_int64 * 2)(128, 128)
+    assert L.gda_attention_workspace_bytes(9360, 128) == ((9360 + 7) // 8) * 129 * 4
+    assert L.gda_attention_fuse_fwd_f32(1, two, ld, 10, 128, one, one, one, 128, one, None) == -4          # one view
+    assert L.gda_attention_fuse_fwd_f32(2, two, ld, 10, 130, one, one, one, 130, one, None) == -4          # h % 4
+    assert L.gda_attention_fuse_fwd_f32(2, two, ld, 10, 516, one, one, one, 516, one, None) == -4          # h > 512
+    assert L.gda_attention_fuse_fwd_f32(2, None, ld, 10, 128, one, one, one, 128, one, None) == -1
+    assert L.gda_attention_fuse_fwd_f32(2, two, ld, 10, 128, None, one, one, 128, one, None) == -1
+    assert L.gda_attention_fuse_fwd_f32(2, two, ld, 0, 128, None, None, None, 128, None, None) == 0        # no rows
+    assert L.gda_attention_fuse_bwd_f32(2, two, ld, 10, 128, two, two, two, 128, two, two, two, None, 0, None) == -3   # workspace
     table = (_lib.AdamTensorStruct * 1)()
     assert L.gda_adam_multi_ex_f32(table, 1, 0.1, 0.9, 0.999, 1e-8, 0.0, 2, None) == -4   # flag
     assert L.gda_adam_multi_ex_f32(table, 0, 0.1, 0.9, 0.999, 1e-8, 0.0, 1, None) == 0

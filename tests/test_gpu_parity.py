@@ -1199,6 +1199,43 @@ def test_fused_adam_matches_torch_adam():
     assert float(o1.state[ours[3]]["step"]) == 3.0 and float(o1.state[ours[0]]["step"]) == 6.0
 
 
+@pytest.mark.parametrize("n,h,K", [(1, 8, 2), (37, 128, 2), (5000, 132, 3), (9360, 128, 2), (300, 512, 4)])
+def test_attention_fuse_vs_the_reference_lines(n, h, K):
+    """csrc/gda_attention.hip against pygda/nn/attention.py:51-54 evaluated by ATen (stack, Linear(h, 1), softmax over
+    the views, weighted sum): output, every view's gradient (one view without one), the score weight's and the bias's
+    gradient -- the latter is zero in exact arithmetic (softmax ignores a common shift) and stays at rounding level."""
+    from pygda_amd.ops import attention_fuse, attention_fuse_ok
+    gen = torch.Generator().manual_seed(n + h + K)
+    views = [torch.randn(n, h, generator=gen) for _ in range(K)]
+    w, b = torch.randn(1, h, generator=gen) * 0.3, torch.randn(1, generator=gen)
+    gy = torch.randn(n, h, generator=gen)
+    ref_v = [v.clone().double().requires_grad_(k != 1) for k, v in enumerate(views)]
+    rw, rb = w.clone().double().requires_grad_(), b.clone().double().requires_grad_()
+    stacked = torch.stack(ref_v, dim=1)
+    want = torch.sum(stacked * torch.softmax(torch.nn.functional.linear(stacked, rw, rb), dim=1), dim=1)
+    want.backward(gy.double())
+    dv = [v.to(DEV).requires_grad_(k != 1) for k, v in enumerate(views)]
+    dw, db = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    assert attention_fuse_ok(dv, dw)
+    got = attention_fuse(dv, dw, db)
+    got.backward(gy.to(DEV))
+    close(got, want.float(), rtol=1e-5, atol=1e-5)
+    for k in range(K):
+        if k == 1:
+            assert dv[k].grad is None
+        else:
+            close(dv[k].grad, ref_v[k].grad.float(), rtol=1e-5, atol=1e-5)
+    scale = max(float(rw.grad.abs().max()), 1e-3)
+    close(dw.grad, rw.grad.float(), rtol=1e-4, atol=1e-5 * scale * max(1.0, n ** 0.5))
+    assert abs(float(db.grad)) <= 1e-4 * max(1.0, float(rw.grad.abs().max()))
+    # the module takes the fused path for device views and returns what the composition returns
+    att = pygda_amd.nn.Attention(h).to(DEV)
+    with torch.no_grad():
+        att.dense_weight.weight.copy_(dw); att.dense_weight.bias.copy_(db)
+    close(att([v.detach() for v in dv]), want.float(), rtol=1e-5, atol=1e-5)
+    assert not attention_fuse_ok([torch.randn(4, 6, device=DEV)] * 2, torch.randn(1, 6, device=DEV))   # h % 4: composition
+
+
 def test_adam_step_counters_bumped_at_the_start_of_the_step():
     """optim.Adam.bump_steps (gda_step_bump + gda_adam_multi_ex_f32, the captured step's order): the counters -- and
     the dropout step counter handed in -- are incremented in one launch BEFORE the gradients exist, the update then
