@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
 FP32_MFMA_PEAK_TF = 157.3      # v_mfma_f32_32x32x2_f32 dense peak
+F16_MFMA_PEAK_TF = 2500.0      # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md: ~2.5 PF, measured 2178-2382)
 LDS_READ_B32_PEAK_GBS = 128 * 256 * 2.4   # ds_read_b32: 128 B/clk/CU (MI355X_MICROARCH.md, LDS table) x 256 CUs x 2.4 GHz
 
 
@@ -417,6 +418,11 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
             "metric": "edges_aggregated_per_sec", "value": edges / dt, "unit": "edges/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": ("fp32 values everywhere; the MMD's two pair products run as three fp16 MFMAs on split operands (hi + lo, 22 "
+                       "significant bits, fp32 accumulation) when the one-pass kernel covers the shape -- error against float64 "
+                       "equal to the fp32-MFMA kernels' (profiles/r4_mmd_one_pass_experiments.txt); PYGDA_AMD_MMD_ONE_PASS=0 "
+                       "runs those instead"),
+           
             "config": {"workload": f"cfg-S: A2GNN on synthetic source+target graphs, {args.nodes} nodes / "
                                    f"{args.nodes * args.avg_degree} directed edges per domain, F={args.feat}, nhid=128, "
                                    f"L=2, s_pnums=0, t_pnums=10, NeighborLoader fan-out {fan}, {args.batch} seeds per GPU "
@@ -766,6 +772,10 @@ def run_cfg_a(args, world, rank, dev, side=False):
         "metric": "edges_aggregated_per_sec", "value": executed * args.steps / dt, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "dtype_note": ("fp32 values everywhere; the MMD's two pair products run as three fp16 MFMAs on split operands (hi + lo, 22 "
+                       "significant bits, fp32 accumulation) when the one-pass kernel covers the shape -- error against float64 "
+                       "equal to the fp32-MFMA kernels' (profiles/r4_mmd_one_pass_experiments.txt); PYGDA_AMD_MMD_ONE_PASS=0 "
+                       "runs those instead"),
         "data": "synthetic",
         "config": {"workload": f"cfg-A: A2GNN ACMv9->DBLPv7 ({graph_note}, "
                                "Ns=9360/Es=15556, Nt=5484/Et=8117, F=6775), nhid=128, L=2, s_pnums=0, "
@@ -806,16 +816,40 @@ def run_cfg_a(args, world, rank, dev, side=False):
         # brackets cover the whole C call (forward = 4 kernels, backward = 2)
         times, m_rows, dd = 5, 2000, hp["hid"]
         full = 2.0 * m_rows * m_rows * dd * times
-        mm = {"shape": {"times": times, "m": m_rows, "d": dd}, "bound": "mfma", "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-              "flops_full_product": full,
-              "live_call_us": {"mmd_fwd[rowstats+bandwidth+pairdist+finalize]": prof["mmd_fwd"]["ms"] * 1e3 / max(prof["mmd_fwd"]["calls"], 1),
-                               "mmd_bwd[k_bwd+scatter]": prof.get("mmd_bwd", {}).get("ms", 0.0) * 1e3 / max(prof.get("mmd_bwd", {}).get("calls", 1), 1)}}
-        for key, prefix, flops in (("k_pairdist", "k_pairdist<", full * (m_rows / 64 + 1) / (2 * m_rows / 64)),
-                                   ("k_bwd", "k_bwd<", full)):
-            us, calls, fname = rocprof_kernel(prefix, prof_pattern)
+        from pygda_amd import ops as _ops
+        one_pass = _ops.mmd_one_pass_segments(times, m_rows // 2, dd) > 0
+        per_call = lambda k: prof.get(k, {}).get("ms", 0.0) * 1e3 / max(prof.get(k, {}).get("calls", 1), 1)
+        if one_pass:
+            # ONE pass over the pairs (csrc/gda_mmd_fused.inc): distance product + gradient product, the full matrix each
+            # (2 x `full`), on the 16-bit matrix cores with split operands -- three fp16 MFMAs per fp32-equivalent product.
+            # `frac` prices the MFMAs it executes against the fp16 roof; `fp32_equivalent` prices the product it
+            # stands for against the fp32-MFMA roof the two-pass kernels run under (it may exceed 1: that is the point).
+            mm = {"shape": {"times": times, "m": m_rows, "d": dd}, "path": "one pass, split-fp16 MFMA (3 products per pair)",
+                  "bound": "mfma", "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s", "flops_full_product": full,
+                  "live_call_us": {"mmd_fwd[tile_stats+bw_split+fused+finalize]": per_call("mmd_fwd"),
+                                   "mmd_bwd[scatter]": per_call("mmd_bwd")}}
+            us, calls, fname = rocprof_kernel("k_mmd_fused<", prof_pattern)
             if us:
-                mm[key] = {"avg_launch_us_rocprof": us, "source": fname, "flops_executed": flops,
-                           "achieved": flops / (us * 1e-6) / 1e12, "frac": flops / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF}
+                mm["k_mmd_fused"] = {"avg_launch_us_rocprof": us, "source": fname, "flops_executed": 3 * 2 * full,
+                                     "achieved": 3 * 2 * full / (us * 1e-6) / 1e12,
+                                     "frac": 3 * 2 * full / (us * 1e-6) / 1e12 / F16_MFMA_PEAK_TF,
+                                     "fp32_equivalent": {"flops": 2 * full, "achieved": 2 * full / (us * 1e-6) / 1e12,
+                                                         "frac_of_fp32_mfma_peak": 2 * full / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF}}
+            for key, prefix in (("k_tile_stats", "k_tile_stats<"), ("k_bw_split", "k_bw_split<"), ("k_bwd_scatter", "k_bwd_scatter<")):
+                us, calls, fname = rocprof_kernel(prefix, prof_pattern)
+                if us:
+                    mm[key] = {"avg_launch_us_rocprof": us, "source": fname}
+        else:
+            mm = {"shape": {"times": times, "m": m_rows, "d": dd}, "path": "two passes, fp32 MFMA", "bound": "mfma",
+                  "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "flops_full_product": full,
+                  "live_call_us": {"mmd_fwd[rowstats+bandwidth+pairdist+finalize]": per_call("mmd_fwd"),
+                                   "mmd_bwd[k_bwd+scatter]": per_call("mmd_bwd")}}
+            for key, prefix, flops in (("k_pairdist", "k_pairdist<", full * (m_rows / 64 + 1) / (2 * m_rows / 64)),
+                                       ("k_bwd", "k_bwd<", full)):
+                us, calls, fname = rocprof_kernel(prefix, prof_pattern)
+                if us:
+                    mm[key] = {"avg_launch_us_rocprof": us, "source": fname, "flops_executed": flops,
+                               "achieved": flops / (us * 1e-6) / 1e12, "frac": flops / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF}
         out["roofline_mmd"] = mm
     if host_launch is not None:
         out["host_per_step"] = host_launch

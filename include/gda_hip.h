@@ -301,6 +301,31 @@ int gda_mmd_bwd_ex_f32(const float* src, int64_t ld_src, const float* tgt, int64
                        const int32_t* sel_t_rowptr, const int32_t* sel_t_col, int64_t n_tgt_rows, float* gtgt,
                        void* workspace, size_t workspace_bytes, gda_stream_t stream);
 
+/* The same loss and gradients in ONE pass over the row pairs (round 4): the kernel weights d K / d L2 are consumed where
+ * they are produced -- multiplied into the rows on the 16-bit matrix cores -- instead of travelling through a
+ * [times, 2n, 2n] matrix.  Both products run on fp16 MFMAs with SPLIT operands (a = hi + lo, three products per pair,
+ * fp32 accumulation: 22 significant bits per operand, an error of the order of an fp32 sum in another order; the rows
+ * are scaled by one power of two per resample first, so fp16's exponent range never matters).  Covered:
+ * kernel_num = 5 with kernel_mul = 2 (every pygda call: mmd.py:57-63 defaults), d in {32, 64, 96, 128}, rows on
+ * 16-byte boundaries; gda_mmd_fused_nseg() returns 0 for anything else (use gda_mmd_fwd_gather_f32 / gda_mmd_bwd_ex_f32).
+ *   grad_part   [times, nseg, 2n, d] fp32 (device; nseg = gda_mmd_fused_nseg(...)): UNSCALED row-gradient partials,
+ *               produced by fwd, consumed by bwd (which multiplies by 4 * grad_loss * scale / (n^2 times), folds the
+ *               segments in order and, given the selection CSRs, scatters onto the feature rows).  Opaque.
+ *   workspace   gda_mmd_workspace_bytes(times, n, d) bytes, as for the two-pass calls
+ * src_idx / tgt_idx need rows_src / rows_tgt (the gathered copy) here. */
+int gda_mmd_fused_nseg(int times, int64_t n, int64_t d, float kernel_mul, int kernel_num);
+int gda_mmd_fused_fwd_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
+                          int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
+                          int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
+                          float scale, const float* add, float* rows_src, float* rows_tgt,
+                          float* loss, float* bandwidth, float* grad_part, int nseg,
+                          void* workspace, size_t workspace_bytes, gda_stream_t stream);
+int gda_mmd_fused_bwd_f32(const float* grad_part, int nseg, int times, int64_t n, int64_t d,
+                          const float* grad_loss, float scale, float* grad_rows,
+                          const int32_t* sel_s_rowptr, const int32_t* sel_s_col, int64_t n_src_rows, float* gsrc,
+                          const int32_t* sel_t_rowptr, const int32_t* sel_t_col, int64_t n_tgt_rows, float* gtgt,
+                          gda_stream_t stream);
+
 /* ------------------------------------------------------------------------------
  * Gradient-reversal + linear domain discriminator + softmax cross-entropy, fused.
  *

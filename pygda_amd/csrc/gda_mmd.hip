@@ -106,8 +106,10 @@ constexpr int SR = 16;        // rows per k_rowstats workgroup (4 per thread: in
 // chunk (t, blockIdx.x): s1 = sum over its rows of |t_i - p|^2, col[c] = sum over its rows of (t_i - p)[c]
 __global__ void __launch_bounds__(TB)
 k_rowstats(Rows R, int64_t d, int64_t m, double* __restrict__ part_s1, float* __restrict__ part_col,
-           float* __restrict__ rows_src, float* __restrict__ rows_tgt, float* __restrict__ norms) {
+           float* __restrict__ rows_src, float* __restrict__ rows_tgt, float* __restrict__ norms,
+           float* __restrict__ part_max) {
     __shared__ double red[TB / 64];
+    __shared__ float redmax[TB / 64];
     __shared__ float colsh[TB / 64][64];
     extern __shared__ float rs_tile[];                    // [SR][d + 1] shifted rows, only when `norms` is asked for
     const int64_t ldt = d + 1;
@@ -116,7 +118,7 @@ k_rowstats(Rows R, int64_t d, int64_t m, double* __restrict__ part_s1, float* __
     const int lane = threadIdx.x % 64, rg = threadIdx.x / 64;
     const float* pivot = row_ptr(R, t, 0);
     float* out = part_col + ((int64_t)t * gridDim.x + blockIdx.x) * d;
-    float s1 = 0.f;
+    float s1 = 0.f, mx = 0.f;
     for (int64_t c0 = 0; c0 < d; c0 += 64) {
         const int64_t c = c0 + lane;
         float col = 0.f;
@@ -130,6 +132,7 @@ k_rowstats(Rows R, int64_t d, int64_t m, double* __restrict__ part_s1, float* __
                         (r < R.n ? rows_src + ((int64_t)t * R.n + r) * d : rows_tgt + ((int64_t)t * R.n + (r - R.n)) * d)[c] = raw;
                     const float v = raw - pv;
                     s1 = fmaf(v, v, s1);
+                    mx = fmaxf(mx, fabsf(v));
                     col += v;
                     if (norms) rs_tile[rr * ldt + c] = v;
                 }
@@ -149,8 +152,15 @@ k_rowstats(Rows R, int64_t d, int64_t m, double* __restrict__ part_s1, float* __
         for (int64_t k = 0; k < d; ++k) acc = fmaf(row[k], row[k], acc);
         norms[(int64_t)t * m + r0 + threadIdx.x] = acc;
     }
-    const double s = block_sum((double)s1, red);
-    if (threadIdx.x == 0) part_s1[(int64_t)t * gridDim.x + blockIdx.x] = s;
+    if (part_max) {                                       // largest |t_i - p| entry of the chunk: the fp16 split's scale (fused path)
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
+        if (lane == 0) redmax[rg] = mx;
+    }
+    const double s = block_sum((double)s1, red);           // (its barriers order redmax as well)
+    if (threadIdx.x == 0) {
+        part_s1[(int64_t)t * gridDim.x + blockIdx.x] = s;
+        if (part_max) part_max[(int64_t)t * gridDim.x + blockIdx.x] = fmaxf(fmaxf(redmax[0], redmax[1]), fmaxf(redmax[2], redmax[3]));
+    }
 }
 
 // bandwidth[t] = (sum_ij L2 + 1e-6) / (m^2 - m) / kernel_mul^(kernel_num/2)     (mmd.py:50-51)
@@ -674,13 +684,14 @@ k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* _
 // grad_rows = 4 * sum over segments (fixed order)
 __global__ void __launch_bounds__(TB)
 k_bwd_reduce(const float* __restrict__ part, int64_t per_t, int nseg, int times,
-             float* __restrict__ grad_rows) {
+             float* __restrict__ grad_rows, const float* __restrict__ grad_loss, float cmul) {
+    const float c4 = grad_loss ? 4.f * (grad_loss[0] * cmul) : 4.f;       // see k_bwd_scatter
     const int64_t total = per_t * times;
     for (int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x; k < total; k += (int64_t)gridDim.x * TB) {
         const int64_t t = k / per_t, r = k % per_t;
         float s = 0.f;
         for (int g = 0; g < nseg; ++g) s += part[(t * nseg + g) * per_t + r];
-        grad_rows[k] = 4.f * s;
+        grad_rows[k] = c4 * s;
     }
 }
 
@@ -693,7 +704,9 @@ __global__ void __launch_bounds__(TB)
 k_bwd_scatter(const float* __restrict__ part, int64_t m, int64_t d, int nseg_rt,
               const int32_t* __restrict__ s_rowptr, const int32_t* __restrict__ s_col, int64_t n_src_rows,
               float* __restrict__ gsrc, const int32_t* __restrict__ t_rowptr, const int32_t* __restrict__ t_col,
-              int64_t n_tgt_rows, float* __restrict__ gtgt) {
+              int64_t n_tgt_rows, float* __restrict__ gtgt, const float* __restrict__ grad_loss, float cmul) {
+    // the fused forward leaves UNSCALED partials: 4 * dloss * cmul is applied here (grad_loss NULL: k_bwd scaled them, 4 is left)
+    const float c4 = grad_loss ? 4.f * (grad_loss[0] * cmul) : 4.f;
     const int nseg = NSEG > 0 ? NSEG : nseg_rt;
     const int64_t rows_per_block = TB / 32;               // 32 lanes x float4 = one 128-wide row slab
     const int lane = threadIdx.x % 32;
@@ -724,8 +737,8 @@ k_bwd_scatter(const float* __restrict__ part, int64_t m, int64_t d, int nseg_rt,
                 float4 sg = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int g = 0; g < NSEG; ++g) { sg.x += v[g].x; sg.y += v[g].y; sg.z += v[g].z; sg.w += v[g].w; }
-                acc.x = __fadd_rn(acc.x, 4.f * sg.x); acc.y = __fadd_rn(acc.y, 4.f * sg.y);
-                acc.z = __fadd_rn(acc.z, 4.f * sg.z); acc.w = __fadd_rn(acc.w, 4.f * sg.w);
+                acc.x = __fadd_rn(acc.x, c4 * sg.x); acc.y = __fadd_rn(acc.y, c4 * sg.y);
+                acc.z = __fadd_rn(acc.z, c4 * sg.z); acc.w = __fadd_rn(acc.w, c4 * sg.w);
             }
             *reinterpret_cast<float4*>(out + c) = acc;
         }
@@ -742,7 +755,7 @@ k_bwd_scatter(const float* __restrict__ part, int64_t m, int64_t d, int nseg_rt,
                 for (int v = 0; v < 4; ++v) if (c + v < d) sg[v] += q[v];
             }
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc[v] = __fadd_rn(acc[v], __fmul_rn(1.0f, 4.f * sg[v]));
+            for (int v = 0; v < 4; ++v) acc[v] = __fadd_rn(acc[v], __fmul_rn(1.0f, c4 * sg[v]));
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) if (c + v < d) out[c + v] = acc[v];
@@ -781,7 +794,13 @@ int launch_bwd(dim3 grid, hipStream_t stream, Rows R, int64_t d, int64_t m, cons
     return GDA_OK;
 }
 
-struct MmdWs { double* kpartial; double* part_s1; float* part_col; float* bwd_part; float* norms; size_t total; };
+#include "gda_mmd_fused.inc"
+
+struct MmdWs {
+    double* kpartial; double* part_s1; float* part_col; float* bwd_part; float* norms;
+    float* part_max; float* xscale; unsigned char* images;      // the fused pass (NULL / empty when it does not cover the shape)
+    size_t total;
+};
 
 MmdWs carve(void* base, int times, int64_t n, int64_t d) {
     const int64_t m = 2 * n, nt = gda_cdiv(m, TILE);
@@ -793,11 +812,19 @@ MmdWs carve(void* base, int times, int64_t n, int64_t d) {
         return p;
     };
     const int64_t chunks = gda_cdiv(m, SR);
-    w.kpartial = (double*)take(sizeof(double) * times * nt * nt);
+    FusedPlan fp;
+    const bool fused = fused_plan(times, n, d, 2.0f, 5, &fp);
+    const int64_t per_t = fused && (int64_t)fp.njb * fp.nseg > nt * nt ? (int64_t)fp.njb * fp.nseg : nt * nt;
+    w.kpartial = (double*)take(sizeof(double) * times * per_t);
     w.part_s1 = (double*)take(sizeof(double) * times * chunks);
     w.part_col = (float*)take(sizeof(float) * times * chunks * (d > 0 ? d : 1));
     w.bwd_part = (float*)take(sizeof(float) * times * BWD_NSEG_MAX * m * (d > 0 ? d : 1));
     w.norms = (float*)take(sizeof(float) * times * m);
+    if (fused) {
+        w.part_max = (float*)take(sizeof(float) * times * chunks);
+        w.xscale = (float*)take(sizeof(float) * times);
+        w.images = (unsigned char*)take((size_t)times * fp.ntiles * fp.img);
+    }
     w.total = off;
     return w;
 }
@@ -874,7 +901,7 @@ extern "C" int gda_mmd_fwd_gather_f32(const float* src, int64_t ld_src, const fl
         GDA_LDS_ATTR_ONCE(k_rowstats, sizeof(float) * SR * 2049);
     }
     k_rowstats<<<dim3(chunks, (unsigned)times), TB, rs_lds, stream>>>(R, d, m, ws.part_s1, ws.part_col, rows_src, rows_tgt,
-                                                                    fast ? ws.norms : nullptr);
+                                                                    fast ? ws.norms : nullptr, nullptr);
     GDA_LAUNCH_CHECK();
     if (rows_src) R = make_rows(rows_src, d, rows_tgt, d, nullptr, nullptr, n);      // gathered: no index from here on
     k_bandwidth<<<(unsigned)times, BW_TB, 0, stream>>>(ws.part_s1, ws.part_col, (int)chunks, d, m, kp, bandwidth);
@@ -948,7 +975,7 @@ extern "C" int gda_mmd_bwd_ex_f32(const float* src, int64_t ld_src, const float*
             const bool quads = d % 4 == 0 && ((uintptr_t)ws.bwd_part % 16 == 0) && ((uintptr_t)gsrc % 16 == 0) &&
                                ((uintptr_t)gtgt % 16 == 0);
 #define GDA_SCATTER(NS) k_bwd_scatter<NS><<<sg, TB, 0, stream>>>(ws.bwd_part, m, d, nseg, sel_s_rowptr, sel_s_col, \
-                                                              n_src_rows, gsrc, sel_t_rowptr, sel_t_col, n_tgt_rows, gtgt)
+                                                              n_src_rows, gsrc, sel_t_rowptr, sel_t_col, n_tgt_rows, gtgt, nullptr, 1.f)
             if (quads && nseg == 6) GDA_SCATTER(6);
             else if (quads && nseg == 4) GDA_SCATTER(4);
             else GDA_SCATTER(0);
@@ -960,7 +987,121 @@ extern "C" int gda_mmd_bwd_ex_f32(const float* src, int64_t ld_src, const float*
     const int64_t total = (int64_t)times * m * d;
     int64_t rg = gda_cdiv(total, TB);
     if (rg > 4096) rg = 4096;
-    k_bwd_reduce<<<(unsigned)rg, TB, 0, stream>>>(ws.bwd_part, m * d, nseg, times, grad_rows);
+    k_bwd_reduce<<<(unsigned)rg, TB, 0, stream>>>(ws.bwd_part, m * d, nseg, times, grad_rows, nullptr, 1.f);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
+
+// ------------------------------------------------------------------ fused pass (gda_mmd_fused.inc) --
+extern "C" int gda_mmd_fused_nseg(int times, int64_t n, int64_t d, float kernel_mul, int kernel_num) {
+    FusedPlan fp;
+    return fused_plan(times, n, d, kernel_mul, kernel_num, &fp) ? fp.nseg : 0;
+}
+
+template <int NB>
+static int launch_fused(hipStream_t stream, const Rows& R, int64_t m, int chunks, const MmdWs& ws, KParams kp, const FusedPlan& fp,
+                        int times, float* bandwidth, float* grad_part) {
+    k_bw_split<NB><<<dim3((unsigned)fp.ntiles, (unsigned)times), TB, 0, stream>>>(R, m, chunks, ws.part_s1, ws.part_col, ws.part_max,
+                                                                             ws.norms, kp, bandwidth, ws.xscale, ws.images);
+    GDA_LAUNCH_CHECK();
+    const size_t lds = 2 * fp.img + sizeof(float) * 32 * (TB / 64);
+    GDA_LDS_ATTR_ONCE((k_mmd_fused<NB>), lds);
+    const unsigned grid = 8u * (unsigned)gda_cdiv(fp.total, 8);
+    k_mmd_fused<NB><<<grid, TB, lds, stream>>>(R, m, fp.ntiles, fp.njb, fp.nseg, fp.total, ws.images, bandwidth, ws.xscale,
+                                              grad_part, ws.kpartial);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+extern "C" int gda_mmd_fused_fwd_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
+                                     int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
+                                     int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
+                                     float scale, const float* add, float* rows_src, float* rows_tgt,
+                                     float* loss, float* bandwidth, float* grad_part, int nseg,
+                                     void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    int st = check_common(src, ld_src, tgt, ld_tgt, d, src_idx, tgt_idx, times, n, kernel_num);
+    if (st != GDA_OK) return st;
+    if (!loss || !bandwidth || !grad_part || !workspace) return GDA_E_NULL;
+    if ((rows_src == nullptr) != (rows_tgt == nullptr) || (rows_src && !src_idx)) return GDA_E_NULL;
+    if (rows_src && (rows_src == src || rows_tgt == tgt)) return GDA_E_ALIAS;
+    FusedPlan fp;
+    if (!fused_plan(times, n, d, kernel_mul, kernel_num, &fp)) return GDA_E_UNSUPPORTED;
+    if (fix_sigma > 0.f) return GDA_E_UNSUPPORTED;                // (a NaN row reaches the loss through the data-dependent bandwidth here)
+    if (nseg != fp.nseg) return GDA_E_SIZE;
+    if (src_idx && !rows_src) return GDA_E_UNSUPPORTED;           // the pass reads rows without an index: gather them
+    Rows R = make_rows(src, ld_src, tgt, ld_tgt, src_idx, tgt_idx, n);
+    if (rows_src ? ((uintptr_t)rows_src % 16 != 0 || (uintptr_t)rows_tgt % 16 != 0) : !R.vec4) return GDA_E_UNSUPPORTED;
+    if ((uintptr_t)grad_part % 16 != 0) return GDA_E_UNSUPPORTED;
+    MmdWs ws = carve(workspace, times, n, d);
+    if (workspace_bytes < ws.total) return GDA_E_WORKSPACE;
+    const int64_t m = 2 * n;
+    hipStream_t stream = (hipStream_t)stream_;
+    const KParams kp{kernel_mul, kernel_num, fix_sigma};
+    const unsigned chunks = (unsigned)fp.ntiles;                   // statistics partials per resample: one per 32-row tile
+    {
+        const dim3 tg((unsigned)fp.ntiles, (unsigned)times);
+        switch (fp.nb) {
+            case 1: k_tile_stats<1><<<tg, TB, 0, stream>>>(R, m, ws.part_s1, ws.part_col, ws.part_max, rows_src, rows_tgt, ws.norms); break;
+            case 2: k_tile_stats<2><<<tg, TB, 0, stream>>>(R, m, ws.part_s1, ws.part_col, ws.part_max, rows_src, rows_tgt, ws.norms); break;
+            case 3: k_tile_stats<3><<<tg, TB, 0, stream>>>(R, m, ws.part_s1, ws.part_col, ws.part_max, rows_src, rows_tgt, ws.norms); break;
+            default: k_tile_stats<4><<<tg, TB, 0, stream>>>(R, m, ws.part_s1, ws.part_col, ws.part_max, rows_src, rows_tgt, ws.norms); break;
+        }
+    }
+    GDA_LAUNCH_CHECK();
+    if (rows_src) R = make_rows(rows_src, d, rows_tgt, d, nullptr, nullptr, n);
+    switch (fp.nb) {
+        case 1: st = launch_fused<1>(stream, R, m, (int)chunks, ws, kp, fp, times, bandwidth, grad_part); break;
+        case 2: st = launch_fused<2>(stream, R, m, (int)chunks, ws, kp, fp, times, bandwidth, grad_part); break;
+        case 3: st = launch_fused<3>(stream, R, m, (int)chunks, ws, kp, fp, times, bandwidth, grad_part); break;
+        default: st = launch_fused<4>(stream, R, m, (int)chunks, ws, kp, fp, times, bandwidth, grad_part); break;
+    }
+    if (st != GDA_OK) return st;
+    k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, fp.njb * fp.nseg, times, n, scale, add, loss);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+extern "C" int gda_mmd_fused_bwd_f32(const float* grad_part, int nseg, int times, int64_t n, int64_t d,
+                                     const float* grad_loss, float scale, float* grad_rows,
+                                     const int32_t* sel_s_rowptr, const int32_t* sel_s_col, int64_t n_src_rows, float* gsrc,
+                                     const int32_t* sel_t_rowptr, const int32_t* sel_t_col, int64_t n_tgt_rows, float* gtgt,
+                                     gda_stream_t stream_) {
+    if (!grad_part || !grad_loss) return GDA_E_NULL;
+    if (times <= 0 || n <= 0 || d <= 0 || nseg < 1 || nseg > F_NSEG_MAX) return GDA_E_SIZE;
+    const bool scatter = sel_s_rowptr != nullptr;
+    if (!scatter && !grad_rows) return GDA_E_NULL;
+    if (scatter && (!sel_s_col || !sel_t_rowptr || !sel_t_col || !gsrc || !gtgt || n_src_rows < 0 || n_tgt_rows < 0))
+        return GDA_E_NULL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t m = 2 * n;
+    const float cmul = scale / ((float)n * (float)n) / (float)times;       // dloss x this x 4: k_bwd's coefficient
+    if (scatter) {
+        const int64_t most = n_src_rows > n_tgt_rows ? n_src_rows : n_tgt_rows;
+        if (most <= 0) return GDA_OK;
+        const dim3 sg((unsigned)gda_cdiv(most, TB / 32), 2);
+        const bool quads = d % 4 == 0 && ((uintptr_t)grad_part % 16 == 0) && ((uintptr_t)gsrc % 16 == 0) && ((uintptr_t)gtgt % 16 == 0);
+#define GDA_SCATTER(NS) k_bwd_scatter<NS><<<sg, TB, 0, stream>>>(grad_part, m, d, nseg, sel_s_rowptr, sel_s_col, n_src_rows, gsrc, \
+                                                              sel_t_rowptr, sel_t_col, n_tgt_rows, gtgt, grad_loss, cmul)
+        if (!quads) GDA_SCATTER(0);
+        else switch (nseg) {
+            case 1: GDA_SCATTER(1); break;
+            case 2: GDA_SCATTER(2); break;
+            case 3: GDA_SCATTER(3); break;
+            case 4: GDA_SCATTER(4); break;
+            case 5: GDA_SCATTER(5); break;
+            case 6: GDA_SCATTER(6); break;
+            case 7: GDA_SCATTER(7); break;
+            default: GDA_SCATTER(8); break;
+        }
+#undef GDA_SCATTER
+        GDA_LAUNCH_CHECK();
+        return GDA_OK;
+    }
+    const int64_t total = (int64_t)times * m * d;
+    int64_t rg = gda_cdiv(total, TB);
+    if (rg > 4096) rg = 4096;
+    k_bwd_reduce<<<(unsigned)rg, TB, 0, stream>>>(grad_part, m * d, nseg, times, grad_rows, grad_loss, cmul);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+

@@ -525,6 +525,16 @@ def lds_colmajor_ok(x, graph, K):
 # ---------------------------------------------------------------------------- MMD --
 MMD_INDEX_IN_KERNEL = _os.environ.get("PYGDA_AMD_MMD_INDEX", "0") == "1"     # sampled rows read through their index inside the kernels (no gather pass)
 MMD_SCATTER_FUSED = _os.environ.get("PYGDA_AMD_MMD_SCATTER", "1") == "1"
+# loss + unscaled row gradients in one pass over the pairs on the 16-bit matrix cores with split operands
+# (csrc/gda_mmd_fused.inc); 0 = the two-pass fp32-MFMA kernels with the [times, m, m] weight matrix in between
+MMD_ONE_PASS = _os.environ.get("PYGDA_AMD_MMD_ONE_PASS", "1") == "1"
+
+
+def mmd_one_pass_segments(times, n, d, kernel_mul=2.0, kernel_num=5):
+    """Row segments of the one-pass MMD for these shapes; 0 when it does not cover them (or is switched off)."""
+    if not MMD_ONE_PASS:
+        return 0
+    return int(_lib.lib().gda_mmd_fused_nseg(int(times), int(n), int(d), float(kernel_mul), int(kernel_num)))
 
 
 class _MMD(torch.autograd.Function):
@@ -551,10 +561,27 @@ class _MMD(torch.autograd.Function):
                 rows_t = torch.empty(times * n, d, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         bw = torch.empty(times, dtype=torch.float32, device=dev)
-        l2 = torch.empty(times, m, m, dtype=torch.float32, device=dev)
         L = _lib.lib()
         ws = _lib.workspace(L.gda_mmd_workspace_bytes(times, n, d), dev, "mmd")
         addc = None if add is None else add.detach().to(torch.float32).reshape(1).contiguous()
+        nseg = 0
+        if (idx_s is None or rows_s is not None) and not fix_sigma:
+            nseg = mmd_one_pass_segments(times, n, d, kernel_mul, kernel_num)
+            aligned = rows_s is not None or (src.data_ptr() % 16 == 0 and tgt.data_ptr() % 16 == 0)
+            nseg = nseg if aligned else 0
+        ctx.one_pass = nseg
+        if nseg:
+            part = torch.empty(times, nseg, m, d, dtype=torch.float32, device=dev)
+            with profiler.region("mmd_fwd", 4, 0, times * 3 * 4 * m * m * d):
+                _lib.check(L.gda_mmd_fused_fwd_f32(
+                    _lib.ptr(src), d, _lib.ptr(tgt), d, d, _lib.ptr(idx_s), _lib.ptr(idx_t), times, n, float(kernel_mul),
+                    int(kernel_num), float(fix_sigma) if fix_sigma else 0.0, float(scale), _lib.ptr(addc),
+                    _lib.ptr(rows_s), _lib.ptr(rows_t), _lib.ptr(loss), _lib.ptr(bw), _lib.ptr(part), nseg,
+                    _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_mmd_fused_fwd_f32")
+            ctx.save_for_backward(src_idx, tgt_idx, part)
+            ctx.cfg = (times, n, d, float(kernel_mul), int(kernel_num))
+            return loss.reshape(())
+        l2 = torch.empty(times, m, m, dtype=torch.float32, device=dev)
         with profiler.region("mmd_fwd", 4, 0, times * (3 * m * m * d // 2 + 12 * m * m)):
             _lib.check(L.gda_mmd_fwd_gather_f32(
                 _lib.ptr(src), d, _lib.ptr(tgt), d, d, _lib.ptr(idx_s), _lib.ptr(idx_t), times, n, float(kernel_mul),
@@ -570,6 +597,8 @@ class _MMD(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gl):
+        if ctx.one_pass:
+            return _MMD._backward_one_pass(ctx, gl)
         src, tgt, src_idx, tgt_idx, bw, l2 = ctx.saved_tensors
         times, n, kernel_mul, kernel_num = ctx.cfg
         d, dev, m = src.size(1), src.device, 2 * n
@@ -610,6 +639,47 @@ class _MMD(torch.autograd.Function):
             gs = _scatter_rows(grad_rows, src_idx, 0, n, ctx.feat_rows[0])
             gt = _scatter_rows(grad_rows, tgt_idx, n, n, ctx.feat_rows[1])
         return (gs if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None) + tail
+
+
+def _mmd_backward_one_pass(ctx, gl):
+    """Backward of the one-pass MMD: the forward left unscaled row-gradient partials; this folds the segments, applies
+    4 * dloss * scale / (n^2 times) and scatters onto the feature rows (one launch with the selection CSRs)."""
+    src_idx, tgt_idx, part = ctx.saved_tensors
+    times, n, d, _, _ = ctx.cfg
+    dev, m = part.device, 2 * n
+    glc = gl.reshape(1).to(torch.float32).contiguous()
+    L = _lib.lib()
+    g_add = gl if ctx.has_add else None
+    tail = (None,) * 9 + (g_add,)
+    if src_idx is not None and ctx.sel is not None and MMD_SCATTER_FUSED:
+        s_rp, s_ci, t_rp, t_ci, _ones = ctx.sel
+        gs = torch.empty(ctx.feat_rows[0], d, dtype=torch.float32, device=dev)
+        gt = torch.empty(ctx.feat_rows[1], d, dtype=torch.float32, device=dev)
+        with profiler.region("mmd_bwd", 1, 0, 0):
+            _lib.check(L.gda_mmd_fused_bwd_f32(
+                _lib.ptr(part), ctx.one_pass, times, n, d, _lib.ptr(glc), ctx.scale, None,
+                _lib.ptr(s_rp), _lib.ptr(s_ci), ctx.feat_rows[0], _lib.ptr(gs),
+                _lib.ptr(t_rp), _lib.ptr(t_ci), ctx.feat_rows[1], _lib.ptr(gt), _lib.stream()), "gda_mmd_fused_bwd_f32")
+        return (gs if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None) + tail
+    grad_rows = torch.empty(times, m, d, dtype=torch.float32, device=dev)
+    with profiler.region("mmd_bwd", 1, 0, 0):
+        _lib.check(L.gda_mmd_fused_bwd_f32(
+            _lib.ptr(part), ctx.one_pass, times, n, d, _lib.ptr(glc), ctx.scale, _lib.ptr(grad_rows),
+            None, None, 0, None, None, None, 0, None, _lib.stream()), "gda_mmd_fused_bwd_f32")
+    if src_idx is None:                       # rows as given, stacked [times, n, d]
+        gs, gt = grad_rows[:, :n].reshape(times * n, d), grad_rows[:, n:].reshape(times * n, d)
+    elif ctx.sel is not None:
+        s_rp, s_ci, t_rp, t_ci, ones = ctx.sel
+        flat = grad_rows.view(times * m, d)
+        gs = _selection_spmm(s_rp, s_ci, ones, flat, ctx.feat_rows[0])
+        gt = _selection_spmm(t_rp, t_ci, ones, flat, ctx.feat_rows[1])
+    else:
+        gs = _scatter_rows(grad_rows, src_idx, 0, n, ctx.feat_rows[0])
+        gt = _scatter_rows(grad_rows, tgt_idx, n, n, ctx.feat_rows[1])
+    return (gs if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None) + tail
+
+
+_MMD._backward_one_pass = staticmethod(_mmd_backward_one_pass)
 
 
 class _PinnedRing:

@@ -203,6 +203,34 @@ def test_round4_entry_points_validate_before_touching_a_device():
     assert L.gda_attention_fuse_fwd_f32(2, two, ld, 10, 128, None, one, one, 128, one, None) == -1
     assert L.gda_attention_fuse_fwd_f32(2, two, ld, 0, 128, None, None, None, 128, None, None) == 0        # no rows
     assert L.gda_attention_fuse_bwd_f32(2, two, ld, 10, 128, two, two, two, 128, two, two, two, None, 0, None) == -3   # workspace
+    # one-pass MMD (csrc/gda_mmd_fused.inc): what it covers, and its argument checks
+    assert L.gda_mmd_fused_nseg(5, 1000, 128, 2.0, 5) == 6          # 16 column blocks x 5 resamples x 6 = 480 workgroups
+    assert L.gda_mmd_fused_nseg(1, 96, 128, 2.0, 5) == 6            # never more segments than 32-row tiles
+    assert L.gda_mmd_fused_nseg(3, 200, 64, 2.0, 5) == 8
+    for bad in ((5, 1000, 645, 2.0, 5), (5, 1000, 160, 2.0, 5), (5, 1000, 16, 2.0, 5), (5, 1000, 128, 3.0, 5),
+                (5, 1000, 128, 2.0, 4), (0, 1000, 128, 2.0, 5), (5, 0, 128, 2.0, 5)):
+        assert L.gda_mmd_fused_nseg(*bad) == 0
+    one, two = ctypes.c_void_p(64), ctypes.c_void_p(128)            # "pointers" on 16-byte boundaries, never dereferenced
+    fwd = lambda **kw: L.gda_mmd_fused_fwd_f32(*[kw.get(k, v) for k, v in (
+        ("src", one), ("lds", 128), ("tgt", two), ("ldt", 128), ("d", 128), ("si", None), ("ti", None), ("times", 5),
+        ("n", 1000), ("mul", 2.0), ("num", 5), ("sigma", 0.0), ("scale", 1.0), ("add", None), ("rs", None), ("rt", None),
+        ("loss", one), ("bw", one), ("part", two), ("nseg", 6), ("ws", one), ("wsb", 0), ("stream", None))])
+    assert fwd() == -3                                               # workspace too small: the last check before a launch
+    assert fwd(src=None) == -1 and fwd(loss=None) == -1 and fwd(part=None) == -1 and fwd(ws=None) == -1
+    assert fwd(nseg=4) == -2                                         # not the segment count of these shapes
+    assert fwd(d=645, lds=645, ldt=645) == -4 and fwd(num=4) == -4 and fwd(mul=3.0) == -4
+    assert fwd(si=one, ti=two) == -4                                 # indexed rows need the gathered copy
+    assert fwd(si=one) == -1                                         # one index without the other
+    assert fwd(src=ctypes.c_void_p(4)) == -4 and fwd(part=ctypes.c_void_p(8)) == -4      # 16-byte alignment
+    assert fwd(lds=130) == -4                                        # row stride off the 16-byte grid
+    bwd = L.gda_mmd_fused_bwd_f32
+    assert bwd(None, 6, 5, 1000, 128, one, 1.0, one, None, None, 0, None, None, None, 0, None, None) == -1
+    assert bwd(one, 6, 5, 1000, 128, None, 1.0, one, None, None, 0, None, None, None, 0, None, None) == -1
+    assert bwd(one, 9, 5, 1000, 128, one, 1.0, one, None, None, 0, None, None, None, 0, None, None) == -2
+    assert bwd(one, 6, 5, 1000, 128, one, 1.0, None, None, None, 0, None, None, None, 0, None, None) == -1   # nowhere to write
+    assert bwd(one, 6, 5, 1000, 128, one, 1.0, None, one, None, 0, one, one, one, 0, one, None) == -1        # half a selection CSR
+    assert bwd(one, 6, 5, 1000, 128, one, 1.0, None, one, one, 0, one, one, one, 0, one, None) == 0          # no feature rows
+    assert L.gda_mmd_workspace_bytes(5, 1000, 128) > L.gda_mmd_workspace_bytes(5, 1000, 132) - 5 * 63 * 38912   # the images
     table = (_lib.AdamTensorStruct * 1)()
     assert L.gda_adam_multi_ex_f32(table, 1, 0.1, 0.9, 0.999, 1e-8, 0.0, 2, None) == -4   # flag
     assert L.gda_adam_multi_ex_f32(table, 0, 0.1, 0.9, 0.999, 1e-8, 0.0, 1, None) == 0

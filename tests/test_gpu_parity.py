@@ -248,6 +248,96 @@ def test_mmd_properties():
     exact(l1, l2)                                                 # deterministic reductions
 
 
+def _mmd_f64(src, tgt, idx_s=None, idx_t=None, times=1):
+    """The reference's arithmetic (mmd.py:43-55, 100-106, 152-157) in float64 on the device, Gram form (harmless in
+    double), bandwidth detached as `.data` does: the yardstick for the two kernel paths' rounding."""
+    src, tgt = src.detach().double().requires_grad_(), tgt.detach().double().requires_grad_()
+    loss = 0
+    for t in range(times):
+        tot = torch.cat([src[idx_s[t]], tgt[idx_t[t]]]) if idx_s is not None else \
+            torch.cat([src.view(times, -1, src.size(1))[t], tgt.view(times, -1, tgt.size(1))[t]])
+        tot = tot - tot[0].detach()
+        sq = (tot * tot).sum(1)
+        L2 = (sq[:, None] + sq[None, :] - 2 * tot @ tot.T).clamp_min(0)
+        m = tot.size(0)
+        n = m // 2
+        bw = (L2.detach().sum() + 1e-6) / (m * m - m) / 4
+        K = sum(torch.exp(-L2 / (bw * 2 ** q)) for q in range(5))
+        loss = loss + (K[:n, :n] + K[n:, n:] - K[:n, n:] - K[n:, :n]).mean()
+    loss = loss / times
+    loss.backward()
+    return float(loss), src.grad, tgt.grad
+
+
+def _mmd_run(s, t, idx=None, rows=None):
+    s, t = s.detach().clone().requires_grad_(), t.detach().clone().requires_grad_()
+    if rows is not None:
+        loss = ops.mmd_loss_rows(s.view(rows, -1, s.size(1)), t.view(rows, -1, t.size(1)))
+    elif idx is None:
+        loss = ops.mmd_loss(s, t)
+    else:
+        loss = ops.mmd_loss(s, t, idx[0], idx[1], sel=idx[2])
+    loss.backward()
+    return float(loss), s.grad, t.grad
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
+
+
+@pytest.mark.parametrize("times,n,d,ns,nt", [(5, 1000, 128, 9360, 5484), (1, 96, 128, 0, 0), (3, 77, 64, 500, 400),
+                                             (2, 33, 32, 100, 90), (4, 300, 96, 1000, 1000), (2, 512, 128, -1, -1)])
+def test_mmd_one_pass_beside_the_two_pass_kernels_and_float64(times, n, d, ns, nt, monkeypatch):
+    """The one-pass MMD (split-fp16 MFMAs, csrc/gda_mmd_fused.inc) and the two-pass fp32-MFMA kernels against the
+    same float64 evaluation: sampled rows with the scatter (ns > 0), get_MMD on the rows as given (0), stacked row
+    sets (-1, the data-parallel entry).  Tolerances: 2e-5 on the loss and on every gradient's relative L2 error (the
+    trainer-level bar is 1e-4), and the one-pass errors stay within a small factor of the fp32 kernels' own."""
+    assert ops.mmd_one_pass_segments(times, n, d) > 0
+    gen = torch.Generator().manual_seed(1000 * times + n + d)
+    if ns > 0:
+        s = torch.randn(ns, d, generator=gen).relu().to(DEV)
+        t = (torch.randn(nt, d, generator=gen) * 1.3 + 0.2).relu().to(DEV)
+        si, ti = torch.randint(0, ns, (times, n), generator=gen), torch.randint(0, nt, (times, n), generator=gen)
+        idx = ops.mmd_samples_to_device(si, ti, ns, nt, torch.device(DEV))
+        run = lambda: _mmd_run(s, t, idx=idx)
+        want = _mmd_f64(s, t, si.to(DEV), ti.to(DEV), times)
+    else:
+        s = torch.randn(times * n, d, generator=gen).to(DEV)
+        t = (torch.randn(times * n, d, generator=gen) * 0.8 + 0.3).to(DEV)
+        run = (lambda: _mmd_run(s, t)) if ns == 0 else (lambda: _mmd_run(s, t, rows=times))
+        want = _mmd_f64(s, t, times=times)
+    one = run()
+    again = run()
+    assert one[0] == again[0] and torch.equal(one[1], again[1]) and torch.equal(one[2], again[2])     # deterministic
+    monkeypatch.setattr(ops, "MMD_ONE_PASS", False)
+    assert ops.mmd_one_pass_segments(times, n, d) == 0
+    two = run()
+    err = lambda got: (abs(got[0] - want[0]) / abs(want[0]), _rel(got[1], want[1]), _rel(got[2], want[2]))
+    e1, e2 = err(one), err(two)
+    print(f"one-pass errors {e1}, two-pass {e2}")
+    for a, b in zip(e1, e2):
+        assert a <= 2e-5 and a <= 16 * b + 2e-6, (e1, e2)
+
+
+@pytest.mark.parametrize("scale", [2.0 ** -10, 1.0, 3.0e4, 2.0 ** 40])
+def test_mmd_one_pass_is_insensitive_to_the_scale_of_the_features(scale):
+    """The split operands live in fp16: one power of two per resample, taken from the largest shifted entry, keeps
+    them in its range whatever the features' own scale (tiny, ordinary, beyond fp16's 65504, huge); a far-away
+    common offset is removed by the pivot shift before anything is rounded.  Duplicated rows, an outlier row."""
+    gen = torch.Generator().manual_seed(11)
+    a = torch.randn(600, 128, generator=gen)
+    b = torch.randn(600, 128, generator=gen) * 1.1 + 0.15
+    a[7] = a[3]; b[9] = a[3]; a[100] *= 50.0                           # duplicates across and inside the domains, an outlier
+    s, t = (a * scale + 1000.0 * scale).to(DEV), (b * scale + 1000.0 * scale).to(DEV)
+    got = _mmd_run(s, t)
+    want = _mmd_f64(s, t)
+    assert abs(got[0] - want[0]) <= 1e-4 * abs(want[0]), (got[0], want[0])
+    assert _rel(got[1], want[1]) <= 1e-3 and _rel(got[2], want[2]) <= 1e-3      # the offset costs the INPUT 10 bits: fp32's own limit
+    assert torch.isfinite(got[1]).all() and torch.isfinite(got[2]).all()
+    same = _mmd_run(s, s.clone())
+    assert abs(same[0]) <= 1e-6                                        # identical domains
+
+
 # --------------------------------------------------- GRL + discriminator + CE --
 @pytest.mark.parametrize("ns,nt,h,C", [(300, 200, 16, 2), (1000, 777, 128, 2), (50, 60, 645, 2), (40, 30, 20, 3)])
 def test_grl_disc_ce_vs_torch(ns, nt, h, C):
