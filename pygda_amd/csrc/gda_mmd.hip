@@ -798,7 +798,7 @@ int launch_bwd(dim3 grid, hipStream_t stream, Rows R, int64_t d, int64_t m, cons
 
 struct MmdWs {
     double* kpartial; double* part_s1; float* part_col; float* bwd_part; float* norms;
-    float* part_max; float* xscale; unsigned char* images;      // the fused pass (NULL / empty when it does not cover the shape)
+    float* part_max; unsigned char* images;      // the fused pass (NULL / empty when it does not cover the shape)
     size_t total;
 };
 
@@ -822,7 +822,6 @@ MmdWs carve(void* base, int times, int64_t n, int64_t d) {
     w.norms = (float*)take(sizeof(float) * times * m);
     if (fused) {
         w.part_max = (float*)take(sizeof(float) * times * chunks);
-        w.xscale = (float*)take(sizeof(float) * times);
         w.images = (unsigned char*)take((size_t)times * fp.ntiles * fp.img);
     }
     w.total = off;
@@ -999,16 +998,17 @@ extern "C" int gda_mmd_fused_nseg(int times, int64_t n, int64_t d, float kernel_
 }
 
 template <int NB>
-static int launch_fused(hipStream_t stream, const Rows& R, int64_t m, int chunks, const MmdWs& ws, KParams kp, const FusedPlan& fp,
-                        int times, float* bandwidth, float* grad_part) {
-    k_bw_split<NB><<<dim3((unsigned)fp.ntiles, (unsigned)times), TB, 0, stream>>>(R, m, chunks, ws.part_s1, ws.part_col, ws.part_max,
-                                                                             ws.norms, kp, bandwidth, ws.xscale, ws.images);
+static int launch_fused(hipStream_t stream, const Rows& Rin, float* rows_src, float* rows_tgt, int64_t m, int64_t d, const MmdWs& ws,
+                        const FusedPlan& fp, int times, float* bandwidth, float* grad_part) {
+    k_tile_split<NB><<<dim3((unsigned)fp.ntiles, (unsigned)times), TB, 0, stream>>>(Rin, m, ws.part_s1, ws.part_col, ws.part_max,
+                                                                               rows_src, rows_tgt, ws.images);
     GDA_LAUNCH_CHECK();
+    const Rows R = rows_src ? make_rows(rows_src, d, rows_tgt, d, nullptr, nullptr, Rin.n) : Rin;   // gathered: no index from here on
     const size_t lds = 2 * fp.img + sizeof(float) * 32 * (TB / 64);
     GDA_LDS_ATTR_ONCE((k_mmd_fused<NB>), lds);
     const unsigned grid = 8u * (unsigned)gda_cdiv(fp.total, 8);
-    k_mmd_fused<NB><<<grid, TB, lds, stream>>>(R, m, fp.ntiles, fp.njb, fp.nseg, fp.total, ws.images, bandwidth, ws.xscale,
-                                              grad_part, ws.kpartial);
+    k_mmd_fused<NB><<<grid, TB, lds, stream>>>(R, m, fp.ntiles, fp.njb, fp.nseg, fp.total, ws.images, ws.part_s1, ws.part_col,
+                                              ws.part_max, bandwidth, grad_part, ws.kpartial);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
@@ -1030,30 +1030,17 @@ extern "C" int gda_mmd_fused_fwd_f32(const float* src, int64_t ld_src, const flo
     if (nseg != fp.nseg) return GDA_E_SIZE;
     if (src_idx && !rows_src) return GDA_E_UNSUPPORTED;           // the pass reads rows without an index: gather them
     Rows R = make_rows(src, ld_src, tgt, ld_tgt, src_idx, tgt_idx, n);
-    if (rows_src ? ((uintptr_t)rows_src % 16 != 0 || (uintptr_t)rows_tgt % 16 != 0) : !R.vec4) return GDA_E_UNSUPPORTED;
+    if (!R.vec4 || (rows_src && ((uintptr_t)rows_src % 16 != 0 || (uintptr_t)rows_tgt % 16 != 0))) return GDA_E_UNSUPPORTED;   // 16-byte loads
     if ((uintptr_t)grad_part % 16 != 0) return GDA_E_UNSUPPORTED;
     MmdWs ws = carve(workspace, times, n, d);
     if (workspace_bytes < ws.total) return GDA_E_WORKSPACE;
     const int64_t m = 2 * n;
     hipStream_t stream = (hipStream_t)stream_;
-    const KParams kp{kernel_mul, kernel_num, fix_sigma};
-    const unsigned chunks = (unsigned)fp.ntiles;                   // statistics partials per resample: one per 32-row tile
-    {
-        const dim3 tg((unsigned)fp.ntiles, (unsigned)times);
-        switch (fp.nb) {
-            case 1: k_tile_stats<1><<<tg, TB, 0, stream>>>(R, m, ws.part_s1, ws.part_col, ws.part_max, rows_src, rows_tgt, ws.norms); break;
-            case 2: k_tile_stats<2><<<tg, TB, 0, stream>>>(R, m, ws.part_s1, ws.part_col, ws.part_max, rows_src, rows_tgt, ws.norms); break;
-            case 3: k_tile_stats<3><<<tg, TB, 0, stream>>>(R, m, ws.part_s1, ws.part_col, ws.part_max, rows_src, rows_tgt, ws.norms); break;
-            default: k_tile_stats<4><<<tg, TB, 0, stream>>>(R, m, ws.part_s1, ws.part_col, ws.part_max, rows_src, rows_tgt, ws.norms); break;
-        }
-    }
-    GDA_LAUNCH_CHECK();
-    if (rows_src) R = make_rows(rows_src, d, rows_tgt, d, nullptr, nullptr, n);
     switch (fp.nb) {
-        case 1: st = launch_fused<1>(stream, R, m, (int)chunks, ws, kp, fp, times, bandwidth, grad_part); break;
-        case 2: st = launch_fused<2>(stream, R, m, (int)chunks, ws, kp, fp, times, bandwidth, grad_part); break;
-        case 3: st = launch_fused<3>(stream, R, m, (int)chunks, ws, kp, fp, times, bandwidth, grad_part); break;
-        default: st = launch_fused<4>(stream, R, m, (int)chunks, ws, kp, fp, times, bandwidth, grad_part); break;
+        case 1: st = launch_fused<1>(stream, R, rows_src, rows_tgt, m, d, ws, fp, times, bandwidth, grad_part); break;
+        case 2: st = launch_fused<2>(stream, R, rows_src, rows_tgt, m, d, ws, fp, times, bandwidth, grad_part); break;
+        case 3: st = launch_fused<3>(stream, R, rows_src, rows_tgt, m, d, ws, fp, times, bandwidth, grad_part); break;
+        default: st = launch_fused<4>(stream, R, rows_src, rows_tgt, m, d, ws, fp, times, bandwidth, grad_part); break;
     }
     if (st != GDA_OK) return st;
     k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, fp.njb * fp.nseg, times, n, scale, add, loss);

@@ -567,7 +567,7 @@ class _MMD(torch.autograd.Function):
         nseg = 0
         if (idx_s is None or rows_s is not None) and not fix_sigma:
             nseg = mmd_one_pass_segments(times, n, d, kernel_mul, kernel_num)
-            aligned = rows_s is not None or (src.data_ptr() % 16 == 0 and tgt.data_ptr() % 16 == 0)
+            aligned = src.data_ptr() % 16 == 0 and tgt.data_ptr() % 16 == 0
             nseg = nseg if aligned else 0
         ctx.one_pass = nseg
         if nseg:
