@@ -2,6 +2,8 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "mmd" 2>&1 | grep -E "passed|failed|Error|assert" > $O/r4_n_tests.txt; cat $O/r4_n_tests.txt
-rm -rf $O/mmdk; timeout 300 python tools/mmd_kernels.py $O/mmdk > $O/r4_n_kernels.json 2>&1; cat $O/r4_n_kernels.json; rm -rf $O/mmdk
-timeout 600 python bench.py --no-cpu-baseline --no-hbm-probe --no-side-lines 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms_per_step', d['ms_per_step'])"
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error|Error|FAILED" > $O/r4_n_tests.txt; cat $O/r4_n_tests.txt
+for w in 384 640; do
+  rm -rf $O/mmdk; PYGDA_AMD_MMD_FUSED_WGS=$w timeout 300 python tools/mmd_kernels.py $O/mmdk 30 | cut -c1-400; rm -rf $O/mmdk
+done
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
