@@ -826,7 +826,7 @@ def run_cfg_a(args, world, rank, dev, side=False):
             # stands for against the fp32-MFMA roof the two-pass kernels run under (it may exceed 1: that is the point).
             mm = {"shape": {"times": times, "m": m_rows, "d": dd}, "path": "one pass, split-fp16 MFMA (3 products per pair)",
                   "bound": "mfma", "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s", "flops_full_product": full,
-                  "live_call_us": {"mmd_fwd[tile_stats+bw_split+fused+finalize]": per_call("mmd_fwd"),
+                  "live_call_us": {"mmd_fwd[tile_split+fused+finalize]": per_call("mmd_fwd"),
                                    "mmd_bwd[scatter]": per_call("mmd_bwd")}}
             us, calls, fname = rocprof_kernel("k_mmd_fused<", prof_pattern)
             if us:
@@ -835,7 +835,7 @@ def run_cfg_a(args, world, rank, dev, side=False):
                                      "frac": 3 * 2 * full / (us * 1e-6) / 1e12 / F16_MFMA_PEAK_TF,
                                      "fp32_equivalent": {"flops": 2 * full, "achieved": 2 * full / (us * 1e-6) / 1e12,
                                                          "frac_of_fp32_mfma_peak": 2 * full / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF}}
-            for key, prefix in (("k_tile_stats", "k_tile_stats<"), ("k_bw_split", "k_bw_split<"), ("k_bwd_scatter", "k_bwd_scatter<")):
+            for key, prefix in (("k_tile_split", "k_tile_split<"), ("k_finalize", "k_finalize"), ("k_bwd_scatter", "k_bwd_scatter<")):
                 us, calls, fname = rocprof_kernel(prefix, prof_pattern)
                 if us:
                     mm[key] = {"avg_launch_us_rocprof": us, "source": fname}

@@ -717,6 +717,14 @@ int gda_adam_multi_f32(const gda_adam_tensor* tensors /* HOST array */, int n_te
 int gda_step_bump(int64_t* counter, float* const* steps /* HOST array */, int n_steps, gda_stream_t stream);
 int gda_adam_multi_ex_f32(const gda_adam_tensor* tensors /* HOST array */, int n_tensors, float lr, float beta1,
                           float beta2, float eps, float weight_decay, int flags, gda_stream_t stream);
+/* ... with a gradient that arrives as TWO contributions: grad2[k] (HOST array of device pointers, entries or the array
+ * itself may be NULL) is added to tensors[k].grad inside the update -- `g = grad + grad2`, one rounding, the value
+ * autograd's accumulation of the two would have stored.  A parameter used by two branches of a step (A2GNN's source
+ * and target passes share every layer, pygda/models/a2gnn.py:181-193) otherwise costs one elementwise launch per
+ * tensor between the last gradient kernel and the update. */
+int gda_adam_multi_sum_f32(const gda_adam_tensor* tensors /* HOST array */, const float* const* grad2 /* HOST array */,
+                           int n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay, int flags,
+                           gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
  * Tall-skinny fp32 GEMMs on the matrix cores: the dense projection of the hidden / classifier

@@ -146,6 +146,7 @@ _SIGNATURES = {
     "gda_attention_fuse_bwd_f32": (c_int, [c_int, _P, _P, c_int64, c_int64, _P, _P, _P, c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "gda_adam_multi_f32": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, c_float, _P]),
     "gda_adam_multi_ex_f32": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
+    "gda_adam_multi_sum_f32": (c_int, [_P, _P, c_int, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
     "gda_step_bump": (c_int, [_P, _P, c_int, _P]),
     "gda_rccl_load": (c_int, [ctypes.c_char_p]),
     "gda_comm_unique_id": (c_int, [_P, c_size_t]),

@@ -19,6 +19,7 @@ constexpr int TB = 256;
 struct AdamTable {
     float* p[GDA_ADAM_MAX_TENSORS];
     const float* g[GDA_ADAM_MAX_TENSORS];
+    const float* g2[GDA_ADAM_MAX_TENSORS];                     // second contribution to the gradient, or NULL (gda_adam_multi_sum_f32)
     float* m[GDA_ADAM_MAX_TENSORS];
     float* v[GDA_ADAM_MAX_TENSORS];
     float* step[GDA_ADAM_MAX_TENSORS];
@@ -41,6 +42,7 @@ k_adam(AdamTable t, float lr, float beta1, float beta2, float eps, float weight_
     const float bc2_sqrt = sqrtf(bc2);
     float* __restrict__ p = t.p[k];
     const float* __restrict__ g = t.g[k];
+    const float* __restrict__ g2 = t.g2[k];
     float* __restrict__ m = t.m[k];
     float* __restrict__ v = t.v[k];
     const int64_t n = t.numel[k];
@@ -50,6 +52,7 @@ k_adam(AdamTable t, float lr, float beta1, float beta2, float eps, float weight_
         if (i >= n) break;
         const float pi = p[i];
         float gi = g[i];
+        if (g2) gi = gi + g2[i];                               // what autograd's accumulation would have stored (one rounding)
         if (weight_decay != 0.f) gi = gi + weight_decay * pi;
         float mi = m[i], vi = v[i];
         mi = mi + (gi - mi) * (1.0f - beta1);                // torch: exp_avg.lerp_(grad, 1 - beta1)
@@ -102,6 +105,12 @@ extern "C" int gda_adam_multi_f32(const gda_adam_tensor* tensors, int n_tensors,
 
 extern "C" int gda_adam_multi_ex_f32(const gda_adam_tensor* tensors, int n_tensors, float lr, float beta1,
                                      float beta2, float eps, float weight_decay, int flags, gda_stream_t stream_) {
+    return gda_adam_multi_sum_f32(tensors, nullptr, n_tensors, lr, beta1, beta2, eps, weight_decay, flags, stream_);
+}
+
+extern "C" int gda_adam_multi_sum_f32(const gda_adam_tensor* tensors, const float* const* grad2, int n_tensors, float lr,
+                                      float beta1, float beta2, float eps, float weight_decay, int flags,
+                                      gda_stream_t stream_) {
     if (flags & ~GDA_ADAM_STEPS_BUMPED) return GDA_E_UNSUPPORTED;
     if (n_tensors < 0 || n_tensors > GDA_ADAM_MAX_TENSORS) return GDA_E_SIZE;
     if (n_tensors == 0) return GDA_OK;
@@ -114,7 +123,9 @@ extern "C" int gda_adam_multi_ex_f32(const gda_adam_tensor* tensors, int n_tenso
         if (e.numel < 0) return GDA_E_SIZE;
         if (e.numel == 0) continue;
         if (!e.param || !e.grad || !e.exp_avg || !e.exp_avg_sq || !e.step) return GDA_E_NULL;
+        if (grad2 && grad2[k] && (grad2[k] == e.grad || (const float*)e.param == grad2[k])) return GDA_E_ALIAS;
         t.p[t.n] = e.param; t.g[t.n] = e.grad; t.m[t.n] = e.exp_avg; t.v[t.n] = e.exp_avg_sq; t.step[t.n] = e.step;
+        t.g2[t.n] = grad2 ? grad2[k] : nullptr;
         t.numel[t.n] = e.numel;
         t.first_item[t.n] = items;
         items += gda_cdiv(e.numel, ITEM);

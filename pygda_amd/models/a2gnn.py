@@ -78,12 +78,14 @@ class A2GNN(BaseGDA):
         """Target feature pass (:193); the loss-unused logits pass (:211) forked from its layer 0."""
         net = self.a2gnn
         tb = None if self.mode == 'node' else target_data.batch
-        if h0_t is None:
-            h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
-        pending = None
-        if self.compute_target_logits and fork:
-            pending = self._target_logits_async(net, target_data, h0_t)
-        target_features = net.feat_bottleneck_from(h0_t, target_data.edge_index, tb, self.t_pnums)   # :193
+        table = getattr(self, "_grad_aliases", None)
+        with (net.second_leaves(table) if table is not None and torch.is_grad_enabled() else _null()):
+            if h0_t is None:
+                h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
+            pending = None
+            if self.compute_target_logits and fork:
+                pending = self._target_logits_async(net, target_data, h0_t)
+            target_features = net.feat_bottleneck_from(h0_t, target_data.edge_index, tb, self.t_pnums)   # :193
         return h0_t, pending, target_features
 
     def _domain_loss(self, loss, source_features, target_features, alpha):
@@ -224,9 +226,17 @@ class A2GNN(BaseGDA):
         # the MMD step reads no per-epoch scalar: consecutive steps may share one capture (hipgraph.GraphedStep.unroll)
         self._graph_unroll_ok = not self.adv and type(self) is A2GNN
         on_gpu = torch.device(self.device).type == "cuda"
+        self._grad_aliases = None
         if on_gpu:           # torch.optim.Adam's update in one multi-tensor launch (pygda_amd/optim.py)
             from ..optim import Adam
             optimizer = Adam(self.a2gnn.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+            import os
+            from .. import distributed
+            # single process: the target branch's gradients of the shared layers go to second leaves and are summed inside
+            # the update kernel (A2GNNBase.second_leaves); data-parallel runs average `.grad` and keep autograd's sums
+            if (type(self) is A2GNN and os.environ.get("PYGDA_AMD_SECOND_LEAVES", "1") == "1"
+                    and not distributed.active()):
+                self._grad_aliases = optimizer.grad_aliases
         else:
             optimizer = torch.optim.Adam(self.a2gnn.parameters(), lr=self.lr, weight_decay=self.weight_decay)
 

@@ -30,6 +30,35 @@ class A2GNNBase(nn.Module):
         if adv:
             self.domain_discriminator = nn.Linear(hid_dim, 2)
 
+    def second_leaves(self, table):
+        """Context manager: inside it the conv layers read their weight / bias through SECOND leaf tensors over the same
+        storage, so the gradients of a second pass over the shared layers (the trainer's target branch) land in those
+        leaves' ``.grad`` instead of being added onto the first pass's by autograd -- one elementwise launch per shared
+        tensor (four at A2GNN's depth, the last two between the final gradient kernel and the optimiser update).
+        ``table`` (``pygda_amd.optim.Adam.grad_aliases``: id(parameter) -> leaf) is kept current; the update kernel
+        forms ``grad + leaf.grad``, the value the accumulation would have stored.  Not in the reference."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            swapped = []
+            for conv in self.convs:
+                for owner, name in ((conv.lin, "weight"), (conv, "bias")):
+                    p = owner._parameters.get(name)
+                    if p is None or not p.requires_grad:
+                        continue
+                    a = table.get(id(p))
+                    if a is None or a.data_ptr() != p.data_ptr() or a.stride() != p.stride() or a.shape != p.shape:
+                        a = table[id(p)] = nn.Parameter(p.detach())      # same storage (re-made if the weight was re-laid out)
+                    owner._parameters[name] = a
+                    swapped.append((owner, name, p))
+            try:
+                yield
+            finally:
+                for owner, name, p in swapped:
+                    owner._parameters[name] = p
+        return scope()
+
     def forward(self, data, prop_nums):
         batch = None if self.mode == "node" else data.batch
         h = self.feat_bottleneck(data.x, data.edge_index, batch, prop_nums=prop_nums)

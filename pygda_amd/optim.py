@@ -19,6 +19,22 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameter")
         # `capturable` is what the hipGraph step looks for (pygda_amd/models/base.py)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=True))
+        # id(parameter) -> a second leaf over the SAME storage whose .grad holds a second contribution to the parameter's
+        # gradient (pygda_amd/nn/a2gnn_base.py::A2GNNBase.second_leaves): summed inside the update kernel
+        self.grad_aliases = {}
+
+    def _second(self, p):
+        a = self.grad_aliases.get(id(p))
+        return None if a is None else a.grad
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none)
+        for a in self.grad_aliases.values():
+            if a.grad is not None:
+                if set_to_none:
+                    a.grad = None
+                else:
+                    a.grad.zero_()
 
     def _state(self, p):
         st = self.state[p]
@@ -58,7 +74,7 @@ class Adam(torch.optim.Optimizer):
             # was bumped and has none gets its increment taken back (a plain device op: captured with the step)
             for group in self.param_groups:
                 for p in group["params"]:
-                    if id(p) in bumped and p.grad is None:
+                    if id(p) in bumped and p.grad is None and self._second(p) is None:
                         self._state(p)["step"].sub_(1.0)
         for group in self.param_groups:
             # A Parameter listed twice (UDAGCN / SpecReg hand the optimiser the conv weights their two
@@ -67,7 +83,7 @@ class Adam(torch.optim.Optimizer):
             # round of launches: rounds run in stream order, so the second update sees the first one's result.
             rounds, seen = [], {}
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None and self._second(p) is None:
                     continue
                 k = seen.get(id(p), 0)
                 seen[id(p)] = k + 1
@@ -77,10 +93,15 @@ class Adam(torch.optim.Optimizer):
             chunks = [r[i:i + MAX_TENSORS] for r in rounds for i in range(0, len(r), MAX_TENSORS)]
             for chunk in chunks:
                 table = (_lib.AdamTensorStruct * len(chunk))()
+                second = (ctypes.c_void_p * len(chunk))()
                 keep = []
                 for k, p in enumerate(chunk):
                     _lib.require_gpu_tensor(p, "parameter", torch.float32)
-                    g = p.grad
+                    g, g2 = p.grad, self._second(p)
+                    if g is None:
+                        g, g2 = g2, None
+                    if g2 is not None and seen.get(id(p), 0) > 1:
+                        raise _lib.GdaError("Adam: a parameter listed twice cannot have a second gradient leaf")
                     if g.is_sparse or g.dtype != torch.float32:
                         raise _lib.GdaError("Adam: dense fp32 gradients only")
                     # the update is elementwise: any dense layout works as long as parameter, gradient and both
@@ -90,7 +111,13 @@ class Adam(torch.optim.Optimizer):
                         raise _lib.GdaError("Adam: parameters must be dense (row- or column-major)")
                     if g.stride() != p.stride():
                         g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
-                    keep.append(g)
+                    if g2 is not None:
+                        if g2.is_sparse or g2.dtype != torch.float32:
+                            raise _lib.GdaError("Adam: dense fp32 gradients only")
+                        if g2.stride() != p.stride():
+                            g2 = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g2)
+                        second[k] = g2.data_ptr()
+                    keep.append((g, g2))
                     st = self._state(p)
                     for name in ("exp_avg", "exp_avg_sq"):
                         if st[name].stride() != p.stride():          # state created before the weight was re-laid out
@@ -98,8 +125,8 @@ class Adam(torch.optim.Optimizer):
                     table[k] = _lib.AdamTensorStruct(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
                                                      st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), p.numel())
                 b1, b2 = group["betas"]
-                _lib.check(L.gda_adam_multi_ex_f32(table, len(chunk), float(group["lr"]), float(b1), float(b2),
-                                                   float(group["eps"]), float(group["weight_decay"]),
-                                                   1 if bumped is not None else 0, _lib.stream()),
-                           "gda_adam_multi_ex_f32")
+                _lib.check(L.gda_adam_multi_sum_f32(table, second, len(chunk), float(group["lr"]), float(b1), float(b2),
+                                                    float(group["eps"]), float(group["weight_decay"]),
+                                                    1 if bumped is not None else 0, _lib.stream()),
+                           "gda_adam_multi_sum_f32")
         return loss

@@ -232,6 +232,12 @@ def test_round4_entry_points_validate_before_touching_a_device():
     assert bwd(one, 6, 5, 1000, 128, one, 1.0, None, one, one, 0, one, one, one, 0, one, None) == 0          # no feature rows
     assert L.gda_mmd_workspace_bytes(5, 1000, 128) > L.gda_mmd_workspace_bytes(5, 1000, 132) - 5 * 63 * 38912   # the images
     table = (_lib.AdamTensorStruct * 1)()
+    # a second gradient contribution summed inside the update (gda_adam_multi_sum_f32)
+    full = (_lib.AdamTensorStruct * 1)(_lib.AdamTensorStruct(64, 128, 192, 256, 320, 10))
+    assert L.gda_adam_multi_sum_f32(full, (ctypes.c_void_p * 1)(128), 1, 0.1, 0.9, 0.999, 1e-8, 0.0, 0, None) == -5   # the gradient twice
+    assert L.gda_adam_multi_sum_f32(full, (ctypes.c_void_p * 1)(64), 1, 0.1, 0.9, 0.999, 1e-8, 0.0, 0, None) == -5    # the parameter itself
+    assert L.gda_adam_multi_sum_f32(None, None, 1, 0.1, 0.9, 0.999, 1e-8, 0.0, 0, None) == -1
+    assert L.gda_adam_multi_sum_f32(full, None, 1, 0.1, 0.9, 0.999, 1e-8, 0.0, 4, None) == -4
     assert L.gda_adam_multi_ex_f32(table, 1, 0.1, 0.9, 0.999, 1e-8, 0.0, 2, None) == -4   # flag
     assert L.gda_adam_multi_ex_f32(table, 0, 0.1, 0.9, 0.999, 1e-8, 0.0, 1, None) == 0
     assert L.gda_adam_multi_ex_f32(None, 2, 0.1, 0.9, 0.999, 1e-8, 0.0, 1, None) == -1
@@ -920,3 +926,47 @@ def test_degree_order_relabelling_is_an_isomorphism():
     a = O.propagate(*O.gcn_norm(d.edge_index, None, n), d.x)
     b = O.propagate(*O.gcn_norm(r.edge_index, None, n), r.x)
     assert torch.allclose(b[new_id], a, atol=1e-6)
+
+
+def test_second_leaves_hold_the_second_pass_gradients_of_the_shared_layers():
+    """A2GNNBase.second_leaves: inside the scope the conv layers read weight / bias through second leaves over the same
+    storage; after backward ``grad + leaf.grad`` equals what autograd's accumulation stores, the module's parameters are
+    its own again, and a leaf is re-made when the parameter's storage was replaced (a weight re-laid out gather-major)."""
+    from pygda_amd.nn import A2GNNBase
+    torch.manual_seed(0)
+    net = A2GNNBase(8, 4, 3, num_layers=2, dropout=0.0)
+    x1, x2 = torch.randn(5, 8), torch.randn(6, 8)
+
+    def run(table):
+        net.zero_grad()
+        a = net.feat_bottleneck(x1, None, None, 0).sum()
+        if table is not None:
+            with net.second_leaves(table):
+                assert all(conv.lin.weight is table[id(p)] for conv, p in zip(net.convs, own_w))
+                b = net.feat_bottleneck(x2, None, None, 0).pow(2).sum()
+        else:
+            b = net.feat_bottleneck(x2, None, None, 0).pow(2).sum()
+        (a + b).backward()
+        out = {}
+        for name, p in net.named_parameters():
+            g, leaf = p.grad, (table or {}).get(id(p))
+            if leaf is not None and leaf.grad is not None:
+                g = leaf.grad if g is None else g + leaf.grad
+            out[name] = g
+        return out
+
+    own_w = [conv.lin.weight for conv in net.convs]
+    ref = {k: None if v is None else v.clone() for k, v in run(None).items()}
+    table = {}
+    got = run(table)
+    assert len(table) == 4 and [conv.lin.weight for conv in net.convs] == own_w           # restored
+    for k in ref:
+        assert (ref[k] is None and got[k] is None) or torch.equal(ref[k], got[k]), k
+    first = table[id(own_w[0])]
+    own_w[0].data = own_w[0].data.clone()                                                 # new storage
+    for leaf in table.values():
+        leaf.grad = None
+    got = run(table)
+    assert table[id(own_w[0])] is not first and table[id(own_w[0])].data_ptr() == own_w[0].data_ptr()
+    for k in ref:
+        assert (ref[k] is None and got[k] is None) or torch.equal(ref[k], got[k]), k

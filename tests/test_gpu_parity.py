@@ -1358,6 +1358,44 @@ def test_adam_step_counters_bumped_at_the_start_of_the_step():
     assert Adam([dup, dup], lr=0.01).bump_steps() is False
 
 
+def test_adam_sums_a_second_gradient_leaf_inside_the_update():
+    """optim.Adam.grad_aliases (gda_adam_multi_sum_f32): a parameter whose gradient arrives as two contributions -- its
+    own ``.grad`` and the ``.grad`` of a second leaf over the same storage (A2GNNBase.second_leaves) -- is updated with
+    ``grad + leaf.grad`` formed inside the kernel: bit-identical to the plain step on the accumulated gradient over
+    five steps, with steps where only one of the two (or neither) exists, and with the step-counter bump in front."""
+    from pygda_amd.optim import Adam
+    gen = torch.Generator().manual_seed(13)
+    shapes = [(300, 128), (128,), (6775, 128), (5,)]
+    init = [torch.randn(s, generator=gen) for s in shapes]
+    a = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    b = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    oa, ob = Adam(a, lr=0.01, weight_decay=0.005), Adam(b, lr=0.01, weight_decay=0.005)
+    leaves = [torch.nn.Parameter(p.detach()) for p in a[:3]]          # the last parameter has no second leaf
+    for p, leaf in zip(a, leaves):
+        assert leaf.data_ptr() == p.data_ptr()
+        oa.grad_aliases[id(p)] = leaf
+    for step in range(5):
+        oa.zero_grad()
+        ob.zero_grad()
+        assert all(leaf.grad is None for leaf in leaves)
+        if step == 3:
+            assert oa.bump_steps() is True
+        for k in range(len(shapes)):
+            g1 = None if (k == 1 and step == 1) or (k == 0 and step == 2) else torch.randn(shapes[k], generator=gen).to(DEV)
+            g2 = None if k == 3 or (k == 1 and step in (1, 4)) else torch.randn(shapes[k], generator=gen).to(DEV)
+            a[k].grad = g1
+            if k < 3:
+                leaves[k].grad = g2
+            b[k].grad = g1.clone() if g2 is None and g1 is not None else (g2.clone() if g1 is None and g2 is not None else
+                                                                         (None if g1 is None else g1 + g2))
+        oa.step(); ob.step()
+    for x, y in zip(a, b):
+        exact(x, y)
+        for key in ("step", "exp_avg", "exp_avg_sq"):
+            exact(oa.state[x][key], ob.state[y][key])
+    assert float(oa.state[a[1]]["step"]) == 4.0                       # the step without either contribution did not count
+
+
 @pytest.mark.parametrize("M,N,K", [(9360, 128, 128), (5484, 5, 128), (1000, 130, 70), (77, 3, 5), (20000, 64, 256),
                                    (4_400_000, 8, 16)])          # > 65535 row tiles: rows ride on grid.x
 def test_tall_gemm_vs_fp64(M, N, K):
