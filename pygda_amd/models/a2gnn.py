@@ -36,22 +36,27 @@ class A2GNN(BaseGDA):
         # three runs each on one box: 2.88 / 2.98 / 2.92 ms/step against 3.10 / 3.11 / 4.11 on one stream
         # (profiles/r4_stream_experiments.txt); eager launches, so none of the forked-graph scheduling of DESIGN 4.7
         self.overlap_sampled = os.environ.get("PYGDA_AMD_SAMPLED_OVERLAP", "1") == "1"
+        self.features_first = os.environ.get("PYGDA_AMD_FEATURES_FIRST", "1") == "1"
 
     def init_model(self, **kwargs):
         return A2GNNBase(in_dim=self.in_dim, hid_dim=self.hid_dim, num_classes=self.num_classes,
                          num_layers=self.num_layers, adv=self.adv, dropout=self.dropout, act=self.act,
                          mode=self.mode, **kwargs).to(self.device)
 
-    def _target_logits_async(self, net, target_data, h0):
+    def _target_logits_async(self, net, target_data, h0, after=None):
         """The reference's second target forward (:211) is not part of the loss.  It is issued on
         a side HIP stream (fork/join, no autograd tape) so that its small aggregation launches
         overlap the loss branch instead of queueing behind it; under hipGraph capture the fork
-        becomes a parallel branch of the graph."""
+        becomes a parallel branch of the graph.  ``after``: an event recorded where ``h0`` was complete -- the side
+        stream then waits for that point instead of for everything issued on this stream since."""
         main = torch.cuda.current_stream()
         side = getattr(self, "_side_stream", None)
         if side is None:
             side = self._side_stream = torch.cuda.Stream()
-        side.wait_stream(main)
+        if after is not None:
+            side.wait_event(after)
+        else:
+            side.wait_stream(main)
         with torch.cuda.stream(side), torch.no_grad():
             feats = net.feat_bottleneck_from(h0.detach(), target_data.edge_index, None, self.t_pnums)
             out = net.feat_classifier(feats, target_data.edge_index, None, 1)
@@ -83,6 +88,16 @@ class A2GNN(BaseGDA):
             if h0_t is None:
                 h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
             pending = None
+            if self.compute_target_logits and fork and self.features_first:
+                # The feature pass (:193) feeds the domain loss, the logits pass (:211) feeds nothing: the pass issued
+                # FIRST is the one a replayed graph starts first -- the other branch of the fork sat 15-35 us behind it
+                # on every timeline (profiles/r4_cfgA_timeline.txt) -- so the feature pass goes first, as in the
+                # reference, and the logits pass forks from an event recorded where layer 0 was complete.
+                ready = torch.cuda.Event()
+                ready.record()
+                target_features = net.feat_bottleneck_from(h0_t, target_data.edge_index, tb, self.t_pnums)   # :193
+                pending = self._target_logits_async(net, target_data, h0_t, after=ready)
+                return h0_t, pending, target_features
             if self.compute_target_logits and fork:
                 pending = self._target_logits_async(net, target_data, h0_t)
             target_features = net.feat_bottleneck_from(h0_t, target_data.edge_index, tb, self.t_pnums)   # :193
