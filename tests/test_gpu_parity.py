@@ -266,7 +266,7 @@ def _mmd_f64(src, tgt, idx_s=None, idx_t=None, times=1):
         loss = loss + (K[:n, :n] + K[n:, n:] - K[:n, n:] - K[n:, :n]).mean()
     loss = loss / times
     loss.backward()
-    return float(loss), src.grad, tgt.grad
+    return float(loss.detach()), src.grad, tgt.grad
 
 
 def _mmd_run(s, t, idx=None, rows=None):
@@ -278,7 +278,7 @@ def _mmd_run(s, t, idx=None, rows=None):
     else:
         loss = ops.mmd_loss(s, t, idx[0], idx[1], sel=idx[2])
     loss.backward()
-    return float(loss), s.grad, t.grad
+    return float(loss.detach()), s.grad, t.grad
 
 
 def _rel(a, b):

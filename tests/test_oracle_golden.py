@@ -31,6 +31,27 @@ def test_mmd_true_oracle(tag):
     eq(loss2, g["loss"], 1e-6)
 
 
+def test_the_float64_yardstick_of_the_gpu_mmd_tests_is_the_reference_arithmetic():
+    """tests/test_gpu_parity.py measures both MMD kernel paths against `_mmd_f64` (Gram form on pivot-shifted rows,
+    float64): here that yardstick against the reference-run goldens (difference form, float32) and against the oracle run
+    in float64 -- loss and both gradients, with the goldens' own row samples."""
+    from tests.test_gpu_parity import _mmd_f64
+    for tag, rtol in (("small", 2e-6), ("mid", 2e-6)):
+        g = load_golden(f"mmd_{tag}")
+        s, t = T(g["src"]), T(g["tgt"])
+        si, ti = T(g["src_idx"]).long(), T(g["tgt_idx"]).long()
+        loss, gs, gt = _mmd_f64(s, t, si, ti, times=si.size(0))
+        assert abs(loss - float(g["loss"])) <= 2e-5 * abs(float(g["loss"])) + 1e-9           # the golden is a float32 run
+        assert float((gs - T(g["gsrc"]).double()).norm() / T(g["gsrc"]).double().norm()) <= 2e-5
+        assert float((gt - T(g["gtgt"]).double()).norm() / T(g["gtgt"]).double().norm()) <= 2e-5
+        sd, td = s.double().requires_grad_(), t.double().requires_grad_()
+        want = O.MMD(sd, td, samples=(si, ti))
+        want.backward()
+        assert abs(loss - float(want)) <= 1e-9 * abs(float(want)) + 1e-15
+        assert float((gs - sd.grad).norm() / sd.grad.norm()) <= 1e-9
+        assert float((gt - td.grad).norm() / td.grad.norm()) <= 1e-9
+
+
 def test_get_mmd_and_kernel():
     g = load_golden("get_mmd_96")
     s, t = T(g["src"]).requires_grad_(), T(g["tgt"]).requires_grad_()
