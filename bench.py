@@ -519,8 +519,9 @@ def init_group(args, world, rank, dev):
             raise SystemExit(f"bench.py: the group's ranks are {args._ranks_seen}, expected 0..{world - 1}")
         args._collectives = "torch.distributed ProcessGroup (" + dist.get_backend() + ")"
         if gpu and dist.get_backend() == "nccl":
-            # the library-owned RCCL communicator is the default for the exchange steps; it is kept only if EVERY rank
-            # built it and passed its self-test (pygda_amd/distributed.py), else all ranks stay on the ProcessGroup
+            # the library-owned RCCL communicator is opt-in (--rccl-direct / PYGDA_AMD_RCCL_DIRECT=1: it has never seen
+            # two ranks); when asked for it is kept only if EVERY rank built it and passed its self-test
+            # (pygda_amd/distributed.py: staged, fault-symmetric), else all ranks stay on the ProcessGroup
             from pygda_amd import distributed as _D
             if _D.direct_agreed() is not None:
                 args._collectives = "library-owned RCCL communicator (gda_comm_*: enqueues on the training stream)"

@@ -314,6 +314,13 @@ int gda_mmd_bwd_ex_f32(const float* src, int64_t ld_src, const float* tgt, int64
  *   workspace   gda_mmd_workspace_bytes(times, n, d) bytes, as for the two-pass calls
  * src_idx / tgt_idx need rows_src / rows_tgt (the gathered copy) here. */
 int gda_mmd_fused_nseg(int times, int64_t n, int64_t d, float kernel_mul, int kernel_num);
+/* Host arithmetic only (no device): what the fused pass lays out for (times, n, d), for tests and debuggers.
+ *   out[16] = { nb, ntiles, njb, nseg, workgroups, image bytes,
+ *               image offsets: rows lo, columns hi, columns lo, norms; float index of the tile scale in the norm block,
+ *               floats reserved for that block (32 norms + scale);
+ *               workspace offsets: images, part_max, kpartial; workspace bytes }
+ * GDA_E_UNSUPPORTED when gda_mmd_fused_nseg() would return 0. */
+int gda_mmd_fused_layout(int times, int64_t n, int64_t d, int64_t* out, int n_out);
 int gda_mmd_fused_fwd_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
                           int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
                           int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,

@@ -48,6 +48,7 @@ _SIGNATURES = {
                                    _P, _P, _P, c_float, _P, _P, _P, c_int64, _P, _P, _P, c_int64, _P,
                                    _P, c_size_t, _P]),
     "gda_mmd_fused_nseg": (c_int, [c_int, c_int64, c_int64, c_float, c_int]),
+    "gda_mmd_fused_layout": (c_int, [c_int, c_int64, c_int64, _P, c_int]),
     "gda_mmd_fused_fwd_f32": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, _P, c_int, c_int64, c_float, c_int, c_float,
                                       c_float, _P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "gda_mmd_fused_bwd_f32": (c_int, [_P, c_int, c_int, c_int64, c_int64, _P, c_float, _P,

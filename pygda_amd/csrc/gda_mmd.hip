@@ -997,6 +997,23 @@ extern "C" int gda_mmd_fused_nseg(int times, int64_t n, int64_t d, float kernel_
     return fused_plan(times, n, d, kernel_mul, kernel_num, &fp) ? fp.nseg : 0;
 }
 
+// What the fused pass lays out for (times, n, d) -- host arithmetic only, no device needed: the CPU test suite checks
+// the image layout, the plan and the workspace carve with it.
+extern "C" int gda_mmd_fused_layout(int times, int64_t n, int64_t d, int64_t* out, int n_out) {
+    if (!out) return GDA_E_NULL;
+    if (n_out < 16) return GDA_E_SIZE;
+    FusedPlan fp;
+    if (!fused_plan(times, n, d, 2.0f, 5, &fp)) return GDA_E_UNSUPPORTED;
+    const MmdWs w = carve((void*)(uintptr_t)4096, times, n, d);       // offsets relative to a fake base
+    const int di = (int)d;
+    const int64_t v[16] = {fp.nb, fp.ntiles, fp.njb, fp.nseg, fp.total, (int64_t)fp.img,
+                           f_off_rl(di), f_off_th(di), f_off_tl(di), f_off_n(di), F_OFF_XS, F_TAIL_FLOATS,
+                           (int64_t)((uintptr_t)w.images - 4096), (int64_t)((uintptr_t)w.part_max - 4096),
+                           (int64_t)((uintptr_t)w.kpartial - 4096), (int64_t)w.total};
+    for (int i = 0; i < 16; ++i) out[i] = v[i];
+    return GDA_OK;
+}
+
 template <int NB>
 static int launch_fused(hipStream_t stream, const Rows& Rin, float* rows_src, float* rows_tgt, int64_t m, int64_t d, const MmdWs& ws,
                         const FusedPlan& fp, int times, float* bandwidth, float* grad_part) {

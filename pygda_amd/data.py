@@ -94,19 +94,42 @@ def relabel(data, new_id):
     list follow): an isomorphic ``Data``, so training on it is training on the original; ``out[new_id]`` maps a
     per-node result of the relabelled graph back to the original numbering."""
     n = data.num_nodes
+    e = data.num_edges
     inv = torch.empty_like(new_id)
     inv[new_id] = torch.arange(n, device=new_id.device)
-    out = {}
+    out, private = {}, {}
     for k, v in data.__dict__.items():
-        if k.startswith("_") or v is None:
+        if v is None:
             continue
-        if k == "edge_index":
+        if k.startswith("_"):
+            # private flags travel (`_static_graph`: the K-step kernel's eligibility); the device-copy cache does not --
+            # it holds copies of the OLD numbering
+            if k != "_device_copies":
+                private[k] = v
+        elif k == "edge_index":
             out[k] = new_id[v]
-        elif torch.is_tensor(v) and v.dim() >= 1 and v.size(0) == n:
+        elif torch.is_tensor(v) and v.dim() >= 1 and v.size(0) == n and not _edge_level(k, v, n, e):
             out[k] = v[inv]
         else:
-            out[k] = v
-    return Data(**out)
+            out[k] = v                                  # per-edge attributes keep their order: the edges did not move
+    res = Data(**out)
+    for k, v in private.items():
+        setattr(res, k, v)
+    return res
+
+
+def _edge_level(key, v, n, e):
+    """Is ``v`` (first dimension n) a per-EDGE attribute?  Only ambiguous when the graph has as many edges as nodes:
+    then the PyG naming convention decides (``edge_attr``, ``edge_weight``, ``edge_*`` are per edge; ``x``, ``y``,
+    ``batch``, ``pos``, ``*_mask`` per node), and anything else is refused rather than guessed."""
+    if e != n:
+        return False
+    if key.startswith("edge"):
+        return True
+    if key in ("x", "y", "batch", "pos") or key.endswith("_mask") or key.startswith("node"):
+        return False
+    raise ValueError(f"relabel: attribute {key!r} has {n} rows and the graph has {n} nodes AND {e} edges -- "
+                     "name it edge_* or node_* so that it is permuted (or not) on purpose")
 
 
 def to_undirected(edge_index, num_nodes=None):

@@ -18,54 +18,76 @@ class _DirectComm:
     """RCCL communicator owned by libgda_hip.so (include/gda_hip.h: gda_comm_*): the two exchange
     steps become plain enqueues on the current stream -- no ProcessGroup work objects, no watchdog
     events -- which is what lets a whole data-parallel step be captured into ONE hipGraph.
-    Default for ``nccl`` groups (:func:`direct`); the rendezvous (shipping the 128-byte id) still rides on
-    the torch.distributed group the launcher set up."""
+    OPT-IN (``PYGDA_AMD_RCCL_DIRECT=1``): it has only ever been exercised on a 1-rank group.  Built in stages by
+    :func:`direct_agreed`, every stage followed by an agreement over the torch.distributed group, so that a rank
+    that fails alone never leaves its peers in a collective it does not join."""
 
     def __init__(self):
         from . import _lib
-        self.L = L = _lib.lib()
+        self.L = _lib.lib()
         self._lib = _lib
+        self.handle = None
+        self.uid = None
+
+    def load(self):
+        """Stage 1 (local, no collective): bind librccl; rank 0 makes the unique id."""
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        _lib.check(L.gda_rccl_load(path.encode() if os.path.isfile(path) else None), "gda_rccl_load")
-        dev = torch.device("cuda", torch.cuda.current_device())
-        uid = torch.zeros(128, dtype=torch.uint8)
+        self._lib.check(self.L.gda_rccl_load(path.encode() if os.path.isfile(path) else None), "gda_rccl_load")
+        self.uid = torch.zeros(128, dtype=torch.uint8)
         if dist.get_rank() == 0:
             buf = (ctypes.c_char * 128)()
-            _lib.check(L.gda_comm_unique_id(buf, 128), "gda_comm_unique_id")
-            uid = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
-        uid = uid.to(dev)
+            self._lib.check(self.L.gda_comm_unique_id(buf, 128), "gda_comm_unique_id")
+            self.uid = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+
+    def init_rank(self):
+        """Stage 2 (collective; entered only when EVERY rank passed stage 1): ship the id, join the communicator."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        uid = self.uid.to(dev)
         dist.broadcast(uid, src=0)
         raw = bytes(uid.cpu().tolist())
         handle = ctypes.c_void_p()
-        _lib.check(L.gda_comm_init_rank(raw, 128, dist.get_world_size(), dist.get_rank(), ctypes.byref(handle)),
-                   "gda_comm_init_rank")
+        self._lib.check(self.L.gda_comm_init_rank(raw, 128, dist.get_world_size(), dist.get_rank(),
+                                                  ctypes.byref(handle)), "gda_comm_init_rank")
         self.handle = handle
 
-    def all_reduce_(self, flat):
-        self._lib.check(self.L.gda_allreduce_f32(self._lib.ptr(flat), flat.numel(), self.handle,
-                                                 self._lib.stream()), "gda_allreduce_f32")
+    def destroy(self):
+        if self.handle is not None:
+            try:
+                self._lib.check(self.L.gda_comm_destroy(self.handle), "gda_comm_destroy")
+            finally:
+                self.handle = None
 
-    def all_gather(self, out, x):
+    def all_reduce_(self, flat, stream=None):
+        self._lib.check(self.L.gda_allreduce_f32(self._lib.ptr(flat), flat.numel(), self.handle,
+                                                 self._lib.stream() if stream is None else stream), "gda_allreduce_f32")
+
+    def all_gather(self, out, x, stream=None):
         self._lib.check(self.L.gda_allgather_f32(self._lib.ptr(x), self._lib.ptr(out), x.numel(), self.handle,
-                                                 self._lib.stream()), "gda_allgather_f32")
+                                                 self._lib.stream() if stream is None else stream), "gda_allgather_f32")
 
 
 _direct = None
 _direct_failed = None       # why the library-owned communicator was given up for this process (str), or None
+_direct_tried = False
 
 
 def _self_test(comm, timeout_s=20.0):
-    """One all-reduce and one all-gather on the fresh communicator, checked against what they must return; polled with
-    a deadline so that a communicator that never completes costs the process `timeout_s`, not the run."""
+    """One all-reduce and one all-gather on the fresh communicator, checked against what they must return.  They run
+    on a stream of their OWN (a self-test that never completes must not leave its collectives queued in front of the
+    training stream's work) and are polled with a deadline, so a dead communicator costs `timeout_s`, not the run."""
     import time
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = torch.device("cuda", torch.cuda.current_device())
-    x = torch.full((257,), float(rank + 1), dtype=torch.float32, device=dev)
-    g = torch.empty(world, 3, dtype=torch.float32, device=dev)
-    comm.all_reduce_(x)
-    comm.all_gather(g, torch.full((3,), float(rank), dtype=torch.float32, device=dev))
-    ev = torch.cuda.Event()
-    ev.record()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        x = torch.full((257,), float(rank + 1), dtype=torch.float32, device=dev)
+        g = torch.empty(world, 3, dtype=torch.float32, device=dev)
+        mine = torch.full((3,), float(rank), dtype=torch.float32, device=dev)
+        comm.all_reduce_(x, stream=side.cuda_stream)
+        comm.all_gather(g, mine, stream=side.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(side)
     t0 = time.time()
     while not ev.query():
         if time.time() - t0 > timeout_s:
@@ -78,62 +100,92 @@ def _self_test(comm, timeout_s=20.0):
         raise RuntimeError("all-gather self-test: rank order of the gathered blocks is wrong")
 
 
+def direct_enabled():
+    """The library-owned communicator is OPT-IN (``PYGDA_AMD_RCCL_DIRECT=1``): no round had a
+    multi-GPU node, so it has never seen two ranks.  The torch.distributed ProcessGroup (the same RCCL underneath)
+    is the default for every collective."""
+    return os.environ.get("PYGDA_AMD_RCCL_DIRECT", "0") == "1"
+
+
 def direct():
-    """The library-owned RCCL communicator (csrc/gda_comm.cpp): the DEFAULT for the exchange steps of an ``nccl``
-    group since round 4 -- plain enqueues on the caller's stream, no ProcessGroup work objects, no per-collective
-    host bookkeeping.  It is built on first use (unique id shipped over the torch.distributed group) and must pass a
-    self-test (all-reduce + all-gather against known answers, with a deadline); ANY failure -- librccl symbols not
-    found, communicator init, wrong answer, timeout -- is reported once and every collective of this process then goes
-    through torch.distributed's ProcessGroup (same RCCL underneath), which stays the fallback.
-    ``PYGDA_AMD_RCCL_DIRECT=0`` switches it off.  gloo groups (CPU tests, ranks sharing a GPU) never use it."""
-    global _direct, _direct_failed
-    if (os.environ.get("PYGDA_AMD_RCCL_DIRECT", "1") == "0" or _direct_failed is not None or not active()
-            or dist.get_backend() != "nccl"):
+    """The communicator :func:`direct_agreed` built and every rank agreed on, or None.  Never builds one itself: a
+    rank constructing it alone, in the middle of a step, is exactly the asymmetric rendezvous that hangs a job."""
+    if not direct_enabled() or not active() or dist.get_backend() != "nccl":
         return None
-    if _direct is None:
-        try:
-            comm = _DirectComm()
-            _self_test(comm)
-            _direct = comm
-        except Exception as exc:                     # noqa: BLE001 -- anything: the ProcessGroup path is complete
-            _direct_failed = f"{type(exc).__name__}: {exc}"
-            import warnings
-            warnings.warn("library-owned RCCL communicator unavailable (" + _direct_failed +
-                          "); collectives go through torch.distributed")
-            return None
-        # every rank must agree (a rank on the ProcessGroup path and a rank on the communicator would deadlock):
-        # the agreement itself rides on the ProcessGroup
     return _direct
 
 
+def _all_ranks_ok(local_ok):
+    flag = torch.tensor([1.0 if local_ok else 0.0], device=torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return float(flag) >= 1.0
+
+
 def direct_agreed():
-    """Collective: build the communicator on every rank and keep it only if EVERY rank succeeded (one rank falling back
-    alone would leave its peers waiting in a collective it never joins).  Call once, at start-up, from all ranks."""
-    global _direct, _direct_failed
-    if not active() or dist.get_backend() != "nccl":
+    """Collective, called once at start-up by ALL ranks (``fit()``, ``bench.py``): build the library-owned RCCL
+    communicator in three stages -- bind librccl + unique id | id broadcast + ``ncclCommInitRank`` | self-test --
+    each followed by an all-reduce(MIN) of "this rank succeeded" over the ProcessGroup.  A failure on ANY rank at ANY
+    stage makes EVERY rank leave at the same point: the ranks' ProcessGroup collectives always match (the hang
+    ADVICE round 4 describes -- one rank skipping the id broadcast -- cannot happen), a half-built communicator is
+    destroyed, and every collective of the run stays on the ProcessGroup path.  Returns the communicator or None."""
+    global _direct, _direct_failed, _direct_tried
+    if not direct_enabled() or not active() or dist.get_backend() != "nccl":
         return None
-    ok = torch.tensor([1.0 if direct() is not None else 0.0], device=torch.device("cuda", torch.cuda.current_device()))
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if float(ok) < 1.0 and _direct is not None:
-        _direct_failed = "another rank could not build its communicator"
-        _direct = None
+    if _direct_tried:
+        return _direct
+    _direct_tried = True
+    import warnings
+    comm, err = None, None
+
+    def stage(name, fn):
+        nonlocal err
+        if err is None:
+            try:
+                fn()
+            except Exception as exc:                 # noqa: BLE001 -- anything: the ProcessGroup path is complete
+                err = f"{name}: {type(exc).__name__}: {exc}"
+        ok = _all_ranks_ok(err is None)
+        if not ok and err is None:
+            err = f"{name}: another rank failed"
+        return ok
+
+    def make():
+        nonlocal comm
+        comm = _DirectComm()
+        comm.load()
+
+    good = stage("load", make) and stage("init_rank", lambda: comm.init_rank()) and \
+        stage("self_test", lambda: _self_test(comm))
+    if good:
+        _direct = comm
+    else:
+        _direct_failed = err
+        if comm is not None:
+            try:
+                comm.destroy()
+            except Exception:                        # noqa: BLE001
+                pass
+        warnings.warn("library-owned RCCL communicator unavailable (" + str(err) +
+                      "); collectives go through torch.distributed")
     return _direct
 
 
 def capture_collectives():
     """Whether a data-parallel step may be captured WITH its collectives into one hipGraph (opt-in,
-    ``PYGDA_AMD_RCCL_CAPTURE=1``: validated on a 1-rank group only -- no multi-GPU node was available to any round --
-    so N > 1 runs keep the collectives eager between captured segments unless asked otherwise)."""
+    ``PYGDA_AMD_RCCL_CAPTURE=1`` on top of ``PYGDA_AMD_RCCL_DIRECT=1``: validated on a 1-rank group only -- no
+    multi-GPU node was available to any round -- so N > 1 runs keep the collectives eager between captured segments
+    unless asked otherwise)."""
     return os.environ.get("PYGDA_AMD_RCCL_CAPTURE") == "1" and direct() is not None
 
 
 def shutdown_direct():
     """Destroy the library-owned communicator (tests; normal runs keep it for the process lifetime)."""
-    global _direct
+    global _direct, _direct_tried, _direct_failed
     if _direct is not None:
         torch.cuda.synchronize()
-        _direct._lib.check(_direct.L.gda_comm_destroy(_direct.handle), "gda_comm_destroy")
+        _direct.destroy()
         _direct = None
+    _direct_tried, _direct_failed = False, None
 
 
 def info():

@@ -447,36 +447,24 @@ class GraphedStepSplit(GraphedStep):
         return out
 
     def _tail(self, rest_part, a, b, with_stats):
-        loss, logits = rest_part(a, b, self.alpha)
+        loss, logits = rest_part(a, b, self.alpha)       # a plain loss tensor: `defer_total` is set for GraphedStep only
         main = torch.cuda.current_stream()
         if with_stats:
             side = self._stat_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 from .ops import ce_stats_for
-                # rest_part may hand back the loss as separate terms (LossTerms, as the one-graph step does): the
-                # reported total is the same fp32 sum as `a + b` in eager mode
-                terms = loss if isinstance(loss, LossTerms) else None
-                total = loss
-                if terms is not None:
-                    total = terms[0].detach()
-                    for extra in terms[1:]:
-                        total = total + extra.detach()
                 by_product = ce_stats_for(logits, self.src.y)     # the loss kernel counted the correct rows already
                 if by_product is not None:
-                    by_product[0:1].copy_(total.detach().reshape(1))   # slot 0: the TOTAL loss of the step
+                    by_product[0:1].copy_(loss.detach().reshape(1))    # slot 0: the TOTAL loss of the step
                     self.stats = by_product
                 else:
                     correct = (logits.detach().argmax(dim=1) == self.src.y).sum()
-                    self.stats = torch.stack([total.detach().double(), correct.double()])
-            for t in ((*terms, logits) if terms is not None else (loss, logits)):
+                    self.stats = torch.stack([loss.detach().double(), correct.double()])
+            for t in (loss, logits):
                 t.record_stream(side)
         self.optimizer.zero_grad(set_to_none=True)
-        if terms is not None:
-            torch.autograd.backward(list(terms))
-            loss = total
-        else:
-            loss.backward()
+        loss.backward()
         self.optimizer.step()
         if with_stats:
             main.wait_stream(side)

@@ -537,6 +537,60 @@ def mmd_one_pass_segments(times, n, d, kernel_mul=2.0, kernel_num=5):
     return int(_lib.lib().gda_mmd_fused_nseg(int(times), int(n), int(d), float(kernel_mul), int(kernel_num)))
 
 
+_one_pass_checked = {}      # device index -> True (agrees with the two-pass kernels) | False (declined) | "running"
+MMD_ONE_PASS_SELF_CHECK = _os.environ.get("PYGDA_AMD_MMD_SELF_CHECK", "1") == "1"
+
+
+def mmd_one_pass_ok(dev):
+    """First use of the one-pass MMD on a device: run it BESIDE the fp32-MFMA two-pass kernels on a small fixed problem
+    (own generator: the global CPU stream that seeded runs depend on is not touched) and keep it only if loss and row
+    gradients agree to 1e-4 -- the kernel is hand-scheduled gfx950 assembly (LDS-DMA, explicit waits) that only the GPU
+    tests execute, so a library built against another driver / compiler is caught here, once, instead of training on a
+    silently different loss.  ~10 launches, once per process and device; never inside a capture."""
+    global MMD_ONE_PASS
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    state = _one_pass_checked.get(key)
+    if state is not None:
+        return state is not False
+    if not MMD_ONE_PASS_SELF_CHECK:
+        _one_pass_checked[key] = True
+        return True
+    if torch.cuda.is_current_stream_capturing():
+        return True                                    # cannot compare inside a capture; checked at the next eager call
+    _one_pass_checked[key] = "running"
+    gen = torch.Generator().manual_seed(20240521)
+    ok, why = True, ""
+    try:
+        for d in (128, 64):
+            times, n = 2, 80
+            a = (torch.randn(times * n, d, generator=gen) * 0.7 + 0.3).to(dev).requires_grad_(True)
+            b = (torch.randn(times * n, d, generator=gen) * 0.9 - 0.1).to(dev).requires_grad_(True)
+            got = []
+            for one in (True, False):
+                MMD_ONE_PASS = one
+                with torch.enable_grad():              # called from inside an autograd Function's forward
+                    loss = _MMD.apply(a, b, None, None, times, n, 2.0, 5, None)
+                    ga, gb = torch.autograd.grad(loss, (a, b))
+                got.append((loss.detach().double(), torch.cat([ga, gb]).double()))
+            MMD_ONE_PASS = True
+            (l1, g1), (l2, g2) = got
+            dl = float((l1 - l2).abs() / l2.abs().clamp_min(1e-30))
+            dg = float((g1 - g2).norm() / g2.norm().clamp_min(1e-30))
+            if not (dl <= 1e-4 and dg <= 1e-4):        # NaN fails too
+                ok, why = False, f"d={d}: loss differs by {dl:.3g}, row gradients by {dg:.3g} (relative)"
+                break
+    except Exception as exc:                           # noqa: BLE001 -- a launch failure is a reason to decline too
+        ok, why = False, f"{type(exc).__name__}: {exc}"
+    finally:
+        MMD_ONE_PASS = True
+    _one_pass_checked[key] = ok
+    if not ok:
+        import warnings
+        warnings.warn("one-pass MMD kernel declined by its first-use self-check (" + why +
+                      "); this process uses the two-pass fp32-MFMA kernels")
+    return ok
+
+
 class _MMD(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, tgt, src_idx, tgt_idx, times, n, kernel_mul, kernel_num, fix_sigma, sel=None, scale=1.0,
@@ -568,7 +622,7 @@ class _MMD(torch.autograd.Function):
         if (idx_s is None or rows_s is not None) and not fix_sigma:
             nseg = mmd_one_pass_segments(times, n, d, kernel_mul, kernel_num)
             aligned = src.data_ptr() % 16 == 0 and tgt.data_ptr() % 16 == 0
-            nseg = nseg if aligned else 0
+            nseg = nseg if aligned and (not nseg or mmd_one_pass_ok(dev)) else 0
         ctx.one_pass = nseg
         if nseg:
             part = torch.empty(times, nseg, m, d, dtype=torch.float32, device=dev)

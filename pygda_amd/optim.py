@@ -51,11 +51,18 @@ class Adam(torch.optim.Optimizer):
         following :meth:`step` then launches the update alone.  The bump used to sit between the last gradient kernel
         and the update (8 us + a launch gap at the end of every replayed step).  Returns False, having done nothing,
         when the optimiser's shape does not allow it (a Parameter listed twice -- UDAGCN -- is updated in two rounds
-        with two increments; more tensors than one launch takes)."""
-        params = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
-        if len({id(p) for p in params}) != len(params) or not 0 < len(params) <= MAX_TENSORS:
+        with two increments; more tensors than one launch takes).
+
+        Only parameters that already HAVE optimiser state are bumped: like ``torch.optim.Adam`` (and this class's own
+        eager path) state is created lazily, on the first step in which a parameter has a gradient -- ``state_dict()``
+        of a captured run therefore holds the same entries as an eager run's, and a parameter that never receives a
+        gradient costs a replayed step nothing.  A parameter that meets its first gradient in a
+        bumped step gets that one increment inside :meth:`step`."""
+        listed = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        if len({id(p) for p in listed}) != len(listed) or not 0 < len(listed) <= MAX_TENSORS:
             return False
-        ptrs = (ctypes.c_void_p * len(params))(*[self._state(p)["step"].data_ptr() for p in params])
+        params = [p for p in listed if self.state.get(p)]
+        ptrs = (ctypes.c_void_p * max(len(params), 1))(*[self.state[p]["step"].data_ptr() for p in params])
         _lib.check(_lib.lib().gda_step_bump(None if counter is None else counter.data_ptr(), ptrs, len(params),
                                             _lib.stream()), "gda_step_bump")
         self._bumped = {id(p) for p in params}
@@ -74,8 +81,11 @@ class Adam(torch.optim.Optimizer):
             # was bumped and has none gets its increment taken back (a plain device op: captured with the step)
             for group in self.param_groups:
                 for p in group["params"]:
-                    if id(p) in bumped and p.grad is None and self._second(p) is None:
-                        self._state(p)["step"].sub_(1.0)
+                    has_grad = p.grad is not None or self._second(p) is not None
+                    if id(p) in bumped and not has_grad:
+                        self.state[p]["step"].sub_(1.0)
+                    elif id(p) not in bumped and has_grad:
+                        self._state(p)["step"].add_(1.0)       # first gradient ever: state is created here, as torch does
         for group in self.param_groups:
             # A Parameter listed twice (UDAGCN / SpecReg hand the optimiser the conv weights their two
             # encoders share twice, pygda/models/udagcn.py:262-268) is updated twice per step, one update after

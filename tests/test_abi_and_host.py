@@ -1,6 +1,7 @@
 """CPU: the C-ABI library loads and exports every symbol include/gda_hip.h declares; the
 host-side mirror of the reference interface (ctor validation, Data, loaders, metrics,
 logger) behaves like the reference.  No kernels are launched here."""
+import ctypes
 import io
 import os
 import re
@@ -926,6 +927,57 @@ def test_degree_order_relabelling_is_an_isomorphism():
     a = O.propagate(*O.gcn_norm(d.edge_index, None, n), d.x)
     b = O.propagate(*O.gcn_norm(r.edge_index, None, n), r.x)
     assert torch.allclose(b[new_id], a, atol=1e-6)
+    # as many edges as nodes: a per-edge attribute must NOT be permuted, a per-node one must, an
+    # attribute that could be either is refused; private flags travel, the cache of device copies does not
+    ei2 = ei[:, :n]
+    ew = torch.rand(n, generator=g)
+    d2 = Data(x=d.x, edge_index=ei2, y=d.y, edge_weight=ew, train_mask=d.y > 0)
+    d2._static_graph = True
+    d2._device_copies["cpu0"] = d2
+    r2 = relabel(d2, new_id)
+    assert torch.equal(r2.edge_weight, ew) and torch.equal(r2.edge_index, new_id[ei2])
+    assert torch.equal(r2.train_mask[new_id], d2.train_mask) and torch.equal(r2.x[new_id], d.x)
+    assert r2._static_graph is True and r2._device_copies == {}
+    a2 = O.propagate(*O.gcn_norm(d2.edge_index, ew, n), d2.x)
+    b2 = O.propagate(*O.gcn_norm(r2.edge_index, r2.edge_weight, n), r2.x)
+    assert torch.allclose(b2[new_id], a2, atol=1e-6)
+    with pytest.raises(ValueError, match="edge_\\* or node_\\*"):
+        relabel(Data(x=d.x, edge_index=ei2, y=d.y, score=ew), new_id)
+
+
+def test_mmd_one_pass_plan_image_layout_and_workspace_carve():
+    """gda_mmd_fused_layout (host arithmetic of csrc/gda_mmd_fused.inc, no device): the work plan, the LDS image a tile
+    is staged as, and the workspace carve of the one-pass MMD -- checked here because the kernel itself only runs on the
+    GPU box (the tile scale lives at float index 32 BEHIND the 32 norms and must be inside the bytes the
+    image reserves for every covered width, not only where rounding to 1 KB happens to leave room)."""
+    L = _lib.lib()
+    out = (ctypes.c_int64 * 16)()
+    for times, n, d in ((5, 1000, 128), (5, 1000, 96), (5, 1000, 64), (5, 1000, 32), (1, 96, 128), (3, 200, 64),
+                        (2, 17, 32), (5, 7000, 128), (1, 1, 32)):
+        assert L.gda_mmd_fused_layout(times, n, d, out, 16) == 0
+        (nb, ntiles, njb, nseg, total, img, off_rl, off_th, off_tl, off_n, xs, tail, ws_img, ws_max, ws_kp,
+         ws_total) = list(out)
+        m = 2 * n
+        # the plan
+        assert nb == d // 32 and ntiles == -(-m // 32) and njb == -(-ntiles // 4)
+        assert 1 <= nseg <= min(8, ntiles) and total == times * njb * nseg
+        assert nseg == L.gda_mmd_fused_nseg(times, n, d, 2.0, 5)
+        # the image: rows hi | rows lo (row-major, (d + 8) halves per row) | columns hi | columns lo (80 bytes per
+        # feature column) | 32 norms + the tile scale
+        rstride = (d + 8) * 2
+        assert off_rl == 32 * rstride and off_th == 2 * off_rl
+        assert off_tl - off_th == d * 80 and off_n - off_tl == d * 80
+        assert off_n % 16 == 0 and img % 1024 == 0
+        assert xs == 32 and tail == 33 and off_n + 4 * tail <= img           # norms AND scale inside the image
+        assert 2 * img <= 160 * 1024 // 2                                    # double-buffered, two workgroups per CU
+        # the carve: aligned, ordered, images last and inside the workspace the Python side allocates
+        assert ws_total == L.gda_mmd_workspace_bytes(times, n, d)
+        assert ws_kp == 0 and 0 < ws_max < ws_img and ws_img % 256 == 0 and ws_max % 256 == 0
+        assert ws_img + times * ntiles * img <= ws_total
+        assert ws_kp + 8 * times * njb * nseg <= ws_max                      # one double per workgroup for k_finalize
+    assert L.gda_mmd_fused_layout(5, 1000, 645, out, 16) == -4               # not covered: GDA_E_UNSUPPORTED
+    assert L.gda_mmd_fused_layout(5, 1000, 128, out, 8) == -2                # GDA_E_SIZE
+    assert L.gda_mmd_fused_layout(5, 1000, 128, None, 16) == -1              # GDA_E_NULL
 
 
 def test_second_leaves_hold_the_second_pass_gradients_of_the_shared_layers():

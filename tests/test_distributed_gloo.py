@@ -215,31 +215,86 @@ def test_sampler_threads_divide_by_the_local_world_size(monkeypatch):
 
 
 def test_direct_communicator_falls_back_when_it_cannot_be_built(monkeypatch):
-    """distributed.direct(): the library-owned RCCL communicator is the default for nccl groups, but ANY failure to
-    build it (no librccl symbols, init error, failed self-test) is reported once and leaves every collective on the
-    torch.distributed ProcessGroup -- no second attempt, no exception into the training loop."""
+    """distributed.direct_agreed(): the library-owned RCCL communicator is OPT-IN and built in stages, each followed by
+    an agreement of all ranks; ANY failure (no librccl symbols, init error, failed self-test, a PEER's failure) is
+    reported once, destroys what was built and leaves every collective on the torch.distributed ProcessGroup -- no
+    second attempt, no exception into the training loop, and the same number of ProcessGroup collectives on a failing
+    rank as on a healthy one (a rank failing alone must not desynchronise the group)."""
     import warnings
     from pygda_amd import distributed as D
-    calls = []
+    log = []
 
-    def boom():
-        calls.append(1)
-        raise RuntimeError("librccl symbols not found")
+    class Comm:
+        def __init__(self):
+            log.append("new")
+            self.handle = None
+
+        def load(self):
+            log.append("load")
+            if fail_at == "load":
+                raise RuntimeError("librccl symbols not found")
+
+        def init_rank(self):
+            log.append("init_rank")
+            self.handle = 1
+            if fail_at == "init_rank":
+                raise RuntimeError("ncclCommInitRank failed")
+
+        def destroy(self):
+            log.append("destroy")
+
+    def self_test(comm):
+        log.append("self_test")
+        if fail_at == "self_test":
+            raise TimeoutError("no completion")
+
+    agreements = []
+
+    def all_ok(local_ok):
+        agreements.append(local_ok)
+        return local_ok and not peer_fails_at == len(agreements)
 
     monkeypatch.setattr(D, "active", lambda: True)
     monkeypatch.setattr(D.dist, "get_backend", lambda *a, **k: "nccl")
-    monkeypatch.setattr(D, "_DirectComm", boom)
-    monkeypatch.setattr(D, "_direct", None)
-    monkeypatch.setattr(D, "_direct_failed", None)
+    monkeypatch.setattr(D, "_DirectComm", Comm)
+    monkeypatch.setattr(D, "_self_test", self_test)
+    monkeypatch.setattr(D, "_all_ranks_ok", all_ok)
+
+    def fresh():
+        monkeypatch.setattr(D, "_direct", None)
+        monkeypatch.setattr(D, "_direct_failed", None)
+        monkeypatch.setattr(D, "_direct_tried", False)
+        log.clear()
+        agreements.clear()
+
+    # off unless asked for: never even attempted, and direct() never builds anything on its own
     monkeypatch.delenv("PYGDA_AMD_RCCL_DIRECT", raising=False)
-    with pytest.warns(UserWarning, match="library-owned RCCL communicator unavailable"):
-        assert D.direct() is None
-    assert "librccl symbols not found" in D._direct_failed and calls == [1]
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")
-        assert D.direct() is None and D.capture_collectives() is False      # remembered: silent, no retry
-    assert calls == [1]
-    # switched off by the environment: never even attempted
-    monkeypatch.setattr(D, "_direct_failed", None)
-    monkeypatch.setenv("PYGDA_AMD_RCCL_DIRECT", "0")
-    assert D.direct() is None and calls == [1]
+    fail_at, peer_fails_at = None, 0
+    fresh()
+    assert D.direct_agreed() is None and D.direct() is None and log == [] and agreements == []
+    monkeypatch.setenv("PYGDA_AMD_RCCL_DIRECT", "1")
+    assert D.direct() is None and log == []
+    # every way of failing on THIS rank: three agreements all the same (the peers' count), later stages skipped
+    for fail_at, ran in (("load", ["new", "load", "destroy"]), ("init_rank", ["new", "load", "init_rank", "destroy"]),
+                         ("self_test", ["new", "load", "init_rank", "self_test", "destroy"])):
+        fresh()
+        with pytest.warns(UserWarning, match="library-owned RCCL communicator unavailable"):
+            assert D.direct_agreed() is None
+        assert log == ran and fail_at in D._direct_failed
+        assert len(agreements) == {"load": 1, "init_rank": 2, "self_test": 3}[fail_at] and agreements[-1] is False
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            assert D.direct_agreed() is None and D.direct() is None and D.capture_collectives() is False   # remembered
+        assert log == ran
+    # a PEER fails at stage 2 while this rank is healthy: this rank leaves at the same point and destroys its handle
+    fail_at, peer_fails_at = None, 2
+    fresh()
+    with pytest.warns(UserWarning, match="another rank failed"):
+        assert D.direct_agreed() is None
+    assert log == ["new", "load", "init_rank", "destroy"] and agreements == [True, True]
+    # all good
+    peer_fails_at = 0
+    fresh()
+    comm = D.direct_agreed()
+    assert comm is not None and D.direct() is comm and agreements == [True, True, True]
+    assert log == ["new", "load", "init_rank", "self_test"]
