@@ -1053,15 +1053,33 @@ def _sum_aggregate(x: Tensor, edge_index: Tensor) -> Tensor:
     return torch.zeros_like(x).index_add_(0, edge_index[1], x.index_select(0, edge_index[0]))
 
 
+def _pyg_linear_reset(lin: nn.Linear) -> None:
+    """PyG ``Linear.reset_parameters()`` with its default initialisers (dense/linear.py: ``kaiming_uniform(weight,
+    fan=in, a=sqrt(5))`` = U(-b, b), b = sqrt(6 / ((1 + a^2) in)); ``inits.uniform(in, bias)`` = U(+-1/sqrt(in))):
+    weight first, then bias -- the order the init RNG stream is consumed in."""
+    fan = lin.weight.size(1)
+    bound = math.sqrt(6 / ((1 + math.sqrt(5) ** 2) * fan))
+    with torch.no_grad():
+        lin.weight.uniform_(-bound, bound)
+        if lin.bias is not None:
+            b = 1.0 / math.sqrt(fan)
+            lin.bias.uniform_(-b, b)
+
+
 class SAGEConv(nn.Module):
     """PyG ``SAGEConv`` defaults as gnn_base.py:73-79 uses it (aggr='mean', root_weight=True):
-    ``lin_l(mean_{j->i} x_j) + lin_r(x_i)``; no self loops; lin_l carries the bias.  No
-    runnable PyG here: restated from the GraphSAGE definition -- parity unpinned."""
+    ``lin_l(mean_{j->i} x_j) + lin_r(x_i)``; no self loops; lin_l carries the bias.  Init: each PyG ``Linear`` draws
+    in its constructor and again in ``SAGEConv.reset_parameters()`` (lin_l.W, lin_l.b, lin_r.W, twice over).
+    Pinned since round 5 by ``tests/golden/gnn_fit2_sage.npz``: the reference's gnn_base.py / gnn.py executed on the
+    stub's SAGEConv (tests/golden/_pyg_stub.py, assumption 13b)."""
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
+        # torch's constructor draws stand where PyG's ``Linear.__init__`` draws (same counts, weight then bias) ...
         self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
         self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+        _pyg_linear_reset(self.lin_l)                  # ... and SAGEConv.reset_parameters() sets the values
+        _pyg_linear_reset(self.lin_r)
 
     def forward(self, x, edge_index, edge_weight=None):
         cnt = torch.zeros(x.size(0), dtype=x.dtype).index_add_(
@@ -1071,13 +1089,16 @@ class SAGEConv(nn.Module):
 
 
 class GINConv(nn.Module):
-    """PyG ``GINConv(nn, train_eps=True)`` (gnn_base.py:89-95): ``nn((1+eps) x_i + sum_j x_j)``,
-    eps initialised to 0.  Parity unpinned (definition-level restatement)."""
+    """PyG ``GINConv(nn, train_eps=True)`` (gnn_base.py:89-95): ``nn(sum_j x_j + (1+eps) x_i)``, eps initialised to 0;
+    its ``reset_parameters()`` re-draws every child of ``nn`` (the torch ``Linear`` of gnn_base.py:89 is initialised
+    twice).  Pinned since round 5 by ``tests/golden/gnn_fit2_gin.npz`` (stub assumption 13c)."""
 
     def __init__(self, net: nn.Module):
         super().__init__()
         self.nn = net
         self.eps = nn.Parameter(torch.zeros(1))
+        for child in net.children():
+            child.reset_parameters()
 
     def forward(self, x, edge_index, edge_weight=None):
         return self.nn(_sum_aggregate(x, edge_index) + (1 + self.eps) * x)
@@ -1086,14 +1107,16 @@ class GINConv(nn.Module):
 class GATConv(nn.Module):
     """PyG ``GATConv(heads=1, concat=False)`` (gnn_base.py:81-87): x' = W x; self loops
     (existing removed, one added per node); e_ij = LeakyReLU_0.2(a_src.x'_j + a_dst.x'_i);
-    alpha = softmax over the incoming edges of i; out_i = sum_j alpha_ij x'_j + bias.
-    Parity unpinned (definition-level restatement)."""
+    alpha = softmax over the incoming edges of i; out_i = sum_j alpha_ij x'_j + bias.  Init: the shared ``lin`` is
+    glorot-drawn by its constructor and again by ``reset_parameters()``, which then draws att_src and att_dst.
+    Pinned since round 5 by ``tests/golden/gnn_fit2_gat.npz`` (stub assumption 13d)."""
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
         self.lin = _Lin(in_channels, out_channels)
         self.att_src = nn.Parameter(torch.empty(1, 1, out_channels))
         self.att_dst = nn.Parameter(torch.empty(1, 1, out_channels))
+        glorot_(self.lin.weight)                       # reset_parameters(): lin again, then the attention vectors
         glorot_(self.att_src); glorot_(self.att_dst)
         self.bias = nn.Parameter(torch.zeros(out_channels))
 
@@ -1106,9 +1129,9 @@ class GATConv(nn.Module):
         a_s = (h * self.att_src.view(1, -1)).sum(-1)
         a_d = (h * self.att_dst.view(1, -1)).sum(-1)
         e = F.leaky_relu(a_s[ei[0]] + a_d[ei[1]], 0.2)
-        m = torch.full((n,), float("-inf")).scatter_reduce(0, ei[1], e, reduce="amax")
+        m = torch.full((n,), float("-inf")).scatter_reduce(0, ei[1], e.detach(), reduce="amax")
         p = torch.exp(e - m[ei[1]])
-        z = torch.zeros(n).index_add_(0, ei[1], p)
+        z = torch.zeros(n).index_add_(0, ei[1], p) + 1e-16
         alpha = p / z[ei[1]]
         out = torch.zeros_like(h).index_add_(0, ei[1], alpha.unsqueeze(1) * h[ei[0]])
         return out + self.bias

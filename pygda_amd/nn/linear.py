@@ -116,11 +116,22 @@ class Linear(nn.Module):
         self.reset_parameters()
 
     def reset_parameters(self):
+        """PyG ``Linear.reset_parameters()`` (dense/linear.py): 'glorot', or its defaults -- ``kaiming_uniform(weight,
+        fan=in, a=sqrt(5))`` = U(+-sqrt(6 / ((1 + a^2) in))) and ``inits.uniform(in, bias)`` = U(+-1/sqrt(in)) --
+        weight first, then bias: the order the init RNG stream is consumed in (tests/golden/_pyg_stub.py, 13a)."""
         if self.weight_initializer == "glorot":
             glorot(self.weight)
         else:
-            nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
-        zeros(self.bias)
+            bound = math.sqrt(6 / ((1 + math.sqrt(5) ** 2) * self.in_channels))
+            with torch.no_grad():
+                self.weight.uniform_(-bound, bound)
+        if self.bias is not None:
+            if self.weight_initializer == "glorot":
+                zeros(self.bias)
+            else:
+                b = 1.0 / math.sqrt(self.in_channels)
+                with torch.no_grad():
+                    self.bias.uniform_(-b, b)
 
     def tall_gemm_ok(self, x):
         """``x`` goes to the hand-written matrix-core kernels (not the sparse-input path, not the BLAS)."""

@@ -39,6 +39,29 @@ boundary" (the MMD / GradReverse / Attention goldens do not go through it).
     order) divided by the node count (clamped at 1).
 12. (graph mode of grade.py / dane.py only) ``len(batch)`` of a collated ``Batch`` = its number of graphs (PyG's
     ``Batch.__len__`` returns ``num_graphs``): grade.py:174,180 size the domain labels / the MMD rows by it.
+13. (gnn_base.py:72-95, ``gnn='sage' | 'gin' | 'gat'``)  The three convolutions, per PyG >= 2.5 sources:
+    a. PyG ``Linear(in, out, bias, weight_initializer=None)``: weight ~ U(-b, b) with b = 1/sqrt(in)
+       (``inits.kaiming_uniform(fan=in, a=sqrt(5))`` = sqrt(6 / ((1 + 5) in))), bias ~ U(-1/sqrt(in), 1/sqrt(in))
+       (``inits.uniform``); drawn weight-then-bias in ``Linear.__init__`` (it ends in ``reset_parameters()``) and again
+       by every ``reset_parameters()``.
+    b. ``SAGEConv(in, out)`` (aggr='mean', root_weight=True, project=False, normalize=False, bias=True):
+       ``lin_l = Linear(in, out, bias=True)``, ``lin_r = Linear(in, out, bias=False)``, then ``reset_parameters()``
+       (lin_l, lin_r) -- RNG order lin_l.W, lin_l.b, lin_r.W, lin_l.W, lin_l.b, lin_r.W.  forward:
+       ``lin_l(mean_{j -> i} x_j) + lin_r(x_i)``; mean = scatter-sum in edge order / max(#messages, 1); multiset
+       neighbourhoods, no self loops added, edge weights ignored (the third positional argument GNNBase passes is
+       SAGEConv's ``size``: None).
+    c. ``GINConv(nn, eps=0., train_eps=True)``: ``eps = Parameter(empty(1))``; ``reset_parameters()`` =
+       ``reset(nn)`` (every child's ``reset_parameters()``: the torch ``Linear`` inside the torch ``Sequential``
+       gnn_base.py:6 builds draws its weight and bias a SECOND time) then ``eps.fill_(0)``.  forward:
+       ``nn(sum_{j -> i} x_j + (1 + eps) x_i)`` (aggregate first, then the root term added).
+    d. ``GATConv(in, out, heads=1, concat=False)`` (negative_slope 0.2, dropout 0, add_self_loops=True, bias=True,
+       edge_dim=None, residual=False; int ``in``: ONE ``lin = Linear(in, out, bias=False, 'glorot')`` shared by source
+       and target, PyG >= 2.5 -- 2.4 names it lin_src / lin_dst and resets it twice): RNG order lin.W (its __init__),
+       then ``reset_parameters()``: lin.W, glorot(att_src [1, 1, out]), glorot(att_dst), zeros(bias).  forward:
+       h = lin(x); a_s = <h, att_src>, a_d = <h, att_dst>; existing self loops removed and one loop per node appended
+       LAST; per edge j -> i: e = leaky_relu(a_s[j] + a_d[i], 0.2); softmax over the incoming edges of i as
+       ``exp(e - max_i) / (sum_i exp(e - max_i) + 1e-16)`` (max taken on the detached scores); out_i = sum alpha h_j
+       (scatter-sum in edge order), mean over the one head, + bias.
 10. (reweight_gnn.py / strurw.py only) ``MessagePassing(aggr='mean', flow='target_to_source')``:
     messages from ``x[edge_index[1]]`` averaged at ``edge_index[0]`` over the number of messages;
     ``update`` receives the propagate kwargs it names; ``to_dense_adj`` sums duplicate edges;
@@ -122,17 +145,29 @@ def uniform(size, t):        # imported by mixup_gcnconv.py for a GraphConv clas
 
 
 class Linear(torch.nn.Module):
+    """Assumptions 4 (glorot, no bias: the GCN-family layers) and 13a (PyG's default initialisers)."""
+
     def __init__(self, in_channels, out_channels, bias=True, weight_initializer=None,
                  bias_initializer=None):
         super().__init__()
-        assert weight_initializer == 'glorot' and not bias
+        assert weight_initializer in ('glorot', None) and bias_initializer is None
         self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight_initializer = weight_initializer
         self.weight = torch.nn.Parameter(torch.empty(out_channels, in_channels))
-        self.register_parameter('bias', None)
+        if bias:
+            self.bias = torch.nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
         self.reset_parameters()
 
     def reset_parameters(self):
-        glorot(self.weight)
+        if self.weight_initializer == 'glorot':
+            glorot(self.weight)
+        else:                                            # inits.kaiming_uniform(weight, fan=in, a=sqrt(5))
+            bound = math.sqrt(6 / ((1 + math.sqrt(5) ** 2) * self.in_channels))
+            self.weight.data.uniform_(-bound, bound)
+        if self.bias is not None:                        # inits.uniform(in, bias)
+            uniform(self.in_channels, self.bias)
 
     def forward(self, x):
         return torch.nn.functional.linear(x, self.weight, self.bias)
@@ -212,6 +247,103 @@ class GCNConv(MessagePassing):
 
     def message(self, x_j, edge_weight):
         return edge_weight.view(-1, 1) * x_j
+
+
+class SAGEConv(MessagePassing):
+    """Assumption 13b."""
+
+    def __init__(self, in_channels, out_channels, aggr='mean', normalize=False, root_weight=True, project=False,
+                 bias=True, **kwargs):
+        assert aggr == 'mean' and not normalize and root_weight and not project
+        super().__init__(aggr='mean')
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin_l = Linear(in_channels, out_channels, bias=bias)
+        self.lin_r = Linear(in_channels, out_channels, bias=False)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin_l.reset_parameters()
+        self.lin_r.reset_parameters()
+
+    def forward(self, x, edge_index, size=None):
+        assert size is None                              # GNNBase hands its edge_weight=None in this slot
+        out = self.propagate(edge_index, x=x)
+        out = self.lin_l(out)
+        return out + self.lin_r(x)
+
+
+def _reset(value):
+    """PyG ``nn.inits.reset``."""
+    if hasattr(value, 'reset_parameters'):
+        value.reset_parameters()
+    else:
+        for child in value.children() if hasattr(value, 'children') else []:
+            _reset(child)
+
+
+class GINConv(MessagePassing):
+    """Assumption 13c."""
+
+    def __init__(self, nn, eps=0., train_eps=False, **kwargs):
+        super().__init__(aggr='add')
+        self.nn = nn
+        self.initial_eps = eps
+        if train_eps:
+            self.eps = torch.nn.Parameter(torch.empty(1))
+        else:
+            self.register_buffer('eps', torch.empty(1))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _reset(self.nn)
+        self.eps.data.fill_(self.initial_eps)
+
+    def forward(self, x, edge_index, size=None):
+        assert size is None
+        out = self.propagate(edge_index, x=x)
+        out = out + (1 + self.eps) * x
+        return self.nn(out)
+
+
+class GATConv(torch.nn.Module):
+    """Assumption 13d (single head)."""
+
+    def __init__(self, in_channels, out_channels, heads=1, concat=True, negative_slope=0.2, dropout=0.0,
+                 add_self_loops=True, edge_dim=None, fill_value='mean', bias=True, **kwargs):
+        super().__init__()
+        assert heads == 1 and not concat and dropout == 0.0 and add_self_loops and edge_dim is None and bias
+        self.in_channels, self.out_channels, self.negative_slope = in_channels, out_channels, negative_slope
+        self.lin = Linear(in_channels, out_channels, bias=False, weight_initializer='glorot')
+        self.att_src = torch.nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = torch.nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = torch.nn.Parameter(torch.empty(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin.reset_parameters()
+        glorot(self.att_src)
+        glorot(self.att_dst)
+        zeros(self.bias)
+
+    def forward(self, x, edge_index, edge_attr=None, size=None):
+        assert edge_attr is None and size is None
+        n, H, C = x.size(0), 1, self.out_channels
+        h = self.lin(x).view(-1, H, C)
+        alpha_src = (h * self.att_src).sum(dim=-1)
+        alpha_dst = (h * self.att_dst).sum(dim=-1)
+        edge_index, _ = remove_self_loops(edge_index)
+        edge_index, _ = add_self_loops(edge_index, num_nodes=n)
+        j, i = edge_index[0], edge_index[1]
+        alpha = torch.nn.functional.leaky_relu(alpha_src[j] + alpha_dst[i], self.negative_slope)     # [E, H]
+        # torch_geometric.utils.softmax(alpha, index=i, num_nodes=n)
+        amax = torch.full((n, H), float('-inf')).scatter_reduce(0, i.view(-1, 1).expand(-1, H), alpha.detach(),
+                                                                reduce='amax', include_self=True)
+        out = (alpha - amax.index_select(0, i)).exp()
+        out_sum = torch.zeros(n, H).index_add_(0, i, out) + 1e-16
+        alpha = out / out_sum.index_select(0, i)
+        msg = alpha.unsqueeze(-1) * h.index_select(0, j)                                              # [E, H, C]
+        agg = torch.zeros(n, H, C).index_add_(0, i, msg)
+        return agg.mean(dim=1) + self.bias
 
 
 def global_mean_pool(x, batch, size=None):
@@ -383,8 +515,7 @@ def install():
     nn_m.global_mean_pool = global_mean_pool
     nn_m.GCNConv = GCNConv
     nn_m.MessagePassing = MessagePassing
-    for missing in ('SAGEConv', 'GATConv', 'GINConv'):
-        setattr(nn_m, missing, None)
+    nn_m.SAGEConv, nn_m.GATConv, nn_m.GINConv = SAGEConv, GATConv, GINConv
     inits = _mod('torch_geometric.nn.inits')
     inits.glorot, inits.zeros, inits.uniform = glorot, zeros, uniform
     dense = _mod('torch_geometric.nn.dense')

@@ -952,6 +952,51 @@ def fx_graph_trainers(ref):
 FIXTURES["graph_trainers"] = fx_graph_trainers
 
 
+def fx_gnn_convs(ref):
+    """GNNBase(gnn='sage' | 'gin' | 'gat') (gnn_base.py:72-95) and the GNN trainer on them (gnn.py:151-212), executed
+    from the reference's own files on the stub's SAGEConv / GINConv / GATConv (assumption 13).  Per backbone:
+    (a) forward in train mode + the gradients of nll(log_softmax(forward)) on a DIRECTED graph with duplicate edges,
+    self loops, an isolated node and nodes without incoming edges (weights from a seed: the init RNG order is part of
+    the fixture); (b) a 2-epoch ``fit()`` + ``predict()`` from a seed, as ``gnn_fit2.npz`` does for gcn."""
+    import pygda.models.gnn as gmod
+    s, t = _connected_pair(121)
+    n = 70
+    ei = make_graph(n, 160, seed=77, undirected=False, self_loops=6, dups=9, isolated=True)
+    gen = torch.Generator().manual_seed(78)
+    x = torch.randn(n, 12, generator=gen)
+    y = torch.randint(0, 3, (n,), generator=gen)
+    for k, kind in enumerate(("sage", "gin", "gat")):
+        arrs = dict(_pair_arrays(s, t), fwd_x=np_(x), fwd_ei=np_(ei), fwd_y=np_(y),
+                    init_seed=np.int64(151 + k), seed=np.int64(161 + k))
+        torch.manual_seed(151 + k)
+        net = ref.GNNBase(12, 8, 3, num_layers=2, dropout=0.0, gnn=kind)
+        arrs["rng_after_init"] = np_(torch.rand(4))         # pins how many draws the constructors consumed
+        net.train()
+        logp = net(x, ei)
+        loss = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(logp, dim=1), y)   # gnn.py:113-116: twice
+        loss.backward()
+        arrs.update(fwd_logp=np_(logp), fwd_loss=np.float64(loss.item()))
+        arrs.update(sd_arrays(net, "param0/")); arrs.update(grads(net, "grad0/"))
+        feats = net.feat_bottleneck(x, ei)
+        arrs["fwd_feat"] = np_(feats)
+        losses = []
+        orig = gmod.logger
+        gmod.logger = lambda **kw: losses.append(kw["loss"])
+        try:
+            g = ref.GNN(12, 8, 3, num_layers=2, dropout=0.0, gnn=kind, lr=0.05, weight_decay=1e-4, device="cpu",
+                        epoch=2, verbose=0)
+            torch.manual_seed(161 + k)
+            g.fit(s, t)
+            logits, labels = g.predict(t)
+            arrs.update(losses=np.array(losses), tgt_logits=np_(logits), **sd_arrays(g.gnn, "final/"))
+        finally:
+            gmod.logger = orig
+        save(f"gnn_fit2_{kind}", **arrs)
+
+
+FIXTURES["gnn_convs"] = fx_gnn_convs
+
+
 def main(argv):
     ref = load_reference()
     for name in (argv or list(FIXTURES)):

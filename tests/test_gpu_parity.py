@@ -679,6 +679,45 @@ def test_gnn_trainer_golden():
 
 
 @pytest.mark.parametrize("kind", ["sage", "gin", "gat"])
+def test_gnn_sage_gin_gat_reference_run_goldens(kind):
+    """SURVEY 8 f4 at the standing of the gcn rows: ``gnn_fit2_{kind}.npz`` holds what the reference's own gnn_base.py /
+    gnn.py produced on the stub's SAGEConv / GINConv / GATConv (assumption 13).  On the HIP kernels: the seeded
+    initialisation (bit for bit, and the generator's position after it), the forward on a directed graph with
+    duplicate edges / self loops / an isolated node, every parameter gradient, the 2-epoch fit and predict."""
+    g = load_golden(f"gnn_fit2_{kind}")
+    torch.manual_seed(int(g["init_seed"]))
+    net = pygda_amd.nn.GNNBase(12, 8, 3, num_layers=2, dropout=0.0, gnn=kind)
+    exact(torch.rand(4), g["rng_after_init"])
+    params0 = sub(g, "param0/")
+    assert sorted(net.state_dict()) == sorted(params0)                 # the reference's state-dict names
+    for k, v in net.state_dict().items():
+        exact(v, params0[k])
+    net = net.to(DEV).train()
+    x, ei, y = T(g["fwd_x"], DEV), T(g["fwd_ei"], DEV), T(g["fwd_y"], DEV)
+    logp = net(x, ei)
+    loss = F.nll_loss(F.log_softmax(logp, dim=1), y)
+    loss.backward()
+    close(logp, g["fwd_logp"], rtol=0, atol=LOGIT_ATOL)
+    close(loss, g["fwd_loss"], rtol=REL)
+    close(net.feat_bottleneck(x, ei), g["fwd_feat"], rtol=0, atol=LOGIT_ATOL)
+    exact(logp.argmax(1), g["fwd_logp"].argmax(1))
+    for k, p in net.named_parameters():
+        want = g["grad0/" + k]
+        close(p.grad, want, rtol=1e-3, atol=1e-4 * float(np.abs(want).max()) + 1e-7)
+    s, t = _pair(g)
+    m = pygda_amd.models.GNN(12, 8, 3, num_layers=2, dropout=0.0, gnn=kind, lr=0.05, weight_decay=1e-4,
+                             device=DEV, epoch=2, verbose=0)
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append(loss)
+    torch.manual_seed(int(g["seed"]))
+    m.fit(s, t)
+    close(seen, g["losses"], rtol=REL)
+    logits, _ = m.predict(t)
+    close(logits, g["tgt_logits"], rtol=0, atol=2e-4)                   # after two Adam steps, as the gcn golden
+    exact(logits.argmax(1), g["tgt_logits"].argmax(1))
+
+
+@pytest.mark.parametrize("kind", ["sage", "gin", "gat"])
 def test_sage_gin_gat_vs_oracle(kind):
     gen = torch.Generator().manual_seed(9)
     n, f, h = 300, 24, 16

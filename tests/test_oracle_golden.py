@@ -338,8 +338,54 @@ def test_gnn_fit_trajectory():
         eq(net(tgt.x, tgt.edge_index), g["tgt_logits"])
 
 
+@pytest.mark.parametrize("kind", ["sage", "gin", "gat"])
+def test_gnn_sage_gin_gat_against_reference_run_goldens(kind):
+    """gnn_base.py:72-95 + gnn.py:151-212 for the three non-gcn backbones: ``gnn_fit2_{kind}.npz`` was
+    recorded by executing the reference's own gnn_base.py / gnn.py on the stub's SAGEConv / GINConv / GATConv
+    (tests/golden/_pyg_stub.py assumption 13) -- the same standing as ``gnn_fit2.npz`` for gcn.  Pins: the init RNG
+    order (every weight from the seed + the generator's position afterwards), the forward on a directed graph with
+    duplicate edges / self loops / an isolated node, every parameter gradient, and a 2-epoch fit + predict."""
+    F = torch.nn.functional
+    g = load_golden(f"gnn_fit2_{kind}")
+    torch.manual_seed(int(g["init_seed"]))
+    net = O.GNNBase(12, 8, 3, num_layers=2, dropout=0.0, gnn=kind)
+    eq(torch.rand(4), g["rng_after_init"])                         # the constructors consumed exactly PyG's draws
+    for k, v in net.state_dict().items():
+        eq(v, g["param0/" + k])
+    net.train()
+    x, ei, y = T(g["fwd_x"]), T(g["fwd_ei"]), T(g["fwd_y"])
+    logp = net(x, ei)
+    loss = F.nll_loss(F.log_softmax(logp, dim=1), y)
+    loss.backward()
+    tol = 0.0 if kind != "gat" else 1e-6                           # bit for bit; GAT's softmax to the last ulp
+    eq(logp, g["fwd_logp"], tol); eq(loss, g["fwd_loss"], tol)
+    eq(net.feat_bottleneck(x, ei), g["fwd_feat"], tol)
+    for k, p in net.named_parameters():
+        eq(p.grad, g["grad0/" + k], 1e-6)
+    # the GNN trainer: two epochs from a seed (CE on the source only, log_softmax twice)
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    torch.manual_seed(int(g["seed"]))
+    net = O.GNNBase(12, 8, 3, num_layers=2, dropout=0.0, gnn=kind)
+    opt = torch.optim.Adam(net.parameters(), lr=0.05, weight_decay=1e-4)
+    losses = []
+    for _ in range(2):
+        net.train()
+        out = net(src.x, src.edge_index)
+        net(tgt.x, tgt.edge_index)
+        loss = F.nll_loss(F.log_softmax(out, dim=1), src.y)
+        losses.append(loss.item())
+        opt.zero_grad(); loss.backward(); opt.step()
+    eq(np.array(losses), g["losses"], 1e-6)
+    net.eval()
+    with torch.no_grad():
+        eq(net(tgt.x, tgt.edge_index), g["tgt_logits"], 1e-5)
+    for k, v in net.state_dict().items():
+        eq(v, g["final/" + k], 1e-5)
+
+
 def test_oracle_sage_gin_gat_against_dense_math():
-    """No PyG to run here: the definition-level restatements are checked against dense algebra."""
+    """A second check beside the reference-run goldens above: the restatements against dense algebra."""
     gen = torch.Generator().manual_seed(3)
     n, f, h = 40, 6, 5
     ei = torch.randint(0, n, (2, 150), generator=gen)
