@@ -31,6 +31,13 @@ _SIGNATURES = {
     "gda_spmm_csr_kstep_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P, c_int64,
                                        _P, _P, _P]),
     "gda_spmm_csr_interior_kstep_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "gda_interior_max_rows": (c_int, []),
+    "gda_interior_max_width": (c_int, []),
+    "gda_interior_plan_bytes": (c_size_t, []),
+    "gda_interior_kstep_lds_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "gda_interior_plan_build": (c_int, [_P, _P, _P, _P, _P, c_size_t, _P, _P]),
+    "gda_interior_kstep_lds_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P, _P,
+                                           c_size_t, _P]),
     "gda_row_split_workspace_bytes": (c_size_t, [c_int64]),
     "gda_row_split_build": (c_int, [_P, c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gda_spmm_csr_split_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P, c_int64,

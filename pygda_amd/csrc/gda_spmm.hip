@@ -611,3 +611,5 @@ extern "C" int gda_spmm_csr_interior_kstep_f32(const int32_t* rowptr, const int3
     // leaves of the transposed operator: interior columns read the summed step inputs, the self loop reads x
     return dispatch_range(rowptr, colidx, val, n_int, n_leaf, d, n_int > 0 ? sacc : x, d, x, d, split, y, d, nullptr, nullptr, 0, s);
 }
+
+#include "gda_interior.inc"

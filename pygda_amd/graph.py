@@ -70,7 +70,7 @@ class CSRGraph:
 
     __slots__ = ("num_nodes", "nnz_cap", "rowptr", "colidx", "val", "t_rowptr", "t_colidx",
                  "t_val", "_nnz", "device", "_split", "_t_split", "t_to_fwd", "static", "_squared", "transient",
-                 "_kplan", "_t_kplan", "n_interior")
+                 "_kplan", "_t_kplan", "n_interior", "iplan")
 
     def __init__(self, num_nodes, nnz_cap, rowptr, colidx, val, t_rowptr, t_colidx, t_val):
         self.num_nodes, self.nnz_cap = num_nodes, nnz_cap
@@ -84,6 +84,8 @@ class CSRGraph:
         self.transient = False    # graph of one sampled mini-batch: nothing about it is worth a host sync
         self._squared = None      # A*A (and its transpose) of a static graph, or False if too dense
         self._kplan = self._t_kplan = None     # register programs of the LDS-resident K-step kernel, or False
+        self.iplan = None         # sampled batch: (forward, transposed) device plans of the one-launch interior K-step
+                                  # (csrc/gda_interior.inc; built by the device sampler), None where not eligible
         self.n_interior = None    # sampled batch: rows from here on hold their unit self loop only (the last hop's
                                   # discoveries are never expanded) and every row is short -- ops.spmm_kstep then
                                   # recomputes the interior rows only (gda_spmm_csr_interior_kstep_f32)

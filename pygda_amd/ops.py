@@ -200,7 +200,8 @@ def _launch_kstep_interior(graph, x, K, bias, transposed, y):
     L = _lib.lib()
     if aggregation_log is not None:
         aggregation_log.append((_logged(graph), int(K)))
-    _note_path("interior-rows", int(K))
+    plan = _interior_lds_plan(graph, x, y, K, transposed)
+    _note_path("interior-lds" if plan is not None else "interior-rows", int(K))
     if profiler.enabled:
         # `bytes`: what the call itself has to move -- forward K interior steps + one copy of the leaf rows; transposed K
         # interior steps + one pass over every entry for the leaves.  `alg_equiv_bytes`: SURVEY 8(d)'s algorithmic
@@ -211,20 +212,38 @@ def _launch_kstep_interior(graph, x, K, bias, transposed, y):
         # compulsory bytes: a step reads every distinct row its entries name at most once (<= n rows; the transposed
         # interior steps name interior rows only), the index arrays, and writes its own rows
         hoist = INTERIOR_HOIST and not transposed and K >= 2 and n_int > 0
-        if transposed:
-            real = K * (3 * n_int * row) + nnz * 8 + n_int * row + 2 * n_leaf * row
-        elif hoist:       # one pass over the leaf columns, then K steps that gather interior rows and add the constant
-            real = (nnz * 8 + min(nnz, n) * row + n_int * row) + K * (nnz * 8 + 3 * n_int * row + (n_int + 1) * 4) \
-                + 2 * n_leaf * row
+        alg = K * (nnz * 8 + (n + 1) * 4 + 2 * n * d * 4)
+        if plan is not None:
+            # the one-launch path: the step loop never leaves LDS; HBM / L2 see the index arrays once, the leaf rows
+            # once (forward: gathered for c; transposed: written), and the interior block crossing the column-major
+            # staging (in: x_I and c or g_I; out: y_I, and the summed step inputs when transposed)
+            real = nnz * 8 + (min(nnz, n) if not transposed else n_int) * row + 6 * n_int * row + 2 * n_leaf * row
+            ctx = profiler.region(f"interior_lds_f32[d={d}]", 4 if transposed else 3, real, K * 2 * nnz * d,
+                                  alg_equiv_bytes=alg, step_loop_launches=1)
         else:
-            real = K * (nnz * 8 + min(nnz, n) * row + n_int * row + (n_int + 1) * 4) + 2 * n_leaf * row
-        # launches: forward = K (+ 1 with the hoisted leaf term) of k_spmm_range + ONE k_rows_copy_bias; transposed = K + 1
-        # of k_spmm_range (`copy_launches` lets the bench price the call with rocprofv3's per-kernel averages)
-        ctx = profiler.region(f"spmm_interior_f32[d={d}]", K + (2 if hoist else 1), real, K * 2 * nnz * d,
-                              alg_equiv_bytes=K * (nnz * 8 + (n + 1) * 4 + 2 * n * d * 4),
-                              copy_launches=0 if transposed else 1)
+            if transposed:
+                real = K * (3 * n_int * row) + nnz * 8 + n_int * row + 2 * n_leaf * row
+            elif hoist:   # one pass over the leaf columns, then K steps that gather interior rows and add the constant
+                real = (nnz * 8 + min(nnz, n) * row + n_int * row) + K * (nnz * 8 + 3 * n_int * row + (n_int + 1) * 4) \
+                    + 2 * n_leaf * row
+            else:
+                real = K * (nnz * 8 + min(nnz, n) * row + n_int * row + (n_int + 1) * 4) + 2 * n_leaf * row
+            # launches: forward = K (+ 1 with the hoisted leaf term) of k_spmm_range + ONE k_rows_copy_bias; transposed =
+            # K + 1 of k_spmm_range (`copy_launches` lets the bench price the call with rocprofv3's per-kernel averages)
+            ctx = profiler.region(f"spmm_interior_f32[d={d}]", K + (2 if hoist else 1), real, K * 2 * nnz * d,
+                                  alg_equiv_bytes=alg, copy_launches=0 if transposed else 1)
     else:
         ctx = profiler.region("", 0)
+    if plan is not None:
+        # ONE launch for the K steps (csrc/gda_interior.inc): 3 launches per call forward, 4 transposed, whatever K is
+        nbytes = L.gda_interior_kstep_lds_workspace_bytes(n_int, d)
+        ws = _lib.workspace(nbytes, x.device, "interior_lds")
+        with ctx:
+            _lib.check(L.gda_interior_kstep_lds_f32(_lib.ptr(rp), _lib.ptr(ci), _lib.ptr(va), n, n_int, d, int(K),
+                                                    int(bool(transposed)), _lib.ptr(plan), _lib.ptr(x), _lib.ptr(y),
+                                                    _lib.ptr(bias), _lib.ptr(ws), nbytes, _lib.stream()),
+                       "gda_interior_kstep_lds_f32")
+        return
     tmp = torch.empty(n_int, d, dtype=torch.float32, device=x.device) if K > 1 and n_int else None
     # transposed: the running sum of the step inputs; forward (K >= 2): the leaf columns' contribution, formed once
     want_sacc = transposed or (INTERIOR_HOIST and K >= 2)
@@ -234,6 +253,36 @@ def _launch_kstep_interior(graph, x, K, bias, transposed, y):
                                                      int(bool(transposed)), _lib.ptr(x), _lib.ptr(y), _lib.ptr(tmp),
                                                      _lib.ptr(sacc), _lib.ptr(bias), _lib.stream()),
                    "gda_spmm_csr_interior_kstep_f32")
+
+
+INTERIOR_LDS_MIN_K = int(_os.environ.get("PYGDA_AMD_INTERIOR_LDS_MIN_K", "3"))
+
+
+def _interior_lds_plan(graph, x, y, K, transposed):
+    """The device plan of this direction when the K interior steps of a sampled batch run as one launch
+    (csrc/gda_interior.inc), else None: the device sampler built a valid plan for the direction (sampler.INTERIOR_LDS),
+    the width is one the kernel takes (a multiple of 4, one workgroup per column up to 128), K is worth it."""
+    plans = getattr(graph, "iplan", None)
+    if plans is None or K < INTERIOR_LDS_MIN_K:
+        return None
+    plan = plans[1 if transposed else 0]
+    n_int, d = graph.n_interior, x.size(1)
+    if plan is None or not n_int or d % 4 or d > _interior_lds_limits()[1] or n_int > _interior_lds_limits()[0]:
+        return None
+    if x.data_ptr() % 16 or y.data_ptr() % 16:
+        return None
+    return plan
+
+
+_il_limits = None
+
+
+def _interior_lds_limits():
+    global _il_limits
+    if _il_limits is None:
+        L = _lib.lib()
+        _il_limits = (int(L.gda_interior_max_rows()), int(L.gda_interior_max_width()))
+    return _il_limits
 
 
 def _takes_interior_path(graph, x, bias, transposed, counts_as=None):

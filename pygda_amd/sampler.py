@@ -130,14 +130,20 @@ class NeighborSampler:
                     batch_size=int(torch.as_tensor(seeds).numel()))
 
 
+import os as _os
+# one launch for the K interior steps of a sampled batch (csrc/gda_interior.inc); 0 keeps the K-launch chain
+INTERIOR_LDS = _os.environ.get("PYGDA_AMD_INTERIOR_LDS", "1") == "1"
+
+
 class _PendingBatch:
-    """A batch the device sampler has enqueued: capacity-sized device arrays + the event after which the five
-    counts ({n_nodes, n_edges, nnz, status, n_interior}) are on the host."""
-    __slots__ = ("nodes", "ei", "csr", "counts_host", "event", "n_seeds", "stream", "short_rows")
+    """A batch the device sampler has enqueued: capacity-sized device arrays + the event after which the
+    counts ({n_nodes, n_edges, nnz, status, n_interior, verdicts of the two interior K-step plans}) are on the host."""
+    __slots__ = ("nodes", "ei", "csr", "counts_host", "event", "n_seeds", "stream", "short_rows", "plans", "plan_ok")
 
     def wait(self):
         self.event.synchronize()
-        n, e, nnz, status, n_int = (int(v) for v in self.counts_host.tolist())
+        n, e, nnz, status, n_int, ok_f, ok_b = (int(v) for v in self.counts_host.tolist()[:7])
+        self.plan_ok = (ok_f > 0, ok_b > 0) if self.plans is not None else (False, False)
         if status == 2:
             raise _lib.GdaError("gda_dsampler_sample: a seed lies outside [0, num_nodes)")
         if status != 0:
@@ -220,7 +226,7 @@ class DeviceNeighborSampler:
                      torch.empty(ncap + 1, **i32), torch.empty(cap, **i32), torch.empty(cap, **f32))
         else:
             p.csr = (None,) * 6
-        counts = torch.empty(5, **i64)
+        counts = torch.zeros(8, **i64)
         L = _lib.lib()
         _lib.check(L.gda_dsampler_sample(_lib.ptr(self.in_ptr), _lib.ptr(self.in_src), self.num_nodes, self.num_edges,
                                          self.max_in_degree, _lib.ptr(seeds_d), p.n_seeds, fan.ctypes.data, fan.size,
@@ -228,6 +234,17 @@ class DeviceNeighborSampler:
                                          _lib.ptr(p.ei[0]), _lib.ptr(p.ei[1]), *(_lib.ptr(t) for t in p.csr),
                                          _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream()),
                    "gda_dsampler_sample")
+        p.plans, p.plan_ok = None, (False, False)
+        if csr and p.short_rows and INTERIOR_LDS:
+            # the register programs of the one-launch interior K-step (csrc/gda_interior.inc), one per direction, built
+            # HERE -- on the sampler's stream, from the CSR pair that was just built -- so the training stream sees no
+            # extra launch; their verdicts ride home with the batch's sizes (counts[5], counts[6])
+            nb = int(L.gda_interior_plan_bytes())
+            p.plans = torch.empty(2, nb, dtype=torch.uint8, device=dev)
+            for k, (rp, ci, va) in enumerate((p.csr[0:3], p.csr[3:6])):
+                _lib.check(L.gda_interior_plan_build(_lib.ptr(rp), _lib.ptr(ci), _lib.ptr(va), counts.data_ptr() + 4 * 8,
+                                                     _lib.ptr(p.plans[k]), nb, counts.data_ptr() + (5 + k) * 8,
+                                                     _lib.stream()), "gda_interior_plan_build")
         p.counts_host = self._pinned_counts()
         p.counts_host.copy_(counts, non_blocking=True)
         p.event = torch.cuda.Event()
@@ -235,11 +252,11 @@ class DeviceNeighborSampler:
         return p
 
     def _pinned_counts(self):
-        """A 5-word pinned landing pad for a batch's counts, from a ring of 64 (a batch's counts are read long before
+        """An 8-word pinned landing pad for a batch's counts, from a ring of 64 (a batch's counts are read long before
         the ring comes round; pinning a fresh block per batch costs a host allocation each time)."""
         ring = getattr(self, "_count_ring", None)
         if ring is None:
-            ring = self._count_ring = [torch.empty(64, 5, dtype=torch.int64).pin_memory(), 0]
+            ring = self._count_ring = [torch.empty(64, 8, dtype=torch.int64).pin_memory(), 0]
         i = ring[1]
         ring[1] = (i + 1) % 64
         return ring[0][i]
@@ -259,6 +276,8 @@ class DeviceNeighborSampler:
         g.transient = True
         if n_int is not None and p.short_rows:      # rows [n_int, n): the last hop's discoveries, self loop only
             g.n_interior = int(n_int)
+            if p.plans is not None:
+                g.iplan = (p.plans[0] if p.plan_ok[0] else None, p.plans[1] if p.plan_ok[1] else None)
         return g
 
     def assemble(self, data, p, sizes=None):
@@ -267,7 +286,7 @@ class DeviceNeighborSampler:
         cur = torch.cuda.current_stream()
         if p.stream != cur:
             cur.wait_event(p.event)
-            for t in (p.nodes, p.ei, *p.csr):
+            for t in (p.nodes, p.ei, *p.csr, p.plans):
                 if t is not None:
                     t.record_stream(cur)          # allocated on the sampler's stream, consumed on this one
         from .ops import gather_rows

@@ -177,6 +177,188 @@ def test_interior_rows_kstep_on_sampled_batches(monkeypatch, K, d):
         np.testing.assert_allclose(xa.grad.cpu().numpy(), want_t.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)
 
 
+# ---- the one-launch interior K-step (csrc/gda_interior.inc) ---------------------------------------------------------
+_IL_E, _IL_TB, _IL_RS = 20, 1024, 17
+_IL_ZERO, _IL_DUMP, _IL_PW = 0, 1, 2
+_IL_LW = _IL_PW + _IL_TB
+_IL_HEAD = _IL_LW + _IL_TB + 2
+
+
+def _il_plan_arrays(plan):
+    """The device plan (gda_interior_plan_build) as thread-major numpy arrays: the layout include/gda_hip.h leaves
+    opaque, restated here so that the kernel can be checked against an emulation of its own program."""
+    b = plan.cpu().numpy()
+    off_pw = _IL_TB * _IL_E * 4
+    off_diag = 2 * off_pw
+    off_act = off_diag + _IL_RS * _IL_TB * 4
+    off_lead = off_act + _IL_TB * 4
+    off_wmax = off_lead + _IL_TB * 4
+    tm = lambda a: np.ascontiguousarray(a.reshape(16, _IL_E, 64).transpose(0, 2, 1).reshape(_IL_TB, _IL_E))
+    return dict(pk=tm(b[:off_pw].view(np.uint32)), pw=tm(b[off_pw:off_diag].view(np.float32)),
+                diag=b[off_diag:off_act].view(np.float32).copy(), actm=b[off_act:off_lead].view(np.uint32).copy(),
+                lead=b[off_lead:off_wmax].view(np.uint32).copy(), wmax=b[off_wmax:off_wmax + 64].view(np.uint32).copy())
+
+
+def _il_emulate(P, x, c, K, n_int, trans):
+    """k_il_lds for ONE feature column in numpy float32 (every multiply and add rounded separately, as the kernel's
+    __fmul_rn / __fadd_rn): -> (values of the interior rows after K steps, the owner registers `cc`)."""
+    f32 = np.float32
+    RS = -(-n_int // _IL_TB)
+    bufw = _IL_HEAD + RS * _IL_TB
+    cur, nxt = np.zeros(bufw, f32), np.full(bufw, np.nan, f32)
+    nxt[_IL_ZERO] = 0
+    cur[_IL_HEAD:_IL_HEAD + n_int] = x
+    rows = np.arange(RS * _IL_TB)
+    dg = P["diag"][:RS * _IL_TB].astype(f32)
+    cc = np.zeros(RS * _IL_TB, f32)
+    if not trans:
+        cc[:n_int] = c
+    act = ((P["actm"][rows & (_IL_TB - 1)] >> (rows >> 10)) & 1).astype(bool)
+    wm = P["wmax"][np.arange(_IL_TB) >> 6]
+    idx, st = (P["pk"] & 0xffff).astype(np.int64), (P["pk"] >> 16).astype(np.int64)
+    for _ in range(K):
+        acc = np.zeros(_IL_TB, f32)
+        for e in range(_IL_E):
+            on = e < wm
+            acc = np.where(on, acc + P["pw"][:, e] * cur[idx[:, e]], acc).astype(f32)
+            nxt[st[on, e]] = acc[on]
+            acc = np.where(on & (st[:, e] != _IL_DUMP), f32(0), acc).astype(f32)
+        for t in np.nonzero(P["lead"])[0]:
+            v = f32(0)
+            for k in range(int(P["lead"][t] >> 16), 0, -1):
+                v = f32(v + nxt[_IL_PW + t - k])
+            nxt[int(P["lead"][t] & 0xffff)] = f32(v + nxt[_IL_LW + t])
+        a = cur[_IL_HEAD + rows]
+        o = np.where(act, nxt[_IL_HEAD + rows], f32(0)).astype(f32)
+        v = (o + (dg * a).astype(f32)).astype(f32)
+        if trans:
+            cc = (cc + a).astype(f32)
+        else:
+            v = (v + cc).astype(f32)
+        nxt[_IL_HEAD + rows] = v
+        cur, nxt = nxt, cur
+    return cur[_IL_HEAD:_IL_HEAD + n_int].copy(), cc[:n_int].copy()
+
+
+def _leaf_contribution(G, x, n_int, col):
+    """c = A_IL x_L of one feature column in k_il_prep's order: the row's entries in CSR order, leaf columns only."""
+    f32 = np.float32
+    rp = G.rowptr[:n_int + 1].cpu().numpy().astype(np.int64)
+    ci, va = G.colidx.cpu().numpy().astype(np.int64), G.val.cpu().numpy()
+    xc = x[:, col].cpu().numpy()
+    acc = np.zeros(n_int, f32)
+    for k in range(int((rp[1:] - rp[:-1]).max())):
+        at = rp[:-1] + k
+        ok = at < rp[1:]
+        at = np.where(ok, at, 0)
+        take = ok & (ci[at] >= n_int)
+        acc = np.where(take, acc + (va[at] * xc[ci[at]]).astype(f32), acc).astype(f32)
+    return acc
+
+
+def _plan_problem(name):
+    """(graph, fan-outs, seeds per batch) of the regimes the plan builder must handle."""
+    if name == "uniform":                         # cfg-S in small: seeds gather ~fan-out interior rows, nobody else does
+        return _graph(200_000, 4_000_000, 21), [15, 10], 1024
+    if name == "dense":                           # a small graph: last-but-one-hop rows find interior neighbours too
+        return _graph(6000, 90_000, 22, loops=True, multi=True), [7, 5], 300
+    g = torch.Generator().manual_seed(23)         # power law: a hub's transposed row crosses many runs
+    n, e = 50_000, 1_000_000
+    w = torch.arange(1, n + 1, dtype=torch.float64).pow(-0.9)
+    ei = torch.stack([torch.multinomial(w, e, True, generator=g), torch.randint(0, n, (e,), generator=g)])
+    return ei, [10, 5], 512
+
+
+@pytest.mark.parametrize("name", ["uniform", "dense", "powerlaw"])
+def test_interior_lds_plan_and_step_loop_against_their_emulation(monkeypatch, name):
+    """gda_interior_plan_build + gda_interior_kstep_lds_f32 (the K interior steps of a sampled batch in ONE launch of
+    the step loop): the plans the sampler's stream built on the device are read back and EMULATED in numpy float32 --
+    runs, pieces of rows cut by run boundaries, owner pass -- and the kernel must reproduce the emulation bit for bit
+    on every interior row, forward (with the leaf columns' contribution c = A_IL x_L in k_il_prep's order) and
+    transposed (with the running sum of the step inputs); leaf rows forward are x + bias exactly.  Then against the
+    K-launch chain it replaces and against K full aggregations (fp32 summation order)."""
+    from pygda_amd import ops, sampler
+    from pygda_amd.graph import as_graph
+    assert sampler.INTERIOR_LDS
+    ei, fan, nseeds = _plan_problem(name)
+    n = int(ei.max()) + 1
+    g = torch.Generator().manual_seed(5)
+    data = Data(x=torch.randn(n, 8, generator=g), edge_index=ei, y=torch.zeros(n, dtype=torch.long)).to(DEV)
+    loader = NeighborLoader(data, fan, batch_size=nseeds, input_nodes=torch.randperm(n, generator=g)[:2 * nseeds], device=DEV)
+    L = _lib.lib()
+    seen = 0
+    for batch in loader:
+        G = as_graph(batch.edge_index, batch.x.size(0))
+        nb, n_int = batch.x.size(0), G.n_interior
+        assert G.iplan is not None and 0 < n_int <= L.gda_interior_max_rows()
+        for K, d in ((10, 128), (3, 64)):
+            x = torch.randn(nb, d, generator=g).to(DEV)
+            bias = torch.randn(d, generator=g).to(DEV)
+            gy = torch.randn(nb, d, generator=g).to(DEV)
+            got = ops.spmm_kstep(G, x, K, bias)
+            got_t = ops.spmm_kstep(G, gy, K, None, transposed=True)
+            for trans, plan, inp, out in ((False, G.iplan[0], x, got), (True, G.iplan[1], gy, got_t)):
+                assert plan is not None, (name, trans)               # these regimes fit the plan
+                P = _il_plan_arrays(plan)
+                rp = (G.t_rowptr if trans else G.rowptr)[:n_int + 1].cpu().numpy().astype(np.int64)
+                ci = (G.t_colidx if trans else G.colidx).cpu().numpy()
+                # the plan holds every off-diagonal interior entry exactly once, in row order
+                ent = np.concatenate([ci[a:b] for a, b in zip(rp[:-1], rp[1:])])
+                rows_of = np.repeat(np.arange(n_int), rp[1:] - rp[:-1])
+                keep = (ent < n_int) & (ent != rows_of)
+                T = int(keep.sum())
+                q = max(1, -(-T // _IL_TB))
+                flat = P["pk"][:, :q].reshape(-1)[:T]
+                exact(flat & 0xffff, ent[keep] + _IL_HEAD)
+                assert int((P["pk"][:, q:] != (_IL_ZERO | (_IL_DUMP << 16))).sum()) == 0
+                for col in (0, d - 1):
+                    c = None if trans else _leaf_contribution(G, x, n_int, col)
+                    want, cc = _il_emulate(P, inp[:n_int, col].cpu().numpy(), c, K, n_int, trans)
+                    if not trans:
+                        want = (want + bias[col].cpu().numpy()).astype(np.float32)
+                    exact(out[:n_int, col], want)
+            exact(got[n_int:], x[n_int:] + bias)                       # leaves: their unit self loop
+            # the chain it replaces, and K full aggregations
+            monkeypatch.setattr(ops, "_interior_lds_plan", lambda *a, **k: None)
+            chain, chain_t = ops.spmm_kstep(G, x, K, bias), ops.spmm_kstep(G, gy, K, None, transposed=True)
+            monkeypatch.undo()
+            monkeypatch.setattr(ops, "INTERIOR_KSTEP", False)
+            full, full_t = ops.spmm_kstep(G, x, K, bias), ops.spmm_kstep(G, gy, K, None, transposed=True)
+            monkeypatch.undo()
+            for a, b in ((got, chain), (got, full), (got_t, chain_t), (got_t, full_t)):
+                np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=2e-6 * float(b.abs().max()))
+            # through autograd: backward = the transposed call
+            xa = x.clone().requires_grad_()
+            ops.propagate(xa, G, K, bias).backward(gy)
+            exact(xa.grad, got_t)
+        seen += 1
+    assert seen == 2
+
+
+def test_interior_lds_plan_declines_what_does_not_fit_and_the_chain_takes_over():
+    """More off-diagonal interior entries than 1024 runs of 20 hold (a dense little graph at fan-out [20, 20]): the
+    builder's verdict is 0 for that direction, the graph carries no plan for it, and the K-launch chain runs -- same
+    values as K full aggregations."""
+    from pygda_amd import ops
+    from pygda_amd.graph import as_graph
+    n = 1500
+    ei = _graph(n, 120_000, 31)
+    g = torch.Generator().manual_seed(6)
+    data = Data(x=torch.randn(n, 8, generator=g), edge_index=ei, y=torch.zeros(n, dtype=torch.long)).to(DEV)
+    loader = NeighborLoader(data, [20, 20], batch_size=700, input_nodes=torch.arange(700), device=DEV)
+    batch = next(iter(loader))
+    G = as_graph(batch.edge_index, batch.x.size(0))
+    assert G.n_interior is not None and G.iplan == (None, None)
+    x = torch.randn(batch.x.size(0), 64, generator=g).to(DEV)
+    got = ops.spmm_kstep(G, x, 5, None)
+    ops.INTERIOR_KSTEP = False
+    try:
+        want = ops.spmm_kstep(G, x, 5, None)
+    finally:
+        ops.INTERIOR_KSTEP = True
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=2e-6 * float(want.abs().max()))
+
+
 def test_sampled_training_no_longer_depends_on_host_sampler_threads():
     """cfg-S style training through the trainer: the loaders pick the device sampler, the step trains."""
     import pygda_amd
