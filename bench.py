@@ -376,9 +376,10 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
         def roof(name):
             r = prof[name]
             secs = r["ms"] * 1e-3
-            if name.startswith("spmm") or name.startswith("kstep_lds"):
+            if name.startswith("spmm") or name.startswith("kstep_lds") or name.startswith("interior_lds"):
                 ach = r["bytes"] / secs / 1e9
-                kern = "k_spmm_range<32, 4" if name.startswith("spmm_interior") else "k_spmm<32, 4"
+                kern = ("k_spmm_range<32, 4" if name.startswith("spmm_interior") else
+                        "k_il_lds" if name.startswith("interior_lds") else "k_spmm<32, 4")
                 traffic, src_file = pmc_traffic(kern, "r[0-9]*_cfgS*_summary.json") if "d=128" in name else (None, None)
                 out = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src_file,
@@ -412,7 +413,8 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
             return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None, "launches": r["launches"],
                     "avg_launch_us": r["avg_us"]}
-        cands = [k for k in prof if k.startswith("spmm") or k.startswith("dense") or k.startswith("kstep_lds")]
+        agg = [k for k in prof if k.startswith("spmm") or k.startswith("kstep_lds") or k.startswith("interior_lds")]
+        cands = agg + [k for k in prof if k.startswith("dense")]
         dominant = max(cands, key=lambda k: prof[k]["ms"])
         out = {
             "metric": "edges_aggregated_per_sec", "value": edges / dt, "unit": "edges/s", "n_gpus": world,
@@ -430,6 +432,8 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                        "edges_aggregated_per_step": edges / args.steps, "final_loss": float(loss.detach()),
                        "host_ms_per_step_max_median": [max(host_ms), sorted(host_ms)[len(host_ms) // 2]],
                        "hipMalloc_calls_in_timed_region": device_allocs,
+                       "aggregation_launches_per_step": sum(prof[k]["launches"] for k in agg) / prof_steps,
+                       "aggregation_paths": {k: prof[k]["launches"] / prof_steps for k in sorted(agg)},
                        "sampler": model.source_loader.sampler_description(),
                        "parallelism": "single GPU" if world == 1 else
                        f"dp{world}: disjoint seed mini-batches per rank, graph + features replicated, all-gathered "
