@@ -166,15 +166,16 @@ int gda_spmm_csr_interior_kstep_f32(const int32_t* rowptr, const int32_t* colidx
                                     gda_stream_t stream);
 
 /* The same K steps with ONE launch for the step loop (round 5; csrc/gda_interior.inc): per feature column the interior
- * block (<= gda_interior_max_rows() = 17,408 rows) is a 64 KB vector that stays in the LDS of one workgroup for all K
+ * block (<= gda_interior_max_rows() = 16,384 rows: 1024 seeds at fan-out 15) is a 64 KB vector that stays in the LDS of one workgroup for all K
  * steps,  y_I <- A_II y_I + c  with the leaf columns' contribution c = A_IL x_L formed once; a call is 3 launches forward
  * (c + transposition | step loop | rows back + leaf copy) and 4 transposed, whatever K is, against K + 2 above.
  *   gda_interior_plan_build: compiles ONE direction of the batch's CSR (rowptr / colidx / val = the by-destination arrays
  *     for the forward operator, the by-source arrays for the transposed one) into the step loop's per-lane register
- *     program ON THE DEVICE -- one single-workgroup launch, typically on the sampler's stream right after
+ *     program ON THE DEVICE -- three small capacity-sized launches, typically on the sampler's stream right after
  *     gda_dsampler_sample; n_int_dev = device int64 (the sampler's counts + 4); plan = gda_interior_plan_bytes() device
- *     bytes, 16-byte aligned; status_dev[0] <- > 0: the plan is valid, 0: the batch does not fit (too many interior rows,
- *     a row with more than 32 off-diagonal interior entries, too many such entries in total): keep the call above.
+ *     bytes, 16-byte aligned; status_dev = device int64[2]: [0] <- > 0: the plan is valid (entries per lane), 0: the batch
+ *     does not fit (too many interior rows, more than 1024 x 26 off-diagonal interior entries): keep the call above;
+ *     [1] <- the number of off-diagonal interior entries.
  *   gda_interior_kstep_lds_f32: x, y [n_rows, d] contiguous, 16-byte aligned; d % 4 == 0, d <= gda_interior_max_width();
  *     workspace = gda_interior_kstep_lds_workspace_bytes(n_int, d) device bytes.  Same sums as the call above with `sacc`
  *     given (bit for bit when the diagonal entry is the last of its row, as in every CSR this library builds). */

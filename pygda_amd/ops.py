@@ -263,7 +263,7 @@ def _interior_lds_plan(graph, x, y, K, transposed):
     (csrc/gda_interior.inc), else None: the device sampler built a valid plan for the direction (sampler.INTERIOR_LDS),
     the width is one the kernel takes (a multiple of 4, one workgroup per column up to 128), K is worth it."""
     plans = getattr(graph, "iplan", None)
-    if plans is None or K < INTERIOR_LDS_MIN_K:
+    if plans is None or K < INTERIOR_LDS_MIN_K or not INTERIOR_HOIST:      # hoist off = the chain's bit-exact row sums asked for
         return None
     plan = plans[1 if transposed else 0]
     n_int, d = graph.n_interior, x.size(1)

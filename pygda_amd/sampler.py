@@ -142,7 +142,7 @@ class _PendingBatch:
 
     def wait(self):
         self.event.synchronize()
-        n, e, nnz, status, n_int, ok_f, ok_b = (int(v) for v in self.counts_host.tolist()[:7])
+        n, e, nnz, status, n_int, ok_f, _, ok_b = (int(v) for v in self.counts_host.tolist()[:8])
         self.plan_ok = (ok_f > 0, ok_b > 0) if self.plans is not None else (False, False)
         if status == 2:
             raise _lib.GdaError("gda_dsampler_sample: a seed lies outside [0, num_nodes)")
@@ -226,7 +226,7 @@ class DeviceNeighborSampler:
                      torch.empty(ncap + 1, **i32), torch.empty(cap, **i32), torch.empty(cap, **f32))
         else:
             p.csr = (None,) * 6
-        counts = torch.zeros(8, **i64)
+        counts = torch.zeros(12, **i64)
         L = _lib.lib()
         _lib.check(L.gda_dsampler_sample(_lib.ptr(self.in_ptr), _lib.ptr(self.in_src), self.num_nodes, self.num_edges,
                                          self.max_in_degree, _lib.ptr(seeds_d), p.n_seeds, fan.ctypes.data, fan.size,
@@ -238,12 +238,12 @@ class DeviceNeighborSampler:
         if csr and p.short_rows and INTERIOR_LDS:
             # the register programs of the one-launch interior K-step (csrc/gda_interior.inc), one per direction, built
             # HERE -- on the sampler's stream, from the CSR pair that was just built -- so the training stream sees no
-            # extra launch; their verdicts ride home with the batch's sizes (counts[5], counts[6])
+            # extra launch; their verdicts ride home with the batch's sizes (counts[5:7], counts[7:9]: {q, T} per direction)
             nb = int(L.gda_interior_plan_bytes())
             p.plans = torch.empty(2, nb, dtype=torch.uint8, device=dev)
             for k, (rp, ci, va) in enumerate((p.csr[0:3], p.csr[3:6])):
                 _lib.check(L.gda_interior_plan_build(_lib.ptr(rp), _lib.ptr(ci), _lib.ptr(va), counts.data_ptr() + 4 * 8,
-                                                     _lib.ptr(p.plans[k]), nb, counts.data_ptr() + (5 + k) * 8,
+                                                     _lib.ptr(p.plans[k]), nb, counts.data_ptr() + (5 + 2 * k) * 8,
                                                      _lib.stream()), "gda_interior_plan_build")
         p.counts_host = self._pinned_counts()
         p.counts_host.copy_(counts, non_blocking=True)
@@ -252,11 +252,11 @@ class DeviceNeighborSampler:
         return p
 
     def _pinned_counts(self):
-        """An 8-word pinned landing pad for a batch's counts, from a ring of 64 (a batch's counts are read long before
+        """A 12-word pinned landing pad for a batch's counts, from a ring of 64 (a batch's counts are read long before
         the ring comes round; pinning a fresh block per batch costs a host allocation each time)."""
         ring = getattr(self, "_count_ring", None)
         if ring is None:
-            ring = self._count_ring = [torch.empty(64, 8, dtype=torch.int64).pin_memory(), 0]
+            ring = self._count_ring = [torch.empty(64, 12, dtype=torch.int64).pin_memory(), 0]
         i = ring[1]
         ring[1] = (i + 1) % 64
         return ring[0][i]

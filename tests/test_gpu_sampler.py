@@ -178,7 +178,7 @@ def test_interior_rows_kstep_on_sampled_batches(monkeypatch, K, d):
 
 
 # ---- the one-launch interior K-step (csrc/gda_interior.inc) ---------------------------------------------------------
-_IL_E, _IL_TB, _IL_RS = 20, 1024, 17
+_IL_E, _IL_TB, _IL_RS = 26, 1024, 16
 _IL_ZERO, _IL_DUMP, _IL_PW = 0, 1, 2
 _IL_LW = _IL_PW + _IL_TB
 _IL_HEAD = _IL_LW + _IL_TB + 2
@@ -258,8 +258,11 @@ def _leaf_contribution(G, x, n_int, col):
 
 def _plan_problem(name):
     """(graph, fan-outs, seeds per batch) of the regimes the plan builder must handle."""
-    if name == "uniform":                         # cfg-S in small: seeds gather ~fan-out interior rows, nobody else does
+    if name == "uniform":                         # seeds gather ~fan-out interior rows, nobody else does
         return _graph(200_000, 4_000_000, 21), [15, 10], 1024
+    if name == "symmetric":                       # cfg-S in small: half of the last-but-one-hop rows sample their seed back
+        ei = _graph(200_000, 2_000_000, 24)
+        return torch.cat([ei, ei.flip(0)], dim=1), [15, 10], 1024
     if name == "dense":                           # a small graph: last-but-one-hop rows find interior neighbours too
         return _graph(6000, 90_000, 22, loops=True, multi=True), [7, 5], 300
     g = torch.Generator().manual_seed(23)         # power law: a hub's transposed row crosses many runs
@@ -269,7 +272,7 @@ def _plan_problem(name):
     return ei, [10, 5], 512
 
 
-@pytest.mark.parametrize("name", ["uniform", "dense", "powerlaw"])
+@pytest.mark.parametrize("name", ["uniform", "symmetric", "dense", "powerlaw"])
 def test_interior_lds_plan_and_step_loop_against_their_emulation(monkeypatch, name):
     """gda_interior_plan_build + gda_interior_kstep_lds_f32 (the K interior steps of a sampled batch in ONE launch of
     the step loop): the plans the sampler's stream built on the device are read back and EMULATED in numpy float32 --
@@ -336,7 +339,7 @@ def test_interior_lds_plan_and_step_loop_against_their_emulation(monkeypatch, na
 
 
 def test_interior_lds_plan_declines_what_does_not_fit_and_the_chain_takes_over():
-    """More off-diagonal interior entries than 1024 runs of 20 hold (a dense little graph at fan-out [20, 20]): the
+    """More off-diagonal interior entries than 1024 runs of 26 hold (a dense little graph at fan-out [30, 30]): the
     builder's verdict is 0 for that direction, the graph carries no plan for it, and the K-launch chain runs -- same
     values as K full aggregations."""
     from pygda_amd import ops
@@ -345,7 +348,7 @@ def test_interior_lds_plan_declines_what_does_not_fit_and_the_chain_takes_over()
     ei = _graph(n, 120_000, 31)
     g = torch.Generator().manual_seed(6)
     data = Data(x=torch.randn(n, 8, generator=g), edge_index=ei, y=torch.zeros(n, dtype=torch.long)).to(DEV)
-    loader = NeighborLoader(data, [20, 20], batch_size=700, input_nodes=torch.arange(700), device=DEV)
+    loader = NeighborLoader(data, [30, 30], batch_size=700, input_nodes=torch.arange(700), device=DEV)
     batch = next(iter(loader))
     G = as_graph(batch.edge_index, batch.x.size(0))
     assert G.n_interior is not None and G.iplan == (None, None)
