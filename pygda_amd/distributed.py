@@ -274,21 +274,48 @@ def global_mean(mean_local, n_local):
     return _GlobalMean.apply(mean_local, int(n_local))
 
 
+def _dense_view(g):
+    """A contiguous view of a dense gradient's memory (a gather-major weight's gradient has transposed strides)."""
+    if g.is_contiguous():
+        return g
+    if g.dim() == 2 and g.t().is_contiguous():
+        return g.t()
+    return None
+
+
 def allreduce_grads(params):
-    """ONE collective per step: flatten, all-reduce(sum), divide by the world size."""
+    """ONE collective launch per step: every gradient summed over the ranks IN PLACE, then divided by the world size.
+
+    ``nccl`` groups: the all-reduces of the individual gradients are issued inside one coalescing group (RCCL fuses a
+    group into a single launch) and divided by one multi-tensor kernel -- no flattened copy, no copy-back per parameter
+    (round 4: ``torch.cat`` + W + one ``copy_`` per parameter, ~2 N launches).  The library-owned
+    communicator and gloo groups (CPU tests; ranks sharing a GPU) keep one flat buffer: a single contiguous operand is
+    what those paths take."""
     if not active():
         return
     params = list(params)
     for p in params:                      # a rank whose batch never touched p still joins
         if p.grad is None:
             p.grad = torch.zeros_like(p)
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
-    comm = direct() if flat.dtype == torch.float32 and flat.is_cuda else None
+    world = dist.get_world_size()
+    grads = [p.grad for p in params]
+    cuda32 = all(g.is_cuda and g.dtype == torch.float32 for g in grads)
+    comm = direct() if cuda32 else None
+    views = [_dense_view(g) for g in grads] if cuda32 else None
+    manager = getattr(dist, "_coalescing_manager", None)
+    if (comm is None and cuda32 and dist.get_backend() == "nccl" and manager is not None
+            and all(v is not None for v in views) and os.environ.get("PYGDA_AMD_COALESCED_GRADS", "1") == "1"):
+        with manager(device=grads[0].device, async_ops=False):
+            for v in views:
+                dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        torch._foreach_div_(views, float(world))
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
     if comm is not None:
         comm.all_reduce_(flat)
     else:
         _all_reduce_sum(flat)
-    flat.div_(dist.get_world_size())
+    flat.div_(world)
     off = 0
     for p in params:
         n = p.numel()

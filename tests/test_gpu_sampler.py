@@ -179,9 +179,9 @@ def test_interior_rows_kstep_on_sampled_batches(monkeypatch, K, d):
 
 # ---- the one-launch interior K-step (csrc/gda_interior.inc) ---------------------------------------------------------
 _IL_E, _IL_TB, _IL_RS = 26, 1024, 16
-_IL_ZERO, _IL_DUMP, _IL_PW = 0, 1, 2
+_IL_ZERO, _IL_DUMP0, _IL_PW = 0, 64, 128
 _IL_LW = _IL_PW + _IL_TB
-_IL_HEAD = _IL_LW + _IL_TB + 2
+_IL_HEAD = _IL_LW + _IL_TB
 
 
 def _il_plan_arrays(plan):
@@ -222,7 +222,7 @@ def _il_emulate(P, x, c, K, n_int, trans):
             on = e < wm
             acc = np.where(on, acc + P["pw"][:, e] * cur[idx[:, e]], acc).astype(f32)
             nxt[st[on, e]] = acc[on]
-            acc = np.where(on & (st[:, e] != _IL_DUMP), f32(0), acc).astype(f32)
+            acc = np.where(on & (st[:, e] >= _IL_PW), f32(0), acc).astype(f32)
         for t in np.nonzero(P["lead"])[0]:
             v = f32(0)
             for k in range(int(P["lead"][t] >> 16), 0, -1):
@@ -313,7 +313,8 @@ def test_interior_lds_plan_and_step_loop_against_their_emulation(monkeypatch, na
                 q = max(1, -(-T // _IL_TB))
                 flat = P["pk"][:, :q].reshape(-1)[:T]
                 exact(flat & 0xffff, ent[keep] + _IL_HEAD)
-                assert int((P["pk"][:, q:] != (_IL_ZERO | (_IL_DUMP << 16))).sum()) == 0
+                dump = ((_IL_DUMP0 + (np.arange(_IL_TB) & 63)) << 16).astype(np.uint32)[:, None]
+                assert int((P["pk"][:, q:] != (_IL_ZERO | dump)).sum()) == 0        # unused entries: zero word -> the lane's dump word
                 for col in (0, d - 1):
                     c = None if trans else _leaf_contribution(G, x, n_int, col)
                     want, cc = _il_emulate(P, inp[:n_int, col].cpu().numpy(), c, K, n_int, trans)
