@@ -296,6 +296,40 @@ k_colsum_final(const float* __restrict__ partial, int blocks, int d, float* __re
     if (g == 0 && c < d) out[c] = red[0][cl];
 }
 
+// Small problems (the classifier's bias gradient: 9,360 rows x 5 classes) in ONE launch of one workgroup: a lane per
+// (row slot, column), eight rows in flight per lane, then the row slots of a column folded as a fixed binary tree in
+// LDS -- the two-launch form costs a second dependent launch (~5 us in a replayed step) for 187 KB of input.
+constexpr int CO_TB = 1024;
+constexpr int64_t CO_MAX_ELEMS = 1 << 17;
+constexpr int CO_MAX_D = 64;
+
+__global__ void __launch_bounds__(CO_TB)
+k_colsum_one(const float* __restrict__ x, int64_t ldx, int64_t n, int d, int slots, float* __restrict__ out) {
+    __shared__ float red[CO_TB];
+    const int tc = threadIdx.x % d, tr = threadIdx.x / d;          // slots = largest power of two <= CO_TB / d
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (tr < slots) {
+        int64_t i = tr;
+        const int64_t stride = slots;
+        for (; i + 7 * stride < n; i += 8 * stride) {
+            const float v0 = x[i * ldx + tc], v1 = x[(i + stride) * ldx + tc];
+            const float v2 = x[(i + 2 * stride) * ldx + tc], v3 = x[(i + 3 * stride) * ldx + tc];
+            const float v4 = x[(i + 4 * stride) * ldx + tc], v5 = x[(i + 5 * stride) * ldx + tc];
+            const float v6 = x[(i + 6 * stride) * ldx + tc], v7 = x[(i + 7 * stride) * ldx + tc];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+            a0 += v4; a1 += v5; a2 += v6; a3 += v7;
+        }
+        for (; i < n; i += stride) a0 += x[i * ldx + tc];
+        red[tr * d + tc] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    for (int w = slots >> 1; w > 0; w >>= 1) {
+        if (tr < w) red[tr * d + tc] += red[(tr + w) * d + tc];
+        __syncthreads();
+    }
+    if (tr == 0) out[tc] = red[tc];
+}
+
 int colsum_blocks(int64_t n, int d) {
     const int rpb = d <= TB ? TB / d : 1;
     const int64_t g = gda_cdiv(n, (int64_t)rpb * 8);                 // >= 8 rows per lane
@@ -429,7 +463,15 @@ extern "C" int gda_colsum_f32(const float* x, int64_t ldx, int64_t n, int64_t d,
         GDA_HIP_TRY(hipMemsetAsync(out, 0, (size_t)d * sizeof(float), s));
         return GDA_OK;
     }
-    if (!x || !workspace) return GDA_E_NULL;
+    if (!x) return GDA_E_NULL;
+    if (d <= CO_MAX_D && n * d <= CO_MAX_ELEMS) {                    // one workgroup, one launch
+        int slots = 1;
+        while (slots * 2 * (int)d <= CO_TB) slots *= 2;
+        k_colsum_one<<<1, CO_TB, 0, s>>>(x, ldx, n, (int)d, slots, out);
+        GDA_LAUNCH_CHECK();
+        return GDA_OK;
+    }
+    if (!workspace) return GDA_E_NULL;
     if (workspace_bytes < gda_colsum_workspace_bytes(n, d)) return GDA_E_WORKSPACE;
     const int blocks = colsum_blocks(n, (int)d);
     k_colsum_partial<<<blocks, TB, 0, s>>>(x, ldx, n, (int)d, static_cast<float*>(workspace));

@@ -276,7 +276,10 @@ class NeighborLoader:
         import threading
         dev = self.data.x.device
         if getattr(self, "_samp_stream", None) is None:
-            self._samp_stream = torch.cuda.Stream(device=dev)
+            import os
+            # the sampler's ~45 small dependent launches per batch sit beside chip-filling training kernels: at the
+            # default priority each of them queues behind whatever the training streams have in flight
+            self._samp_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PYGDA_AMD_SAMPLER_PRIORITY", "0")))
         side = self._samp_stream
         side.wait_stream(torch.cuda.current_stream())       # the graph / features may have just been produced
         q, stop = queue.Queue(maxsize=self.prefetch), threading.Event()

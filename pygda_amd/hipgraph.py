@@ -339,6 +339,7 @@ class GraphedStep:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 loss, logits = self._run(with_stats=True)      # an epoch then needs ONE small D2H
             self.loss, self.logits = loss.detach(), logits.detach()
+            self._preroll()
             self._stat_pins = [torch.zeros(2, dtype=torch.float64).pin_memory() for _ in range(2)]
             self._stat_events = [None, None]
             self._stat_turn = 0
@@ -354,6 +355,33 @@ class GraphedStep:
         finally:
             _mmd.sample_provider, _mmd.dp_index_provider, host_rand_provider = prev, prev_dp, prev_rand
         return self
+
+    def _preroll(self):
+        """Between capture and roll-back: hand the fresh executable graphs to the device ahead of their first timed
+        launch (``hipGraphUpload``) and / or replay them a few times (``PYGDA_AMD_GRAPH_PREROLL=R``) -- everything a replay
+        changes (parameters, optimiser state) is rolled back right after, the sample blocks are not refilled.  Why:
+        every long run met ONE replay of 5-8 ms early in a graph's life in which the host's launch call blocks
+        (profiles/r4_replay_jitter.txt); with four steps per capture it fell inside a 20-step timed region."""
+        import os
+        graphs = [g for g in (getattr(self, "graph_multi", None), getattr(self, "graph", None),
+                               *getattr(self, "graphs", ())) if g is not None]
+        if os.environ.get("PYGDA_AMD_GRAPH_UPLOAD", "1") == "1":
+            try:
+                import ctypes
+                hip = ctypes.CDLL("libamdhip64.so")
+                hip.hipGraphUpload.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+                hip.hipGraphUpload.restype = ctypes.c_int
+                stream = torch.cuda.current_stream().cuda_stream
+                self.upload_status = [int(hip.hipGraphUpload(ctypes.c_void_p(g.raw_cuda_graph_exec()),
+                                                             ctypes.c_void_p(stream))) for g in graphs]
+            except Exception as exc:                 # noqa: BLE001 -- an optimisation hint: never a reason to fail
+                self.upload_status = f"{type(exc).__name__}: {exc}"
+        rolls = int(os.environ.get("PYGDA_AMD_GRAPH_PREROLL", "0"))
+        for g in graphs:
+            for _ in range(rolls):
+                g.replay()
+        if rolls:
+            torch.cuda.synchronize()
 
     def _replay(self):
         self.graph.replay()
@@ -494,6 +522,7 @@ class GraphedStepSplit(GraphedStep):
             dropout_state.next_step(dev)               # eager, as in front of every replay
             loss, logits = self._run_split(self.graphs)
             self.loss, self.logits = loss.detach(), logits.detach()
+            self._preroll()
             self._stat_pins = [torch.zeros(2, dtype=torch.float64).pin_memory() for _ in range(2)]
             self._stat_events = [None, None]
             self._stat_turn = 0

@@ -249,6 +249,35 @@ def test_two_rank_udagcn_adagcn_step_equals_concatenated_batch_gpu(kind):
             close(results[0]["disc10"][k], v, rtol=1e-3, atol=1e-4)
 
 
+def test_data_parallel_mmd_estimator_has_the_single_process_mean():
+    """The data-parallel MMD (pygda_amd/utils/mmd.py: every rank draws sampling_num / W rows per resample from ITS OWN
+    batch, the rows are all-gathered and every rank evaluates the statistic on the gathered 1000 + 1000 rows) against the
+    single-process estimator (1000 rows per domain drawn from the concatenated batch, mmd.py:148-149): the two are the
+    same estimator up to stratification of the draws, so over 240 resamples their means must agree within the standard
+    error.  So far only equality with IDENTICAL picks was tested (tests/dp_equality.py); here the draws are independent.
+    Shards of unequal size (the sampled sub-graphs of two ranks never have the same node count) and a real domain gap."""
+    g = torch.Generator().manual_seed(77)
+    d, W, times, n = 128, 2, 5, 1000
+    sizes_s, sizes_t = (9000, 11000), (5200, 4800)
+    src = [(torch.randn(k, d, generator=g) * 0.8 + 0.15).to(DEV) for k in sizes_s]         # shards of ONE source domain
+    tgt = [(torch.randn(k, d, generator=g) * 1.1 - 0.10).to(DEV) for k in sizes_t]
+    src_all, tgt_all = torch.cat(src), torch.cat(tgt)
+    per = n // W
+    one, dp = [], []
+    for _ in range(48):                                          # 48 calls x 5 resamples = 240 resamples per estimator
+        si, ti = torch.randint(src_all.size(0), (times, n), generator=g), torch.randint(tgt_all.size(0), (times, n), generator=g)
+        one.append(float(ops.mmd_loss(src_all, tgt_all, si.to(DEV), ti.to(DEV))))
+        rows_s = torch.cat([ops.sample_rows(src[r], torch.randint(sizes_s[r], (times, per), generator=g).to(DEV)) for r in range(W)], dim=1)
+        rows_t = torch.cat([ops.sample_rows(tgt[r], torch.randint(sizes_t[r], (times, per), generator=g).to(DEV)) for r in range(W)], dim=1)
+        assert rows_s.shape == (times, n, d)
+        dp.append(float(ops.mmd_loss_rows(rows_s, rows_t)))
+    one, dp = np.array(one), np.array(dp)
+    se = np.sqrt(one.var(ddof=1) / one.size + dp.var(ddof=1) / dp.size)
+    assert one.mean() > 20 * se                                   # the statistic sees the domain gap: a real signal
+    assert abs(one.mean() - dp.mean()) <= 4 * se, (one.mean(), dp.mean(), se)
+    assert 0.5 <= dp.std(ddof=1) / one.std(ddof=1) <= 2.0         # same spread: neither estimator is the noisier one
+
+
 def test_bench_two_rank_path_end_to_end_on_one_gpu():
     """`bench.py --gpus 2` as the driver launches it, except that the two ranks share this GPU over gloo
     (`--share-gpus`): the launcher, seed shards per rank on the device sampler, the all-gathered MMD rows and the

@@ -1648,7 +1648,7 @@ def test_strurw_fit_predict_golden(gnn, mode):
 
 
 # ------------------------------------------- stacked source passes (A2GNN, s_pnums = 0) --
-@pytest.mark.parametrize("n,d", [(9360, 128), (7, 4), (1000, 5), (300, 1024), (5000, 300), (1, 1)])
+@pytest.mark.parametrize("n,d", [(9360, 128), (7, 4), (1000, 5), (9360, 5), (2048, 64), (300, 1024), (5000, 300), (1, 1)])
 def test_colsum_vs_torch(n, d):
     gen = torch.Generator().manual_seed(n + d)
     x = torch.randn(n, d, generator=gen).to(DEV)

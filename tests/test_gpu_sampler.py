@@ -261,7 +261,7 @@ def _plan_problem(name):
     if name == "uniform":                         # seeds gather ~fan-out interior rows, nobody else does
         return _graph(200_000, 4_000_000, 21), [15, 10], 1024
     if name == "symmetric":                       # cfg-S in small: half of the last-but-one-hop rows sample their seed back
-        ei = _graph(200_000, 2_000_000, 24)
+        ei = _graph(2_000_000, 20_000_000, 24)    # (large enough that other interior neighbours stay rare: T ~ 24 k <= 26,624)
         return torch.cat([ei, ei.flip(0)], dim=1), [15, 10], 1024
     if name == "dense":                           # a small graph: last-but-one-hop rows find interior neighbours too
         return _graph(6000, 90_000, 22, loops=True, multi=True), [7, 5], 300
