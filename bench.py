@@ -68,6 +68,25 @@ def make_cfg_a(seed=200, ns=9360, es=15556, nt=5484, et=8117, feat=6775, classes
     return graph(ns, es), graph(nt, et)
 
 
+def library_sha16():
+    """First 16 hex digits of the SHA-256 of the loaded libgda_hip.so: what a committed rocprofv3 summary must carry
+    (tools/summarize_rocprof.py records it) for its kernel durations to be quoted beside this run's without a warning."""
+    import hashlib
+    try:
+        from pygda_amd._build import LIB
+        return hashlib.sha256(open(LIB, "rb").read()).hexdigest()[:16]
+    except Exception:                     # noqa: BLE001
+        return None
+
+
+def summary_library(fname):
+    """The library hash a committed summary was made with (None: an older summary that does not record one)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", fname))).get("library_sha16")
+    except Exception:                     # noqa: BLE001
+        return None
+
+
 def pmc_traffic(prefix="k_spmm<32, 4", pattern="*_rocprof_summary.json"):
     """HBM-side bytes per launch of the aggregation kernel from the committed rocprofv3 PMC passes
     (profiles/*_rocprof_summary.json, made by tools/summarize_rocprof.py: separate --pmc FETCH_SIZE
@@ -301,6 +320,8 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
         torch.cuda.synchronize()
 
     import gc
+    if os.environ.get("PYGDA_AMD_SWITCH_US"):     # experiment: the interpreter's thread switch interval (default 5 ms)
+        sys.setswitchinterval(1e-6 * float(os.environ["PYGDA_AMD_SWITCH_US"]))
     gc.collect()                 # nothing of an earlier workload in this process (captured graphs) dies inside the region
     for _ in range(args.warmup):
         one_step()
@@ -310,14 +331,19 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
     ms0 = torch.cuda.memory_stats(dev)
     allocs0 = ms0.get("num_device_alloc", 0)
     t0 = time.perf_counter()
-    marks = []
+    c0 = time.thread_time()
+    marks, cpu_marks = [], []
     for _ in range(args.steps):
         loss = one_step()
         marks.append(time.perf_counter())
+        cpu_marks.append(time.thread_time())
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
     host_ms = [1e3 * (b - a) for a, b in zip([t0] + marks[:-1], marks)]        # host time per step (enqueue side)
+    # ... and how much of it the training thread spent ON a core: the rest is waiting (the interpreter lock held by the
+    # loaders' producer threads / the MMD helper, a full launch queue, the loader's queue)
+    host_cpu_ms = [1e3 * (b - a) for a, b in zip([c0] + cpu_marks[:-1], cpu_marks)]
     ms1 = torch.cuda.memory_stats(dev)
     device_allocs = ms1.get("num_device_alloc", 0) - allocs0   # hipMalloc calls inside the region
     if os.environ.get("PYGDA_AMD_BENCH_ALLOC_DEBUG") == "1":
@@ -393,6 +419,10 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                         copies = r.get("copy_launches", 0)
                         rp_secs = (ru * (r["launches"] - copies) + cu * copies) * 1e-6
                         out["rocprof"] = {"k_spmm_range_avg_us": ru, "k_rows_copy_bias_avg_us": cu, "source": rf,
+                                          "what": "committed rocprofv3 averages: a labelled side figure, `frac` above is "
+                                                  "this run's HIP-event duration",
+                                          "same_library_as_this_run": summary_library(rf) is not None
+                                          and summary_library(rf) == library_sha16(),
                                           "region_us_from_rocprof": rp_secs * 1e6, "region_us_live": secs * 1e6,
                                           "frac_rocprof": r["bytes"] / rp_secs / 1e9 / HBM_PEAK_GBS}
                 if r.get("alg_equiv_bytes"):
@@ -431,6 +461,7 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                                    "per step, MMD domain loss",
                        "edges_aggregated_per_step": edges / args.steps, "final_loss": float(loss.detach()),
                        "host_ms_per_step_max_median": [max(host_ms), sorted(host_ms)[len(host_ms) // 2]],
+                       "host_cpu_ms_per_step_median": sorted(host_cpu_ms)[len(host_cpu_ms) // 2],
                        "hipMalloc_calls_in_timed_region": device_allocs,
                        "aggregation_launches_per_step": sum(prof[k]["launches"] for k in agg) / prof_steps,
                        "aggregation_paths": {k: prof[k]["launches"] / prof_steps for k in sorted(agg)},
@@ -442,7 +473,8 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
             "roofline": dict(roof(dominant), timing=f"HIP events on the launch stream, {prof_steps} extra steps after "
                                                     "the timed region"),
             "roofline_dense_projection": {k: roof(k) for k in sorted(prof) if k.startswith("dense_projection")},
-            "kernel_time_ms_per_step": {k: v["ms"] / prof_steps for k, v in sorted(prof.items())}}
+            "kernel_time_ms_per_step": {k: v["ms"] / prof_steps for k, v in sorted(prof.items())},
+            "library_sha16": library_sha16()}
         if world == 1 and cpu_base and not args.no_cpu_baseline:
             # the oracle's training step on ONE sampled batch pair of this run (its sub-graphs, its features)
             sb, tb = last["s"], last["t"]
@@ -586,6 +618,44 @@ def run_cfg_a(args, world, rank, dev, side=False):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    sustained = None
+    if graphed and world == 1 and not side and not args.profile_run and not args.no_sustained and hasattr(_g, "launch"):
+        # the 20-step timed region above is 9 ms; the same replays over >= 400 launches, with the device time of every
+        # replay (HIP events between consecutive replay ends): what a long fit() sustains, and how it spreads
+        from pygda_amd import hipgraph as _hg
+        rec, per = [], max(1, getattr(_g, "unroll", 1) if getattr(_g, "graph_multi", None) is not None else 1)
+        orig_multi, orig_single = _hg.GraphedStep.launch_multi, _hg.GraphedStep.launch
+
+        def _traced(fn):
+            def run(self):
+                h0 = time.perf_counter()
+                t = fn(self)
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                rec.append((h0, time.perf_counter(), ev))
+                return t
+            return run
+
+        _hg.GraphedStep.launch_multi, _hg.GraphedStep.launch = _traced(orig_multi), _traced(orig_single)
+        try:
+            n_sus = 400 * per
+            sync()
+            s0 = time.perf_counter()
+            model._train_epochs(*state, epochs=range(10 ** 6, 10 ** 6 + n_sus))
+            sync()
+            sdt = time.perf_counter() - s0
+        finally:
+            _hg.GraphedStep.launch_multi, _hg.GraphedStep.launch = orig_multi, orig_single
+        dev_ms = sorted(rec[i - 1][2].elapsed_time(rec[i][2]) / per for i in range(1, len(rec)))
+        host_us = sorted(1e6 * (b - a) for a, b, _ in rec)
+        pick = lambda v, q: v[min(len(v) - 1, int(q * len(v)))]
+        sustained = {"replays": len(rec), "steps": n_sus, "steps_per_replay": per, "ms_per_step": 1e3 * sdt / n_sus,
+                     "device_ms_per_step_p50": pick(dev_ms, 0.5), "device_ms_per_step_p99": pick(dev_ms, 0.99),
+                     "device_ms_per_step_max": dev_ms[-1], "host_launch_call_us_p50": pick(host_us, 0.5),
+                     "host_launch_call_us_p99": pick(host_us, 0.99),
+                     "replays_slower_than_1p5x_median": sum(1 for v in dev_ms if v > 1.5 * pick(dev_ms, 0.5)),
+                     "note": "same captured step, continued after the timed region; per-replay device time from HIP events "
+                             "between consecutive replay ends, divided by the steps per replay"}
     execution = (({"dp": "four hipGraph segments with eager RCCL collectives between them",
                    "dp-whole": "hipGraph replay of the whole data-parallel step, RCCL collectives captured "
                                "(library-owned communicator)"}
@@ -647,7 +717,9 @@ def run_cfg_a(args, world, rank, dev, side=False):
         # read as a 0.93 ms "kernel" inside a 0.52 ms step in the round-3 driver line
         model._train_epochs(*state, epochs=range(total_epochs, total_epochs + 1))
         sync()
+        profile_attempts = 0
         for attempt in range(2):
+            profile_attempts += 1
             profiler.start()
             model._train_epochs(*state, epochs=range(total_epochs + 1 + attempt * args.steps,
                                                      total_epochs + 1 + (attempt + 1) * args.steps))
@@ -720,17 +792,25 @@ def run_cfg_a(args, world, rank, dev, side=False):
             peak = LDS_READ_B32_PEAK_GBS * cus / 256.0
             per_launch = r["lds_bytes"] / r["launches"]
             rp_us, rp_calls, rp_file = rocprof_kernel("k_kstep_lds<", prof_pattern)
-            dur_us = rp_us if rp_us else r["avg_us"]
+            # THIS run's durations price the line: the HIP-event bracket of every launch of the eager
+            # pass (event pair included: the conservative figure) is `frac`; 30 launches back to back between two events
+            # stand beside it.  The committed rocprofv3 in-graph average is a labelled side figure, flagged stale when
+            # the summary was made with another build of the library.
+            dur_us = r["avg_us"]
             ach = per_launch / (dur_us * 1e-6) / 1e9
+            rp_lib = summary_library(rp_file) if rp_file else None
             out = {"kernel": name, "bound": "lds", "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
                    "frac_is": "LDS gather rate over the ds_read_b32 rate of the CUs the launch occupies "
                               f"({cus} workgroups = {cus} of 256 CUs)",
                    "duration_used_us": dur_us,
-                   "duration_source": (f"{rp_file}: rocprofv3 in-graph average over {rp_calls} launches" if rp_us else
-                                       "HIP events of this run (no committed rocprof summary found)"),
-                   "avg_launch_us_rocprof": rp_us, "avg_launch_us": r["avg_us"], "back_to_back_launch_us": alone_us,
-                   "frac_live_events": per_launch / (r["avg_us"] * 1e-6) / 1e9 / peak,
+                   "duration_source": "HIP events of THIS run: per-launch bracket on the launch stream in the eager pass "
+                                      "after the timed region (same kernels, same data, same launch configuration)",
+                   "avg_launch_us": r["avg_us"], "back_to_back_launch_us": alone_us,
                    "frac_back_to_back": (per_launch / (alone_us * 1e-6) / 1e9 / peak) if alone_us else None,
+                   "rocprof_committed": None if not rp_us else {
+                       "avg_launch_us": rp_us, "launches": rp_calls, "file": rp_file, "what": "rocprofv3 in-graph average",
+                       "frac": per_launch / (rp_us * 1e-6) / 1e9 / peak, "library_sha16": rp_lib,
+                       "same_library_as_this_run": rp_lib is not None and rp_lib == library_sha16()},
                    "lds_bytes_gathered_per_launch": per_launch, "launches": r["launches"],
                    "cus_occupied": cus, "frac_of_whole_chip": ach / LDS_READ_B32_PEAK_GBS}
             if alone_us and fixed_us and alone_us > fixed_us:
@@ -835,6 +915,7 @@ def run_cfg_a(args, world, rank, dev, side=False):
                                    "mmd_bwd[scatter]": per_call("mmd_bwd")}}
             us, calls, fname = rocprof_kernel("k_mmd_fused<", prof_pattern)
             if us:
+                mm["rocprof_same_library_as_this_run"] = summary_library(fname) is not None and summary_library(fname) == library_sha16()
                 mm["k_mmd_fused"] = {"avg_launch_us_rocprof": us, "source": fname, "flops_executed": 3 * 2 * full,
                                      "achieved": 3 * 2 * full / (us * 1e-6) / 1e12,
                                      "frac": 3 * 2 * full / (us * 1e-6) / 1e12 / F16_MFMA_PEAK_TF,
@@ -858,6 +939,11 @@ def run_cfg_a(args, world, rank, dev, side=False):
         out["roofline_mmd"] = mm
     if host_launch is not None:
         out["host_per_step"] = host_launch
+    if sustained is not None:
+        out["sustained"] = sustained
+    out["library_sha16"] = library_sha16()
+    if graphed:
+        out["profile_pass_attempts"] = profile_attempts       # 2: the first eager pass met an event-bracket artefact and was repeated
     # the trainer and its captured graphs form a reference cycle: collect it HERE, device idle -- left to the cyclic
     # collector, the hipGraphs (and their memory pool) were destroyed whenever it next ran, e.g. inside the timed
     # region of the cfg-S side line that follows (a 100 ms stall in a 33 ms region)
@@ -908,6 +994,7 @@ def main():
     ap.add_argument("--profile-run", action="store_true",
                     help="for runs under rocprofv3: stop after the timed region (no eager HIP-event pass, no back-to-back "
                          "kernel probes), so that the profiler's per-kernel averages are those of the replayed steps")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the 400-replay sustained measurement of cfg-A")
     ap.add_argument("--no-rccl-direct", action="store_true",
                     help="collectives through torch.distributed's ProcessGroup instead of the library-owned RCCL communicator")
     ap.add_argument("--rccl-direct", action="store_true",

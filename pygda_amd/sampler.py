@@ -181,6 +181,7 @@ class DeviceNeighborSampler:
         if bad:
             raise IndexError(f"edge_index values must lie in [0, {N}): {bad} edges do not")
         self._ws = {}
+        self._layouts = {}
 
     def _caps(self, n_seeds, fanouts):
         fan = np.ascontiguousarray(np.asarray(fanouts, dtype=np.int32))
@@ -202,49 +203,90 @@ class DeviceNeighborSampler:
     def description(self):
         return "device sampler (csrc/gda_dsampler.hip): in-neighbour lists in HBM, no host sampling threads"
 
+    def _layout(self, n_seeds, fanouts, csr, plans):
+        """Byte offsets of one batch's device arrays inside ONE block (256-byte aligned each) -- computed once per
+        (seed count, fan-outs): a batch then costs the producer thread one allocation and a handful of views instead of
+        a dozen allocator calls under the interpreter lock the training thread is waiting for."""
+        key = (int(n_seeds), tuple(int(f) for f in fanouts), bool(csr), bool(plans))
+        hit = self._layouts.get(key)
+        if hit is None:
+            caps = self._caps(int(n_seeds), fanouts)
+            if caps is None:
+                raise _lib.GdaError(f"device sampler: fan-outs {list(fanouts)} are not supported (0, or above 64)")
+            fan, ncap, ecap, need = caps
+            off, at = {}, 0
+
+            def take(name, nbytes):
+                nonlocal at
+                off[name] = (at, nbytes)
+                at += (nbytes + 255) // 256 * 256
+
+            take("counts", 12 * 8)
+            take("nodes", ncap * 8)
+            take("ei", 2 * ecap * 8)
+            if csr:
+                cap = ecap + ncap
+                for name, nbytes in (("rp", (ncap + 1) * 4), ("ci", cap * 4), ("va", cap * 4),
+                                     ("trp", (ncap + 1) * 4), ("tci", cap * 4), ("tva", cap * 4)):
+                    take(name, nbytes)
+            nb = int(_lib.lib().gda_interior_plan_bytes()) if plans else 0
+            if plans:
+                take("plan0", nb)
+                take("plan1", nb)
+            hit = self._layouts[key] = (fan, ncap, ecap, need, off, at, nb)
+        return hit
+
     def enqueue(self, seeds, fanouts, seed=0, csr=True):
         """Launch the batch on the CURRENT stream; returns a :class:`_PendingBatch`."""
-        caps = self._caps(int(torch.as_tensor(seeds).numel()), fanouts)
-        if caps is None:
-            raise _lib.GdaError(f"device sampler: fan-outs {list(fanouts)} are not supported (0, or above 64)")
-        fan, ncap, ecap, need = caps
+        seeds_t = torch.as_tensor(seeds)
+        short_rows = len(fanouts) > 0 and min(int(f) for f in fanouts) > 0    # every row holds at most fan-out + 1 entries
+        plans = bool(csr and short_rows and INTERIOR_LDS)
+        fan, ncap, ecap, need, off, total, nb = self._layout(seeds_t.numel(), fanouts, csr, plans)
         dev = self.device
         stream = torch.cuda.current_stream()
         ws = self._ws.get(stream.cuda_stream)
         if ws is None or ws.numel() < need:
             ws = self._ws[stream.cuda_stream] = torch.empty(need, dtype=torch.uint8, device=dev)
-        seeds_d = torch.as_tensor(seeds).to(dev, torch.int64, non_blocking=True).contiguous()
-        i64, i32, f32 = (dict(dtype=t, device=dev) for t in (torch.int64, torch.int32, torch.float32))
+        seeds_d = seeds_t.to(dev, torch.int64, non_blocking=True).contiguous()
         p = _PendingBatch()
-        p.n_seeds, p.stream = int(seeds_d.numel()), stream
-        p.short_rows = bool(fan.size) and int(fan.min()) > 0        # every row holds at most fan-out + 1 entries
-        p.nodes = torch.empty(ncap, **i64)
-        p.ei = torch.empty(2, ecap, **i64)
+        p.n_seeds, p.stream, p.short_rows = int(seeds_d.numel()), stream, short_rows
+        block = torch.empty(total, dtype=torch.uint8, device=dev)
+        base = block.data_ptr()
+
+        def view(name, dtype):
+            a, nbytes = off[name]
+            return block[a:a + nbytes].view(dtype)
+
+        counts = view("counts", torch.int64)
+        counts.zero_()
+        p.nodes = view("nodes", torch.int64)
+        p.ei = view("ei", torch.int64).view(2, ecap)
         if csr:
-            cap = ecap + ncap
-            p.csr = (torch.empty(ncap + 1, **i32), torch.empty(cap, **i32), torch.empty(cap, **f32),
-                     torch.empty(ncap + 1, **i32), torch.empty(cap, **i32), torch.empty(cap, **f32))
+            p.csr = (view("rp", torch.int32), view("ci", torch.int32), view("va", torch.float32),
+                     view("trp", torch.int32), view("tci", torch.int32), view("tva", torch.float32))
+            csr_ptrs = [base + off[k][0] for k in ("rp", "ci", "va", "trp", "tci", "tva")]
         else:
             p.csr = (None,) * 6
-        counts = torch.zeros(12, **i64)
+            csr_ptrs = [None] * 6
         L = _lib.lib()
+        st = _lib.stream()
         _lib.check(L.gda_dsampler_sample(_lib.ptr(self.in_ptr), _lib.ptr(self.in_src), self.num_nodes, self.num_edges,
                                          self.max_in_degree, _lib.ptr(seeds_d), p.n_seeds, fan.ctypes.data, fan.size,
-                                         ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _lib.ptr(p.nodes),
-                                         _lib.ptr(p.ei[0]), _lib.ptr(p.ei[1]), *(_lib.ptr(t) for t in p.csr),
-                                         _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream()),
+                                         ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), base + off["nodes"][0],
+                                         base + off["ei"][0], base + off["ei"][0] + ecap * 8, *csr_ptrs,
+                                         base + off["counts"][0], _lib.ptr(ws), ws.numel(), st),
                    "gda_dsampler_sample")
         p.plans, p.plan_ok = None, (False, False)
-        if csr and p.short_rows and INTERIOR_LDS:
+        if plans:
             # the register programs of the one-launch interior K-step (csrc/gda_interior.inc), one per direction, built
             # HERE -- on the sampler's stream, from the CSR pair that was just built -- so the training stream sees no
             # extra launch; their verdicts ride home with the batch's sizes (counts[5:7], counts[7:9]: {q, T} per direction)
-            nb = int(L.gda_interior_plan_bytes())
-            p.plans = torch.empty(2, nb, dtype=torch.uint8, device=dev)
-            for k, (rp, ci, va) in enumerate((p.csr[0:3], p.csr[3:6])):
-                _lib.check(L.gda_interior_plan_build(_lib.ptr(rp), _lib.ptr(ci), _lib.ptr(va), counts.data_ptr() + 4 * 8,
-                                                     _lib.ptr(p.plans[k]), nb, counts.data_ptr() + (5 + 2 * k) * 8,
-                                                     _lib.stream()), "gda_interior_plan_build")
+            p.plans = (view("plan0", torch.uint8), view("plan1", torch.uint8))
+            cbase = base + off["counts"][0]
+            for k in range(2):
+                _lib.check(L.gda_interior_plan_build(csr_ptrs[3 * k], csr_ptrs[3 * k + 1], csr_ptrs[3 * k + 2], cbase + 4 * 8,
+                                                     base + off[f"plan{k}"][0], nb, cbase + (5 + 2 * k) * 8, st),
+                           "gda_interior_plan_build")
         p.counts_host = self._pinned_counts()
         p.counts_host.copy_(counts, non_blocking=True)
         p.event = torch.cuda.Event()
@@ -286,9 +328,8 @@ class DeviceNeighborSampler:
         cur = torch.cuda.current_stream()
         if p.stream != cur:
             cur.wait_event(p.event)
-            for t in (p.nodes, p.ei, *p.csr, p.plans):
-                if t is not None:
-                    t.record_stream(cur)          # allocated on the sampler's stream, consumed on this one
+            p.nodes.record_stream(cur)            # ONE block (views share its storage): allocated on the sampler's stream,
+                                                  # consumed on this one
         from .ops import gather_rows
         n_id = p.nodes[:n]
         ei = p.ei[:, :e]

@@ -44,16 +44,16 @@ _prefetched = None
 PREFETCH = __import__("os").environ.get("PYGDA_AMD_MMD_PREFETCH", "1") == "1"
 
 
-def prefetch_samples(ns, nt, dev, sampling_num=1000, times=5):
-    global _prefetched
-    if (not PREFETCH or _prefetched is not None or distributed.active() or sample_provider is not None
-            or torch.device(dev).type != "cuda"):
-        return
-    import threading
-    stream = torch.cuda.current_stream(dev)
-    box = {}
+_worker = None          # (thread, job queue): ONE helper thread for the process -- a thread per step cost the training
+                        # thread a thread creation (~0.1 ms) per step
 
-    def work():
+
+def _worker_loop(jobs):
+    while True:
+        job = jobs.get()
+        if job is None:
+            return
+        ns, nt, times, sampling_num, dev, stream, box, done = job
         try:
             with torch.cuda.device(dev), torch.cuda.stream(stream):
                 s_cpu = torch.randint(ns, (times, sampling_num))
@@ -62,10 +62,26 @@ def prefetch_samples(ns, nt, dev, sampling_num=1000, times=5):
                 box["out"] = mmd_samples_to_device(s_cpu, t_cpu, ns, nt, torch.device(dev))
         except BaseException as exc:          # surfaced by the consumer
             box["err"] = exc
+        finally:
+            done.set()
 
-    th = threading.Thread(target=work, daemon=True)
-    th.start()
-    _prefetched = (ns, nt, times, sampling_num, str(torch.device(dev)), th, box)
+
+def prefetch_samples(ns, nt, dev, sampling_num=1000, times=5):
+    global _prefetched, _worker
+    if (not PREFETCH or _prefetched is not None or distributed.active() or sample_provider is not None
+            or torch.device(dev).type != "cuda"):
+        return
+    import queue
+    import threading
+    if _worker is None or not _worker[0].is_alive():
+        jobs = queue.SimpleQueue()
+        th = threading.Thread(target=_worker_loop, args=(jobs,), daemon=True, name="pygda-amd-mmd-draws")
+        th.start()
+        _worker = (th, jobs)
+    stream = torch.cuda.current_stream(dev)
+    box, done = {}, threading.Event()
+    _worker[1].put((ns, nt, times, sampling_num, dev, stream, box, done))
+    _prefetched = (ns, nt, times, sampling_num, str(torch.device(dev)), done, box)
 
 
 def _take_prefetched(ns, nt, times, sampling_num, dev):
@@ -73,7 +89,7 @@ def _take_prefetched(ns, nt, times, sampling_num, dev):
     hit, _prefetched = _prefetched, None
     if hit is None:
         return None
-    hit[5].join()
+    hit[5].wait()
     if "err" in hit[6]:
         raise hit[6]["err"]
     if hit[:5] != (ns, nt, times, sampling_num, str(torch.device(dev))):

@@ -43,6 +43,12 @@ def main():
     os.makedirs(a.out, exist_ok=True)
     lines = [f"# rocprofv3 summary `{a.tag}`", ""]
     result = {"tag": a.tag}
+    try:                  # the library the profiled command loaded: bench.py quotes this summary's durations beside its own
+        import hashlib    # live ones and says so when the hashes differ
+        lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pygda_amd", "libgda_hip.so")
+        result["library_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+    except Exception:
+        result["library_sha16"] = None
     if a.bench and os.path.exists(a.bench):
         txt = [l for l in open(a.bench).read().splitlines() if l.startswith("{")]
         if txt:
