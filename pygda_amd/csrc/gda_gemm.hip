@@ -449,6 +449,7 @@ k_skinny_dgrad(const float* __restrict__ GY, int64_t ldg, const float* __restric
 #pragma unroll
     for (int n = 0; n < SK_N; ++n)
         w[n] = n < N ? *reinterpret_cast<const float4*>(W + (int64_t)n * ldw + 4 * p) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
     for (int64_t row = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / pieces; row < M;
          row += (int64_t)gridDim.x * rows_per_block) {
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -473,6 +474,9 @@ k_skinny_wgrad(const float* __restrict__ GY, int64_t ldg, const float* __restric
     float cs[SK_N];
 #pragma unroll
     for (int n = 0; n < SK_N; ++n) { acc[n] = make_float4(0.f, 0.f, 0.f, 0.f); cs[n] = 0.f; }
+    // four rows' loads in flight per lane (same accumulation order): one row at a time left every iteration waiting for
+    // its own loads -- 55-118 us for an 80 MB operand at 157 k rows
+#pragma unroll 4
     for (int64_t row = r0 + rl; row < r1; row += rlanes) {
         const float4 v = *reinterpret_cast<const float4*>(X + row * ldx + 4 * p);
 #pragma unroll
