@@ -216,6 +216,11 @@ def hbm_regime_probe(device, nodes=5_000_000, avg_degree=20, d=128, iters=5):
            "traffic": traffic, "traffic_source": src_file, "avg_launch_us": us, "launches": iters,
            "algorithmic_bytes_per_launch": alg, "gather_model_bytes_per_launch": gather,
            "gather_model_GBs": gather / us / 1e3, "gather_model_frac": gather / us / 1e3 / HBM_PEAK_GBS,
+           "traffic_over_algorithmic": (traffic / alg) if traffic else None,
+           "what_the_waste_is": "uniform random neighbours share nothing: every one of the nnz neighbour rows is a distinct "
+                                "512-byte read (the gather model), ten Infinity Caches of feature rows -- counter traffic "
+                                "equals the gather model to 0.3 %, i.e. the kernel runs at the memory system's limit on "
+                                "9.6 x the algorithmic bytes",
            "timing": "HIP events on the launch stream, same process, after the timed region"}
     out["rmat_2^22"] = rmat_probe(device, d, iters)
     return out
@@ -233,10 +238,16 @@ def rmat_probe(device, d=128, iters=5):
     ei = rmat_edges(22, 32_000_000, gen)
     ei = torch.cat([ei, ei.flip(0)], dim=1)
     res = {}
-    for name in ("as_generated", "degree_sorted"):
-        if name == "degree_sorted":
-            from pygda_amd.data import degree_order
-            ei = degree_order(ei, n)[ei]
+    from pygda_amd.data import Data, auto_reorder
+    for name in ("as_generated", "trainer_default"):
+        if name == "trainer_default":
+            # what A2GNN.fit() trains on BY DEFAULT for a full-batch graph of this size and skew: the loader applies
+            # data.auto_reorder (degree-ordered relabelling, predict() maps the rows back) -- no opt-in by the caller
+            probe = Data(x=torch.empty(n, 1, device=device), edge_index=ei, y=None)
+            relabelled, new_id = auto_reorder(probe)
+            res["trainer_default_reorders"] = new_id is not None
+            ei = relabelled.edge_index
+            del probe, relabelled, new_id
         G = build_csr(ei, n, validate=False)
         x = torch.randn(n, d, device=device, generator=gen)
         for _ in range(2):
@@ -250,7 +261,14 @@ def rmat_probe(device, d=128, iters=5):
         torch.cuda.synchronize()
         us = s.elapsed_time(e) * 1e3 / iters
         alg = G.nnz * 8 + (n + 1) * 4 + 2 * n * d * 4
-        res[name] = {"avg_launch_us": us, "nnz": G.nnz, "algorithmic_GBs": alg / us / 1e3, "frac": alg / us / 1e3 / HBM_PEAK_GBS}
+        gather = G.nnz * (8 + 4 * d) + n * d * 4          # the no-reuse gather model: every neighbour row a distinct read
+        res[name] = {"avg_launch_us": us, "nnz": G.nnz, "algorithmic_GBs": alg / us / 1e3, "frac": alg / us / 1e3 / HBM_PEAK_GBS,
+                     "gather_model_over_algorithmic": gather / alg, "gather_model_GBs": gather / us / 1e3}
+        # counter traffic of the same aggregation from the committed PMC passes (tools/rmat_pmc_case.py under separate
+        # --pmc FETCH_SIZE / WRITE_SIZE runs): how much of the gather model the caches absorb on a skewed graph
+        traffic, tfile = pmc_traffic("k_spmm<32, 4", "r[0-9]*_rmat_" + ("asgen" if name == "as_generated" else "reorder") + "*_summary.json")
+        if traffic:
+            res[name].update(traffic_bytes_per_launch=traffic, traffic_source=tfile, traffic_over_algorithmic=traffic / alg)
         del G, x
         torch.cuda.empty_cache()
     return res

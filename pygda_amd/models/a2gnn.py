@@ -37,6 +37,9 @@ class A2GNN(BaseGDA):
         # (profiles/r4_stream_experiments.txt); eager launches, so none of the forked-graph scheduling of DESIGN 4.7
         self.overlap_sampled = os.environ.get("PYGDA_AMD_SAMPLED_OVERLAP", "1") == "1"
         self.features_first = os.environ.get("PYGDA_AMD_FEATURES_FIRST", "1") == "1"
+        # the step reads nothing but the loaders' batches: a large power-law full-batch graph may be trained on its
+        # degree-ordered relabelling (pygda_amd/data.py::auto_reorder; predict() maps the rows back)
+        self._auto_reorder_ok = type(self) is A2GNN
 
     def init_model(self, **kwargs):
         return A2GNNBase(in_dim=self.in_dim, hid_dim=self.hid_dim, num_classes=self.num_classes,

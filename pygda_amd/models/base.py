@@ -70,9 +70,13 @@ class BaseGDA(ABC):
         else:
             sb = tb = self.batch_size
         full = self.batch_size == 0
-        kw = {} if full else dict(dist, device=self.device, full_batch=False if self.force_sampler else None)
+        kw = (dict(auto_reorder=bool(getattr(self, "_auto_reorder_ok", False))) if full else
+              dict(dist, device=self.device, full_batch=False if self.force_sampler else None))
         self.source_loader = NeighborLoader(source_data, self.num_neigh, batch_size=sb, **kw)
         self.target_loader = NeighborLoader(target_data, self.num_neigh, batch_size=tb, **kw)
+        from ..utils import mmd as _mmd
+        maps = tuple(None if l.new_id is None else l.new_id.cpu() for l in (self.source_loader, self.target_loader))
+        _mmd.row_maps = maps if any(m is not None for m in maps) else None      # MMD draws stay in the caller's numbering
 
     def _graph_loaders(self, source_data, target_data):
         """``mode='graph'`` (a2gnn.py:278-286, the same block in grade.py:244-252, udagcn.py:248-256, adagcn.py:244-252,
@@ -308,7 +312,12 @@ class BaseGDA(ABC):
                 k = getattr(batch, "batch_size", None)
                 outs.append(out if k is None else out[:k])
                 labs.append(batch.y if k is None else batch.y[:k])
-        return torch.cat(outs), torch.cat(labs)
+        out, lab = torch.cat(outs), torch.cat(labs)
+        new_id = getattr(loader, "new_id", None)
+        if new_id is not None:                   # the loader trains on a degree-ordered relabelling (data.auto_reorder):
+            new_id = new_id.to(out.device)       # row new_id[i] of its batch is node i of the caller's numbering
+            out, lab = out[new_id], lab[new_id]
+        return out, lab
 
 
 _gc_frozen = False

@@ -182,6 +182,7 @@ class DeviceNeighborSampler:
             raise IndexError(f"edge_index values must lie in [0, {N}): {bad} edges do not")
         self._ws = {}
         self._layouts = {}
+        self._warmed = set()
 
     def _caps(self, n_seeds, fanouts):
         fan = np.ascontiguousarray(np.asarray(fanouts, dtype=np.int32))
@@ -250,6 +251,15 @@ class DeviceNeighborSampler:
         seeds_d = seeds_t.to(dev, torch.int64, non_blocking=True).contiguous()
         p = _PendingBatch()
         p.n_seeds, p.stream, p.short_rows = int(seeds_d.numel()), stream, short_rows
+        warm = (stream.cuda_stream, total)
+        if warm not in self._warmed:
+            # the caching allocator keeps its pools per stream and hands a block back only after the streams that used it
+            # have passed the point of its release: with the device a step or two behind the host a loader needs more
+            # blocks than it holds batches.  Eight of them are put into this stream's pool once, so that no hipMalloc
+            # (tens of milliseconds for a block of this size) falls into a training step later
+            self._warmed.add(warm)
+            spare = [torch.empty(total, dtype=torch.uint8, device=dev) for _ in range(8)]
+            del spare
         block = torch.empty(total, dtype=torch.uint8, device=dev)
         base = block.data_ptr()
 

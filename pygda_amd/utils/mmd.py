@@ -28,6 +28,20 @@ def get_MMD(source_feat, target_feat, kernel_mul=2.0, kernel_num=5, fix_sigma=No
 # Optional source of the row samples: a callable (n_src, n_tgt, times, sampling_num) -> two device
 # int64 tensors.  The hipGraph-captured training step installs one that hands out STATIC device
 # buffers which it refills (from the same CPU-generator draws) before every replay.
+# (source map, target map) or None: full-batch loaders that train on a degree-ordered relabelling of a large power-law
+# graph (pygda_amd/data.py::auto_reorder) -- the draws below are made in the CALLER's node numbering, exactly as the
+# reference makes them (mmd.py:148-149), and mapped to the rows those nodes occupy in the relabelled batch
+row_maps = None
+
+
+def apply_row_maps(source_sample, target_sample):
+    """In place: node ids of the caller's numbering -> rows of the (possibly relabelled) batch."""
+    if row_maps is not None:
+        for sample, m in ((source_sample, row_maps[0]), (target_sample, row_maps[1])):
+            if m is not None:
+                sample.copy_(m[sample])
+
+
 sample_provider = None
 dp_index_provider = None       # data-parallel branch: (n_src, n_tgt, times, per) -> (idx_s, idx_t, sel_s, sel_t)
 
@@ -58,6 +72,7 @@ def _worker_loop(jobs):
             with torch.cuda.device(dev), torch.cuda.stream(stream):
                 s_cpu = torch.randint(ns, (times, sampling_num))
                 t_cpu = torch.randint(nt, (times, sampling_num))
+                apply_row_maps(s_cpu, t_cpu)
                 from ..ops import mmd_samples_to_device
                 box["out"] = mmd_samples_to_device(s_cpu, t_cpu, ns, nt, torch.device(dev))
         except BaseException as exc:          # surfaced by the consumer
@@ -122,6 +137,7 @@ def MMD(source_feat, target_feat, sampling_num=1000, times=5, *, scale=1.0, add=
             s_idx, t_idx, sel_s, sel_t = dp_index_provider(ns, nt, times, per)
         else:
             s_cpu, t_cpu = torch.randint(ns, (times, per)), torch.randint(nt, (times, per))
+            apply_row_maps(s_cpu, t_cpu)
             if dev.type == "cuda":      # one pinned block, one asynchronous copy (pageable .to() calls drain the stream)
                 from ..ops import mmd_samples_to_device
                 s_idx, t_idx, sel = mmd_samples_to_device(s_cpu, t_cpu, ns, nt, dev, stacked=False)
@@ -148,6 +164,7 @@ def MMD(source_feat, target_feat, sampling_num=1000, times=5, *, scale=1.0, add=
         return mmd_loss(source_feat, target_feat, s_idx, t_idx, sel=sel, scale=scale, add=add)
     source_sample = torch.randint(source_feat.size(0), (times, sampling_num))
     target_sample = torch.randint(target_feat.size(0), (times, sampling_num))
+    apply_row_maps(source_sample, target_sample)
     from ..ops import mmd_samples_to_device
     s_idx, t_idx, sel = mmd_samples_to_device(source_sample, target_sample, source_feat.size(0), target_feat.size(0), dev)
     return mmd_loss(source_feat, target_feat, s_idx, t_idx, sel=sel, scale=scale, add=add)

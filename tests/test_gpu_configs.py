@@ -249,6 +249,48 @@ def test_two_rank_udagcn_adagcn_step_equals_concatenated_batch_gpu(kind):
             close(results[0]["disc10"][k], v, rtol=1e-3, atol=1e-4)
 
 
+def test_auto_reorder_trains_the_same_model_and_predict_maps_the_rows_back(monkeypatch):
+    """data.auto_reorder: a full-batch A2GNN fit on a large power-law graph runs on the
+    degree-ordered relabelling without the caller asking -- here with the size threshold lowered to a 3,000-node Zipf
+    graph.  The relabelled run is the SAME training run: MMD draws are made in the caller's numbering and mapped
+    (utils.mmd.row_maps), predict() returns rows in the caller's order; against the run with the reordering switched
+    off: per-epoch losses 1e-4 relative, logits 1e-4, labels and label order identical."""
+    from pygda_amd import data as D
+    from pygda_amd.utils import mmd as M
+    g = torch.Generator().manual_seed(3)
+    n, f = 3000, 24
+
+    def domain(seed, shift):
+        gg = torch.Generator().manual_seed(seed)
+        w = torch.arange(1, n + 1, dtype=torch.float64).pow(-1.0)
+        src = torch.randint(0, n, (40_000,), generator=gg)
+        dst = torch.multinomial(w, 40_000, True, generator=gg)
+        ei = D.to_undirected(torch.stack([src, dst]), n)
+        return Data(x=torch.randn(n, f, generator=gg) + shift, edge_index=ei, y=torch.randint(0, 4, (n,), generator=gg))
+
+    src, tgt = domain(11, 0.0), domain(12, 0.3)
+    runs = {}
+    for on in (True, False):
+        monkeypatch.setattr(D, "AUTO_REORDER", on)
+        monkeypatch.setattr(D, "AUTO_REORDER_MIN_NODES", 1000)
+        monkeypatch.setattr(D, "AUTO_REORDER_SKEW", 8.0)
+        m = pygda_amd.models.A2GNN(f, 32, 4, num_layers=2, dropout=0.0, s_pnums=0, t_pnums=5, weight=10, lr=0.01,
+                                   weight_decay=0.005, device=DEV, epoch=3, verbose=0, use_hip_graph=on)
+        seen = []
+        m.epoch_hook = lambda e, loss, acc, secs: seen.append(loss)
+        torch.manual_seed(9)
+        m.fit(src, tgt)
+        assert (m.target_loader.new_id is not None) == on and (M.row_maps is not None) == on
+        logits, labels = m.predict(tgt)
+        runs[on] = (seen, logits, labels)
+        exact(labels, tgt.y)                                  # the caller's order
+    close(runs[True][0], runs[False][0], rtol=REL)
+    close(runs[True][1], runs[False][1], rtol=0, atol=LOGIT_ATOL)
+    exact(runs[True][1].argmax(1), runs[False][1].argmax(1))
+    monkeypatch.undo()
+    M.row_maps = None
+
+
 def test_data_parallel_mmd_estimator_has_the_single_process_mean():
     """The data-parallel MMD (pygda_amd/utils/mmd.py: every rank draws sampling_num / W rows per resample from ITS OWN
     batch, the rows are all-gathered and every rank evaluates the statistic on the gathered 1000 + 1000 rows) against the

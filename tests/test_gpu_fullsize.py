@@ -158,6 +158,46 @@ def test_cfg_a_full_size_fit_captured_vs_eager_vs_oracle(monkeypatch):
     exact(labels_e, tgt.y)
 
 
+def test_cfg_a_one_pass_mmd_is_not_worse_than_two_pass_after_training(monkeypatch):
+    """the one-pass MMD (split-fp16 MFMAs, csrc/gda_mmd_fused.inc) against the two-pass fp32-MFMA
+    kernels AFTER training, over three stand-in seeds: three Adam steps of the full-size cfg-A fit with each kernel path,
+    both measured against the CPU oracle's loop on the same inputs (same init stream, same MMD draws).  Round 4 only
+    PRINTED the share of logits beyond 1e-4 (seed 200: 4.7 % one-pass against 0.14 % two-pass; seed 201: 54.6 % / 54.8 %)
+    and called it a lottery on which near-zero gradient entries change sign under Adam's sign-like first steps.  If that
+    is what it is, the one-pass path must not be SYSTEMATICALLY further from the oracle: averaged over the seeds its
+    largest logit deviation and its RMS deviation stay within 1.5 x the two-pass path's (a floor of 5e-5 / 1e-5 keeps a
+    near-perfect two-pass seed from turning the ratio into noise), no single seed beyond 3 x, and both paths keep the
+    1e-3 bound of the trajectory test."""
+    from bench import make_cfg_a
+    rows = []
+    for seed in (200, 201, 202):
+        src, tgt = make_cfg_a(seed=seed)
+        torch.manual_seed(5)
+        ora = O.A2GNNBase(src.x.size(1), 128, 5, num_layers=2, dropout=0.0)
+        opt = torch.optim.Adam(ora.parameters(), lr=HP["lr"], weight_decay=HP["weight_decay"])
+        s, t = O.Graph(src.x, src.edge_index, src.y), O.Graph(tgt.x, tgt.edge_index, tgt.y)
+        for _ in range(3):
+            O.a2gnn_train_step(ora, opt, s, t, 0.0, HP["s_pnums"], HP["t_pnums"], False, HP["weight"], _mmd_chunk())
+        ora.eval()
+        with torch.no_grad():
+            want = ora(t, HP["t_pnums"])
+        dev = {}
+        for one_pass in (True, False):
+            monkeypatch.setattr(ops, "MMD_ONE_PASS", one_pass)
+            _, _, logits, _ = _fit(src, tgt, False)
+            d = (logits.cpu() - want).abs()
+            dev[one_pass] = (float(d.max()), float(d.pow(2).mean().sqrt()), float((d > LOGIT_ATOL).float().mean()))
+            assert dev[one_pass][0] <= 1e-3, (seed, one_pass, dev[one_pass])
+        monkeypatch.undo()
+        rows.append((seed, dev[True], dev[False]))
+        print(f"seed {seed}: one-pass max {dev[True][0]:.2e} rms {dev[True][1]:.2e} share>1e-4 {dev[True][2]:.4f} | "
+              f"two-pass max {dev[False][0]:.2e} rms {dev[False][1]:.2e} share>1e-4 {dev[False][2]:.4f}")
+        assert dev[True][0] <= 3.0 * max(dev[False][0], 5e-5), rows[-1]
+    mean = lambda k, which: sum(r[which][k] for r in rows) / len(rows)
+    assert mean(0, 1) <= 1.5 * max(mean(0, 2), 5e-5), rows             # largest deviation, averaged over the seeds
+    assert mean(1, 1) <= 1.5 * max(mean(1, 2), 1e-5), rows             # RMS deviation, averaged over the seeds
+
+
 def test_cfg_s_full_size_aggregation_properties():
     """configs[4]: one domain at its full size -- 5 M nodes, 100 M directed edges + self loops, d = 128."""
     n, deg, d = 5_000_000, 20, 128
