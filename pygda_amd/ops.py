@@ -236,7 +236,9 @@ def _launch_kstep_interior(graph, x, K, bias, transposed, y):
         ctx = profiler.region("", 0)
     if plan is not None:
         # ONE launch for the K steps (csrc/gda_interior.inc): 3 launches per call forward, 4 transposed, whatever K is
-        nbytes = L.gda_interior_kstep_lds_workspace_bytes(n_int, d)
+        # sized for the LARGEST interior block the kernel takes, not for this batch's: a scratch that grows with every
+        # record-size batch is a hipMalloc (tens of milliseconds) in the middle of a training step
+        nbytes = L.gda_interior_kstep_lds_workspace_bytes(_interior_lds_limits()[0], d)
         ws = _lib.workspace(nbytes, x.device, "interior_lds")
         with ctx:
             _lib.check(L.gda_interior_kstep_lds_f32(_lib.ptr(rp), _lib.ptr(ci), _lib.ptr(va), n, n_int, d, int(K),
