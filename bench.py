@@ -321,15 +321,22 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
     it = zip(iter(model.source_loader), iter(model.target_loader))
     from pygda_amd.models.base import _allreduce_grads
 
+    phases = []              # per step: host seconds in (loader hand-over, forward, backward, exchange + optimiser)
+
     def one_step():
+        h0 = time.perf_counter()
         s, t = next(it)
+        h1 = time.perf_counter()
         ops.dropout_state.next_step(s.x.device)
         net.train()
         loss, _ = step_fn(s, t, 0.0, 0)
+        h2 = time.perf_counter()
         optimizer.zero_grad()
         loss.backward()
+        h3 = time.perf_counter()
         _allreduce_grads(optimizer)
         optimizer.step()
+        phases.append((h1 - h0, h2 - h1, h3 - h2, time.perf_counter() - h3))
         return loss
 
     def sync():
@@ -345,6 +352,7 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
         one_step()
     ops.aggregation_log = []
     sync()
+    phases.clear()
     gc.disable()                 # a generation-2 pass of the cyclic collector is milliseconds; the steps are 3 ms
     ms0 = torch.cuda.memory_stats(dev)
     allocs0 = ms0.get("num_device_alloc", 0)
@@ -362,6 +370,13 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
     # ... and how much of it the training thread spent ON a core: the rest is waiting (the interpreter lock held by the
     # loaders' producer threads / the MMD helper, a full launch queue, the loader's queue)
     host_cpu_ms = [1e3 * (b - a) for a, b in zip([c0] + cpu_marks[:-1], cpu_marks)]
+    timed_phases = phases[:args.steps]
+    worst = max(range(len(timed_phases)), key=lambda i: sum(timed_phases[i])) if timed_phases else None
+    med = lambda k: sorted(p[k] for p in timed_phases)[len(timed_phases) // 2] * 1e3
+    host_phases = None if worst is None else {
+        "median_ms": {"loader": med(0), "forward": med(1), "backward": med(2), "exchange_optimiser": med(3)},
+        "slowest_step": {"index": worst, "loader": 1e3 * timed_phases[worst][0], "forward": 1e3 * timed_phases[worst][1],
+                         "backward": 1e3 * timed_phases[worst][2], "exchange_optimiser": 1e3 * timed_phases[worst][3]}}
     ms1 = torch.cuda.memory_stats(dev)
     device_allocs = ms1.get("num_device_alloc", 0) - allocs0   # hipMalloc calls inside the region
     if os.environ.get("PYGDA_AMD_BENCH_ALLOC_DEBUG") == "1":
@@ -480,6 +495,7 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                        "edges_aggregated_per_step": edges / args.steps, "final_loss": float(loss.detach()),
                        "host_ms_per_step_max_median": [max(host_ms), sorted(host_ms)[len(host_ms) // 2]],
                        "host_cpu_ms_per_step_median": sorted(host_cpu_ms)[len(host_cpu_ms) // 2],
+                       "host_phases": host_phases,
                        "hipMalloc_calls_in_timed_region": device_allocs,
                        "aggregation_launches_per_step": sum(prof[k]["launches"] for k in agg) / prof_steps,
                        "aggregation_paths": {k: prof[k]["launches"] / prof_steps for k in sorted(agg)},

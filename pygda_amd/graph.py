@@ -29,6 +29,16 @@ class RowSplit:
         bounds and the kernels pick up the live counts from device memory -- for graphs that live one
         step, where a sync per graph would drain the queue every mini-batch."""
         dev = rowptr.device
+        self.threshold, self.counts, self._scratch = threshold, None, {}
+        if not deferred and num_rows > 0:
+            # a static matrix whose longest row is within 2 x the threshold gains nothing from chunking (a 131-entry row
+            # beside 128-entry ones is no load imbalance) and pays for it with the chunk reduce launch on every call --
+            # the bag-of-words transpose of the cfg-A stand-ins (rows ~ Binomial(9360, 0.01): longest ~131) was split
+            # for a handful of such rows; whole rows also keep the sequential, CPU-order sums
+            longest = int((rowptr[1:num_rows + 1] - rowptr[:num_rows]).max())
+            if longest <= 2 * threshold:
+                self.n_long = self.n_chunks = 0
+                return
         cap_long = nnz_cap // threshold + 1
         cap_chunks = 2 * (nnz_cap // threshold) + 2
         i32 = dict(dtype=torch.int32, device=dev)
@@ -42,13 +52,11 @@ class RowSplit:
                                          _lib.ptr(self.long_chunk_ptr), _lib.ptr(self.chunk_long),
                                          _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream()),
                    "gda_row_split_build")
-        self.threshold = threshold
         self.counts = counts if deferred else None
         if deferred:
             self.n_long, self.n_chunks = cap_long, cap_chunks
         else:
             self.n_long, self.n_chunks = (int(v) for v in counts.tolist())   # one sync per graph
-        self._scratch = {}                 # per stream: concurrent streams must not share partials
 
     def struct(self, d):
         """The C struct for a width-``d`` call (scratch grown on demand), or None without hubs."""
