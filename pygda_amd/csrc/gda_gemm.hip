@@ -677,7 +677,9 @@ extern "C" int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, cons
 //   TN  C[M, N] = A[rows, M]^T B[rows, N]        M <= 8, N in {32, 64, 128, 256}, K = rows; colsum[M] = A's column sums
 // 16-byte aligned operands with leading dimensions % 4 == 0 where rows are read in 16-byte pieces.
 // GDA_E_UNSUPPORTED outside that envelope.
-static int64_t skinny_slabs(int64_t rows) { return min((int64_t)512, max((int64_t)1, rows / 256)); }
+// row slabs of the weight gradient: >= 64 rows each, at most 512 (at citation size -- 9,360 rows -- 146 workgroups instead
+// of the 36 that 256-row slabs would leave on 256 CUs)
+static int64_t skinny_slabs(int64_t rows) { return min((int64_t)512, max((int64_t)1, rows / 64)); }
 
 extern "C" size_t gda_gemm_skinny_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
     if (mode != GDA_GEMM_TN || M <= 0 || M > SK_N || K <= 0) return 0;

@@ -106,23 +106,32 @@ def gemm_raw(mode, M, N, K, a, lda, b, ldb, c, ldc, name="dense_projection"):
 TALL_ROWS = int(_os.environ.get("PYGDA_AMD_TALL_GEMM_ROWS", "32768"))    # node counts from here on: the tall kernels
 
 
+TALL_WGRAD_ROWS = int(_os.environ.get("PYGDA_AMD_TALL_WGRAD_ROWS", str(TALL_ROWS)))
+
+
 def _tall_shape(mode, M, N, K, a, b):
     """The envelope of gda_gemm_tall_f32 (csrc/gda_gemm.hip): sampled sub-graphs (10^5 rows and more) against a weight
     whose extents are 128 or 256."""
     if mode == GEMM_TN:          # gW = gy^T x: `a` = gy [rows, 128], reduction over the rows; 16-byte row loads of both
-        return (M == 128 and N in (128, 256) and K >= TALL_ROWS and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+        return (M == 128 and N in (128, 256) and K >= TALL_WGRAD_ROWS and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
     return M >= TALL_ROWS and N in (128, 256) and K in (128, 256) and a.data_ptr() % 16 == 0
 
 
+SKINNY_ROWS = int(_os.environ.get("PYGDA_AMD_SKINNY_GEMM_ROWS", "2048"))   # the classifier projection's vector kernels from here on
+
+
 def _skinny_shape(mode, M, N, K, a, b, c_ld):
-    """The envelope of gda_gemm_skinny_f32: the classifier projection (at most 8 classes) at sampled-batch row counts."""
+    """The envelope of gda_gemm_skinny_f32: the classifier projection (at most 8 classes).  Round 5: from citation size
+    on, not only at sampled-batch row counts -- a 64 x 64 matrix-core tile is 92 % padding for 5 classes, and on the
+    64 x 64-tile kernel the classifier's weight gradient (9,360 rows -> a 5 x 128 result) was a 22 us kernel on the tail of
+    the cfg-A step."""
     wide = (32, 64, 128, 256)
     al = lambda t: t.data_ptr() % 16 == 0
     if mode == GEMM_NT:
-        return M >= TALL_ROWS and N <= 8 and K in wide and al(a)
+        return M >= SKINNY_ROWS and N <= 8 and K in wide and al(a)
     if mode == GEMM_NN:
-        return M >= TALL_ROWS and K <= 8 and N in wide and al(b)
-    return K >= TALL_ROWS and M <= 8 and N in wide and al(b)
+        return M >= SKINNY_ROWS and K <= 8 and N in wide and al(b)
+    return K >= SKINNY_ROWS and M <= 8 and N in wide and al(b)
 
 
 def gemm(mode, a, b, bias=None, colsum=None):
