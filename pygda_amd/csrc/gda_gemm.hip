@@ -17,6 +17,8 @@
 //                                      a deterministic split-K)
 #include "gda_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int TB = 256;
@@ -312,6 +314,8 @@ k_tall_fwd16(const float* __restrict__ A, int64_t lda, const float* __restrict__
 #undef TF_FETCH
 #undef TF_STASH
 }
+
+#include "gda_gemm_split.inc"
 
 template <int NT8>
 __global__ void __launch_bounds__(TALL_TB, 1)
@@ -650,6 +654,28 @@ extern "C" int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, cons
     if ((N != 128 && N != 256) || (K != 128 && K != 256) || lda < K || lda % 4 || ((uintptr_t)A & 15)) return GDA_E_UNSUPPORTED;
     if (mode == GDA_GEMM_NT ? ldb < K : ldb < N) return GDA_E_SIZE;
     if (bias && mode != GDA_GEMM_NT) return GDA_E_UNSUPPORTED;
+    // forward / data gradient on the 16-bit matrix cores with split operands (gda_gemm_split.inc): the default
+    static const bool split16 = [] { const char* e = std::getenv("PYGDA_AMD_GEMM_SPLIT_F16"); return !(e && e[0] == '0'); }();
+    if (split16) {
+        const int64_t bm = K == 128 ? 128 : 64;
+        const int64_t nt = gda_cdiv(M, bm);
+        const dim3 g((unsigned)min(nt, (int64_t)256), (unsigned)(N / 128));
+        const size_t img = (size_t)bm * (K + 8) * 2;
+        const size_t lds = 4 * img + 2 * (size_t)bm * sizeof(float);
+#define TH_LAUNCH(K_, BT_)                                                                                    \
+    do {                                                                                                      \
+        GDA_LDS_ATTR_ONCE((k_tall_fwd_h<K_, BT_>), 160 * 1024);                                               \
+        k_tall_fwd_h<K_, BT_><<<g, TALL_TB, lds, stream>>>(A, lda, B, ldb, C, ldc, M, bias);                  \
+    } while (0)
+        if (mode == GDA_GEMM_NT) {
+            if (K == 128) TH_LAUNCH(128, false); else TH_LAUNCH(256, false);
+        } else {
+            if (K == 128) TH_LAUNCH(128, true); else TH_LAUNCH(256, true);
+        }
+#undef TH_LAUNCH
+        GDA_LAUNCH_CHECK();
+        return GDA_OK;
+    }
     const int64_t ntiles = gda_cdiv(M, TALL_BM);
     const dim3 grid((unsigned)min(ntiles, (int64_t)256), (unsigned)(N / 128));
     // 64-deep chunks (one barrier per 128 MFMAs of a wave; 32-deep: 186 -> 183 us forward, 201 -> 187 us data gradient
