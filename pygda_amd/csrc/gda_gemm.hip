@@ -656,12 +656,25 @@ extern "C" int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, cons
     if (bias && mode != GDA_GEMM_NT) return GDA_E_UNSUPPORTED;
     // forward / data gradient on the 16-bit matrix cores with split operands (gda_gemm_split.inc): the default
     static const bool split16 = [] { const char* e = std::getenv("PYGDA_AMD_GEMM_SPLIT_F16"); return !(e && e[0] == '0'); }();
-    if (split16) {
+    if (split16 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 && ldb % 4 == 0 && ((uintptr_t)B & 15) == 0) {
+        static const int dbg = [] { const char* e = std::getenv("PYGDA_AMD_GEMM_DBG"); return e ? std::atoi(e) : 0; }();
         const int64_t bm = K == 128 ? 128 : 64;
         const int64_t nt = gda_cdiv(M, bm);
         const dim3 g((unsigned)min(nt, (int64_t)256), (unsigned)(N / 128));
         const size_t img = (size_t)bm * (K + 8) * 2;
         const size_t lds = 4 * img + 2 * (size_t)bm * sizeof(float);
+#define TH_DBG(D_)                                                                                            \
+    do {                                                                                                      \
+        GDA_LDS_ATTR_ONCE((k_tall_fwd_h<128, false, D_>), 160 * 1024);                                        \
+        k_tall_fwd_h<128, false, D_><<<g, TALL_TB, lds, stream>>>(A, lda, B, ldb, C, ldc, M, bias);           \
+        GDA_LAUNCH_CHECK();                                                                                   \
+        return GDA_OK;                                                                                        \
+    } while (0)
+        if (dbg && mode == GDA_GEMM_NT && K == 128) {          // phase-elimination probes (tools/gemm_probe.py): not a product
+            if (dbg == 1) TH_DBG(1); if (dbg == 2) TH_DBG(2); if (dbg == 4) TH_DBG(4); if (dbg == 3) TH_DBG(3);
+            if (dbg == 6) TH_DBG(6); if (dbg == 7) TH_DBG(7);
+        }
+#undef TH_DBG
 #define TH_LAUNCH(K_, BT_)                                                                                    \
     do {                                                                                                      \
         GDA_LDS_ATTR_ONCE((k_tall_fwd_h<K_, BT_>), 160 * 1024);                                               \
