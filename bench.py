@@ -393,6 +393,7 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "profile_run": True}
     # the HIP-event pass below brackets kernel families on their launch stream: with the two branches on two streams an
     # event pair also spans the other stream's kernels, so this pass runs the step on ONE stream
+    timed_loaders = (model.source_loader, model.target_loader)
     model.overlap_sampled = False
     # roofline inputs: a short pass of the same steps with HIP events around every kernel family (the timed
     # region above runs without them)
@@ -496,6 +497,8 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                        "host_ms_per_step_max_median": [max(host_ms), sorted(host_ms)[len(host_ms) // 2]],
                        "host_cpu_ms_per_step_median": sorted(host_cpu_ms)[len(host_cpu_ms) // 2],
                        "host_phases": host_phases,
+                       "producer_cpu_ms_per_batch": [1e3 * getattr(l, "producer_cpu_s", 0.0) / max(getattr(l, "producer_batches", 0), 1)
+                                                     for l in timed_loaders],
                        "hipMalloc_calls_in_timed_region": device_allocs,
                        "aggregation_launches_per_step": sum(prof[k]["launches"] for k in agg) / prof_steps,
                        "aggregation_paths": {k: prof[k]["launches"] / prof_steps for k in sorted(agg)},

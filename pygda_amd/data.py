@@ -307,6 +307,8 @@ class NeighborLoader:
             return
         import queue
         import threading
+        import time
+        self.producer_cpu_s, self.producer_batches = 0.0, 0
         dev = self.data.x.device
         if getattr(self, "_samp_stream", None) is None:
             import os
@@ -324,8 +326,14 @@ class NeighborLoader:
                     for b, seeds in enumerate(batches):
                         if stop.is_set():
                             return
+                        c0 = time.thread_time()
                         p = S.enqueue(seeds, self.num_neighbors, seed=seeds_of(b))
-                        q.put((p, p.wait()))
+                        sizes = p.wait()
+                        # on-core time of this thread per batch: what the training thread may have to wait for when it
+                        # wants the interpreter lock back (bench.py: config.producer_cpu_ms_per_batch)
+                        self.producer_cpu_s += time.thread_time() - c0
+                        self.producer_batches += 1
+                        q.put((p, sizes))
                 q.put(None)
             except BaseException as exc:
                 q.put(exc)
