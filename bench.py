@@ -315,7 +315,7 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
     if world > 1:                # replicas of ONE model (fit() does this in its epoch loop; the generators stay per rank)
         from pygda_amd.distributed import broadcast_parameters
         broadcast_parameters(net)
-    kw = dict(rank=rank, world_size=world, device=dev)
+    kw = dict(rank=rank, world_size=world, device=dev, recycle=True)         # as BaseGDA._node_loaders builds them
     model.source_loader = NeighborLoader(src, fan, batch_size=args.batch, input_nodes=seeds_s, **kw)
     model.target_loader = NeighborLoader(tgt, fan, batch_size=args.batch, input_nodes=seeds_t, **kw)
     it = zip(iter(model.source_loader), iter(model.target_loader))
@@ -359,10 +359,22 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
     t0 = time.perf_counter()
     c0 = time.thread_time()
     marks, cpu_marks = [], []
+    cprof = None
+    if os.environ.get("PYGDA_AMD_BENCH_CPROFILE"):     # experiment: where the training thread's host time goes
+        import cProfile
+        cprof = cProfile.Profile()
+        cprof.enable()
     for _ in range(args.steps):
         loss = one_step()
         marks.append(time.perf_counter())
         cpu_marks.append(time.thread_time())
+    if cprof is not None:
+        cprof.disable()
+        import pstats
+        with open(os.environ["PYGDA_AMD_BENCH_CPROFILE"], "w") as fh:
+            st = pstats.Stats(cprof, stream=fh)
+            st.sort_stats("tottime").print_stats(60)
+            st.sort_stats("cumulative").print_stats(70)
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -499,6 +511,8 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                        "host_phases": host_phases,
                        "producer_cpu_ms_per_batch": [1e3 * getattr(l, "producer_cpu_s", 0.0) / max(getattr(l, "producer_batches", 0), 1)
                                                      for l in timed_loaders],
+                       "producer_enqueue_cpu_ms_per_batch": [1e3 * getattr(l, "producer_enqueue_cpu_s", 0.0) / max(getattr(l, "producer_batches", 0), 1)
+                                                             for l in timed_loaders],
                        "hipMalloc_calls_in_timed_region": device_allocs,
                        "aggregation_launches_per_step": sum(prof[k]["launches"] for k in agg) / prof_steps,
                        "aggregation_paths": {k: prof[k]["launches"] / prof_steps for k in sorted(agg)},

@@ -602,6 +602,30 @@ int gda_dsampler_sample(const int64_t* in_ptr, const int32_t* in_src, int64_t N,
                         int32_t* t_rowptr, int32_t* t_colidx, float* t_val,
                         int64_t* counts, void* workspace, size_t workspace_bytes, gda_stream_t stream);
 
+/* One foreign call per batch for a loader that RECYCLES its batch blocks (round 5; pygda_amd/sampler.py, the producer
+ * thread of pygda_amd/data.py's NeighborLoader -- the reference's NeighborLoader workers, pygda/models/a2gnn.py:260-277):
+ *   [stream waits for wait_event] -> seeds (host OR device, int64 [n_seeds]) copied to seeds_dev -> gda_dsampler_sample
+ *   -> gda_interior_plan_build for both directions when plan_fwd / plan_bwd are given (both or neither; their {q, T} land
+ *   in counts[5:7] / counts[7:9]) -> counts (device int64[12], zeroed first) copied to counts_host (PINNED int64[12]) ->
+ *   [done_event recorded].  Every array may be a block an earlier batch used: wait_event (recorded by the consumer on its
+ *   stream once it has moved on) orders the overwrite.
+ * gda_event_*: plain HIP events without timing, owned by the library, so that neither side of that hand-over builds
+ *   framework objects per batch.  gda_event_synchronize blocks the calling host thread. */
+int gda_event_create(void** event_out);
+int gda_event_destroy(void* event);
+int gda_event_record(void* event, gda_stream_t stream);
+int gda_event_synchronize(void* event);
+int gda_stream_wait_event(gda_stream_t stream, void* event);
+int gda_dsampler_batch(const int64_t* in_ptr, const int32_t* in_src, int64_t N, int64_t E, int64_t max_in_degree,
+                       const int64_t* seeds, int64_t n_seeds, int64_t* seeds_dev,
+                       const int32_t* fanouts_host, int L, uint64_t rng_seed,
+                       int64_t* nodes, int64_t* esrc, int64_t* edst,
+                       int32_t* rowptr, int32_t* colidx, float* val,
+                       int32_t* t_rowptr, int32_t* t_colidx, float* t_val,
+                       int64_t* counts, void* plan_fwd, void* plan_bwd, size_t plan_bytes,
+                       int64_t* counts_host, void* wait_event, void* done_event,
+                       void* workspace, size_t workspace_bytes, gda_stream_t stream);
+
 /* ------------------------------------------------------------------------------
  * Host construction of the PPMI graph (HOST pointers).
  *

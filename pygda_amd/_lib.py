@@ -93,6 +93,13 @@ _SIGNATURES = {
     "gda_dsampler_workspace_bytes": (c_size_t, [c_int64, _P, c_int, c_int64, c_int64, c_int64]),
     "gda_dsampler_sample": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int, ctypes.c_uint64,
                                     _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gda_event_create": (c_int, [_P]),
+    "gda_event_destroy": (c_int, [_P]),
+    "gda_event_record": (c_int, [_P, _P]),
+    "gda_event_synchronize": (c_int, [_P]),
+    "gda_stream_wait_event": (c_int, [_P, _P]),
+    "gda_dsampler_batch": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, c_int64, _P, _P, c_int, ctypes.c_uint64,
+                                   _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, _P, _P, _P, c_size_t, _P]),
     "gda_selection_csr_host": (c_int, [_P, c_int, c_int64, c_int64, c_int64, c_int64, _P, _P]),
     "gda_ppmi_build_host": (c_int, [_P, _P, c_int64, c_int64, c_int, c_int, ctypes.c_uint64,
                                     ctypes.POINTER(c_void_p)]),

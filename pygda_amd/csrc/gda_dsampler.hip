@@ -534,3 +534,70 @@ extern "C" int gda_dsampler_sample(const int64_t* in_ptr, const int32_t* in_src,
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
+
+// ---- one call per batch for a loader that recycles its batch blocks ------------------------------------------------
+// Events the loader's producer and consumer threads order themselves with (plain HIP events, no timing), owned by the
+// library so that a batch costs the producer thread ONE foreign call: no tensor views, no allocator, no event objects
+// under the interpreter lock the training thread is waiting for.
+extern "C" int gda_event_create(void** event_out) {
+    if (!event_out) return GDA_E_NULL;
+    hipEvent_t ev = nullptr;
+    GDA_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    *event_out = (void*)ev;
+    return GDA_OK;
+}
+extern "C" int gda_event_destroy(void* event) {
+    if (!event) return GDA_OK;
+    GDA_HIP_TRY(hipEventDestroy((hipEvent_t)event));
+    return GDA_OK;
+}
+extern "C" int gda_event_record(void* event, gda_stream_t stream) {
+    if (!event) return GDA_E_NULL;
+    GDA_HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return GDA_OK;
+}
+extern "C" int gda_event_synchronize(void* event) {
+    if (!event) return GDA_E_NULL;
+    GDA_HIP_TRY(hipEventSynchronize((hipEvent_t)event));
+    return GDA_OK;
+}
+extern "C" int gda_stream_wait_event(gda_stream_t stream, void* event) {
+    if (!event) return GDA_E_NULL;
+    GDA_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return GDA_OK;
+}
+
+// gda_dsampler_sample + the two interior K-step plans + the counts' trip home, as ONE call on `stream`:
+//   [wait_event] -> seeds (host or device, n_seeds int64) -> seeds_dev -> the batch -> plan_fwd / plan_bwd (both or
+//   neither; counts[5:7] / counts[7:9] <- their {q, T}) -> counts (device int64[12], zeroed first) -> counts_host (pinned
+//   int64[12]) -> [done_event].  The arrays may be a block the caller overwrote before: wait_event is what makes that safe.
+extern "C" int gda_dsampler_batch(const int64_t* in_ptr, const int32_t* in_src, int64_t N, int64_t E, int64_t max_in_degree,
+                                  const int64_t* seeds, int64_t n_seeds, int64_t* seeds_dev,
+                                  const int32_t* fanouts_host, int L, uint64_t rng_seed,
+                                  int64_t* nodes, int64_t* esrc, int64_t* edst,
+                                  int32_t* rowptr, int32_t* colidx, float* val,
+                                  int32_t* t_rowptr, int32_t* t_colidx, float* t_val,
+                                  int64_t* counts, void* plan_fwd, void* plan_bwd, size_t plan_bytes,
+                                  int64_t* counts_host, void* wait_event, void* done_event,
+                                  void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    if (!counts || !counts_host || (n_seeds > 0 && (!seeds || !seeds_dev))) return GDA_E_NULL;
+    if ((plan_fwd == nullptr) != (plan_bwd == nullptr)) return GDA_E_NULL;
+    if (plan_fwd && !rowptr) return GDA_E_NULL;
+    if (n_seeds < 0) return GDA_E_SIZE;
+    hipStream_t s = (hipStream_t)stream_;
+    if (wait_event) GDA_HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)wait_event, 0));
+    if (n_seeds > 0) GDA_HIP_TRY(hipMemcpyAsync(seeds_dev, seeds, sizeof(int64_t) * (size_t)n_seeds, hipMemcpyDefault, s));
+    GDA_HIP_TRY(hipMemsetAsync(counts, 0, 12 * sizeof(int64_t), s));
+    int st = gda_dsampler_sample(in_ptr, in_src, N, E, max_in_degree, seeds_dev, n_seeds, fanouts_host, L, rng_seed, nodes, esrc,
+                                 edst, rowptr, colidx, val, t_rowptr, t_colidx, t_val, counts, workspace, workspace_bytes, stream_);
+    if (st != GDA_OK) return st;
+    if (plan_fwd) {
+        st = gda_interior_plan_build(rowptr, colidx, val, counts + 4, plan_fwd, plan_bytes, counts + 5, stream_);
+        if (st != GDA_OK) return st;
+        st = gda_interior_plan_build(t_rowptr, t_colidx, t_val, counts + 4, plan_bwd, plan_bytes, counts + 7, stream_);
+        if (st != GDA_OK) return st;
+    }
+    GDA_HIP_TRY(hipMemcpyAsync(counts_host, counts, 12 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    if (done_event) GDA_HIP_TRY(hipEventRecord((hipEvent_t)done_event, s));
+    return GDA_OK;
+}

@@ -134,6 +134,7 @@ def _edge_level(key, v, n, e):
 
 import os as _os
 AUTO_REORDER = _os.environ.get("PYGDA_AMD_AUTO_REORDER", "1") == "1"
+RECYCLE = _os.environ.get("PYGDA_AMD_LOADER_RECYCLE", "1") == "1"      # NeighborLoader(recycle=True) is honoured
 AUTO_REORDER_MIN_NODES = int(_os.environ.get("PYGDA_AMD_AUTO_REORDER_MIN_NODES", str(1 << 20)))
 AUTO_REORDER_SKEW = float(_os.environ.get("PYGDA_AMD_AUTO_REORDER_SKEW", "64"))
 
@@ -174,8 +175,13 @@ class NeighborLoader:
     in-neighbourhoods, seeds first, exactly ``batch.batch_size`` of them."""
 
     def __init__(self, data, num_neighbors, batch_size=1, shuffle=False, input_nodes=None,
-                 rank=0, world_size=1, seed=0, device=None, prefetch=2, full_batch=None, auto_reorder=False, **kwargs):
+                 rank=0, world_size=1, seed=0, device=None, prefetch=2, full_batch=None, auto_reorder=False, recycle=False,
+                 **kwargs):
         self.prefetch = int(prefetch)
+        # sampled batches in a ring of prefetch + 4 blocks written round and round (sampler._Ring: one foreign call per batch
+        # in the producer thread).  Only for consumers that are done with a batch when they take the next one
+        self.recycle = bool(recycle) and RECYCLE
+        self._ring = None
         self.num_neighbors = list(num_neighbors)
         self.batch_size, self.shuffle = int(batch_size), shuffle
         self.rank, self.world_size, self.seed = rank, world_size, seed
@@ -308,7 +314,7 @@ class NeighborLoader:
         import queue
         import threading
         import time
-        self.producer_cpu_s, self.producer_batches = 0.0, 0
+        self.producer_cpu_s, self.producer_batches, self.producer_enqueue_cpu_s = 0.0, 0, 0.0
         dev = self.data.x.device
         if getattr(self, "_samp_stream", None) is None:
             import os
@@ -317,6 +323,12 @@ class NeighborLoader:
             self._samp_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PYGDA_AMD_SAMPLER_PRIORITY", "0")))
         side = self._samp_stream
         side.wait_stream(torch.cuda.current_stream())       # the graph / features may have just been produced
+        ring = None
+        if self.recycle:
+            if self._ring is None:
+                self._ring = S.new_ring(self.prefetch + 4)
+            ring = self._ring
+            ring.reset()          # (the wait above also puts the last pass's batches behind the sampler's stream)
         q, stop = queue.Queue(maxsize=self.prefetch), threading.Event()
 
         def producer():
@@ -327,7 +339,8 @@ class NeighborLoader:
                         if stop.is_set():
                             return
                         c0 = time.thread_time()
-                        p = S.enqueue(seeds, self.num_neighbors, seed=seeds_of(b))
+                        p = S.enqueue(seeds, self.num_neighbors, seed=seeds_of(b), ring=ring)
+                        self.producer_enqueue_cpu_s += time.thread_time() - c0
                         sizes = p.wait()
                         # on-core time of this thread per batch: what the training thread may have to wait for when it
                         # wants the interpreter lock back (bench.py: config.producer_cpu_ms_per_batch)

@@ -71,7 +71,7 @@ class BaseGDA(ABC):
             sb = tb = self.batch_size
         full = self.batch_size == 0
         kw = (dict(auto_reorder=bool(getattr(self, "_auto_reorder_ok", False))) if full else
-              dict(dist, device=self.device, full_batch=False if self.force_sampler else None))
+              dict(dist, device=self.device, full_batch=False if self.force_sampler else None, recycle=True))
         self.source_loader = NeighborLoader(source_data, self.num_neigh, batch_size=sb, **kw)
         self.target_loader = NeighborLoader(target_data, self.num_neigh, batch_size=tb, **kw)
         from ..utils import mmd as _mmd

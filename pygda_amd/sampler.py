@@ -139,16 +139,61 @@ class _PendingBatch:
     """A batch the device sampler has enqueued: capacity-sized device arrays + the event after which the
     counts ({n_nodes, n_edges, nnz, status, n_interior, verdicts of the two interior K-step plans}) are on the host."""
     __slots__ = ("nodes", "ei", "csr", "counts_host", "event", "n_seeds", "stream", "short_rows", "plans", "plan_ok")
+    recycled = False
 
     def wait(self):
         self.event.synchronize()
-        n, e, nnz, status, n_int, ok_f, _, ok_b = (int(v) for v in self.counts_host.tolist()[:8])
+        return self._sizes(self.counts_host.tolist()[:8])
+
+    def _sizes(self, counts):
+        n, e, nnz, status, n_int, ok_f, _, ok_b = (int(v) for v in counts)
         self.plan_ok = (ok_f > 0, ok_b > 0) if self.plans is not None else (False, False)
         if status == 2:
             raise _lib.GdaError("gda_dsampler_sample: a seed lies outside [0, num_nodes)")
         if status != 0:
             raise _lib.GdaError("gda_dsampler_sample: a capacity bound was exceeded (internal error)")
         return n, e, nnz, n_int
+
+
+class _Slot(_PendingBatch):
+    """A pending batch whose block belongs to a loader's ring (:class:`_Ring`) and is written again ``depth`` batches
+    later: the views, the pointers of the one foreign call that fills it and its two events are made ONCE."""
+    __slots__ = ("block", "ring", "done", "free", "freed", "counts_np", "args", "marked")
+    recycled = True
+
+    def wait(self):
+        _lib.check(_lib.lib().gda_event_synchronize(self.done), "gda_event_synchronize")      # off the interpreter lock
+        return self._sizes(self.counts_np[:8])
+
+
+class _Ring:
+    """``depth`` recyclable batch blocks of one loader (one seed count, one fan-out list, one sampler stream).
+
+    Hand-over protocol -- producer thread: batch b goes into slot b % depth; the sampler's stream first waits for the
+    slot's ``free`` event when the consumer has recorded one.  Consumer thread (``DeviceNeighborSampler.assemble``):
+    orders its stream behind the slot's ``done`` event and, having moved on to this batch, records ``free`` of the
+    PREVIOUS slot on its stream -- everything it enqueued for that batch is ahead of that record.  With a queue of
+    ``prefetch`` batches between the two, depth >= prefetch + 3 guarantees the record precedes the slot's reuse
+    (data.py builds prefetch + 4).  The consumer must not read a batch after it has taken the next one from the same
+    loader: the trainers' loops and predict() do not (their outputs and label gathers are new tensors)."""
+
+    def __init__(self, depth):
+        self.depth, self.slots, self.key, self.at, self.last = int(depth), None, None, 0, None
+
+    def reset(self):
+        """A new pass over the loader: the caller has ordered the sampler's stream behind the consumer's."""
+        self.at, self.last = 0, None
+        for s in self.slots or ():
+            s.freed = False
+
+    def __del__(self):
+        try:
+            L = _lib.lib()
+            for s in self.slots or ():
+                L.gda_event_destroy(s.done)
+                L.gda_event_destroy(s.free)
+        except Exception:                 # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 class DeviceNeighborSampler:
@@ -223,6 +268,7 @@ class DeviceNeighborSampler:
                 at += (nbytes + 255) // 256 * 256
 
             take("counts", 12 * 8)
+            take("seeds", max(int(n_seeds), 1) * 8)
             take("nodes", ncap * 8)
             take("ei", 2 * ecap * 8)
             if csr:
@@ -237,11 +283,79 @@ class DeviceNeighborSampler:
             hit = self._layouts[key] = (fan, ncap, ecap, need, off, at, nb)
         return hit
 
-    def enqueue(self, seeds, fanouts, seed=0, csr=True):
-        """Launch the batch on the CURRENT stream; returns a :class:`_PendingBatch`."""
+    def new_ring(self, depth):
+        return _Ring(depth)
+
+    def _make_slots(self, ring, key, layout, stream, csr, plans, short_rows, n_seeds):
+        """The ring's blocks, views, events and argument lists (once per loader)."""
+        fan, ncap, ecap, need, off, total, nb = layout
+        L, dev = _lib.lib(), self.device
+        ws = self._ws.get(stream.cuda_stream)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[stream.cuda_stream] = torch.empty(need, dtype=torch.uint8, device=dev)
+        pinned = torch.empty(ring.depth, 12, dtype=torch.int64).pin_memory()
+        ring._pinned = pinned
+        slots = []
+        for i in range(ring.depth):
+            sl = _Slot()
+            block = sl.block = torch.empty(total, dtype=torch.uint8, device=dev)
+            base = block.data_ptr()
+            at = lambda name: base + off[name][0]
+            view = lambda name, dtype: block[off[name][0]:off[name][0] + off[name][1]].view(dtype)
+            sl.n_seeds, sl.stream, sl.short_rows, sl.ring, sl.event = int(n_seeds), stream, short_rows, ring, None
+            sl.nodes = view("nodes", torch.int64)
+            sl.ei = view("ei", torch.int64).view(2, ecap)
+            names = ("rp", "ci", "va", "trp", "tci", "tva")
+            sl.csr = ((view("rp", torch.int32), view("ci", torch.int32), view("va", torch.float32),
+                       view("trp", torch.int32), view("tci", torch.int32), view("tva", torch.float32))
+                      if csr else (None,) * 6)
+            csr_ptrs = [at(k) for k in names] if csr else [None] * 6
+            sl.plans = (view("plan0", torch.uint8), view("plan1", torch.uint8)) if plans else None
+            sl.plan_ok = (False, False)
+            sl.counts_host = pinned[i]
+            sl.counts_np = pinned[i].numpy()
+            ev = [ctypes.c_void_p(), ctypes.c_void_p()]
+            for e in ev:
+                _lib.check(L.gda_event_create(ctypes.byref(e)), "gda_event_create")
+            sl.done, sl.free, sl.freed, sl.marked = ev[0].value, ev[1].value, False, None
+            # gda_dsampler_batch's arguments; [5] = seeds, [10] = generator seed, [25] = wait_event change per batch
+            sl.args = [_lib.ptr(self.in_ptr), _lib.ptr(self.in_src), self.num_nodes, self.num_edges, self.max_in_degree,
+                       None, int(n_seeds), at("seeds"), fan.ctypes.data, fan.size, None,
+                       at("nodes"), at("ei"), at("ei") + ecap * 8, *csr_ptrs,
+                       at("counts"), at("plan0") if plans else None, at("plan1") if plans else None, nb,
+                       pinned[i].data_ptr(), None, sl.done, _lib.ptr(ws), ws.numel(), stream.cuda_stream]
+            slots.append(sl)
+        ring.slots, ring.key, ring._fan, ring._ws = slots, key, fan, ws
+        return slots
+
+    def _enqueue_slot(self, ring, seeds_t, fanouts, seed, csr, plans, short_rows, stream):
+        """One foreign call: the next slot of the ring, filled on the sampler's stream (None: not this ring's shape)."""
+        key = (stream.cuda_stream, int(seeds_t.numel()), tuple(int(f) for f in fanouts), bool(csr), bool(plans))
+        if ring.slots is None:
+            self._make_slots(ring, key, self._layout(seeds_t.numel(), fanouts, csr, plans), stream, csr, plans, short_rows,
+                             seeds_t.numel())
+        if ring.key != key:
+            return None
+        sl = ring.slots[ring.at % ring.depth]
+        ring.at += 1
+        a = sl.args
+        a[5] = seeds_t.data_ptr()
+        a[10] = ctypes.c_uint64(int(seed) & (2 ** 64 - 1))
+        a[25] = sl.free if sl.freed else None
+        sl.freed = False
+        _lib.check(_lib.lib().gda_dsampler_batch(*a), "gda_dsampler_batch")
+        return sl
+
+    def enqueue(self, seeds, fanouts, seed=0, csr=True, ring=None):
+        """Launch the batch on the CURRENT stream; returns a :class:`_PendingBatch` (``ring``: into the next block of a
+        loader's :class:`_Ring` with one foreign call, when the batch has the ring's shape)."""
         seeds_t = torch.as_tensor(seeds)
         short_rows = len(fanouts) > 0 and min(int(f) for f in fanouts) > 0    # every row holds at most fan-out + 1 entries
         plans = bool(csr and short_rows and INTERIOR_LDS)
+        if ring is not None and seeds_t.dtype == torch.int64 and seeds_t.is_contiguous():
+            sl = self._enqueue_slot(ring, seeds_t, fanouts, seed, csr, plans, short_rows, torch.cuda.current_stream())
+            if sl is not None:
+                return sl
         fan, ncap, ecap, need, off, total, nb = self._layout(seeds_t.numel(), fanouts, csr, plans)
         dev = self.device
         stream = torch.cuda.current_stream()
@@ -336,7 +450,18 @@ class DeviceNeighborSampler:
         """Consumer side (training stream): order behind the sampler's stream, gather the feature rows."""
         n, e, nnz, n_int = sizes if sizes is not None else p.wait()
         cur = torch.cuda.current_stream()
-        if p.stream != cur:
+        if p.recycled:
+            L, ring, h = _lib.lib(), p.ring, cur.cuda_stream
+            _lib.check(L.gda_stream_wait_event(h, p.done), "gda_stream_wait_event")
+            prev = ring.last
+            if prev is not None and prev is not p:       # this stream has moved on from the previous batch: its block may
+                _lib.check(L.gda_event_record(prev.free, h), "gda_event_record")      # be written again behind this point
+                prev.freed = True
+            ring.last = p
+            if p.marked != h:                 # the ring's blocks die with the loader: not before this stream is through
+                p.block.record_stream(cur)
+                p.marked = h
+        elif p.stream != cur:
             cur.wait_event(p.event)
             p.nodes.record_stream(cur)            # ONE block (views share its storage): allocated on the sampler's stream,
                                                   # consumed on this one

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from pygda_amd import _lib
+from pygda_amd import _lib, ops
 from pygda_amd.data import Data, NeighborLoader
 from pygda_amd.graph import build_csr
 from pygda_amd.sampler import DeviceNeighborSampler, NeighborSampler
@@ -131,6 +131,47 @@ def test_loader_on_the_device_sampler_equals_the_host_loader(monkeypatch, prefet
     again = list(dev_loader)
     exact(again[0].n_id[:256], dev_batches[0].n_id[:256])
     assert again[0].n_id.numel() != dev_batches[0].n_id.numel() or not torch.equal(again[0].n_id, dev_batches[0].n_id)
+
+
+@pytest.mark.parametrize("lag", [False, True])
+def test_recycling_loader_hands_out_the_batches_of_the_allocating_loader(lag):
+    """``NeighborLoader(recycle=True)`` (round 5: a ring of prefetch + 4 blocks, one foreign call per batch in the producer
+    thread -- sampler._Ring / gda_dsampler_batch) against the loader that allocates every batch, consumed the way the
+    trainers consume them (done with a batch when the next one is taken): ids, edge list, features, labels, the
+    prebuilt CSR pair, the interior K-step plans and their verdicts, over three times the ring's depth plus a ragged
+    last batch (which takes the allocating path) and a second pass.  ``lag``: the consumer's stream is kept a few
+    milliseconds behind its host thread, so that blocks come round while the device still reads them -- what the
+    ring's ``free`` events order."""
+    n = 60000
+    ei = _graph(n, 600000, 5, loops=True)
+    g = torch.Generator().manual_seed(1)
+    d = Data(x=torch.randn(n, 16, generator=g), edge_index=ei, y=torch.randint(0, 5, (n,), generator=g)).to(DEV)
+    kw = dict(batch_size=512, input_nodes=torch.randint(0, n, (512 * 20 + 100,), generator=g), device=DEV, prefetch=2)
+    fresh, ring = NeighborLoader(d, [5, 4], **kw), NeighborLoader(d, [5, 4], recycle=True, **kw)
+
+    def digest(b):
+        G = b.edge_index._gda_prebuilt
+        parts = [b.n_id.sum(), b.edge_index.sum(), b.x.double().sum(), b.y.sum(), G.rowptr.sum(), G.colidx[:G.nnz].sum(),
+                 G.val[:G.nnz].double().sum(), G.t_rowptr.sum(), G.t_colidx[:G.nnz].sum(), G.t_val[:G.nnz].double().sum()]
+        if G.iplan is not None:               # the plans at work (their unused bytes are not defined): forward and transposed
+            parts.append(ops.spmm_kstep(G, b.x, 3, None).double().sum())
+            parts.append(ops.spmm_kstep(G, b.x, 3, None, transposed=True).double().sum())
+        return torch.stack([p.double() for p in parts]), (b.x.size(0), b.edge_index.size(1), G.nnz, G.n_interior,
+                                                           tuple(pl is not None for pl in (G.iplan or ())))
+
+    for _ in range(2):                       # second pass: the ring is reset and written again
+        want = [digest(b) for b in fresh]
+        got = []
+        for b in ring:
+            if lag:
+                torch.cuda._sleep(3_000_000)            # ~1.5 ms of device time ahead of every read of the batch
+            got.append(digest(b))
+        torch.cuda.synchronize()
+        assert len(want) == len(got) == 21
+        assert ring._ring is not None and ring._ring.depth == 6 and ring._ring.at == 20        # the ragged batch allocates
+        for (a, sa), (b, sb) in zip(want, got):
+            assert sa == sb
+            exact(a, b)
 
 
 @pytest.mark.parametrize("K,d", [(1, 128), (3, 5), (10, 128), (4, 36)])
