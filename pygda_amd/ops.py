@@ -106,9 +106,10 @@ def gemm_raw(mode, M, N, K, a, lda, b, ldb, c, ldc, name="dense_projection"):
 TALL_ROWS = int(_os.environ.get("PYGDA_AMD_TALL_GEMM_ROWS", "32768"))    # node counts from here on: the tall kernels
 
 
-# the weight gradient gy^T x with one workgroup per row slab (k_tall_wgrad) from 8 k rows on: at cfg-A's stacked source rows
-# (18,720) the 64 x 64-tile kernel's 64 slabs took 27 us on the tail of the step, the slab kernel 2 - 3 % off the step
-TALL_WGRAD_ROWS = int(_os.environ.get("PYGDA_AMD_TALL_WGRAD_ROWS", "8192"))
+# the weight gradient gy^T x with one workgroup per row slab (k_tall_wgrad) from 4 k rows on: at cfg-A's stacked source rows
+# (18,720) the 64 x 64-tile kernel's 64 slabs took 27 us on the tail of the step, the slab kernel 2 - 3 % off the step; the
+# target's 5,484 rows give another 2 % (same box, ms/step: 32768 -> 0.4355 / 0.4338, 8192 -> 0.4271 / 0.4348, 4096 -> 0.4252 / 0.4128)
+TALL_WGRAD_ROWS = int(_os.environ.get("PYGDA_AMD_TALL_WGRAD_ROWS", "4096"))
 
 
 def _tall_shape(mode, M, N, K, a, b):
