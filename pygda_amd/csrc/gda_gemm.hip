@@ -568,6 +568,7 @@ extern "C" int gda_gemm_ex_f32(int mode, int64_t M, int64_t N, int64_t K, const 
     if (gx > 65535 || gy > INT32_MAX) return GDA_E_SIZE;          // row tiles ride on grid.x, column tiles on grid.y
     if (K == 0) {
         GDA_HIP_TRY(hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, (size_t)M, stream));
+        if (colsum) GDA_HIP_TRY(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)M, stream));      // an empty sum
         return GDA_OK;
     }
     const bool va = vec_ok(A, lda), vb = vec_ok(B, ldb);

@@ -20,6 +20,7 @@ from .base import BaseGDA
 
 
 import os
+from ..nn.linear import DenseLinear
 
 FUSED_LSGAN = os.environ.get("PYGDA_AMD_FUSED_LSGAN", "1") == "1"
 
@@ -154,8 +155,8 @@ class DANE(BaseGDA):
             self.sample_size = min(len(source_data), len(target_data))                  # :220: number of graphs
         self._loaders(source_data, target_data)
         self.gnn = self.init_model(**self.kwargs)
-        self.domain_discriminator = nn.Sequential(nn.Linear(self.hid_dim, self.hid_dim), nn.ReLU(),
-                                                  nn.Linear(self.hid_dim, 1)).to(self.device)
+        self.domain_discriminator = nn.Sequential(DenseLinear(self.hid_dim, self.hid_dim), nn.ReLU(),
+                                                  DenseLinear(self.hid_dim, 1)).to(self.device)
         self.g_optimizer = torch.optim.Adam(self.gnn.parameters(), lr=self.lr, weight_decay=self.weight_decay)
         self.d_optimizer = torch.optim.Adam(self.domain_discriminator.parameters(), lr=self.lr,
                                             weight_decay=self.weight_decay)

@@ -26,6 +26,7 @@ from ..nn.mixup_base import MixupBase, ShuffledEdges
 from ..nn.reweight_gnn import ReweightGNN
 from ..utils import MMD, logger
 from .base import BaseGDA
+from ..nn.linear import DenseLinear
 
 
 class StruRW(BaseGDA):
@@ -145,7 +146,7 @@ class StruRW(BaseGDA):
                 "handed (strurw.py:487), which a sampled batch does not carry back to the graph")
         self.gnn = self.init_model(**self.kwargs)
         if self.mode == 'adv':
-            self.domain_discriminator = nn.Linear(self.hid_dim, 2).to(self.device)
+            self.domain_discriminator = DenseLinear(self.hid_dim, 2).to(self.device)
             params = itertools.chain(self.gnn.parameters(), self.domain_discriminator.parameters())
         else:
             params = self.gnn.parameters()

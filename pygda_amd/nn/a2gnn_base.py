@@ -6,6 +6,7 @@ from torch import nn
 
 from .prop_gcn_conv import PropGCNConv
 from .reverse_layer import GradReverse
+from .linear import DenseLinear
 
 
 def global_mean_pool(x, batch, size=None):
@@ -26,9 +27,9 @@ class A2GNNBase(nn.Module):
         self.num_layers, self.adv, self.dropout, self.act, self.mode = num_layers, adv, dropout, act, mode
         widths = [in_dim] + [hid_dim] * num_layers
         self.convs = nn.ModuleList(PropGCNConv(a, b) for a, b in zip(widths[:-1], widths[1:]))
-        self.cls = PropGCNConv(hid_dim, num_classes) if mode == "node" else nn.Linear(hid_dim, num_classes)
+        self.cls = PropGCNConv(hid_dim, num_classes) if mode == "node" else DenseLinear(hid_dim, num_classes)
         if adv:
-            self.domain_discriminator = nn.Linear(hid_dim, 2)
+            self.domain_discriminator = DenseLinear(hid_dim, 2)
 
     def second_leaves(self, table):
         """Context manager: inside it the conv layers read their weight / bias through SECOND leaf tensors over the same

@@ -8,6 +8,7 @@ from torch import nn
 from .a2gnn_base import global_mean_pool
 from .gcn_conv import GCNConv
 from .ppmi_conv import PPMIConv
+from .linear import DenseLinear
 
 
 class GNN(nn.Module):
@@ -42,7 +43,7 @@ class AdaGCNBase(nn.Module):
                  mode='node', **kwargs):
         super().__init__()
         self.encoder = GNN(in_dim=in_dim, hid_dim=hid_dim, gnn_type=gnn_type, act=act, num_layers=num_layers)
-        self.cls_model = nn.Sequential(nn.Linear(hid_dim, num_classes))
+        self.cls_model = nn.Sequential(DenseLinear(hid_dim, num_classes))
         self.mode = mode
         self.loss_func = nn.CrossEntropyLoss()
 

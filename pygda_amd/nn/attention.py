@@ -4,12 +4,13 @@ kernels of csrc/gda_attention.hip (no [N, K, h] temporaries); anything else comp
 import torch
 import torch.nn.functional as F
 from torch import nn
+from .linear import DenseLinear
 
 
 class Attention(nn.Module):
     def __init__(self, in_channels):
         super().__init__()
-        self.dense_weight = nn.Linear(in_channels, 1)
+        self.dense_weight = DenseLinear(in_channels, 1)
         self.dropout = nn.Dropout(0.1)     # constructed, never applied -- as in the reference (:26)
 
     def forward(self, inputs):

@@ -14,6 +14,7 @@ from torch import nn
 from .. import sparse_features
 from ..graph import as_graph
 from ..ops import bern_filter
+from .linear import DenseLinear
 
 
 class _InputLinear(nn.Linear):
@@ -29,6 +30,9 @@ class _InputLinear(nn.Linear):
                 return sparse_features.sparse_linear(self.weight, sf, dropout) + self.bias
         if dropout > 0.0:
             x = F.dropout(x, p=dropout, training=True)
+        if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
+            from .linear import tall_linear_bias             # the hand-written matrix-core kernels (no BLAS on the GPU path)
+            return tall_linear_bias(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)
 
 
@@ -61,7 +65,7 @@ class DGSDABase(nn.Module):
     def __init__(self, features, hidden, classes, dprate=0.0, K=15):
         super().__init__()
         self.lin1 = _InputLinear(features, hidden)
-        self.lin2 = nn.Linear(hidden, classes)
+        self.lin2 = DenseLinear(hidden, classes)
         self.prop1 = BernProp(K)
         self.prop2 = BernProp(K)
         self.prop3 = BernProp(K)

@@ -7,6 +7,7 @@ from torch import nn
 from .a2gnn_base import global_mean_pool
 from .gcn_conv import GCNConv
 from .sage_gin_conv import GINConv, SAGEConv
+from .linear import DenseLinear
 
 
 def _make(gnn, a, b):
@@ -15,7 +16,7 @@ def _make(gnn, a, b):
     if gnn == 'sage':
         return SAGEConv(a, b)
     if gnn == 'gin':
-        return GINConv(nn.Sequential(nn.Linear(a, b)), train_eps=True)
+        return GINConv(nn.Sequential(DenseLinear(a, b)), train_eps=True)
     from .gat_conv import GATConv
     return GATConv(a, b, heads=1, concat=False)
 
@@ -29,7 +30,7 @@ class GNNBase(nn.Module):
         self.num_layers, self.dropout, self.gnn, self.act, self.mode = num_layers, dropout, gnn, act, mode
         dims = [in_dim] + [hid_dim] * num_layers
         self.convs = nn.ModuleList(_make(gnn, dims[i], dims[i + 1]) for i in range(num_layers))
-        self.cls = _make(gnn, hid_dim, num_classes) if mode == 'node' else nn.Linear(hid_dim, num_classes)
+        self.cls = _make(gnn, hid_dim, num_classes) if mode == 'node' else DenseLinear(hid_dim, num_classes)
 
     def forward(self, x, edge_index, edge_weight=None, batch=None):
         x = self.feat_bottleneck(x, edge_index, edge_weight)

@@ -6,6 +6,7 @@ from torch import nn
 
 from .a2gnn_base import global_mean_pool
 from .gcn_conv import GCNConv
+from .linear import DenseLinear
 
 
 class GRADEBase(nn.Module):
@@ -16,9 +17,9 @@ class GRADEBase(nn.Module):
         self.num_layers, self.dropout, self.act, self.mode = num_layers, dropout, act, mode
         widths = [in_dim] + [hid_dim] * num_layers
         self.convs = nn.ModuleList(GCNConv(a, b) for a, b in zip(widths[:-1], widths[1:]))
-        self.cls = nn.Linear(hid_dim, num_classes)
+        self.cls = DenseLinear(hid_dim, num_classes)
         feat_width = hid_dim * num_layers + num_classes * (1 if disc == "JS" else 2)
-        self.discriminator = nn.Sequential(nn.Linear(feat_width, 2))
+        self.discriminator = nn.Sequential(DenseLinear(feat_width, 2))
         self.criterion = nn.CrossEntropyLoss()
 
     def forward(self, data):

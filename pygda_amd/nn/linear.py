@@ -1,9 +1,9 @@
 """PyG-style ``Linear`` (weight ``[out, in]``, glorot) used inside the conv layers.
 
-The dense hidden x weight contraction of a node matrix (1024 rows and more, weight extents up to 256) runs on the
-hand-written fp32 matrix-core kernels of csrc/gda_gemm.hip -- 64 x 64 tiles at citation size, the weight-in-registers
-kernels for sampled sub-graphs of 10^5 rows and more; other shapes (tiny row counts, wide weights) go through
-``F.linear``.
+The dense hidden x weight contraction of a node matrix runs on the hand-written fp32 matrix-core kernels of
+csrc/gda_gemm.hip -- 64 x 64 tiles at citation size (any shape: gda_gemm_ex_f32), the weight-in-registers kernels for
+sampled sub-graphs of 10^5 rows and more, the vector kernels for the classifier's few columns.  ``F.linear`` is left to
+host tensors.
 """
 import math
 
@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .. import profiler, sparse_features
+from .. import sparse_features
 
 
 def glorot(t):
@@ -97,9 +97,25 @@ class _TallMatmul(torch.autograd.Function):
         return gx, gw
 
 
+class DenseLinear(nn.Linear):
+    """``torch.nn.Linear`` -- same parameters, same initialisation stream, same state dict -- whose product with a GPU
+    tensor runs on the hand-written matrix-core kernels (bias in the forward epilogue, its gradient beside the weight
+    gradient): the classifier heads and discriminators the reference builds from ``nn.Linear`` (a2gnn_base.py:62-66,
+    grade_base.py:66-70, udagcn_base.py:100-108 ...).  NOT for modules that are differentiated twice (the gradient-penalty
+    critics of specreg.py / adagcn.py keep ``nn.Linear``: this function's backward is not itself differentiable)."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32 and x.dim() >= 1:
+            rows = x.reshape(-1, x.size(-1))
+            y = (_TallLinear.apply(rows, self.weight) if self.bias is None
+                 else _TallLinearBias.apply(rows, self.weight, self.bias))
+            return y if x.dim() == 2 else y.view(*x.shape[:-1], self.out_features)
+        return F.linear(x, self.weight, self.bias)
+
+
 def tall_matmul_ok(x, weight):
-    return (x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
-            and 1024 <= x.size(0) and weight.size(0) <= 256 and weight.size(1) <= 256)
+    """Every 2-D fp32 product on the GPU (round 5: the general entry takes any shape; the BLAS is left to host tensors)."""
+    return x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
 
 
 def tall_matmul(x, weight):
@@ -149,13 +165,13 @@ class Linear(nn.Module):
         if (self.bias is None and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and x.size(0) >= 1024
                 and self.in_channels <= 256 and self.out_channels <= 256):
             return _TallLinear.apply(x, self.weight)          # every row count: ops.gemm picks the kernel by shape
-        if profiler.enabled:
-            n = x.numel() // x.size(-1)
-            with profiler.region(f"dense_projection[{self.in_channels}x{self.out_channels}]", 1,
-                                 4 * (x.numel() + self.weight.numel() + n * self.out_channels),
-                                 2 * n * self.in_channels * self.out_channels):
-                return F.linear(x, self.weight, self.bias)
-        return F.linear(x, self.weight, self.bias)
+        if x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32 and x.dim() >= 1:
+            # every other GPU shape (a bias, fewer than 1024 rows, extents above 256, batched inputs): the same hand-written
+            # kernels through their general 64 x 64-tile entry (gda_gemm_ex_f32 takes any shape) -- no BLAS on the path
+            rows = x.reshape(-1, x.size(-1))
+            y = _TallLinear.apply(rows, self.weight) if self.bias is None else _TallLinearBias.apply(rows, self.weight, self.bias)
+            return y if x.dim() == 2 else y.view(*x.shape[:-1], self.out_channels)
+        return F.linear(x, self.weight, self.bias)              # host tensors (CPU-side tests of the module logic)
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, bias={self.bias is not None})"

@@ -14,6 +14,7 @@ from torch import nn
 
 from ..ops import gather_rows, mixup_combine, mixup_combine_ok
 from .mixup_gcnconv import MixupGraphCache, MixUpGCNConv
+from .linear import DenseLinear
 
 
 class ShuffledEdges:
@@ -38,7 +39,7 @@ class MixupBase(nn.Module):
         self.dropout, self.act, self.rw_lmda = dropout, act, rw_lmda
         self.convs = nn.ModuleList([MixUpGCNConv(in_dim, hid_dim)] +
                                    [MixUpGCNConv(hid_dim, hid_dim) for _ in range(num_layers - 1)])
-        self.cls = nn.Linear(hid_dim, num_classes)
+        self.cls = DenseLinear(hid_dim, num_classes)
         self._graphs = MixupGraphCache()                   # one CSR for all layers (same normalisation)
 
     def forward(self, x, edge_index, edge_index_b, lam, id_new_value_old, edge_weight):

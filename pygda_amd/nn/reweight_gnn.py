@@ -14,6 +14,7 @@ from torch import nn
 from ..graph import build_csr
 from ..ops import propagate
 from .linear import Linear, zeros
+from .linear import DenseLinear
 
 
 class _ReweightedGraphCache:
@@ -49,8 +50,8 @@ class GS_reweight(nn.Module):
         if reducer not in ("mean", "add"):
             raise NotImplementedError(f"aggregation {reducer!r} is outside the covered StruRW configurations")
         self.aggr = reducer
-        self.lin = nn.Linear(in_channels, out_channels)
-        self.agg_lin = nn.Linear(out_channels + in_channels, out_channels)
+        self.lin = DenseLinear(in_channels, out_channels)
+        self.agg_lin = DenseLinear(out_channels + in_channels, out_channels)
         self.normalize_emb = normalize_embedding
         self._graphs = _ReweightedGraphCache()
 
@@ -100,7 +101,7 @@ class ReweightGNN(nn.Module):
         self.bns = nn.ModuleList(nn.BatchNorm1d(gnn_dim) for _ in range(gnn_layers - 1))
         self.bn_mlp = nn.BatchNorm1d(cls_dim)
         dims = [gnn_dim, output_dim] if cls_layers == 1 else [gnn_dim] + [cls_dim] * (cls_layers - 1) + [output_dim]
-        self.mlp_classify = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.mlp_classify = nn.ModuleList(DenseLinear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
     def forward(self, data, h):
         x, edge_index, edge_weight = h, data.edge_index, data.edge_weight

@@ -12,6 +12,7 @@ from torch import nn
 from .attention import Attention
 from .cached_gcn_conv import CachedGCNConv
 from .ppmi_conv import PPMIConv
+from .linear import DenseLinear
 
 
 class GNN(nn.Module):
@@ -44,9 +45,9 @@ class UDAGCNBase(nn.Module):
         if ppmi:
             self.ppmi_encoder = GNN(in_dim=in_dim, hid_dim=hid_dim, base_model=self.encoder,
                                     num_layers=num_layers, gnn_type='ppmi', path_len=10)
-        self.cls_model = nn.Sequential(nn.Linear(hid_dim, num_classes))
-        self.domain_model = nn.Sequential(nn.Linear(hid_dim, adv_dim), nn.ReLU(), nn.Dropout(0.1),
-                                          nn.Linear(adv_dim, 2))
+        self.cls_model = nn.Sequential(DenseLinear(hid_dim, num_classes))
+        self.domain_model = nn.Sequential(DenseLinear(hid_dim, adv_dim), nn.ReLU(), nn.Dropout(0.1),
+                                          DenseLinear(adv_dim, 2))
         self.att_model = Attention(hid_dim)
         self.models = [self.encoder, self.cls_model, self.domain_model]
         if ppmi:

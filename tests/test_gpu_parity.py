@@ -1436,7 +1436,8 @@ def test_adam_sums_a_second_gradient_leaf_inside_the_update():
 
 
 @pytest.mark.parametrize("M,N,K", [(9360, 128, 128), (5484, 5, 128), (1000, 130, 70), (77, 3, 5), (20000, 64, 256),
-                                   (4_400_000, 8, 16)])          # > 65535 row tiles: rows ride on grid.x
+                                   (4_400_000, 8, 16),           # > 65535 row tiles: rows ride on grid.x
+                                   (9360, 128, 6775), (5000, 300, 600)])     # a dense first layer; extents above 256
 def test_tall_gemm_vs_fp64(M, N, K):
     """NT / NN / TN products on the matrix cores against fp64: fp32 fma chains, 1e-5 of the largest
     entry; ragged sizes exercise the zero-filled tile edges and the scalar-load path."""
@@ -1450,6 +1451,45 @@ def test_tall_gemm_vs_fp64(M, N, K):
                       (ops.gemm(ops.GEMM_TN, gyd, ad), gy.double().t() @ a.double())):
         close(got, want, rtol=0, atol=2e-6 * float(want.abs().max()) * max(1.0, (max(M, K) / 128) ** 0.5))
     exact(ops.gemm(ops.GEMM_TN, gyd, ad), ops.gemm(ops.GEMM_TN, gyd, ad))      # split-K is deterministic
+
+
+@pytest.mark.parametrize("shape,out,bias", [((500, 70), 33, True), ((3, 5), 2, True), ((4, 10, 16), 8, True), ((16,), 4, True),
+                                            ((2000, 300), 7, False), ((0, 12), 5, True), ((9000, 128), 2, True)])
+def test_no_blas_on_the_gpu_path_linear_modules_against_f_linear(shape, out, bias):
+    """``nn.linear.Linear`` and ``DenseLinear`` (the reference's ``torch.nn.Linear`` heads: a2gnn_base.py:62-66,
+    grade_base.py:66-70) on the hand-written kernels for EVERY GPU shape -- a bias, a handful of rows, extents above 256,
+    batched and 1-D inputs, no rows at all (nothing on the path reaches ``F.linear``): values
+    and all three gradients against ``F.linear`` in float64."""
+    from pygda_amd.nn.linear import DenseLinear, Linear
+    gen = torch.Generator().manual_seed(sum(shape) + out)
+    x = torch.randn(*shape, generator=gen)
+    gy = torch.randn(*shape[:-1], out, generator=gen)
+    for make in (lambda: Linear(shape[-1], out, bias=bias), lambda: DenseLinear(shape[-1], out, bias=bias)):
+        torch.manual_seed(3)
+        mod = make().to(DEV)
+        xd = x.to(DEV).requires_grad_()
+        import torch.nn.functional as F
+        called = []
+        orig = F.linear
+        try:
+            F.linear = lambda *a, **k: called.append(1) or orig(*a, **k)
+            y = mod(xd)
+            y.backward(gy.to(DEV))
+        finally:
+            F.linear = orig
+        assert not called, "the GPU path reached F.linear"
+        w64 = mod.weight.detach().double().cpu().requires_grad_()
+        b64 = None if not bias else mod.bias.detach().double().cpu().requires_grad_()
+        x64 = x.double().requires_grad_()
+        y64 = orig(x64, w64, b64)
+        y64.backward(gy.double())
+        tol = lambda t: 4e-6 * max(float(t.abs().max()) if t.numel() else 0.0, 1e-3) * max(1.0, (max(shape[-1], x.numel() // shape[-1]) / 128) ** 0.5)
+        assert y.shape == y64.shape
+        close(y, y64.detach(), rtol=0, atol=tol(y64.detach()))
+        close(xd.grad, x64.grad, rtol=0, atol=tol(x64.grad))
+        close(mod.weight.grad, w64.grad, rtol=0, atol=tol(w64.grad))
+        if bias:
+            close(mod.bias.grad, b64.grad, rtol=0, atol=tol(b64.grad))
 
 
 @pytest.mark.parametrize("M,N,K", [(33_000, 128, 128), (40_001, 128, 256), (65_536, 256, 128), (150_037, 128, 256),
