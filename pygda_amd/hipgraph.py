@@ -281,7 +281,18 @@ class GraphedStep:
                 t.record_stream(side)
         self.optimizer.zero_grad(set_to_none=True)
         if terms is not None:
-            torch.autograd.backward(list(terms), [self._one.reshape(t.shape) for t in terms])
+            # every term that still has a history is seeded with 1; a term whose backward the trainer has issued already
+            # (A2GNN: the cross-entropy chain, on its own stream behind the loss kernel) arrives detached, with the
+            # tensor its chain stopped at and that tensor's gradient as a further root, and the gradients of the
+            # parameters only that chain reaches
+            roots = [t for t in terms if t.requires_grad]
+            seeds = [self._one.reshape(t.shape) for t in roots]
+            for t, g in getattr(terms, "extra_roots", ()):
+                roots.append(t)
+                seeds.append(g)
+            for p, g in getattr(terms, "preset_grads", ()):
+                p.grad = g
+            torch.autograd.backward(roots, seeds)
         else:
             loss.backward()
         if self.dp:

@@ -16,6 +16,9 @@ import contextlib
 _null = contextlib.nullcontext
 
 
+EARLY_CE_BACKWARD = __import__("os").environ.get("PYGDA_AMD_EARLY_CE_BACKWARD", "1") == "1"
+
+
 class A2GNN(BaseGDA):
     def __init__(self, in_dim, hid_dim, num_classes, mode='node', num_layers=3, dropout=0.,
                  act=F.relu, s_pnums=0, t_pnums=30, adv=False, weight=5, weight_decay=0., lr=4e-3,
@@ -80,6 +83,28 @@ class A2GNN(BaseGDA):
         source_features, feats = net.feat_pair_from(h0_s, source_data.edge_index, sb, self.s_pnums)   # :192, :181
         source_logits = net.feat_classifier(feats, source_data.edge_index, sb, 1)            # :181
         loss = self._gmean(source_ce(source_logits, source_data.y), source_logits.size(0))   # :182, fused
+        from .. import hipgraph
+        self._early = self._src_ready = None
+        if (EARLY_CE_BACKWARD and hipgraph.defer_total and type(self) is A2GNN and not self.adv and self.mode == 'node'
+                and torch.is_grad_enabled() and feats.requires_grad):
+            # Captured step: the part of the backward pass that hangs off the cross-entropy alone -- loss -> logits ->
+            # classifier aggregation and its two products, down to the classifier's input `feats` -- is issued HERE, on
+            # this branch's stream, right behind the loss kernel, instead of behind the domain loss's forward kernels
+            # (one engine run seeds all terms from the stream the MMD was launched on: the 8 kernels of this chain waited
+            # for the 55 - 80 us MMD kernel and then led the source branch's backward, the step's last chain to finish).
+            # The rest of the backward pass continues from `feats` with this gradient as a second root
+            # (GraphedStep._run); the classifier's parameters receive their only gradient here.  Same kernels, same sums.
+            # Measured (cfg-A, alternating runs on one box): 0.4177 / 0.4127 / 0.4009 against 0.4239 / 0.4256 / 0.4215.
+            # Issuing the target feature pass ahead of the source branch as well, this chain and the loss-unused
+            # logits pass behind the domain loss and the backward pass as ordered engine runs was built and measured in
+            # the same session: 0.48 - 0.60 ms (the runtime puts the source branch on the logits pass's queue, as in
+            # round 2 -- DESIGN 4.7) -- removed again.
+            cls_params = [p for p in net.cls.parameters() if p.requires_grad]
+            self._src_ready = torch.cuda.Event()      # what the other branches join on: the forward pass, not this chain
+            self._src_ready.record()
+            grads = torch.autograd.grad(loss, [feats] + cls_params)
+            self._early = (feats, grads[0], cls_params, grads[1:])
+            loss = loss.detach()
         return loss, source_logits, source_features
 
     def _target_branch(self, target_data, fork, h0_t=None):
@@ -123,7 +148,13 @@ class A2GNN(BaseGDA):
         mmd = MMD(source_features, target_features, scale=self.weight)                  # :206-209
         from .. import hipgraph
         if hipgraph.defer_total and type(self) is A2GNN:
-            return hipgraph.LossTerms((loss, mmd))       # summed beside the backward pass (hipgraph.LossTerms)
+            terms = hipgraph.LossTerms((loss, mmd))      # summed beside the backward pass (hipgraph.LossTerms)
+            early = getattr(self, "_early", None)
+            if early is not None:
+                feats, g_feats, cls_params, g_cls = early
+                terms.extra_roots, terms.preset_grads = [(feats, g_feats)], list(zip(cls_params, g_cls))
+                self._early = None
+            return terms
         return loss + mmd
 
     def _split_graph_parts(self):
@@ -182,7 +213,11 @@ class A2GNN(BaseGDA):
             loss, source_logits, source_features = self._source_branch(source_data)
         h0_t, pending, target_features = self._target_branch(target_data, fork)
         if fork:
-            main.wait_stream(src_stream)                                                 # join
+            ready = getattr(self, "_src_ready", None)
+            if ready is not None:                       # (the early cross-entropy backward stays on its branch: the engine
+                main.wait_event(ready)                  # run of the remaining backward pass joins that stream at its end)
+            else:
+                main.wait_stream(src_stream)                                             # join
             for t in (loss, source_logits, source_features):
                 t.record_stream(main)
         return loss, source_logits, source_features, target_features, h0_t, pending, (sb, tb)

@@ -827,6 +827,41 @@ def test_hipgraph_step_matches_eager_trajectory(monkeypatch, unroll):
     exact(logits.argmax(1), g["tgt_logits"].argmax(1))
 
 
+@pytest.mark.parametrize("unroll", [1, 2])
+def test_early_cross_entropy_backward_leaves_the_trajectory_bit_for_bit(monkeypatch, unroll):
+    """Round 5: in the captured A2GNN step the backward chain that hangs off the cross-entropy alone is issued on the
+    source branch's stream right behind the loss kernel (models/a2gnn.py::_source_branch) and the rest of the backward pass
+    continues from the classifier's input with that gradient as a second root (hipgraph.GraphedStep._run).  Same kernels,
+    same sums: five epochs WITH dropout (the masks are keyed on the step counter and the call site, not on issue time)
+    give the same losses, parameters and Adam moments as the one-run backward, bit for bit."""
+    from pygda_amd.models import a2gnn as mod
+    monkeypatch.setenv("PYGDA_AMD_GRAPH_UNROLL", str(unroll))
+    g = load_golden("a2gnn_fit3_mmd")
+    s, t = _pair(g)
+    runs = {}
+    for early in (True, False):
+        monkeypatch.setattr(mod, "EARLY_CE_BACKWARD", early)
+        m = pygda_amd.models.A2GNN(24, 16, 5, num_layers=2, dropout=0.5, s_pnums=0, t_pnums=10, adv=False,
+                                   weight=10, lr=0.01, weight_decay=0.005, device=DEV, epoch=5, verbose=0,
+                                   use_hip_graph=True)
+        seen = []
+        m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+        torch.manual_seed(11)
+        torch.cuda.synchronize()
+        ops.dropout_state.seed, ops.dropout_state.site = 1234, 0         # the process-wide generator state: same for both runs
+        ops.dropout_state.counter(torch.device(DEV)).zero_()
+        m.fit(s, t)
+        assert getattr(m, "_graphed", None) is not None, "step was not captured"
+        runs[early] = (seen, {k: v.detach().clone() for k, v in m.a2gnn.state_dict().items()})
+        del m
+        import gc
+        gc.collect()
+    diffs = {k: float((v.double() - runs[False][1][k].double()).abs().max()) for k, v in runs[True][1].items()}
+    assert runs[True][0] == runs[False][0], (runs[True][0], runs[False][0], diffs)
+    for k, v in runs[True][1].items():
+        exact(v, runs[False][1][k])
+
+
 # -------------------------------------------------- hub rows (power-law graphs) --
 def test_spmm_long_rows_split_matches_dense():
     """Rows with more than SPLIT_THRESHOLD (128) entries are processed as chunks + an ordered reduce: same
