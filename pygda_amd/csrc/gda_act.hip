@@ -374,7 +374,7 @@ extern "C" int gda_relu_dropout_fwd_cm_f32(const float* xT, int64_t ldT, float* 
     if (d % 4 != 0 || (uintptr_t)y % 16 != 0) return GDA_E_UNSUPPORTED;
     const dim3 grid((unsigned)gda_cdiv(n, TT), (unsigned)gda_cdiv(d, TT));
     if (grid.y > 65535) return GDA_E_SIZE;
-    k_relu_dropout_fwd_T<<<grid, TB, 0, (hipStream_t)stream>>>(xT, ldT, y, (int)n, (int)d, p, 1.f / (1.f - p), seed,
+    GDA_UNLESS_SKIPPED("k_relu_dropout_fwd_T") k_relu_dropout_fwd_T<<<grid, TB, 0, (hipStream_t)stream>>>(xT, ldT, y, (int)n, (int)d, p, 1.f / (1.f - p), seed,
                                                                step, site);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
@@ -388,7 +388,7 @@ extern "C" int gda_relu_dropout_bwd_cm_f32(const float* gy, const float* y, floa
     if (d % 4 != 0 || ((uintptr_t)gy | (uintptr_t)y) % 16 != 0) return GDA_E_UNSUPPORTED;
     const dim3 grid((unsigned)gda_cdiv(n, TT), (unsigned)gda_cdiv(d, TT));
     if (grid.y > 65535) return GDA_E_SIZE;
-    k_relu_dropout_bwd_T<<<grid, TB, 0, (hipStream_t)stream>>>(gy, y, gxT, ldT, (int)n, (int)d, 1.f / (1.f - p));
+    GDA_UNLESS_SKIPPED("k_relu_dropout_bwd_T") k_relu_dropout_bwd_T<<<grid, TB, 0, (hipStream_t)stream>>>(gy, y, gxT, ldT, (int)n, (int)d, 1.f / (1.f - p));
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
@@ -432,7 +432,7 @@ extern "C" int gda_relu_dropout_pair_bwd_f32(const float* gy, const float* y, fl
     float* partial = static_cast<float*>(workspace);
     k_relu_dropout_pair_bwd_colsum<<<blocks, TB, 0, s>>>(gy, y, gx, n, (int)d, 1.f / (1.f - p), partial);
     GDA_LAUNCH_CHECK();
-    k_colsum_final<<<(unsigned)gda_cdiv(d, CF_COLS), TB, 0, s>>>(partial, blocks, (int)d, colsum);
+    GDA_UNLESS_SKIPPED("k_colsum_final") k_colsum_final<<<(unsigned)gda_cdiv(d, CF_COLS), TB, 0, s>>>(partial, blocks, (int)d, colsum);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
@@ -442,7 +442,7 @@ extern "C" int gda_stack2_f32(const float* a, const float* b, float* out, int64_
     if (half_elems == 0) return GDA_OK;
     if (!out) return GDA_E_NULL;
     if (half_elems % 4 != 0 || ((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) % 16 != 0) return GDA_E_UNSUPPORTED;
-    k_stack2<<<grid_for(2 * half_elems), TB, 0, (hipStream_t)stream>>>(a, b, out, half_elems);
+    GDA_UNLESS_SKIPPED("k_stack2") k_stack2<<<grid_for(2 * half_elems), TB, 0, (hipStream_t)stream>>>(a, b, out, half_elems);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
@@ -476,7 +476,7 @@ extern "C" int gda_colsum_f32(const float* x, int64_t ldx, int64_t n, int64_t d,
     const int blocks = colsum_blocks(n, (int)d);
     k_colsum_partial<<<blocks, TB, 0, s>>>(x, ldx, n, (int)d, static_cast<float*>(workspace));
     GDA_LAUNCH_CHECK();
-    k_colsum_final<<<(unsigned)gda_cdiv(d, CF_COLS), TB, 0, s>>>(static_cast<const float*>(workspace), blocks, (int)d, out);
+    GDA_UNLESS_SKIPPED("k_colsum_final") k_colsum_final<<<(unsigned)gda_cdiv(d, CF_COLS), TB, 0, s>>>(static_cast<const float*>(workspace), blocks, (int)d, out);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }

@@ -558,6 +558,7 @@ extern "C" int gda_gemm_ex_f32(int mode, int64_t M, int64_t N, int64_t K, const 
     if (bias != nullptr && mode != GDA_GEMM_NT) return GDA_E_UNSUPPORTED;
     if (colsum != nullptr && mode != GDA_GEMM_TN) return GDA_E_UNSUPPORTED;
     if (mode != GDA_GEMM_NT && mode != GDA_GEMM_NN && mode != GDA_GEMM_TN) return GDA_E_UNSUPPORTED;
+    if (gda_dbg_skip(mode == GDA_GEMM_TN ? "gemm_ex_tn" : mode == GDA_GEMM_NN ? "gemm_ex_nn" : "gemm_ex_nt")) return GDA_OK;
     if (M < 0 || N < 0 || K < 0 || ldc < N) return GDA_E_SIZE;
     if ((mode == GDA_GEMM_TN ? lda < M : lda < K) || (mode == GDA_GEMM_NT ? ldb < K : ldb < N)) return GDA_E_SIZE;
     if (M == 0 || N == 0) return GDA_OK;
@@ -592,7 +593,7 @@ extern "C" int gda_gemm_ex_f32(int mode, int64_t M, int64_t N, int64_t K, const 
             if (tn) GDA_GEMM_LAUNCH(true, true, dim3((unsigned)gy, (unsigned)gx, s), (float*)workspace, N, k_slab);
             else GDA_GEMM_LAUNCH(false, true, dim3((unsigned)gy, (unsigned)gx, s), (float*)workspace, N, k_slab);
             GDA_LAUNCH_CHECK();
-            k_slab_sum<<<(unsigned)gda_cdiv(M * N + (colsum ? M : 0), SS_OUT), TB, 0, stream>>>(
+            GDA_UNLESS_SKIPPED("k_slab_sum") k_slab_sum<<<(unsigned)gda_cdiv(M * N + (colsum ? M : 0), SS_OUT), TB, 0, stream>>>(
                 (const float*)workspace, s, M, N, C, ldc, cs_part, colsum);
         } else if (tn) {
             GDA_GEMM_LAUNCH(true, true, dim3((unsigned)gy, (unsigned)gx, 1), C, ldc, K);
@@ -646,7 +647,7 @@ extern "C" int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, cons
         if (N == 128) k_tall_wgrad<4><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, B, ldb, part, colsum ? cs_part : nullptr, K, rows);
         else k_tall_wgrad<8><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, B, ldb, part, colsum ? cs_part : nullptr, K, rows);
         GDA_LAUNCH_CHECK();
-        k_slab_sum<<<(unsigned)gda_cdiv(128 * N + (colsum ? 128 : 0), SS_OUT), TB, 0, stream>>>(
+        GDA_UNLESS_SKIPPED("k_slab_sum") k_slab_sum<<<(unsigned)gda_cdiv(128 * N + (colsum ? 128 : 0), SS_OUT), TB, 0, stream>>>(
             part, (int)slabs, 128, N, C, ldc, cs_part, colsum);
         GDA_LAUNCH_CHECK();
         return GDA_OK;
@@ -753,7 +754,7 @@ extern "C" int gda_gemm_skinny_f32(int mode, int64_t M, int64_t N, int64_t K, co
         float* cs_part = part + (size_t)slabs * M * N;
         k_skinny_wgrad<<<(unsigned)slabs, TB, 0, stream>>>(A, lda, B, ldb, part, colsum ? cs_part : nullptr, K, rows, (int)M, (int)N);
         GDA_LAUNCH_CHECK();
-        k_slab_sum<<<(unsigned)gda_cdiv(M * N + (colsum ? M : 0), SS_OUT), TB, 0, stream>>>(part, (int)slabs, M, N, C, ldc, cs_part, colsum);
+        GDA_UNLESS_SKIPPED("k_slab_sum") k_slab_sum<<<(unsigned)gda_cdiv(M * N + (colsum ? M : 0), SS_OUT), TB, 0, stream>>>(part, (int)slabs, M, N, C, ldc, cs_part, colsum);
     } else {
         return GDA_E_UNSUPPORTED;
     }

@@ -543,6 +543,7 @@ extern "C" int gda_kstep_lds_colmajor_f32(const void* plan, int slots, int64_t n
     if (n_rows < 0 || d < 0 || K < 0 || n_rows > KS_MAX_ROWS || d > 65535) return GDA_E_SIZE;
     if (n_rows == 0 || d == 0) return GDA_OK;
     if (!plan || !xT || !yT) return GDA_E_NULL;
+    if (gda_dbg_skip("kstep_colmajor")) return GDA_OK;
     const int n_pad = ((int)n_rows + 3) / 4 * 4;
     if (ldx < n_pad || ldy < n_pad || ldx % 4 || ldy % 4 || ((uintptr_t)xT % 16) || ((uintptr_t)yT % 16)) return GDA_E_SIZE;
     const int S = slots & 0xff, hub_waves = (slots >> 8) & 0xff;       // the value gda_kstep_plan_host returned
@@ -572,7 +573,7 @@ extern "C" int gda_transpose_f32(const float* in, int64_t ldi, float* out, int64
     if (in == out) return GDA_E_ALIAS;
     const dim3 grid((unsigned)gda_cdiv(rows, 64), (unsigned)gda_cdiv(cols, 64));
     if (grid.y > 65535) return GDA_E_SIZE;
-    k_transpose<<<grid, 256, 0, (hipStream_t)stream>>>(in, ldi, out, ldo, (int)rows, (int)cols);
+    GDA_UNLESS_SKIPPED("k_transpose") k_transpose<<<grid, 256, 0, (hipStream_t)stream>>>(in, ldi, out, ldo, (int)rows, (int)cols);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }

@@ -916,7 +916,7 @@ extern "C" int gda_mmd_fwd_gather_f32(const float* src, int64_t ld_src, const fl
     else
         k_pairdist<0, false, false><<<grid, TB, 0, stream>>>(R, d, m, (int)nt, bandwidth, kp, l2_saved, ws.kpartial, nullptr);
     GDA_LAUNCH_CHECK();
-    k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, (int)ntri, times, n, scale, add, loss);
+    GDA_UNLESS_SKIPPED("k_finalize") k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, (int)ntri, times, n, scale, add, loss);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
@@ -1017,14 +1017,14 @@ extern "C" int gda_mmd_fused_layout(int times, int64_t n, int64_t d, int64_t* ou
 template <int NB>
 static int launch_fused(hipStream_t stream, const Rows& Rin, float* rows_src, float* rows_tgt, int64_t m, int64_t d, const MmdWs& ws,
                         const FusedPlan& fp, int times, float* bandwidth, float* grad_part) {
-    k_tile_split<NB><<<dim3((unsigned)fp.ntiles, (unsigned)times), TB, 0, stream>>>(Rin, m, ws.part_s1, ws.part_col, ws.part_max,
+    GDA_UNLESS_SKIPPED("k_tile_split") k_tile_split<NB><<<dim3((unsigned)fp.ntiles, (unsigned)times), TB, 0, stream>>>(Rin, m, ws.part_s1, ws.part_col, ws.part_max,
                                                                                rows_src, rows_tgt, ws.images);
     GDA_LAUNCH_CHECK();
     const Rows R = rows_src ? make_rows(rows_src, d, rows_tgt, d, nullptr, nullptr, Rin.n) : Rin;   // gathered: no index from here on
     const size_t lds = 2 * fp.img + sizeof(float) * 32 * (TB / 64);
     GDA_LDS_ATTR_ONCE((k_mmd_fused<NB>), lds);
     const unsigned grid = 8u * (unsigned)gda_cdiv(fp.total, 8);
-    k_mmd_fused<NB><<<grid, TB, lds, stream>>>(R, m, fp.ntiles, fp.njb, fp.nseg, fp.total, ws.images, ws.part_s1, ws.part_col,
+    GDA_UNLESS_SKIPPED("k_mmd_fused") k_mmd_fused<NB><<<grid, TB, lds, stream>>>(R, m, fp.ntiles, fp.njb, fp.nseg, fp.total, ws.images, ws.part_s1, ws.part_col,
                                               ws.part_max, bandwidth, grad_part, ws.kpartial);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
@@ -1060,7 +1060,7 @@ extern "C" int gda_mmd_fused_fwd_f32(const float* src, int64_t ld_src, const flo
         default: st = launch_fused<4>(stream, R, rows_src, rows_tgt, m, d, ws, fp, times, bandwidth, grad_part); break;
     }
     if (st != GDA_OK) return st;
-    k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, fp.njb * fp.nseg, times, n, scale, add, loss);
+    GDA_UNLESS_SKIPPED("k_finalize") k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, fp.njb * fp.nseg, times, n, scale, add, loss);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
