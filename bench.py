@@ -864,6 +864,13 @@ def run_cfg_a(args, world, rank, dev, side=False):
                        "same_library_as_this_run": rp_lib is not None and rp_lib == library_sha16()},
                    "lds_bytes_gathered_per_launch": per_launch, "launches": r["launches"],
                    "cus_occupied": cus, "frac_of_whole_chip": ach / LDS_READ_B32_PEAK_GBS}
+            # ... of which useful: one 4-byte word per stored entry of the graph, column and step (the plan pads its slots and
+            # splits hub rows: `frac` counts those reads too) -- VERDICT round 4, item 2
+            K_name = int(name.split("K=")[1].rstrip("]"))
+            useful = 4.0 * nnz_t * cols * K_name
+            out["useful_gather_bytes_per_launch"] = useful
+            out["useful_gather_frac"] = useful / (dur_us * 1e-6) / 1e9 / peak
+            out["gathered_words_that_are_padding"] = 1.0 - useful / per_launch if per_launch else None
             if alone_us and fixed_us and alone_us > fixed_us:
                 # where the launch's time goes: K = 0 launches cost `fixed_us` (the slot program, 262 KB per workgroup,
                 # and the column in / out); the rest is the K step loops, whose LDS gather rate is the kernel's bound
