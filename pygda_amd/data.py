@@ -324,11 +324,12 @@ class NeighborLoader:
         side = self._samp_stream
         side.wait_stream(torch.cuda.current_stream())       # the graph / features may have just been produced
         ring = None
-        if self.recycle:
+        if self.recycle and not getattr(self, "_ring_busy", False):     # (a second live iterator over this loader allocates)
             if self._ring is None:
                 self._ring = S.new_ring(self.prefetch + 4)
             ring = self._ring
             ring.reset()          # (the wait above also puts the last pass's batches behind the sampler's stream)
+            self._ring_busy = True
         q, stop = queue.Queue(maxsize=self.prefetch), threading.Event()
 
         def producer():
@@ -368,6 +369,8 @@ class NeighborLoader:
                     q.get_nowait()
                 except queue.Empty:
                     th.join(timeout=0.01)
+            if ring is not None:
+                self._ring_busy = False
 
 
 def collate_graphs(graphs):

@@ -76,6 +76,19 @@ def test_round3_entry_points_validate_before_touching_a_device():
     assert L.gda_dsampler_sample(None, None, 10, 5, 2, None, 1, fan.ctypes.data, 2, 0, None, None, None, None, None, None,
                                  None, None, None, None, None, 0, None) == -1
     assert L.gda_dsampler_build_graph(one, one, 2 ** 31, 10, one, one, one, one, 1 << 40, None) == -2      # int32 edge count
+    # the one-call batch of the recycling loader and its events: arguments are checked before anything is enqueued
+    args = [None] * 30
+    args[2:5], args[6], args[9], args[10], args[23], args[28] = [10, 5, 2], 1, 2, 0, 0, 0
+    assert L.gda_dsampler_batch(*args) == -1                                   # no counts / landing pad
+    args[20], args[24] = one, one
+    assert L.gda_dsampler_batch(*args) == -1                                   # seeds without a device copy
+    args[5], args[7], args[6] = one, one, -1
+    assert L.gda_dsampler_batch(*args) == -2                                   # negative seed count
+    args[6], args[21] = 1, one
+    assert L.gda_dsampler_batch(*args) == -1                                   # one plan without the other
+    for fn in (L.gda_event_record, L.gda_stream_wait_event):
+        assert fn(None, None) == -1
+    assert L.gda_event_synchronize(None) == -1 and L.gda_event_create(None) == -1 and L.gda_event_destroy(None) == 0
     # GEMM envelopes: refused shapes are the general kernel's business
     assert L.gda_gemm_tall_f32(0, 100_000, 96, 128, one, 128, one, 128, ctypes.c_void_p(2), 96, None, None, None, 0, None) == -4
     assert L.gda_gemm_tall_f32(0, 100_000, 128, 100, one, 100, one, 100, ctypes.c_void_p(2), 128, None, None, None, 0, None) == -4
