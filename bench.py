@@ -323,7 +323,20 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
 
     phases = []              # per step: host seconds in (loader hand-over, forward, backward, exchange + optimiser)
 
+    stall_ms = float(os.environ.get("PYGDA_AMD_BENCH_STALL_TRACE", "0"))     # diagnosis: dump every thread's stack when a step
+    if stall_ms > 0:                                                           # takes longer than this on the host
+        import faulthandler
+
     def one_step():
+        if stall_ms > 0:
+            faulthandler.dump_traceback_later(stall_ms * 1e-3, exit=False)     # a C watchdog thread: needs no interpreter lock
+        try:
+            return one_step_()
+        finally:
+            if stall_ms > 0:
+                faulthandler.cancel_dump_traceback_later()
+
+    def one_step_():
         h0 = time.perf_counter()
         s, t = next(it)
         h1 = time.perf_counter()
@@ -1068,6 +1081,9 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
+    import pygda_amd                      # first of all: caps the host thread pool at the container's CPU quota (pygda_amd/_cpu.py)
+    from pygda_amd import _cpu
+    throttle0 = _cpu.throttle_counters()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(relaunch(args))          # start the ranks ourselves; each re-enters main() with the env set
@@ -1121,6 +1137,10 @@ def main():
                 "value": side["value"], "unit": side["unit"], "ms_per_step": side["ms_per_step"],
                 "steps": side["steps"], "workload": side["config"]["workload"],
                 "sampler": side["config"].get("sampler"),
+                # the host side of those steps: [slowest, median] step, and where the slowest one spent its time -- a
+                # single slow step is 1/30 of this figure
+                "host_ms_per_step_max_median": side["config"].get("host_ms_per_step_max_median"),
+                "host_slowest_step": (side["config"].get("host_phases") or {}).get("slowest_step"),
                 "roofline": side["roofline"], "roofline_dense_projection": side["roofline_dense_projection"]}
         elif world > 1 and rank == 0:
             out["config"]["parallelism"] = (f"{world} full-batch replicas (explicit --workload cfgA; value is ONE "
@@ -1129,6 +1149,13 @@ def main():
         if thunk is not None:
             out["cpu_baseline"] = thunk()
     if rank == 0:
+        throttle1 = _cpu.throttle_counters()
+        out["host_cpu"] = {"intra_op_threads": torch.get_num_threads(), "cgroup_quota_cores": _cpu.cpu_quota(),
+                           "visible_cpus": len(os.sched_getaffinity(0)),
+                           "cgroup_throttle_events_during_this_process": None if throttle0 is None or throttle1 is None
+                           else throttle1[0] - throttle0[0],
+                           "note": "a throttle event freezes every thread of the container for the rest of a 100 ms "
+                                   "period: pygda_amd/_cpu.py keeps the intra-op pool inside the quota"}
         if getattr(args, "_ranks_seen", None) is not None:
             out["rccl_ranks_seen"] = args._ranks_seen            # all-gather of the ranks over the group (init_group)
             out["collectives"] = args._collectives

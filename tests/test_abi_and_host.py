@@ -1035,3 +1035,26 @@ def test_second_leaves_hold_the_second_pass_gradients_of_the_shared_layers():
     assert table[id(own_w[0])] is not first and table[id(own_w[0])].data_ptr() == own_w[0].data_ptr()
     for k in ref:
         assert (ref[k] is None and got[k] is None) or torch.equal(ref[k], got[k]), k
+
+
+def test_host_thread_pool_stays_inside_the_cpu_quota(tmp_path):
+    """pygda_amd/_cpu.py: the intra-op pool is capped at the cgroup's CPU quota (less a reserve for the training thread,
+    the loaders' producer threads and the runtime's own), shared by the ranks of a node; an explicit thread count wins,
+    ``0`` leaves PyTorch alone.  (The GPU box allows 16 cores' time and shows 128 CPUs: without the cap a host parallel
+    region can freeze the whole process for the rest of a 100 ms period.)"""
+    import subprocess
+    import sys
+    from pygda_amd import _cpu
+    assert _cpu.pool_size_for(16.0, 128) == 12 and _cpu.pool_size_for(16.0, 8) == 8
+    assert _cpu.pool_size_for(2.0, 64) == 1 and _cpu.pool_size_for(1.0, 8) == 1 and _cpu.pool_size_for(6.0, 64) == 3
+    assert _cpu.pool_size_for(None, 64) == 64
+    q = _cpu.cpu_quota()
+    assert q is None or q > 0
+    t = _cpu.throttle_counters()
+    assert t is None or (t[0] >= 0 and t[1] >= 0)
+    code = "import torch; torch.set_num_threads(6); import pygda_amd; print(torch.get_num_threads())"
+    run = lambda env: int(subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True,
+                                         text=True, check=True).stdout.split()[-1])
+    assert run({"PYGDA_AMD_CPU_THREADS": "2"}) == 2
+    assert run({"PYGDA_AMD_CPU_THREADS": "0"}) == 6
+    assert run({"PYGDA_AMD_CPU_THREADS": "64"}) == 6          # never more than PyTorch would take
