@@ -158,7 +158,7 @@ class _PendingBatch:
 class _Slot(_PendingBatch):
     """A pending batch whose block belongs to a loader's ring (:class:`_Ring`) and is written again ``depth`` batches
     later: the views, the pointers of the one foreign call that fills it and its two events are made ONCE."""
-    __slots__ = ("block", "ring", "done", "free", "freed", "counts_np", "args", "marked")
+    __slots__ = ("block", "ring", "done", "free", "freed", "counts_np", "args", "marked", "seeds_pin")
     recycled = True
 
     def wait(self):
@@ -293,7 +293,10 @@ class DeviceNeighborSampler:
         ws = self._ws.get(stream.cuda_stream)
         if ws is None or ws.numel() < need:
             ws = self._ws[stream.cuda_stream] = torch.empty(need, dtype=torch.uint8, device=dev)
-        pinned = torch.empty(ring.depth, 12, dtype=torch.int64).pin_memory()
+        # pinned per slot: the 12 counts coming home and the seeds going out (a copy out of pageable memory is staged
+        # synchronously by the runtime: the producer thread would sit inside the copy call until its stream -- possibly
+        # waiting for the slot's `free` event -- gets there)
+        pinned = torch.empty(ring.depth, 12 + max(int(n_seeds), 1), dtype=torch.int64).pin_memory()
         ring._pinned = pinned
         slots = []
         for i in range(ring.depth):
@@ -312,8 +315,9 @@ class DeviceNeighborSampler:
             csr_ptrs = [at(k) for k in names] if csr else [None] * 6
             sl.plans = (view("plan0", torch.uint8), view("plan1", torch.uint8)) if plans else None
             sl.plan_ok = (False, False)
-            sl.counts_host = pinned[i]
-            sl.counts_np = pinned[i].numpy()
+            sl.counts_host = pinned[i, :12]
+            sl.counts_np = pinned[i, :12].numpy()
+            sl.seeds_pin = pinned[i, 12:]
             ev = [ctypes.c_void_p(), ctypes.c_void_p()]
             for e in ev:
                 _lib.check(L.gda_event_create(ctypes.byref(e)), "gda_event_create")
@@ -339,7 +343,13 @@ class DeviceNeighborSampler:
         sl = ring.slots[ring.at % ring.depth]
         ring.at += 1
         a = sl.args
-        a[5] = seeds_t.data_ptr()
+        if seeds_t.is_cuda:
+            a[5] = seeds_t.data_ptr()
+        else:
+            # this slot's pinned seeds are free again: the copy that read them precedes the slot's previous `done` event,
+            # which this thread waited for (p.wait) before it enqueued anything else
+            sl.seeds_pin[:seeds_t.numel()].copy_(seeds_t)
+            a[5] = sl.seeds_pin.data_ptr()
         a[10] = ctypes.c_uint64(int(seed) & (2 ** 64 - 1))
         a[25] = sl.free if sl.freed else None
         sl.freed = False
