@@ -67,14 +67,14 @@ def _worker_loop(jobs):
         job = jobs.get()
         if job is None:
             return
-        ns, nt, times, sampling_num, dev, stream, box, done = job
+        ns, nt, times, sampling_num, dev, stream, box, done, stacked = job
         try:
             with torch.cuda.device(dev), torch.cuda.stream(stream):
                 s_cpu = torch.randint(ns, (times, sampling_num))
                 t_cpu = torch.randint(nt, (times, sampling_num))
                 apply_row_maps(s_cpu, t_cpu)
                 from ..ops import mmd_samples_to_device
-                box["out"] = mmd_samples_to_device(s_cpu, t_cpu, ns, nt, torch.device(dev))
+                box["out"] = mmd_samples_to_device(s_cpu, t_cpu, ns, nt, torch.device(dev), stacked=stacked)
         except BaseException as exc:          # surfaced by the consumer
             box["err"] = exc
         finally:
@@ -83,9 +83,15 @@ def _worker_loop(jobs):
 
 def prefetch_samples(ns, nt, dev, sampling_num=1000, times=5):
     global _prefetched, _worker
-    if (not PREFETCH or _prefetched is not None or distributed.active() or sample_provider is not None
+    if (not PREFETCH or _prefetched is not None or sample_provider is not None or dp_index_provider is not None
             or torch.device(dev).type != "cuda"):
         return
+    stacked = True
+    if distributed.active():
+        # data-parallel: this rank's 1/W share of every resample, scattered out of its own [times, per, d] block (the
+        # same two draws MMD()'s data-parallel branch makes, in the same order)
+        sampling_num = -(-sampling_num // distributed.info()["world_size"])
+        stacked = False
     import queue
     import threading
     if _worker is None or not _worker[0].is_alive():
@@ -95,7 +101,7 @@ def prefetch_samples(ns, nt, dev, sampling_num=1000, times=5):
         _worker = (th, jobs)
     stream = torch.cuda.current_stream(dev)
     box, done = {}, threading.Event()
-    _worker[1].put((ns, nt, times, sampling_num, dev, stream, box, done))
+    _worker[1].put((ns, nt, times, sampling_num, dev, stream, box, done, stacked))
     _prefetched = (ns, nt, times, sampling_num, str(torch.device(dev)), done, box)
 
 
@@ -135,6 +141,9 @@ def MMD(source_feat, target_feat, sampling_num=1000, times=5, *, scale=1.0, add=
         ns, nt = source_feat.size(0), target_feat.size(0)
         if dp_index_provider is not None:       # captured step: static device buffers, refilled per replay
             s_idx, t_idx, sel_s, sel_t = dp_index_provider(ns, nt, times, per)
+        elif dev.type == "cuda" and (ready := _take_prefetched(ns, nt, times, per, dev)) is not None:
+            s_idx, t_idx, sel = ready           # drawn beside the forward passes (prefetch_samples)
+            sel_s, sel_t = (sel[0], sel[1], sel[4]), (sel[2], sel[3], sel[4])
         else:
             s_cpu, t_cpu = torch.randint(ns, (times, per)), torch.randint(nt, (times, per))
             apply_row_maps(s_cpu, t_cpu)
