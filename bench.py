@@ -1059,7 +1059,9 @@ def main():
     ap.add_argument("--no-side-lines", action="store_true",
                     help="skip the second workload's labelled side object (N = 1: cfg-S on one GPU, the base point "
                          "of the scaling curve; N > 1: cfg-A replicas)")
-    ap.add_argument("--side-steps", type=int, default=30)
+    ap.add_argument("--side-steps", type=int, default=60,
+                    help="timed steps of the labelled side line (60: one rare 30 - 50 ms host stall, DESIGN 5, moves a 30-step\n"
+                         "figure by 1.1 - 1.6 ms/step)")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel code path (RCCL exchange steps) on a 1-rank group")
     ap.add_argument("--profile-run", action="store_true",
