@@ -14,6 +14,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wno-unused-result", "-Wno-unused-value"]
 
 
+# PYGDA_AMD_MEASUREMENT_AIDS=1: also compile the what-if hooks (PYGDA_AMD_DBG_SKIP, PYGDA_AMD_GEMM_DBG: launches left out /
+# kernel phases disabled to read a clock, results WRONG).  The release build -- the default, what build() makes and what
+# every test and bench line runs -- contains none of them.
+if os.environ.get("PYGDA_AMD_MEASUREMENT_AIDS", "0") == "1":
+    FLAGS.append("-DGDA_MEASUREMENT_AIDS")
+
+
 def _hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

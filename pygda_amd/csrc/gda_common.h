@@ -13,19 +13,29 @@
     } while (0)
 
 // kernel launches do not return a status: pick up launch-configuration errors here
-// Measurement aid (tools/whatif_cfgA.sh): PYGDA_AMD_DBG_SKIP="k_slab_sum,k_transpose" leaves the named launches out -- the
-// results are then WRONG; what is read off is what the step would cost without those launches, before anything is built to
-// remove them.  Unset (the product): one cached getenv per translation unit, no effect.
+// Measurement aid (tools/whatif_cfgA.sh): with the library built with -DGDA_MEASUREMENT_AIDS (PYGDA_AMD_MEASUREMENT_AIDS=1 for
+// pygda_amd/_build.py), PYGDA_AMD_DBG_SKIP="k_slab_sum,k_transpose" leaves the named launches out -- the results are then
+// WRONG; what is read off is what the step would cost without those launches, before anything is built to remove them.
+// The release build (the default) compiles none of it: the variable has no effect on the product library.
+#ifdef GDA_MEASUREMENT_AIDS
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 static inline bool gda_dbg_skip(const char* name) {
-    static const char* env = std::getenv("PYGDA_AMD_DBG_SKIP");
+    static const char* env = [] {
+        const char* e = std::getenv("PYGDA_AMD_DBG_SKIP");
+        if (e && *e) std::fprintf(stderr, "libgda_hip.so: PYGDA_AMD_DBG_SKIP=%s -- named launches are LEFT OUT, results are wrong\n", e);
+        return e;
+    }();
     if (!env || !*env) return false;
     const size_t n = std::strlen(name);
     for (const char* p = std::strstr(env, name); p; p = std::strstr(p + 1, name))
         if ((p == env || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
     return false;
 }
+#else
+static inline constexpr bool gda_dbg_skip(const char*) { return false; }
+#endif
 #define GDA_UNLESS_SKIPPED(name) if (!gda_dbg_skip(name))
 
 #define GDA_LAUNCH_CHECK()                             \

@@ -659,12 +659,13 @@ extern "C" int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, cons
     // forward / data gradient on the 16-bit matrix cores with split operands (gda_gemm_split.inc): the default
     static const bool split16 = [] { const char* e = std::getenv("PYGDA_AMD_GEMM_SPLIT_F16"); return !(e && e[0] == '0'); }();
     if (split16 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 && ldb % 4 == 0 && ((uintptr_t)B & 15) == 0) {
-        static const int dbg = [] { const char* e = std::getenv("PYGDA_AMD_GEMM_DBG"); return e ? std::atoi(e) : 0; }();
         const int64_t bm = K == 128 ? 128 : 64;
         const int64_t nt = gda_cdiv(M, bm);
         const dim3 g((unsigned)min(nt, (int64_t)256), (unsigned)(N / 128));
         const size_t img = (size_t)bm * (K + 8) * 2;
         const size_t lds = 4 * img + 2 * (size_t)bm * sizeof(float);
+#ifdef GDA_MEASUREMENT_AIDS
+        static const int dbg = [] { const char* e = std::getenv("PYGDA_AMD_GEMM_DBG"); return e ? std::atoi(e) : 0; }();
 #define TH_DBG(D_)                                                                                            \
     do {                                                                                                      \
         GDA_LDS_ATTR_ONCE((k_tall_fwd_h<128, false, D_>), 160 * 1024);                                        \
@@ -677,6 +678,7 @@ extern "C" int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, cons
             if (dbg == 6) TH_DBG(6); if (dbg == 7) TH_DBG(7);
         }
 #undef TH_DBG
+#endif
 #define TH_LAUNCH(K_, BT_)                                                                                    \
     do {                                                                                                      \
         GDA_LDS_ATTR_ONCE((k_tall_fwd_h<K_, BT_>), 160 * 1024);                                               \

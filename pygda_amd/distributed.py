@@ -274,6 +274,9 @@ def global_mean(mean_local, n_local):
     return _GlobalMean.apply(mean_local, int(n_local))
 
 
+_coalesced_state = None       # None: unchecked, "on": first-step check passed, "off": it failed (flat buffer from then on)
+
+
 def _dense_view(g):
     """A contiguous view of a dense gradient's memory (a gather-major weight's gradient has transposed strides)."""
     if g.is_contiguous():
@@ -303,12 +306,45 @@ def allreduce_grads(params):
     comm = direct() if cuda32 else None
     views = [_dense_view(g) for g in grads] if cuda32 else None
     manager = getattr(dist, "_coalescing_manager", None)
-    if (comm is None and cuda32 and dist.get_backend() == "nccl" and manager is not None
-            and all(v is not None for v in views) and os.environ.get("PYGDA_AMD_COALESCED_GRADS", "1") == "1"):
+    global _coalesced_state
+    want = os.environ.get("PYGDA_AMD_COALESCED_GRADS", "check")        # "1": trust it, "0": flat buffer, default: check once
+    if (comm is None and cuda32 and dist.get_backend() == "nccl" and manager is not None and want != "0"
+            and _coalesced_state != "off" and all(v is not None for v in views)):
+        # The coalescing group is a private torch API applied to transposed views, and no build round has had two GPUs to
+        # run it on.  So the FIRST step of a process runs both forms: the flat-buffer all-reduce below
+        # (the validated path) on a copy, then the in-place group; the ranks agree on the verdict with one more
+        # all-reduce.  Equal -> the group serves every later step; different -> a loud warning, the flat result is
+        # installed and the flat path serves the rest of the process.
+        reference = None
+        if _coalesced_state is None and want != "1":
+            reference = torch.cat([v.reshape(-1) for v in views])
+            _all_reduce_sum(reference)
+            reference.div_(world)
         with manager(device=grads[0].device, async_ops=False):
             for v in views:
                 dist.all_reduce(v, op=dist.ReduceOp.SUM)
         torch._foreach_div_(views, float(world))
+        if reference is None:
+            _coalesced_state = "on"
+            return
+        got = torch.cat([v.reshape(-1) for v in views])
+        # sums of W fp32 terms in two association orders: equal to a few ulps of the largest term
+        tol = 1e-5 * float(reference.abs().max()) + 1e-30
+        bad = ((got - reference).abs() > tol).any().to(torch.float32).reshape(1)
+        _all_reduce_sum(bad)
+        if float(bad) == 0.0:
+            _coalesced_state = "on"
+            return
+        import warnings
+        warnings.warn("pygda_amd.distributed: the coalesced in-place gradient all-reduce disagrees with the flat-buffer "
+                      "all-reduce on this stack; using the flat buffer from here on (PYGDA_AMD_COALESCED_GRADS=0 "
+                      "skips the check)")
+        _coalesced_state = "off"
+        off = 0
+        for v in views:
+            n = v.numel()
+            v.copy_(reference[off:off + n].view_as(v))
+            off += n
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     if comm is not None:

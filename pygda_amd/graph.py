@@ -78,7 +78,7 @@ class CSRGraph:
 
     __slots__ = ("num_nodes", "nnz_cap", "rowptr", "colidx", "val", "t_rowptr", "t_colidx",
                  "t_val", "_nnz", "device", "_split", "_t_split", "t_to_fwd", "static", "_squared", "transient",
-                 "_kplan", "_t_kplan", "n_interior", "iplan")
+                 "_kplan", "_t_kplan", "n_interior", "iplan", "iplan_T", "_slot", "_gen")
 
     def __init__(self, num_nodes, nnz_cap, rowptr, colidx, val, t_rowptr, t_colidx, t_val):
         self.num_nodes, self.nnz_cap = num_nodes, nnz_cap
@@ -91,6 +91,9 @@ class CSRGraph:
         self.static = False       # graph of a full-batch loader: lives for the whole fit()
         self.transient = False    # graph of one sampled mini-batch: nothing about it is worth a host sync
         self._squared = None      # A*A (and its transpose) of a static graph, or False if too dense
+        self.iplan_T = None       # sampled batch: off-diagonal entries of the interior block (the sampler's count)
+        self._slot, self._gen = None, 0        # sampled batch out of a recycling loader ring: its block and the block's
+                                               # generation when this batch was written (as_graph refuses a stale one)
         self._kplan = self._t_kplan = None     # register programs of the LDS-resident K-step kernel, or False
         self.iplan = None         # sampled batch: (forward, transposed) device plans of the one-launch interior K-step
                                   # (csrc/gda_interior.inc; built by the device sampler), None where not eligible
@@ -312,6 +315,13 @@ def as_graph(edge_index, num_nodes, edge_weight=None, improved=False, add_self_l
     pre = getattr(edge_index, "_gda_prebuilt", None)   # a sampled batch whose gcn_norm graph the sampler built (sampler.py)
     if (pre is not None and edge_weight is None and not improved and (add_self_loops is True or add_self_loops == 1) and normalize
             and degree_side == "col" and pre.num_nodes == int(num_nodes)):
+        sl = pre._slot
+        if sl is not None and sl.gen != pre._gen:
+            # the batch came out of a recycling loader ring (NeighborLoader(recycle=True)) and the ring has come round:
+            # its block -- node ids, edge list, both CSRs, the K-step plans -- now holds ANOTHER batch's graph
+            raise _lib.GdaError("this mini-batch's graph has been recycled: a batch of NeighborLoader(recycle=True) is "
+                                "valid until prefetch + 4 further batches have been taken from the same loader "
+                                "(keep a batch longer with recycle=False / PYGDA_AMD_LOADER_RECYCLE=0, or clone it)")
         return pre
     g = graph_cache.get(edge_index, num_nodes, edge_weight, improved, add_self_loops, normalize, degree_side)
     if getattr(edge_index, "_gda_static", False):      # tagged by the full-batch loader (pygda_amd/data.py)

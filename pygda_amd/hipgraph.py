@@ -91,7 +91,7 @@ class _DPSamples:
         p = self.pinv[k]
         torch.randint(self.ns, (self.times, self.per), out=p[0])
         torch.randint(self.nt, (self.times, self.per), out=p[1])
-        _mmd.apply_row_maps(p[0], p[1])
+        _mmd.apply_row_maps(p[0], p[1], self.ns, self.nt)
         selection_csr_host(p[0], self.ns, 0, self.per, out=(p[2], p[3]))
         selection_csr_host(p[1], self.nt, 0, self.per, out=(p[4], p[5]))
         self.dev.copy_(self.pin[k], non_blocking=True)
@@ -189,7 +189,7 @@ class GraphedStep:
         pins = e["pinv"][k]
         torch.randint(ns, (times, n), out=pins[0])                  # eager MMD()'s draws, same order,
         torch.randint(nt, (times, n), out=pins[1])                  # straight into pinned memory
-        _mmd.apply_row_maps(pins[0], pins[1])
+        _mmd.apply_row_maps(pins[0], pins[1], ns, nt)
         selection_csr_host(pins[0], ns, 0, 2 * n, out=(pins[2], pins[3]))
         selection_csr_host(pins[1], nt, n, 2 * n, out=(pins[4], pins[5]))
         e["dev"].copy_(e["pin"][k], non_blocking=True)

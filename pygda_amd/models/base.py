@@ -74,9 +74,10 @@ class BaseGDA(ABC):
               dict(dist, device=self.device, full_batch=False if self.force_sampler else None, recycle=True))
         self.source_loader = NeighborLoader(source_data, self.num_neigh, batch_size=sb, **kw)
         self.target_loader = NeighborLoader(target_data, self.num_neigh, batch_size=tb, **kw)
-        from ..utils import mmd as _mmd
+        # MMD draws stay in the caller's numbering: the maps live on THIS trainer and are installed in utils.mmd only
+        # while its own epoch loop runs (_train_epochs), never between fits or for another model
         maps = tuple(None if l.new_id is None else l.new_id.cpu() for l in (self.source_loader, self.target_loader))
-        _mmd.row_maps = maps if any(m is not None for m in maps) else None      # MMD draws stay in the caller's numbering
+        self._mmd_row_maps = maps if any(m is not None for m in maps) else None
 
     def _graph_loaders(self, source_data, target_data):
         """``mode='graph'`` (a2gnn.py:278-286, the same block in grade.py:244-252, udagcn.py:248-256, adagcn.py:244-252,
@@ -87,6 +88,7 @@ class BaseGDA(ABC):
         bs_t = len(target_data) if self.batch_size == 0 else self.batch_size
         self.source_loader = DataLoader(source_data, batch_size=bs_s, shuffle=True)
         self.target_loader = DataLoader(target_data, batch_size=bs_t, shuffle=True)
+        self._mmd_row_maps = None
 
     def _loaders(self, source_data, target_data):
         mode = getattr(self, "mode", "node")
@@ -101,6 +103,11 @@ class BaseGDA(ABC):
         """The epoch loop of a2gnn.py:298-336: ``step_fn(src, tgt, alpha, epoch)`` returns
         ``(loss, source_logits)``; the optimiser step happens here.  ``epochs`` (default
         ``range(self.epoch)``) lets a harness run the same loop in slices."""
+        from ..utils.mmd import scoped_row_maps
+        with scoped_row_maps(getattr(self, "_mmd_row_maps", None)):
+            return self._train_epochs_scoped(net, optimizer, step_fn, alpha_fn, before_step, epochs)
+
+    def _train_epochs_scoped(self, net, optimizer, step_fn, alpha_fn, before_step=None, epochs=None):
         start = time.time()
         _freeze_gc()
         if not getattr(self, "_dp_synced", None) is net:      # data-parallel: one set of initial weights

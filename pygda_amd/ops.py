@@ -210,9 +210,19 @@ def _launch_kstep_interior(graph, x, K, bias, transposed, y):
     n, d = x.shape
     n_int = graph.n_interior
     L = _lib.lib()
-    if aggregation_log is not None:
-        aggregation_log.append((_logged(graph), int(K)))
     plan = _interior_lds_plan(graph, x, y, K, transposed)
+    if aggregation_log is not None:
+        # (graph, K) = the K full aggregations the call stands for (SURVEY 8d's reference-equivalent count); third
+        # element = the entries whose multiply-add this call really EXECUTES.  One-launch path: every entry of the batch
+        # once (the leaf columns' contribution / the leaves' final pass, the leaf rows' unit self loops as one copy) + the
+        # T off-diagonal and n_int diagonal entries of the interior block in each of the other K - 1 steps.  Launch
+        # chain: its K steps walk every entry of the interior rows (skipped ones stay in the chain as w * 0).
+        nnz_h, T = getattr(graph, "_nnz", None), getattr(graph, "iplan_T", None)
+        executed = None
+        if nnz_h is not None:
+            executed = (nnz_h + (int(K) - 1) * (T + n_int) if (plan is not None and T is not None)
+                        else int(K) * (nnz_h - (n - n_int)) + (n - n_int))
+        aggregation_log.append((_logged(graph), int(K), executed))
     _note_path("interior-lds" if plan is not None else "interior-rows", int(K))
     if profiler.enabled:
         # `bytes`: what the call itself has to move -- forward K interior steps + one copy of the leaf rows; transposed K

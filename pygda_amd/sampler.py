@@ -138,7 +138,7 @@ INTERIOR_LDS = _os.environ.get("PYGDA_AMD_INTERIOR_LDS", "1") == "1"
 class _PendingBatch:
     """A batch the device sampler has enqueued: capacity-sized device arrays + the event after which the
     counts ({n_nodes, n_edges, nnz, status, n_interior, verdicts of the two interior K-step plans}) are on the host."""
-    __slots__ = ("nodes", "ei", "csr", "counts_host", "event", "n_seeds", "stream", "short_rows", "plans", "plan_ok")
+    __slots__ = ("nodes", "ei", "csr", "counts_host", "event", "n_seeds", "stream", "short_rows", "plans", "plan_ok", "T_int")
     recycled = False
 
     def wait(self):
@@ -146,8 +146,9 @@ class _PendingBatch:
         return self._sizes(self.counts_host.tolist()[:8])
 
     def _sizes(self, counts):
-        n, e, nnz, status, n_int, ok_f, _, ok_b = (int(v) for v in counts)
+        n, e, nnz, status, n_int, ok_f, t_f, ok_b = (int(v) for v in counts)
         self.plan_ok = (ok_f > 0, ok_b > 0) if self.plans is not None else (False, False)
+        self.T_int = t_f if (self.plans is not None and ok_f > 0) else None      # off-diagonal entries of the interior block
         if status == 2:
             raise _lib.GdaError("gda_dsampler_sample: a seed lies outside [0, num_nodes)")
         if status != 0:
@@ -158,7 +159,7 @@ class _PendingBatch:
 class _Slot(_PendingBatch):
     """A pending batch whose block belongs to a loader's ring (:class:`_Ring`) and is written again ``depth`` batches
     later: the views, the pointers of the one foreign call that fills it and its two events are made ONCE."""
-    __slots__ = ("block", "ring", "done", "free", "freed", "counts_np", "args", "marked", "seeds_pin")
+    __slots__ = ("block", "ring", "done", "free", "freed", "counts_np", "args", "marked", "seeds_pin", "gen")
     recycled = True
 
     def wait(self):
@@ -175,7 +176,13 @@ class _Ring:
     PREVIOUS slot on its stream -- everything it enqueued for that batch is ahead of that record.  With a queue of
     ``prefetch`` batches between the two, depth >= prefetch + 3 guarantees the record precedes the slot's reuse
     (data.py builds prefetch + 4).  The consumer must not read a batch after it has taken the next one from the same
-    loader: the trainers' loops and predict() do not (their outputs and label gathers are new tensors)."""
+    loader: the trainers' loops and predict() do not (their outputs and label gathers are new tensors).
+    Enforced where it can be: every slot counts its generations and the graph of a batch carries the one it was written
+    in -- ``graph.as_graph`` (every conv's entry) raises on a batch whose block has been written again, instead of
+    aggregating over another batch's graph.  Stream requirement: ``assemble()`` must run on a stream that is ordered
+    behind everything the consumer enqueued for the PREVIOUS batch (the trainers run a whole step on the stream that is
+    current when they take the next batch, or join their side streams back into it): the ``free`` record covers that
+    stream only."""
 
     def __init__(self, depth):
         self.depth, self.slots, self.key, self.at, self.last = int(depth), None, None, 0, None
@@ -322,6 +329,7 @@ class DeviceNeighborSampler:
             for e in ev:
                 _lib.check(L.gda_event_create(ctypes.byref(e)), "gda_event_create")
             sl.done, sl.free, sl.freed, sl.marked = ev[0].value, ev[1].value, False, None
+            sl.gen = 0                   # bumped every time the block is written again: batches carry the value they saw
             # gda_dsampler_batch's arguments; [5] = seeds, [10] = generator seed, [25] = wait_event change per batch
             sl.args = [_lib.ptr(self.in_ptr), _lib.ptr(self.in_src), self.num_nodes, self.num_edges, self.max_in_degree,
                        None, int(n_seeds), at("seeds"), fan.ctypes.data, fan.size, None,
@@ -353,6 +361,7 @@ class DeviceNeighborSampler:
         a[10] = ctypes.c_uint64(int(seed) & (2 ** 64 - 1))
         a[25] = sl.free if sl.freed else None
         sl.freed = False
+        sl.gen += 1                      # graphs handed out for the block's previous contents are stale from here on
         _lib.check(_lib.lib().gda_dsampler_batch(*a), "gda_dsampler_batch")
         return sl
 
@@ -450,10 +459,13 @@ class DeviceNeighborSampler:
         g = CSRGraph(n, n + e, rp[:n + 1], ci, va, trp[:n + 1], tci, tva)
         g._nnz = nnz
         g.transient = True
+        if getattr(p, "recycled", False):
+            g._slot, g._gen = p, p.gen
         if n_int is not None and p.short_rows:      # rows [n_int, n): the last hop's discoveries, self loop only
             g.n_interior = int(n_int)
             if p.plans is not None:
                 g.iplan = (p.plans[0] if p.plan_ok[0] else None, p.plans[1] if p.plan_ok[1] else None)
+                g.iplan_T = getattr(p, "T_int", None)
         return g
 
     def assemble(self, data, p, sizes=None):

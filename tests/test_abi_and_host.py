@@ -1058,3 +1058,60 @@ def test_host_thread_pool_stays_inside_the_cpu_quota(tmp_path):
     assert run({"PYGDA_AMD_CPU_THREADS": "2"}) == 2
     assert run({"PYGDA_AMD_CPU_THREADS": "0"}) == 6
     assert run({"PYGDA_AMD_CPU_THREADS": "64"}) == 6          # never more than PyTorch would take
+
+
+def test_mmd_row_maps_are_scoped_to_the_trainer_that_built_them():
+    """the relabelling maps of data.auto_reorder used to stay installed in utils.mmd after a fit and
+    were applied to the draws of whatever ran next.  Now they live on the trainer, are installed for the duration of its
+    own epoch loop only, and a map of another length than the draws' row count is refused."""
+    from pygda_amd.utils import mmd as M
+    assert M.row_maps is None
+    s, t = torch.tensor([[0, 1, 2]]), torch.tensor([[2, 1, 0]])
+    M.apply_row_maps(s, t, 3, 3)                                  # nothing installed: untouched
+    assert s.tolist() == [[0, 1, 2]] and t.tolist() == [[2, 1, 0]]
+    maps = (torch.tensor([2, 0, 1]), None)
+    with M.scoped_row_maps(maps):
+        assert M.row_maps is maps
+        M.apply_row_maps(s, t, 3, 3)
+        assert s.tolist() == [[2, 0, 1]] and t.tolist() == [[2, 1, 0]]
+        with pytest.raises(RuntimeError, match="another trainer"):
+            M.apply_row_maps(torch.tensor([[0, 1]]), t, 5, 3)     # draws over 5 rows, a map of 3
+    assert M.row_maps is None
+    with pytest.raises(ValueError):                               # restored on the way out of an exception too
+        with M.scoped_row_maps(maps):
+            raise ValueError("boom")
+    assert M.row_maps is None
+    with M.scoped_row_maps((None, None)):                         # a pair without maps installs nothing
+        assert M.row_maps is None
+
+    class _T(pygda_amd.models.base.BaseGDA):
+        init_model = process_graph = forward_model = lambda self, *a, **k: None
+
+    tr = _T(4, 4, 2, device="cpu")
+    tr._mmd_row_maps = maps
+    seen = []
+    tr._train_epochs_scoped = lambda *a, **k: seen.append(M.row_maps)
+    tr._train_epochs(None, None, None, None)
+    assert seen == [maps] and M.row_maps is None
+
+
+def test_a_recycled_batch_graph_is_refused_not_silently_reused():
+    """NeighborLoader(recycle=True) hands out views into ring blocks that are written again
+    prefetch + 4 batches later.  A graph carries the generation of its block; once the block has been rewritten,
+    as_graph (the entry of every conv) raises instead of aggregating over another batch's graph."""
+    from pygda_amd.graph import CSRGraph, as_graph
+
+    class Slot:
+        gen = 3
+
+    z = torch.zeros(3, dtype=torch.int32)
+    g = CSRGraph(2, 2, z, z[:2], z[:2].float(), z, z[:2], z[:2].float())
+    g._slot, g._gen = Slot, 3
+    ei = torch.zeros(2, 0, dtype=torch.long)
+    ei._gda_prebuilt = g
+    assert as_graph(ei, 2) is g                       # the block still holds this batch
+    Slot.gen = 4                                      # the ring came round
+    with pytest.raises(pygda_amd._lib.GdaError, match="recycled"):
+        as_graph(ei, 2)
+    g._slot = None                                    # an allocating loader's batch is never stale
+    assert as_graph(ei, 2) is g

@@ -253,7 +253,7 @@ def test_auto_reorder_trains_the_same_model_and_predict_maps_the_rows_back(monke
     """data.auto_reorder: a full-batch A2GNN fit on a large power-law graph runs on the
     degree-ordered relabelling without the caller asking -- here with the size threshold lowered to a 3,000-node Zipf
     graph.  The relabelled run is the SAME training run: MMD draws are made in the caller's numbering and mapped
-    (utils.mmd.row_maps), predict() returns rows in the caller's order; against the run with the reordering switched
+    (the trainer's maps, installed in utils.mmd.row_maps for the duration of its epoch loop), predict() returns rows in the caller's order; against the run with the reordering switched
     off: per-epoch losses 1e-4 relative, logits 1e-4, labels and label order identical."""
     from pygda_amd import data as D
     from pygda_amd.utils import mmd as M
@@ -280,7 +280,8 @@ def test_auto_reorder_trains_the_same_model_and_predict_maps_the_rows_back(monke
         m.epoch_hook = lambda e, loss, acc, secs: seen.append(loss)
         torch.manual_seed(9)
         m.fit(src, tgt)
-        assert (m.target_loader.new_id is not None) == on and (M.row_maps is not None) == on
+        assert (m.target_loader.new_id is not None) == on and (m._mmd_row_maps is not None) == on
+        assert M.row_maps is None                             # installed only while the trainer's own epoch loop runs
         logits, labels = m.predict(tgt)
         runs[on] = (seen, logits, labels)
         exact(labels, tgt.y)                                  # the caller's order
@@ -288,7 +289,6 @@ def test_auto_reorder_trains_the_same_model_and_predict_maps_the_rows_back(monke
     close(runs[True][1], runs[False][1], rtol=0, atol=LOGIT_ATOL)
     exact(runs[True][1].argmax(1), runs[False][1].argmax(1))
     monkeypatch.undo()
-    M.row_maps = None
 
 
 def test_data_parallel_mmd_estimator_has_the_single_process_mean():
