@@ -374,7 +374,7 @@ class GRADEBase(nn.Module):
 
 def grade_forward_model(net: GRADEBase, src: Graph, tgt: Graph, alpha: float,
                         disc: str, weight: float, mmd_chunk_rows=None, mmd_samples=None):
-    """grade.py:129-197 for disc in {'JS', 'MMD'}."""
+    """grade.py:129-197 for disc in {'JS', 'MMD', 'C'}."""
     s_logits, s_feats = net(src)
     t_logits, t_feats = net(tgt)
     loss = F.nll_loss(F.log_softmax(s_logits, dim=1), src.y)
@@ -387,6 +387,16 @@ def grade_forward_model(net: GRADEBase, src: Graph, tgt: Graph, alpha: float,
     elif disc == "MMD":                                                      # :177-182
         m = min(src.x.size(0), tgt.x.size(0)) if net.mode == "node" else min(src.num_graphs, tgt.num_graphs)
         dom = MMD(s_feats[:m], t_feats[:m], chunk_rows=mmd_chunk_rows, samples=mmd_samples)
+    elif disc == "C":                                                        # :183-193
+        # label-conditional: the discriminator sees [features, 8 x one-hot source label] / [features, 8 x softmax of
+        # the target logits] (the softmax is differentiated: the target logits get a gradient through it)
+        ratio = 8
+        eye = torch.eye(net.num_classes)                                     # grade_base.py:183-202
+        s_l_f = torch.cat([s_feats, ratio * eye[src.y]], dim=1)
+        t_l_f = torch.cat([t_feats, ratio * F.softmax(t_logits, dim=1)], dim=1)
+        preds = net.discriminator(grad_reverse(torch.cat([s_l_f, t_l_f], 0), alpha))
+        ns, nt = (src.x.size(0), tgt.x.size(0)) if net.mode == "node" else (src.num_graphs, tgt.num_graphs)
+        dom = F.cross_entropy(preds, torch.tensor([0] * ns + [1] * nt))
     else:
         raise NotImplementedError(disc)
     return loss + dom * weight, s_logits, t_logits
@@ -407,6 +417,78 @@ def a2gnn_train_step(net: A2GNNBase, opt: torch.optim.Optimizer, src: Graph, tgt
     loss.backward()
     opt.step()
     return val, s_logits
+
+
+def neighbor_batches(g: Graph, num_hops: int, batch_size: int) -> List[Graph]:
+    """The batches ``NeighborLoader(data, [-1] * num_hops, batch_size=batch_size)`` (a2gnn.py:260-277, ``shuffle=False``)
+    yields.  PyG's published algorithm for fan-out -1 (no draw is made): seeds ``batch_size`` at a time in node order;
+    hop l expands every node first reached in hop l-1 (hop 1: the seeds), in discovery order, and takes all of its
+    in-edges in CSC order (edge list stably sorted by destination); nodes = seeds first, then discoveries in order;
+    edges relabelled, grouped by destination in expansion order.  ``batch_size >= N``: the graph itself."""
+    n = g.x.size(0)
+    if batch_size >= n:
+        return [g]
+    ei = g.edge_index
+    perm = torch.argsort(ei[1], stable=True)
+    src = ei[0][perm].tolist()
+    ptr = [0] + torch.cumsum(torch.bincount(ei[1], minlength=n), 0).tolist()
+    out = []
+    for start in range(0, n, batch_size):
+        nodes = list(range(start, min(start + batch_size, n)))
+        local = {v: i for i, v in enumerate(nodes)}
+        frontier, rows, cols = list(nodes), [], []
+        for _ in range(num_hops):
+            reached = []
+            for v in frontier:
+                for u in src[ptr[v]:ptr[v + 1]]:
+                    if u not in local:
+                        local[u] = len(nodes)
+                        nodes.append(u)
+                        reached.append(u)
+                    rows.append(local[u])
+                    cols.append(local[v])
+            frontier = reached
+        n_id = torch.tensor(nodes, dtype=torch.long)
+        out.append(Graph(g.x[n_id], torch.tensor([rows, cols], dtype=torch.long).reshape(2, -1), g.y[n_id]))
+    return out
+
+
+def a2gnn_fit(net: A2GNNBase, opt: torch.optim.Optimizer, src_batches: List[Graph], tgt_batches: List[Graph], epochs: int,
+              s_pnums: int, t_pnums: int, adv: bool, weight: float):
+    """The epoch loop of a2gnn.py:298-336 over given loaders' batches: per epoch alpha = 2 / (1 + e^{-10 p}) - 1 (:305-306),
+    ``zip`` of the two loaders (:308: stops at the shorter one), one optimiser step per pair, ``epoch_loss`` = sum of
+    ``loss.item()`` (:315), micro-F1 of the concatenated WHOLE-batch source logits (:321-330; single-label micro-F1 =
+    accuracy).  Returns (losses, accs)."""
+    losses, accs = [], []
+    for epoch in range(epochs):
+        alpha = 2. / (1. + math.exp(-10. * float(epoch) / epochs)) - 1
+        tot, logits, labels = 0.0, [], []
+        for sb, tb in zip(src_batches, tgt_batches):
+            val, s_logits = a2gnn_train_step(net, opt, sb, tb, alpha, s_pnums, t_pnums, adv, weight)
+            tot += val
+            logits.append(s_logits.detach())
+            labels.append(sb.y)
+        losses.append(tot)
+        accs.append(float((torch.cat(logits).argmax(1) == torch.cat(labels)).double().mean()))
+    return losses, accs
+
+
+def a2gnn_predict(net: A2GNNBase, batches: List[Graph], pnums: int):
+    """``A2GNN.predict`` as written (a2gnn.py:384-411), its multi-batch behaviour included: for ``idx > 0`` the fresh
+    ``logits`` OVERWRITES the accumulated one before it is concatenated with itself (:402-405 / :413-416), so with B > 1
+    batches the result is the LAST batch's logits twice, beside the labels of ALL batches (whole batches: seeds and
+    their sampled neighbours).  One batch: (logits, labels) of that batch."""
+    net.eval()
+    logits = labels = None
+    with torch.no_grad():
+        for idx, b in enumerate(batches):
+            logits_b = net(b, pnums)
+            if idx == 0:
+                logits, labels = logits_b, b.y
+            else:
+                logits = torch.cat((logits_b, logits_b))
+                labels = torch.cat((labels, b.y))
+    return logits, labels
 
 
 # ----------------------------------------------------------------------------

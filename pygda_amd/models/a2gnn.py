@@ -308,8 +308,10 @@ class A2GNN(BaseGDA):
     def process_graph(self, data):
         pass
 
-    def predict(self, data, source=False):
-        """``data`` is ignored, as in the reference: the loaders stored by fit() are replayed."""
+    def predict(self, data, source=False, reference_compat=None):
+        """``data`` is ignored, as in the reference: the loaders stored by fit() are replayed.  ``reference_compat``
+        (keyword, not in the reference): with several batches return what a2gnn.py:402-409 literally return instead of
+        every node once -- see ``BaseGDA._predict_loader``; None = the trainer's ``reference_predict`` setting."""
         self.a2gnn.eval()
         loader, k = (self.source_loader, self.s_pnums) if source else (self.target_loader, self.t_pnums)
-        return self._predict_loader(loader, lambda batch: self.a2gnn(batch, k))
+        return self._predict_loader(loader, lambda batch: self.a2gnn(batch, k), reference_compat)

@@ -38,6 +38,12 @@ class BaseGDA(ABC):
         self.use_hip_graph = kwargs.pop("use_hip_graph", None)
         # tests: route even a whole-graph request (fan-out -1, batch_size >= N) through the sampler
         self.force_sampler = kwargs.pop("force_sampler", False)
+        # predict() over SEVERAL batches: False (default) = every node once, the seeds' rows of every batch in loader order;
+        # True = what the reference's loop literally returns (a2gnn.py:402-409, the same lines in every trainer): the
+        # LAST batch's whole-batch logits twice beside the labels of all batches.  One batch: identical either way.
+        # (``reference_predict=True`` here, ``predict(..., reference_compat=True)`` per call, or PYGDA_AMD_REFERENCE_PREDICT=1)
+        import os
+        self.reference_predict = bool(kwargs.pop("reference_predict", os.environ.get("PYGDA_AMD_REFERENCE_PREDICT", "0") == "1"))
         self.kwargs = kwargs
 
     # -- API of the reference -------------------------------------------------------
@@ -307,19 +313,34 @@ class BaseGDA(ABC):
             return mean_local
         return global_mean(mean_local, n_local)
 
-    def _predict_loader(self, loader, forward):
-        """predict() of the reference (a2gnn.py:384-411) keeps only the last batch when the
-        loader has several (:402-409 overwrite ``logits`` before concatenating it with itself);
-        here every batch's rows are returned, in loader order.  Identical for one batch."""
+    def _predict_loader(self, loader, forward, reference_compat=None):
+        """predict() of the reference (a2gnn.py:384-411) over the loader fit() stored.
+
+        One batch (every benchmark setting of the reference): that batch's logits and labels, as in the reference.
+        Several batches, default: every node exactly once -- the seeds' rows of every batch, in loader order (what the
+        docstring of the reference's predict() describes: "concatenates results for full predictions").
+        Several batches, ``reference_compat=True``: what the reference's loop RETURNS -- its ``idx > 0`` branch assigns
+        the fresh ``logits`` before concatenating "the accumulated logits" with it (:402-405, :413-416), so the result is
+        the LAST batch's whole-batch logits (seeds and sampled neighbours) twice, beside the labels of ALL batches
+        (whole batches): ``logits.shape[0] != labels.shape[0]`` in general.  Tested against a reference-run golden
+        (``a2gnn_fit3_mb_*.npz``); the default's deviation is deliberate and is exactly this."""
+        compat = self.reference_predict if reference_compat is None else bool(reference_compat)
         outs, labs = [], []
         with torch.no_grad():
             for batch in loader:
                 batch = batch.to(self.device)
                 out = forward(batch)
-                k = getattr(batch, "batch_size", None)
-                outs.append(out if k is None else out[:k])
-                labs.append(batch.y if k is None else batch.y[:k])
-        out, lab = torch.cat(outs), torch.cat(labs)
+                k = None if compat else getattr(batch, "batch_size", None)
+                if compat:
+                    outs = [out]                  # :402 / :413 -- `logits = self.a2gnn(...)` replaces what was accumulated
+                    labs.append(batch.y)
+                else:
+                    outs.append(out if k is None else out[:k])
+                    labs.append(batch.y if k is None else batch.y[:k])
+        if compat and len(labs) > 1:
+            out, lab = torch.cat((outs[0], outs[0])), torch.cat(labs)        # :405 / :416
+        else:
+            out, lab = torch.cat(outs), torch.cat(labs)
         new_id = getattr(loader, "new_id", None)
         if new_id is not None:                   # the loader trains on a degree-ordered relabelling (data.auto_reorder):
             new_id = new_id.to(out.device)       # row new_id[i] of its batch is node i of the caller's numbering

@@ -62,6 +62,15 @@ boundary" (the MMD / GradReverse / Attention goldens do not go through it).
        LAST; per edge j -> i: e = leaky_relu(a_s[j] + a_d[i], 0.2); softmax over the incoming edges of i as
        ``exp(e - max_i) / (sum_i exp(e - max_i) + 1e-16)`` (max taken on the detached scores); out_i = sum alpha h_j
        (scatter-sum in edge order), mean over the one head, + bias.
+14. (round 6; multi-batch node mode only) ``NeighborLoader(data, [-1]*L, batch_size=B)`` with B < N, ``shuffle=False``:
+    seeds are taken B at a time in node order (the last batch is short).  A batch is the L-hop IN-neighbourhood of its
+    seeds: hop l expands, in discovery order, every node first reached in hop l-1 (hop 1: the seeds) and takes ALL of
+    its in-edges (fan-out -1) in the order of the CSC PyG builds with a stable sort of the edge list by destination
+    (``to_csc`` / ``index_sort``: inside one destination, input edge order; duplicate edges are kept as often as they
+    occur).  Nodes: the seeds first, then newly reached nodes in discovery order; ``edge_index`` relabelled to that
+    numbering, grouped by destination in expansion order (nodes reached in the LAST hop are never expanded: they
+    have no in-edges in the batch); ``x`` / ``y`` = the rows of ``n_id``; ``batch_size`` = the number of seeds.
+    Deterministic (no draw is made for fan-out -1), which is why the multi-batch goldens use it.
 10. (reweight_gnn.py / strurw.py only) ``MessagePassing(aggr='mean', flow='target_to_source')``:
     messages from ``x[edge_index[1]]`` averaged at ``edge_index[0]`` over the number of messages;
     ``update`` receives the propagate kwargs it names; ``to_dense_adj`` sums duplicate edges;
@@ -461,17 +470,48 @@ def random_walk(row, col, start, walk_length, p=1, q=1, coalesced=True, num_node
 
 
 class NeighborLoader:
-    """Full-batch only (assumption 6)."""
+    """Full batch (assumption 6), or seed mini-batches with whole neighbourhoods (fan-out -1, assumption 14)."""
 
     def __init__(self, data, num_neighbors, batch_size=1, **kw):
-        assert all(k == -1 for k in num_neighbors) and batch_size >= data.x.size(0)
-        self.data = data
-
-    def __iter__(self):
-        yield self.data
+        assert all(k == -1 for k in num_neighbors), "the stub samples nothing: fan-out -1 only"
+        assert not kw.get("shuffle", False)
+        self.data, self.hops, self.batch_size = data, len(num_neighbors), int(batch_size)
 
     def __len__(self):
-        return 1
+        n = self.data.x.size(0)
+        return 1 if self.batch_size >= n else -(-n // self.batch_size)
+
+    def __iter__(self):
+        data = self.data
+        n = data.x.size(0)
+        if self.batch_size >= n:
+            yield data
+            return
+        ei = data.edge_index
+        perm = torch.argsort(ei[1], stable=True)                  # CSC: by destination, input order inside one
+        src = ei[0][perm].tolist()
+        ptr = [0] + torch.cumsum(torch.bincount(ei[1], minlength=n), 0).tolist()
+        for start in range(0, n, self.batch_size):
+            nodes = list(range(start, min(start + self.batch_size, n)))
+            n_seeds = len(nodes)
+            local = {v: i for i, v in enumerate(nodes)}
+            frontier, rows, cols = list(nodes), [], []
+            for _ in range(self.hops):
+                reached = []
+                for v in frontier:
+                    for u in src[ptr[v]:ptr[v + 1]]:
+                        if u not in local:
+                            local[u] = len(nodes)
+                            nodes.append(u)
+                            reached.append(u)
+                        rows.append(local[u])
+                        cols.append(local[v])
+                frontier = reached
+            n_id = torch.tensor(nodes, dtype=torch.long)
+            b = Data(x=data.x[n_id], edge_index=torch.tensor([rows, cols], dtype=torch.long).reshape(2, -1),
+                     y=data.y[n_id])
+            b.n_id, b.batch_size = n_id, n_seeds
+            yield b
 
 
 class Batch(Data):

@@ -268,7 +268,7 @@ def fx_a2gnn(ref):
 
 def fx_grade(ref):
     s, t = _domain_pair(61)
-    for disc in ("JS", "MMD"):
+    for disc in ("JS", "MMD", "C"):         # 'C': the label-conditional discriminator (grade.py:183-193)
         m = ref.GRADE(24, 8, 5, num_layers=3, dropout=0.0, disc=disc, weight=0.01, device="cpu",
                       epoch=3, verbose=0)
         torch.manual_seed(71)
@@ -995,6 +995,43 @@ def fx_gnn_convs(ref):
 
 
 FIXTURES["gnn_convs"] = fx_gnn_convs
+
+
+def fx_a2gnn_minibatch(ref):
+    """The reference's OWN multi-batch loop (a2gnn.py:260-277 loaders, :308-336 step loop, :384-411 predict) with
+    ``batch_size=128`` on 300 / 200 nodes: 3 source and 2 target batches, so ``zip`` runs TWO steps per epoch and never
+    sees the third source batch; ``epoch_loss`` sums ``loss.item()`` per batch, the epoch's micro-F1 is taken over the
+    concatenated whole-batch logits (seeds AND their neighbours), and ``predict()`` returns what :402-409 make of
+    several batches -- the LAST batch's logits twice (the ``idx > 0`` branch overwrites ``logits`` before concatenating
+    it with itself) beside the labels of ALL batches.  Batches: ``_pyg_stub.NeighborLoader`` assumption 14 (fan-out -1:
+    whole 2-hop in-neighbourhoods, no draw).  Three epochs from a fixed seed, MMD and adversarial."""
+    s, t = _domain_pair(31)
+    import pygda.models.a2gnn as a2mod
+    losses, accs = [], []
+    orig = a2mod.logger
+    a2mod.logger = lambda **kw: (losses.append(kw["loss"]), accs.append(kw["source_train_acc"]))
+    try:
+        for adv in (False, True):
+            losses.clear(); accs.clear()
+            m = ref.A2GNN(24, 16, 5, num_layers=2, dropout=0.0, s_pnums=0, t_pnums=10, adv=adv, weight=10, lr=0.01,
+                          weight_decay=0.005, device="cpu", epoch=3, batch_size=128, verbose=0)
+            torch.manual_seed(51)
+            m.fit(s, t)
+            assert len(m.source_loader) == 3 and len(m.target_loader) == 2
+            logits, labels = m.predict(t)
+            slogits, slabels = m.predict(s, source=True)
+            arrs = dict(_pair_arrays(s, t), seed=np.int64(51), batch_size=np.int64(128),
+                        losses=np.array(losses, dtype=np.float64), accs=np.array(accs, dtype=np.float64),
+                        tgt_logits=np_(logits), tgt_labels=np_(labels), src_logits=np_(slogits), src_labels=np_(slabels),
+                        tgt_batch_nodes=np.array([b.x.size(0) for b in m.target_loader], dtype=np.int64),
+                        src_batch_nodes=np.array([b.x.size(0) for b in m.source_loader], dtype=np.int64))
+            arrs.update(sd_arrays(m.a2gnn, "final/"))
+            save("a2gnn_fit3_mb_adv" if adv else "a2gnn_fit3_mb_mmd", **arrs)
+    finally:
+        a2mod.logger = orig
+
+
+FIXTURES["a2gnn_minibatch"] = fx_a2gnn_minibatch
 
 
 def main(argv):

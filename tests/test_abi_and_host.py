@@ -1115,3 +1115,32 @@ def test_a_recycled_batch_graph_is_refused_not_silently_reused():
         as_graph(ei, 2)
     g._slot = None                                    # an allocating loader's batch is never stale
     assert as_graph(ei, 2) is g
+
+
+def test_predict_over_several_batches_default_and_reference_compat():
+    """a6: predict() with several batches.  Default: every node once (the seeds' rows of each batch, loader order).
+    ``reference_compat=True``: the return value of a2gnn.py:402-409 -- the last batch's whole-batch logits twice beside
+    all batches' labels (pinned to a reference-run golden on the GPU: test_multi_batch_fit_and_predict_against_the_
+    reference_run).  One batch: identical."""
+    from pygda_amd.data import Data
+
+    class _T(pygda_amd.models.base.BaseGDA):
+        init_model = process_graph = forward_model = lambda self, *a, **k: None
+
+    def batch(lo, hi, extra):
+        ids = list(range(lo, hi)) + extra
+        return Data(x=torch.tensor(ids, dtype=torch.float32).reshape(-1, 1), y=torch.tensor(ids), batch_size=hi - lo)
+
+    loader = [batch(0, 3, [7, 8]), batch(3, 6, [0]), batch(6, 7, [1, 2, 3])]
+    fwd = lambda b: b.x * 10.0
+    tr = _T(4, 4, 2, device="cpu")
+    assert tr.reference_predict is False
+    out, lab = tr._predict_loader(loader, fwd)
+    assert lab.tolist() == list(range(7)) and out.reshape(-1).tolist() == [10.0 * i for i in range(7)]
+    out, lab = tr._predict_loader(loader, fwd, reference_compat=True)
+    assert out.reshape(-1).tolist() == [60.0, 10.0, 20.0, 30.0] * 2                    # the LAST batch, twice
+    assert lab.tolist() == [0, 1, 2, 7, 8, 3, 4, 5, 0, 6, 1, 2, 3]                     # every batch's labels
+    one = loader[:1]
+    a, b = tr._predict_loader(one, fwd), tr._predict_loader(one, fwd, reference_compat=True)
+    assert a[1].tolist() == [0, 1, 2] and b[1].tolist() == [0, 1, 2, 7, 8]             # (seed rows vs the whole batch)
+    assert _T(4, 4, 2, device="cpu", reference_predict=True).reference_predict is True

@@ -23,7 +23,7 @@ from pygda_amd.data import Data
 from pygda_amd.graph import build_csr
 from pygda_amd.sampler import NeighborSampler
 from oracle import pygda_cpu as O
-from tests.conftest import T, load_golden
+from tests.conftest import T, load_golden, sub
 from tests.test_gpu_parity import DEV, LOGIT_ATOL, REL, _no_dropout, _pair, close, exact
 
 pytestmark = pytest.mark.gpu
@@ -151,6 +151,53 @@ def test_minibatch_path_fit_golden(monkeypatch, which, dp):
     close(logits, g[pre + "tgt_logits"], rtol=0, atol=LOGIT_ATOL)
     exact(labels, g[pre + "tgt_labels"])
     exact(logits.argmax(1), g[pre + "tgt_logits"].argmax(1))
+
+
+@pytest.mark.parametrize("adv", [False, True])
+def test_multi_batch_fit_and_predict_against_the_reference_run(adv):
+    """``batch_size=128`` on 300 / 200 nodes at fan-out -1 -- the reference's own multi-batch
+    loop recorded in ``a2gnn_fit3_mb_*.npz`` (zip of 3 source and 2 target batches = two steps per epoch, loss.item()
+    summed per batch, micro-F1 over the concatenated whole-batch logits; predict() of several batches).  Our loader's
+    batches ARE the reference's (tests/test_sampler_host.py compares them with the stub's, bit for bit), so the HIP
+    trainer must log the same three epochs and end at the same weights; ``predict(reference_compat=True)`` returns what
+    a2gnn.py:402-409 return (the last batch's logits twice beside every batch's labels); the default returns every
+    node once, and the difference between the two is exactly that overwrite."""
+    g = load_golden("a2gnn_fit3_mb_adv" if adv else "a2gnn_fit3_mb_mmd")
+    s, t = _pair(g)
+    m = pygda_amd.models.A2GNN(24, 16, 5, num_layers=2, dropout=0.0, s_pnums=0, t_pnums=10, adv=adv, weight=10, lr=0.01,
+                               weight_decay=0.005, device=DEV, epoch=3, batch_size=int(g["batch_size"]), verbose=0)
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append((float(loss), acc))
+    torch.manual_seed(int(g["seed"]))
+    m.fit(s, t)
+    assert len(m.source_loader) == 3 and len(m.target_loader) == 2
+    close([x[0] for x in seen], g["losses"], rtol=REL)
+    close([x[1] for x in seen], g["accs"], rtol=0, atol=1e-12)
+    for k, v in sub(g, "final/").items():
+        close(m.a2gnn.state_dict()[k], v, rtol=1e-3, atol=1e-4 * max(np.abs(v).max(), 1e-3))
+    # the reference's return value, bug and all
+    logits, labels = m.predict(t, reference_compat=True)
+    assert tuple(logits.shape) == g["tgt_logits"].shape and tuple(labels.shape) == g["tgt_labels"].shape
+    close(logits, g["tgt_logits"], rtol=0, atol=LOGIT_ATOL)
+    exact(labels, g["tgt_labels"])
+    slogits, slabels = m.predict(s, source=True, reference_compat=True)
+    close(slogits, g["src_logits"], rtol=0, atol=LOGIT_ATOL)
+    exact(slabels, g["src_labels"])
+    # the default: every node once, in node order (seed batches in loader order) ...
+    dl, dy = m.predict(t)
+    assert tuple(dl.shape) == (t.x.size(0), 5)
+    exact(dy, t.y)
+    # ... and the two differ by exactly the overwrite: the compat result is the LAST batch's whole-batch logits twice,
+    # whose first rows (its seeds) are the default's last rows
+    n_last = int(g["tgt_batch_nodes"][-1])
+    seeds_last = t.x.size(0) - int(g["batch_size"]) * (len(g["tgt_batch_nodes"]) - 1)
+    assert logits.size(0) == 2 * n_last
+    exact(logits[:n_last], logits[n_last:])
+    exact(logits[:seeds_last], dl[-seeds_last:])
+    # the trainer-level switch says the same
+    m.reference_predict = True
+    l2, y2 = m.predict(t)
+    exact(l2, logits); exact(y2, labels)
 
 
 @pytest.mark.parametrize("which", ["udagcn", "adagcn"])

@@ -442,7 +442,7 @@ def test_a2gnn_fit_golden_as_three_graphs(monkeypatch):
     exact(logits.argmax(1), g["tgt_logits"].argmax(1))
 
 
-@pytest.mark.parametrize("disc", ["JS", "MMD"])
+@pytest.mark.parametrize("disc", ["JS", "MMD", "C"])
 def test_grade_forward_model_golden(disc):
     g = load_golden(f"grade_forward_{disc.lower()}")
     s, t = _pair(g)

@@ -170,6 +170,33 @@ def test_a2gnn_fit_trajectory(adv):
         eq(net(tgt, 10), g["tgt_logits"]); eq(net(src, 0), g["src_logits"])
 
 
+@pytest.mark.parametrize("adv", [False, True])
+def test_a2gnn_multi_batch_fit_and_predict_as_the_reference_runs_them(adv):
+    """the reference's OWN multi-batch loop (batch_size=128 on 300 / 200 nodes: zip of 3 source
+    and 2 target batches = two steps per epoch, per-batch loss.item() sums, whole-batch logits in the epoch's micro-F1)
+    and its predict() with several batches (a2gnn.py:402-409: the last batch's logits twice beside every batch's
+    labels), recorded from the reference's files -- the oracle's restatements reproduce all of it bit for bit."""
+    g = load_golden("a2gnn_fit3_mb_adv" if adv else "a2gnn_fit3_mb_mmd")
+    src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))
+    tgt = O.Graph(T(g["tgt_x"]), T(g["tgt_ei"]), T(g["tgt_y"]))
+    sb, tb = O.neighbor_batches(src, 2, int(g["batch_size"])), O.neighbor_batches(tgt, 2, int(g["batch_size"]))
+    assert [b.x.size(0) for b in sb] == g["src_batch_nodes"].tolist()
+    assert [b.x.size(0) for b in tb] == g["tgt_batch_nodes"].tolist()
+    torch.manual_seed(int(g["seed"]))
+    net = O.A2GNNBase(24, 16, 5, num_layers=2, adv=adv, dropout=0.0)
+    opt = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=0.005)
+    losses, accs = O.a2gnn_fit(net, opt, sb, tb, 3, 0, 10, adv, 10)
+    eq(np.array(losses), g["losses"])
+    np.testing.assert_allclose(accs, g["accs"], atol=1e-12)
+    for k, v in sub(g, "final/").items():
+        eq(net.state_dict()[k], v)
+    logits, labels = O.a2gnn_predict(net, tb, 10)
+    eq(logits, g["tgt_logits"]); eq(labels, g["tgt_labels"])
+    assert logits.size(0) == 2 * tb[-1].x.size(0) and labels.numel() == sum(b.x.size(0) for b in tb)
+    slogits, slabels = O.a2gnn_predict(net, sb, 0)
+    eq(slogits, g["src_logits"]); eq(slabels, g["src_labels"])
+
+
 def _graph_dataset(g, prefix):
     return [O.Graph(T(g[f"{prefix}/{i}/x"]), T(g[f"{prefix}/{i}/ei"]), T(g[f"{prefix}/{i}/y"]))
             for i in range(int(g[f"{prefix}/count"]))]
@@ -226,7 +253,7 @@ def test_a2gnn_graph_mode_fit_trajectory(batch_size):
                 eq(net(tb, 5), g["tgt_logits"]); eq(tb.y, g["tgt_labels"])
 
 
-@pytest.mark.parametrize("disc", ["JS", "MMD"])
+@pytest.mark.parametrize("disc", ["JS", "MMD", "C"])
 def test_grade_forward_model(disc):
     g = load_golden(f"grade_forward_{disc.lower()}")
     src = O.Graph(T(g["src_x"]), T(g["src_ei"]), T(g["src_y"]))

@@ -197,3 +197,28 @@ def test_sampled_batches_are_pinned():
             n_id, sub = S.sample(seeds, list(fan), seed=seed)
             assert (n_id.numel(), sub.size(1)) == (nn, ne)
             assert hashlib.sha1(n_id.numpy().tobytes() + sub.numpy().tobytes()).hexdigest() == digest, (fan, seed, threads)
+
+
+def test_fanout_minus_one_batches_are_the_stub_loaders_batches():
+    """The multi-batch goldens (``a2gnn_fit3_mb_*.npz``) were recorded from the reference's loop over
+    ``tests/golden/_pyg_stub.NeighborLoader`` (assumption 14: PyG's published fan-out -1 algorithm -- seeds in node
+    order, hop-wise expansion in discovery order, in-edges in stable CSC order).  The product's loader and the oracle's
+    ``neighbor_batches`` hand out the SAME batches, bit for bit: node order (the MMD's row draws index it), edge order
+    (fp32 summation order), features, labels, seed counts -- on graphs with duplicate edges, self loops and an isolated
+    node, with a short last batch."""
+    from oracle import pygda_cpu as O
+    from pygda_amd.data import Data, NeighborLoader
+    from tests.conftest import T, load_golden
+    from tests.golden import _pyg_stub as S
+    g = load_golden("a2gnn_fit3_mb_mmd")
+    for dom in ("src", "tgt"):
+        x, ei, y = T(g[f"{dom}_x"]), T(g[f"{dom}_ei"]), T(g[f"{dom}_y"])
+        stub = list(S.NeighborLoader(S.Data(x=x, edge_index=ei, y=y), [-1, -1], batch_size=int(g["batch_size"])))
+        ours = list(NeighborLoader(Data(x=x, edge_index=ei, y=y), [-1, -1], batch_size=int(g["batch_size"])))
+        orac = O.neighbor_batches(O.Graph(x, ei, y), 2, int(g["batch_size"]))
+        assert [b.x.size(0) for b in stub] == g[f"{dom}_batch_nodes"].tolist()
+        assert len(stub) == len(ours) == len(orac) > 1
+        for a, b, c in zip(stub, ours, orac):
+            assert torch.equal(a.n_id, b.n_id) and a.batch_size == b.batch_size
+            assert torch.equal(a.edge_index, b.edge_index) and torch.equal(a.edge_index, c.edge_index)
+            assert torch.equal(a.x, b.x) and torch.equal(a.x, c.x) and torch.equal(a.y, b.y) and torch.equal(a.y, c.y)
