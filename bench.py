@@ -318,8 +318,18 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
     kw = dict(rank=rank, world_size=world, device=dev, recycle=True)         # as BaseGDA._node_loaders builds them
     model.source_loader = NeighborLoader(src, fan, batch_size=args.batch, input_nodes=seeds_s, **kw)
     model.target_loader = NeighborLoader(tgt, fan, batch_size=args.batch, input_nodes=seeds_t, **kw)
-    it = zip(iter(model.source_loader), iter(model.target_loader))
+    if args.eager:
+        model.use_hip_graph = False
+    # the step replayed at ONE static shape (pygda_amd/sampled_graph.py: what fit() does for sampled A2GNN training on
+    # one GPU); None -> eager launches (--eager, data-parallel runs, PYGDA_AMD_SAMPLED_GRAPH=0)
+    model._declare_static_shape(model.source_loader, model.target_loader)
+    stepper = model._sampled_stepper(net, optimizer, step_fn)
+    raw_its = (model.source_loader.iter_raw(), model.target_loader.iter_raw()) if stepper is not None else (None, None)
+    if raw_its[0] is None or raw_its[1] is None:
+        stepper = None
+    it = zip(*raw_its) if stepper is not None else zip(iter(model.source_loader), iter(model.target_loader))
     from pygda_amd.models.base import _allreduce_grads
+    step_sizes = []          # captured steps log no aggregation calls: their edge counts come from the batches' live sizes
 
     phases = []              # per step: host seconds in (loader hand-over, forward, backward, exchange + optimiser)
 
@@ -340,6 +350,15 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
         h0 = time.perf_counter()
         s, t = next(it)
         h1 = time.perf_counter()
+        if stepper is not None:
+            (ps, zs), (pt, zt) = s, t
+            ticket = stepper.step(ps, zs, pt, zt)
+            if ticket is not None:
+                step_sizes.append((zs, ps.T_int, zt, pt.T_int))
+                phases.append((h1 - h0, time.perf_counter() - h1, 0.0, 0.0))
+                return stepper.stats
+            s = model.source_loader._sampler.assemble(model.source_loader.data, ps, zs)      # a pair the static shape
+            t = model.target_loader._sampler.assemble(model.target_loader.data, pt, zt)      # cannot take: eager, real shape
         ops.dropout_state.next_step(s.x.device)
         net.train()
         loss, _ = step_fn(s, t, 0.0, 0)
@@ -366,6 +385,9 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
     ops.aggregation_log = []
     sync()
     phases.clear()
+    step_sizes.clear()
+    if stepper is not None:
+        stepper.host_wait_s = stepper.host_work_s = 0.0
     gc.disable()                 # a generation-2 pass of the cyclic collector is milliseconds; the steps are 3 ms
     ms0 = torch.cuda.memory_stats(dev)
     allocs0 = ms0.get("num_device_alloc", 0)
@@ -415,6 +437,10 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
     # unit self loops nor the leaf columns' constant contribution per step) -- `value` is the executed one
     edges_ref = sum(e[0].nnz * e[1] for e in log)
     edges = sum((e[2] if len(e) > 2 and e[2] is not None else e[0].nnz * e[1]) for e in log)
+    for zs, ts_, zt, tt_ in step_sizes:          # the replayed steps, from their batches' live sizes
+        r, d_ = stepper.edges_of(zs, ts_, zt, tt_)
+        edges_ref += r
+        edges += d_
     if args.profile_run:
         if rank != 0:
             return None
@@ -527,7 +553,14 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                        "note": "value counts the entries whose multiply-add the step EXECUTES: the interior-rows "
                                "K-step paths do the leaf rows' unit self loops and the leaf columns' contribution once per "
                                "call, not once per step; reference_equivalent counts every call as K full aggregations",
-                       "final_loss": float(loss.detach()),
+                       "final_loss": float(loss.detach().reshape(-1)[0]),
+                       "execution": ("eager launches" if stepper is None else
+                                     "hipGraph replay of the step captured at its static capacity shape (single stream): "
+                                     f"{stepper.replays} replays, {stepper.fallbacks} eager fall-backs; rows per matrix "
+                                     f"{stepper.static[0].ncap} + {stepper.static[1].ncap} (capacity) for "
+                                     f"{int(sum(z[0][0] for z in step_sizes) / max(len(step_sizes), 1))} + "
+                                     f"{int(sum(z[2][0] for z in step_sizes) / max(len(step_sizes), 1))} live ones"
+                                     if stepper.static is not None else "eager launches (static shape declined)"),
                        "host_ms_per_step_max_median": [max(host_ms), sorted(host_ms)[len(host_ms) // 2]],
                        "host_cpu_ms_per_step_median": sorted(host_cpu_ms)[len(host_cpu_ms) // 2],
                        "host_phases": host_phases,
@@ -536,6 +569,11 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                        "producer_enqueue_cpu_ms_per_batch": [1e3 * getattr(l, "producer_enqueue_cpu_s", 0.0) / max(getattr(l, "producer_batches", 0), 1)
                                                              for l in timed_loaders],
                        "hipMalloc_calls_in_timed_region": device_allocs,
+                       # captured steps: the training thread's time inside step() split into event waits (the device is
+                       # behind: back-pressure, not work) and everything else -- draws, counting sorts, two block copies,
+                       # the graph launch.  `host_ms_per_step_max_median` above includes the waits.
+                       "host_work_ms_per_step": None if stepper is None else 1e3 * stepper.host_work_s / max(len(step_sizes), 1),
+                       "host_wait_ms_per_step": None if stepper is None else 1e3 * stepper.host_wait_s / max(len(step_sizes), 1),
                        "aggregation_launches_per_step": sum(prof[k]["launches"] for k in agg) / prof_steps,
                        "aggregation_paths": {k: prof[k]["launches"] / prof_steps for k in sorted(agg)},
                        "sampler": model.source_loader.sampler_description(),

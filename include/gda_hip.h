@@ -190,6 +190,16 @@ int gda_interior_kstep_lds_f32(const int32_t* rowptr, const int32_t* colidx, con
                                int64_t n_rows, int64_t n_int, int64_t d, int K, int transposed,
                                const void* plan, const float* x, float* y, const float* bias,
                                void* workspace, size_t workspace_bytes, gda_stream_t stream);
+/* The forward call with the conv layer's activation (pygda/nn/a2gnn_base.py:135-138: relu, then inverted dropout) in its
+ * epilogue: y0 = dropout_{site0}(relu(A^K x + bias)); y1 (may be NULL) = dropout_{site1}(relu(the same values)) -- a second,
+ * independent draw for the trainer's second pass over a shared layer-0 output.  The values gda_relu_dropout_fwd_f32 would
+ * produce from gda_interior_kstep_lds_f32's result with the same (seed, step, site); the pre-activation is not stored
+ * (gda_relu_dropout_bwd_f32 needs y > 0 only).  p <= 0: relu only. */
+int gda_interior_kstep_lds_act_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                                   int64_t n_rows, int64_t n_int, int64_t d, int K, const void* plan,
+                                   const float* x, float* y0, float* y1, const float* bias,
+                                   float p, uint64_t seed, const int64_t* step_dev, uint32_t site0, uint32_t site1,
+                                   void* workspace, size_t workspace_bytes, gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
  * K-step aggregation in ONE launch for graphs whose feature columns fit a CU's LDS
@@ -487,6 +497,11 @@ size_t gda_relu_dropout_pair_workspace_bytes(int64_t d);
 int gda_relu_dropout_pair_bwd_f32(const float* gy, const float* y, float* gx, int64_t n, int64_t d, float p,
                                   float* colsum, void* workspace, size_t workspace_bytes, gda_stream_t stream);
 int gda_stack2_f32(const float* a, const float* b, float* out, int64_t half_elems, gda_stream_t stream);
+/* The backward of `relu_dropout` followed by a split into halves, in one pass: gx [2 * half_elems] = mask(y) * [ga ; gb]
+ * / (1 - p) with mask = (y > 0) -- gda_stack2_f32 and gda_relu_dropout_bwd_f32 without the unmasked stack in between
+ * (a NULL half reads as zeros). */
+int gda_relu_dropout_bwd2_f32(const float* ga, const float* gb, const float* y, float* gx, int64_t half_elems,
+                              float p, gda_stream_t stream);
 
 /* Column sums of a row-major [n, d] matrix (ld = ldx): the bias gradient `gy.sum(0)` of a conv layer
  * (out += self.bias, pygda/nn/prop_gcn_conv.py:212-213) as a deterministic two-stage sum; d <= 1024. */
@@ -625,6 +640,19 @@ int gda_dsampler_batch(const int64_t* in_ptr, const int32_t* in_src, int64_t N, 
                        int64_t* counts, void* plan_fwd, void* plan_bwd, size_t plan_bytes,
                        int64_t* counts_host, void* wait_event, void* done_event,
                        void* workspace, size_t workspace_bytes, gda_stream_t stream);
+/* _ex: interior_rows > 0 declares the batch's first min(interior_rows, n_nodes) rows "interior" (counts[4] is raised to it
+ * before the plans are built): for a consumer that runs every batch at ONE static shape (the captured sampled step).  The
+ * rows between the sampled n_interior and interior_rows hold their unit self loop only, so the interior-rows kernels
+ * leave them as the leaf copy would. */
+int gda_dsampler_batch_ex(const int64_t* in_ptr, const int32_t* in_src, int64_t N, int64_t E, int64_t max_in_degree,
+                          const int64_t* seeds, int64_t n_seeds, int64_t* seeds_dev,
+                          const int32_t* fanouts_host, int L, uint64_t rng_seed,
+                          int64_t* nodes, int64_t* esrc, int64_t* edst,
+                          int32_t* rowptr, int32_t* colidx, float* val,
+                          int32_t* t_rowptr, int32_t* t_colidx, float* t_val,
+                          int64_t* counts, void* plan_fwd, void* plan_bwd, size_t plan_bytes,
+                          int64_t* counts_host, void* wait_event, void* done_event, int64_t interior_rows,
+                          void* workspace, size_t workspace_bytes, gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
  * Host construction of the PPMI graph (HOST pointers).
@@ -859,6 +887,15 @@ int gda_softmax_nll_fwd_ex_f32(const float* logits, int64_t ld, const int64_t* l
                                gda_stream_t stream);
 int gda_softmax_nll_bwd_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
                             const float* grad_loss, float* grad_logits, int64_t ldg, gda_stream_t stream);
+/* _nv: n_valid (DEVICE int64[1], or NULL = all N rows): only rows [0, *n_valid) are real -- the loss is THEIR mean, the
+ * count is theirs, the backward pass writes exact zeros into the rows behind them.  For batches padded to a static
+ * capacity (the captured sampled step): the row count is read on the device, the launch is the same for every batch. */
+int gda_softmax_nll_fwd_nv_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
+                               const int64_t* n_valid, float* loss, double* stats, void* workspace,
+                               size_t workspace_bytes, gda_stream_t stream);
+int gda_softmax_nll_bwd_nv_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
+                               const int64_t* n_valid, const float* grad_loss, float* grad_logits, int64_t ldg,
+                               gda_stream_t stream);
 
 /* PPMI graph construction on the DEVICE: the estimator and the walks of gda_ppmi_build_host (same
  * counter-based generator, so both builders count the same visits), as sorts + run-length counts.

@@ -38,6 +38,9 @@ _SIGNATURES = {
     "gda_interior_plan_build": (c_int, [_P, _P, _P, _P, _P, c_size_t, _P, _P]),
     "gda_interior_kstep_lds_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P, _P,
                                            c_size_t, _P]),
+    "gda_interior_kstep_lds_act_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, _P, _P, _P, _P, _P,
+                                               ctypes.c_float, ctypes.c_uint64, _P, ctypes.c_uint32, ctypes.c_uint32,
+                                               _P, c_size_t, _P]),
     "gda_row_split_workspace_bytes": (c_size_t, [c_int64]),
     "gda_row_split_build": (c_int, [_P, c_int64, ctypes.c_int32, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gda_spmm_csr_split_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P, c_int64,
@@ -100,6 +103,9 @@ _SIGNATURES = {
     "gda_stream_wait_event": (c_int, [_P, _P]),
     "gda_dsampler_batch": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, c_int64, _P, _P, c_int, ctypes.c_uint64,
                                    _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, _P, _P, _P, c_size_t, _P]),
+    "gda_dsampler_batch_ex": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, c_int64, _P, _P, c_int, ctypes.c_uint64,
+                                      _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, _P, _P, c_int64, _P,
+                                      c_size_t, _P]),
     "gda_selection_csr_host": (c_int, [_P, c_int, c_int64, c_int64, c_int64, c_int64, _P, _P]),
     "gda_ppmi_build_host": (c_int, [_P, _P, c_int64, c_int64, c_int, c_int, ctypes.c_uint64,
                                     ctypes.POINTER(c_void_p)]),
@@ -123,6 +129,7 @@ _SIGNATURES = {
     "gda_relu_dropout_pair_workspace_bytes": (ctypes.c_size_t, [c_int64]),
     "gda_relu_dropout_pair_bwd_f32": (c_int, [_P, _P, _P, c_int64, c_int64, c_float, _P, _P, ctypes.c_size_t, _P]),
     "gda_stack2_f32": (c_int, [_P, _P, _P, c_int64, _P]),
+    "gda_relu_dropout_bwd2_f32": (c_int, [_P, _P, _P, _P, c_int64, ctypes.c_float, _P]),
     "gda_colsum_workspace_bytes": (ctypes.c_size_t, [c_int64, c_int64]),
     "gda_colsum_f32": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, ctypes.c_size_t, _P]),
     "gda_softmax_nll_fwd_ex_f32": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, _P, ctypes.c_size_t, _P]),
@@ -145,6 +152,8 @@ _SIGNATURES = {
     "gda_softmax_nll_workspace_bytes": (c_size_t, []),
     "gda_softmax_nll_fwd_f32": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, c_size_t, _P]),
     "gda_softmax_nll_bwd_f32": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, c_int64, _P]),
+    "gda_softmax_nll_fwd_nv_f32": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "gda_softmax_nll_bwd_nv_f32": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, _P, c_int64, _P]),
     "gda_gemm_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64]),
     "gda_gemm_f32": (c_int, [c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64,
                              _P, c_size_t, _P]),

@@ -224,6 +224,27 @@ k_stack2(const float* __restrict__ a, const float* __restrict__ b, float* __rest
     }
 }
 
+// gx = [a ; b] masked by the activation's own output: gx[i] = y[i] > 0 ? ([a ; b])[i] * scale : 0 -- k_stack2 and
+// k_relu_dropout_bwd in one pass (the stacked gradient is never written unmasked)
+__global__ void __launch_bounds__(TB)
+k_relu_dropout_bwd2(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ y,
+                    float* __restrict__ gx, int64_t half, float scale) {
+    const int64_t quads = half / 4;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x; q < 2 * quads; q += (int64_t)gridDim.x * TB) {
+        const float* src = q < quads ? a : b;
+        const int64_t k = q < quads ? q : q - quads;
+        const float4 g = src ? *reinterpret_cast<const float4*>(src + k * 4) : z;
+        const float4 v = *reinterpret_cast<const float4*>(y + q * 4);
+        float4 o;
+        o.x = v.x > 0.f ? g.x * scale : 0.f;
+        o.y = v.y > 0.f ? g.y * scale : 0.f;
+        o.z = v.z > 0.f ? g.z * scale : 0.f;
+        o.w = v.w > 0.f ? g.w * scale : 0.f;
+        *reinterpret_cast<float4*>(gx + q * 4) = o;
+    }
+}
+
 // Column sums of a row-major [n, d] matrix (bias gradients), deterministic two-stage: fixed rows per block lane,
 // fixed-order block partials, fixed-order final sum.  d <= 256: TB / d rows in flight per block; wider: one row
 // at a time, a thread owning columns tid, tid + TB, ...
@@ -443,6 +464,17 @@ extern "C" int gda_stack2_f32(const float* a, const float* b, float* out, int64_
     if (!out) return GDA_E_NULL;
     if (half_elems % 4 != 0 || ((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) % 16 != 0) return GDA_E_UNSUPPORTED;
     GDA_UNLESS_SKIPPED("k_stack2") k_stack2<<<grid_for(2 * half_elems), TB, 0, (hipStream_t)stream>>>(a, b, out, half_elems);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+extern "C" int gda_relu_dropout_bwd2_f32(const float* ga, const float* gb, const float* y, float* gx, int64_t half_elems,
+                                         float p, gda_stream_t stream) {
+    if (half_elems < 0 || !(p >= 0.f && p < 1.f)) return GDA_E_SIZE;
+    if (half_elems == 0) return GDA_OK;
+    if (!y || !gx) return GDA_E_NULL;
+    if (half_elems % 4 != 0 || ((uintptr_t)ga | (uintptr_t)gb | (uintptr_t)y | (uintptr_t)gx) % 16 != 0) return GDA_E_UNSUPPORTED;
+    k_relu_dropout_bwd2<<<grid_for(2 * half_elems), TB, 0, (hipStream_t)stream>>>(ga, gb, y, gx, half_elems, 1.f / (1.f - p));
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }

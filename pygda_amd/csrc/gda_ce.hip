@@ -48,10 +48,11 @@ __device__ __forceinline__ double block_sum(double (&sh)[TB], double acc) {
 template <bool COUNT>
 __global__ void __launch_bounds__(TB)
 k_ce_fwd(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ y, int64_t N, int C,
-         double* __restrict__ partial) {
+         double* __restrict__ partial, const int64_t* __restrict__ n_valid) {
     __shared__ double sh[TB];
     double acc = 0.0, hit = 0.0;
     float v[MAXC];
+    if (n_valid) N = min(N, max(*n_valid, (int64_t)0));          // rows from *n_valid on are padding: no loss, no count
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < N; i += (int64_t)gridDim.x * TB) {
         const float lse = row_lse(x + i * ldx, C, v);
         acc += (double)(lse - x[i * ldx + y[i]]);
@@ -66,8 +67,10 @@ k_ce_fwd(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ y
 }
 
 __global__ void __launch_bounds__(TB)
-k_ce_final(const double* __restrict__ partial, int n, int64_t N, float* __restrict__ loss, double* __restrict__ stats) {
+k_ce_final(const double* __restrict__ partial, int n, int64_t N, float* __restrict__ loss, double* __restrict__ stats,
+           const int64_t* __restrict__ n_valid) {
     __shared__ double sh[TB];
+    if (n_valid) N = min(N, max(*n_valid, (int64_t)0));
     double a = 0.0, h = 0.0;
     for (int k = threadIdx.x; k < n; k += TB) a += partial[k];
     if (stats)
@@ -82,10 +85,15 @@ k_ce_final(const double* __restrict__ partial, int n, int64_t N, float* __restri
 
 __global__ void __launch_bounds__(TB)
 k_ce_bwd(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ y, int64_t N, int C,
-         const float* __restrict__ grad_loss, float* __restrict__ gx, int64_t ldg) {
-    const float scale = *grad_loss / (float)N;
+         const float* __restrict__ grad_loss, float* __restrict__ gx, int64_t ldg, const int64_t* __restrict__ n_valid) {
+    const int64_t NV = n_valid ? min(N, max(*n_valid, (int64_t)0)) : N;
+    const float scale = *grad_loss / (float)NV;
     float v[MAXC];
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < N; i += (int64_t)gridDim.x * TB) {
+        if (i >= NV) {                                               // padding rows: exact zeros
+            for (int c = 0; c < C; ++c) gx[i * ldg + c] = 0.f;
+            continue;
+        }
         const float lse = row_lse(x + i * ldx, C, v);
         const int64_t yi = y[i];
         for (int c = 0; c < C; ++c)
@@ -97,9 +105,12 @@ k_ce_bwd(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ y
 
 extern "C" size_t gda_softmax_nll_workspace_bytes(void) { return 2 * CE_BLOCKS * sizeof(double); }
 
-extern "C" int gda_softmax_nll_fwd_ex_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
-                                          float* loss, double* stats, void* workspace, size_t workspace_bytes,
-                                          gda_stream_t stream_) {
+// n_valid (device int64[1], or NULL = all N rows): only rows [0, *n_valid) are real -- the loss is their mean, the count is
+// theirs, and the backward pass writes exact zeros into the rows behind them.  For batches padded to a static capacity
+// (the captured sampled step, pygda_amd/sampled_graph.py): the row count is read on the device, the launch stays the same.
+extern "C" int gda_softmax_nll_fwd_nv_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
+                                          const int64_t* n_valid, float* loss, double* stats, void* workspace,
+                                          size_t workspace_bytes, gda_stream_t stream_) {
     if (N < 0 || C < 1 || C > MAXC || ld < C) return C > MAXC ? GDA_E_UNSUPPORTED : GDA_E_SIZE;
     if (!loss || !workspace || (N > 0 && (!logits || !labels))) return GDA_E_NULL;
     if (workspace_bytes < gda_softmax_nll_workspace_bytes()) return GDA_E_WORKSPACE;
@@ -114,12 +125,18 @@ extern "C" int gda_softmax_nll_fwd_ex_f32(const float* logits, int64_t ld, const
         return GDA_OK;
     }
     const int blocks = (int)(gda_cdiv(N, TB) < CE_BLOCKS ? gda_cdiv(N, TB) : CE_BLOCKS);
-    if (stats) k_ce_fwd<true><<<blocks, TB, 0, stream>>>(logits, ld, labels, N, C, (double*)workspace);
-    else k_ce_fwd<false><<<blocks, TB, 0, stream>>>(logits, ld, labels, N, C, (double*)workspace);
+    if (stats) k_ce_fwd<true><<<blocks, TB, 0, stream>>>(logits, ld, labels, N, C, (double*)workspace, n_valid);
+    else k_ce_fwd<false><<<blocks, TB, 0, stream>>>(logits, ld, labels, N, C, (double*)workspace, n_valid);
     GDA_LAUNCH_CHECK();
-    GDA_UNLESS_SKIPPED("k_ce_final") k_ce_final<<<1, TB, 0, stream>>>((const double*)workspace, blocks, N, loss, stats);
+    GDA_UNLESS_SKIPPED("k_ce_final") k_ce_final<<<1, TB, 0, stream>>>((const double*)workspace, blocks, N, loss, stats, n_valid);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
+}
+
+extern "C" int gda_softmax_nll_fwd_ex_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
+                                          float* loss, double* stats, void* workspace, size_t workspace_bytes,
+                                          gda_stream_t stream_) {
+    return gda_softmax_nll_fwd_nv_f32(logits, ld, labels, N, C, nullptr, loss, stats, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int gda_softmax_nll_fwd_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
@@ -128,15 +145,21 @@ extern "C" int gda_softmax_nll_fwd_f32(const float* logits, int64_t ld, const in
     return gda_softmax_nll_fwd_ex_f32(logits, ld, labels, N, C, loss, nullptr, workspace, workspace_bytes, stream_);
 }
 
-extern "C" int gda_softmax_nll_bwd_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
-                                       const float* grad_loss, float* grad_logits, int64_t ldg,
-                                       gda_stream_t stream_) {
+extern "C" int gda_softmax_nll_bwd_nv_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
+                                          const int64_t* n_valid, const float* grad_loss, float* grad_logits, int64_t ldg,
+                                          gda_stream_t stream_) {
     if (N < 0 || C < 1 || C > MAXC || ld < C || ldg < C) return C > MAXC ? GDA_E_UNSUPPORTED : GDA_E_SIZE;
     if (N == 0) return GDA_OK;
     if (!logits || !labels || !grad_loss || !grad_logits) return GDA_E_NULL;
     if (grad_logits == logits) return GDA_E_ALIAS;
     const int64_t blocks = gda_cdiv(N, TB) < 4096 ? gda_cdiv(N, TB) : 4096;
-    k_ce_bwd<<<(unsigned)blocks, TB, 0, (hipStream_t)stream_>>>(logits, ld, labels, N, C, grad_loss, grad_logits, ldg);
+    k_ce_bwd<<<(unsigned)blocks, TB, 0, (hipStream_t)stream_>>>(logits, ld, labels, N, C, grad_loss, grad_logits, ldg, n_valid);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
+}
+
+extern "C" int gda_softmax_nll_bwd_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
+                                       const float* grad_loss, float* grad_logits, int64_t ldg,
+                                       gda_stream_t stream_) {
+    return gda_softmax_nll_bwd_nv_f32(logits, ld, labels, N, C, nullptr, grad_loss, grad_logits, ldg, stream_);
 }

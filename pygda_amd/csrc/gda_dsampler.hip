@@ -571,15 +571,26 @@ extern "C" int gda_stream_wait_event(gda_stream_t stream, void* event) {
 //   [wait_event] -> seeds (host or device, n_seeds int64) -> seeds_dev -> the batch -> plan_fwd / plan_bwd (both or
 //   neither; counts[5:7] / counts[7:9] <- their {q, T}) -> counts (device int64[12], zeroed first) -> counts_host (pinned
 //   int64[12]) -> [done_event].  The arrays may be a block the caller overwrote before: wait_event is what makes that safe.
-extern "C" int gda_dsampler_batch(const int64_t* in_ptr, const int32_t* in_src, int64_t N, int64_t E, int64_t max_in_degree,
-                                  const int64_t* seeds, int64_t n_seeds, int64_t* seeds_dev,
-                                  const int32_t* fanouts_host, int L, uint64_t rng_seed,
-                                  int64_t* nodes, int64_t* esrc, int64_t* edst,
-                                  int32_t* rowptr, int32_t* colidx, float* val,
-                                  int32_t* t_rowptr, int32_t* t_colidx, float* t_val,
-                                  int64_t* counts, void* plan_fwd, void* plan_bwd, size_t plan_bytes,
-                                  int64_t* counts_host, void* wait_event, void* done_event,
-                                  void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+namespace {
+// counts[4] (n_interior) <- min(max(n_interior, rows), n_nodes): a batch whose consumer runs at STATIC shapes (the captured
+// sampled step) declares a fixed number of leading rows "interior".  Rows between the sampled n_interior and `rows` are
+// last-hop discoveries -- their only entry is the unit self loop -- so every interior-rows kernel computes the same
+// values for them (1 * x + 0 + 0) that the leaf copy would have produced.
+__global__ void k_ds_round_interior(int64_t* counts, int64_t rows) {
+    const int64_t n = counts[0], ni = counts[4];
+    if (counts[3] == 0 && rows > ni) counts[4] = rows < n ? rows : n;
+}
+}  // namespace
+
+extern "C" int gda_dsampler_batch_ex(const int64_t* in_ptr, const int32_t* in_src, int64_t N, int64_t E, int64_t max_in_degree,
+                                     const int64_t* seeds, int64_t n_seeds, int64_t* seeds_dev,
+                                     const int32_t* fanouts_host, int L, uint64_t rng_seed,
+                                     int64_t* nodes, int64_t* esrc, int64_t* edst,
+                                     int32_t* rowptr, int32_t* colidx, float* val,
+                                     int32_t* t_rowptr, int32_t* t_colidx, float* t_val,
+                                     int64_t* counts, void* plan_fwd, void* plan_bwd, size_t plan_bytes,
+                                     int64_t* counts_host, void* wait_event, void* done_event, int64_t interior_rows,
+                                     void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
     if (!counts || !counts_host || (n_seeds > 0 && (!seeds || !seeds_dev))) return GDA_E_NULL;
     if ((plan_fwd == nullptr) != (plan_bwd == nullptr)) return GDA_E_NULL;
     if (plan_fwd && !rowptr) return GDA_E_NULL;
@@ -591,6 +602,10 @@ extern "C" int gda_dsampler_batch(const int64_t* in_ptr, const int32_t* in_src, 
     int st = gda_dsampler_sample(in_ptr, in_src, N, E, max_in_degree, seeds_dev, n_seeds, fanouts_host, L, rng_seed, nodes, esrc,
                                  edst, rowptr, colidx, val, t_rowptr, t_colidx, t_val, counts, workspace, workspace_bytes, stream_);
     if (st != GDA_OK) return st;
+    if (interior_rows > 0) {
+        k_ds_round_interior<<<1, 1, 0, s>>>(counts, interior_rows);
+        GDA_LAUNCH_CHECK();
+    }
     if (plan_fwd) {
         st = gda_interior_plan_build(rowptr, colidx, val, counts + 4, plan_fwd, plan_bytes, counts + 5, stream_);
         if (st != GDA_OK) return st;
@@ -600,4 +615,18 @@ extern "C" int gda_dsampler_batch(const int64_t* in_ptr, const int32_t* in_src, 
     GDA_HIP_TRY(hipMemcpyAsync(counts_host, counts, 12 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     if (done_event) GDA_HIP_TRY(hipEventRecord((hipEvent_t)done_event, s));
     return GDA_OK;
+}
+
+extern "C" int gda_dsampler_batch(const int64_t* in_ptr, const int32_t* in_src, int64_t N, int64_t E, int64_t max_in_degree,
+                                  const int64_t* seeds, int64_t n_seeds, int64_t* seeds_dev,
+                                  const int32_t* fanouts_host, int L, uint64_t rng_seed,
+                                  int64_t* nodes, int64_t* esrc, int64_t* edst,
+                                  int32_t* rowptr, int32_t* colidx, float* val,
+                                  int32_t* t_rowptr, int32_t* t_colidx, float* t_val,
+                                  int64_t* counts, void* plan_fwd, void* plan_bwd, size_t plan_bytes,
+                                  int64_t* counts_host, void* wait_event, void* done_event,
+                                  void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    return gda_dsampler_batch_ex(in_ptr, in_src, N, E, max_in_degree, seeds, n_seeds, seeds_dev, fanouts_host, L, rng_seed, nodes,
+                                 esrc, edst, rowptr, colidx, val, t_rowptr, t_colidx, t_val, counts, plan_fwd, plan_bwd, plan_bytes,
+                                 counts_host, wait_event, done_event, 0, workspace, workspace_bytes, stream_);
 }

@@ -16,6 +16,7 @@
 // requests per group are in flight.
 // HBM bound: algorithmic bytes per call = nnz*8 + (N+1)*4 + 2*N*d*4.
 #include "gda_common.h"
+#include "gda_philox.h"
 
 #include <cstdlib>
 

@@ -289,6 +289,25 @@ class NeighborLoader:
                         th.join(timeout=0.01)
 
 
+    def iter_raw(self):
+        """The batches of :meth:`__iter__` WITHOUT their consumer-side assembly: ``(slot, (n, e, nnz, n_interior))`` per
+        batch, ``slot`` = the ring block the device sampler filled (sampler._Slot: node ids, edge list, CSR pair, interior
+        K-step plans, all capacity-sized; its ``done`` event orders a consumer behind the sampler's stream).  For the
+        captured sampled step (pygda_amd/sampled_graph.py), which copies the block into its static buffers and gathers
+        the feature rows inside the graph.  Device sampler + recycling ring only (None otherwise)."""
+        from .sampler import DeviceNeighborSampler
+        if self.full_batch or not self.recycle or self.prefetch <= 0:
+            return None
+        if self._sampler is None:
+            self._sampler = self._make_sampler()
+        if not isinstance(self._sampler, DeviceNeighborSampler):
+            return None
+        epoch = self._epoch
+        self._epoch += 1
+        batches = self._batches(epoch)
+        seeds_of = lambda b: hash((self.seed, epoch, b, self.rank)) & 0x7FFFFFFF
+        return self._device_batches(batches, seeds_of, raw=True)
+
     def _make_sampler(self):
         """The device sampler when the graph and the features live on the GPU and the fan-outs allow it (1..64, or
         -1 within its workspace budget); the native host sampler otherwise (``PYGDA_AMD_DEVICE_SAMPLER=0`` forces it)."""
@@ -302,7 +321,7 @@ class NeighborLoader:
                 return ds
         return NeighborSampler(ei, self.data.num_nodes)
 
-    def _device_batches(self, batches, seeds_of):
+    def _device_batches(self, batches, seeds_of, raw=False):
         """Batches from the device sampler.  With prefetching, a producer thread enqueues batch b+1.. on a side
         stream and waits for their sizes there, so the training stream never waits for a size read-back; the
         consumer orders itself behind the side stream with an event and gathers the feature rows."""
@@ -326,7 +345,7 @@ class NeighborLoader:
         ring = None
         if self.recycle and not getattr(self, "_ring_busy", False):     # (a second live iterator over this loader allocates)
             if self._ring is None:
-                self._ring = S.new_ring(self.prefetch + 4)
+                self._ring = S.new_ring(self.prefetch + 4, getattr(self, "static_interior", 0))
             ring = self._ring
             ring.reset()          # (the wait above also puts the last pass's batches behind the sampler's stream)
             self._ring_busy = True
@@ -361,7 +380,7 @@ class NeighborLoader:
                     break
                 if isinstance(item, BaseException):
                     raise item
-                yield S.assemble(self.data, *item)
+                yield item if raw else S.assemble(self.data, *item)
         finally:
             stop.set()
             while th.is_alive():

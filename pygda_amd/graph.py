@@ -78,7 +78,7 @@ class CSRGraph:
 
     __slots__ = ("num_nodes", "nnz_cap", "rowptr", "colidx", "val", "t_rowptr", "t_colidx",
                  "t_val", "_nnz", "device", "_split", "_t_split", "t_to_fwd", "static", "_squared", "transient",
-                 "_kplan", "_t_kplan", "n_interior", "iplan", "iplan_T", "_slot", "_gen")
+                 "_kplan", "_t_kplan", "n_interior", "iplan", "iplan_T", "_slot", "_gen", "tag")
 
     def __init__(self, num_nodes, nnz_cap, rowptr, colidx, val, t_rowptr, t_colidx, t_val):
         self.num_nodes, self.nnz_cap = num_nodes, nnz_cap
@@ -91,6 +91,7 @@ class CSRGraph:
         self.static = False       # graph of a full-batch loader: lives for the whole fit()
         self.transient = False    # graph of one sampled mini-batch: nothing about it is worth a host sync
         self._squared = None      # A*A (and its transpose) of a static graph, or False if too dense
+        self.tag = None           # bookkeeping label (the captured sampled step tags its two static graphs)
         self.iplan_T = None       # sampled batch: off-diagonal entries of the interior block (the sampler's count)
         self._slot, self._gen = None, 0        # sampled batch out of a recycling loader ring: its block and the block's
                                                # generation when this batch was written (as_graph refuses a stale one)

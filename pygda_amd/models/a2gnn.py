@@ -64,7 +64,7 @@ class A2GNN(BaseGDA):
         else:
             side.wait_stream(main)
         with torch.cuda.stream(side), torch.no_grad():
-            feats = net.feat_bottleneck_from(h0.detach(), target_data.edge_index, None, self.t_pnums)
+            feats = net.feat_bottleneck_from(h0.detach(), target_data.edge_index, None, self.t_pnums, draw=1)
             out = net.feat_classifier(feats, target_data.edge_index, None, 1)
         out.record_stream(main)
         return out, side
@@ -114,7 +114,10 @@ class A2GNN(BaseGDA):
         table = getattr(self, "_grad_aliases", None)
         with (net.second_leaves(table) if table is not None and torch.is_grad_enabled() else _null()):
             if h0_t is None:
-                h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums)
+                # sampled batches: layer 0's activation (both passes' dropout draws) rides in the aggregation's epilogue
+                h0_t = net.first_conv(target_data.x, target_data.edge_index, self.t_pnums,
+                                      draws=(2 if self.compute_target_logits else 1)
+                                      if getattr(target_data, "n_id", None) is not None else 0)
             pending = None
             if self.compute_target_logits and fork and self.features_first:
                 # The feature pass (:193) feeds the domain loss, the logits pass (:211) feeds nothing: the pass issued
@@ -241,7 +244,7 @@ class A2GNN(BaseGDA):
             target_logits, side = pending
             torch.cuda.current_stream().wait_stream(side)                                # join
         elif self.compute_target_logits:                                                 # :211
-            feats_t = net.feat_bottleneck_from(h0_t, target_data.edge_index, tb, self.t_pnums)
+            feats_t = net.feat_bottleneck_from(h0_t, target_data.edge_index, tb, self.t_pnums, draw=1)
             target_logits = net.feat_classifier(feats_t, target_data.edge_index, tb, 1)
         else:
             target_logits = None
@@ -270,6 +273,9 @@ class A2GNN(BaseGDA):
 
     def _prepare(self, source_data, target_data):
         """Everything fit() does before its epoch loop (a2gnn.py:254-296)."""
+        # sampled mini-batches with the MMD loss: the step reads no per-epoch scalar and every batch of the device
+        # sampler fits one capacity shape -- it may be captured once and replayed (pygda_amd/sampled_graph.py)
+        self._sampled_graph_ok = type(self) is A2GNN and not self.adv and self.mode == 'node'
         self._loaders(source_data, target_data)                                          # :254-288
         self.a2gnn = self.init_model(**self.kwargs)
         # the MMD branch never reads alpha/epoch; the adversarial branch reads the GRL alpha, which the

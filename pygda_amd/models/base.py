@@ -80,10 +80,49 @@ class BaseGDA(ABC):
               dict(dist, device=self.device, full_batch=False if self.force_sampler else None, recycle=True))
         self.source_loader = NeighborLoader(source_data, self.num_neigh, batch_size=sb, **kw)
         self.target_loader = NeighborLoader(target_data, self.num_neigh, batch_size=tb, **kw)
+        if not full:
+            self._declare_static_shape(self.source_loader, self.target_loader)
         # MMD draws stay in the caller's numbering: the maps live on THIS trainer and are installed in utils.mmd only
         # while its own epoch loop runs (_train_epochs), never between fits or for another model
         maps = tuple(None if l.new_id is None else l.new_id.cpu() for l in (self.source_loader, self.target_loader))
         self._mmd_row_maps = maps if any(m is not None for m in maps) else None
+
+    def _wants_sampled_graph(self):
+        """A trainer whose sampled step may be captured at a static shape (pygda_amd/sampled_graph.py) says so with
+        ``_sampled_graph_ok``; single process, on the GPU, not switched off."""
+        import os
+        from ..distributed import active
+        return (getattr(self, "_sampled_graph_ok", False) and self.use_hip_graph is not False
+                and os.environ.get("PYGDA_AMD_SAMPLED_GRAPH", "1") == "1" and os.environ.get("PYGDA_AMD_HIPGRAPH", "1") == "1"
+                and torch.device(self.device).type == "cuda" and torch.cuda.is_available() and not active())
+
+    def _declare_static_shape(self, *loaders):
+        """Before the loaders' rings exist: every batch declares the interior capacity's worth of leading rows interior,
+        so that all batches of a loader share ONE shape (sampled_graph.static_shape_ok)."""
+        if not self._wants_sampled_graph():
+            return
+        from ..sampled_graph import static_shape_ok
+        caps = [static_shape_ok(l) for l in loaders]
+        if all(c is not None for c in caps):
+            for l, c in zip(loaders, caps):
+                l.static_interior = c
+
+    def _sampled_stepper(self, net, optimizer, step_fn, capture=True):
+        """The captured static-shape step for this trainer's sampled loaders, or None."""
+        if not self._wants_sampled_graph():
+            return None
+        ls = (self.source_loader, self.target_loader)
+        if any(getattr(l, "static_interior", 0) <= 0 or getattr(l, "full_batch", True) for l in ls):
+            return None
+        if not any(g.get("capturable", False) for g in optimizer.param_groups):
+            return None
+        hit = getattr(self, "_sampled_graphed", None)
+        if hit is not None and hit[0] == (id(optimizer), id(ls[0]), id(ls[1]), capture):
+            return hit[1]
+        from ..sampled_graph import GraphedSampledStep
+        stepper = GraphedSampledStep(self, net, step_fn, optimizer, ls[0], ls[1], capture=capture)
+        self._sampled_graphed = ((id(optimizer), id(ls[0]), id(ls[1]), capture), stepper)
+        return stepper
 
     def _graph_loaders(self, source_data, target_data):
         """``mode='graph'`` (a2gnn.py:278-286, the same block in grade.py:244-252, udagcn.py:248-256, adagcn.py:244-252,
@@ -126,9 +165,65 @@ class BaseGDA(ABC):
         graphed = self._maybe_graphed_step(optimizer, step_fn, before_step, net)
         if graphed is not None and hasattr(graphed, "launch"):
             return self._graphed_epochs(graphed, range(self.epoch) if epochs is None else epochs, start, alpha_fn)
+        import os
+        # (PYGDA_AMD_SAMPLED_GRAPH_CAPTURE=0: the same static-shape step issued eagerly every time -- tests)
+        stepper = self._sampled_stepper(net, optimizer, step_fn,
+                                        capture=os.environ.get("PYGDA_AMD_SAMPLED_GRAPH_CAPTURE", "1") == "1") \
+            if (graphed is None and before_step is None) else None
         for epoch in (range(self.epoch) if epochs is None else epochs):
             epoch_loss, logits, labels, dev_loss = 0.0, [], [], None
             alpha = alpha_fn(epoch)
+            raw = None
+            if stepper is not None:
+                raw = (self.source_loader.iter_raw(), self.target_loader.iter_raw())
+                if raw[0] is None or raw[1] is None:
+                    raw = stepper = None
+            if raw is not None:
+                # sampled mini-batches, the step replayed at its static shape (a2gnn.py:308-319 per pair; same numbers):
+                # per step the captured graph leaves {loss, #correct source rows}; they are read a few steps later, so the
+                # host never waits for the step it has just launched
+                tickets, rows, correct, dev_correct = [], 0, 0.0, None
+                S_s, S_t = self.source_loader._sampler, self.target_loader._sampler
+
+                def settle(keep):
+                    nonlocal epoch_loss, rows, correct
+                    while len(tickets) > keep:
+                        loss_v, corr, n_live = stepper.result(tickets.pop(0))
+                        epoch_loss += loss_v
+                        correct += corr
+                        rows += n_live
+
+                for (ps, zs), (pt, zt) in zip(*raw):
+                    ticket = stepper.step(ps, zs, pt, zt)
+                    if ticket is not None:
+                        tickets.append(ticket)
+                        settle(2)
+                        continue
+                    # a pair the static shape cannot take: the ordinary eager step on its real shape
+                    net.train()
+                    src, tgt = S_s.assemble(self.source_loader.data, ps, zs), S_t.assemble(self.target_loader.data, pt, zt)
+                    from ..ops import dropout_state
+                    dropout_state.next_step(src.x.device)
+                    loss, source_logits = step_fn(src, tgt, alpha, epoch)
+                    optimizer.zero_grad()
+                    loss.backward()
+                    optimizer.step()
+                    dev_loss = loss.detach().double() if dev_loss is None else dev_loss + loss.detach().double()
+                    hit = (source_logits.detach().argmax(dim=1) == src.y).sum()
+                    dev_correct = hit if dev_correct is None else dev_correct + hit
+                    rows += int(src.y.numel())
+                settle(0)
+                for gen in raw:              # (a zip that stopped at the shorter loader leaves the other generator open)
+                    gen.close()
+                if dev_loss is not None:
+                    epoch_loss += dev_loss.item()
+                    correct += float(dev_correct.item())
+                acc = correct / rows if rows else 0.0
+                secs = time.time() - start
+                logger(epoch=epoch, loss=epoch_loss, source_train_acc=acc, time=secs, verbose=self.verbose, train=True)
+                if self.epoch_hook is not None:
+                    self.epoch_hook(epoch, epoch_loss, acc, secs)
+                continue
             if graphed is not None:
                 loss, source_logits = graphed()
                 epoch_loss += loss.item()

@@ -19,6 +19,20 @@ def global_mean_pool(x, batch, size=None):
     return segment_mean(x, batch, size)
 
 
+class ActPair:
+    """Layer 0's output ALREADY through ``dropout(relu(.))``, in two independent draws: ``draws[0]`` for the pass that is
+    differentiated (the features the domain loss reads), ``draws[1]`` (may be None) for the trainer's second pass over the
+    same layer-0 output.  What :meth:`A2GNNBase.first_conv` hands out when the aggregation's epilogue applied the
+    activation (ops.propagate_act); :meth:`A2GNNBase.feat_bottleneck_from` continues from either form."""
+    __slots__ = ("draws",)
+
+    def __init__(self, a, b=None):
+        self.draws = (a, b)
+
+    def detach(self):
+        return ActPair(self.draws[0].detach(), None if self.draws[1] is None else self.draws[1].detach())
+
+
 class A2GNNBase(nn.Module):
     def __init__(self, in_dim, hid_dim, num_classes, num_layers=1, adv=False, dropout=0.1,
                  act=F.relu, mode="node", **kwargs):
@@ -68,11 +82,18 @@ class A2GNNBase(nn.Module):
     def feat_bottleneck(self, x, edge_index, batch, prop_nums=30):
         return self.feat_bottleneck_from(self.first_conv(x, edge_index, prop_nums), edge_index, batch, prop_nums)
 
-    def first_conv(self, x, edge_index, prop_nums):
+    def first_conv(self, x, edge_index, prop_nums, draws=0):
         """Output of layer 0 BEFORE activation / dropout: a deterministic function of the inputs,
         so the two passes the trainer makes over the same graph (features and logits) can share
-        it -- the reference recomputes it, projection and all ``prop_nums`` aggregations, per pass."""
+        it -- the reference recomputes it, projection and all ``prop_nums`` aggregations, per pass.
+        ``draws`` (1 or 2; the trainers' sampled steps): the caller will continue with that many
+        :meth:`feat_bottleneck_from` passes and accepts an :class:`ActPair` -- the activation applied by the
+        aggregation's epilogue -- when this batch allows it."""
         conv = self.convs[0]
+        if draws and self.act is F.relu and self.mode == "node" and prop_nums > 0:
+            hit = conv.forward_act(x, edge_index, prop_nums, self.dropout, self.training, pair=draws > 1)
+            if hit is not None:
+                return ActPair(*hit) if draws > 1 else ActPair(hit)
         return conv.forward_colmajor(x, edge_index, prop_nums) if self._fused_act(x) else conv(x, edge_index, prop_nums)
 
     def _fused_act(self, x):
@@ -87,10 +108,19 @@ class A2GNNBase(nn.Module):
             return relu_dropout(x, self.dropout, self.training)
         return F.dropout(self.act(x), p=self.dropout, training=self.training)
 
-    def feat_bottleneck_from(self, h0, edge_index, batch, prop_nums=30):
-        """``feat_bottleneck`` continued from a precomputed :meth:`first_conv` output."""
-        x = self._act_dropout(h0)
+    def feat_bottleneck_from(self, h0, edge_index, batch, prop_nums=30, draw=0):
+        """``feat_bottleneck`` continued from a precomputed :meth:`first_conv` output (``draw``: which of an
+        :class:`ActPair`'s two dropout draws this pass continues from)."""
+        if isinstance(h0, ActPair):
+            x = h0.draws[draw] if h0.draws[draw] is not None else h0.draws[0]
+        else:
+            x = self._act_dropout(h0)
         for conv in self.convs[1:]:
+            hit = conv.forward_act(x, edge_index, prop_nums, self.dropout, self.training) \
+                if (self.act is F.relu and self.mode == "node" and prop_nums > 0) else None
+            if hit is not None:
+                x = hit
+                continue
             x = self._act_dropout(conv.forward_colmajor(x, edge_index, prop_nums) if self._fused_act(x)
                                   else conv(x, edge_index, prop_nums))
         if self.mode == "graph":
@@ -109,8 +139,12 @@ class A2GNNBase(nn.Module):
             return (self.feat_bottleneck_from(h0, edge_index, batch, prop_nums),
                     self.feat_bottleneck_from(h0, edge_index, batch, prop_nums))
         x = relu_dropout_pair(h0, self.dropout, self.training)
-        for conv in self.convs[1:]:
+        rest = list(self.convs[1:])
+        for conv in rest[:-1]:
             x = self._act_dropout(conv(x, edge_index, prop_nums))
+        if rest:            # the last activation hands out the two halves itself: its backward stacks and masks in one pass
+            from ..ops import relu_dropout_split
+            return relu_dropout_split(rest[-1](x, edge_index, prop_nums), self.dropout, self.training)
         return split_halves(x)
 
     def feat_classifier(self, x, edge_index, batch, prop_nums=1):

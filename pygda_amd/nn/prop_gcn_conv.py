@@ -71,6 +71,26 @@ class PropGCNConv(nn.Module):
         layout) for the fused activation kernel that follows a conv in A2GNNBase; not in the reference."""
         return self._forward(x, edge_index, prop_nums, edge_weight, True)
 
+    def forward_act(self, x, edge_index, prop_nums, p, training, pair=False):
+        """``dropout(relu(forward(x, edge_index, prop_nums)), p, training)`` when the aggregation's own epilogue can
+        apply the activation -- a sampled batch on the one-launch interior K-step (ops.propagate_act) -- else None (the
+        caller composes).  ``pair``: two independent dropout draws of the same pre-activation ``(a, b)``; ``b`` is not
+        differentiated (the trainer's loss-unused second pass).  Not in the reference."""
+        if prop_nums <= 0 or not isinstance(x, torch.Tensor) or not x.is_cuda or x.dim() != 2:
+            return None
+        from ..ops import propagate_act, propagate_act_ok
+        g = self._graph(x, edge_index, None)
+        if getattr(g, "n_interior", None) is None or getattr(g, "iplan", None) is None or self.out_channels % 4:
+            return None
+        # decide before projecting: shapes only (the plan is per batch and direction, the width is out_channels)
+        out = self.lin(x)                                        # :205
+        if not propagate_act_ok(out, g, prop_nums, self.bias):
+            from ..ops import relu_dropout
+            pre = propagate(out, g, prop_nums, self.bias)
+            a = relu_dropout(pre, p, training)
+            return (a, relu_dropout(pre.detach(), p, training)) if pair else a
+        return propagate_act(out, g, prop_nums, self.bias, p, training, pair)
+
     def _forward(self, x, edge_index, prop_nums, edge_weight, colmajor_out):
         if colmajor_out and prop_nums > 0 and self.lin.tall_gemm_ok(x):
             # dense projection on the matrix-core kernels: it can write the K-step kernel's column-major

@@ -31,9 +31,12 @@ class _SoftmaxNLL(torch.autograd.Function):
         stats = torch.empty(2, dtype=torch.float64, device=x.device)       # {loss, #(argmax == label)}: the epoch log
         L = _lib.lib()
         ws = _lib.workspace(L.gda_softmax_nll_workspace_bytes(), x.device, "ce")
-        _lib.check(L.gda_softmax_nll_fwd_ex_f32(_lib.ptr(x), c, _lib.ptr(labels.contiguous()), n, c, _lib.ptr(loss),
-                                                _lib.ptr(stats), _lib.ptr(ws), ws.numel(), _lib.stream()),
-                   "gda_softmax_nll_fwd_ex_f32")
+        # a batch padded to a static capacity (pygda_amd/sampled_graph.py) tags its labels with the DEVICE count of its
+        # real rows: the loss is their mean, the rows behind them get zero gradients
+        ctx.nv = nv = getattr(labels, "_gda_valid_rows", None)
+        _lib.check(L.gda_softmax_nll_fwd_nv_f32(_lib.ptr(x), c, _lib.ptr(labels.contiguous()), n, c, _lib.ptr(nv),
+                                                _lib.ptr(loss), _lib.ptr(stats), _lib.ptr(ws), ws.numel(), _lib.stream()),
+                   "gda_softmax_nll_fwd_nv_f32")
         global _ce_stats
         # weak references + version counters: the entry pins neither the [rows, C] logits nor the labels of a sampled
         # batch (the eager loop never looks it up), and a tensor that died -- whose storage may since have been handed
@@ -48,8 +51,9 @@ class _SoftmaxNLL(torch.autograd.Function):
         n, c = x.shape
         gx = torch.empty_like(x)
         gl = gl.reshape(1).to(torch.float32).contiguous()
-        _lib.check(_lib.lib().gda_softmax_nll_bwd_f32(_lib.ptr(x), c, _lib.ptr(labels.contiguous()), n, c, _lib.ptr(gl),
-                                                      _lib.ptr(gx), c, _lib.stream()), "gda_softmax_nll_bwd_f32")
+        _lib.check(_lib.lib().gda_softmax_nll_bwd_nv_f32(_lib.ptr(x), c, _lib.ptr(labels.contiguous()), n, c,
+                                                         _lib.ptr(ctx.nv), _lib.ptr(gl), _lib.ptr(gx), c, _lib.stream()),
+                   "gda_softmax_nll_bwd_nv_f32")
         return gx, None
 
 
@@ -179,14 +183,15 @@ class _Nnz:
     sampler): the number, not the graph -- a logged graph object pins its batch's CSR buffers for as long as the log
     lives, ~13 MB per sampled step that the caching allocator then has to hipMalloc afresh (1.7 device allocations per
     step inside bench.py's timed cfg-S region, one of them now and then 30 ms long)."""
-    __slots__ = ("nnz",)
+    __slots__ = ("nnz", "tag")
 
-    def __init__(self, nnz):
-        self.nnz = nnz
+    def __init__(self, nnz, tag=None):
+        self.nnz, self.tag = nnz, tag
 
 
 def _logged(graph):
-    return _Nnz(graph._nnz) if getattr(graph, "_nnz", None) is not None and getattr(graph, "transient", False) else graph
+    return (_Nnz(graph._nnz, getattr(graph, "tag", None))
+            if getattr(graph, "_nnz", None) is not None and getattr(graph, "transient", False) else graph)
 
 kstep_paths = None       # or a dict: which kernel ran the K >= 3 aggregation calls ("lds-one-launch" / "launch-chain"),
                          # counted per call while the profiler is on (bench.py: config.kstep_aggregation_path)
@@ -222,7 +227,7 @@ def _launch_kstep_interior(graph, x, K, bias, transposed, y):
         if nnz_h is not None:
             executed = (nnz_h + (int(K) - 1) * (T + n_int) if (plan is not None and T is not None)
                         else int(K) * (nnz_h - (n - n_int)) + (n - n_int))
-        aggregation_log.append((_logged(graph), int(K), executed))
+        aggregation_log.append((_logged(graph), int(K), executed, "interior-lds" if plan is not None else "interior-rows"))
     _note_path("interior-lds" if plan is not None else "interior-rows", int(K))
     if profiler.enabled:
         # `bytes`: what the call itself has to move -- forward K interior steps + one copy of the leaf rows; transposed K
@@ -587,6 +592,89 @@ def propagate(x, graph: CSRGraph, K=1, bias=None, colmajor_out=False):
     if colmajor_out and lds_colmajor_ok(x, graph, K):
         return ColMajor(_PropagateT.apply(x, bias, graph, int(K)), x.size(0))
     return _Propagate.apply(x, bias, graph, int(K))
+
+
+FUSED_INTERIOR_ACT = _os.environ.get("PYGDA_AMD_FUSED_INTERIOR_ACT", "1") == "1"
+
+
+def propagate_act_ok(x, graph, K, bias):
+    """``relu_dropout(propagate(x, graph, K, bias))`` runs as the one-launch interior K-step with the activation in its
+    epilogue (gda_interior_kstep_lds_act_f32): a sampled batch whose forward plan the device sampler built."""
+    return (FUSED_INTERIOR_ACT and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+            and x.is_contiguous() and _takes_interior_path(graph, x, bias, False)
+            and _interior_lds_plan(graph, x, x, int(K), False) is not None)
+
+
+class _PropagateAct(torch.autograd.Function):
+    """``act(A_hat^K x + bias)`` with ``act = dropout(relu(.))`` applied by the aggregation's own epilogue; with ``pair`` a
+    second output carries an independent dropout draw of the same pre-activation (not differentiated: the trainer's
+    loss-unused pass).  Backward: the activation's mask from the saved OUTPUT (y > 0 <=> x > 0 and kept), then the
+    K-step kernel on the by-source CSR -- nothing but the output and the graph is saved."""
+
+    @staticmethod
+    def forward(ctx, x, bias, graph, K, p, pair):
+        x = _f32c(x, "x")
+        n, d = x.shape
+        n_int = graph.n_interior
+        y0 = torch.empty_like(x)
+        y1 = torch.empty_like(x) if pair else None
+        b = None if bias is None else _f32c(bias, "bias")
+        plan = _interior_lds_plan(graph, x, y0, K, False)
+        st = dropout_state
+        if st.seed is None:
+            st.seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+        site0 = st.next_site()
+        site1 = st.next_site() if pair else 0
+        L = _lib.lib()
+        if aggregation_log is not None:
+            nnz_h, T = getattr(graph, "_nnz", None), getattr(graph, "iplan_T", None)
+            executed = None
+            if nnz_h is not None:
+                executed = (nnz_h + (int(K) - 1) * (T + n_int) if T is not None
+                            else int(K) * (nnz_h - (n - n_int)) + (n - n_int))
+            aggregation_log.append((_logged(graph), int(K), executed, "interior-lds"))
+        _note_path("interior-lds", int(K))
+        if profiler.enabled:
+            global aggregated_edges
+            aggregated_edges += int(K) * graph.nnz
+            nnz, n_leaf, row = graph.nnz, n - n_int, 4 * d
+            alg = K * (nnz * 8 + (n + 1) * 4 + 2 * n * d * 4)
+            real = nnz * 8 + min(nnz, n) * row + 6 * n_int * row + (2 + bool(pair)) * n_leaf * row
+            region = profiler.region(f"interior_lds_f32[d={d}]", 3, real, K * 2 * nnz * d, alg_equiv_bytes=alg,
+                                     step_loop_launches=1)
+        else:
+            region = profiler.region("", 0)
+        nbytes = L.gda_interior_kstep_lds_workspace_bytes(_interior_lds_limits()[0], d)
+        ws = _lib.workspace(nbytes, x.device, "interior_lds")
+        with region:
+            _lib.check(L.gda_interior_kstep_lds_act_f32(
+                _lib.ptr(graph.rowptr), _lib.ptr(graph.colidx), _lib.ptr(graph.val), n, n_int, d, int(K), _lib.ptr(plan),
+                _lib.ptr(x), _lib.ptr(y0), _lib.ptr(y1), _lib.ptr(b), float(p), ctypes.c_uint64(st.seed),
+                _lib.ptr(st.counter(x.device)), ctypes.c_uint32(site0), ctypes.c_uint32(site1), _lib.ptr(ws), nbytes,
+                _lib.stream()), "gda_interior_kstep_lds_act_f32")
+        ctx.graph, ctx.K, ctx.has_bias, ctx.p = graph, K, bias is not None, float(p)
+        ctx.save_for_backward(y0)
+        if pair:
+            ctx.mark_non_differentiable(y1)
+            return y0, y1
+        return y0
+
+    @staticmethod
+    def backward(ctx, g0, g1=None):
+        (y0,) = ctx.saved_tensors
+        g0 = g0.contiguous()
+        gpre = torch.empty_like(g0)
+        _lib.check(_lib.lib().gda_relu_dropout_bwd_f32(_lib.ptr(g0), _lib.ptr(y0), _lib.ptr(gpre), g0.numel(), ctx.p,
+                                                       _lib.stream()), "gda_relu_dropout_bwd_f32")
+        gx = spmm_kstep(ctx.graph, gpre, ctx.K, None, transposed=True) if ctx.needs_input_grad[0] else None
+        gb = colsum(gpre) if ctx.has_bias and ctx.needs_input_grad[1] else None
+        return gx, gb, None, None, None, None
+
+
+def propagate_act(x, graph, K, bias, p, training, pair=False):
+    """``relu_dropout(propagate(x, graph, K, bias), p, training)`` -- twice, with independent draws, when ``pair`` -- as ONE
+    call when :func:`propagate_act_ok`; the caller checks that first."""
+    return _PropagateAct.apply(x, bias, graph, int(K), float(p) if training else 0.0, bool(pair))
 
 
 def lds_colmajor_ok(x, graph, K):
@@ -1420,6 +1508,50 @@ class _SplitHalves(torch.autograd.Function):
 
 def split_halves(x):
     return _SplitHalves.apply(x)
+
+
+class _ReluDropoutSplit(torch.autograd.Function):
+    """``split_halves(relu_dropout(x, p))`` for a stacked ``x [2n, d]``: the forward is the ordinary activation kernel,
+    the backward masks the two halves' gradients while it stacks them (gda_relu_dropout_bwd2_f32) -- the unmasked
+    ``[2n, d]`` stack that `_SplitHalves` + `_ReluDropout` write and read back is never formed."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        x = _f32c(x, "x")
+        y = torch.empty_like(x)
+        st = dropout_state
+        if st.seed is None:
+            st.seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+        _lib.check(_lib.lib().gda_relu_dropout_fwd_f32(_lib.ptr(x), _lib.ptr(y), x.numel(), float(p),
+                                                       ctypes.c_uint64(st.seed), _lib.ptr(st.counter(x.device)),
+                                                       ctypes.c_uint32(st.next_site()), _lib.stream()),
+                   "gda_relu_dropout_fwd_f32")
+        ctx.save_for_backward(y)
+        ctx.p = float(p)
+        ctx.set_materialize_grads(False)
+        n = x.size(0) // 2
+        return y.narrow(0, 0, n), y.narrow(0, n, n)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        (y,) = ctx.saved_tensors
+        if ga is None and gb is None:
+            return None, None
+        ga = None if ga is None else ga.contiguous()
+        gb = None if gb is None else gb.contiguous()
+        gx = torch.empty_like(y)
+        _lib.check(_lib.lib().gda_relu_dropout_bwd2_f32(_lib.ptr(ga), _lib.ptr(gb), _lib.ptr(y), _lib.ptr(gx),
+                                                        y.numel() // 2, ctx.p, _lib.stream()), "gda_relu_dropout_bwd2_f32")
+        return gx, None
+
+
+def relu_dropout_split(x, p, training=True):
+    """``split_halves(relu_dropout(x, p, training))`` with a fused backward; ``x [2n, d]`` on the device, d % 4 == 0,
+    training with p > 0 -- otherwise the composition."""
+    if (training and p > 0.0 and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+            and x.size(0) % 2 == 0 and (x.size(0) // 2 * x.size(1)) % 4 == 0):
+        return _ReluDropoutSplit.apply(x, float(p))
+    return split_halves(relu_dropout(x, p, training))
 
 
 def relu_dropout(x, p, training=True):

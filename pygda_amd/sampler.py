@@ -184,8 +184,11 @@ class _Ring:
     current when they take the next batch, or join their side streams back into it): the ``free`` record covers that
     stream only."""
 
-    def __init__(self, depth):
+    def __init__(self, depth, interior_rows=0):
         self.depth, self.slots, self.key, self.at, self.last = int(depth), None, None, 0, None
+        # > 0: every batch declares its first min(interior_rows, n) rows interior (gda_dsampler_batch_ex) -- the static
+        # shape the captured sampled step replays at (pygda_amd/sampled_graph.py)
+        self.interior_rows = int(interior_rows)
 
     def reset(self):
         """A new pass over the loader: the caller has ordered the sampler's stream behind the consumer's."""
@@ -290,8 +293,8 @@ class DeviceNeighborSampler:
             hit = self._layouts[key] = (fan, ncap, ecap, need, off, at, nb)
         return hit
 
-    def new_ring(self, depth):
-        return _Ring(depth)
+    def new_ring(self, depth, interior_rows=0):
+        return _Ring(depth, interior_rows)
 
     def _make_slots(self, ring, key, layout, stream, csr, plans, short_rows, n_seeds):
         """The ring's blocks, views, events and argument lists (once per loader)."""
@@ -308,7 +311,9 @@ class DeviceNeighborSampler:
         slots = []
         for i in range(ring.depth):
             sl = _Slot()
-            block = sl.block = torch.empty(total, dtype=torch.uint8, device=dev)
+            # zeroed once: the tail of a capacity-sized array behind a batch's live part then always holds valid node ids
+            # (zeros, or an earlier batch's) -- a consumer that runs at capacity shape gathers those rows too
+            block = sl.block = torch.zeros(total, dtype=torch.uint8, device=dev)
             base = block.data_ptr()
             at = lambda name: base + off[name][0]
             view = lambda name, dtype: block[off[name][0]:off[name][0] + off[name][1]].view(dtype)
@@ -330,12 +335,12 @@ class DeviceNeighborSampler:
                 _lib.check(L.gda_event_create(ctypes.byref(e)), "gda_event_create")
             sl.done, sl.free, sl.freed, sl.marked = ev[0].value, ev[1].value, False, None
             sl.gen = 0                   # bumped every time the block is written again: batches carry the value they saw
-            # gda_dsampler_batch's arguments; [5] = seeds, [10] = generator seed, [25] = wait_event change per batch
+            # gda_dsampler_batch_ex's arguments; [5] = seeds, [10] = generator seed, [25] = wait_event change per batch
             sl.args = [_lib.ptr(self.in_ptr), _lib.ptr(self.in_src), self.num_nodes, self.num_edges, self.max_in_degree,
                        None, int(n_seeds), at("seeds"), fan.ctypes.data, fan.size, None,
                        at("nodes"), at("ei"), at("ei") + ecap * 8, *csr_ptrs,
                        at("counts"), at("plan0") if plans else None, at("plan1") if plans else None, nb,
-                       pinned[i].data_ptr(), None, sl.done, _lib.ptr(ws), ws.numel(), stream.cuda_stream]
+                       pinned[i].data_ptr(), None, sl.done, ring.interior_rows, _lib.ptr(ws), ws.numel(), stream.cuda_stream]
             slots.append(sl)
         ring.slots, ring.key, ring._fan, ring._ws = slots, key, fan, ws
         return slots
@@ -362,7 +367,7 @@ class DeviceNeighborSampler:
         a[25] = sl.free if sl.freed else None
         sl.freed = False
         sl.gen += 1                      # graphs handed out for the block's previous contents are stale from here on
-        _lib.check(_lib.lib().gda_dsampler_batch(*a), "gda_dsampler_batch")
+        _lib.check(_lib.lib().gda_dsampler_batch_ex(*a), "gda_dsampler_batch_ex")
         return sl
 
     def enqueue(self, seeds, fanouts, seed=0, csr=True, ring=None):

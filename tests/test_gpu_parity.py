@@ -1765,6 +1765,58 @@ def test_relu_dropout_pair_and_split(p):
     assert (ops.relu_dropout_pair(x, p, False) == torch.cat([base, base])).all()
 
 
+@pytest.mark.parametrize("p", [0.0, 0.4])
+def test_relu_dropout_split_is_the_composition_with_one_backward_pass(p):
+    """ops.relu_dropout_split = split_halves(relu_dropout(x)) at the same dropout site: both halves bit for bit, and the
+    gradient (gda_relu_dropout_bwd2_f32: mask and stack in one pass) bit for bit -- with both halves consumed and with
+    one of them only (the missing gradient reads as zeros)."""
+    n, d = 3001 * 2, 64
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(n, d, generator=gen).to(DEV)
+    wa, wb = torch.randn(n // 2, d, generator=gen).to(DEV), torch.randn(n // 2, d, generator=gen).to(DEV)
+    st = ops.dropout_state
+    st.next_step(torch.device(DEV))
+    for which in ("both", "a", "b"):
+        res = []
+        for fused in (True, False):
+            xa = x.clone().requires_grad_()
+            st.site = 17
+            a, b = ops.relu_dropout_split(xa, p, True) if fused else ops.split_halves(ops.relu_dropout(xa, p, True))
+            loss = ((a * wa).sum() if which in ("both", "a") else 0) + ((b * wb).sum() if which in ("both", "b") else 0)
+            loss.backward()
+            res.append((a.detach(), b.detach(), xa.grad))
+        for got, want in zip(*res):
+            exact(got, want)
+    if p > 0:
+        assert float((res[0][0] == 0).float().mean()) > 0.5
+
+
+def test_cross_entropy_over_the_first_n_valid_rows_of_a_padded_batch():
+    """gda_softmax_nll_*_nv_f32 (the captured sampled step's padded batches): labels tagged with a DEVICE row count -> the
+    loss, the correct-prediction count and the gradient are those of the first n_valid rows; the rows behind them get
+    exact zeros whatever they hold (here: NaN logits and out-of-range labels)."""
+    gen = torch.Generator().manual_seed(6)
+    n, c, nv = 5000, 5, 3777
+    logits = torch.randn(n, c, generator=gen)
+    labels = torch.randint(0, c, (n,), generator=gen)
+    logits[nv:] = float("nan")
+    labels[nv:] = 0
+    lg = logits.to(DEV).requires_grad_()
+    lb = labels.to(DEV)
+    lb._gda_valid_rows = torch.tensor([nv], device=DEV)
+    loss = ops.softmax_nll(lg, lb)
+    stats = ops.ce_stats_for(lg, lb)
+    loss.backward()
+    ref_l = logits[:nv].clone().requires_grad_()
+    ref = F.nll_loss(F.log_softmax(ref_l, dim=1), labels[:nv])
+    ref.backward()
+    close(loss, ref, rtol=1e-6)
+    close(lg.grad[:nv], ref_l.grad, rtol=1e-5, atol=1e-9)
+    assert float(lg.grad[nv:].abs().max()) == 0.0
+    assert int(stats[1]) == int((logits[:nv].argmax(1) == labels[:nv]).sum())
+    close(stats[0], ref.double(), rtol=1e-6)
+
+
 def test_ce_stats_by_product():
     """The loss kernel's {loss, #correct} pair = loss.double() and (argmax == label).sum() of torch, ties and all."""
     gen = torch.Generator().manual_seed(4)

@@ -424,3 +424,125 @@ def test_sampled_training_no_longer_depends_on_host_sampler_threads():
     logits, labels = m.predict(tgt)
     assert logits.shape == (4 * 512, 5) and bool(torch.isfinite(logits).all())
     exact(labels, tgt.y[:4 * 512])
+
+
+def _sampled_fit(monkeypatch, env, steps=6, seed=1, dropout=0.5):
+    """cfg-S in small through the trainer's own loop: 200 k nodes per domain, 512 seeds at fan-out [15, 10], dropout on."""
+    import pygda_amd
+    from bench import make_cfg_s
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    N = 200_000
+    src, tgt = make_cfg_s(N, 20, 64, 5, 200, DEV), make_cfg_s(N, 20, 64, 5, 201, DEV)
+    m = pygda_amd.models.A2GNN(64, 32, 5, num_layers=2, dropout=dropout, s_pnums=0, t_pnums=10, weight=10, lr=0.005,
+                               weight_decay=0.001, device=DEV, epoch=2, verbose=0, batch_size=512, num_neigh=[15, 10])
+    torch.manual_seed(seed)
+    ops.dropout_state.counter(torch.device(DEV)).zero_()
+    ops.dropout_state.seed = 12345
+    net, optimizer, step, alpha = m._prepare(src, tgt)
+    m.source_loader.input_nodes = m.source_loader.input_nodes[:steps * 512]
+    m.target_loader.input_nodes = m.target_loader.input_nodes[:steps * 512]
+    seen = []
+    m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+    m._train_epochs(net, optimizer, step, alpha)
+    torch.cuda.synchronize()
+    return m, seen, {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+
+def test_captured_sampled_step_equals_the_eager_static_step_bit_for_bit(monkeypatch):
+    """the sampled step captured once at its static capacity shape and replayed
+    (pygda_amd/sampled_graph.py) against the SAME static-shape step issued eagerly every time -- same kernels, same
+    shapes, same draws, dropout on: per-epoch loss and accuracy and every parameter after 2 x 6 steps, bit for bit.  Then
+    against the ordinary eager loop on the batches' real shapes, dropout off (the keep-bits of the stacked source rows are
+    keyed on the element index, which moves with the row count; everything else differs by the row counts in the
+    reductions: fp32 summation order) -- losses to 1e-5 relative, parameters to 1e-4."""
+    mc, seen_c, par_c = _sampled_fit(monkeypatch, {"PYGDA_AMD_SAMPLED_GRAPH": "1", "PYGDA_AMD_SAMPLED_GRAPH_CAPTURE": "1"})
+    st = mc._sampled_graphed[1]
+    assert st.graph is not None and st.replays == 12 and st.fallbacks == 0, (st.replays, st.fallbacks)
+    assert mc.source_loader.static_interior == 512 * 16 and st.static[0].n_int == 512 * 16
+    assert st.static[0].ncap < st.static[0].ncap_block          # the static shape hugs the live count, not the capacity
+    me, seen_e, par_e = _sampled_fit(monkeypatch, {"PYGDA_AMD_SAMPLED_GRAPH": "1", "PYGDA_AMD_SAMPLED_GRAPH_CAPTURE": "0"})
+    assert me._sampled_graphed[1].graph is None and me._sampled_graphed[1].replays == 12
+    assert seen_c == seen_e, (seen_c, seen_e)
+    for k in par_c:
+        exact(par_c[k], par_e[k])
+    mc, seen_c, par_c = _sampled_fit(monkeypatch, {"PYGDA_AMD_SAMPLED_GRAPH": "1", "PYGDA_AMD_SAMPLED_GRAPH_CAPTURE": "1"},
+                                     dropout=0.0)
+    assert mc._sampled_graphed[1].replays == 12 and mc._sampled_graphed[1].fallbacks == 0
+    mr, seen_r, par_r = _sampled_fit(monkeypatch, {"PYGDA_AMD_SAMPLED_GRAPH": "0"}, dropout=0.0)
+    assert getattr(mr, "_sampled_graphed", None) is None
+    np.testing.assert_allclose([v[0] for v in seen_c], [v[0] for v in seen_r], rtol=1e-5)
+    np.testing.assert_allclose([v[1] for v in seen_c], [v[1] for v in seen_r], atol=2e-5)      # one row in 80 k may flip
+    for k in par_c:
+        scale = float(par_r[k].abs().max()) + 1e-12
+        np.testing.assert_allclose(par_c[k].cpu().numpy(), par_r[k].cpu().numpy(), rtol=0, atol=1e-4 * scale, err_msg=k)
+    # predict() after a captured fit: the loaders still hand out ordinary batches
+    logits, labels = mc.predict(None)
+    assert logits.shape == (6 * 512, 5) and bool(torch.isfinite(logits).all())
+
+
+def test_captured_sampled_step_falls_back_on_a_batch_it_cannot_take(monkeypatch):
+    """A pair whose interior plan is declined (here: forced) runs the ordinary eager step on its real shape, between two
+    replays, on the same optimiser state -- and the epoch's numbers stay those of the all-eager loop to fp32 order."""
+    from pygda_amd import sampled_graph as SG
+    orig = SG._StaticBatch.takes
+    calls = {"n": 0}
+
+    def takes(self, slot, sizes):
+        calls["n"] += 1
+        return orig(self, slot, sizes) and calls["n"] != 7      # the 4th pair's source batch (two calls per accepted pair)
+    monkeypatch.setattr(SG._StaticBatch, "takes", takes)
+    mc, seen_c, par_c = _sampled_fit(monkeypatch, {"PYGDA_AMD_SAMPLED_GRAPH": "1"}, dropout=0.0)
+    st = mc._sampled_graphed[1]
+    assert st.fallbacks == 1 and st.replays == 11, (st.fallbacks, st.replays)
+    monkeypatch.setattr(SG._StaticBatch, "takes", orig)
+    mr, seen_r, par_r = _sampled_fit(monkeypatch, {"PYGDA_AMD_SAMPLED_GRAPH": "0"}, dropout=0.0)
+    np.testing.assert_allclose([v[0] for v in seen_c], [v[0] for v in seen_r], rtol=1e-5)
+    for k in par_c:
+        scale = float(par_r[k].abs().max()) + 1e-12
+        np.testing.assert_allclose(par_c[k].cpu().numpy(), par_r[k].cpu().numpy(), rtol=0, atol=1e-4 * scale, err_msg=k)
+
+
+@pytest.mark.parametrize("p,pair", [(0.5, True), (0.3, False), (0.0, True)])
+def test_interior_kstep_with_the_activation_in_its_epilogue(p, pair):
+    """ops.propagate_act (gda_interior_kstep_lds_act_f32): the one-launch interior K-step writing dropout(relu(.)) itself
+    -- twice with independent draws for ``pair`` -- against relu_dropout(propagate(.)) at the same dropout sites: outputs
+    bit for bit (same pre-activation values, same keep-bits), and the gradients of x and the bias through autograd."""
+    from pygda_amd.graph import as_graph
+    n = 20000
+    ei = _graph(n, 300000, 11, loops=True)
+    g = torch.Generator().manual_seed(5)
+    data = Data(x=torch.randn(n, 16, generator=g), edge_index=ei, y=torch.zeros(n, dtype=torch.long)).to(DEV)
+    loader = NeighborLoader(data, [7, 5], batch_size=300, input_nodes=torch.randperm(n, generator=g)[:600], device=DEV)
+    K, d = 10, 128
+    st = ops.dropout_state
+    for batch in loader:
+        G = as_graph(batch.edge_index, batch.x.size(0))
+        nb = batch.x.size(0)
+        x = torch.randn(nb, d, generator=g).to(DEV)
+        bias = torch.randn(d, generator=g).to(DEV)
+        gy = torch.randn(nb, d, generator=g).to(DEV)
+        assert ops.propagate_act_ok(x, G, K, bias)
+        st.counter(x.device).fill_(3)
+        xa, ba = x.clone().requires_grad_(), bias.clone().requires_grad_()
+        st.site = 40
+        got = ops.propagate_act(xa, G, K, ba, p, True, pair)
+        g0 = got[0] if pair else got
+        if pair:
+            assert not got[1].requires_grad
+        g0.backward(gy)
+        xb, bb = x.clone().requires_grad_(), bias.clone().requires_grad_()
+        st.site = 40
+        pre = ops.propagate(xb, G, K, bb)
+        want0 = ops.relu_dropout(pre, p, True)
+        want1 = ops.relu_dropout(pre.detach(), p, True) if pair else None
+        want0.backward(gy)
+        exact(g0, want0)
+        if pair:
+            exact(got[1], want1)
+            if p > 0:
+                assert not torch.equal(got[0], got[1])                   # two draws, not one
+        exact(xa.grad, xb.grad)
+        exact(ba.grad, bb.grad)
+        kept = float((g0 != 0).float().mean())
+        assert 0.05 < kept < 0.6 * (1 - p) + 0.05                        # about half the pre-activations are positive
