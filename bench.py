@@ -110,6 +110,36 @@ def pmc_traffic(prefix="k_spmm<32, 4", pattern="*_rocprof_summary.json"):
     return None, None
 
 
+def traffic_provenance(fname):
+    """``{file, library_sha16, same_library_as_this_run}`` of a committed PMC summary: a counter
+    figure printed beside this run's durations says which build of the library it was taken with."""
+    if not fname:
+        return None
+    lib = summary_library(fname)
+    return {"file": fname, "library_sha16": lib, "same_library_as_this_run": lib is not None and lib == library_sha16()}
+
+
+def strict_fp32_companion(workload, steps, warmup, extra=()):
+    """ms/step of the SAME workload with every product in strict fp32 arithmetic -- PYGDA_AMD_MMD_ONE_PASS=0 (the two-pass
+    fp32-MFMA MMD kernels instead of the split-fp16 one-pass kernel) and PYGDA_AMD_GEMM_SPLIT_F16=0 (the fp32-MFMA tall
+    products) -- measured in a child process (both switches are read once per process), short form of this script
+    (VERDICT round 5, item 4b).  None if the child fails: a side figure must not cost the line."""
+    import subprocess
+    env = dict(os.environ, PYGDA_AMD_MMD_ONE_PASS="0", PYGDA_AMD_GEMM_SPLIT_F16="0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu-baseline", "--no-hbm-probe", "--no-side-lines", "--no-sustained", "--profile-run", "--no-strict-fp32",
+           *extra]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        return {"ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                "what": "same workload, same process layout, PYGDA_AMD_MMD_ONE_PASS=0 + PYGDA_AMD_GEMM_SPLIT_F16=0: every "
+                        "product on fp32 MFMAs (the reference's own arithmetic type), child process"}
+    except Exception as exc:              # noqa: BLE001
+        return {"error": f"{type(exc).__name__}: {exc}"[:200]}
+
+
 def rocprof_kernel(prefix, pattern="*_rocprof_summary.json"):
     """``(avg_us, calls, file)`` of the first kernel whose name starts with ``prefix`` in the newest committed
     ``rocprofv3 --kernel-trace --stats`` summary matching ``pattern`` (profiles/, made by tools/profile_r4.sh from this
@@ -208,12 +238,15 @@ def hbm_regime_probe(device, nodes=5_000_000, avg_degree=20, d=128, iters=5):
     us = s.elapsed_time(e) * 1e3 / iters
     alg = nnz * 8 + (nodes + 1) * 4 + 2 * nodes * d * 4
     gather = nnz * (8 + 4 * d) + nodes * d * 4
-    traffic, src_file = pmc_traffic("k_spmm<32, 4", "r2_spmm5m*_summary.json")
+    traffic, src_file = pmc_traffic("k_spmm<32, 4", "r[0-9]*_hbm_uniform*_summary.json")      # tools/profile.sh <round> hbm
+    if traffic is None:
+        traffic, src_file = pmc_traffic("k_spmm<32, 4", "r2_spmm5m*_summary.json")
     del G, x, y, ei
     torch.cuda.empty_cache()
     out = {"kernel": f"spmm_csr_f32[d={d}] (k_spmm<32,4>), N={nodes}, nnz={nnz}", "bound": "hbm",
            "achieved": alg / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBS,
-           "traffic": traffic, "traffic_source": src_file, "avg_launch_us": us, "launches": iters,
+           "traffic": traffic, "traffic_source": src_file, "traffic_provenance": traffic_provenance(src_file),
+           "avg_launch_us": us, "launches": iters,
            "algorithmic_bytes_per_launch": alg, "gather_model_bytes_per_launch": gather,
            "gather_model_GBs": gather / us / 1e3, "gather_model_frac": gather / us / 1e3 / HBM_PEAK_GBS,
            "traffic_over_algorithmic": (traffic / alg) if traffic else None,
@@ -266,9 +299,13 @@ def rmat_probe(device, d=128, iters=5):
                      "gather_model_over_algorithmic": gather / alg, "gather_model_GBs": gather / us / 1e3}
         # counter traffic of the same aggregation from the committed PMC passes (tools/rmat_pmc_case.py under separate
         # --pmc FETCH_SIZE / WRITE_SIZE runs): how much of the gather model the caches absorb on a skewed graph
-        traffic, tfile = pmc_traffic("k_spmm<32, 4", "r[0-9]*_rmat_" + ("asgen" if name == "as_generated" else "reorder") + "*_summary.json")
+        which = "asgen" if name == "as_generated" else "reorder"
+        traffic, tfile = pmc_traffic("k_spmm<32, 4", "r[0-9]*_hbm_" + which + "*_summary.json")
+        if traffic is None:
+            traffic, tfile = pmc_traffic("k_spmm<32, 4", "r[0-9]*_rmat_" + which + "*_summary.json")
         if traffic:
-            res[name].update(traffic_bytes_per_launch=traffic, traffic_source=tfile, traffic_over_algorithmic=traffic / alg)
+            res[name].update(traffic_bytes_per_launch=traffic, traffic_source=tfile, traffic_over_algorithmic=traffic / alg,
+                             traffic_provenance=traffic_provenance(tfile))
         del G, x
         torch.cuda.empty_cache()
     return res
@@ -529,7 +566,21 @@ def run_cfg_s(args, world, rank, dev, cpu_base=True):
                                       "are accounting figures, the kernel's counter traffic is in `traffic`")
                 return out
             ach = r["flops"] / secs / 1e12
-            return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            split16 = (os.environ.get("PYGDA_AMD_GEMM_SPLIT_F16", "1") != "0"
+                       and (name.startswith("dense_projection[") or name.startswith("dense_projection_dgrad["))
+                       and all(v in ("128", "256") for v in name.split("[")[1].rstrip("]").split("x")))
+            if split16:
+                # k_tall_fwd_h (csrc/gda_gemm_split.inc): three fp16 MFMAs on split operands per fp32-equivalent product
+                # -- priced against the roof of the instructions it EXECUTES; the fp32-equivalent figure stands beside it
+                return {"kernel": name, "bound": "mfma", "executes": "v_mfma_f32_32x32x16_f16 on split operands (hi.hi + "
+                        "hi.lo + lo.hi): 3 x the fp32-equivalent flops", "achieved": 3 * ach, "peak": F16_MFMA_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": 3 * ach / F16_MFMA_PEAK_TF, "traffic": None, "launches": r["launches"],
+                        "avg_launch_us": r["avg_us"],
+                        "fp32_equivalent": {"achieved": ach, "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TF},
+                        "note": "memory-bound at these shapes (a [rows, 128] operand in, one out): the MFMA fraction is small "
+                                "by construction"}
+            return {"kernel": name, "bound": "mfma", "executes": "v_mfma_f32_*_f32", "achieved": ach,
+                    "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None, "launches": r["launches"],
                     "avg_launch_us": r["avg_us"]}
         agg = [k for k in prof if k.startswith("spmm") or k.startswith("kstep_lds") or k.startswith("interior_lds")]
@@ -938,12 +989,19 @@ def run_cfg_a(args, world, rank, dev, side=False):
                 out["back_to_back_launch_us_K0"] = fixed_us
                 out["frac_in_step_loops_back_to_back"] = per_launch / ((alone_us - fixed_us) * 1e-6) / 1e9 / peak
             out["traffic"], out["traffic_source"] = pmc_traffic("k_kstep_lds", prof_pattern)
+            out["traffic_provenance"] = traffic_provenance(out["traffic_source"])
             if r.get("hbm_bytes"):
                 out["hbm_bytes_per_launch"] = r["hbm_bytes"] / r["launches"]
                 out["hbm_frac_real"] = r["hbm_bytes"] / r["launches"] / (dur_us * 1e-6) / 1e9 / HBM_PEAK_GBS
             # SURVEY 8(d)'s accounting for comparison only: the K aggregations one launch stands for, as if each had
             # moved its algorithmic bytes over HBM -- an equivalence, not a bandwidth
             alg = r["bytes"] / r["launches"]
+            out["frac_survey_8d"] = alg / (dur_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+            out["frac_survey_8d_is"] = ("SURVEY 8(d): the algorithmic bytes of the K aggregations one launch stands for "
+                                        "(K x (nnz*8 + (N+1)*4 + 2*N*d*4)) over this launch's duration over 8 TB/s -- an "
+                                        "equivalence, the operands never leave LDS")
+            if alone_us:
+                out["frac_survey_8d_back_to_back"] = alg / (alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS
             out["algorithmic_equivalent"] = {"bytes_per_launch": alg, "K_aggregations_per_launch": int(name.split("K=")[1].rstrip("]")),
                                              "GBs": alg / (dur_us * 1e-6) / 1e9,
                                              "algorithmic_equivalent_frac": alg / (dur_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
@@ -1082,6 +1140,189 @@ def run_cfg_a(args, world, rank, dev, side=False):
     return out
 
 
+def other_configs(dev, epochs=30, which=("grade_mmd", "grade_js", "udagcn", "adagcn")):
+    """BASELINE.json configs[2] / configs[3] in the measured set: GRADE Citationv1 -> DBLPv7 with
+    the MMD and the (script default) JS discriminator, UDAGCN and AdaGCN ACMv9 -> Citationv1, full batch, at the
+    hyper-parameters of benchmark/node/run_citation.sh:45,109-110 on shape-identical stand-ins (Citationv1: 8,935 nodes /
+    15,098 edges).  Per trainer: steady-state ms/epoch of ``fit()`` as it runs by default (the captured step where the
+    trainer has one), then a short eager pass under the HIP-event profiler for the dominant kernel family and its roofline."""
+    import numpy as np
+    import pygda_amd
+    from pygda_amd import profiler
+    M = pygda_amd.models
+    pairs = {"C->D": make_cfg_a(seed=204, ns=8935, es=15098, nt=5484, et=8117),
+             "A->C": make_cfg_a(seed=203, ns=9360, es=15556, nt=8935, et=15098)}
+    F = 6775
+
+    def build(name, graphed, ep):
+        kw = dict(device=dev, epoch=ep, verbose=0, use_hip_graph=graphed)
+        if name == "grade_mmd":
+            return "C->D", M.GRADE(F, 128, 5, num_layers=5, dropout=0.5, disc="MMD", weight=0.01, lr=0.001, weight_decay=0.001, **kw)
+        if name == "grade_js":
+            return "C->D", M.GRADE(F, 128, 5, num_layers=5, dropout=0.5, disc="JS", weight=0.01, lr=0.001, weight_decay=0.001, **kw)
+        if name == "udagcn":
+            return "A->C", M.UDAGCN(F, 128, 5, num_layers=2, ppmi=True, adv_dim=40, lr=0.0001, weight_decay=0.001, **kw)
+        return "A->C", M.AdaGCN(F, 128, 5, num_layers=2, dropout=0.4, adv_dim=40, lr=0.01, weight_decay=0.01, **kw)
+
+    import gc
+    out = {}
+    for name in which:
+        try:
+            torch.manual_seed(0)
+            np.random.seed(0)
+            task, m = build(name, None, epochs)
+            src, tgt = pairs[task]
+            stamps = []
+            m.epoch_hook = lambda e, loss, acc, secs: stamps.append((time.perf_counter(), loss))
+            m.fit(src, tgt)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            half = len(stamps) // 2           # steady state: the first epochs hold ingestion, PPMI builds, the capture
+            ms = (t1 - stamps[half - 1][0]) / (len(stamps) - half) * 1e3
+            res = {"task": task, "ms_per_epoch": ms, "epochs": epochs,
+                   "execution": "hipGraph replay" if getattr(m, "_graphed", None) is not None else "eager launches",
+                   "finite": bool(np.isfinite(stamps[-1][1]))}
+            del m
+            torch.cuda.synchronize()
+            gc.collect()
+            # the kernel families of one eager epoch
+            task, m = build(name, False, 4)
+            seen = []
+            m.epoch_hook = lambda e, loss, acc, secs: (seen.append(e), profiler.start() if e == 0 else None)
+            m.fit(src, tgt)
+            torch.cuda.synchronize()
+            profiler.stop()
+            prof = profiler.summary()
+            n_ep = max(len(seen) - 1, 1)
+            if prof:
+                dom = max(prof, key=lambda k: prof[k]["ms"])
+                r = prof[dom]
+                secs = r["ms"] * 1e-3
+                hbm = dom.startswith("spmm") or dom.startswith("kstep") or dom.startswith("sparse")
+                res["dominant_kernel"] = {
+                    "kernel": dom, "ms_per_epoch": r["ms"] / n_ep, "launches_per_epoch": r["launches"] / n_ep,
+                    "bound": "hbm" if hbm else "mfma",
+                    "frac": (r["bytes"] / secs / 1e9 / HBM_PEAK_GBS) if hbm else (r["flops"] / secs / 1e12 / FP32_MFMA_PEAK_TF),
+                    "frac_is": ("SURVEY 8(d) algorithmic bytes over the HIP-event duration over 8 TB/s (cache-resident at this "
+                                "size: an accounting figure)" if hbm else "flops over the HIP-event duration over the fp32 MFMA peak"),
+                    "timing": "HIP events around the family's launches, eager epochs"}
+                res["kernel_time_ms_per_epoch"] = {k: v["ms"] / n_ep for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:6]}
+            out[name] = res
+            del m
+            torch.cuda.synchronize()
+            gc.collect()
+        except Exception as exc:                  # noqa: BLE001 -- a side object must not cost the line
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            profiler.stop()
+    torch.cuda.empty_cache()
+    return out
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(out, budget=1990):
+    """The contract line, under 2 kB: the driver's keys, `roofline` (with SURVEY 8(d)'s fraction inside it), `cpu_baseline`,
+    `kernel_time_ms_per_step` and one short object per side measurement.  Everything else -- the long explanatory strings,
+    the per-kernel rooflines, the sustained / HBM-regime / MMD objects -- is in the details object (stderr line and
+    bench_details.json), which this line names."""
+    c = _pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "epochs_per_sec", "steps_per_sec", "reference_equivalent_edges_per_sec",
+              "library_sha16", "profile_run", "functional_check", "rccl_ranks_seen")
+    c["vs_baseline"] = out.get("vs_baseline")                  # null: BASELINE.md holds no published number for this metric
+    cfg = out.get("config", {})
+    c["config"] = _pick(cfg, "edges_aggregated_per_step", "edges_aggregated_per_step_reference_equivalent", "graph",
+                        "host_ms_per_step_max_median", "host_work_ms_per_step", "hipMalloc_calls_in_timed_region",
+                        "aggregation_launches_per_step")
+    c["config"]["workload"] = str(cfg.get("workload", ""))[:150]
+    for k in ("execution", "parallelism"):
+        if cfg.get(k):
+            c["config"][k] = str(cfg[k])[:90]
+    r = out.get("roofline") or {}
+    c["roofline"] = _pick(r, "kernel", "bound", "achieved", "peak", "unit", "frac", "frac_survey_8d", "traffic",
+                          "avg_launch_us", "back_to_back_launch_us", "back_to_back_launch_us_K0",
+                          "gathered_words_that_are_padding", "launches", "cus_occupied")
+    if "frac_is" in r:
+        c["roofline"]["frac_is"] = str(r["frac_is"])[:110]
+    if "cpu_baseline" in out:
+        c["cpu_baseline"] = _pick(out["cpu_baseline"], "value", "unit", "cores", "kind", "cpu")
+        c["cpu_baseline"]["sample"] = str(out["cpu_baseline"].get("sample", ""))[:100]
+    if "kernel_time_ms_per_step" in out:
+        c["kernel_time_ms_per_step"] = {k.replace("dense_projection", "gemm").replace("sparse_projection", "spgemm"): round(v, 4)
+                                        for k, v in out["kernel_time_ms_per_step"].items()}
+    sr = out.get("scaling_reference")
+    if sr:
+        c["scaling_reference"] = _pick(sr, "value", "unit", "ms_per_step", "steps", "host_work_ms_per_step",
+                                       "host_ms_per_step_max_median", "reference_equivalent_edges_per_sec")
+    if out.get("sustained"):
+        c["sustained"] = _pick(out["sustained"], "ms_per_step", "device_ms_per_step_p50", "device_ms_per_step_p99", "steps")
+    hb = out.get("roofline_hbm_regime")
+    if hb:
+        c["hbm_regime"] = _pick(hb, "frac", "traffic_over_algorithmic", "avg_launch_us")
+        rm = (hb.get("rmat_2^22") or {}).get("trainer_default")
+        if rm:
+            c["hbm_regime"]["rmat"] = _pick(rm, "frac", "traffic_over_algorithmic")
+    mm = (out.get("roofline_mmd") or {}).get("k_mmd_fused")
+    if mm:
+        c["mmd_fused"] = _pick(mm, "avg_launch_us_rocprof", "frac")
+    if out.get("strict_fp32"):
+        c["strict_fp32_ms_per_step"] = {k: (v.get("ms_per_step") if isinstance(v, dict) else None)
+                                        for k, v in out["strict_fp32"].items()}
+    if out.get("other_configs"):
+        c["other_configs_ms_per_epoch"] = {k: (round(v["ms_per_epoch"], 4) if isinstance(v, dict) and "ms_per_epoch" in v else None)
+                                           for k, v in out["other_configs"].items()}
+    if out.get("cfgA_replicas"):
+        c["cfgA_replicas"] = _pick(out["cfgA_replicas"], "ms_per_step", "epochs_per_sec", "replicas", "error")
+    c["details"] = "bench_details.json + the stderr line: all objects in full"
+
+    def rnd(v):                                 # six significant digits are what a reader compares; 17 are what json prints
+        if isinstance(v, float):
+            return float(f"{v:.6g}")
+        if isinstance(v, dict):
+            return {k: rnd(x) for k, x in v.items()}
+        if isinstance(v, list):
+            return [rnd(x) for x in v]
+        return v
+    c = rnd(c)
+    # the driver's tail is 2,000 characters: shed the least-read parts first, never the contract keys / roofline / cpu_baseline
+    size = lambda: len(json.dumps(c))
+    if size() > budget and "kernel_time_ms_per_step" in c:
+        c["kernel_time_ms_per_step"] = dict(sorted(c["kernel_time_ms_per_step"].items(), key=lambda kv: -kv[1])[:8])
+    for k in ("roofline.frac_is", "cpu_baseline.sample", "config.execution", "config.workload", "mmd_fused", "sustained",
+              "hbm_regime", "other_configs_ms_per_epoch", "kernel_time_ms_per_step"):
+        if size() <= budget:
+            break
+        a, _, b = k.partition(".")
+        if b:
+            if k == "config.workload":
+                c["config"]["workload"] = c["config"]["workload"][:60]
+            else:
+                c.get(a, {}).pop(b, None)
+        else:
+            c.pop(a, None)
+    return c
+
+
+def emit(out, args):
+    """stdout: ONE line -- the compact contract line (or, with --full-line, everything).  The whole object also goes to
+    stderr (one line, ahead of the contract line) and to bench_details.json beside this script (gpurun_out/ when it exists)."""
+    full = json.dumps(out)
+    if args.full_line:
+        print(full)
+        return
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        path = os.path.join(d if os.path.isdir(d) else ROOT, "bench_details.json")
+        with open(path, "w") as fh:
+            fh.write(full + "\n")
+    except OSError:
+        pass
+    sys.stderr.write(full + "\n")
+    sys.stderr.flush()
+    print(json.dumps(compact_line(out)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1116,6 +1357,14 @@ def main():
                     help="for runs under rocprofv3: stop after the timed region (no eager HIP-event pass, no back-to-back "
                          "kernel probes), so that the profiler's per-kernel averages are those of the replayed steps")
     ap.add_argument("--no-sustained", action="store_true", help="skip the 400-replay sustained measurement of cfg-A")
+    ap.add_argument("--no-strict-fp32", action="store_true",
+                    help="skip the strict-fp32 companion figures (child processes with PYGDA_AMD_MMD_ONE_PASS=0 and "
+                         "PYGDA_AMD_GEMM_SPLIT_F16=0)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the configs[2] / configs[3] side object (GRADE, UDAGCN, AdaGCN epoch times)")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the whole result object as the stdout line (default: the compact contract line on stdout, "
+                         "the whole object on stderr and in bench_details.json)")
     ap.add_argument("--no-rccl-direct", action="store_true",
                     help="collectives through torch.distributed's ProcessGroup instead of the library-owned RCCL communicator")
     ap.add_argument("--rccl-direct", action="store_true",
@@ -1170,10 +1419,34 @@ def main():
     if workload == "cfgS":
         out = run_cfg_s(args, world, rank, dev)
         if world > 1 and not args.no_side_lines:
+            # The side object runs code that has never met two GPUs (segmented / whole-step capture with collectives
+            # between the ranks): an exception is caught below, a HANG cannot be -- so a watchdog per rank ends the
+            # process cleanly after PYGDA_AMD_BENCH_SIDE_TIMEOUT seconds, rank 0 printing the scaling line it already
+            # holds with the side object marked as timed out.
+            import threading
+            limit = float(os.environ.get("PYGDA_AMD_BENCH_SIDE_TIMEOUT", "240"))
+
+            def give_up():
+                if rank == 0:
+                    out["cfgA_replicas"] = {"error": f"watchdog: the cfg-A replicas side measurement did not finish within "
+                                                     f"{limit:.0f} s and was abandoned; the scaling line above it is complete"}
+                    if args.share_gpus:
+                        out["functional_check"] = f"{world} ranks over gloo (--share-gpus): NOT a measurement"
+                    emit(out, args)
+                    sys.stdout.flush()
+                sys.stderr.write(f"bench.py rank {rank}: side-object watchdog fired after {limit:.0f} s\n")
+                sys.stderr.flush()
+                os._exit(0)
+
+            guard = threading.Timer(limit, give_up)
+            guard.daemon = True
+            guard.start()
             try:                          # a labelled side object must not cost the scaling line
                 side = run_cfg_a(side_args, world, rank, dev, side=True)
             except Exception as exc:      # noqa: BLE001 -- reported in the line, rank-local
                 side = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+            finally:
+                guard.cancel()
             if rank == 0:
                 out["cfgA_replicas"] = side
     else:
@@ -1190,12 +1463,29 @@ def main():
                 # the host side of those steps: [slowest, median] step, and where the slowest one spent its time -- a
                 # single slow step is 1/30 of this figure
                 "host_ms_per_step_max_median": side["config"].get("host_ms_per_step_max_median"),
+                "host_work_ms_per_step": side["config"].get("host_work_ms_per_step"),
+                "host_wait_ms_per_step": side["config"].get("host_wait_ms_per_step"),
+                "hipMalloc_calls_in_timed_region": side["config"].get("hipMalloc_calls_in_timed_region"),
+                "execution": side["config"].get("execution"),
+                "edges_aggregated_per_step": side["config"].get("edges_aggregated_per_step"),
+                "edges_aggregated_per_step_reference_equivalent": side["config"].get("edges_aggregated_per_step_reference_equivalent"),
+                "reference_equivalent_edges_per_sec": side.get("reference_equivalent_edges_per_sec"),
                 "host_slowest_step": (side["config"].get("host_phases") or {}).get("slowest_step"),
                 "roofline": side["roofline"], "roofline_dense_projection": side["roofline_dense_projection"]}
         elif world > 1 and rank == 0:
             out["config"]["parallelism"] = (f"{world} full-batch replicas (explicit --workload cfgA; value is ONE "
                                             "replica's rate, the job's epoch rate is epochs_per_sec)")
         thunk = out.pop("_cpu_baseline_thunk", None) if isinstance(out, dict) else None
+        if (rank == 0 and world == 1 and not args.no_other_configs and not args.profile_run and not args.force_dp
+                and not args.adv and not args.eager and not args.no_side_lines):
+            out["other_configs"] = other_configs(dev)
+        strict = (rank == 0 and world == 1 and not args.no_strict_fp32 and not args.profile_run and not args.force_dp
+                  and not args.adv and not args.eager)
+        if strict:
+            # BEFORE the CPU baseline (30 s of all host cores): the children want a quiet host
+            out["strict_fp32"] = {"cfgA": strict_fp32_companion("cfgA", args.steps, args.warmup, ["--graph", args.graph])}
+            if "scaling_reference" in out:
+                out["strict_fp32"]["cfgS"] = strict_fp32_companion("cfgS", min(args.steps, 30), min(max(args.warmup, 5), 10))
         if thunk is not None:
             out["cpu_baseline"] = thunk()
     if rank == 0:
@@ -1212,7 +1502,7 @@ def main():
         if args.share_gpus:
             out["functional_check"] = (f"{world} ranks on {torch.cuda.device_count()} GPU(s) over gloo (--share-gpus): "
                                        "the N-rank code path end to end, NOT a measurement")
-        print(json.dumps(out))
+        emit(out, args)
     if dist.is_initialized():
         dist.destroy_process_group()
 
