@@ -262,7 +262,7 @@ def hbm_regime_probe(device, nodes=5_000_000, avg_degree=20, d=128, iters=5):
 def rmat_probe(device, d=128, iters=5):
     """The same full-graph aggregation on a power-law graph (R-MAT a, b, c = 0.57, 0.19, 0.19; 2^22 nodes, 32 M edges
     symmetrised), as generated and after a degree-sorted relabelling (hubs first: the rows most rows gather share
-    cache lines and pages) -- the locality option a uniform graph has no use for."""
+    cache lines and pages) -- the locality option a uniform graph has no use for (profiles/HISTORY.md 5, round 3)."""
     from pygda_amd import ops
     from pygda_amd.graph import build_csr
     from tools.spmm_sweep import rmat_edges
@@ -1072,7 +1072,7 @@ def run_cfg_a(args, world, rank, dev, side=False):
             del out["kernel_time_ms_per_step"][k]
     assert all(v <= ms for v in out["kernel_time_ms_per_step"].values())
     if not args.adv and "mmd_fwd" in prof:
-        # the MMD pair: the two matrix-core kernels against the products they evaluate.  times x [m x m] pair
+        # the MMD pair (profiles/HISTORY.md 4.3): the two matrix-core kernels against the products they evaluate.  times x [m x m] pair
         # tiles over d features: the distance product (only the upper triangle of the symmetric matrix is computed) and
         # the backward's G x T product (full).  Durations: committed rocprofv3 averages per kernel when present; the live
         # brackets cover the whole C call (forward = 4 kernels, backward = 2)
@@ -1349,7 +1349,7 @@ def main():
                     help="skip the second workload's labelled side object (N = 1: cfg-S on one GPU, the base point "
                          "of the scaling curve; N > 1: cfg-A replicas)")
     ap.add_argument("--side-steps", type=int, default=60,
-                    help="timed steps of the labelled side line (60: one rare 30 - 50 ms host stall, DESIGN 5, moves a 30-step\n"
+                    help="timed steps of the labelled side line (60: one rare 30 - 50 ms host stall, profiles/HISTORY.md 5, moves a 30-step\n"
                          "figure by 1.1 - 1.6 ms/step)")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel code path (RCCL exchange steps) on a 1-rank group")
@@ -1415,7 +1415,7 @@ def main():
     workload = args.workload or ("cfgA" if world == 1 else "cfgS")
     side_args = argparse.Namespace(**vars(args))
     side_args.steps = args.side_steps if args.steps >= 20 else min(args.steps, args.side_steps)
-    side_args.warmup = max(args.warmup, 10) if args.steps >= 20 else min(args.warmup, 5)     # a fresh allocator pool: see DESIGN 5
+    side_args.warmup = max(args.warmup, 10) if args.steps >= 20 else min(args.warmup, 5)     # a fresh allocator pool: see profiles/HISTORY.md 5
     if workload == "cfgS":
         out = run_cfg_s(args, world, rank, dev)
         if world > 1 and not args.no_side_lines:

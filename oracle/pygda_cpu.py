@@ -11,7 +11,7 @@ in the same evaluation order, so that on CPU the results are bit-identical to th
 reference running on PyG's non-fused path (``index_select`` -> multiply ->
 scatter-add in edge order).
 
-Pinning status (see ``tests/golden/make_golden.py`` and DESIGN.md §3):
+Pinning status (see ``tests/golden/make_golden.py`` and profiles/HISTORY.md §3):
   * ``guassian_kernel`` / ``get_MMD`` / ``MMD`` / ``GradReverse`` / ``Attention``:
     PINNED -- checked against the reference's own files imported by path.
   * ``gcn_norm`` / ``PropGCNConv`` / ``CachedGCNConv`` / ``A2GNNBase`` /

@@ -242,7 +242,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // chunk k + 1 are issued before chunk k's MFMAs, and no thread walks a norm chain between the barrier and the MFMAs.
 template <int KN, bool SQ, bool FAST>
 // round 4: asked for eight workgroups per CU the compiler fits the kernel into 63 registers, accumulators included, without a
-// spill (unhinted: 80 + 16 = five waves per SIMD) -- this kernel lives on occupancy (see the 128-tile experiment)
+// spill (unhinted: 80 + 16 = five waves per SIMD) -- this kernel lives on occupancy (see the 128-tile experiment, profiles/HISTORY.md 4.3)
 __global__ void __launch_bounds__(TB, 8)
 k_pairdist(Rows R, int64_t d, int64_t m, int nt, const float* __restrict__ bandwidth, KParams kp,
            float* __restrict__ l2, double* __restrict__ partial, const float* __restrict__ norms) {

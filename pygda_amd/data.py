@@ -81,7 +81,7 @@ class Data:
 def degree_order(edge_index, num_nodes):
     """``new_id [N]``: the relabelling that numbers the nodes by decreasing in-degree (ties in id order).  On a power-law
     graph the rows most rows gather then share cache lines and pages: the full-graph aggregation of an R-MAT 2^22 graph
-    runs 6.8 -> 5.2 ms with it (`roofline_hbm_regime.rmat_2^22`); a uniform graph has nothing to gain."""
+    runs 6.8 -> 5.2 ms with it (profiles/HISTORY.md 5, `roofline_hbm_regime.rmat_2^22`); a uniform graph has nothing to gain."""
     deg = torch.bincount(edge_index[1], minlength=num_nodes)
     order = torch.argsort(deg, descending=True, stable=True)          # order[k] = old id of the k-th node
     new_id = torch.empty_like(order)
@@ -194,7 +194,7 @@ class NeighborLoader:
         # assembled there by the row-gather kernel, only node / edge ids cross PCIe
         self.data = data.to(device) if (device is not None and not full) else data
         # full batch on a large power-law graph: train on the degree-ordered relabelling (hubs first: the rows most
-        # rows gather share cache lines and pages -- 7.85 -> 5.16 ms per aggregation on R-MAT 2^22); node i
+        # rows gather share cache lines and pages -- 7.85 -> 5.16 ms per aggregation on R-MAT 2^22, profiles/HISTORY.md 5); node i
         # of the caller's numbering is row new_id[i] of every batch, predict() maps results back
         # (``auto_reorder=True``: the trainers whose step reads nothing but the loader's batches ask for it -- a caller
         # that indexes a batch with structures of its own built from the original numbering must not)

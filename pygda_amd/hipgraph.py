@@ -131,7 +131,7 @@ class GraphedStep:
         self._order = []
         # `unroll` consecutive steps in ONE capture (each with its own sample block): between the last kernel of a
         # replay and the first of the next the device idles 40-50 us on this runtime whatever the host does
-        # (DESIGN 4.7); a replay of U steps pays that once.  A one-step graph of the same step serves the remainder.
+        # (profiles/HISTORY.md 4.7); a replay of U steps pays that once.  A one-step graph of the same step serves the remainder.
         self.unroll = max(1, int(unroll)) if (type(self) is GraphedStep and not dp) else 1
         self._sub = 0                     # sub-step being issued (selects the sample block)
         self._fills = {}                  # sub-step -> refill callables, in call order
@@ -452,7 +452,7 @@ class GraphedStepSplit(GraphedStep):
     optimiser step.
 
     Why: on this runtime a forked capture replays with 5-6 us of spacing per kernel and runs branches forked at
-    its root one after the other (tools/graph_fork_*.py) -- the one-graph A2GNN step spends the first
+    its root one after the other (tools/graph_fork_*.py, profiles/HISTORY.md 4.7) -- the one-graph A2GNN step spends the first
     110 us on the source branch alone.  Single-branch graphs replay gap-free through pre-built AQL packets, and two
     graph launches on two streams do overlap.  Autograd's tape spans the captures (the technique of
     torch.cuda.make_graphed_callables and of GraphedStepDP): the forward graphs keep their outputs and saved

@@ -33,11 +33,11 @@ class A2GNN(BaseGDA):
         self.compute_target_logits = True
         import os
         self.overlap_streams = os.environ.get("PYGDA_AMD_OVERLAP", "1") == "1"
-        self.split_graphs = os.environ.get("PYGDA_AMD_SPLIT_GRAPHS", "0") == "1"   # measured slower: opt-in
+        self.split_graphs = os.environ.get("PYGDA_AMD_SPLIT_GRAPHS", "0") == "1"   # measured slower (profiles/HISTORY.md 4.7): opt-in
         # sampled mini-batches: the source branch (s_pnums = 0: projections and activations, chip-filling kernels) beside
         # the target branch (K-step launches over ~17 k interior rows: latency-sized) on two streams -- cfg-S, 40 steps,
         # three runs each on one box: 2.88 / 2.98 / 2.92 ms/step against 3.10 / 3.11 / 4.11 on one stream
-        # (profiles/r4_stream_experiments.txt); eager launches, so none of the forked-graph scheduling of DESIGN 4.7
+        # (profiles/r4_stream_experiments.txt); eager launches, so none of the forked-graph scheduling of profiles/HISTORY.md 4.7
         self.overlap_sampled = os.environ.get("PYGDA_AMD_SAMPLED_OVERLAP", "1") == "1"
         self.features_first = os.environ.get("PYGDA_AMD_FEATURES_FIRST", "1") == "1"
         # the step reads nothing but the loaders' batches: a large power-law full-batch graph may be trained on its
@@ -98,7 +98,7 @@ class A2GNN(BaseGDA):
             # Issuing the target feature pass ahead of the source branch as well, this chain and the loss-unused
             # logits pass behind the domain loss and the backward pass as ordered engine runs was built and measured in
             # the same session: 0.48 - 0.60 ms (the runtime puts the source branch on the logits pass's queue, as in
-            # round 2 -- DESIGN 4.7) -- removed again.
+            # round 2 -- profiles/HISTORY.md 4.7) -- removed again.
             cls_params = [p for p in net.cls.parameters() if p.requires_grad]
             self._src_ready = torch.cuda.Event()      # what the other branches join on: the forward pass, not this chain
             self._src_ready.record()

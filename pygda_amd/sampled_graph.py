@@ -20,7 +20,7 @@ behind the live ones, both interior K-step plans).  So the step runs at the capa
   a few microseconds -- after which the ring block is free again), the MMD draws over the live counts into the static
   sample block (the same CPU-generator draws, in the same order, as the eager ``MMD()``), one ``hipGraphLaunch``.
 
-The capture is single-stream (no fork: a forked capture is enqueued node by node on this runtime; a
+The capture is single-stream (no fork: a forked capture is enqueued node by node on this runtime, profiles/HISTORY.md 4.7; a
 single-stream one replays through pre-built packets), statistics included.  A batch the static shape cannot take (an
 interior plan declined, fewer live rows than twice the interior capacity) runs the ordinary eager step on its real
 shape -- same optimiser state, same dropout counters -- and the next one replays again.

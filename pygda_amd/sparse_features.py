@@ -97,7 +97,7 @@ class _SparseLinear(torch.autograd.Function):
     def forward(ctx, weight, sf, vals=None, bias=None):
         # [F, h]: no copy once the weight is stored gather-major (_store_gather_major).  Sharing one transposed copy
         # between the source and the target branch (formed before the streams fork) was measured and dropped: a
-        # kernel ahead of the fork costs the captured step 60-70 us
+        # kernel ahead of the fork costs the captured step 60-70 us (profiles/HISTORY.md 4.7)
         wt = weight.t().contiguous()
         g = sf.graph
         val, t_val = (g.val, g.t_val) if vals is None else vals

@@ -422,7 +422,7 @@ def test_a2gnn_fit_predict_golden(adv):
 
 def test_a2gnn_fit_golden_as_three_graphs(monkeypatch):
     """PYGDA_AMD_SPLIT_GRAPHS=1 (hipgraph.GraphedStepSplit: source forward | target forward | loss + backward + Adam as
-    three captures; opt-in) against the same 3-epoch golden -- the path had no test and its statistics
+    three captures; opt-in, profiles/HISTORY.md 4.7) against the same 3-epoch golden -- the path had no test and its statistics
     branch referred to an undefined name."""
     monkeypatch.setenv("PYGDA_AMD_SPLIT_GRAPHS", "1")
     g = load_golden("a2gnn_fit3_mmd")

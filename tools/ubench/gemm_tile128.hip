@@ -1,6 +1,6 @@
 // Stand-alone probe (NOT part of libgda_hip.so): the tall projection  C[M, N] = A[M, K] * B[N, K]^T  (x W^T, fp32) on
 // 128 x 128 macro-tiles with 2 x 2 MFMA tiles per wave -- the shape class where the library's 64 x 64-tile kernel
-// (csrc/gda_gemm.hip: one 32x32 accumulator per wave) loses to the BLAS by 20-35 % (75 k - 300 k rows) and
+// (csrc/gda_gemm.hip: one 32x32 accumulator per wave) loses to the BLAS by 20-35 % (75 k - 300 k rows, profiles/HISTORY.md 4.6) and
 // nn/linear.py hands the product to F.linear.  Written at the end of round 2 and run ONCE with the last GPU seconds
 // (profiles/r2_gemm_tile128_ubench.txt): self-checks pass; 150,000 x 256 -> 128 in 122.4 us = 80.3 TF = 51 % of the fp32
 // MFMA peak, 150,000 x 128 -> 128 in 73.7 us (42 %), 9,360 x 128 -> 128 in 20.3 us -- the BLAS does the first shape in
