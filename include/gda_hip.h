@@ -368,6 +368,16 @@ int gda_mmd_fused_bwd_f32(const float* grad_part, int nseg, int times, int64_t n
                           const int32_t* sel_s_rowptr, const int32_t* sel_s_col, int64_t n_src_rows, float* gsrc,
                           const int32_t* sel_t_rowptr, const int32_t* sel_t_col, int64_t n_tgt_rows, float* gtgt,
                           gda_stream_t stream);
+/* _mask: mask_src / mask_tgt (either may be NULL) = the OUTPUT y [n_*_rows, d] of the activation dropout(relu(.), p_*) that
+ * produced that domain's feature rows: the scattered row gradient is stored as y > 0 ? g / (1 - p) : 0, i.e. already
+ * through that activation's backward (gda_relu_dropout_bwd_f32's values) -- its launch and one [rows, d] round trip
+ * disappear.  Scatter form only (selection CSRs given). */
+int gda_mmd_fused_bwd_mask_f32(const float* grad_part, int nseg, int times, int64_t n, int64_t d,
+                               const float* grad_loss, float scale, float* grad_rows,
+                               const int32_t* sel_s_rowptr, const int32_t* sel_s_col, int64_t n_src_rows, float* gsrc,
+                               const int32_t* sel_t_rowptr, const int32_t* sel_t_col, int64_t n_tgt_rows, float* gtgt,
+                               const float* mask_src, float p_src, const float* mask_tgt, float p_tgt,
+                               gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
  * Gradient-reversal + linear domain discriminator + softmax cross-entropy, fused.
@@ -855,6 +865,12 @@ size_t gda_gemm_skinny_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K
 int gda_gemm_skinny_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                         const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, float* colsum,
                         void* workspace, size_t workspace_bytes, gda_stream_t stream);
+/* Data gradient with the upstream activation's backward in its epilogue: C[M, N] = (y > 0) * (A[M, K] B[K, N]) / (1 - p) with
+ * y [M, N] (ld = ldm) the output of dropout(relu(.), p) -- gda_relu_dropout_bwd_f32(A B, y) in one launch, same values.
+ * Envelopes: tall (N, K in {128, 256}, the split-fp16 kernel) and skinny (K <= 8, N in {32, 64, 128, 256});
+ * GDA_E_UNSUPPORTED elsewhere. */
+int gda_gemm_nn_mask_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                         float* C, int64_t ldc, const float* y, int64_t ldm, float p, gda_stream_t stream);
 int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                       const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, float* colsum,
                       void* workspace, size_t workspace_bytes, gda_stream_t stream);

@@ -63,6 +63,9 @@ _SIGNATURES = {
                                       c_float, _P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "gda_mmd_fused_bwd_f32": (c_int, [_P, c_int, c_int, c_int64, c_int64, _P, c_float, _P,
                                       _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P]),
+    "gda_mmd_fused_bwd_mask_f32": (c_int, [_P, c_int, c_int, c_int64, c_int64, _P, c_float, _P,
+                                           _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, c_float, _P, c_float, _P]),
+    "gda_gemm_nn_mask_f32": (c_int, [c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_float, _P]),
     "gda_grl_disc_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "gda_grl_mlp_ce_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "gda_lsgan_head_workspace_bytes": (c_size_t, [c_int64]),

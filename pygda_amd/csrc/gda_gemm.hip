@@ -447,7 +447,8 @@ k_skinny_fwd(const float* __restrict__ X, int64_t ldx, const float* __restrict__
 // gx[M, K] = gy[M, N] W[N, K]: K / 4 lanes per row, a 16-byte piece each
 __global__ void __launch_bounds__(TB)
 k_skinny_dgrad(const float* __restrict__ GY, int64_t ldg, const float* __restrict__ W, int64_t ldw, float* __restrict__ GX,
-               int64_t ldx, int64_t M, int N, int K) {
+               int64_t ldx, int64_t M, int N, int K,
+               const float* __restrict__ mask = nullptr, int64_t ldm = 0, float mscale = 1.f) {
     const int pieces = K / 4, p = threadIdx.x % pieces, rows_per_block = TB / pieces;
     float4 w[SK_N];
 #pragma unroll
@@ -463,6 +464,11 @@ k_skinny_dgrad(const float* __restrict__ GY, int64_t ldg, const float* __restric
                 const float g = GY[row * ldg + n];
                 o.x = fmaf(g, w[n].x, o.x); o.y = fmaf(g, w[n].y, o.y); o.z = fmaf(g, w[n].z, o.z); o.w = fmaf(g, w[n].w, o.w);
             }
+        if (mask) {              // the activation's backward in the epilogue (see k_tall_fwd_h)
+            const float4 y = *reinterpret_cast<const float4*>(mask + row * ldm + 4 * p);
+            o.x = y.x > 0.f ? o.x * mscale : 0.f; o.y = y.y > 0.f ? o.y * mscale : 0.f;
+            o.z = y.z > 0.f ? o.z * mscale : 0.f; o.w = y.w > 0.f ? o.w * mscale : 0.f;
+        }
         *reinterpret_cast<float4*>(GX + row * ldx + 4 * p) = o;
     }
 }
@@ -759,6 +765,45 @@ extern "C" int gda_gemm_skinny_f32(int mode, int64_t M, int64_t N, int64_t K, co
         GDA_UNLESS_SKIPPED("k_slab_sum") k_slab_sum<<<(unsigned)gda_cdiv(M * N + (colsum ? M : 0), SS_OUT), TB, 0, stream>>>(part, (int)slabs, M, N, C, ldc, cs_part, colsum);
     } else {
         return GDA_E_UNSUPPORTED;
+    }
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+// Data gradient with the upstream activation's backward in its epilogue:
+//   C[M, N] = mask(y) * (A[M, K] B[K, N]) / (1 - p),  mask = (y > 0),  y [M, N] (ld = ldm) = the output of dropout(relu(.))
+// -- gda_relu_dropout_bwd_f32(gda_gemm NN(A, B), y) in one launch, same values.  Two envelopes: the tall split-fp16 kernel
+// (N, K in {128, 256}; 16-byte aligned operands) and the skinny classifier kernel (K <= 8, N in {32, 64, 128, 256});
+// GDA_E_UNSUPPORTED elsewhere (the caller composes).
+extern "C" int gda_gemm_nn_mask_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                                    float* C, int64_t ldc, const float* y, int64_t ldm, float p, gda_stream_t stream_) {
+    if (M <= 0 || N <= 0 || K <= 0 || ldc < N || ldm < N || lda < K || ldb < N) return GDA_E_SIZE;
+    if (!A || !B || !C || !y) return GDA_E_NULL;
+    if (C == A || C == B || C == y) return GDA_E_ALIAS;
+    if (!(p >= 0.f && p < 1.f)) return GDA_E_SIZE;
+    if (ldc % 4 || ldm % 4 || ldb % 4 || (((uintptr_t)C | (uintptr_t)y | (uintptr_t)B) & 15)) return GDA_E_UNSUPPORTED;
+    hipStream_t stream = (hipStream_t)stream_;
+    const float mscale = 1.f / (1.f - p);
+    if (K <= SK_N && (N == 32 || N == 64 || N == 128 || N == 256)) {
+        const int64_t rpb = TB / (N / 4);
+        const int64_t blocks = min(gda_cdiv(M, rpb), (int64_t)256 * 16);
+        k_skinny_dgrad<<<(unsigned)blocks, TB, 0, stream>>>(A, lda, B, ldb, C, ldc, M, (int)K, (int)N, y, ldm, mscale);
+        GDA_LAUNCH_CHECK();
+        return GDA_OK;
+    }
+    static const bool split16 = [] { const char* e = std::getenv("PYGDA_AMD_GEMM_SPLIT_F16"); return !(e && e[0] == '0'); }();
+    if (!split16 || (N != 128 && N != 256) || (K != 128 && K != 256) || lda % 4 || ((uintptr_t)A & 15)) return GDA_E_UNSUPPORTED;
+    const int64_t bm = K == 128 ? 128 : 64;
+    const int64_t nt = gda_cdiv(M, bm);
+    const dim3 g((unsigned)min(nt, (int64_t)256), (unsigned)(N / 128));
+    const size_t img = (size_t)bm * (K + 8) * 2;
+    const size_t lds = 4 * img + 2 * (size_t)bm * sizeof(float);
+    if (K == 128) {
+        GDA_LDS_ATTR_ONCE((k_tall_fwd_h<128, true>), 160 * 1024);
+        k_tall_fwd_h<128, true><<<g, TALL_TB, lds, stream>>>(A, lda, B, ldb, C, ldc, M, nullptr, y, ldm, mscale);
+    } else {
+        GDA_LDS_ATTR_ONCE((k_tall_fwd_h<256, true>), 160 * 1024);
+        k_tall_fwd_h<256, true><<<g, TALL_TB, lds, stream>>>(A, lda, B, ldb, C, ldc, M, nullptr, y, ldm, mscale);
     }
     GDA_LAUNCH_CHECK();
     return GDA_OK;

@@ -704,7 +704,12 @@ __global__ void __launch_bounds__(TB)
 k_bwd_scatter(const float* __restrict__ part, int64_t m, int64_t d, int nseg_rt,
               const int32_t* __restrict__ s_rowptr, const int32_t* __restrict__ s_col, int64_t n_src_rows,
               float* __restrict__ gsrc, const int32_t* __restrict__ t_rowptr, const int32_t* __restrict__ t_col,
-              int64_t n_tgt_rows, float* __restrict__ gtgt, const float* __restrict__ grad_loss, float cmul) {
+              int64_t n_tgt_rows, float* __restrict__ gtgt, const float* __restrict__ grad_loss, float cmul,
+              const float* __restrict__ mask_s = nullptr, float mscale_s = 1.f,
+              const float* __restrict__ mask_t = nullptr, float mscale_t = 1.f) {
+    // mask_* (may be NULL): the OUTPUT y of the activation dropout(relu(.)) that produced this domain's feature rows -- the
+    // row gradient is then written as y > 0 ? g * mscale : 0, i.e. already through that activation's backward
+    // (gda_relu_dropout_bwd_f32's values bit for bit), and the activation's own backward launch disappears.
     // the fused forward leaves UNSCALED partials: 4 * dloss * cmul is applied here (grad_loss NULL: k_bwd scaled them, 4 is left)
     const float c4 = grad_loss ? 4.f * (grad_loss[0] * cmul) : 4.f;
     const int nseg = NSEG > 0 ? NSEG : nseg_rt;
@@ -717,6 +722,9 @@ k_bwd_scatter(const float* __restrict__ part, int64_t m, int64_t d, int nseg_rt,
     const int32_t* rp = tgt ? t_rowptr : s_rowptr;
     const int32_t* ci = tgt ? t_col : s_col;
     float* out = (tgt ? gtgt : gsrc) + r * d;
+    const float* mk = tgt ? mask_t : mask_s;
+    const float msc = tgt ? mscale_t : mscale_s;
+    if (mk) mk += r * d;
     const int32_t b = rp[r], e = rp[r + 1];
     if constexpr (NSEG > 0) {
         // d % 4 == 0 and 16-byte aligned arrays (the launcher checks): the NSEG partial quads of an entry are NSEG
@@ -740,6 +748,11 @@ k_bwd_scatter(const float* __restrict__ part, int64_t m, int64_t d, int nseg_rt,
                 acc.x = __fadd_rn(acc.x, c4 * sg.x); acc.y = __fadd_rn(acc.y, c4 * sg.y);
                 acc.z = __fadd_rn(acc.z, c4 * sg.z); acc.w = __fadd_rn(acc.w, c4 * sg.w);
             }
+            if (mk) {
+                const float4 y = *reinterpret_cast<const float4*>(mk + c);
+                acc.x = y.x > 0.f ? acc.x * msc : 0.f; acc.y = y.y > 0.f ? acc.y * msc : 0.f;
+                acc.z = y.z > 0.f ? acc.z * msc : 0.f; acc.w = y.w > 0.f ? acc.w * msc : 0.f;
+            }
             *reinterpret_cast<float4*>(out + c) = acc;
         }
         return;
@@ -758,7 +771,7 @@ k_bwd_scatter(const float* __restrict__ part, int64_t m, int64_t d, int nseg_rt,
             for (int v = 0; v < 4; ++v) acc[v] = __fadd_rn(acc[v], __fmul_rn(1.0f, c4 * sg[v]));
         }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) if (c + v < d) out[c + v] = acc[v];
+        for (int v = 0; v < 4; ++v) if (c + v < d) out[c + v] = mk ? (mk[c + v] > 0.f ? acc[v] * msc : 0.f) : acc[v];
     }
 }
 
@@ -1065,11 +1078,16 @@ extern "C" int gda_mmd_fused_fwd_f32(const float* src, int64_t ld_src, const flo
     return GDA_OK;
 }
 
-extern "C" int gda_mmd_fused_bwd_f32(const float* grad_part, int nseg, int times, int64_t n, int64_t d,
-                                     const float* grad_loss, float scale, float* grad_rows,
-                                     const int32_t* sel_s_rowptr, const int32_t* sel_s_col, int64_t n_src_rows, float* gsrc,
-                                     const int32_t* sel_t_rowptr, const int32_t* sel_t_col, int64_t n_tgt_rows, float* gtgt,
-                                     gda_stream_t stream_) {
+extern "C" int gda_mmd_fused_bwd_mask_f32(const float* grad_part, int nseg, int times, int64_t n, int64_t d,
+                                          const float* grad_loss, float scale, float* grad_rows,
+                                          const int32_t* sel_s_rowptr, const int32_t* sel_s_col, int64_t n_src_rows, float* gsrc,
+                                          const int32_t* sel_t_rowptr, const int32_t* sel_t_col, int64_t n_tgt_rows, float* gtgt,
+                                          const float* mask_src, float p_src, const float* mask_tgt, float p_tgt,
+                                          gda_stream_t stream_) {
+    if ((mask_src && !(p_src >= 0.f && p_src < 1.f)) || (mask_tgt && !(p_tgt >= 0.f && p_tgt < 1.f))) return GDA_E_SIZE;
+    if ((mask_src || mask_tgt) && !sel_s_rowptr) return GDA_E_UNSUPPORTED;        // masks ride on the scatter only
+    if (((uintptr_t)mask_src | (uintptr_t)mask_tgt) % 16) return GDA_E_UNSUPPORTED;
+    const float ms_s = mask_src ? 1.f / (1.f - p_src) : 1.f, ms_t = mask_tgt ? 1.f / (1.f - p_tgt) : 1.f;
     if (!grad_part || !grad_loss) return GDA_E_NULL;
     if (times <= 0 || n <= 0 || d <= 0 || nseg < 1 || nseg > F_NSEG_MAX) return GDA_E_SIZE;
     const bool scatter = sel_s_rowptr != nullptr;
@@ -1085,7 +1103,8 @@ extern "C" int gda_mmd_fused_bwd_f32(const float* grad_part, int nseg, int times
         const dim3 sg((unsigned)gda_cdiv(most, TB / 32), 2);
         const bool quads = d % 4 == 0 && ((uintptr_t)grad_part % 16 == 0) && ((uintptr_t)gsrc % 16 == 0) && ((uintptr_t)gtgt % 16 == 0);
 #define GDA_SCATTER(NS) k_bwd_scatter<NS><<<sg, TB, 0, stream>>>(grad_part, m, d, nseg, sel_s_rowptr, sel_s_col, n_src_rows, gsrc, \
-                                                              sel_t_rowptr, sel_t_col, n_tgt_rows, gtgt, grad_loss, cmul)
+                                                              sel_t_rowptr, sel_t_col, n_tgt_rows, gtgt, grad_loss, cmul,    \
+                                                              mask_src, ms_s, mask_tgt, ms_t)
         if (!quads) GDA_SCATTER(0);
         else switch (nseg) {
             case 1: GDA_SCATTER(1); break;
@@ -1107,5 +1126,15 @@ extern "C" int gda_mmd_fused_bwd_f32(const float* grad_part, int nseg, int times
     k_bwd_reduce<<<(unsigned)rg, TB, 0, stream>>>(grad_part, m * d, nseg, times, grad_rows, grad_loss, cmul);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
+}
+
+extern "C" int gda_mmd_fused_bwd_f32(const float* grad_part, int nseg, int times, int64_t n, int64_t d,
+                                     const float* grad_loss, float scale, float* grad_rows,
+                                     const int32_t* sel_s_rowptr, const int32_t* sel_s_col, int64_t n_src_rows, float* gsrc,
+                                     const int32_t* sel_t_rowptr, const int32_t* sel_t_col, int64_t n_tgt_rows, float* gtgt,
+                                     gda_stream_t stream_) {
+    return gda_mmd_fused_bwd_mask_f32(grad_part, nseg, times, n, d, grad_loss, scale, grad_rows, sel_s_rowptr, sel_s_col,
+                                      n_src_rows, gsrc, sel_t_rowptr, sel_t_col, n_tgt_rows, gtgt, nullptr, 0.f, nullptr, 0.f,
+                                      stream_);
 }
 

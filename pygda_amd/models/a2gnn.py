@@ -236,8 +236,15 @@ class A2GNN(BaseGDA):
             # a helper thread beside the forward passes (utils.mmd.prefetch_samples: same draws, same order)
             from ..utils.mmd import prefetch_samples
             prefetch_samples(source_data.x.size(0), target_data.x.size(0), source_data.x.device)
-        loss, source_logits, source_features, target_features, h0_t, pending, (sb, tb) = \
-            self._branches(source_data, target_data)
+        from .. import ops as _ops
+        # sampled steps of THIS trainer: every activation output feeds exactly one op (features -> the MMD, the stacked
+        # second half -> the classifier's projection, the target's layer-0 draw -> the next projection), so the
+        # activations may hand their backward to those producers' epilogues (ops.GradSink)
+        sinks = (type(self) is A2GNN and not self.adv and self.mode == 'node' and source_data.x.is_cuda
+                 and getattr(source_data, "n_id", None) is not None and getattr(target_data, "n_id", None) is not None)
+        with (_ops.grad_sinks() if sinks else _null()):
+            loss, source_logits, source_features, target_features, h0_t, pending, (sb, tb) = \
+                self._branches(source_data, target_data)
         net = self.a2gnn
         loss = self._domain_loss(loss, source_features, target_features, alpha)
         if pending is not None:

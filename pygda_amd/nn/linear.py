@@ -37,16 +37,19 @@ class _TallLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight):
-        from ..ops import GEMM_NT, gemm
+        from ..ops import GEMM_NT, gemm, sink_of
+        ctx.sink = sink_of(x)             # x = the output of dropout(relu(.)) that offered a GradSink (ops.grad_sinks)
         ctx.save_for_backward(x, weight)
         return gemm(GEMM_NT, x, weight)
 
     @staticmethod
     def backward(ctx, gy):
-        from ..ops import GEMM_NN, GEMM_TN, gemm
+        from ..ops import GEMM_NN, GEMM_TN, gemm, masked_dgrad
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
-        gx = gemm(GEMM_NN, gy, weight) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:       # (the data gradient stored through the activation's backward when it has a sink)
+            gx = masked_dgrad(gy, weight, ctx.sink) if ctx.sink is not None else gemm(GEMM_NN, gy, weight)
         gw = gemm(GEMM_TN, gy, x) if ctx.needs_input_grad[1] else None
         return gx, gw
 
@@ -58,16 +61,19 @@ class _TallLinearBias(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        from ..ops import GEMM_NT, gemm
+        from ..ops import GEMM_NT, gemm, sink_of
+        ctx.sink = sink_of(x)
         ctx.save_for_backward(x, weight)
         return gemm(GEMM_NT, x, weight, bias=bias.contiguous())
 
     @staticmethod
     def backward(ctx, gy):
-        from ..ops import GEMM_NN, GEMM_TN, gemm
+        from ..ops import GEMM_NN, GEMM_TN, gemm, masked_dgrad
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
-        gx = gemm(GEMM_NN, gy, weight) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = masked_dgrad(gy, weight, ctx.sink) if ctx.sink is not None else gemm(GEMM_NN, gy, weight)
         gb = torch.empty(weight.size(0), dtype=torch.float32, device=gy.device)
         gw = gemm(GEMM_TN, gy, x, colsum=gb)
         return gx, gw, gb

@@ -18,6 +18,79 @@ def _f32c(t, name):
     return t.contiguous()
 
 
+# ------------------------------------------------- the activation's backward in its producer's epilogue --
+# dropout(relu(.)) needs, going backwards, only its own OUTPUT y: gx = (y > 0) * g / (1 - p).  When the gradient g of y has
+# exactly one producer and that producer is one of ours, it can apply the mask while it stores g -- the activation's own
+# backward launch and one [rows, d] round trip through HBM disappear (cfg-S: ~0.2 ms of a 2.5 ms step).  Protocol: an
+# activation that is willing hands its output a GradSink (buffer for the masked gradient, y, p); a sink-aware producer
+# (`gemm(GEMM_NN, ..., sink=)`, the one-pass MMD's scatter) writes the MASKED gradient into `sink.buf`, sets `written` and
+# returns that buffer; the activation's backward recognises its own buffer and passes it on untouched.  Anything else
+# (another producer, autograd summing two producers into a fresh tensor) arrives as an ordinary gradient and takes the
+# ordinary kernel.  ONLY sound when y has a single consumer: a second, sink-unaware consumer's gradient would be summed
+# onto an already masked one and masked again.  So sinks are handed out only inside `grad_sinks()`, which the A2GNN
+# trainer opens around its sampled step, where every activation output feeds exactly one op.
+GRAD_SINKS = _os.environ.get("PYGDA_AMD_GRAD_SINKS", "1") == "1"
+_sinks_on = False
+sink_hits = 0            # activation backward launches that a producer's epilogue made unnecessary (tests read it)
+
+
+class grad_sinks:
+    """``with grad_sinks():`` -- activations created inside may hand out GradSinks (see above)."""
+
+    def __enter__(self):
+        global _sinks_on
+        self.prev, _sinks_on = _sinks_on, GRAD_SINKS
+        return self
+
+    def __exit__(self, *exc):
+        global _sinks_on
+        _sinks_on = self.prev
+        return False
+
+
+class GradSink:
+    __slots__ = ("buf", "y", "p", "written")
+
+    def __init__(self, buf, y, p):
+        self.buf, self.y, self.p, self.written = buf, y, float(p), False
+
+    def mine(self, g):
+        """Is ``g`` the masked gradient a producer left in this sink?  (consumes the flag)"""
+        global sink_hits
+        hit = self.written and g is not None and g.data_ptr() == self.buf.data_ptr() and g.shape == self.buf.shape
+        self.written = False
+        sink_hits += bool(hit)
+        return hit
+
+
+def sink_of(t):
+    return getattr(t, "_gda_grad_sink", None) if torch.is_tensor(t) else None
+
+
+def _offer_sink(y, p, buf=None, wanted=True):
+    """Attach a sink to the activation output ``y`` when sinks are on and the activation's input wants a gradient."""
+    if _sinks_on and wanted and y.is_cuda and y.dim() == 2 and y.size(1) % 4 == 0 and y.is_contiguous():
+        y._gda_grad_sink = GradSink(torch.empty_like(y) if buf is None else buf, y, p)
+        return y._gda_grad_sink
+    return None
+
+
+def masked_dgrad(gy, weight, sink):
+    """``sink.buf <- (sink.y > 0) * (gy @ weight) / (1 - p)`` in the product's epilogue when the kernel takes the shape,
+    else product + activation backward as two launches; either way the sink is written."""
+    gy, weight = _f32c(gy, "gy"), _f32c(weight, "weight")
+    (M, K), (K2, N) = gy.shape, weight.shape
+    L = _lib.lib()
+    st = L.gda_gemm_nn_mask_f32(M, N, K, _lib.ptr(gy), K, _lib.ptr(weight), N, _lib.ptr(sink.buf), N, _lib.ptr(sink.y), N,
+                                sink.p, _lib.stream()) if (M == sink.buf.size(0) and N == sink.buf.size(1)) else -1
+    if st != 0:
+        gx = gemm(GEMM_NN, gy, weight)
+        _lib.check(L.gda_relu_dropout_bwd_f32(_lib.ptr(gx), _lib.ptr(sink.y), _lib.ptr(sink.buf), gx.numel(), sink.p,
+                                              _lib.stream()), "gda_relu_dropout_bwd_f32")
+    sink.written = True
+    return sink.buf
+
+
 # ------------------------------------------------------ source classification loss --
 class _SoftmaxNLL(torch.autograd.Function):
     @staticmethod
@@ -654,6 +727,7 @@ class _PropagateAct(torch.autograd.Function):
                 _lib.stream()), "gda_interior_kstep_lds_act_f32")
         ctx.graph, ctx.K, ctx.has_bias, ctx.p = graph, K, bias is not None, float(p)
         ctx.save_for_backward(y0)
+        ctx.sink = _offer_sink(y0, p, wanted=ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         if pair:
             ctx.mark_non_differentiable(y1)
             return y0, y1
@@ -662,10 +736,13 @@ class _PropagateAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g0, g1=None):
         (y0,) = ctx.saved_tensors
-        g0 = g0.contiguous()
-        gpre = torch.empty_like(g0)
-        _lib.check(_lib.lib().gda_relu_dropout_bwd_f32(_lib.ptr(g0), _lib.ptr(y0), _lib.ptr(gpre), g0.numel(), ctx.p,
-                                                       _lib.stream()), "gda_relu_dropout_bwd_f32")
+        if ctx.sink is not None and ctx.sink.mine(g0):       # masked by its producer already (GradSink)
+            gpre = g0
+        else:
+            g0 = g0.contiguous()
+            gpre = torch.empty_like(g0)
+            _lib.check(_lib.lib().gda_relu_dropout_bwd_f32(_lib.ptr(g0), _lib.ptr(y0), _lib.ptr(gpre), g0.numel(), ctx.p,
+                                                           _lib.stream()), "gda_relu_dropout_bwd_f32")
         gx = spmm_kstep(ctx.graph, gpre, ctx.K, None, transposed=True) if ctx.needs_input_grad[0] else None
         gb = colsum(gpre) if ctx.has_bias and ctx.needs_input_grad[1] else None
         return gx, gb, None, None, None, None
@@ -759,6 +836,7 @@ class _MMD(torch.autograd.Function):
         """``(add +) scale * MMD``: the trainer's loss line ``loss = CE + MMD(...) * weight`` (a2gnn.py:207-209)
         without elementwise glue kernels around the loss kernels."""
         ctx.sel, ctx.scale, ctx.has_add = sel, float(scale), add is not None
+        ctx.sinks = (sink_of(src), sink_of(tgt))
         src, tgt = _f32c(src, "source_feat"), _f32c(tgt, "target_feat")
         d = src.size(1)
         if tgt.size(1) != d:
@@ -868,13 +946,25 @@ def _mmd_backward_one_pass(ctx, gl):
     tail = (None,) * 9 + (g_add,)
     if src_idx is not None and ctx.sel is not None and MMD_SCATTER_FUSED:
         s_rp, s_ci, t_rp, t_ci, _ones = ctx.sel
-        gs = torch.empty(ctx.feat_rows[0], d, dtype=torch.float32, device=dev)
-        gt = torch.empty(ctx.feat_rows[1], d, dtype=torch.float32, device=dev)
+        # a feature matrix that came straight out of dropout(relu(.)) may have handed over a GradSink: its row gradients
+        # are then stored already through that activation's backward (mask in the scatter's epilogue)
+        ok = lambda k, rows: (k is not None and k.buf.shape == (rows, d) and k.buf.data_ptr() % 16 == 0
+                              and k.y.data_ptr() % 16 == 0)
+        ks = ctx.sinks[0] if ok(ctx.sinks[0], ctx.feat_rows[0]) and ctx.needs_input_grad[0] else None
+        kt = ctx.sinks[1] if ok(ctx.sinks[1], ctx.feat_rows[1]) and ctx.needs_input_grad[1] else None
+        gs = ks.buf if ks is not None else torch.empty(ctx.feat_rows[0], d, dtype=torch.float32, device=dev)
+        gt = kt.buf if kt is not None else torch.empty(ctx.feat_rows[1], d, dtype=torch.float32, device=dev)
         with profiler.region("mmd_bwd", 1, 0, 0):
-            _lib.check(L.gda_mmd_fused_bwd_f32(
+            _lib.check(L.gda_mmd_fused_bwd_mask_f32(
                 _lib.ptr(part), ctx.one_pass, times, n, d, _lib.ptr(glc), ctx.scale, None,
                 _lib.ptr(s_rp), _lib.ptr(s_ci), ctx.feat_rows[0], _lib.ptr(gs),
-                _lib.ptr(t_rp), _lib.ptr(t_ci), ctx.feat_rows[1], _lib.ptr(gt), _lib.stream()), "gda_mmd_fused_bwd_f32")
+                _lib.ptr(t_rp), _lib.ptr(t_ci), ctx.feat_rows[1], _lib.ptr(gt),
+                _lib.ptr(ks.y if ks is not None else None), ks.p if ks is not None else 0.0,
+                _lib.ptr(kt.y if kt is not None else None), kt.p if kt is not None else 0.0, _lib.stream()),
+                "gda_mmd_fused_bwd_mask_f32")
+        for k in (ks, kt):
+            if k is not None:
+                k.written = True
         return (gs if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None) + tail
     grad_rows = torch.empty(times, m, d, dtype=torch.float32, device=dev)
     with profiler.region("mmd_bwd", 1, 0, 0):
@@ -1385,11 +1475,14 @@ class _ReluDropout(torch.autograd.Function):
                    "gda_relu_dropout_fwd_f32")
         ctx.save_for_backward(y)
         ctx.p = float(p)
+        ctx.sink = _offer_sink(y, p, wanted=ctx.needs_input_grad[0])
         return y
 
     @staticmethod
     def backward(ctx, gy):
         (y,) = ctx.saved_tensors
+        if ctx.sink is not None and ctx.sink.mine(gy):       # the producer stored it masked already (GradSink)
+            return gy, None
         gy = gy.contiguous()
         gx = torch.empty_like(gy)
         L = _lib.lib()
@@ -1530,18 +1623,41 @@ class _ReluDropoutSplit(torch.autograd.Function):
         ctx.p = float(p)
         ctx.set_materialize_grads(False)
         n = x.size(0) // 2
-        return y.narrow(0, 0, n), y.narrow(0, n, n)
+        a, b = y.narrow(0, 0, n), y.narrow(0, n, n)
+        ctx.sinks, ctx.G = (None, None), None
+        if _sinks_on and ctx.needs_input_grad[0]:
+            # both halves' masked gradients land in ONE [2n, d] buffer: when both producers wrote, it IS the result
+            ctx.G = torch.empty_like(y)
+            ctx.sinks = (_offer_sink(a, p, ctx.G.narrow(0, 0, n)), _offer_sink(b, p, ctx.G.narrow(0, n, n)))
+        return a, b
 
     @staticmethod
     def backward(ctx, ga, gb):
         (y,) = ctx.saved_tensors
         if ga is None and gb is None:
             return None, None
+        L = _lib.lib()
+        n = y.size(0) // 2
+        done = [k is not None and k.mine(g) for k, g in zip(ctx.sinks, (ga, gb))]
+        if any(done):
+            # a half that arrived masked sits in G already; the other one (an ordinary gradient, or none) is masked into its
+            # half of G by the ordinary kernel
+            for k, (g, ok) in enumerate(zip((ga, gb), done)):
+                if ok:
+                    continue
+                dst, yh = ctx.G.narrow(0, k * n, n), y.narrow(0, k * n, n)
+                if g is None:
+                    dst.zero_()
+                else:
+                    g = g.contiguous()
+                    _lib.check(L.gda_relu_dropout_bwd_f32(_lib.ptr(g), _lib.ptr(yh), _lib.ptr(dst), g.numel(), ctx.p,
+                                                          _lib.stream()), "gda_relu_dropout_bwd_f32")
+            return ctx.G, None
         ga = None if ga is None else ga.contiguous()
         gb = None if gb is None else gb.contiguous()
         gx = torch.empty_like(y)
-        _lib.check(_lib.lib().gda_relu_dropout_bwd2_f32(_lib.ptr(ga), _lib.ptr(gb), _lib.ptr(y), _lib.ptr(gx),
-                                                        y.numel() // 2, ctx.p, _lib.stream()), "gda_relu_dropout_bwd2_f32")
+        _lib.check(L.gda_relu_dropout_bwd2_f32(_lib.ptr(ga), _lib.ptr(gb), _lib.ptr(y), _lib.ptr(gx),
+                                               y.numel() // 2, ctx.p, _lib.stream()), "gda_relu_dropout_bwd2_f32")
         return gx, None
 
 

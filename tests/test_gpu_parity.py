@@ -2538,3 +2538,71 @@ def test_linear_bias_fused_in_gemms():
         x2 = x0.clone().requires_grad_()
         (conv(x2, ei, 0) * gy).sum().backward()
         exact(x2.grad, x.grad)
+
+
+@pytest.mark.parametrize("shape", ["tall", "skinny", "small"])
+def test_activation_backward_in_the_producers_epilogue_is_the_same_gradient(shape):
+    """ops.GradSink: inside `grad_sinks()` an activation output that feeds ONE sink-aware op has its backward applied by
+    that op's epilogue (gda_gemm_nn_mask_f32) -- same kernels' values, one launch and one round trip fewer.  Against the
+    same computation without sinks: every gradient bit for bit; `sink_hits` shows the epilogue path ran (for the shape the
+    masked kernels do not take, the protocol still holds: product + activation backward as two launches)."""
+    from pygda_amd.nn.linear import Linear
+    gen = torch.Generator().manual_seed(12)
+    n, d, out = {"tall": (40000, 128, 128), "skinny": (40000, 128, 5), "small": (3000, 64, 48)}[shape]
+    x0 = torch.randn(n, d, generator=gen).to(DEV)
+    lin = Linear(d, out, bias=False).to(DEV)
+    w = torch.randn(n, out, generator=gen).to(DEV)
+    st = ops.dropout_state
+    st.next_step(torch.device(DEV))
+    res = []
+    for on in (True, False):
+        x = x0.clone().requires_grad_()
+        lin.weight.grad = None
+        st.site = 3
+        hits = ops.sink_hits
+        with (ops.grad_sinks() if on else torch.enable_grad()):
+            y = ops.relu_dropout(x, 0.4, True)
+            assert (ops.sink_of(y) is not None) == on
+            z = lin(y)
+        (z * w).sum().backward()
+        assert ops.sink_hits - hits == (1 if on else 0)
+        res.append((y.detach(), z.detach(), x.grad, lin.weight.grad.clone()))
+    for got, want in zip(*res):
+        exact(got, want)
+
+
+def test_grad_sinks_through_the_split_activation_the_mmd_scatter_and_the_classifier():
+    """The A2GNN source branch in small: stacked rows -> relu_dropout_split -> (first half: MMD row scatter, second half:
+    classifier projection); target features straight out of an activation.  With sinks all three activation backwards
+    ride in their producers' epilogues (`sink_hits` + 3); gradients bit for bit those of the plain kernels.  Then with the
+    second half unused (its gradient is None): the half that arrived masked stays, the other is zeroed."""
+    from pygda_amd.nn.linear import Linear
+    from pygda_amd.utils import MMD
+    gen = torch.Generator().manual_seed(13)
+    n, d = 6000, 128
+    xs0, xt0 = torch.randn(2 * n, d, generator=gen).to(DEV), torch.randn(n + 500, d, generator=gen).to(DEV)
+    cls = Linear(d, 5, bias=False).to(DEV)
+    wl = torch.randn(n, 5, generator=gen).to(DEV)
+    st = ops.dropout_state
+    st.next_step(torch.device(DEV))
+    for use_b in (True, False):
+        res = []
+        for on in (True, False):
+            xs, xt = xs0.clone().requires_grad_(), xt0.clone().requires_grad_()
+            cls.weight.grad = None
+            st.site = 5
+            hits = ops.sink_hits
+            with (ops.grad_sinks() if on else torch.enable_grad()):
+                a, b = ops.relu_dropout_split(xs, 0.5, True)
+                ft = ops.relu_dropout(xt, 0.5, True)
+            torch.manual_seed(77)
+            loss = MMD(a, ft, sampling_num=500, times=3, scale=10.0)
+            if use_b:
+                loss = loss + (cls(b) * wl).sum()
+            loss.backward()
+            assert ops.sink_hits - hits == ((3 if use_b else 2) if on else 0)
+            res.append((loss.detach(), xs.grad, xt.grad) + ((cls.weight.grad.clone(),) if use_b else ()))
+        for got, want in zip(*res):
+            exact(got, want)
+        if not use_b:
+            assert float(res[0][1][n:].abs().max()) == 0.0

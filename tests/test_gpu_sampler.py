@@ -481,6 +481,22 @@ def test_captured_sampled_step_equals_the_eager_static_step_bit_for_bit(monkeypa
     assert logits.shape == (6 * 512, 5) and bool(torch.isfinite(logits).all())
 
 
+def test_sampled_training_with_and_without_grad_sinks_is_the_same_run(monkeypatch):
+    """ops.GradSink in the trainer (A2GNN's sampled step opens `grad_sinks()`): four activation backward launches per step
+    ride in their producers' epilogues.  Same 2 x 6 captured steps, dropout on, with the protocol switched off: per-epoch
+    numbers and every parameter bit for bit."""
+    hits = ops.sink_hits
+    m1, seen1, par1 = _sampled_fit(monkeypatch, {"PYGDA_AMD_SAMPLED_GRAPH": "1"})
+    assert ops.sink_hits - hits >= 4, ops.sink_hits - hits        # (counted while capturing / warming up: replays run no Python)
+    monkeypatch.setattr(ops, "GRAD_SINKS", False)
+    hits = ops.sink_hits
+    m0, seen0, par0 = _sampled_fit(monkeypatch, {"PYGDA_AMD_SAMPLED_GRAPH": "1"})
+    assert ops.sink_hits == hits
+    assert seen1 == seen0, (seen1, seen0)
+    for k in par1:
+        exact(par1[k], par0[k])
+
+
 def test_captured_sampled_step_falls_back_on_a_batch_it_cannot_take(monkeypatch):
     """A pair whose interior plan is declined (here: forced) runs the ordinary eager step on its real shape, between two
     replays, on the same optimiser state -- and the epoch's numbers stay those of the all-eager loop to fp32 order."""
