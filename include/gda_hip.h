@@ -871,6 +871,22 @@ int gda_gemm_skinny_f32(int mode, int64_t M, int64_t N, int64_t K, const float* 
  * GDA_E_UNSUPPORTED elsewhere. */
 int gda_gemm_nn_mask_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                          float* C, int64_t ldc, const float* y, int64_t ldm, float p, gda_stream_t stream);
+/* The sampled batch's first projection without its gather pass, and projections with the conv layer's activation
+ * (pygda/nn/a2gnn_base.py:135-138) in the epilogue.  Forward (NT): C = act(A[arow] B^T + bias).
+ *   arow (may be NULL): int64 [M] device row ids -- row i of the tall operand is A[arow[i]] (x[n_id] of a sampled batch).
+ *   act_mode 0: none; 1: C [M, N] = dropout_site0(relu(.)); 2: C [2M, N], rows i / M + i = two independent draws of the same
+ *   pre-activation (gda_relu_dropout_pair_fwd_f32's stacked pair).  Keep-bits as gda_relu_dropout_fwd_f32 / _pair_fwd_f32
+ *   would draw them on the [M, N] pre-activation; p <= 0: relu only.
+ * Envelope: N, K in {128, 256}, ldc == N, 16-byte aligned operands, the split-fp16 kernel; GDA_E_UNSUPPORTED elsewhere.
+ * gda_gemm_tall_wgrad_gather_f32: the TN form of gda_gemm_tall_f32 (C[128, N] = A[Krows, 128]^T X[xrow], colsum[128]) reading
+ * x through the batch's node ids; same workspace (gda_gemm_tall_workspace_bytes(TN, 128, N, Krows)). */
+int gda_gemm_tall_fwd_ex_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const int64_t* arow,
+                             const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                             int act_mode, float p, uint64_t seed, const int64_t* step_dev, uint32_t site0,
+                             uint32_t site1, gda_stream_t stream);
+int gda_gemm_tall_wgrad_gather_f32(int64_t N, int64_t Krows, const float* A, int64_t lda, const float* X, int64_t ldx,
+                                   const int64_t* xrow, float* C, int64_t ldc, float* colsum,
+                                   void* workspace, size_t workspace_bytes, gda_stream_t stream);
 int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                       const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, float* colsum,
                       void* workspace, size_t workspace_bytes, gda_stream_t stream);

@@ -16,6 +16,7 @@
 //                                      split into row slabs, partial tiles summed in slab order --
 //                                      a deterministic split-K)
 #include "gda_common.h"
+#include "gda_philox.h"
 
 #include <cstdlib>
 
@@ -320,7 +321,8 @@ k_tall_fwd16(const float* __restrict__ A, int64_t lda, const float* __restrict__
 template <int NT8>
 __global__ void __launch_bounds__(TALL_TB, 1)
 k_tall_wgrad(const float* __restrict__ G, int64_t ldg, const float* __restrict__ X, int64_t ldx, float* __restrict__ P,
-             float* __restrict__ CS, int64_t M, int64_t rows_per_slab) {
+             float* __restrict__ CS, int64_t M, int64_t rows_per_slab, const int64_t* __restrict__ xrow = nullptr) {
+    // xrow (may be NULL): row r of x is X[xrow[r]] (the batch's feature gather done by the operand fetch)
     constexpr int XC = 32 * NT8, RC = 32;             // x columns; rows per chunk
     constexpr int HT = NT8 / 2;                       // column tiles per wave (the two waves of a row group split them)
     constexpr int XQ = RC * XC / 4 / TALL_TB, GQ = RC * 128 / 4 / TALL_TB;      // 16-byte pieces per thread and chunk
@@ -344,6 +346,7 @@ k_tall_wgrad(const float* __restrict__ G, int64_t ldg, const float* __restrict__
         const int idx = tid + TALL_TB * q, row = idx / (XC / 4), c4 = idx % (XC / 4);                      \
         int64_t r = (M0) + row;                                                                            \
         r = r < r1 ? r : r1 - 1;              /* past the slab: the last row, with gy as zero */           \
+        if (xrow) r = xrow[r];                                                                             \
         vx[q] = *reinterpret_cast<const float4*>(X + r * ldx + 4 * c4);                                    \
     }                                                                                                      \
     _Pragma("unroll") for (int q = 0; q < GQ; ++q) {                                                       \
@@ -805,6 +808,71 @@ extern "C" int gda_gemm_nn_mask_f32(int64_t M, int64_t N, int64_t K, const float
         GDA_LDS_ATTR_ONCE((k_tall_fwd_h<256, true>), 160 * 1024);
         k_tall_fwd_h<256, true><<<g, TALL_TB, lds, stream>>>(A, lda, B, ldb, C, ldc, M, nullptr, y, ldm, mscale);
     }
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+// ---- the sampled batch's first projection without its gather pass, and projections with the activation in the epilogue ----
+// Forward (NT):  C = act(A[arow] B^T + bias)
+//   arow (may be NULL): row i of the tall operand is A[arow[i]] (int64 [M], device) -- x[n_id] of a sampled batch read by
+//     the operand fetch; A then has any number of rows, lda >= K.
+//   act_mode 0: none.  1: C [M, N] = dropout_site0(relu(.)).  2: C [2M, N], row i = dropout_site0, row M + i = an independent
+//     draw dropout_site1 of the same pre-activation (gda_relu_dropout_pair_fwd_f32's stacked pair).  Keep-bits exactly as
+//     gda_relu_dropout_fwd_f32 / _pair_fwd_f32 would draw them on the [M, N] pre-activation; p <= 0: relu only.
+// Envelope: N, K in {128, 256}, ldc == N, 16-byte aligned operands, the split-fp16 kernel (PYGDA_AMD_GEMM_SPLIT_F16 != 0);
+// GDA_E_UNSUPPORTED elsewhere.
+extern "C" int gda_gemm_tall_fwd_ex_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const int64_t* arow,
+                                        const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                                        int act_mode, float p, uint64_t seed, const int64_t* step_dev, uint32_t site0,
+                                        uint32_t site1, gda_stream_t stream_) {
+    if (M <= 0 || N <= 0 || K <= 0 || lda < K || ldb < K) return GDA_E_SIZE;
+    if (!A || !B || !C) return GDA_E_NULL;
+    if (act_mode < 0 || act_mode > 2 || !(p < 1.f) || (act_mode && p > 0.f && !step_dev)) return GDA_E_SIZE;
+    if (C == A || C == B) return GDA_E_ALIAS;
+    static const bool split16 = [] { const char* e = std::getenv("PYGDA_AMD_GEMM_SPLIT_F16"); return !(e && e[0] == '0'); }();
+    if (!split16 || (N != 128 && N != 256) || (K != 128 && K != 256) || ldc != N || lda % 4 || ldb % 4 ||
+        (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15))
+        return GDA_E_UNSUPPORTED;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t bm = K == 128 ? 128 : 64;
+    const int64_t nt = gda_cdiv(M, bm);
+    const dim3 g((unsigned)min(nt, (int64_t)256), (unsigned)(N / 128));
+    const size_t img = (size_t)bm * (K + 8) * 2;
+    const size_t lds = 4 * img + 2 * (size_t)bm * sizeof(float);
+    const TallAct act{p > 0.f ? p : 0.f, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, step_dev, site0, site1};
+#define TFX(K_, ACT_)                                                                                              \
+    do {                                                                                                           \
+        GDA_LDS_ATTR_ONCE((k_tall_fwd_h<K_, false, 0, ACT_>), 160 * 1024);                                         \
+        k_tall_fwd_h<K_, false, 0, ACT_><<<g, TALL_TB, lds, stream>>>(A, lda, B, ldb, C, ldc, M, bias, nullptr, 0, 1.f, arow, act); \
+    } while (0)
+    if (K == 128) { if (act_mode == 0) TFX(128, 0); else if (act_mode == 1) TFX(128, 1); else TFX(128, 2); }
+    else          { if (act_mode == 0) TFX(256, 0); else if (act_mode == 1) TFX(256, 1); else TFX(256, 2); }
+#undef TFX
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+// Weight gradient (TN) with the gathered operand:  C[128, N] = A[Krows, 128]^T X[xrow][Krows, N], colsum[128] = column sums of
+// A -- gda_gemm_tall_f32's TN form reading x through the batch's node ids.  Same envelope, same workspace.
+extern "C" int gda_gemm_tall_wgrad_gather_f32(int64_t N, int64_t Krows, const float* A, int64_t lda, const float* X, int64_t ldx,
+                                              const int64_t* xrow, float* C, int64_t ldc, float* colsum,
+                                              void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    if (Krows <= 0 || (N != 128 && N != 256) || lda < 128 || ldx < N || ldc < N) return GDA_E_UNSUPPORTED;
+    if (!A || !X || !C || !xrow) return GDA_E_NULL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t slabs = min((int64_t)256, gda_cdiv(Krows, 64));
+    const int64_t rows = gda_cdiv(gda_cdiv(Krows, slabs), 8) * 8;
+    if (!workspace || workspace_bytes < gda_gemm_tall_workspace_bytes(GDA_GEMM_TN, 128, N, Krows)) return GDA_E_WORKSPACE;
+    float* part = (float*)workspace;
+    float* cs_part = part + (size_t)slabs * 128 * N;
+    if (lda % 4 || ldx % 4 || ((uintptr_t)A & 15) || ((uintptr_t)X & 15)) return GDA_E_UNSUPPORTED;
+    const size_t lds = (size_t)2 * 32 * (N + 128) * sizeof(float);
+    GDA_LDS_ATTR_ONCE(k_tall_wgrad<4>, 160 * 1024);
+    GDA_LDS_ATTR_ONCE(k_tall_wgrad<8>, 160 * 1024);
+    if (N == 128) k_tall_wgrad<4><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, X, ldx, part, colsum ? cs_part : nullptr, Krows, rows, xrow);
+    else k_tall_wgrad<8><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, X, ldx, part, colsum ? cs_part : nullptr, Krows, rows, xrow);
+    GDA_LAUNCH_CHECK();
+    k_slab_sum<<<(unsigned)gda_cdiv(128 * N + (colsum ? 128 : 0), SS_OUT), TB, 0, stream>>>(part, (int)slabs, 128, N, C, ldc, cs_part, colsum);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }

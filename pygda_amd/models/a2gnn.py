@@ -73,7 +73,9 @@ class A2GNN(BaseGDA):
         """Source logits pass (:181-182) and source feature pass (:192) over one shared layer 0."""
         net = self.a2gnn
         sb = None if self.mode == 'node' else source_data.batch
-        h0_s = net.first_conv(source_data.x, source_data.edge_index, self.s_pnums)
+        # sampled batches with s_pnums = 0: layer 0's projection writes both passes' activations itself ("stacked")
+        h0_s = net.first_conv(source_data.x, source_data.edge_index, self.s_pnums,
+                              draws="stacked" if (self.s_pnums <= 0 and getattr(source_data, "n_id", None) is not None) else 0)
         # The feature pass (:192) is issued BEFORE the logits pass (:181-182) although the reference runs them the
         # other way round (independent passes, same values): autograd walks newer nodes first, so the backward of
         # the logits / cross-entropy path -- which needs nothing from the domain loss -- is enqueued on this

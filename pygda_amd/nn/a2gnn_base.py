@@ -33,6 +33,15 @@ class ActPair:
         return ActPair(self.draws[0].detach(), None if self.draws[1] is None else self.draws[1].detach())
 
 
+class StackedAct:
+    """Layer 0's output of the trainer's TWO source passes, already through ``dropout(relu(.))`` with independent draws and
+    stacked ``[2n, h]`` (the projection's epilogue wrote it: ops.tall_linear_act mode 2)."""
+    __slots__ = ("y",)
+
+    def __init__(self, y):
+        self.y = y
+
+
 class A2GNNBase(nn.Module):
     def __init__(self, in_dim, hid_dim, num_classes, num_layers=1, adv=False, dropout=0.1,
                  act=F.relu, mode="node", **kwargs):
@@ -90,6 +99,14 @@ class A2GNNBase(nn.Module):
         :meth:`feat_bottleneck_from` passes and accepts an :class:`ActPair` -- the activation applied by the
         aggregation's epilogue -- when this batch allows it."""
         conv = self.convs[0]
+        if draws == "stacked":
+            # the two source passes as one pass over stacked rows (feat_pair_from) on a sampled batch: projection, bias,
+            # both dropout draws of the activation -- and the batch's feature gather -- in one launch
+            hit = conv.forward_stacked(x, self.dropout, self.training, 2) \
+                if (prop_nums <= 0 and self.act is F.relu and self.mode == "node" and self.hid_dim % 4 == 0) else None
+            if hit is not None:
+                return StackedAct(hit)
+            draws = 0
         if draws and self.act is F.relu and self.mode == "node" and prop_nums > 0:
             hit = conv.forward_act(x, edge_index, prop_nums, self.dropout, self.training, pair=draws > 1)
             if hit is not None:
@@ -134,16 +151,21 @@ class A2GNNBase(nn.Module):
         gradient GEMM per layer instead of two plus an accumulation, the gradient of ``h0`` summed inside the
         activation's backward kernel.  Otherwise: two passes, the first result first."""
         from ..ops import relu_dropout_pair, relu_dropout_pair_ok, split_halves
-        if not (prop_nums <= 0 and self.mode == "node" and self.act is F.relu and relu_dropout_pair_ok(h0)
-                and self.hid_dim % 4 == 0):
+        stacked = isinstance(h0, StackedAct)
+        if not stacked and not (prop_nums <= 0 and self.mode == "node" and self.act is F.relu and relu_dropout_pair_ok(h0)
+                                and self.hid_dim % 4 == 0):
             return (self.feat_bottleneck_from(h0, edge_index, batch, prop_nums),
                     self.feat_bottleneck_from(h0, edge_index, batch, prop_nums))
-        x = relu_dropout_pair(h0, self.dropout, self.training)
+        x = h0.y if stacked else relu_dropout_pair(h0, self.dropout, self.training)
         rest = list(self.convs[1:])
         for conv in rest[:-1]:
-            x = self._act_dropout(conv(x, edge_index, prop_nums))
+            hit = conv.forward_stacked(x, self.dropout, self.training, 1) if stacked else None
+            x = hit if hit is not None else self._act_dropout(conv(x, edge_index, prop_nums))
         if rest:            # the last activation hands out the two halves itself: its backward stacks and masks in one pass
             from ..ops import relu_dropout_split
+            hit = rest[-1].forward_stacked(x, self.dropout, self.training, 3) if stacked else None
+            if hit is not None:
+                return hit
             return relu_dropout_split(rest[-1](x, edge_index, prop_nums), self.dropout, self.training)
         return split_halves(x)
 

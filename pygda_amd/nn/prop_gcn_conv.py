@@ -71,19 +71,33 @@ class PropGCNConv(nn.Module):
         layout) for the fused activation kernel that follows a conv in A2GNNBase; not in the reference."""
         return self._forward(x, edge_index, prop_nums, edge_weight, True)
 
+    def forward_stacked(self, x, p, training, mode):
+        """``prop_nums = 0`` layers of a sampled batch with the activation in the projection's epilogue
+        (ops.tall_linear_act): ``mode`` 2 = two dropout draws of ``relu(x W^T + b)`` stacked ``[2n, out]`` (layer 0 of the
+        trainer's two source passes), 3 = activation, handed out as the stacked rows' two halves (their last layer), 1 =
+        plain.  None when the shape is not the fused kernel's (the caller composes).  ``x``: tensor or GatheredRows."""
+        from ..ops import tall_fused_ok, tall_linear_act
+        if self.bias is None or not tall_fused_ok(x, self.lin.weight):
+            return None
+        return tall_linear_act(x, self.lin.weight, self.bias, p, training, mode)
+
     def forward_act(self, x, edge_index, prop_nums, p, training, pair=False):
         """``dropout(relu(forward(x, edge_index, prop_nums)), p, training)`` when the aggregation's own epilogue can
         apply the activation -- a sampled batch on the one-launch interior K-step (ops.propagate_act) -- else None (the
         caller composes).  ``pair``: two independent dropout draws of the same pre-activation ``(a, b)``; ``b`` is not
         differentiated (the trainer's loss-unused second pass).  Not in the reference."""
-        if prop_nums <= 0 or not isinstance(x, torch.Tensor) or not x.is_cuda or x.dim() != 2:
+        from ..ops import GatheredRows, propagate_act, propagate_act_ok, tall_fused_ok, tall_linear_act
+        gathered = isinstance(x, GatheredRows)
+        if prop_nums <= 0 or not (isinstance(x, torch.Tensor) or gathered) or not x.is_cuda or x.dim() != 2:
             return None
-        from ..ops import propagate_act, propagate_act_ok
         g = self._graph(x, edge_index, None)
         if getattr(g, "n_interior", None) is None or getattr(g, "iplan", None) is None or self.out_channels % 4:
             return None
-        # decide before projecting: shapes only (the plan is per batch and direction, the width is out_channels)
-        out = self.lin(x)                                        # :205
+        if gathered:             # the batch's feature gather rides in the projection's operand fetch when it can
+            out = tall_linear_act(x, self.lin.weight, None, 0.0, False, 0) if tall_fused_ok(x, self.lin.weight) \
+                else self.lin(x.dense())
+        else:
+            out = self.lin(x)                                    # :205
         if not propagate_act_ok(out, g, prop_nums, self.bias):
             from ..ops import relu_dropout
             pre = propagate(out, g, prop_nums, self.bias)
@@ -92,6 +106,9 @@ class PropGCNConv(nn.Module):
         return propagate_act(out, g, prop_nums, self.bias, p, training, pair)
 
     def _forward(self, x, edge_index, prop_nums, edge_weight, colmajor_out):
+        from ..ops import GatheredRows
+        if isinstance(x, GatheredRows):      # (only the fused sampled-batch paths above read a batch's rows through its ids)
+            x = x.dense()
         if colmajor_out and prop_nums > 0 and self.lin.tall_gemm_ok(x):
             # dense projection on the matrix-core kernels: it can write the K-step kernel's column-major
             # layout itself (and read the column-major gradient), so no transposition is left around the

@@ -52,7 +52,9 @@ class GradSink:
     __slots__ = ("buf", "y", "p", "written")
 
     def __init__(self, buf, y, p):
-        self.buf, self.y, self.p, self.written = buf, y, float(p), False
+        # (an ALIAS of y, not y itself: y carries this sink as an attribute, and a tensor <-> sink reference cycle would
+        # keep every eager step's activations alive until the cyclic collector runs -- which the training loops switch off)
+        self.buf, self.y, self.p, self.written = buf, y.detach(), float(p), False
 
     def mine(self, g):
         """Is ``g`` the masked gradient a producer left in this sink?  (consumes the flag)"""
@@ -1659,6 +1661,176 @@ class _ReluDropoutSplit(torch.autograd.Function):
         _lib.check(L.gda_relu_dropout_bwd2_f32(_lib.ptr(ga), _lib.ptr(gb), _lib.ptr(y), _lib.ptr(gx),
                                                y.numel() // 2, ctx.p, _lib.stream()), "gda_relu_dropout_bwd2_f32")
         return gx, None
+
+
+# ------------------------------- projections of a sampled batch: gather in the operand fetch, activation in the epilogue --
+TALL_FUSED = _os.environ.get("PYGDA_AMD_TALL_FUSED", "1") == "1"
+
+
+class GatheredRows:
+    """``base[idx]`` NOT materialised: the feature rows of a sampled batch as (resident feature matrix, node ids).  The
+    batch's first projection reads them through the ids in its operand fetch (gda_gemm_tall_fwd_ex_f32) and so does its
+    weight gradient (gda_gemm_tall_wgrad_gather_f32): the gather pass that wrote and re-read ``[n, F]`` per domain and step
+    is gone.  Quacks like the tensor where the trainers only ask for its shape / device; ``dense()`` materialises."""
+    __slots__ = ("base", "idx", "_dense")
+    requires_grad = False
+    _version = 0
+
+    def __init__(self, base, idx):
+        self.base, self.idx, self._dense = base, idx, None
+
+    shape = property(lambda self: torch.Size((self.idx.numel(), self.base.size(1))))
+    device = property(lambda self: self.base.device)
+    dtype = property(lambda self: self.base.dtype)
+    is_cuda = property(lambda self: self.base.is_cuda)
+
+    def size(self, k=None):
+        return self.shape if k is None else self.shape[k]
+
+    def dim(self):
+        return 2
+
+    def data_ptr(self):
+        return 0
+
+    def dense(self):
+        if self._dense is None:
+            self._dense = gather_rows(self.base, self.idx)
+        return self._dense
+
+
+def tall_fused_ok(x, weight, need_rows=None):
+    """The envelope of gda_gemm_tall_fwd_ex_f32 for ``x W^T``: a sampled batch's row count, extents 128 / 256."""
+    rows = x.size(0)
+    return (TALL_FUSED and x.is_cuda and x.dtype == torch.float32 and rows >= TALL_ROWS
+            and weight.size(0) in (128, 256) and weight.size(1) in (128, 256) and x.size(1) == weight.size(1)
+            and _os.environ.get("PYGDA_AMD_GEMM_SPLIT_F16", "1") != "0")
+
+
+class _TallLinearAct(torch.autograd.Function):
+    """``act(x W^T + b)`` of a sampled batch in ONE launch: the tall split-fp16 product with (optionally) the feature
+    gather in its operand fetch and ``dropout(relu(.))`` in its epilogue.  ``mode``: 0 no activation; 1 activation; 2 two
+    independent draws stacked ``[2M, N]`` (A2GNN's two source passes over one layer-0 output); 3 activation, result handed
+    out as its two halves (the stacked rows' last layer), both halves offering GradSinks into one ``[M, N]`` buffer.
+    Backward: the activation's mask from the saved OUTPUT, the weight gradient through the same node ids, the bias
+    gradient as the weight-gradient kernel's column sums (mode 2: of the pair kernel's)."""
+
+    @staticmethod
+    def forward(ctx, base, idx, weight, bias, p, mode):
+        base, weight = _f32c(base, "x"), _f32c(weight, "weight")
+        M = base.size(0) if idx is None else idx.numel()
+        K, N = base.size(1), weight.size(0)
+        y = torch.empty((2 * M if mode == 2 else M), N, dtype=torch.float32, device=base.device)
+        st = dropout_state
+        if st.seed is None:
+            st.seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+        site0 = st.next_site() if mode else 0
+        site1 = st.next_site() if mode == 2 else 0
+        b = None if bias is None else _f32c(bias, "bias")
+        L = _lib.lib()
+        with profiler.region(f"dense_projection[{K}x{N}]", 1, 4 * (M * K + N * K + y.numel()), 2 * M * N * K):
+            _lib.check(L.gda_gemm_tall_fwd_ex_f32(M, N, K, _lib.ptr(base), K, _lib.ptr(idx), _lib.ptr(weight), K, _lib.ptr(y), N,
+                                                  _lib.ptr(b), 2 if mode == 2 else (1 if mode else 0), float(p),
+                                                  ctypes.c_uint64(st.seed), _lib.ptr(st.counter(base.device)),
+                                                  ctypes.c_uint32(site0), ctypes.c_uint32(site1), _lib.stream()),
+                       "gda_gemm_tall_fwd_ex_f32")
+        ctx.mode, ctx.p, ctx.has_bias, ctx.M = mode, float(p), bias is not None, M
+        ctx.sink_in = sink_of(base) if idx is None else None
+        ctx.save_for_backward(base, idx, weight, y if mode else None)
+        want = ctx.needs_input_grad[0] or ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        ctx.sink = ctx.sinks = ctx.G = None
+        if mode == 1:
+            ctx.sink = _offer_sink(y, p, wanted=want)
+        if mode == 3:
+            h = M // 2
+            a, c = y.narrow(0, 0, h), y.narrow(0, h, h)
+            if _sinks_on and want:
+                ctx.G = torch.empty_like(y)
+                ctx.sinks = (_offer_sink(a, p, ctx.G.narrow(0, 0, h)), _offer_sink(c, p, ctx.G.narrow(0, h, h)))
+            ctx.set_materialize_grads(False)
+            return a, c
+        return y
+
+    @staticmethod
+    def backward(ctx, g, g2=None):
+        base, idx, weight, y = ctx.saved_tensors
+        L = _lib.lib()
+        M, mode, dev = ctx.M, ctx.mode, weight.device
+        N, K = weight.shape
+        gb = None
+        if mode == 0:
+            gpre = g.contiguous()
+        elif mode == 1:
+            if ctx.sink is not None and ctx.sink.mine(g):
+                gpre = g
+            else:
+                g = g.contiguous()
+                gpre = torch.empty_like(g)
+                _lib.check(L.gda_relu_dropout_bwd_f32(_lib.ptr(g), _lib.ptr(y), _lib.ptr(gpre), g.numel(), ctx.p, _lib.stream()),
+                           "gda_relu_dropout_bwd_f32")
+        elif mode == 2:
+            # (the bias gradient comes from the weight-gradient kernel's column sums below, as in tall_linear_bias: the same
+            # summation order as the unfused composition)
+            g = g.contiguous()
+            gpre = torch.empty(M, N, dtype=torch.float32, device=dev)
+            _lib.check(L.gda_relu_dropout_pair_bwd_f32(_lib.ptr(g), _lib.ptr(y), _lib.ptr(gpre), M, N, ctx.p, None,
+                                                       None, 0, _lib.stream()), "gda_relu_dropout_pair_bwd_f32")
+        else:
+            ga, gc = g, g2
+            if ga is None and gc is None:
+                return None, None, None, None, None, None
+            h = M // 2
+            done = [k is not None and k.mine(t) for k, t in zip(ctx.sinks or (None, None), (ga, gc))]
+            if any(done):
+                for k, (t, ok) in enumerate(zip((ga, gc), done)):
+                    if ok:
+                        continue
+                    dst, yh = ctx.G.narrow(0, k * h, h), y.narrow(0, k * h, h)
+                    if t is None:
+                        dst.zero_()
+                    else:
+                        t = t.contiguous()
+                        _lib.check(L.gda_relu_dropout_bwd_f32(_lib.ptr(t), _lib.ptr(yh), _lib.ptr(dst), t.numel(), ctx.p,
+                                                              _lib.stream()), "gda_relu_dropout_bwd_f32")
+                gpre = ctx.G
+            else:
+                ga = None if ga is None else ga.contiguous()
+                gc = None if gc is None else gc.contiguous()
+                gpre = torch.empty_like(y)
+                _lib.check(L.gda_relu_dropout_bwd2_f32(_lib.ptr(ga), _lib.ptr(gc), _lib.ptr(y), _lib.ptr(gpre), y.numel() // 2,
+                                                       ctx.p, _lib.stream()), "gda_relu_dropout_bwd2_f32")
+        gw = None
+        if ctx.needs_input_grad[2]:
+            want_cs = ctx.has_bias and gb is None and ctx.needs_input_grad[3]
+            if want_cs:
+                gb = torch.empty(N, dtype=torch.float32, device=dev)
+            if idx is None:
+                gw = gemm(GEMM_TN, gpre, base, colsum=gb if want_cs else None)
+            else:
+                gw = torch.empty(N, K, dtype=torch.float32, device=dev)
+                need = L.gda_gemm_tall_workspace_bytes(GEMM_TN, 128, K, M)
+                ok = N == 128 and need > 0 and M >= TALL_WGRAD_ROWS
+                if ok:
+                    ws = _lib.workspace(need, dev, "gemm")
+                    with profiler.region(f"dense_projection_wgrad[{N}x{K}]", 2, 4 * (M * N + M * K + N * K), 2 * M * N * K):
+                        _lib.check(L.gda_gemm_tall_wgrad_gather_f32(K, M, _lib.ptr(gpre), N, _lib.ptr(base), K, _lib.ptr(idx),
+                                                                    _lib.ptr(gw), K, _lib.ptr(gb if want_cs else None),
+                                                                    _lib.ptr(ws), ws.numel(), _lib.stream()),
+                                   "gda_gemm_tall_wgrad_gather_f32")
+                else:
+                    gw = gemm(GEMM_TN, gpre, gather_rows(base, idx), colsum=gb if want_cs else None)
+        elif ctx.has_bias and gb is None and ctx.needs_input_grad[3]:
+            gb = colsum(gpre)
+        gx = None
+        if idx is None and ctx.needs_input_grad[0]:
+            gx = masked_dgrad(gpre, weight, ctx.sink_in) if ctx.sink_in is not None else gemm(GEMM_NN, gpre, weight)
+        return gx, None, gw, (gb if ctx.has_bias else None), None, None
+
+
+def tall_linear_act(x, weight, bias, p, training, mode):
+    """See :class:`_TallLinearAct`; ``x`` a tensor or :class:`GatheredRows`; the caller checked :func:`tall_fused_ok`."""
+    base, idx = (x.base, x.idx) if isinstance(x, GatheredRows) else (x, None)
+    return _TallLinearAct.apply(base, idx, weight, bias, float(p) if training else 0.0, int(mode))
 
 
 def relu_dropout_split(x, p, training=True):

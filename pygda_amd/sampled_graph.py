@@ -118,10 +118,11 @@ class _StaticBatch:
 
     def materialise(self):
         """Inside the step: the feature rows and labels of the block's node ids (all ``ncap`` of them)."""
-        from .ops import gather_rows
+        from .ops import GatheredRows, TALL_FUSED, gather_rows
         src = self.loader.data
         d = self.data
-        d.x = gather_rows(src.x, self.nodes)
+        # the feature rows stay where they are: the first projection (and its weight gradient) read them through the ids
+        d.x = GatheredRows(src.x, self.nodes) if TALL_FUSED else gather_rows(src.x, self.nodes)
         d.y = None if src.y is None else src.y[self.nodes]
         if d.y is not None:
             d.y._gda_valid_rows = self.counts[0:1]

@@ -2606,3 +2606,43 @@ def test_grad_sinks_through_the_split_activation_the_mmd_scatter_and_the_classif
             exact(got, want)
         if not use_b:
             assert float(res[0][1][n:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("mode,gather,K", [(0, True, 256), (1, False, 128), (2, True, 256), (2, False, 128), (3, False, 128)])
+def test_tall_projection_with_gather_and_activation_fused_is_the_composition(mode, gather, K):
+    """ops.tall_linear_act (gda_gemm_tall_fwd_ex_f32 / gda_gemm_tall_wgrad_gather_f32): the sampled batch's projection
+    reading its rows through the node ids and writing dropout(relu(.)) -- one draw, two stacked draws, or one draw handed out
+    as halves -- against gather_rows + tall_linear_bias + relu_dropout[_pair | _split] at the same dropout sites: outputs,
+    and the gradients of weight and bias (and of a dense input), bit for bit."""
+    from pygda_amd.nn.linear import tall_linear_bias
+    gen = torch.Generator().manual_seed(21 + mode)
+    nbase, M, N, p = 90000, 70000 if mode != 3 else 70000 * 2, 128, 0.35
+    base = torch.randn(nbase if gather else M, K, generator=gen).to(DEV)
+    idx = torch.randint(0, nbase, (M,), generator=gen).to(DEV) if gather else None
+    W0 = (torch.randn(N, K, generator=gen) * 0.1).to(DEV)
+    b0 = torch.randn(N, generator=gen).to(DEV)
+    rows_out = 2 * M if mode == 2 else M
+    wy = torch.randn(rows_out, N, generator=gen).to(DEV)
+    st = ops.dropout_state
+    st.next_step(torch.device(DEV))
+    res = []
+    for fused in (True, False):
+        W, b = W0.clone().requires_grad_(), b0.clone().requires_grad_()
+        xin = base.clone().requires_grad_() if not gather else base
+        st.site = 9
+        if fused:
+            x = ops.GatheredRows(xin, idx) if gather else xin
+            assert ops.tall_fused_ok(x, W)
+            out = ops.tall_linear_act(x, W, b, p, True, mode)
+        else:
+            x = ops.gather_rows(xin, idx) if gather else xin
+            pre = tall_linear_bias(x, W, b)
+            out = (pre if mode == 0 else ops.relu_dropout(pre, p, True) if mode == 1 else
+                   ops.relu_dropout_pair(pre, p, True) if mode == 2 else ops.relu_dropout_split(pre, p, True))
+        y = torch.cat(out) if mode == 3 else out
+        (y * wy).sum().backward()
+        res.append((y.detach(), W.grad, b.grad) + ((xin.grad,) if not gather else ()))
+    for got, want in zip(*res):
+        exact(got, want)
+    if mode:
+        assert 0.2 < float((res[0][0] != 0).float().mean()) < 0.45

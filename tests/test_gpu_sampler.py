@@ -495,6 +495,13 @@ def test_sampled_training_with_and_without_grad_sinks_is_the_same_run(monkeypatc
     assert seen1 == seen0, (seen1, seen0)
     for k in par1:
         exact(par1[k], par0[k])
+    # ... and with the projections' fused gather / activation epilogues (ops.tall_linear_act) switched off as well: the same
+    # kernels' values through separate launches
+    monkeypatch.setattr(ops, "TALL_FUSED", False)
+    m2, seen2, par2 = _sampled_fit(monkeypatch, {"PYGDA_AMD_SAMPLED_GRAPH": "1"})
+    assert seen1 == seen2, (seen1, seen2)
+    for k in par1:
+        exact(par1[k], par2[k])
 
 
 def test_captured_sampled_step_falls_back_on_a_batch_it_cannot_take(monkeypatch):
