@@ -319,7 +319,7 @@ k_tall_fwd16(const float* __restrict__ A, int64_t lda, const float* __restrict__
 #include "gda_gemm_split.inc"
 
 template <int NT8>
-__global__ void __launch_bounds__(TALL_TB, 1)
+__global__ void __launch_bounds__(TALL_TB, NT8 == 4 ? 2 : 1)
 k_tall_wgrad(const float* __restrict__ G, int64_t ldg, const float* __restrict__ X, int64_t ldx, float* __restrict__ P,
              float* __restrict__ CS, int64_t M, int64_t rows_per_slab, const int64_t* __restrict__ xrow = nullptr) {
     // xrow (may be NULL): row r of x is X[xrow[r]] (the batch's feature gather done by the operand fetch)
@@ -627,9 +627,19 @@ extern "C" int gda_gemm_ex_f32(int mode, int64_t M, int64_t N, int64_t K, const 
 //   TN  C[128, N] = A[Mrows, 128]^T B[Mrows, N]   (mode TN: M = 128 output rows, K = the tall reduction), N in {128, 256};
 //       colsum[128] = column sums of A.  Workspace: gda_gemm_tall_workspace_bytes.
 // GDA_E_UNSUPPORTED outside that envelope (callers use gda_gemm_ex_f32).
+// Row slabs of the tall weight gradient: one workgroup each, 256 = one per CU.  Measured in round 6 (tools/wgrad_sweep.py,
+// 158,720 rows, us for x 128 / 256 wide): 256 slabs 71.3 / 128.5, 384 79.9 / 155.6, 512 (two workgroups per CU for the
+// 128-wide form) 72.8 / 146.8, 768 83.0 / 159.1, 1024 86.1 / 164.6 -- the fp32 kernel is bound by its MFMAs (time doubles
+// with the width), not by load latency: more workgroups buy nothing.  PYGDA_AMD_WGRAD_SLABS overrides (experiments).
+static int64_t tall_wgrad_slabs(int64_t rows, int64_t N) {
+    static const int64_t forced = [] { const char* e = std::getenv("PYGDA_AMD_WGRAD_SLABS"); return e ? (int64_t)std::atoi(e) : (int64_t)0; }();
+    (void)N;
+    return min(forced > 0 ? forced : (int64_t)256, gda_cdiv(rows, 64));
+}
+
 extern "C" size_t gda_gemm_tall_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
     if (mode != GDA_GEMM_TN || M != 128 || (N != 128 && N != 256) || K <= 0) return 0;
-    const int64_t slabs = min((int64_t)256, gda_cdiv(K, 64));
+    const int64_t slabs = tall_wgrad_slabs(K, N);
     return (size_t)slabs * 128 * (size_t)(N + 1) * sizeof(float);
 }
 
@@ -644,7 +654,7 @@ extern "C" int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, cons
     if (mode == GDA_GEMM_TN) {
         if (bias) return GDA_E_UNSUPPORTED;
         if (M != 128 || (N != 128 && N != 256) || lda < 128 || ldb < N) return GDA_E_UNSUPPORTED;
-        const int64_t slabs = min((int64_t)256, gda_cdiv(K, 64));
+        const int64_t slabs = tall_wgrad_slabs(K, N);
         const int64_t rows = gda_cdiv(gda_cdiv(K, slabs), 8) * 8;
         if (!workspace || workspace_bytes < gda_gemm_tall_workspace_bytes(mode, M, N, K)) return GDA_E_WORKSPACE;
         float* part = (float*)workspace;
@@ -860,7 +870,7 @@ extern "C" int gda_gemm_tall_wgrad_gather_f32(int64_t N, int64_t Krows, const fl
     if (Krows <= 0 || (N != 128 && N != 256) || lda < 128 || ldx < N || ldc < N) return GDA_E_UNSUPPORTED;
     if (!A || !X || !C || !xrow) return GDA_E_NULL;
     hipStream_t stream = (hipStream_t)stream_;
-    const int64_t slabs = min((int64_t)256, gda_cdiv(Krows, 64));
+    const int64_t slabs = tall_wgrad_slabs(Krows, N);
     const int64_t rows = gda_cdiv(gda_cdiv(Krows, slabs), 8) * 8;
     if (!workspace || workspace_bytes < gda_gemm_tall_workspace_bytes(GDA_GEMM_TN, 128, N, Krows)) return GDA_E_WORKSPACE;
     float* part = (float*)workspace;
