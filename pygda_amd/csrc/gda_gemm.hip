@@ -637,6 +637,44 @@ static int64_t tall_wgrad_slabs(int64_t rows, int64_t N) {
     return min(forced > 0 ? forced : (int64_t)256, gda_cdiv(rows, 64));
 }
 
+// The slab kernel of the tall weight gradient: the fp32-MFMA form (k_tall_wgrad, the default) or split-fp16 MFMAs
+// (k_tall_wgrad_h, PYGDA_AMD_WGRAD_SPLIT_F16=1).  Round 6 built the second one expecting the first to be MFMA-bound (its time
+// doubles with the width) -- and measured, at 158,720 rows x 128 x {128, 256} (tools/wgrad_sweep.py, us incl. the slab sum):
+//   fp32 MFMA 71.0 / 127.9 | split fp16 (5.3 x less matrix time) 72.0 / 122.9 | + chunks dealt round-robin 71.9 / 114.8 |
+//   + two chunks of loads in flight 73.3 / - | fp32 with two workgroups per CU 72.8 / 146.8
+// and in the cfg-S step 2.26 ms with the fp16 form against 2.17 with the fp32 one.  Every variant streams its 160 - 240 MB at
+// 2.3 - 2.7 TB/s while two torch reductions over the same arrays reach 3.7 - 4.5 (tools/stream_probe.py): the kernel is bound
+// neither by its MFMAs, nor by load latency, nor by the slabs' address pattern -- what the forms share is 256 - 512
+// workgroups of 8 waves staging through LDS behind one barrier per 32 rows.  The fp16 form stays in as the opt-in it was
+// measured as (same results to 3e-7 of the fp64 product); the next thing to try is many small workgroups without LDS.
+static int tall_wgrad_launch(int64_t N, const float* A, int64_t lda, const float* X, int64_t ldx, const int64_t* xrow, float* part,
+                             float* cs_part, int64_t Krows, int64_t rows, int64_t slabs, hipStream_t stream) {
+    // (rows: contiguous rows per slab; 0 = chunks dealt round-robin -- k_tall_wgrad_h only)
+    static const bool split16 = [] {
+        const char* e = std::getenv("PYGDA_AMD_GEMM_SPLIT_F16");
+        const char* w = std::getenv("PYGDA_AMD_WGRAD_SPLIT_F16");
+        return !(e && e[0] == '0') && (w && w[0] == '1');
+    }();
+    static const bool dealt = [] { const char* e = std::getenv("PYGDA_AMD_WGRAD_DEALT"); return e && e[0] == '1'; }();
+    if (split16) {
+        if (dealt) rows = 0;
+        const size_t lds4 = 2 * (size_t)(2 * 128 * TWH_CS + 2 * 128 * TWH_CS + 128 * 4 + 128 * 4);
+        const size_t lds8 = 2 * (size_t)(2 * 128 * TWH_CS + 2 * 256 * TWH_CS + 128 * 4 + 256 * 4);
+        GDA_LDS_ATTR_ONCE(k_tall_wgrad_h<4>, 160 * 1024);
+        GDA_LDS_ATTR_ONCE(k_tall_wgrad_h<8>, 160 * 1024);
+        if (N == 128) k_tall_wgrad_h<4><<<(unsigned)slabs, TALL_TB, lds4, stream>>>(A, lda, X, ldx, part, cs_part, Krows, rows, xrow);
+        else k_tall_wgrad_h<8><<<(unsigned)slabs, TALL_TB, lds8, stream>>>(A, lda, X, ldx, part, cs_part, Krows, rows, xrow);
+    } else {
+        const size_t lds = (size_t)2 * 32 * (N + 128) * sizeof(float);           // both images of x and gy chunks
+        GDA_LDS_ATTR_ONCE(k_tall_wgrad<4>, 160 * 1024);
+        GDA_LDS_ATTR_ONCE(k_tall_wgrad<8>, 160 * 1024);
+        if (N == 128) k_tall_wgrad<4><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, X, ldx, part, cs_part, Krows, rows, xrow);
+        else k_tall_wgrad<8><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, X, ldx, part, cs_part, Krows, rows, xrow);
+    }
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
 extern "C" size_t gda_gemm_tall_workspace_bytes(int mode, int64_t M, int64_t N, int64_t K) {
     if (mode != GDA_GEMM_TN || M != 128 || (N != 128 && N != 256) || K <= 0) return 0;
     const int64_t slabs = tall_wgrad_slabs(K, N);
@@ -660,12 +698,8 @@ extern "C" int gda_gemm_tall_f32(int mode, int64_t M, int64_t N, int64_t K, cons
         float* part = (float*)workspace;
         float* cs_part = part + (size_t)slabs * 128 * N;
         if (lda % 4 || ldb % 4 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return GDA_E_UNSUPPORTED;
-        const size_t lds = (size_t)2 * 32 * (N + 128) * sizeof(float);           // both images of x and gy chunks
-        GDA_LDS_ATTR_ONCE(k_tall_wgrad<4>, 160 * 1024);
-        GDA_LDS_ATTR_ONCE(k_tall_wgrad<8>, 160 * 1024);
-        if (N == 128) k_tall_wgrad<4><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, B, ldb, part, colsum ? cs_part : nullptr, K, rows);
-        else k_tall_wgrad<8><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, B, ldb, part, colsum ? cs_part : nullptr, K, rows);
-        GDA_LAUNCH_CHECK();
+        int st = tall_wgrad_launch(N, A, lda, B, ldb, nullptr, part, colsum ? cs_part : nullptr, K, rows, slabs, stream);
+        if (st != GDA_OK) return st;
         GDA_UNLESS_SKIPPED("k_slab_sum") k_slab_sum<<<(unsigned)gda_cdiv(128 * N + (colsum ? 128 : 0), SS_OUT), TB, 0, stream>>>(
             part, (int)slabs, 128, N, C, ldc, cs_part, colsum);
         GDA_LAUNCH_CHECK();
@@ -876,12 +910,8 @@ extern "C" int gda_gemm_tall_wgrad_gather_f32(int64_t N, int64_t Krows, const fl
     float* part = (float*)workspace;
     float* cs_part = part + (size_t)slabs * 128 * N;
     if (lda % 4 || ldx % 4 || ((uintptr_t)A & 15) || ((uintptr_t)X & 15)) return GDA_E_UNSUPPORTED;
-    const size_t lds = (size_t)2 * 32 * (N + 128) * sizeof(float);
-    GDA_LDS_ATTR_ONCE(k_tall_wgrad<4>, 160 * 1024);
-    GDA_LDS_ATTR_ONCE(k_tall_wgrad<8>, 160 * 1024);
-    if (N == 128) k_tall_wgrad<4><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, X, ldx, part, colsum ? cs_part : nullptr, Krows, rows, xrow);
-    else k_tall_wgrad<8><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, X, ldx, part, colsum ? cs_part : nullptr, Krows, rows, xrow);
-    GDA_LAUNCH_CHECK();
+    int st = tall_wgrad_launch(N, A, lda, X, ldx, xrow, part, colsum ? cs_part : nullptr, Krows, rows, slabs, stream);
+    if (st != GDA_OK) return st;
     k_slab_sum<<<(unsigned)gda_cdiv(128 * N + (colsum ? 128 : 0), SS_OUT), TB, 0, stream>>>(part, (int)slabs, 128, N, C, ldc, cs_part, colsum);
     GDA_LAUNCH_CHECK();
     return GDA_OK;

@@ -8,6 +8,9 @@ order differs from the CPU's) is compared at 1e-4 absolute on logits / 1e-4 rela
 losses and gradients -- the bound BASELINE.json's north_star states -- with predicted
 labels identical.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -2646,3 +2649,45 @@ def test_tall_projection_with_gather_and_activation_fused_is_the_composition(mod
         exact(got, want)
     if mode:
         assert 0.2 < float((res[0][0] != 0).float().mean()) < 0.45
+
+
+def test_tall_weight_gradient_on_split_fp16_mfma_matches_fp64_in_a_child_process():
+    """k_tall_wgrad_h (csrc/gda_gemm_split.inc, opt-in: PYGDA_AMD_WGRAD_SPLIT_F16=1 -- measured no faster than the fp32 form,
+    csrc/gda_gemm.hip::tall_wgrad_launch): the weight gradient with split-fp16 operands transposed in the staging registers,
+    per-column power-of-two scales per 32-row chunk, against the float64 product at cfg-S's shapes, plain and with the
+    gathered operand; column sums (the bias gradient) included.  The switch is read once per process: a child runs it."""
+    import subprocess
+    import sys
+    code = r'''
+import json, os, sys, torch
+sys.path.insert(0, os.getcwd())
+from pygda_amd import ops, _lib
+out = {}
+gen = torch.Generator().manual_seed(5)
+for n, k in ((70001, 128), (50000, 256)):
+    x = (torch.randn(n + 999, k, generator=gen) * torch.logspace(-3, 2, k)).cuda()
+    gy = (torch.randn(n, 128, generator=gen) * 1e-4).cuda()
+    gy[:, 7] = 0
+    idx = torch.randint(0, n + 999, (n,), generator=gen).cuda()
+    cs = torch.empty(128, device="cuda")
+    got = ops.gemm(ops.GEMM_TN, gy, x[:n].contiguous(), colsum=cs)
+    ref = gy.double().t() @ x[:n].double()
+    out[f"plain{k}"] = float(((got.double() - ref).abs() / (gy.double().abs().t() @ x[:n].double().abs() + 1e-30)).max())
+    out[f"cs{k}"] = float((cs.double() - gy.double().sum(0)).abs().max() / gy.double().abs().sum(0).max())
+    L = _lib.lib()
+    gw = torch.empty(128, k, device="cuda")
+    need = L.gda_gemm_tall_workspace_bytes(ops.GEMM_TN, 128, k, n)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    _lib.check(L.gda_gemm_tall_wgrad_gather_f32(k, n, _lib.ptr(gy), 128, _lib.ptr(x), k, _lib.ptr(idx), _lib.ptr(gw), k, None,
+                                                _lib.ptr(ws), need, _lib.stream()), "gather")
+    refg = gy.double().t() @ x[idx].double()
+    out[f"gather{k}"] = float(((gw.double() - refg).abs() / (gy.double().abs().t() @ x[idx].double().abs() + 1e-30)).max())
+print(json.dumps(out))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYGDA_AMD_WGRAD_SPLIT_F16="1")
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert run.returncode == 0, run.stderr[-2000:]
+    res = json.loads(run.stdout.strip().splitlines()[-1])
+    for k, v in res.items():
+        assert v < 2e-6, (k, v, res)          # error relative to sum |a||b|: an fp32 accumulation's class
