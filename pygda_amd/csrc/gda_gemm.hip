@@ -405,6 +405,133 @@ k_tall_wgrad(const float* __restrict__ G, int64_t ldg, const float* __restrict__
     }
 }
 
+// k_tall_wgrad with its operand chunks arriving by LDS-DMA (round 6).  The register-staged kernel above issues ONE chunk of
+// loads per iteration and stashes it half a chunk of MFMAs later: whenever the loads take longer than that half (they do:
+// ~1.2 us against 0.85 us at 128 columns) every wave of the workgroup stands at the stash, and the compiler's vmcnt(0)
+// there defeats any deeper register prefetch (measured: tall_wgrad_launch).  tools/ubench/wgrad_stream.hip streams the same
+// operands through the same launch shape, LDS and barrier included, in 24 us -- the 60 us of the real kernels are this
+// exposed latency plus the MFMAs, not the memory system.  The LDS image of a chunk is the chunk's rows exactly as they lie
+// in memory, which is what global_load_lds_dwordx4 writes (1 KB per wave instruction, LDS address = M0 + 16 lane): no
+// staging registers, no stash phase, and the prefetch depth is a matter of LDS -- THREE chunk buffers, two chunks of loads
+// in flight while the third is multiplied; one barrier per chunk.  The loads are inline assembly with one explicit
+// s_waitcnt per chunk (behind the builtin the compiler waits for every transfer before the next LDS read).  A partial last
+// chunk (rows past the slab: gy must read as zero) goes through the register path.  Same accumulation order as
+// k_tall_wgrad: bit-identical results.
+template <int NT8>
+__global__ void __launch_bounds__(TALL_TB, 1)
+k_tall_wgrad_dma(const float* __restrict__ G, int64_t ldg, const float* __restrict__ X, int64_t ldx, float* __restrict__ P,
+                 float* __restrict__ CS, int64_t M, int64_t rows_per_slab, const int64_t* __restrict__ xrow) {
+    constexpr int XC = 32 * NT8, RC = 32, HT = NT8 / 2;
+    constexpr int XB = RC * XC * 4, GB = RC * 128 * 4, BUFB = XB + GB;          // bytes: x part, gy part, one chunk buffer
+    constexpr int NI = BUFB / 1024, IPW = NI / 8;                              // DMA instructions per chunk / per wave
+    constexpr int XQ = RC * XC / 4 / TALL_TB, GQ = RC * 128 / 4 / TALL_TB;
+    static_assert(NI % 8 == 0, "every wave issues the same number of transfers");
+    extern __shared__ __attribute__((aligned(16))) char td_lds[];               // [3][ x [RC][XC] | gy [RC][128] ]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ka = lane >> 5, la = lane & 31;
+    const int n0 = 32 * (wave & 3), t0 = HT * (wave >> 2);
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab, r1 = min(M, r0 + rows_per_slab);
+    const int64_t nfull = r0 < r1 ? (r1 - r0) / RC : 0;                         // whole chunks; the rest takes the register path
+    f32x16 acc[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float csum = 0.f;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)td_lds;
+    // gathered x: the slab's row ids are staged in LDS ONCE (behind the three buffers) -- read per transfer from global memory
+    // they would sit in the same in-order vmcnt queue as the transfers and every wait for an id would drain the prefetch
+    int64_t* ids = reinterpret_cast<int64_t*>(td_lds + 3 * BUFB);
+    if (xrow) {
+        for (int64_t i = tid; i < r1 - r0; i += TALL_TB) ids[i] = xrow[r0 + i];
+        __syncthreads();
+    }
+    // transfer j of a chunk covers bytes [1024 j, 1024 j + 1024) of its buffer; this lane's 16 bytes sit at 1024 j + 16 lane
+#define TD_ISSUE(CH, B_)                                                                                     \
+    _Pragma("unroll") for (int k = 0; k < IPW; ++k) {                                                        \
+        const int j = wave + 8 * k;                                                                          \
+        const int b = 1024 * j + 16 * lane;                                                                  \
+        const float* gp;                                                                                     \
+        if (b < XB) {                                                                                        \
+            int64_t r = r0 + (CH) * RC + b / (XC * 4);                                                       \
+            if (xrow) r = ids[(CH) * RC + b / (XC * 4)];                                                     \
+            gp = X + r * ldx + (b % (XC * 4)) / 4;                                                           \
+        } else {                                                                                             \
+            const int bb = b - XB;                                                                           \
+            gp = G + (r0 + (CH) * RC + bb / 512) * ldg + (bb % 512) / 4;                                     \
+        }                                                                                                    \
+        const uint32_t lp = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((B_) * BUFB + 1024 * j));       \
+        uint32_t keep;                                                                                       \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep) : "v"(gp), "s"(lp) : "memory");                                           \
+    }
+#define TD_MFMA(B_)                                                                                          \
+    {                                                                                                        \
+        const float* xs = reinterpret_cast<const float*>(td_lds + (B_) * BUFB) + ka * XC + 32 * t0 + la;     \
+        const float* gs = reinterpret_cast<const float*>(td_lds + (B_) * BUFB + XB) + ka * 128 + n0 + la;    \
+        _Pragma("unroll") for (int p = 0; p < RC / 2; ++p) {                                                 \
+            const float a = gs[2 * p * 128];                                                                 \
+            csum += a;                                                                                       \
+            _Pragma("unroll") for (int t = 0; t < HT; ++t)                                                   \
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs[2 * p * XC + 32 * t], acc[t], 0, 0, 0);  \
+        }                                                                                                    \
+    }
+    if (nfull > 0) { TD_ISSUE(0, 0) }
+    if (nfull > 1) { TD_ISSUE(1, 1) }
+    int buf = 0;
+    for (int64_t c = 0; c < nfull; ++c) {
+        // this wave's transfers of chunk c have landed when at most the IPW newer ones (chunk c + 1) are outstanding
+        if (c + 1 < nfull) { if constexpr (IPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // everybody's transfers of chunk c; everybody done with chunk c - 1's buffer
+        if (c + 2 < nfull) { const int nb = buf == 0 ? 2 : buf - 1; TD_ISSUE(c + 2, nb) }
+        TD_MFMA(buf)
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    if (r0 < r1 && r0 + nfull * RC < r1) {             // the partial last chunk, through registers (rows past the end: gy = 0)
+        const int64_t m0 = r0 + nfull * RC;
+        float4 vx[XQ], vg[GQ];
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int idx = tid + TALL_TB * q, row = idx / (XC / 4), c4 = idx % (XC / 4);
+            int64_t r = m0 + row;
+            r = r < r1 ? r : r1 - 1;
+            if (xrow) r = xrow[r];
+            vx[q] = *reinterpret_cast<const float4*>(X + r * ldx + 4 * c4);
+        }
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) {
+            const int idx = tid + TALL_TB * q, row = idx / 32, c4 = idx % 32;
+            const int64_t r = m0 + row;
+            const bool in = r < r1;
+            float4 g = *reinterpret_cast<const float4*>(G + (in ? r : r1 - 1) * ldg + 4 * c4);
+            g.x = in ? g.x : 0.f; g.y = in ? g.y : 0.f; g.z = in ? g.z : 0.f; g.w = in ? g.w : 0.f;
+            vg[q] = g;
+        }
+        __syncthreads();                               // every wave is past its last MFMAs on the buffers
+        float* xw = reinterpret_cast<float*>(td_lds);
+        float* gw = reinterpret_cast<float*>(td_lds + XB);
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) *reinterpret_cast<float4*>(xw + 4 * (tid + TALL_TB * q)) = vx[q];
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) *reinterpret_cast<float4*>(gw + 4 * (tid + TALL_TB * q)) = vg[q];
+        __syncthreads();
+        TD_MFMA(0)
+    }
+#undef TD_ISSUE
+#undef TD_MFMA
+    float* out = P + (int64_t)blockIdx.x * 128 * XC;
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            out[(int64_t)(n0 + (r & 3) + 8 * (r >> 2) + 4 * ka) * XC + 32 * (t0 + t) + la] = acc[t][r];
+    if (CS && t0 == 0) {
+        const float other = __shfl_down(csum, 32, 64);
+        if (ka == 0) CS[(int64_t)blockIdx.x * 128 + n0 + la] = csum + other;
+    }
+}
+
 // ---- skinny products: the classifier projection h -> C (C <= 8 classes) at 10^5 rows ---------------------------------
 // On the 64 x 64-tile kernel 92 % of such a product's matrix-core work is padding (5 of 64 columns) and its weight
 // gradient ran 179 us per cfg-S step; the products are memory-bound streams (read x once / write gx once), so they run on
@@ -645,8 +772,14 @@ static int64_t tall_wgrad_slabs(int64_t rows, int64_t N) {
 // and in the cfg-S step 2.26 ms with the fp16 form against 2.17 with the fp32 one.  Every variant streams its 160 - 240 MB at
 // 2.3 - 2.7 TB/s while two torch reductions over the same arrays reach 3.7 - 4.5 (tools/stream_probe.py): the kernel is bound
 // neither by its MFMAs, nor by load latency, nor by the slabs' address pattern -- what the forms share is 256 - 512
-// workgroups of 8 waves staging through LDS behind one barrier per 32 rows.  The fp16 form stays in as the opt-in it was
-// measured as (same results to 3e-7 of the fp64 product); the next thing to try is many small workgroups without LDS.
+// workgroups of 8 waves staging through LDS behind one barrier per 32 rows.  tools/ubench/wgrad_stream.hip then streamed the
+// same operands through the same launch shape, LDS and barrier included, in 24 us: the shape is innocent; what costs is the
+// exposed latency of a one-chunk register prefetch (the compiler's vmcnt(0) at the stash defeats a deeper one) on top of the
+// arithmetic.  k_tall_wgrad_dma (LDS-DMA, three buffers, fp32 MFMAs; the default, PYGDA_AMD_WGRAD_DMA=0 restores the
+// register-staged kernel) hides it: 66.7 / 122.6 us, cfg-S 2.20 -> 2.13 ms/step -- and is then bound by its MFMAs (58 % of
+// the fp32 roof).  The fp16 form cannot take the same route cheaply: with DMA the operands arrive as fp32 and every wave
+// that consumes an element converts it again (~350 VALU per chunk and wave: the matrix time saved).  It stays in as the
+// opt-in it was measured as (same results to 3e-7 of the fp64 product).
 static int tall_wgrad_launch(int64_t N, const float* A, int64_t lda, const float* X, int64_t ldx, const int64_t* xrow, float* part,
                              float* cs_part, int64_t Krows, int64_t rows, int64_t slabs, hipStream_t stream) {
     // (rows: contiguous rows per slab; 0 = chunks dealt round-robin -- k_tall_wgrad_h only)
@@ -656,6 +789,7 @@ static int tall_wgrad_launch(int64_t N, const float* A, int64_t lda, const float
         return !(e && e[0] == '0') && (w && w[0] == '1');
     }();
     static const bool dealt = [] { const char* e = std::getenv("PYGDA_AMD_WGRAD_DEALT"); return e && e[0] == '1'; }();
+    static const bool dma = [] { const char* e = std::getenv("PYGDA_AMD_WGRAD_DMA"); return !(e && e[0] == '0'); }();
     if (split16) {
         if (dealt) rows = 0;
         const size_t lds4 = 2 * (size_t)(2 * 128 * TWH_CS + 2 * 128 * TWH_CS + 128 * 4 + 128 * 4);
@@ -664,6 +798,12 @@ static int tall_wgrad_launch(int64_t N, const float* A, int64_t lda, const float
         GDA_LDS_ATTR_ONCE(k_tall_wgrad_h<8>, 160 * 1024);
         if (N == 128) k_tall_wgrad_h<4><<<(unsigned)slabs, TALL_TB, lds4, stream>>>(A, lda, X, ldx, part, cs_part, Krows, rows, xrow);
         else k_tall_wgrad_h<8><<<(unsigned)slabs, TALL_TB, lds8, stream>>>(A, lda, X, ldx, part, cs_part, Krows, rows, xrow);
+    } else if (dma && lda % 4 == 0 && ldx % 4 == 0 && (!xrow || rows <= 1024)) {
+        const size_t lds = (size_t)3 * 32 * (N + 128) * sizeof(float) + (xrow ? (size_t)rows * 8 : 0);   // three chunk buffers (+ row ids)
+        GDA_LDS_ATTR_ONCE(k_tall_wgrad_dma<4>, 160 * 1024);
+        GDA_LDS_ATTR_ONCE(k_tall_wgrad_dma<8>, 160 * 1024);
+        if (N == 128) k_tall_wgrad_dma<4><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, X, ldx, part, cs_part, Krows, rows, xrow);
+        else k_tall_wgrad_dma<8><<<(unsigned)slabs, TALL_TB, lds, stream>>>(A, lda, X, ldx, part, cs_part, Krows, rows, xrow);
     } else {
         const size_t lds = (size_t)2 * 32 * (N + 128) * sizeof(float);           // both images of x and gy chunks
         GDA_LDS_ATTR_ONCE(k_tall_wgrad<4>, 160 * 1024);
