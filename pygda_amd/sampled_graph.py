@@ -20,8 +20,9 @@ behind the live ones, both interior K-step plans).  So the step runs at the capa
   a few microseconds -- after which the ring block is free again), the MMD draws over the live counts into the static
   sample block (the same CPU-generator draws, in the same order, as the eager ``MMD()``), one ``hipGraphLaunch``.
 
-The capture is single-stream (no fork: a forked capture is enqueued node by node on this runtime, profiles/HISTORY.md 4.7; a
-single-stream one replays through pre-built packets), statistics included.  A batch the static shape cannot take (an
+The capture keeps the eager step's branch structure (source branch and the loss-unused target logits pass on side streams:
+the one-launch interior K-step occupies half the chip, the source branch's projections run beside it: 2.13 -> 1.92 ms/step;
+`FORK` below), statistics on the main stream.  A batch the static shape cannot take (an
 interior plan declined, fewer live rows than twice the interior capacity) runs the ordinary eager step on its real
 shape -- same optimiser state, same dropout counters -- and the next one replays again.
 """
@@ -39,6 +40,12 @@ from .utils import mmd as _mmd
 
 import os as _os
 ROW_MARGIN = float(_os.environ.get("PYGDA_AMD_SAMPLED_GRAPH_ROW_MARGIN", "0.015"))
+# The source branch on a second stream inside the capture (and the loss-unused target logits pass on a third), as the eager
+# sampled step runs them.  A forked graph is enqueued node by node (~3 us each) instead of replaying pre-built
+# packets -- but these kernels are 30 - 100 us each, the one-launch interior K-step occupies HALF the chip (one workgroup per
+# feature column) and the source branch's chip-filling projections fit beside it: measured 2.13 -> 1.92 ms/step at cfg-S
+# with 0.37 - 0.42 ms of host work either way.  PYGDA_AMD_SAMPLED_GRAPH_FORK=0: one stream.
+FORK = _os.environ.get("PYGDA_AMD_SAMPLED_GRAPH_FORK", "1") == "1"
 
 
 def interior_capacity(n_seeds, fanouts):
@@ -220,7 +227,7 @@ class GraphedSampledStep(GraphedStep):
         counter = dropout_state.counter(dev)
         saved_counter = counter.clone()
         prev_overlap = getattr(self.trainer, "overlap_sampled", None)
-        self.trainer.overlap_sampled = False                       # ONE stream: no fork inside the capture
+        self.trainer.overlap_sampled = FORK                        # ONE stream by default: no fork inside the capture
         import gc
         torch.cuda.synchronize()
         gc.collect()
@@ -310,7 +317,7 @@ class GraphedSampledStep(GraphedStep):
             if self.graph is not None:
                 self.graph.replay()
             else:
-                self.trainer.overlap_sampled = False
+                self.trainer.overlap_sampled = FORK
                 self._run(with_stats=True)
         finally:
             _mmd.sample_provider = prev
