@@ -212,6 +212,8 @@ class BaseGDA(ABC):
                     hit = (source_logits.detach().argmax(dim=1) == src.y).sum()
                     dev_correct = hit if dev_correct is None else dev_correct + hit
                     rows += int(src.y.numel())
+                    S_s.release(ps)              # everything that reads the two ring blocks is enqueued: hand them back
+                    S_t.release(pt)
                 settle(0)
                 for gen in raw:              # (a zip that stopped at the shorter loader leaves the other generator open)
                     gen.close()

@@ -473,6 +473,18 @@ class DeviceNeighborSampler:
                 g.iplan_T = getattr(p, "T_int", None)
         return g
 
+    def release(self, p):
+        """The consumer has ENQUEUED everything that reads batch ``p`` on the current stream and will not look at it again:
+        hand its ring block back now (instead of when the next batch is assembled).  For consumers that mix
+        :meth:`assemble` with their own reading of the raw slots (the captured sampled step's eager fall-back): without
+        it the block would come round unguarded -- ``assemble`` of the NEXT batch is what normally records ``free``."""
+        if not getattr(p, "recycled", False):
+            return
+        _lib.check(_lib.lib().gda_event_record(p.free, torch.cuda.current_stream().cuda_stream), "gda_event_record")
+        p.freed = True
+        if p.ring.last is p:
+            p.ring.last = None
+
     def assemble(self, data, p, sizes=None):
         """Consumer side (training stream): order behind the sampler's stream, gather the feature rows."""
         n, e, nnz, n_int = sizes if sizes is not None else p.wait()

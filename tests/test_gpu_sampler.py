@@ -426,7 +426,7 @@ def test_sampled_training_no_longer_depends_on_host_sampler_threads():
     exact(labels, tgt.y[:4 * 512])
 
 
-def _sampled_fit(monkeypatch, env, steps=6, seed=1, dropout=0.5):
+def _sampled_fit(monkeypatch, env, steps=6, seed=1, dropout=0.5, extra_seeds=0):
     """cfg-S in small through the trainer's own loop: 200 k nodes per domain, 512 seeds at fan-out [15, 10], dropout on."""
     import pygda_amd
     from bench import make_cfg_s
@@ -440,8 +440,8 @@ def _sampled_fit(monkeypatch, env, steps=6, seed=1, dropout=0.5):
     ops.dropout_state.counter(torch.device(DEV)).zero_()
     ops.dropout_state.seed = 12345
     net, optimizer, step, alpha = m._prepare(src, tgt)
-    m.source_loader.input_nodes = m.source_loader.input_nodes[:steps * 512]
-    m.target_loader.input_nodes = m.target_loader.input_nodes[:steps * 512]
+    m.source_loader.input_nodes = m.source_loader.input_nodes[:steps * 512 + extra_seeds]
+    m.target_loader.input_nodes = m.target_loader.input_nodes[:steps * 512 + extra_seeds]
     seen = []
     m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
     m._train_epochs(net, optimizer, step, alpha)
@@ -479,6 +479,22 @@ def test_captured_sampled_step_equals_the_eager_static_step_bit_for_bit(monkeypa
     # predict() after a captured fit: the loaders still hand out ordinary batches
     logits, labels = mc.predict(None)
     assert logits.shape == (6 * 512, 5) and bool(torch.isfinite(logits).all())
+
+
+def test_captured_sampled_step_with_a_short_last_batch(monkeypatch):
+    """Seeds that do not fill the last batch (5 x 512 + 100): that batch has another shape than the ring's blocks, comes as
+    an ordinary pending batch and takes the eager step -- per epoch five replays and one fall-back; the epoch's numbers are
+    those of the all-eager loop to fp32 summation order, and the ring blocks of replayed and eager steps are all handed
+    back (two epochs run through the same six-block ring without touching a batch still in use)."""
+    mc, seen_c, par_c = _sampled_fit(monkeypatch, {"PYGDA_AMD_SAMPLED_GRAPH": "1"}, steps=5, dropout=0.0, extra_seeds=100)
+    st = mc._sampled_graphed[1]
+    assert st.replays == 10 and st.fallbacks == 2, (st.replays, st.fallbacks)
+    mr, seen_r, par_r = _sampled_fit(monkeypatch, {"PYGDA_AMD_SAMPLED_GRAPH": "0"}, steps=5, dropout=0.0, extra_seeds=100)
+    np.testing.assert_allclose([v[0] for v in seen_c], [v[0] for v in seen_r], rtol=1e-5)
+    np.testing.assert_allclose([v[1] for v in seen_c], [v[1] for v in seen_r], atol=2e-5)
+    for k in par_c:
+        scale = float(par_r[k].abs().max()) + 1e-12
+        np.testing.assert_allclose(par_c[k].cpu().numpy(), par_r[k].cpu().numpy(), rtol=0, atol=1e-4 * scale, err_msg=k)
 
 
 def test_sampled_training_with_and_without_grad_sinks_is_the_same_run(monkeypatch):
