@@ -379,6 +379,33 @@ int gda_mmd_fused_bwd_mask_f32(const float* grad_part, int nseg, int times, int6
                                const float* mask_src, float p_src, const float* mask_tgt, float p_tgt,
                                gda_stream_t stream);
 
+/* The one-pass MMD for ANY feature width d <= 1024 (round 6; pygda/models/grade.py:177-182 calls MMD() on 645-wide rows):
+ * the feature dimension is cut into chunks of 32 | 64 | 96 | 128 columns -- the chunk width that pads d least --, a
+ * workgroup keeps the 32 x 32 distance blocks of up to eight row tiles in accumulators over all chunks, takes the
+ * exponentials once, and forms the gradient chunk by chunk (csrc/gda_mmd_chunked.inc).  Rows of any alignment; same
+ * split-fp16 arithmetic and the same error class as gda_mmd_fused_fwd_f32.  kernel_num = 5, kernel_mul = 2, n <= 1024.
+ *   gda_mmd_chunked_plan   host arithmetic only: out[8] = { nseg, padded width dp, nb (32-column blocks per chunk), nc
+ *                          (chunks), ntiles, njb, workgroups, image bytes }; GDA_E_UNSUPPORTED outside the envelope
+ *   rows_src / rows_tgt    [times * n, ld_rows] fp32 scratch, ld_rows = dp, 16-byte aligned: the gathered (src_idx given)
+ *                          or copied (NULL: rows stacked [times, n, d]) rows, zero padded -- REQUIRED
+ *   grad_part              [times, nseg, 2n, ld_part] fp32, ld_part = dp: unscaled row-gradient partials for
+ *                          gda_mmd_fused_bwd_ld_f32 (= gda_mmd_fused_bwd_mask_f32 with the partials' row stride)
+ *   workspace              gda_mmd_chunked_workspace_bytes(times, n, d) */
+int gda_mmd_chunked_plan(int times, int64_t n, int64_t d, float kernel_mul, int kernel_num, int64_t* out, int n_out);
+size_t gda_mmd_chunked_workspace_bytes(int times, int64_t n, int64_t d);
+int gda_mmd_chunked_fwd_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
+                            int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
+                            int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
+                            float scale, const float* add, float* rows_src, float* rows_tgt, int64_t ld_rows,
+                            float* loss, float* bandwidth, float* grad_part, int64_t ld_part, int nseg,
+                            void* workspace, size_t workspace_bytes, gda_stream_t stream);
+int gda_mmd_fused_bwd_ld_f32(const float* grad_part, int64_t ld_part, int nseg, int times, int64_t n, int64_t d,
+                             const float* grad_loss, float scale, float* grad_rows,
+                             const int32_t* sel_s_rowptr, const int32_t* sel_s_col, int64_t n_src_rows, float* gsrc,
+                             const int32_t* sel_t_rowptr, const int32_t* sel_t_col, int64_t n_tgt_rows, float* gtgt,
+                             const float* mask_src, float p_src, const float* mask_tgt, float p_tgt,
+                             gda_stream_t stream);
+
 /* ------------------------------------------------------------------------------
  * Gradient-reversal + linear domain discriminator + softmax cross-entropy, fused.
  *

@@ -65,6 +65,12 @@ _SIGNATURES = {
                                       _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P]),
     "gda_mmd_fused_bwd_mask_f32": (c_int, [_P, c_int, c_int, c_int64, c_int64, _P, c_float, _P,
                                            _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, c_float, _P, c_float, _P]),
+    "gda_mmd_chunked_plan": (c_int, [c_int, c_int64, c_int64, c_float, c_int, _P, c_int]),
+    "gda_mmd_chunked_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64]),
+    "gda_mmd_chunked_fwd_f32": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, _P, c_int, c_int64, c_float, c_int, c_float,
+                                        c_float, _P, _P, _P, c_int64, _P, _P, _P, c_int64, c_int, _P, c_size_t, _P]),
+    "gda_mmd_fused_bwd_ld_f32": (c_int, [_P, c_int64, c_int, c_int, c_int64, c_int64, _P, c_float, _P,
+                                         _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, c_float, _P, c_float, _P]),
     "gda_gemm_tall_fwd_ex_f32": (c_int, [c_int64, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, _P, c_int,
                                          c_float, ctypes.c_uint64, _P, ctypes.c_uint32, ctypes.c_uint32, _P]),
     "gda_gemm_tall_wgrad_gather_f32": (c_int, [c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P, _P, c_size_t, _P]),

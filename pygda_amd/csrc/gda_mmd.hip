@@ -682,6 +682,20 @@ k_bwd(Rows R, int64_t d, int64_t m, const float* __restrict__ l2, const float* _
 }
 
 // grad_rows = 4 * sum over segments (fixed order)
+// the same fold for partials whose rows are padded to ldp >= d floats (the chunked one-pass kernel): grad_rows is [times, m, d]
+__global__ void __launch_bounds__(TB)
+k_bwd_reduce_ld(const float* __restrict__ part, int64_t m, int64_t d, int64_t ldp, int nseg, int times,
+                float* __restrict__ grad_rows, const float* __restrict__ grad_loss, float cmul) {
+    const float c4 = grad_loss ? 4.f * (grad_loss[0] * cmul) : 4.f;
+    const int64_t total = m * d * times;
+    for (int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x; k < total; k += (int64_t)gridDim.x * TB) {
+        const int64_t t = k / (m * d), r = k % (m * d), i = r / d, c = r % d;
+        float s = 0.f;
+        for (int g = 0; g < nseg; ++g) s += part[((t * nseg + g) * m + i) * ldp + c];
+        grad_rows[k] = c4 * s;
+    }
+}
+
 __global__ void __launch_bounds__(TB)
 k_bwd_reduce(const float* __restrict__ part, int64_t per_t, int nseg, int times,
              float* __restrict__ grad_rows, const float* __restrict__ grad_loss, float cmul) {
@@ -701,7 +715,7 @@ k_bwd_reduce(const float* __restrict__ part, int64_t per_t, int nseg, int times,
 // -- the values k_bwd_reduce followed by the selection-matrix SpMM produce, bit for bit; rows nobody sampled get 0.
 template <int NSEG>
 __global__ void __launch_bounds__(TB)
-k_bwd_scatter(const float* __restrict__ part, int64_t m, int64_t d, int nseg_rt,
+k_bwd_scatter(const float* __restrict__ part, int64_t m, int64_t d, int64_t ldp, bool vec_out, int nseg_rt,
               const int32_t* __restrict__ s_rowptr, const int32_t* __restrict__ s_col, int64_t n_src_rows,
               float* __restrict__ gsrc, const int32_t* __restrict__ t_rowptr, const int32_t* __restrict__ t_col,
               int64_t n_tgt_rows, float* __restrict__ gtgt, const float* __restrict__ grad_loss, float cmul,
@@ -727,7 +741,7 @@ k_bwd_scatter(const float* __restrict__ part, int64_t m, int64_t d, int nseg_rt,
     if (mk) mk += r * d;
     const int32_t b = rp[r], e = rp[r + 1];
     if constexpr (NSEG > 0) {
-        // d % 4 == 0 and 16-byte aligned arrays (the launcher checks): the NSEG partial quads of an entry are NSEG
+        // ldp % 4 == 0 and a 16-byte aligned partial array (the launcher checks): the NSEG partial quads of an entry are NSEG
         // independent 16-byte loads in flight at once (the generic loop below issues one dependent 4-byte load after
         // the other: 34 us at the A2GNN shapes against 8) -- added in the same segment order, entry after entry
         const int mi = (int)m;
@@ -738,15 +752,22 @@ k_bwd_scatter(const float* __restrict__ part, int64_t m, int64_t d, int nseg_rt,
                 const int p = pn;
                 if (k + 1 < e) pn = ci[k + 1];
                 const int t = p / mi, i = p - t * mi;
-                const float* q = part + (((int64_t)t * NSEG) * m + i) * d + c;
+                const float* q = part + (((int64_t)t * NSEG) * m + i) * ldp + c;
                 float4 v[NSEG];
 #pragma unroll
-                for (int g = 0; g < NSEG; ++g) v[g] = *reinterpret_cast<const float4*>(q + (int64_t)g * m * d);
+                for (int g = 0; g < NSEG; ++g) v[g] = *reinterpret_cast<const float4*>(q + (int64_t)g * m * ldp);
                 float4 sg = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int g = 0; g < NSEG; ++g) { sg.x += v[g].x; sg.y += v[g].y; sg.z += v[g].z; sg.w += v[g].w; }
                 acc.x = __fadd_rn(acc.x, c4 * sg.x); acc.y = __fadd_rn(acc.y, c4 * sg.y);
                 acc.z = __fadd_rn(acc.z, c4 * sg.z); acc.w = __fadd_rn(acc.w, c4 * sg.w);
+            }
+            if (!vec_out) {                                        // output rows of any width / alignment (d = 645: GRADE)
+                const float a4[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+                for (int v2 = 0; v2 < 4; ++v2)
+                    if (c + v2 < d) out[c + v2] = mk ? (mk[c + v2] > 0.f ? a4[v2] * msc : 0.f) : a4[v2];
+                continue;
             }
             if (mk) {
                 const float4 y = *reinterpret_cast<const float4*>(mk + c);
@@ -763,7 +784,7 @@ k_bwd_scatter(const float* __restrict__ part, int64_t m, int64_t d, int nseg_rt,
             const int64_t p = ci[k], t = p / m, i = p % m;
             float sg[4] = {0.f, 0.f, 0.f, 0.f};
             for (int g = 0; g < nseg; ++g) {
-                const float* q = part + (((int64_t)t * nseg + g) * m + i) * d + c;
+                const float* q = part + (((int64_t)t * nseg + g) * m + i) * ldp + c;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) if (c + v < d) sg[v] += q[v];
             }
@@ -808,6 +829,7 @@ int launch_bwd(dim3 grid, hipStream_t stream, Rows R, int64_t d, int64_t m, cons
 }
 
 #include "gda_mmd_fused.inc"
+#include "gda_mmd_chunked.inc"
 
 struct MmdWs {
     double* kpartial; double* part_s1; float* part_col; float* bwd_part; float* norms;
@@ -986,7 +1008,7 @@ extern "C" int gda_mmd_bwd_ex_f32(const float* src, int64_t ld_src, const float*
             const dim3 sg((unsigned)gda_cdiv(most, TB / 32), 2);
             const bool quads = d % 4 == 0 && ((uintptr_t)ws.bwd_part % 16 == 0) && ((uintptr_t)gsrc % 16 == 0) &&
                                ((uintptr_t)gtgt % 16 == 0);
-#define GDA_SCATTER(NS) k_bwd_scatter<NS><<<sg, TB, 0, stream>>>(ws.bwd_part, m, d, nseg, sel_s_rowptr, sel_s_col, \
+#define GDA_SCATTER(NS) k_bwd_scatter<NS><<<sg, TB, 0, stream>>>(ws.bwd_part, m, d, d, true, nseg, sel_s_rowptr, sel_s_col, \
                                                               n_src_rows, gsrc, sel_t_rowptr, sel_t_col, n_tgt_rows, gtgt, nullptr, 1.f)
             if (quads && nseg == 6) GDA_SCATTER(6);
             else if (quads && nseg == 4) GDA_SCATTER(4);
@@ -1078,15 +1100,105 @@ extern "C" int gda_mmd_fused_fwd_f32(const float* src, int64_t ld_src, const flo
     return GDA_OK;
 }
 
+// ------------------------------------------------------------------ chunked one-pass (gda_mmd_chunked.inc) --
+extern "C" int gda_mmd_chunked_plan(int times, int64_t n, int64_t d, float kernel_mul, int kernel_num, int64_t* out, int n_out) {
+    if (!out) return GDA_E_NULL;
+    if (n_out < 8) return GDA_E_SIZE;
+    ChunkPlan fp;
+    if (!chunk_plan(times, n, d, kernel_mul, kernel_num, &fp)) return GDA_E_UNSUPPORTED;
+    const int64_t v[8] = {fp.nseg, fp.dp, fp.nb, fp.nc, fp.ntiles, fp.njb, fp.total, (int64_t)fp.img};
+    for (int i = 0; i < 8; ++i) out[i] = v[i];
+    return GDA_OK;
+}
+
+#ifdef GDA_MMD_TRACE
+extern "C" int gda_dbg_mmd_trace(unsigned long long* buf) {
+    GDA_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gda_mmd_trace_buf), &buf, sizeof(buf)));
+    return GDA_OK;
+}
+#endif
+
+extern "C" size_t gda_mmd_chunked_workspace_bytes(int times, int64_t n, int64_t d) {
+    ChunkPlan fp;
+    if (!chunk_plan(times, n, d, 2.0f, 5, &fp)) return 0;
+    return chunk_carve(nullptr, times, fp).total;
+}
+
+template <int NB>
+static int launch_chunked(hipStream_t stream, const Rows& Rin, float* rows_src, float* rows_tgt, int64_t ldr, int64_t m, int64_t d,
+                          const ChunkWs& ws, const ChunkPlan& fp, int times, float* bandwidth, float* grad_part, int64_t ldp) {
+    GDA_UNLESS_SKIPPED("k_tile_split") k_tile_split_c<NB><<<dim3((unsigned)fp.ntiles, (unsigned)times), TB, 0, stream>>>(
+        Rin, m, d, fp.nc, ws.part_s1, ws.part_col, ws.part_max, rows_src, rows_tgt, ldr, ws.images);
+    GDA_LAUNCH_CHECK();
+    k_bw_fold<<<dim3((unsigned)gda_cdiv(fp.dp, 64), (unsigned)times), TB, 0, stream>>>(fp.ntiles, fp.dp, ws.part_s1, ws.part_col, ws.part_max, ws.bwstat);
+    GDA_LAUNCH_CHECK();
+    const Rows R = make_rows(rows_src, ldr, rows_tgt, ldr, nullptr, nullptr, Rin.n);          // the padded copy from here on
+    constexpr int D = 32 * NB, PR = 2 * FT * f_rstride(D), PC = 2 * D * F_TSTRIDE;
+    const size_t lds = FC_NBUF * (size_t)(PC > PR ? PC : PR) + sizeof(float) * (FC_NI * 36 + 32 * (TB / 64) + FC_STG * (TB / 64));
+    GDA_LDS_ATTR_ONCE((k_mmd_chunked<NB>), lds);
+    const unsigned grid = 8u * (unsigned)gda_cdiv(fp.total, 8);
+    GDA_UNLESS_SKIPPED("k_mmd_fused") k_mmd_chunked<NB><<<grid, TB, lds, stream>>>(R, m, fp.ntiles, fp.nc, fp.njb, fp.nseg, fp.total, ws.images,
+                                                                                  ws.bwstat, bandwidth, grad_part, ldp, ws.kpartial);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+extern "C" int gda_mmd_chunked_fwd_f32(const float* src, int64_t ld_src, const float* tgt, int64_t ld_tgt,
+                                       int64_t d, const int64_t* src_idx, const int64_t* tgt_idx,
+                                       int times, int64_t n, float kernel_mul, int kernel_num, float fix_sigma,
+                                       float scale, const float* add, float* rows_src, float* rows_tgt, int64_t ld_rows,
+                                       float* loss, float* bandwidth, float* grad_part, int64_t ld_part, int nseg,
+                                       void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    int st = check_common(src, ld_src, tgt, ld_tgt, d, src_idx, tgt_idx, times, n, kernel_num);
+    if (st != GDA_OK) return st;
+    if (!loss || !bandwidth || !grad_part || !workspace || !rows_src || !rows_tgt) return GDA_E_NULL;
+    if (rows_src == src || rows_tgt == tgt || rows_src == rows_tgt) return GDA_E_ALIAS;
+    ChunkPlan fp;
+    if (!chunk_plan(times, n, d, kernel_mul, kernel_num, &fp)) return GDA_E_UNSUPPORTED;
+    if (fix_sigma > 0.f) return GDA_E_UNSUPPORTED;
+    if (nseg != fp.nseg || ld_rows != fp.dp || ld_part != fp.dp) return GDA_E_SIZE;
+    if (((uintptr_t)rows_src | (uintptr_t)rows_tgt | (uintptr_t)grad_part) % 16 != 0) return GDA_E_UNSUPPORTED;
+    Rows R = make_rows(src, ld_src, tgt, ld_tgt, src_idx, tgt_idx, n);
+    ChunkWs ws = chunk_carve(workspace, times, fp);
+    if (workspace_bytes < ws.total) return GDA_E_WORKSPACE;
+    if ((uintptr_t)ws.images % 16 != 0) return GDA_E_UNSUPPORTED;
+    const int64_t m = 2 * n;
+    hipStream_t stream = (hipStream_t)stream_;
+    switch (fp.nb) {
+        case 1: st = launch_chunked<1>(stream, R, rows_src, rows_tgt, ld_rows, m, d, ws, fp, times, bandwidth, grad_part, ld_part); break;
+        case 2: st = launch_chunked<2>(stream, R, rows_src, rows_tgt, ld_rows, m, d, ws, fp, times, bandwidth, grad_part, ld_part); break;
+        case 3: st = launch_chunked<3>(stream, R, rows_src, rows_tgt, ld_rows, m, d, ws, fp, times, bandwidth, grad_part, ld_part); break;
+        default: st = launch_chunked<4>(stream, R, rows_src, rows_tgt, ld_rows, m, d, ws, fp, times, bandwidth, grad_part, ld_part); break;
+    }
+    if (st != GDA_OK) return st;
+    GDA_UNLESS_SKIPPED("k_finalize") k_finalize<<<1, TB, 0, stream>>>(ws.kpartial, fp.njb * fp.nseg, times, n, scale, add, loss);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
 extern "C" int gda_mmd_fused_bwd_mask_f32(const float* grad_part, int nseg, int times, int64_t n, int64_t d,
                                           const float* grad_loss, float scale, float* grad_rows,
                                           const int32_t* sel_s_rowptr, const int32_t* sel_s_col, int64_t n_src_rows, float* gsrc,
                                           const int32_t* sel_t_rowptr, const int32_t* sel_t_col, int64_t n_tgt_rows, float* gtgt,
                                           const float* mask_src, float p_src, const float* mask_tgt, float p_tgt,
                                           gda_stream_t stream_) {
+    return gda_mmd_fused_bwd_ld_f32(grad_part, d, nseg, times, n, d, grad_loss, scale, grad_rows, sel_s_rowptr, sel_s_col,
+                                    n_src_rows, gsrc, sel_t_rowptr, sel_t_col, n_tgt_rows, gtgt, mask_src, p_src, mask_tgt, p_tgt,
+                                    stream_);
+}
+
+// The same with the partials' rows padded to ld_part >= d floats (the chunked one-pass kernel pads every width to whole
+// 32-column blocks: 645 -> 672); the feature-row gradients gsrc / gtgt and grad_rows stay d wide, of any alignment.
+extern "C" int gda_mmd_fused_bwd_ld_f32(const float* grad_part, int64_t ld_part, int nseg, int times, int64_t n, int64_t d,
+                                        const float* grad_loss, float scale, float* grad_rows,
+                                        const int32_t* sel_s_rowptr, const int32_t* sel_s_col, int64_t n_src_rows, float* gsrc,
+                                        const int32_t* sel_t_rowptr, const int32_t* sel_t_col, int64_t n_tgt_rows, float* gtgt,
+                                        const float* mask_src, float p_src, const float* mask_tgt, float p_tgt,
+                                        gda_stream_t stream_) {
+    if (ld_part < d) return GDA_E_SIZE;
     if ((mask_src && !(p_src >= 0.f && p_src < 1.f)) || (mask_tgt && !(p_tgt >= 0.f && p_tgt < 1.f))) return GDA_E_SIZE;
     if ((mask_src || mask_tgt) && !sel_s_rowptr) return GDA_E_UNSUPPORTED;        // masks ride on the scatter only
-    if (((uintptr_t)mask_src | (uintptr_t)mask_tgt) % 16) return GDA_E_UNSUPPORTED;
+    if ((((uintptr_t)mask_src | (uintptr_t)mask_tgt) % 16) && d % 4 == 0) return GDA_E_UNSUPPORTED;
     const float ms_s = mask_src ? 1.f / (1.f - p_src) : 1.f, ms_t = mask_tgt ? 1.f / (1.f - p_tgt) : 1.f;
     if (!grad_part || !grad_loss) return GDA_E_NULL;
     if (times <= 0 || n <= 0 || d <= 0 || nseg < 1 || nseg > F_NSEG_MAX) return GDA_E_SIZE;
@@ -1101,8 +1213,10 @@ extern "C" int gda_mmd_fused_bwd_mask_f32(const float* grad_part, int nseg, int 
         const int64_t most = n_src_rows > n_tgt_rows ? n_src_rows : n_tgt_rows;
         if (most <= 0) return GDA_OK;
         const dim3 sg((unsigned)gda_cdiv(most, TB / 32), 2);
-        const bool quads = d % 4 == 0 && ((uintptr_t)grad_part % 16 == 0) && ((uintptr_t)gsrc % 16 == 0) && ((uintptr_t)gtgt % 16 == 0);
-#define GDA_SCATTER(NS) k_bwd_scatter<NS><<<sg, TB, 0, stream>>>(grad_part, m, d, nseg, sel_s_rowptr, sel_s_col, n_src_rows, gsrc, \
+        // partial quads by 16-byte loads when their rows allow it; the feature-row gradients by 16-byte stores when THEIR rows do
+        const bool vec_out = d % 4 == 0 && ((uintptr_t)gsrc % 16 == 0) && ((uintptr_t)gtgt % 16 == 0);
+        const bool quads = ld_part % 4 == 0 && ((uintptr_t)grad_part % 16 == 0) && (vec_out || ld_part > d);
+#define GDA_SCATTER(NS) k_bwd_scatter<NS><<<sg, TB, 0, stream>>>(grad_part, m, d, ld_part, vec_out, nseg, sel_s_rowptr, sel_s_col, n_src_rows, gsrc, \
                                                               sel_t_rowptr, sel_t_col, n_tgt_rows, gtgt, grad_loss, cmul,    \
                                                               mask_src, ms_s, mask_tgt, ms_t)
         if (!quads) GDA_SCATTER(0);
@@ -1123,7 +1237,8 @@ extern "C" int gda_mmd_fused_bwd_mask_f32(const float* grad_part, int nseg, int 
     const int64_t total = (int64_t)times * m * d;
     int64_t rg = gda_cdiv(total, TB);
     if (rg > 4096) rg = 4096;
-    k_bwd_reduce<<<(unsigned)rg, TB, 0, stream>>>(grad_part, m * d, nseg, times, grad_rows, grad_loss, cmul);
+    if (ld_part == d) k_bwd_reduce<<<(unsigned)rg, TB, 0, stream>>>(grad_part, m * d, nseg, times, grad_rows, grad_loss, cmul);
+    else k_bwd_reduce_ld<<<(unsigned)rg, TB, 0, stream>>>(grad_part, m, d, ld_part, nseg, times, grad_rows, grad_loss, cmul);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }

@@ -770,10 +770,29 @@ MMD_SCATTER_FUSED = _os.environ.get("PYGDA_AMD_MMD_SCATTER", "1") == "1"
 MMD_ONE_PASS = _os.environ.get("PYGDA_AMD_MMD_ONE_PASS", "1") == "1"
 
 
+# the chunked one-pass kernel (csrc/gda_mmd_chunked.inc: any width up to 1024): "auto" = the widths the register-resident
+# kernel does not cover (d > 128 or not a multiple of 32: GRADE's 645), "always" = every width (experiments), "0" = never
+MMD_CHUNKED = _os.environ.get("PYGDA_AMD_MMD_CHUNKED", "auto")
+
+
+def mmd_chunked_plan(times, n, d, kernel_mul=2.0, kernel_num=5):
+    """``(nseg, padded width)`` when the chunked one-pass MMD takes these shapes, else None."""
+    if not MMD_ONE_PASS or MMD_CHUNKED == "0" or not (MMD_CHUNKED == "always" or d > 128 or d % 32):
+        return None
+    import ctypes
+    out = (ctypes.c_int64 * 8)()
+    if _lib.lib().gda_mmd_chunked_plan(int(times), int(n), int(d), float(kernel_mul), int(kernel_num), out, 8) != 0:
+        return None
+    return int(out[0]), int(out[1])
+
+
 def mmd_one_pass_segments(times, n, d, kernel_mul=2.0, kernel_num=5):
     """Row segments of the one-pass MMD for these shapes; 0 when it does not cover them (or is switched off)."""
     if not MMD_ONE_PASS:
         return 0
+    plan = mmd_chunked_plan(times, n, d, kernel_mul, kernel_num)
+    if plan is not None:
+        return plan[0]
     return int(_lib.lib().gda_mmd_fused_nseg(int(times), int(n), int(d), float(kernel_mul), int(kernel_num)))
 
 
@@ -801,7 +820,7 @@ def mmd_one_pass_ok(dev):
     gen = torch.Generator().manual_seed(20240521)
     ok, why = True, ""
     try:
-        for d in (128, 64):
+        for d in (128, 64, 200):                       # 200: the chunked kernel (two chunks of 128 | 96)
             times, n = 2, 80
             a = (torch.randn(times * n, d, generator=gen) * 0.7 + 0.3).to(dev).requires_grad_(True)
             b = (torch.randn(times * n, d, generator=gen) * 0.9 - 0.1).to(dev).requires_grad_(True)
@@ -847,9 +866,12 @@ class _MMD(torch.autograd.Function):
         m = 2 * n
         ctx.feat_rows = (src.size(0), tgt.size(0))
         idx_s = idx_t = rows_s = rows_t = None
+        plan = mmd_chunked_plan(times, n, d, kernel_mul, kernel_num) if not fix_sigma else None
+        if plan is not None and not mmd_one_pass_ok(dev):
+            plan = None
         if src_idx is not None:
             idx_s, idx_t = src_idx.contiguous(), tgt_idx.contiguous()
-            if not (MMD_INDEX_IN_KERNEL and sel is not None):
+            if plan is None and not (MMD_INDEX_IN_KERNEL and sel is not None):
                 # the sampled rows gathered ONCE into [times*n, d] (2 x 2.5 MB at the A2GNN shapes) -- by the
                 # statistics kernel, which reads them through the index anyway; everything after reads the copy
                 rows_s = torch.empty(times * n, d, dtype=torch.float32, device=dev)
@@ -857,14 +879,30 @@ class _MMD(torch.autograd.Function):
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         bw = torch.empty(times, dtype=torch.float32, device=dev)
         L = _lib.lib()
-        ws = _lib.workspace(L.gda_mmd_workspace_bytes(times, n, d), dev, "mmd")
         addc = None if add is None else add.detach().to(torch.float32).reshape(1).contiguous()
         nseg = 0
+        if plan is not None:
+            nseg, dp = plan
+            rows_s = torch.empty(times * n, dp, dtype=torch.float32, device=dev)     # gathered / copied, zero padded
+            rows_t = torch.empty(times * n, dp, dtype=torch.float32, device=dev)
+            part = torch.empty(times, nseg, m, dp, dtype=torch.float32, device=dev)
+            ws = _lib.workspace(L.gda_mmd_chunked_workspace_bytes(times, n, d), dev, "mmd_chunked")
+            with profiler.region("mmd_fwd", 5, 0, times * 3 * 4 * m * m * dp):
+                _lib.check(L.gda_mmd_chunked_fwd_f32(
+                    _lib.ptr(src), d, _lib.ptr(tgt), d, d, _lib.ptr(idx_s), _lib.ptr(idx_t), times, n, float(kernel_mul),
+                    int(kernel_num), 0.0, float(scale), _lib.ptr(addc), _lib.ptr(rows_s), _lib.ptr(rows_t), dp,
+                    _lib.ptr(loss), _lib.ptr(bw), _lib.ptr(part), dp, nseg, _lib.ptr(ws), ws.numel(), _lib.stream()),
+                    "gda_mmd_chunked_fwd_f32")
+            ctx.one_pass, ctx.ldp = nseg, dp
+            ctx.save_for_backward(src_idx, tgt_idx, part)
+            ctx.cfg = (times, n, d, float(kernel_mul), int(kernel_num))
+            return loss.reshape(())
+        ws = _lib.workspace(L.gda_mmd_workspace_bytes(times, n, d), dev, "mmd")
         if (idx_s is None or rows_s is not None) and not fix_sigma:
             nseg = mmd_one_pass_segments(times, n, d, kernel_mul, kernel_num)
             aligned = src.data_ptr() % 16 == 0 and tgt.data_ptr() % 16 == 0
             nseg = nseg if aligned and (not nseg or mmd_one_pass_ok(dev)) else 0
-        ctx.one_pass = nseg
+        ctx.one_pass, ctx.ldp = nseg, d
         if nseg:
             part = torch.empty(times, nseg, m, d, dtype=torch.float32, device=dev)
             with profiler.region("mmd_fwd", 4, 0, times * 3 * 4 * m * m * d):
@@ -957,22 +995,22 @@ def _mmd_backward_one_pass(ctx, gl):
         gs = ks.buf if ks is not None else torch.empty(ctx.feat_rows[0], d, dtype=torch.float32, device=dev)
         gt = kt.buf if kt is not None else torch.empty(ctx.feat_rows[1], d, dtype=torch.float32, device=dev)
         with profiler.region("mmd_bwd", 1, 0, 0):
-            _lib.check(L.gda_mmd_fused_bwd_mask_f32(
-                _lib.ptr(part), ctx.one_pass, times, n, d, _lib.ptr(glc), ctx.scale, None,
+            _lib.check(L.gda_mmd_fused_bwd_ld_f32(
+                _lib.ptr(part), ctx.ldp, ctx.one_pass, times, n, d, _lib.ptr(glc), ctx.scale, None,
                 _lib.ptr(s_rp), _lib.ptr(s_ci), ctx.feat_rows[0], _lib.ptr(gs),
                 _lib.ptr(t_rp), _lib.ptr(t_ci), ctx.feat_rows[1], _lib.ptr(gt),
                 _lib.ptr(ks.y if ks is not None else None), ks.p if ks is not None else 0.0,
                 _lib.ptr(kt.y if kt is not None else None), kt.p if kt is not None else 0.0, _lib.stream()),
-                "gda_mmd_fused_bwd_mask_f32")
+                "gda_mmd_fused_bwd_ld_f32")
         for k in (ks, kt):
             if k is not None:
                 k.written = True
         return (gs if ctx.needs_input_grad[0] else None, gt if ctx.needs_input_grad[1] else None) + tail
     grad_rows = torch.empty(times, m, d, dtype=torch.float32, device=dev)
     with profiler.region("mmd_bwd", 1, 0, 0):
-        _lib.check(L.gda_mmd_fused_bwd_f32(
-            _lib.ptr(part), ctx.one_pass, times, n, d, _lib.ptr(glc), ctx.scale, _lib.ptr(grad_rows),
-            None, None, 0, None, None, None, 0, None, _lib.stream()), "gda_mmd_fused_bwd_f32")
+        _lib.check(L.gda_mmd_fused_bwd_ld_f32(
+            _lib.ptr(part), ctx.ldp, ctx.one_pass, times, n, d, _lib.ptr(glc), ctx.scale, _lib.ptr(grad_rows),
+            None, None, 0, None, None, None, 0, None, None, 0.0, None, 0.0, _lib.stream()), "gda_mmd_fused_bwd_ld_f32")
     if src_idx is None:                       # rows as given, stacked [times, n, d]
         gs, gt = grad_rows[:, :n].reshape(times * n, d), grad_rows[:, n:].reshape(times * n, d)
     elif ctx.sel is not None:

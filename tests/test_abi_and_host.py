@@ -993,6 +993,37 @@ def test_mmd_one_pass_plan_image_layout_and_workspace_carve():
     assert L.gda_mmd_fused_layout(5, 1000, 128, None, 16) == -1              # GDA_E_NULL
 
 
+def test_mmd_chunked_plan_and_workspace():
+    """gda_mmd_chunked_plan (host arithmetic of csrc/gda_mmd_chunked.inc, no device): chunk width and count, the padded
+    width the Python side allocates rows and partials with, segments of at most eight row tiles, an LDS budget that lets
+    two workgroups share a CU, and a workspace that holds every (tile, chunk) image."""
+    from pygda_amd import ops
+    L = _lib.lib()
+    L.gda_mmd_chunked_workspace_bytes.restype = ctypes.c_size_t
+    out = (ctypes.c_int64 * 8)()
+    for times, n, d in ((5, 1000, 645), (5, 1000, 128), (2, 100, 160), (1, 231, 200), (2, 64, 33), (1, 40, 1000),
+                        (1, 1024, 260), (3, 5, 1), (1, 1, 1024)):
+        assert L.gda_mmd_chunked_plan(times, n, d, 2.0, 5, out, 8) == 0, (times, n, d)
+        nseg, dp, nb, nc, ntiles, njb, total, img = list(out)
+        m = 2 * n
+        assert 1 <= nb <= 4 and 1 <= nc <= 8 and dp == 32 * nb * nc and d <= dp < d + 32 * nb
+        assert ntiles == -(-m // 32) and njb == -(-ntiles // 4) and nseg == -(-ntiles // 8) <= 8 and total == times * njb * nseg
+        rows, cols = 2 * 32 * (32 * nb + 8) * 2, 2 * 32 * nb * 80              # the two parts of a tile image (hi | lo each)
+        assert rows % 1024 == 0 and cols % 1024 == 0 and img >= rows + cols + 33 * 4 and img % 1024 == 0
+        lds = 3 * max(rows, cols) + 4 * (8 * 36 + 4 * 32 + 4 * 32 * 32)        # three tile buffers + norms + row sums + result blocks
+        assert 2 * lds <= 160 * 1024                                           # two workgroups per CU
+        assert L.gda_mmd_chunked_workspace_bytes(times, n, d) >= times * ntiles * nc * img + 4 * times * ntiles * dp
+        if d > 128 or d % 32:
+            assert ops.mmd_chunked_plan(times, n, d) == (nseg, dp) and ops.mmd_one_pass_segments(times, n, d) == nseg
+    assert list(out) and L.gda_mmd_chunked_plan(5, 1000, 645, 2.0, 5, out, 8) == 0 and list(out)[:4] == [8, 672, 3, 7]   # GRADE
+    assert L.gda_mmd_chunked_plan(5, 1000, 1025, 2.0, 5, out, 8) == -4           # wider than eight chunks: GDA_E_UNSUPPORTED
+    assert L.gda_mmd_chunked_plan(5, 1025, 128, 2.0, 5, out, 8) == -4            # more than eight segments of eight tiles
+    assert L.gda_mmd_chunked_plan(5, 1000, 128, 3.0, 5, out, 8) == -4 and L.gda_mmd_chunked_plan(5, 1000, 128, 2.0, 4, out, 8) == -4
+    assert L.gda_mmd_chunked_plan(5, 1000, 128, 2.0, 5, out, 4) == -2 and L.gda_mmd_chunked_plan(5, 1000, 128, 2.0, 5, None, 8) == -1
+    assert L.gda_mmd_chunked_workspace_bytes(5, 1000, 1025) == 0
+    assert ops.mmd_chunked_plan(5, 1000, 128) is None and ops.mmd_chunked_plan(5, 2000, 645) is None    # -> register kernel / two passes
+
+
 def test_second_leaves_hold_the_second_pass_gradients_of_the_shared_layers():
     """A2GNNBase.second_leaves: inside the scope the conv layers read weight / bias through second leaves over the same
     storage; after backward ``grad + leaf.grad`` equals what autograd's accumulation stores, the module's parameters are

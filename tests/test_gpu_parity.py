@@ -289,12 +289,21 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("times,n,d,ns,nt", [(5, 1000, 128, 9360, 5484), (1, 96, 128, 0, 0), (3, 77, 64, 500, 400),
-                                             (2, 33, 32, 100, 90), (4, 300, 96, 1000, 1000), (2, 512, 128, -1, -1)])
+                                             (2, 33, 32, 100, 90), (4, 300, 96, 1000, 1000), (2, 512, 128, -1, -1),
+                                             # the chunked kernel (csrc/gda_mmd_chunked.inc): GRADE's width, odd widths, 1..8 chunks
+                                             (5, 1000, 645, 9360, 5484), (2, 100, 160, 300, 250), (1, 231, 200, 0, 0),
+                                             (2, 64, 33, -1, -1), (1, 40, 1000, 90, 80), (1, 1024, 260, 0, 0),
+                                             # ... and at the widths of the register-resident kernel (PYGDA_AMD_MMD_CHUNKED=always)
+                                             (5, 1000, -128, 9360, 5484), (3, 77, -64, 500, 400), (2, 200, -96, -1, -1)])
 def test_mmd_one_pass_beside_the_two_pass_kernels_and_float64(times, n, d, ns, nt, monkeypatch):
     """The one-pass MMD (split-fp16 MFMAs, csrc/gda_mmd_fused.inc) and the two-pass fp32-MFMA kernels against the
     same float64 evaluation: sampled rows with the scatter (ns > 0), get_MMD on the rows as given (0), stacked row
     sets (-1, the data-parallel entry).  Tolerances: 2e-5 on the loss and on every gradient's relative L2 error (the
     trainer-level bar is 1e-4), and the one-pass errors stay within a small factor of the fp32 kernels' own."""
+    if d < 0:
+        d = -d
+        monkeypatch.setattr(ops, "MMD_CHUNKED", "always")
+    assert (ops.mmd_chunked_plan(times, n, d) is not None) == (d > 128 or d % 32 != 0 or ops.MMD_CHUNKED == "always")
     assert ops.mmd_one_pass_segments(times, n, d) > 0
     gen = torch.Generator().manual_seed(1000 * times + n + d)
     if ns > 0:
@@ -322,14 +331,15 @@ def test_mmd_one_pass_beside_the_two_pass_kernels_and_float64(times, n, d, ns, n
         assert a <= 2e-5 and a <= 16 * b + 2e-6, (e1, e2)
 
 
-@pytest.mark.parametrize("scale", [2.0 ** -10, 1.0, 3.0e4, 2.0 ** 40])
-def test_mmd_one_pass_is_insensitive_to_the_scale_of_the_features(scale):
+@pytest.mark.parametrize("scale,d", [(2.0 ** -10, 128), (1.0, 128), (3.0e4, 128), (2.0 ** 40, 128),
+                                     (2.0 ** -10, 645), (3.0e4, 645), (2.0 ** 40, 200)])
+def test_mmd_one_pass_is_insensitive_to_the_scale_of_the_features(scale, d):
     """The split operands live in fp16: one power of two per resample, taken from the largest shifted entry, keeps
     them in its range whatever the features' own scale (tiny, ordinary, beyond fp16's 65504, huge); a far-away
     common offset is removed by the pivot shift before anything is rounded.  Duplicated rows, an outlier row."""
     gen = torch.Generator().manual_seed(11)
-    a = torch.randn(600, 128, generator=gen)
-    b = torch.randn(600, 128, generator=gen) * 1.1 + 0.15
+    a = torch.randn(600, d, generator=gen)
+    b = torch.randn(600, d, generator=gen) * 1.1 + 0.15
     a[7] = a[3]; b[9] = a[3]; a[100] *= 50.0                           # duplicates across and inside the domains, an outlier
     s, t = (a * scale + 1000.0 * scale).to(DEV), (b * scale + 1000.0 * scale).to(DEV)
     got = _mmd_run(s, t)
