@@ -135,6 +135,8 @@ class GraphedStep:
         self.unroll = max(1, int(unroll)) if (type(self) is GraphedStep and not dp) else 1
         self._sub = 0                     # sub-step being issued (selects the sample block)
         self._fills = {}                  # sub-step -> refill callables, in call order
+        self._fill_keys = {}              # sub-step -> the sample blocks' keys, in call order
+        self._groups = {}                 # (ns, nt, times, n) -> the sub-steps' blocks as ONE device / pinned allocation
         self.graph = None
         self.warmup = warmup
         self.loss = self.logits = None
@@ -164,38 +166,63 @@ class GraphedStep:
                       ((times * n,), torch.int32), ((nt + 1,), torch.int32), ((times * n,), torch.int32)]
             total = sum((torch.empty(0, dtype=dt).element_size() * int(torch.tensor(sh).prod()) + 15) // 16 * 16
                         for sh, dt in shapes)
-            dev_block = torch.zeros(total, dtype=torch.uint8, device=dev)
-            pin_blocks = [torch.zeros(total, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            group = None
+            if self.unroll > 1:
+                # The sub-steps of a multi-step capture share ONE device block and one pair of pinned blocks: a replay's
+                # refill is then ONE host-to-device copy, whatever the number of steps in the capture.  With a copy per
+                # sub-step, four or eight asynchronous copies queued up behind the replay in flight, and once per process
+                # hipMemcpyAsync blocked for 5 - 6 ms in one of them (the runtime brings up another copy queue the first
+                # time it finds the one in use busy: tools/replay_series.py, profiles/r6_stall_refill.txt) -- the "one slow
+                # replay early in a graph's life", inside a 20-step timed region as soon as a capture held four steps.
+                total = (total + 255) // 256 * 256
+                group = self._groups.get(key[:4])
+                if group is None:
+                    group = self._groups[key[:4]] = dict(
+                        dev=torch.zeros(self.unroll * total, dtype=torch.uint8, device=dev),
+                        pin=[torch.zeros(self.unroll * total, dtype=torch.uint8).pin_memory() for _ in range(2)],
+                        done=[None, None], turn=0)
+                lo = self._sub * total
+                dev_block = group["dev"][lo:lo + total]
+                pin_blocks = [b[lo:lo + total] for b in group["pin"]]
+            else:
+                dev_block = torch.zeros(total, dtype=torch.uint8, device=dev)
+                pin_blocks = [torch.zeros(total, dtype=torch.uint8).pin_memory() for _ in range(2)]
             ones = torch.ones(times * n, dtype=torch.float32, device=dev)
             self._samples[key] = dict(dev=dev_block, devv=self._carve(dev_block, shapes), pin=pin_blocks,
                                       pinv=[self._carve(b, shapes) for b in pin_blocks],
-                                      done=[None, None], turn=0, ones=ones)
+                                      done=[None, None], turn=0, ones=ones, group=group)
             fill = lambda key=key: self._fill_one(key)      # noqa: E731
             self._order.append(fill)
             self._fills.setdefault(self._sub, []).append(fill)
+            self._fill_keys.setdefault(self._sub, []).append(key)
             self._fill_one(key)
         e = self._samples[key]
         d = e["devv"]
         return d[0], d[1], (d[2], d[3], d[4], d[5], e["ones"])
 
-    def _fill_one(self, key):
+    def _draw_one(self, key, k):
+        """The draws of one MMD call of one (sub-)step into half ``k`` of its pinned block."""
         from .ops import selection_csr_host
         ns, nt, times, n = key[:4]
-        e = self._samples[key]
-        k = e["turn"]
-        e["turn"] = 1 - k
-        if e["done"][k] is not None:
-            e["done"][k].synchronize()                              # the copy that last read this block
-        pins = e["pinv"][k]
+        pins = self._samples[key]["pinv"][k]
         torch.randint(ns, (times, n), out=pins[0])                  # eager MMD()'s draws, same order,
         torch.randint(nt, (times, n), out=pins[1])                  # straight into pinned memory
         _mmd.apply_row_maps(pins[0], pins[1], ns, nt)
         selection_csr_host(pins[0], ns, 0, 2 * n, out=(pins[2], pins[3]))
         selection_csr_host(pins[1], nt, n, 2 * n, out=(pins[4], pins[5]))
+
+    def _fill_one(self, key):
+        e = self._samples[key]
+        st = e["group"] if e.get("group") is not None else e        # whose turn / events: the pinned allocation's owner
+        k = st["turn"]
+        st["turn"] = 1 - k
+        if st["done"][k] is not None:
+            st["done"][k].synchronize()                             # the copy that last read this block
+        self._draw_one(key, k)
         e["dev"].copy_(e["pin"][k], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        e["done"][k] = ev
+        st["done"][k] = ev
 
     def _provider_dp(self, ns, nt, times, per):
         """Data-parallel branch of MMD(): local row samples + the selection CSRs of their scatter."""
@@ -229,10 +256,27 @@ class GraphedStep:
             e.fill()
 
     def _refill_multi(self):
-        """The refills of `unroll` consecutive steps, in step order (the CPU generator's order in eager mode)."""
+        """The refills of `unroll` consecutive steps, in step order (the CPU generator's order in eager mode), shipped as
+        ONE copy per MMD call site."""
+        if not self._groups:
+            for u in range(self.unroll):
+                for fill in self._fills.get(u, ()):
+                    fill()
+            return
+        half = {}
+        for gk, g in self._groups.items():
+            k = half[gk] = g["turn"]
+            g["turn"] = 1 - k
+            if g["done"][k] is not None:
+                g["done"][k].synchronize()
         for u in range(self.unroll):
-            for fill in self._fills.get(u, ()):
-                fill()
+            for key in self._fill_keys.get(u, ()):
+                self._draw_one(key, half[key[:4]])
+        for gk, g in self._groups.items():
+            g["dev"].copy_(g["pin"][half[gk]], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            g["done"][half[gk]] = ev
 
     def _run(self, with_stats=False):
         from .ops import dropout_state

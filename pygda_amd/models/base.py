@@ -371,7 +371,8 @@ class BaseGDA(ABC):
                     # environment variable asks for more explicitly; hooks should consume the numbers they are
                     # handed -- with pipelined epochs the model is always at least one launch ahead of them
                     env_unroll = os.environ.get("PYGDA_AMD_GRAPH_UNROLL")
-                    unroll = int(env_unroll or ("1" if self.epoch_hook is not None else "2")) \
+                    # (four steps per replay since the refill of a multi-step replay is ONE copy: hipgraph.GraphedStep._provider)
+                    unroll = int(env_unroll or ("1" if self.epoch_hook is not None else "4")) \
                         if getattr(self, "_graph_unroll_ok", False) else 1
                     graphed = GraphedStep(scalar_step, optimizer, src, tgt,
                                           extra_optimizers=getattr(self, "_graph_extra_optimizers", ()),

@@ -815,7 +815,7 @@ def test_sparse_projection_hands_the_kstep_kernel_its_own_layout(monkeypatch):
 
 
 # ---------------------------------------------------------------- hipGraph capture --
-@pytest.mark.parametrize("unroll", [1, 2, 3])
+@pytest.mark.parametrize("unroll", [1, 2, 3, 4])
 def test_hipgraph_step_matches_eager_trajectory(monkeypatch, unroll):
     """The captured step (forward + backward + Adam in one hipGraph) replays the same training
     trajectory as eager mode and as the reference: per-epoch losses and final logits against

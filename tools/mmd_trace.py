@@ -2,7 +2,7 @@
 """Where does a workgroup of the chunked one-pass MMD spend its time?  Needs a tracing build of gda_mmd.hip:
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DGDA_MMD_TRACE -shared pygda_amd/csrc/gda_mmd.hip -o <lib.so>
-    python tools/mmd_trace.py <lib.so> [d, default 128]
+    python tools/mmd_trace.py <lib.so> [d, default 128] [resamples, default 5; 1 = at most one workgroup per CU]
 
 Calls gda_mmd_chunked_fwd_f32 at (times 5, 1000 rows per domain, d) a few times and prints, from the per-workgroup clock
 stamps of the last call (s_memtime at the phase boundaries, thread 0 of every workgroup): mean / max cycles of prologue,
@@ -19,7 +19,7 @@ P = ctypes.c_void_p
 def main():
     lib = ctypes.CDLL(sys.argv[1])
     d = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-    times, n = 5, 1000
+    times, n = (int(sys.argv[3]) if len(sys.argv) > 3 else 5), 1000
     dev = torch.device("cuda:0")
     plan = (ctypes.c_int64 * 8)()
     assert lib.gda_mmd_chunked_plan(times, ctypes.c_int64(n), ctypes.c_int64(d), ctypes.c_float(2.0), 5, plan, 8) == 0
