@@ -1347,8 +1347,11 @@ def emit(out, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # 200 timed steps by default (76 ms of cfg-A): a 20-step window is five replays, and what surrounds them -- the first
+    # refill and launch before the device has anything to do, the last read-back -- cost it 0.45 ms, 6 % of the window
+    # (20 steps 0.401 ms/step, the same replays sustained over 1600 steps 0.379: profiles/r6_bench_details.json)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true",
                     help="skip the 5 M-node / 100 M-edge aggregation timed after the cfg-A region (roofline_hbm_regime)")
