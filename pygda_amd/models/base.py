@@ -260,6 +260,40 @@ class BaseGDA(ABC):
             if self.epoch_hook is not None:
                 self.epoch_hook(epoch, epoch_loss, acc, secs)
 
+    def _stacked_pair(self, source_data, target_data):
+        """Two full-batch graphs as ONE block-diagonal batch -- rows ``[source nodes ; target nodes]``, the target's edges
+        shifted by the source's node count -- for trainers that run the SAME network over both domains
+        (pygda/models/grade.py:162-163 and the like): one pass over ``ns + nt`` rows instead of two passes, half the
+        launches each way on a step that is launch-latency bound, one weight-gradient product per layer instead of two
+        and an accumulation.  Per-row results are the two passes' (same neighbours in the same order, the same
+        normalisation, row-wise layers).  Built once per pair of static device graphs (bag-of-words features registered
+        for the sparse projection like any feature matrix entering the device); None when the batches are not such a pair."""
+        import os
+        from ..data import Data
+        s, t = source_data, target_data
+        if (os.environ.get("PYGDA_AMD_STACKED_DOMAINS", "1") != "1" or self.mode != 'node'
+                or getattr(s, "x", None) is None or not s.x.is_cuda or s.x.dim() != 2 or t.x.dim() != 2
+                or s.x.size(1) != t.x.size(1) or s.x.dtype != t.x.dtype
+                or not getattr(s.edge_index, "_gda_static", False) or not getattr(t.edge_index, "_gda_static", False)
+                or getattr(s, "edge_weight", None) is not None or getattr(t, "edge_weight", None) is not None):
+            return None
+        key = (s.x.data_ptr(), t.x.data_ptr(), s.edge_index.data_ptr(), t.edge_index.data_ptr(), s.x._version, t.x._version)
+        hit = self.__dict__.get("_stacked_pair_cache")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        ns = s.x.size(0)
+        with torch.no_grad():
+            x = torch.cat([s.x, t.x])
+            ei = torch.cat([s.edge_index, t.edge_index + ns], dim=1)
+        ei._gda_static = True
+        from .. import sparse_features
+        sparse_features.maybe_register(x)
+        both = Data(x=x, edge_index=ei, y=None)
+        both._static_graph = True
+        both.ns = ns
+        self._stacked_pair_cache = (key, both, s, t)          # (keeps the two batches alive: the key holds their addresses)
+        return both
+
     def _graphed_epochs(self, graphed, epochs, start, alpha_fn=None):
         """Full-batch epochs as hipGraph replays, software-pipelined by one step: the host draws the
         MMD samples of epoch e+1 and launches it while epoch e's two numbers (loss, source accuracy --

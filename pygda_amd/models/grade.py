@@ -29,8 +29,16 @@ class GRADE(BaseGDA):
 
     def forward_model(self, source_data, target_data, alpha):
         net = self.grade
-        source_logits, source_feats = net(source_data)
-        target_logits, target_feats = net(target_data)
+        both = self._stacked_pair(source_data, target_data) if net.training else None
+        if both is not None:
+            # full-batch node mode: the two passes :162-163 over one network as ONE pass over the block-diagonal pair
+            from ..ops import split_rows
+            logits, feats = net(both)
+            source_logits, target_logits = split_rows(logits, both.ns)
+            source_feats, target_feats = split_rows(feats, both.ns)
+        else:
+            source_logits, source_feats = net(source_data)
+            target_logits, target_feats = net(target_data)
         loss = source_ce(source_logits, source_data.y)
         lin = net.discriminator[0]
         domain_loss = 0

@@ -31,8 +31,13 @@ class GRADEBase(nn.Module):
 
     def feat_bottleneck(self, x, edge_index, batch):
         feats = []
+        fused = self.act is F.relu and x.is_cuda and x.dtype == torch.float32
         for conv in self.convs:
-            x = F.dropout(self.act(conv(x, edge_index)), p=self.dropout, training=self.training)
+            if fused:                    # activation + dropout as one kernel each way (no mask tensor)
+                from ..ops import relu_dropout
+                x = relu_dropout(conv(x, edge_index), self.dropout, self.training)
+            else:
+                x = F.dropout(self.act(conv(x, edge_index)), p=self.dropout, training=self.training)
             feats.append(x if self.mode == "node" else global_mean_pool(x, batch))
         if self.mode == "graph":
             x = global_mean_pool(x, batch)

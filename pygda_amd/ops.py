@@ -1643,6 +1643,35 @@ def split_halves(x):
     return _SplitHalves.apply(x)
 
 
+class _SplitRows(torch.autograd.Function):
+    """``x [n, d] -> (x[:k], x[k:])`` (views); backward writes the two gradients into ONE buffer (a missing one as
+    zeros): two copies instead of autograd's fill + copy per slice and the add that joins them."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k, ctx.shape = int(k), tuple(x.shape)
+        ctx.set_materialize_grads(False)
+        return x.narrow(0, 0, ctx.k), x.narrow(0, ctx.k, x.size(0) - ctx.k)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        ref = ga if ga is not None else gb
+        if ref is None:
+            return None, None
+        out = torch.empty(ctx.shape, dtype=ref.dtype, device=ref.device)
+        for part, g in ((out[:ctx.k], ga), (out[ctx.k:], gb)):
+            if g is None:
+                part.zero_()
+            else:
+                part.copy_(g)
+        return out, None
+
+
+def split_rows(x, k):
+    """The first ``k`` rows and the rest of a stacked matrix (a block-diagonal pair of graphs: BaseGDA._stacked_pair)."""
+    return _SplitRows.apply(x, k)
+
+
 class _ReluDropoutSplit(torch.autograd.Function):
     """``split_halves(relu_dropout(x, p))`` for a stacked ``x [2n, d]``: the forward is the ordinary activation kernel,
     the backward masks the two halves' gradients while it stacks them (gda_relu_dropout_bwd2_f32) -- the unmasked
