@@ -157,6 +157,24 @@ class CSRGraph:
         return torch.stack([src[:nnz], dst[:nnz]]), self.val[:nnz]
 
 
+def block_diag(a, b):
+    """Two ingested graphs as ONE block-diagonal :class:`CSRGraph` (rows / columns of ``b`` behind those of ``a``): each
+    row keeps its entries, their order and their values -- whatever normalisation either graph was ingested with --, so an
+    aggregation over the pair is the two aggregations row for row, bit for bit (BaseGDA._stacked_pair: trainers that run
+    one network over both domains; cached operators such as UDAGCN's PPMI graphs are combined, not rebuilt)."""
+    na, nb, ea, eb = a.num_nodes, b.num_nodes, a.nnz, b.nnz
+
+    def join(rp_a, ci_a, v_a, rp_b, ci_b, v_b):
+        return (torch.cat([rp_a[:na + 1], rp_b[1:nb + 1] + ea]),
+                torch.cat([ci_a[:ea], ci_b[:eb] + na]), torch.cat([v_a[:ea], v_b[:eb]]))
+
+    g = CSRGraph(na + nb, ea + eb, *join(a.rowptr, a.colidx, a.val, b.rowptr, b.colidx, b.val),
+                 *join(a.t_rowptr, a.t_colidx, a.t_val, b.t_rowptr, b.t_colidx, b.t_val))
+    g._nnz = ea + eb
+    g.static = a.static and b.static
+    return g
+
+
 def _kstep_plan(g, transposed):
     import ctypes
     L = _lib.lib()

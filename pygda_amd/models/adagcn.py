@@ -117,6 +117,10 @@ class AdaGCN(BaseGDA):
 
     def forward_model(self, source_data, target_data):
         net = self.adagcn
+        both = self._stacked_pair(source_data, target_data) \
+            if (torch.is_grad_enabled() and net.encoder.gnn_type == 'gcn' and getattr(source_data, "n_id", None) is None) else None
+        if both is not None:
+            return self._forward_model_stacked(both, source_data, target_data)
         # the first conv of the encoder (projection + aggregation, nothing random) once per domain and step
         h0_s, h0_t = net.first_conv(source_data), net.first_conv(target_data)
         # The critic loop re-encodes both domains every step (:170-171) with an encoder that does not change inside
@@ -150,6 +154,41 @@ class AdaGCN(BaseGDA):
         cls_loss = self._gmean(self.adagcn.loss_func(source_logits, source_data.y), source_logits.size(0))
         dis_loss = torch.abs(self._critic_gap(encoded_source, encoded_target))
         target_logits = self.adagcn.cls_model(encoded_target)
+        return cls_loss + dis_loss * self.domain_weight, source_logits, target_logits
+
+    def _forward_model_stacked(self, both, source_data, target_data):
+        """forward_model() with every encoder pass over BOTH domains at once (the block-diagonal pair of
+        BaseGDA._stacked_pair): the first conv, the critic loop's `critic_steps` re-encodings (stacked copies of the pair)
+        and the encoder update's pass -- half the encoder launches each way; the critic updates are the same calls on the
+        same rows."""
+        from ..ops import split_rows
+        net, ns = self.adagcn, both.ns
+        h0 = net.first_conv(both)
+        batched = self._batched_encodes(h0, source_data, target_data)
+        if batched:
+            with torch.no_grad():
+                e_all = self._encode_copies(h0.detach(), both)            # [critic_steps, ns + nt, hid]
+        for k in range(self.critic_steps):                                            # :169-183
+            if batched:
+                encoded_source, encoded_target = e_all[k, :ns], e_all[k, ns:]
+            else:
+                with torch.no_grad():
+                    e = net.forward_from(h0.detach(), both)
+                encoded_source, encoded_target = e[:ns], e[ns:]
+            if self._fused_critic(encoded_source):
+                self._critic_update_fused(encoded_source, encoded_target)
+                continue
+            gp_loss = self.gradient_penalty(encoded_source, encoded_target)
+            loss = -torch.abs(self._critic_gap(encoded_source, encoded_target)) + self.gp_weight * gp_loss
+            self.c_optimizer.zero_grad()
+            loss.backward()
+            _allreduce_grads(self.c_optimizer)
+            self.c_optimizer.step()
+        encoded_source, encoded_target = split_rows(net.forward_from(h0, both), ns)  # :186-196
+        source_logits = net.cls_model(encoded_source)
+        cls_loss = self._gmean(net.loss_func(source_logits, source_data.y), source_logits.size(0))
+        dis_loss = torch.abs(self._critic_gap(encoded_source, encoded_target))
+        target_logits = net.cls_model(encoded_target)
         return cls_loss + dis_loss * self.domain_weight, source_logits, target_logits
 
     def _prepare(self, source_data, target_data):

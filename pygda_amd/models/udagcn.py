@@ -78,10 +78,31 @@ class UDAGCN(BaseGDA):
             + gm(net.loss_func(target_domain_preds,
                                torch.ones(target_domain_preds.size(0), dtype=torch.long, device=dev)), nt)
 
+    def _stacked_caches(self):
+        """Every conv layer's cached operator of the block-diagonal (source, target) pair, combined from the two it cached
+        for the domains (the PPMI graphs are NOT rebuilt: their walks were drawn per domain, in the reference's order);
+        False until both exist -- the first step therefore runs the two passes."""
+        from ..graph import block_diag
+        for enc in (self.udagcn.encoder, getattr(self.udagcn, "ppmi_encoder", None)):
+            for conv in (() if enc is None else enc.conv_layers):
+                if "source+target" not in conv.cache_dict:
+                    gs, gt = conv.cache_dict.get("source"), conv.cache_dict.get("target")
+                    if gs is None or gt is None:
+                        return False
+                    conv.cache_dict["source+target"] = block_diag(gs, gt)
+        return True
+
     def forward_model(self, source_data, target_data, alpha, epoch):
         net = self.udagcn
-        encoded_source = net.encode(source_data, self._cache_key(source_data, "source"))
-        encoded_target = net.encode(target_data, self._cache_key(target_data, "target"))
+        both = self._stacked_pair(source_data, target_data) \
+            if (torch.is_grad_enabled() and getattr(source_data, "n_id", None) is None) else None
+        if both is not None and self._stacked_caches():
+            # full-batch node mode: the encoder over both domains as ONE pass over the block-diagonal pair (:165-166)
+            from ..ops import split_rows
+            encoded_source, encoded_target = split_rows(net.encode(both, "source+target"), both.ns)
+        else:
+            encoded_source = net.encode(source_data, self._cache_key(source_data, "source"))
+            encoded_target = net.encode(target_data, self._cache_key(target_data, "target"))
         if self.mode == 'graph':                                                              # :168-170
             encoded_source = global_mean_pool(encoded_source, source_data.batch)
             encoded_target = global_mean_pool(encoded_target, target_data.batch)

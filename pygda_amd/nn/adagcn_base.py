@@ -2,6 +2,7 @@
 ``Dropout(0.1)`` between layers and a linear classifier.  As in the reference, the
 ``dropout`` given to ``AdaGCNBase`` never reaches the stack (:145 builds ``GNN`` without it,
 so the helper's default 0.1 at :39 always applies)."""
+import torch
 import torch.nn.functional as F
 from torch import nn
 
@@ -34,7 +35,11 @@ class GNN(nn.Module):
             if i > 0:
                 x = conv(x, edge_index)
             if i < last:
-                x = self.dropout(self.act(x))
+                if self.act is F.relu and x.is_cuda and x.dtype == torch.float32:
+                    from ..ops import relu_dropout                  # one kernel each way, no mask tensor
+                    x = relu_dropout(x, self.dropout.p, self.dropout.training)
+                else:
+                    x = self.dropout(self.act(x))
         return global_mean_pool(x, batch) if mode == 'graph' else x
 
 

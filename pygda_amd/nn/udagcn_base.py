@@ -6,6 +6,7 @@ Two behaviours of the reference are kept on purpose, because they change its out
 the per-layer ``Dropout(0.1)`` modules live in a plain Python list (:47) -- not registered, so
 never switched to eval and active even in ``predict()`` -- and the constructor's ``dropout``
 argument is ignored."""
+import torch
 import torch.nn.functional as F
 from torch import nn
 
@@ -32,7 +33,12 @@ class GNN(nn.Module):
         for i, conv in enumerate(self.conv_layers):
             x = conv(x, edge_index, cache_name)
             if i < last:
-                x = self.dropout_layers[i](self.act(x))
+                drop = self.dropout_layers[i]
+                if self.act is F.relu and x.is_cuda and x.dtype == torch.float32:
+                    from ..ops import relu_dropout                  # one kernel each way, no mask tensor
+                    x = relu_dropout(x, drop.p, drop.training)
+                else:
+                    x = drop(self.act(x))
         return x
 
 
