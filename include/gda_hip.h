@@ -936,6 +936,14 @@ int gda_csr_square_host(const int32_t* rowptr_host, const int32_t* colidx_host, 
  * Labels are trusted (no ignore_index): the trainers pass dataset labels.
  * ---------------------------------------------------------------------------- */
 size_t gda_softmax_nll_workspace_bytes(void);
+/* Mean entropy of the clamped softmax: loss = mean_i sum_c -q_ic log q_ic, q = clamp(softmax(logits_i), clamp_min, 1) --
+ * UDAGCN's target term (pygda/models/udagcn.py:193-197: softmax, clamp(min=1e-9, max=1.0), -p log p, sum, mean: seven library
+ * launches forward and their autograd twins) as one row kernel + the loss kernels' final fold each way.  The clamp's
+ * gradient is the reference's (passes where clamp_min <= p <= 1).  workspace: gda_softmax_nll_workspace_bytes(). */
+int gda_softmax_entropy_fwd_f32(const float* logits, int64_t ld, int64_t N, int C, float clamp_min, float* loss,
+                                void* workspace, size_t workspace_bytes, gda_stream_t stream);
+int gda_softmax_entropy_bwd_f32(const float* logits, int64_t ld, int64_t N, int C, float clamp_min,
+                                const float* grad_loss, float* grad_logits, int64_t ldg, gda_stream_t stream);
 int gda_softmax_nll_fwd_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t N, int C,
                             float* loss, void* workspace, size_t workspace_bytes, gda_stream_t stream);
 /* _ex: stats (may be NULL) [2] doubles = {loss, number of rows whose argmax (first maximum, as torch.argmax) is the

@@ -101,7 +101,81 @@ k_ce_bwd(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ y
     }
 }
 
+// ---- mean entropy of the clamped softmax (UDAGCN's target term, pygda/models/udagcn.py:193-197) --------------------------
+// p = clamp(softmax(z), lo, 1);  loss = mean_i sum_c -p_ic log p_ic.  One row per thread, the probabilities in registers.
+__device__ __forceinline__ void row_probs(const float* __restrict__ x, int C, float (&p)[MAXC]) {
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) { p[c] = x[c]; mx = fmaxf(mx, p[c]); }
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) { p[c] = expf(p[c] - mx); s += p[c]; }
+    for (int c = 0; c < C; ++c) p[c] = p[c] / s;
+}
+
+__global__ void __launch_bounds__(TB)
+k_entropy_fwd(const float* __restrict__ x, int64_t ldx, int64_t N, int C, float lo, double* __restrict__ partial) {
+    __shared__ double sh[TB];
+    double acc = 0.0;
+    float p[MAXC];
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < N; i += (int64_t)gridDim.x * TB) {
+        row_probs(x + i * ldx, C, p);
+        float e = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float q = fminf(fmaxf(p[c], lo), 1.f);
+            e += -q * logf(q);
+        }
+        acc += (double)e;
+    }
+    const double a = block_sum(sh, acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+
+// d loss / d z_j = p_j (g_j - sum_c g_c p_c) / N,  g_c = -(log q_c + 1) where the clamp passes (lo <= p_c <= 1), else 0
+__global__ void __launch_bounds__(TB)
+k_entropy_bwd(const float* __restrict__ x, int64_t ldx, int64_t N, int C, float lo, const float* __restrict__ grad_loss,
+              float* __restrict__ gx, int64_t ldg) {
+    const float scale = *grad_loss / (float)N;
+    float p[MAXC], g[MAXC];
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < N; i += (int64_t)gridDim.x * TB) {
+        row_probs(x + i * ldx, C, p);
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const bool pass = p[c] >= lo && p[c] <= 1.f;
+            g[c] = pass ? -(logf(p[c]) + 1.f) : 0.f;
+            dot += g[c] * p[c];
+        }
+        for (int c = 0; c < C; ++c) gx[i * ldg + c] = p[c] * (g[c] - dot) * scale;
+    }
+}
+
 }  // namespace
+
+extern "C" int gda_softmax_entropy_fwd_f32(const float* logits, int64_t ld, int64_t N, int C, float clamp_min, float* loss,
+                                           void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    if (N <= 0 || C <= 0 || ld < C || !(clamp_min > 0.f && clamp_min < 1.f)) return GDA_E_SIZE;
+    if (C > MAXC) return GDA_E_UNSUPPORTED;
+    if (!logits || !loss || !workspace) return GDA_E_NULL;
+    if (workspace_bytes < 2 * CE_BLOCKS * sizeof(double)) return GDA_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int blocks = (int)min((int64_t)CE_BLOCKS, gda_cdiv(N, TB));
+    double* partial = static_cast<double*>(workspace);
+    k_entropy_fwd<<<blocks, TB, 0, stream>>>(logits, ld, N, C, clamp_min, partial);
+    GDA_LAUNCH_CHECK();
+    k_ce_final<<<1, TB, 0, stream>>>(partial, blocks, N, loss, nullptr, nullptr);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+extern "C" int gda_softmax_entropy_bwd_f32(const float* logits, int64_t ld, int64_t N, int C, float clamp_min,
+                                           const float* grad_loss, float* grad_logits, int64_t ldg, gda_stream_t stream_) {
+    if (N <= 0 || C <= 0 || ld < C || ldg < C || !(clamp_min > 0.f && clamp_min < 1.f)) return GDA_E_SIZE;
+    if (C > MAXC) return GDA_E_UNSUPPORTED;
+    if (!logits || !grad_loss || !grad_logits) return GDA_E_NULL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int blocks = (int)min((int64_t)1024, gda_cdiv(N, TB));
+    k_entropy_bwd<<<blocks, TB, 0, stream>>>(logits, ld, N, C, clamp_min, grad_loss, grad_logits, ldg);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
 
 extern "C" size_t gda_softmax_nll_workspace_bytes(void) { return 2 * CE_BLOCKS * sizeof(double); }
 

@@ -23,7 +23,8 @@ constexpr int WAVES = TB / 64;
 constexpr int RB = 4;              // rows per wavefront: every W1 word read from LDS feeds RB rows
 constexpr int HC = 2;              // columns per lane (h <= 128)
 constexpr int AMAX = 64;           // hidden width limit (one lane per unit)
-constexpr int MAX_BLOCKS = 128;
+constexpr int MAX_BLOCKS = 512;    // two workgroups per CU (round 6: 128 left half the chip idle -- forward 73 us, backward 130 us
+                                   // at UDAGCN's 16 k rows; the folds below sum their partials on four chains with eight loads in flight)
 
 struct Mlp { const float* W1; const float* b1; const float* W2; const float* b2; int h, a; };
 struct Rows2 { const float* es; int64_t ld_s, n_s; const float* et; int64_t ld_t, n_t; };
@@ -145,14 +146,20 @@ k_mlp_ce_fwd(Mlp M, Rows2 R, Drop dr, double* __restrict__ part) {
 
 __global__ void k_mlp_ce_fwd_final(const double* __restrict__ part, int blocks, int64_t n_s, int64_t n_t,
                                    float* __restrict__ losses) {
-    if (threadIdx.x < 2 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int b = 0; b < blocks; ++b) s += part[(int64_t)threadIdx.x * blocks + b];
-        const int64_t n = threadIdx.x ? n_t : n_s;
-        losses[threadIdx.x] = n > 0 ? (float)(s / (double)n) : 0.f;       // mean over an empty domain: 0 (no rows, no term)
+    // 64 threads: lanes 0-31 fold the source partials, 32-63 the target's -- lane l the blocks l, l + 32, ... in order,
+    // then a fixed shuffle tree over the 32 lanes
+    const int dom = threadIdx.x >> 5, l = threadIdx.x & 31;
+    double s = 0.0;
+    for (int b = l; b < blocks; b += 32) s += part[(int64_t)dom * blocks + b];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
+    __shared__ float both[2];
+    if (l == 0) {
+        const int64_t n = dom ? n_t : n_s;
+        both[dom] = losses[dom] = n > 0 ? (float)(s / (double)n) : 0.f;   // mean over an empty domain: 0 (no rows, no term)
     }
     __syncthreads();
-    if (threadIdx.x == 0 && blockIdx.x == 0) losses[2] = losses[0] + losses[1];   // what udagcn.py:183-190 adds to the loss
+    if (threadIdx.x == 0) losses[2] = both[0] + both[1];                  // what udagcn.py:183-190 adds to the loss
 }
 
 // Per-workgroup partials: pW1 [blocks][a*h], pb1 [blocks][a], pW2 [blocks][2a], pb2 [blocks][2].
@@ -274,18 +281,36 @@ k_mlp_ce_bwd(Mlp M, Rows2 R, Drop dr, const float* __restrict__ grad, int grad_s
 // out[e] = sum over blocks of partial[b][e], blocks in order -- the four partial arrays in ONE launch
 struct Fold4 { const float* part[4]; float* out[4]; int64_t elems[4]; };
 
-__global__ void k_fold4(Fold4 F, int blocks) {
-    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// 256 threads = 64 outputs x 4 chains: chain q adds the blocks q, q + 4, ... in order, eight loads in flight at a time; the
+// four chain sums are combined as (c0 + c1) + (c2 + c3).  (One thread per output adding block after block was a chain of
+// `blocks` dependent loads: 35 us at 128 blocks.)
+__global__ void __launch_bounds__(256) k_fold4(Fold4 F, int blocks) {
+    __shared__ float chain[4][64];
+    const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
+    int64_t e = (int64_t)blockIdx.x * 64 + l;
+    const float* src = nullptr;
+    float* dst = nullptr;
+    int64_t stride = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (e < F.elems[i]) {
-            float s = 0.f;
-            for (int b = 0; b < blocks; ++b) s += F.part[i][(int64_t)b * F.elems[i] + e];
-            F.out[i][e] = s;
-            return;
-        }
-        e -= F.elems[i];
+        if (!src && e < F.elems[i]) { src = F.part[i] + e; dst = F.out[i] + e; stride = F.elems[i]; }
+        if (!src) e -= F.elems[i];
     }
+    float s = 0.f;
+    if (src) {
+        int b = q;
+        for (; b + 28 < blocks; b += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + 4 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < blocks; b += 4) s += src[(int64_t)b * stride];
+    }
+    chain[q][l] = s;
+    __syncthreads();
+    if (q == 0 && dst) *dst = (chain[0][l] + chain[1][l]) + (chain[2][l] + chain[3][l]);
 }
 
 int blocks_for(int64_t n) {
@@ -389,7 +414,7 @@ extern "C" int gda_grl_mlp_ce_bwd_f32(const float* es, int64_t ld_s, int64_t n_s
 #undef GDA_MLP_BWD
     GDA_LAUNCH_CHECK();
     const Fold4 F{{ws.pW1, ws.pb1, ws.pW2, ws.pb2}, {gW1, gb1, gW2, gb2}, {a * h, a, 2 * a, 2}};
-    k_fold4<<<(unsigned)gda_cdiv(a * h + 3 * a + 2, 256), 256, 0, stream>>>(F, nb);
+    k_fold4<<<(unsigned)gda_cdiv(a * h + 3 * a + 2, 64), 256, 0, stream>>>(F, nb);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
@@ -542,7 +567,7 @@ extern "C" int gda_lsgan_head_bwd_f32(const float* Z, int64_t ldz, int64_t rows,
     k_lsgan_bwd<<<nb, TB, 0, stream>>>(Z, ldz, rows, (int)a, w2, pre, target, grad_loss, gZ, ldg, ws.pw2, ws.pb2);
     GDA_LAUNCH_CHECK();
     const Fold4 F{{ws.pw2, ws.pb2, nullptr, nullptr}, {gw2, gb2, nullptr, nullptr}, {a, 1, 0, 0}};
-    k_fold4<<<(unsigned)gda_cdiv(a + 1, 256), 256, 0, stream>>>(F, nb);
+    k_fold4<<<(unsigned)gda_cdiv(a + 1, 64), 256, 0, stream>>>(F, nb);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }

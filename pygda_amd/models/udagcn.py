@@ -109,12 +109,14 @@ class UDAGCN(BaseGDA):
         source_logits = net.cls_model(encoded_source)
         gm = self._gmean
         ns, nt = encoded_source.size(0), encoded_target.size(0)
-        loss = gm(net.loss_func(source_logits, source_data.y), ns)                           # :172
+        from ..ops import softmax_entropy, source_ce
+        ce = source_ce(source_logits, source_data.y) if isinstance(net.loss_func, torch.nn.CrossEntropyLoss) \
+            else net.loss_func(source_logits, source_data.y)          # (the fused loss kernels; same mean over the rows)
+        loss = gm(ce, ns)                                                                    # :172
         dev = encoded_source.device
         loss = loss + self._domain_loss(net, encoded_source, encoded_target, alpha, ns, nt)   # :176-190
         target_logits = net.cls_model(encoded_target)
-        target_probs = torch.clamp(F.softmax(target_logits, dim=-1), min=1e-9, max=1.0)
-        loss_entropy = gm(torch.mean(torch.sum(-target_probs * torch.log(target_probs), dim=-1)), nt)  # :193-197
+        loss_entropy = gm(softmax_entropy(target_logits, 1e-9), nt)                            # :193-197
         return loss + loss_entropy * (epoch / self.epoch * 0.01), source_logits, target_logits
 
     def _prepare(self, source_data, target_data):

@@ -165,6 +165,45 @@ def source_ce(logits, labels):
     return F.nll_loss(F.log_softmax(logits, dim=1), labels)
 
 
+class _SoftmaxEntropy(torch.autograd.Function):
+    """``mean_i sum_c -q log q``, ``q = clamp(softmax(logits_i), lo, 1)`` (gda_softmax_entropy_{fwd,bwd}_f32)."""
+
+    @staticmethod
+    def forward(ctx, logits, lo):
+        x = _f32c(logits, "logits")
+        n, c = x.shape
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        L = _lib.lib()
+        ws = _lib.workspace(L.gda_softmax_nll_workspace_bytes(), x.device, "entropy")
+        _lib.check(L.gda_softmax_entropy_fwd_f32(_lib.ptr(x), c, n, c, float(lo), _lib.ptr(loss), _lib.ptr(ws), ws.numel(),
+                                                 _lib.stream()), "gda_softmax_entropy_fwd_f32")
+        ctx.save_for_backward(x)
+        ctx.lo = float(lo)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        (x,) = ctx.saved_tensors
+        n, c = x.shape
+        gx = torch.empty_like(x)
+        gl = gl.reshape(1).to(torch.float32).contiguous()
+        _lib.check(_lib.lib().gda_softmax_entropy_bwd_f32(_lib.ptr(x), c, n, c, ctx.lo, _lib.ptr(gl), _lib.ptr(gx), c,
+                                                         _lib.stream()), "gda_softmax_entropy_bwd_f32")
+        return gx, None
+
+
+def softmax_entropy(logits, clamp_min=1e-9):
+    """UDAGCN's target entropy term (pygda/models/udagcn.py:193-197): ``p = clamp(softmax(logits, -1), min, 1.0)``,
+    ``mean(sum(-p log p, -1))`` -- one row kernel each way for device logits with up to 64 classes, the reference's
+    composition otherwise."""
+    if (logits.is_cuda and logits.dim() == 2 and 0 < logits.size(1) <= 64 and logits.size(0) > 0
+            and logits.dtype == torch.float32):
+        return _SoftmaxEntropy.apply(logits, clamp_min)
+    import torch.nn.functional as F
+    p = torch.clamp(F.softmax(logits, dim=-1), min=clamp_min, max=1.0)
+    return torch.mean(torch.sum(-p * torch.log(p), dim=-1))
+
+
 # --------------------------------------------------------- tall-skinny GEMMs (MFMA) --
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 

@@ -373,6 +373,51 @@ def test_grl_disc_ce_vs_torch(ns, nt, h, C):
         close(a_.grad, b_.grad, rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("n,c", [(5484, 5), (1, 2), (777, 64), (4096, 3)])
+def test_softmax_entropy_vs_torch(n, c):
+    """UDAGCN's target entropy term (udagcn.py:193-197) as one kernel each way against the reference's composition in
+    float64 -- ordinary rows, rows whose softmax saturates (probabilities below the 1e-9 clamp: no gradient through
+    them, as torch.clamp's backward) and a constant row."""
+    gen = torch.Generator().manual_seed(n + c)
+    z = torch.randn(n, c, generator=gen) * 3.0
+    if n > 10:
+        z[3] = torch.linspace(-60.0, 40.0, c)                      # saturated: clamped entries
+        z[5] = 0.25                                                # uniform
+    ref = z.double().clone().requires_grad_()
+    p = torch.clamp(F.softmax(ref, dim=-1), min=1e-9, max=1.0)
+    want = torch.mean(torch.sum(-p * torch.log(p), dim=-1))
+    (want * 0.37).backward()
+    got_in = z.to(DEV).requires_grad_()
+    got = ops.softmax_entropy(got_in, 1e-9)
+    (got * 0.37).backward()
+    close(got, want.float(), rtol=2e-6)
+    close(got_in.grad, ref.grad.float(), rtol=1e-4, atol=1e-7 / n)
+    assert torch.equal(ops.softmax_entropy(got_in.detach(), 1e-9), got.detach())      # deterministic
+
+
+def test_block_diagonal_pair_of_graphs_aggregates_like_the_two_graphs():
+    """graph.block_diag (BaseGDA._stacked_pair, UDAGCN's combined cached operators): rows, order and values of both
+    ingested graphs are kept, so one aggregation over the pair is the two aggregations, bit for bit, both ways --
+    whatever normalisation the graphs were ingested with (here: source-degree, weighted, as CachedGCNConv / PPMIConv)."""
+    from pygda_amd.graph import block_diag
+    gen = torch.Generator().manual_seed(8)
+    na, nb, d = 700, 333, 64
+    ea = torch.randint(0, na, (2, 5000), generator=gen).to(DEV)
+    eb = torch.randint(0, nb, (2, 2100), generator=gen).to(DEV)
+    wa, wb = torch.rand(5000, generator=gen).to(DEV), torch.rand(2100, generator=gen).to(DEV)
+    ga = build_csr(ea, na, wa, False, True, True, "row")
+    gb = build_csr(eb, nb, wb, False, True, True, "row")
+    g = block_diag(ga, gb)
+    assert g.num_nodes == na + nb and g.nnz == ga.nnz + gb.nnz
+    x = torch.randn(na + nb, d, generator=gen).to(DEV)
+    exact(ops.spmm_kstep(g, x, 1), torch.cat([ops.spmm_kstep(ga, x[:na].contiguous(), 1), ops.spmm_kstep(gb, x[na:].contiguous(), 1)]))
+    exact(ops.spmm_kstep(g, x, 1, transposed=True),
+          torch.cat([ops.spmm_kstep(ga, x[:na].contiguous(), 1, transposed=True),
+                     ops.spmm_kstep(gb, x[na:].contiguous(), 1, transposed=True)]))
+    a, b = ops.split_rows(x.clone().requires_grad_(), na)
+    assert a.shape == (na, d) and b.shape == (nb, d)
+
+
 def test_gather_rows():
     gen = torch.Generator(device=DEV).manual_seed(2)
     for d in (256, 5):
