@@ -51,8 +51,13 @@ class _RandSlot:
         self.dev = torch.zeros(shape, dtype=torch.float32, device=dev)
         self.pin = [torch.zeros(shape, dtype=torch.float32).pin_memory() for _ in range(2)]
         self.done, self.turn = [None, None], 0
+        self.arena = None          # GraphedStep._consolidate_rand: every slot of a step in ONE block, shipped by ONE copy
 
     def fill(self):
+        if self.arena is not None:                       # the draw now, in call order; the copy once, behind the last fill
+            torch.rand(self.shape, out=self.pin[self.arena["half"]])
+            self.arena["dirty"] = True
+            return
         k = self.turn
         self.turn = 1 - k
         if self.done[k] is not None:
@@ -246,12 +251,47 @@ class GraphedStep:
             raise RuntimeError("host_rand call sequence changed between steps: the step cannot be replayed")
         return slot.dev
 
+    def _consolidate_rand(self):
+        """Every ``host_rand`` slot of the step as a view of ONE device block and one pair of pinned blocks (after the first
+        warm-up run has met them all): a refill is then one host-to-device copy instead of one per call site.  AdaGCN
+        draws interpolation weights at ten call sites per step; their ten copies queued in front of every replay cost
+        ~320 us of the device's time per epoch (profiles/r6_experiments.txt, 8)."""
+        slots = self._rand_slots
+        if len(slots) < 2 or getattr(self, "_rand_arena", None) is not None:
+            return
+        offs, total = [], 0
+        for sl in slots:
+            offs.append(total)
+            total += (sl.dev.numel() + 3) // 4 * 4
+        dev = slots[0].dev.device
+        arena = dict(dev=torch.zeros(total, dtype=torch.float32, device=dev),
+                     pin=[torch.zeros(total, dtype=torch.float32).pin_memory() for _ in range(2)],
+                     done=[None, None], turn=0, half=0, dirty=False)
+        for sl, o in zip(slots, offs):
+            n = sl.dev.numel()
+            sl.dev = arena["dev"][o:o + n].view(sl.shape)
+            sl.pin = [p[o:o + n].view(sl.shape) for p in arena["pin"]]
+            sl.arena = arena
+        self._rand_arena = arena
+
     def _refill(self):
         """The refills of ONE step: sub-step 0's sample blocks, every host_rand slot, the data-parallel blocks."""
         later = {id(f) for u, fs in self._fills.items() if u > 0 for f in fs}
+        arena = getattr(self, "_rand_arena", None)
+        if arena is not None:
+            k = arena["half"] = arena["turn"]
+            arena["turn"] = 1 - k
+            if arena["done"][k] is not None:
+                arena["done"][k].synchronize()
+            arena["dirty"] = False
         for fill in self._order:
             if id(fill) not in later:
                 fill()
+        if arena is not None and arena["dirty"]:
+            arena["dev"].copy_(arena["pin"][arena["half"]], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            arena["done"][arena["half"]] = ev
         for e in self._dp_idx.values():
             e.fill()
 
@@ -365,9 +405,11 @@ class GraphedStep:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _ in range(self.warmup):       # allocator warm-up + first sample buffers
+                for i in range(self.warmup):       # allocator warm-up + first sample buffers
                     self._refill()
                     self._run()
+                    if i == 0:
+                        self._consolidate_rand()
                 if self.unroll > 1 and (self._rand_slots or self.extra_optimizers or not self._fills):
                     self.unroll = 1                # host_rand call sites / critics: one step per capture
                 for u in range(1, self.unroll):    # the further sub-steps' sample blocks are created (and filled) eagerly

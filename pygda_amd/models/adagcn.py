@@ -151,10 +151,18 @@ class AdaGCN(BaseGDA):
         encoded_source = net.forward_from(h0_s, source_data)                          # :186-196
         encoded_target = net.forward_from(h0_t, target_data)
         source_logits = self.adagcn.cls_model(encoded_source)
-        cls_loss = self._gmean(self.adagcn.loss_func(source_logits, source_data.y), source_logits.size(0))
+        cls_loss = self._gmean(self._source_loss(source_logits, source_data.y), source_logits.size(0))
         dis_loss = torch.abs(self._critic_gap(encoded_source, encoded_target))
         target_logits = self.adagcn.cls_model(encoded_target)
         return cls_loss + dis_loss * self.domain_weight, source_logits, target_logits
+
+    def _source_loss(self, logits, labels):
+        """``loss_func(source_logits, y)`` (adagcn.py:189) -- the fused loss kernels for the CrossEntropyLoss the trainer builds."""
+        lf = self.adagcn.loss_func
+        if isinstance(lf, nn.CrossEntropyLoss):
+            from ..ops import source_ce
+            return source_ce(logits, labels)
+        return lf(logits, labels)
 
     def _forward_model_stacked(self, both, source_data, target_data):
         """forward_model() with every encoder pass over BOTH domains at once (the block-diagonal pair of
@@ -186,7 +194,7 @@ class AdaGCN(BaseGDA):
             self.c_optimizer.step()
         encoded_source, encoded_target = split_rows(net.forward_from(h0, both), ns)  # :186-196
         source_logits = net.cls_model(encoded_source)
-        cls_loss = self._gmean(net.loss_func(source_logits, source_data.y), source_logits.size(0))
+        cls_loss = self._gmean(self._source_loss(source_logits, source_data.y), source_logits.size(0))
         dis_loss = torch.abs(self._critic_gap(encoded_source, encoded_target))
         target_logits = net.cls_model(encoded_target)
         return cls_loss + dis_loss * self.domain_weight, source_logits, target_logits
