@@ -1203,12 +1203,19 @@ def other_configs(dev, epochs=30, which=("grade_mmd", "grade_js", "udagcn", "ada
                 r = prof[dom]
                 secs = r["ms"] * 1e-3
                 hbm = dom.startswith("spmm") or dom.startswith("kstep") or dom.startswith("sparse")
+                from pygda_amd import ops as _ops
+                # the one-pass MMD kernels execute split-fp16 MFMAs (three products per pair: the flops the region counts)
+                f16 = dom.startswith("mmd") and _ops.MMD_ONE_PASS
                 res["dominant_kernel"] = {
-                    "kernel": dom, "ms_per_epoch": r["ms"] / n_ep, "launches_per_epoch": r["launches"] / n_ep,
+                    "kernel": dom + (" [tile split + one-pass pair kernel + finalize, split-fp16 MFMAs]" if f16 else ""),
+                    "ms_per_epoch": r["ms"] / n_ep, "launches_per_epoch": r["launches"] / n_ep,
                     "bound": "hbm" if hbm else "mfma",
-                    "frac": (r["bytes"] / secs / 1e9 / HBM_PEAK_GBS) if hbm else (r["flops"] / secs / 1e12 / FP32_MFMA_PEAK_TF),
+                    "frac": (r["bytes"] / secs / 1e9 / HBM_PEAK_GBS) if hbm
+                    else (r["flops"] / secs / 1e12 / (F16_MFMA_PEAK_TF if f16 else FP32_MFMA_PEAK_TF)),
                     "frac_is": ("SURVEY 8(d) algorithmic bytes over the HIP-event duration over 8 TB/s (cache-resident at this "
-                                "size: an accounting figure)" if hbm else "flops over the HIP-event duration over the fp32 MFMA peak"),
+                                "size: an accounting figure)" if hbm else
+                                "executed fp16 MFMA flops over the HIP-event duration of the whole call over the fp16 MFMA peak" if f16
+                                else "flops over the HIP-event duration over the fp32 MFMA peak"),
                     "timing": "HIP events around the family's launches, eager epochs"}
                 res["kernel_time_ms_per_epoch"] = {k: v["ms"] / n_ep for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:6]}
             out[name] = res
