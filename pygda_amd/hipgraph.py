@@ -124,11 +124,19 @@ BUMP_AT_START = __import__("os").environ.get("PYGDA_AMD_BUMP_AT_START", "1") == 
 class GraphedStep:
     """Captures ``loss, logits = step_fn(src, tgt)``, ``backward`` and ``optimizer.step()``."""
 
-    def __init__(self, step_fn, optimizer, src, tgt, warmup=3, dp=False, extra_optimizers=(), unroll=1):
+    def __init__(self, step_fn, optimizer, src, tgt, warmup=3, dp=False, extra_optimizers=(), unroll=1,
+                 inline_stats=False):
         """``dp``: data-parallel step with the library-owned RCCL communicator -- the gradient
         all-reduce and the MMD row all-gather are enqueued on the capturing stream like any kernel,
         so the whole step is still ONE graph."""
         self.step_fn, self.optimizer, self.src, self.tgt, self.dp = step_fn, optimizer, src, tgt, dp
+        # A capture that never forks replays through pre-built packets (~0.4 us between dependent kernels, a launch call of
+        # ~0.3 us per node); ONE fork anywhere makes the runtime enqueue the graph node by node (3 us of host time and 5 - 6
+        # us of device spacing per kernel: profiles/HISTORY.md 4.7).  A trainer whose step is one chain of kernels (GRADE,
+        # UDAGCN, AdaGCN, ...: everything but A2GNN's three-branch step) therefore takes its two log numbers on the main
+        # stream instead of on the statistics side branch -- two tiny kernels in line against every kernel of the step
+        # paying for the fork.  AdaGCN's launch call took 2.6 ms for a 2.6 ms replay: the host never got ahead.
+        self.inline_stats = bool(inline_stats)
         self.extra_optimizers = list(extra_optimizers)    # stepped INSIDE step_fn (critics): rolled back too
         self._rand_slots, self._rand_cursor = [], 0
         self._dp_idx = {}                 # (ns, nt, times, per) -> (dev_s, dev_t, pin_s, pin_t)
@@ -346,8 +354,9 @@ class GraphedStep:
             # per-epoch numbers of the reference's loop (loss, source micro-F1 = accuracy): two doubles
             # produced inside the graph, on a side branch that runs beside the backward pass
             main = torch.cuda.current_stream()
-            side = self._stat_stream
-            side.wait_stream(main)
+            side = main if self.inline_stats else self._stat_stream
+            if side is not main:
+                side.wait_stream(main)
             with torch.cuda.stream(side):
                 from .ops import ce_stats_for
                 if terms is not None:                             # the reported total: same fp32 sum as `a + b` in eager mode
@@ -361,8 +370,9 @@ class GraphedStep:
                 else:
                     correct = (logits.detach().argmax(dim=1) == self.src.y).sum()
                     self.stats = torch.stack([loss.detach().double(), correct.double()])
-            for t in (loss, logits):
-                t.record_stream(side)
+            if side is not main:
+                for t in (loss, logits):
+                    t.record_stream(side)
         self.optimizer.zero_grad(set_to_none=True)
         if terms is not None:
             # every term that still has a history is seeded with 1; a term whose backward the trainer has issued already
@@ -383,7 +393,7 @@ class GraphedStep:
             from .distributed import allreduce_grads
             allreduce_grads(p for g in self.optimizer.param_groups for p in g["params"])
         self.optimizer.step()
-        if with_stats:
+        if with_stats and side is not main:
             main.wait_stream(side)
             self.stats.record_stream(main)
         return loss, logits
@@ -588,12 +598,13 @@ class GraphedStepSplit(GraphedStep):
                 else:
                     correct = (logits.detach().argmax(dim=1) == self.src.y).sum()
                     self.stats = torch.stack([loss.detach().double(), correct.double()])
-            for t in (loss, logits):
-                t.record_stream(side)
+            if side is not main:
+                for t in (loss, logits):
+                    t.record_stream(side)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self.optimizer.step()
-        if with_stats:
+        if with_stats and side is not main:
             main.wait_stream(side)
             self.stats.record_stream(main)
         return loss, logits

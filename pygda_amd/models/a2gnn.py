@@ -293,6 +293,7 @@ class A2GNN(BaseGDA):
         self._graph_safe_step, self._graph_uses_scalars = self.mode == 'node', bool(self.adv)
         # the MMD step reads no per-epoch scalar: consecutive steps may share one capture (hipgraph.GraphedStep.unroll)
         self._graph_unroll_ok = not self.adv and type(self) is A2GNN
+        self._graph_forks = self.overlap_streams          # three parallel branches: the statistics ride on a fourth
         on_gpu = torch.device(self.device).type == "cuda"
         self._grad_aliases = None
         if on_gpu:           # torch.optim.Adam's update in one multi-tensor launch (pygda_amd/optim.py)

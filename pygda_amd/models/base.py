@@ -410,7 +410,9 @@ class BaseGDA(ABC):
                         if getattr(self, "_graph_unroll_ok", False) else 1
                     graphed = GraphedStep(scalar_step, optimizer, src, tgt,
                                           extra_optimizers=getattr(self, "_graph_extra_optimizers", ()),
-                                          unroll=unroll).capture()
+                                          unroll=unroll,
+                                          inline_stats=not getattr(self, "_graph_forks", False)
+                                          and os.environ.get("PYGDA_AMD_INLINE_STATS", "1") == "1").capture()
         except Exception as exc:       # anything a custom activation / exotic configuration may do under capture
             if self.use_hip_graph:     # explicitly requested: do not hide the failure
                 raise
