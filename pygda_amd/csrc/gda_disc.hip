@@ -79,13 +79,15 @@ k_fwd(Feat F, int h, int C, const float* __restrict__ W, const float* __restrict
     if (threadIdx.x == 0) { double s = 0.0; for (int w = 0; w < WAVES; ++w) s += red[w]; partial[blockIdx.x] = s; }
 }
 
+// 64 threads: lane l adds the partials l, l + 64, ... in order, then a fixed shuffle tree (one thread adding block after
+// block was a chain of nblocks dependent loads: 27 us at GRADE's 14 k rows)
 __global__ void k_fwd_finalize(const double* __restrict__ partial, int nblocks, int64_t n,
                                float* __restrict__ loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int k = 0; k < nblocks; ++k) s += partial[k];
-        loss[0] = (float)(s / (double)n);
-    }
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nblocks; k += 64) s += partial[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (threadIdx.x == 0) loss[0] = (float)(s / (double)n);
 }
 
 template <int CPL>
@@ -146,19 +148,35 @@ k_bwd(Feat F, int h, int C, const float* __restrict__ W, const int64_t* __restri
     }
 }
 
-__global__ void k_bwd_finalize(const float* __restrict__ gw_partial, const float* __restrict__ gb_partial,
-                               int nblocks, int h, int C, float* __restrict__ gW, float* __restrict__ gb) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < C * h) {
-        float s = 0.f;
-        for (int b = 0; b < nblocks; ++b) s += gw_partial[(int64_t)b * C * h + k];
-        gW[k] = s;
+// 256 threads = 64 outputs x 4 chains: chain q adds the blocks q, q + 4, ... in order with eight loads in flight, the four
+// chain sums are combined as (c0 + c1) + (c2 + c3).  Outputs: the C h weight gradients, then (gb given) the C bias
+// gradients.  (One thread per output adding block after block: 164 us at GRADE's shapes.)
+__global__ void __launch_bounds__(256)
+k_bwd_finalize(const float* __restrict__ gw_partial, const float* __restrict__ gb_partial,
+               int nblocks, int h, int C, float* __restrict__ gW, float* __restrict__ gb) {
+    __shared__ float chain[4][64];
+    const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int k = blockIdx.x * 64 + l;
+    const float* src = nullptr;
+    float* dst = nullptr;
+    int64_t stride = 0;
+    if (k < C * h) { src = gw_partial + k; dst = gW + k; stride = (int64_t)C * h; }
+    else if (gb && k - C * h < C) { src = gb_partial + (k - C * h); dst = gb + (k - C * h); stride = MAXC; }
+    float s = 0.f;
+    if (src) {
+        int b = q;
+        for (; b + 28 < nblocks; b += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + 4 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nblocks; b += 4) s += src[(int64_t)b * stride];
     }
-    if (k < C && gb) {
-        float s = 0.f;
-        for (int b = 0; b < nblocks; ++b) s += gb_partial[b * MAXC + k];
-        gb[k] = s;
-    }
+    chain[q][l] = s;
+    __syncthreads();
+    if (q == 0 && dst) *dst = (chain[0][l] + chain[1][l]) + (chain[2][l] + chain[3][l]);
 }
 
 int nblocks_for(int64_t n) {
@@ -255,7 +273,7 @@ extern "C" int gda_grl_disc_ce_bwd_f32(const float* feat_src, int64_t ld_src, in
     CPL_SWITCH(h, CALL);
 #undef CALL
     GDA_LAUNCH_CHECK();
-    k_bwd_finalize<<<(unsigned)gda_cdiv(C * h, 256), 256, 0, stream>>>(ws.gw_partial, ws.gb_partial, nb,
+    k_bwd_finalize<<<(unsigned)gda_cdiv(C * h + C, 64), 256, 0, stream>>>(ws.gw_partial, ws.gb_partial, nb,
                                                                         (int)h, C, gW, gb);
     GDA_LAUNCH_CHECK();
     return GDA_OK;

@@ -460,11 +460,11 @@ k_lsgan_fwd(const float* __restrict__ Z, int64_t ldz, int64_t rows, int a, const
 }
 
 __global__ void k_lsgan_fwd_final(const double* __restrict__ part, int blocks, int64_t rows, float* __restrict__ loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int b = 0; b < blocks; ++b) s += part[b];
-        loss[0] = (float)(s / (double)rows);
-    }
+    double s = 0.0;                                       // 64 threads: lane l the blocks l, l + 64, ..., then a fixed tree
+    for (int b = threadIdx.x; b < blocks; b += 64) s += part[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (threadIdx.x == 0) loss[0] = (float)(s / (double)rows);
 }
 
 // pw2 [blocks][a], pb2 [blocks]
