@@ -661,10 +661,15 @@ k_skinny_wgrad(const float* __restrict__ GY, int64_t ldg, const float* __restric
 
 bool vec_ok(const float* p, int64_t ld) { return ld % 4 == 0 && ((uintptr_t)p & 15) == 0; }
 
+// Row slabs of a split-K product: 128 rows each, at most 256 (round 6; 256 rows / at most 64 before: a workgroup then walks
+// 8 - 15 chunks of 32 rows one after the other -- AdaGCN's two critic products of 16 k / 31 k rows took 17 / 31 us ten times per
+// step: 2.42 -> 2.32 ms/epoch with shorter slabs, cfg-A 0.370 -> 0.367; 64-row slabs cost cfg-A 4 %)
 int slabs_for(int64_t K) {
-    int64_t s = gda_cdiv(K, 256);
+    static const int per = [] { const char* e = std::getenv("PYGDA_AMD_GEMM_SLAB_ROWS"); const int v = e ? std::atoi(e) : 0; return v >= 32 ? v : 128; }();
+    static const int cap = [] { const char* e = std::getenv("PYGDA_AMD_GEMM_SLABS_MAX"); const int v = e ? std::atoi(e) : 0; return v >= 1 ? v : 256; }();
+    int64_t s = gda_cdiv(K, per);
     if (s < 1) s = 1;
-    if (s > 64) s = 64;
+    if (s > cap) s = cap;
     return (int)s;
 }
 
