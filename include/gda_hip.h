@@ -654,6 +654,12 @@ int gda_dsampler_sample(const int64_t* in_ptr, const int32_t* in_src, int64_t N,
                         int32_t* t_rowptr, int32_t* t_colidx, float* t_val,
                         int64_t* counts, void* workspace, size_t workspace_bytes, gda_stream_t stream);
 
+/* Host-to-device copy of a PINNED host block (hipHostMalloc / hipHostRegister, 16-byte aligned both sides) as a kernel on
+ * `stream` that reads the host memory over the bus: for the 0.1 - 1 MB blocks a captured step is fed with per replay (MMD row
+ * samples, interpolation weights), where a DMA-engine copy queued behind a running graph idles the device for the engine
+ * hand-over.  GDA_E_UNSUPPORTED when the block is not device-mapped or misaligned (callers fall back to hipMemcpyAsync). */
+int gda_copy_from_pinned(void* dst, const void* src_host, size_t bytes, gda_stream_t stream);
+
 /* One foreign call per batch for a loader that RECYCLES its batch blocks (round 5; pygda_amd/sampler.py, the producer
  * thread of pygda_amd/data.py's NeighborLoader -- the reference's NeighborLoader workers, pygda/models/a2gnn.py:260-277):
  *   [stream waits for wait_event] -> seeds (host OR device, int64 [n_seeds]) copied to seeds_dev -> gda_dsampler_sample

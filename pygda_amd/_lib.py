@@ -65,6 +65,7 @@ _SIGNATURES = {
                                       _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P]),
     "gda_mmd_fused_bwd_mask_f32": (c_int, [_P, c_int, c_int, c_int64, c_int64, _P, c_float, _P,
                                            _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, c_float, _P, c_float, _P]),
+    "gda_copy_from_pinned": (c_int, [_P, _P, c_size_t, _P]),
     "gda_softmax_entropy_fwd_f32": (c_int, [_P, c_int64, c_int64, c_int, c_float, _P, _P, c_size_t, _P]),
     "gda_softmax_entropy_bwd_f32": (c_int, [_P, c_int64, c_int64, c_int, c_float, _P, _P, c_int64, _P]),
     "gda_mmd_chunked_plan": (c_int, [c_int, c_int64, c_int64, c_float, c_int, _P, c_int]),

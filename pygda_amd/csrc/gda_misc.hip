@@ -55,7 +55,40 @@ k_segment_mean_bwd(const float* __restrict__ gout, int64_t ldg, const int64_t* _
     gx[i * ldx + c] = __fdiv_rn(gout[g * ldg + c], (float)(m > 1 ? m : 1));
 }
 
+// dst[i] = src[i] for n 16-byte pieces + tail bytes: a copy whose SOURCE may be pinned host memory read over the bus
+__global__ void __launch_bounds__(TB)
+k_copy_pieces(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t pieces, const unsigned char* __restrict__ tail_src,
+              unsigned char* __restrict__ tail_dst, int tail) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < pieces; i += (int64_t)gridDim.x * TB) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) tail_dst[threadIdx.x] = tail_src[threadIdx.x];
+}
+
 }  // namespace
+
+// Host-to-device copy of a PINNED (hipHostMalloc / hipHostRegister) block as a KERNEL on `stream` that reads the host
+// memory over the bus -- for the small per-step blocks a captured training step is fed with (row samples, interpolation
+// weights: 0.1 - 1 MB).  hipMemcpyAsync hands such a copy to a DMA engine; behind a running graph the hand-over from the
+// compute queue to the engine and back costs 200 - 370 us of idle device time per replay (profiles/r6_experiments.txt, 10),
+// a kernel in the stream costs its own 20 - 30 us.  GDA_E_UNSUPPORTED when the host block is not device-mapped.
+extern "C" int gda_copy_from_pinned(void* dst, const void* src_host, size_t bytes, gda_stream_t stream) {
+    if (bytes == 0) return GDA_OK;
+    if (!dst || !src_host) return GDA_E_NULL;
+    void* dsrc = nullptr;
+    if (hipHostGetDevicePointer(&dsrc, const_cast<void*>(src_host), 0) != hipSuccess || !dsrc) {
+        (void)hipGetLastError();
+        return GDA_E_UNSUPPORTED;
+    }
+    if (((uintptr_t)dst | (uintptr_t)dsrc) % 16 != 0) return GDA_E_UNSUPPORTED;
+    const int64_t pieces = (int64_t)(bytes / 16);
+    const int tail = (int)(bytes % 16);
+    int64_t blocks = gda_cdiv(pieces > 0 ? pieces : 1, TB);
+    if (blocks > 1024) blocks = 1024;
+    k_copy_pieces<<<(unsigned)blocks, TB, 0, (hipStream_t)stream>>>(
+        static_cast<const uint4*>(dsrc), static_cast<uint4*>(dst), pieces,
+        static_cast<const unsigned char*>(dsrc) + pieces * 16, static_cast<unsigned char*>(dst) + pieces * 16, tail);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
 
 extern "C" int gda_abi_version(void) { return 1; }
 

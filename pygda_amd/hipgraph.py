@@ -13,6 +13,8 @@ seeded run still samples the same rows).  Dropout masks come from torch's graph-
 state.  Steps whose arithmetic depends on a per-epoch Python scalar (the GRL alpha of the
 adversarial branch) are not captured.
 """
+import ctypes
+
 import torch
 
 from .utils import mmd as _mmd
@@ -43,6 +45,21 @@ def _mem_flat(g, p):
 def _mem_view(flat, p):
     """The inverse: a view of ``flat`` with the shape AND strides of ``p``."""
     return flat.view(p.size(1), p.size(0)).t() if _col_major(p) else flat.view_as(p)
+
+
+H2D_KERNEL = __import__("os").environ.get("PYGDA_AMD_H2D_KERNEL", "1") == "1"
+
+
+def _ship(dst, pinned):
+    """``dst.copy_(pinned, non_blocking=True)`` for a small pinned block in front of a replay -- as a kernel of the current
+    stream that reads the pinned memory itself (gda_copy_from_pinned) when it can, else the runtime's asynchronous copy."""
+    if H2D_KERNEL and dst.is_cuda and dst.is_contiguous() and pinned.is_contiguous():
+        from . import _lib
+        nbytes = dst.numel() * dst.element_size()
+        if nbytes == pinned.numel() * pinned.element_size() and \
+                _lib.lib().gda_copy_from_pinned(_lib.ptr(dst), ctypes.c_void_p(pinned.data_ptr()), nbytes, _lib.stream()) == 0:
+            return
+    dst.copy_(pinned, non_blocking=True)
 
 
 class _RandSlot:
@@ -232,7 +249,7 @@ class GraphedStep:
         if st["done"][k] is not None:
             st["done"][k].synchronize()                             # the copy that last read this block
         self._draw_one(key, k)
-        e["dev"].copy_(e["pin"][k], non_blocking=True)
+        _ship(e["dev"], e["pin"][k])
         ev = torch.cuda.Event()
         ev.record()
         st["done"][k] = ev
@@ -296,7 +313,7 @@ class GraphedStep:
             if id(fill) not in later:
                 fill()
         if arena is not None and arena["dirty"]:
-            arena["dev"].copy_(arena["pin"][arena["half"]], non_blocking=True)
+            _ship(arena["dev"], arena["pin"][arena["half"]])
             ev = torch.cuda.Event()
             ev.record()
             arena["done"][arena["half"]] = ev
@@ -321,7 +338,7 @@ class GraphedStep:
             for key in self._fill_keys.get(u, ()):
                 self._draw_one(key, half[key[:4]])
         for gk, g in self._groups.items():
-            g["dev"].copy_(g["pin"][half[gk]], non_blocking=True)
+            _ship(g["dev"], g["pin"][half[gk]])
             ev = torch.cuda.Event()
             ev.record()
             g["done"][half[gk]] = ev
