@@ -455,7 +455,7 @@ def test_captured_sampled_step_equals_the_eager_static_step_bit_for_bit(monkeypa
     shapes, same draws, dropout on: per-epoch loss and accuracy and every parameter after 2 x 6 steps, bit for bit.  Then
     against the ordinary eager loop on the batches' real shapes, dropout off (the keep-bits of the stacked source rows are
     keyed on the element index, which moves with the row count; everything else differs by the row counts in the
-    reductions: fp32 summation order) -- losses to 1e-5 relative, parameters to 3e-4."""
+    reductions: fp32 summation order) -- losses to 1e-5 relative, parameters to 5e-4."""
     mc, seen_c, par_c = _sampled_fit(monkeypatch, {"PYGDA_AMD_SAMPLED_GRAPH": "1", "PYGDA_AMD_SAMPLED_GRAPH_CAPTURE": "1"})
     st = mc._sampled_graphed[1]
     assert st.graph is not None and st.replays == 12 and st.fallbacks == 0, (st.replays, st.fallbacks)
@@ -475,9 +475,9 @@ def test_captured_sampled_step_equals_the_eager_static_step_bit_for_bit(monkeypa
     np.testing.assert_allclose([v[1] for v in seen_c], [v[1] for v in seen_r], atol=2e-5)      # one row in 80 k may flip
     for k in par_c:
         scale = float(par_r[k].abs().max()) + 1e-12
-        # (3e-4: a bias that twelve Adam steps moved by 2e-2 in all -- its gradient is a column sum over 128-row slabs whose
+        # (5e-4: a bias that twelve Adam steps moved by 2e-2 in all -- its gradient is a column sum over 128-row slabs whose
         # boundaries move with the row count, and Adam turns a 1e-7 difference in a tiny gradient into 1e-5 of a step)
-        np.testing.assert_allclose(par_c[k].cpu().numpy(), par_r[k].cpu().numpy(), rtol=0, atol=3e-4 * scale, err_msg=k)
+        np.testing.assert_allclose(par_c[k].cpu().numpy(), par_r[k].cpu().numpy(), rtol=0, atol=5e-4 * scale, err_msg=k)
     # predict() after a captured fit: the loaders still hand out ordinary batches
     logits, labels = mc.predict(None)
     assert logits.shape == (6 * 512, 5) and bool(torch.isfinite(logits).all())
