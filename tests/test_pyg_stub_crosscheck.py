@@ -43,7 +43,6 @@ def test_stub_convs_equal_pyg(name):
     for k in sd_t:
         assert torch.equal(sd_t[k], sd_o[k]), k                   # the same draws in the same order
     assert torch.allclose(theirs(x, ei), ours(x, ei), atol=1e-6)
-    assert torch.equal(torch.rand(3), torch.rand(3)) or True      # (the generators' positions are compared below)
     torch.manual_seed(11)
     getattr(pnn, name)(12, 8)
     a = torch.rand(4)
