@@ -34,7 +34,7 @@ import torch
 from . import _lib
 from .data import Data
 from .graph import CSRGraph
-from .hipgraph import GraphedStep
+from .hipgraph import GraphedStep, _ship
 from .utils import mmd as _mmd
 
 
@@ -171,7 +171,7 @@ class GraphedSampledStep(GraphedStep):
         torch.randint(live_t, (times, n), out=pins[1])
         selection_csr_host(pins[0], ns, 0, 2 * n, out=(pins[2], pins[3]))
         selection_csr_host(pins[1], nt, n, 2 * n, out=(pins[4], pins[5]))
-        e["dev"].copy_(e["pin"][k], non_blocking=True)
+        _ship(e["dev"], e["pin"][k])                               # a kernel of this stream reading the pinned block
         ev = torch.cuda.Event()
         ev.record()
         e["done"][k] = ev
