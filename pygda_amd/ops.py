@@ -1118,7 +1118,8 @@ def mmd_samples_to_device(source_sample, target_sample, ns, nt, dev, stacked=Tru
     selection_csr_host(target_sample, nt, n if stacked else 0, m,
                        out=(view(4, torch.int32, nt + 1), view(5, torch.int32, times * n)))
     block = torch.empty(offs[-1], dtype=torch.uint8, device=dev)
-    block.copy_(host[:offs[-1]], non_blocking=True)
+    from .hipgraph import _ship
+    _ship(block, host[:offs[-1]])              # a kernel of this stream that reads the pinned block (no DMA-engine hand-over)
     _pinned_ring.sent(slot, torch.cuda.current_stream())
     dview = lambda k, dt, cnt: block[offs[k]:offs[k] + sizes[k]].view(dt)[:cnt]
     sel = (dview(2, torch.int32, ns + 1), dview(3, torch.int32, times * n),
