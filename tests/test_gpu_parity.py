@@ -2325,6 +2325,46 @@ def test_grade_adagcn_fit_predict_golden(monkeypatch, which, graphed):
     exact(logits.argmax(1), g[f"{which}/tgt_logits"].argmax(1))
 
 
+@pytest.mark.parametrize("which", ["grade_js", "grade_mmd", "udagcn", "adagcn"])
+def test_two_domain_stacked_pass_is_the_two_passes(monkeypatch, which):
+    """BaseGDA._stacked_pair (round 6): GRADE / UDAGCN / AdaGCN run their network over the block-diagonal (source, target)
+    pair in ONE pass.  Three captured epochs with and without it (``PYGDA_AMD_STACKED_DOMAINS``), dropout off: the same
+    per-epoch losses and accuracies to fp32 summation order of the weight gradients (one product over ns + nt rows
+    against two products and an accumulation), the same predictions."""
+    import torch.nn as nn
+    g = load_golden("grade_adagcn_fit3")
+    s, t = _pair(g)
+    orig = nn.Dropout.__init__
+    monkeypatch.setattr(nn.Dropout, "__init__", lambda self, p=0.5, inplace=False: orig(self, 0.0, inplace))
+
+    def run(stacked):
+        monkeypatch.setenv("PYGDA_AMD_STACKED_DOMAINS", "1" if stacked else "0")
+        kw = dict(device=DEV, epoch=3, verbose=0, lr=0.01)
+        if which.startswith("grade"):
+            m = pygda_amd.models.GRADE(12, 8, 3, num_layers=2, dropout=0.0, disc="JS" if which == "grade_js" else "MMD",
+                                       weight=0.5, weight_decay=0.001, **kw)
+        elif which == "udagcn":
+            np.random.seed(5)                                     # the PPMI walks
+            m = pygda_amd.models.UDAGCN(12, 8, 3, num_layers=2, dropout=0.0, **kw)
+        else:
+            m = pygda_amd.models.AdaGCN(12, 8, 3, num_layers=2, dropout=0.0, adv_dim=6, gp_weight=5, domain_weight=1, **kw)
+        seen = []
+        m.epoch_hook = lambda e, loss, acc, secs: seen.append((loss, acc))
+        torch.manual_seed(int(g["seed"]))
+        m.fit(s, t)
+        used = m.__dict__.get("_stacked_pair_cache") is not None
+        logits, _ = m.predict(t)
+        return seen, logits, used
+
+    a, la, used_a = run(True)
+    b, lb, used_b = run(False)
+    assert used_a and not used_b
+    close([x[0] for x in a], [x[0] for x in b], rtol=2e-5)
+    close([x[1] for x in a], [x[1] for x in b], rtol=0, atol=1e-12)
+    close(la, lb, rtol=0, atol=LOGIT_ATOL)
+    exact(la.argmax(1), lb.argmax(1))
+
+
 # ------------------------------------------- one-launch LDS-resident K-step aggregation --
 @pytest.mark.parametrize("name,d", [("g7", 3), ("g64", 8), ("g300d", 128), ("g300u", 5), ("g300u", 260)])
 @pytest.mark.parametrize("K", [3, 10, 11])
