@@ -457,6 +457,21 @@ int gda_grl_mlp_ce_bwd_f32(const float* es, int64_t ld_s, int64_t n_s, const flo
                            const float* grad_losses, int grad_stride, float alpha, const float* alpha_dev,
                            float* g_es, float* g_et, float* gW1, float* gb1, float* gW2, float* gb2,
                            void* workspace, size_t workspace_bytes, gda_stream_t stream);
+/* The same row kernels with the head given: head = 0 is gda_grl_mlp_ce_*; head = 1 -- ONE logit per row through a sigmoid, the
+ * loss term of a domain the MEAN of its rows' sigmoids: losses[0] = mean_s D(x), losses[1] = mean_t D(x), D = Linear(h, a) -
+ * ReLU - Dropout(p) - Linear(a, 1) - Sigmoid, i.e. the critic of pygda/models/adagcn.py:264-270 inside the encoder's loss
+ * (:190-193, `torch.mean(D(source)) - torch.mean(D(target))`), W2 [1, a], b2 [1], gW2 [1, a], gb2 [1]; no reversal: pass
+ * alpha = -1 (the input gradient is multiplied by -alpha). */
+int gda_mlp_head_fwd_f32(int head, const float* es, int64_t ld_s, int64_t n_s, const float* et, int64_t ld_t, int64_t n_t,
+                         int64_t h, int64_t a, const float* W1, const float* b1, const float* W2, const float* b2,
+                         float dropout_p, uint64_t seed, const int64_t* step, uint32_t site,
+                         float* losses, void* workspace, size_t workspace_bytes, gda_stream_t stream);
+int gda_mlp_head_bwd_f32(int head, const float* es, int64_t ld_s, int64_t n_s, const float* et, int64_t ld_t, int64_t n_t,
+                         int64_t h, int64_t a, const float* W1, const float* b1, const float* W2, const float* b2,
+                         float dropout_p, uint64_t seed, const int64_t* step, uint32_t site,
+                         const float* grad_losses, int grad_stride, float alpha, const float* alpha_dev,
+                         float* g_es, float* g_et, float* gW1, float* gb1, float* gW2, float* gb2,
+                         void* workspace, size_t workspace_bytes, gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
  * DANE's LSGAN discriminator head (csrc/gda_disc_mlp.hip).  Replaces what follows the first layer of

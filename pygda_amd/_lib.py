@@ -89,6 +89,11 @@ _SIGNATURES = {
     "gda_grl_mlp_ce_bwd_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P,
                                        c_float, ctypes.c_uint64, _P, ctypes.c_uint32, _P, c_int, c_float, _P,
                                        _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gda_mlp_head_fwd_f32": (c_int, [c_int, _P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P,
+                                     c_float, ctypes.c_uint64, _P, ctypes.c_uint32, _P, _P, c_size_t, _P]),
+    "gda_mlp_head_bwd_f32": (c_int, [c_int, _P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P,
+                                     c_float, ctypes.c_uint64, _P, ctypes.c_uint32, _P, c_int, c_float, _P,
+                                     _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gda_grl_disc_ce_fwd_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int,
                                         _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gda_grl_disc_ce_bwd_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int,

@@ -26,7 +26,10 @@ constexpr int AMAX = 64;           // hidden width limit (one lane per unit)
 constexpr int MAX_BLOCKS = 512;    // two workgroups per CU (round 6: 128 left half the chip idle -- forward 73 us, backward 130 us
                                    // at UDAGCN's 16 k rows; the folds below sum their partials on four chains with eight loads in flight)
 
-struct Mlp { const float* W1; const float* b1; const float* W2; const float* b2; int h, a; };
+// head = 0: two logits per row, softmax cross-entropy against the row's domain (UDAGCN's domain model); head = 1: ONE logit per
+// row through a sigmoid, the loss term of a domain is the MEAN of its rows' sigmoids (AdaGCN's critic D = Linear - ReLU -
+// Dropout - Linear(a, 1) - Sigmoid in the encoder's loss, adagcn.py:190-193: W2 is [1, a], b2 [1])
+struct Mlp { const float* W1; const float* b1; const float* W2; const float* b2; int h, a; int head; };
 struct Rows2 { const float* es; int64_t ld_s, n_s; const float* et; int64_t ld_t, n_t; };
 struct Drop { float p; uint64_t seed; const int64_t* step; uint32_t site; };
 
@@ -119,8 +122,8 @@ k_mlp_ce_fwd(Mlp M, Rows2 R, Drop dr, double* __restrict__ part) {
     const uint64_t st = dr.p > 0.f ? (uint64_t)dr.step[0] : 0;
     const int a = M.a;
     const float b1k = lane < a ? M.b1[lane] : 0.f;
-    const float w20k = lane < a ? M.W2[lane] : 0.f, w21k = lane < a ? M.W2[a + lane] : 0.f;
-    const float b20 = M.b2[0], b21 = M.b2[1];
+    const float w20k = lane < a ? M.W2[lane] : 0.f, w21k = (lane < a && M.head == 0) ? M.W2[a + lane] : 0.f;
+    const float b20 = M.b2[0], b21 = M.head == 0 ? M.b2[1] : 0.f;
     const int64_t groups = (R.n_s + R.n_t + RB - 1) / RB;
     double acc[2] = {0.0, 0.0};
     for (int64_t grp = (int64_t)blockIdx.x * WAVES + wave; grp < groups; grp += (int64_t)gridDim.x * WAVES) {
@@ -129,6 +132,7 @@ k_mlp_ce_fwd(Mlp M, Rows2 R, Drop dr, double* __restrict__ part) {
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
             if (!G.live[q]) continue;
+            if (M.head == 1) { acc[G.dom[q]] += (double)(1.f / (1.f + expf(-G.z0[q]))); continue; }
             const float mx = fmaxf(G.z0[q], G.z1[q]);
             const float lse = mx + logf(expf(G.z0[q] - mx) + expf(G.z1[q] - mx));
             acc[G.dom[q]] += (double)(lse - (G.dom[q] ? G.z1[q] : G.z0[q]));
@@ -179,8 +183,8 @@ k_mlp_ce_bwd(Mlp M, Rows2 R, Drop dr, const float* __restrict__ grad, int grad_s
     const uint64_t st = dr.p > 0.f ? (uint64_t)dr.step[0] : 0;
     const int h = M.h, a = M.a;
     const float b1k = lane < a ? M.b1[lane] : 0.f;
-    const float w20k = lane < a ? M.W2[lane] : 0.f, w21k = lane < a ? M.W2[a + lane] : 0.f;
-    const float b20 = M.b2[0], b21 = M.b2[1];
+    const float w20k = lane < a ? M.W2[lane] : 0.f, w21k = (lane < a && M.head == 0) ? M.W2[a + lane] : 0.f;
+    const float b20 = M.b2[0], b21 = M.head == 0 ? M.b2[1] : 0.f;
     const float neg_alpha = -(alpha_dev ? alpha_dev[0] : alpha);
     const float sc[2] = {R.n_s > 0 ? grad[0] / (float)R.n_s : 0.f, R.n_t > 0 ? grad[grad_stride] / (float)R.n_t : 0.f};
     const int64_t groups = (R.n_s + R.n_t + RB - 1) / RB;
@@ -200,8 +204,9 @@ k_mlp_ce_bwd(Mlp M, Rows2 R, Drop dr, const float* __restrict__ grad, int grad_s
             const float e0 = expf(G.z0[q] - mx), e1 = expf(G.z1[q] - mx);
             const float inv = 1.f / (e0 + e1);
             const float s = G.live[q] ? sc[G.dom[q]] : 0.f;
-            const float dz0 = (e0 * inv - (G.dom[q] == 0 ? 1.f : 0.f)) * s;
-            const float dz1 = (e1 * inv - (G.dom[q] == 1 ? 1.f : 0.f)) * s;
+            const float sgm = 1.f / (1.f + expf(-G.z0[q]));
+            const float dz0 = M.head == 1 ? sgm * (1.f - sgm) * s : (e0 * inv - (G.dom[q] == 0 ? 1.f : 0.f)) * s;
+            const float dz1 = M.head == 1 ? 0.f : (e1 * inv - (G.dom[q] == 1 ? 1.f : 0.f)) * s;
             u[q] = G.mr[q] * fmaf(w20k, dz0, w21k * dz1);          // d loss / d a_k
             gw20 = fmaf(dz0, G.hid[q], gw20);
             gw21 = fmaf(dz1, G.hid[q], gw21);
@@ -274,12 +279,12 @@ k_mlp_ce_bwd(Mlp M, Rows2 R, Drop dr, const float* __restrict__ grad, int grad_s
         else { slot = 3 * AMAX + (t - 3 * a); dst = pb2 + (int64_t)blockIdx.x * 2 + (t - 3 * a); }
         float v = 0.f;
         for (int w = 0; w < WAVES; ++w) v += small[w][slot];
-        *dst = v;
+        *dst = v;                                       // (head 1: the second logit's entries are zeros nobody folds)
     }
 }
 
 // out[e] = sum over blocks of partial[b][e], blocks in order -- the four partial arrays in ONE launch
-struct Fold4 { const float* part[4]; float* out[4]; int64_t elems[4]; };
+struct Fold4 { const float* part[4]; float* out[4]; int64_t elems[4]; int64_t stride[4]; };     // stride: floats per block of a partial array (>= elems)
 
 // 256 threads = 64 outputs x 4 chains: chain q adds the blocks q, q + 4, ... in order, eight loads in flight at a time; the
 // four chain sums are combined as (c0 + c1) + (c2 + c3).  (One thread per output adding block after block was a chain of
@@ -293,7 +298,7 @@ __global__ void __launch_bounds__(256) k_fold4(Fold4 F, int blocks) {
     int64_t stride = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (!src && e < F.elems[i]) { src = F.part[i] + e; dst = F.out[i] + e; stride = F.elems[i]; }
+        if (!src && e < F.elems[i]) { src = F.part[i] + e; dst = F.out[i] + e; stride = F.stride[i]; }
         if (!src) e -= F.elems[i];
     }
     float s = 0.f;
@@ -357,6 +362,15 @@ extern "C" int gda_grl_mlp_ce_fwd_f32(const float* es, int64_t ld_s, int64_t n_s
                                       int64_t h, int64_t a, const float* W1, const float* b1, const float* W2,
                                       const float* b2, float dropout_p, uint64_t seed, const int64_t* step, uint32_t site,
                                       float* losses, void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    return gda_mlp_head_fwd_f32(0, es, ld_s, n_s, et, ld_t, n_t, h, a, W1, b1, W2, b2, dropout_p, seed, step, site, losses,
+                                workspace, workspace_bytes, stream_);
+}
+
+extern "C" int gda_mlp_head_fwd_f32(int head, const float* es, int64_t ld_s, int64_t n_s, const float* et, int64_t ld_t, int64_t n_t,
+                                    int64_t h, int64_t a, const float* W1, const float* b1, const float* W2,
+                                    const float* b2, float dropout_p, uint64_t seed, const int64_t* step, uint32_t site,
+                                    float* losses, void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    if (head != 0 && head != 1) return GDA_E_UNSUPPORTED;
     int st = check(es, ld_s, n_s, et, ld_t, n_t, h, a);
     if (st != GDA_OK) return st;
     if (!W1 || !b1 || !W2 || !b2 || !losses || !workspace || (dropout_p > 0.f && !step)) return GDA_E_NULL;
@@ -364,7 +378,7 @@ extern "C" int gda_grl_mlp_ce_fwd_f32(const float* es, int64_t ld_s, int64_t n_s
     MlpWs ws = carve(workspace, h, a);
     if (workspace_bytes < ws.total) return GDA_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
-    const Mlp M{W1, b1, W2, b2, (int)h, (int)a};
+    const Mlp M{W1, b1, W2, b2, (int)h, (int)a, head};
     const Rows2 R{es, ld_s, n_s, et, ld_t, n_t};
     const Drop dr{dropout_p, seed, step, site};
     const int nb = blocks_for(n_s + n_t);
@@ -382,6 +396,17 @@ extern "C" int gda_grl_mlp_ce_bwd_f32(const float* es, int64_t ld_s, int64_t n_s
                                       const float* grad_losses, int grad_stride, float alpha, const float* alpha_dev,
                                       float* g_es, float* g_et, float* gW1, float* gb1, float* gW2, float* gb2,
                                       void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    return gda_mlp_head_bwd_f32(0, es, ld_s, n_s, et, ld_t, n_t, h, a, W1, b1, W2, b2, dropout_p, seed, step, site, grad_losses,
+                                grad_stride, alpha, alpha_dev, g_es, g_et, gW1, gb1, gW2, gb2, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int gda_mlp_head_bwd_f32(int head, const float* es, int64_t ld_s, int64_t n_s, const float* et, int64_t ld_t, int64_t n_t,
+                                    int64_t h, int64_t a, const float* W1, const float* b1, const float* W2,
+                                    const float* b2, float dropout_p, uint64_t seed, const int64_t* step, uint32_t site,
+                                    const float* grad_losses, int grad_stride, float alpha, const float* alpha_dev,
+                                    float* g_es, float* g_et, float* gW1, float* gb1, float* gW2, float* gb2,
+                                    void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    if (head != 0 && head != 1) return GDA_E_UNSUPPORTED;
     int st = check(es, ld_s, n_s, et, ld_t, n_t, h, a);
     if (st != GDA_OK) return st;
     if (!W1 || !b1 || !W2 || !b2 || !grad_losses || !gW1 || !gb1 || !gW2 || !gb2 || !workspace ||
@@ -390,7 +415,7 @@ extern "C" int gda_grl_mlp_ce_bwd_f32(const float* es, int64_t ld_s, int64_t n_s
     MlpWs ws = carve(workspace, h, a);
     if (workspace_bytes < ws.total) return GDA_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
-    const Mlp M{W1, b1, W2, b2, (int)h, (int)a};
+    const Mlp M{W1, b1, W2, b2, (int)h, (int)a, head};
     const Rows2 R{es, ld_s, n_s, et, ld_t, n_t};
     const Drop dr{dropout_p, seed, step, site};
     const int nb = blocks_for(n_s + n_t);
@@ -413,8 +438,10 @@ extern "C" int gda_grl_mlp_ce_bwd_f32(const float* es, int64_t ld_s, int64_t n_s
     else GDA_MLP_BWD(64);
 #undef GDA_MLP_BWD
     GDA_LAUNCH_CHECK();
-    const Fold4 F{{ws.pW1, ws.pb1, ws.pW2, ws.pb2}, {gW1, gb1, gW2, gb2}, {a * h, a, 2 * a, 2}};
-    k_fold4<<<(unsigned)gda_cdiv(a * h + 3 * a + 2, 64), 256, 0, stream>>>(F, nb);
+    // (head 1: W2 is [1, a] -- only the first logit's a + 1 entries are folded; the partials keep their [blocks][2 a] / [2] strides)
+    const int64_t nz = head == 0 ? 2 : 1;
+    const Fold4 F{{ws.pW1, ws.pb1, ws.pW2, ws.pb2}, {gW1, gb1, gW2, gb2}, {a * h, a, nz * a, nz}, {a * h, a, 2 * a, 2}};
+    k_fold4<<<(unsigned)gda_cdiv(a * h + a + nz * a + nz, 64), 256, 0, stream>>>(F, nb);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }
@@ -566,7 +593,7 @@ extern "C" int gda_lsgan_head_bwd_f32(const float* Z, int64_t ldz, int64_t rows,
     const int nb = ls_blocks(rows);
     k_lsgan_bwd<<<nb, TB, 0, stream>>>(Z, ldz, rows, (int)a, w2, pre, target, grad_loss, gZ, ldg, ws.pw2, ws.pb2);
     GDA_LAUNCH_CHECK();
-    const Fold4 F{{ws.pw2, ws.pb2, nullptr, nullptr}, {gw2, gb2, nullptr, nullptr}, {a, 1, 0, 0}};
+    const Fold4 F{{ws.pw2, ws.pb2, nullptr, nullptr}, {gw2, gb2, nullptr, nullptr}, {a, 1, 0, 0}, {a, 1, 0, 0}};
     k_fold4<<<(unsigned)gda_cdiv(a + 1, 64), 256, 0, stream>>>(F, nb);
     GDA_LAUNCH_CHECK();
     return GDA_OK;

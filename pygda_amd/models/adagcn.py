@@ -42,6 +42,14 @@ class AdaGCN(BaseGDA):
 
     def _critic_gap(self, es, et):
         # data-parallel: E D(s), E D(t) are means over every rank's rows (node-count weighted)
+        d = self.discriminator
+        if torch.is_grad_enabled() and self._fused_critic(es) and d[0].in_features <= 128:
+            # the encoder's loss (:190-193): both means and their input gradients from the two-layer discriminator's row
+            # kernels with a sigmoid-mean head -- ~40 library launches each way as two
+            from ..ops import critic_means, critic_means_ok
+            if critic_means_ok(es, d[0].weight, d[3].weight):
+                ms, mt = critic_means(es, et, d[0].weight, d[0].bias, d[3].weight, d[3].bias, d[2].p if d.training else 0.0)
+                return self._gmean(ms, es.size(0)) - self._gmean(mt, et.size(0))
         return self._gmean(torch.mean(self.discriminator(es).reshape(-1)), es.size(0)) \
             - self._gmean(torch.mean(self.discriminator(et).reshape(-1)), et.size(0))
 

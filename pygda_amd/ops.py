@@ -1288,7 +1288,8 @@ def grl_disc_ce(source_feat, target_feat, weight, bias, alpha, labels=None):
 
 
 # ------------------------------ GRL + two-layer discriminator + per-domain CE (fused) --
-def _grl_mlp_fwd(ctx, es, et, W1, b1, W2, b2, alpha, p):
+def _grl_mlp_fwd(ctx, es, et, W1, b1, W2, b2, alpha, p, head=0):
+    ctx.head = head
     es, et = _f32c(es, "source_feat"), _f32c(et, "target_feat")
     W1, b1, W2, b2 = _f32c(W1, "W1"), _f32c(b1, "b1"), _f32c(W2, "W2"), _f32c(b2, "b2")
     ns, nt, h, a = es.size(0), et.size(0), es.size(1), W1.size(0)
@@ -1301,10 +1302,10 @@ def _grl_mlp_fwd(ctx, es, et, W1, b1, W2, b2, alpha, p):
     losses = torch.empty(3, dtype=torch.float32, device=dev)
     L = _lib.lib()
     ws = _lib.workspace(L.gda_grl_mlp_ce_workspace_bytes(h, a), dev, "disc_mlp")
-    _lib.check(L.gda_grl_mlp_ce_fwd_f32(
-        _lib.ptr(es), h, ns, _lib.ptr(et), h, nt, h, a, _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
+    _lib.check(L.gda_mlp_head_fwd_f32(
+        head, _lib.ptr(es), h, ns, _lib.ptr(et), h, nt, h, a, _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
         float(p), ctypes.c_uint64(st.seed), _lib.ptr(st.counter(dev)), ctypes.c_uint32(site),
-        _lib.ptr(losses), _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_grl_mlp_ce_fwd_f32")
+        _lib.ptr(losses), _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_mlp_head_fwd_f32")
     ctx.save_for_backward(es, et, W1, b1, W2, b2, alpha if torch.is_tensor(alpha) else None)
     ctx.alpha = None if torch.is_tensor(alpha) else float(alpha)
     ctx.p, ctx.seed, ctx.site = float(p), st.seed, site
@@ -1322,12 +1323,12 @@ def _grl_mlp_bwd(ctx, g, stride):
         alpha_dev = alpha_dev.detach().reshape(1).to(torch.float32)
     L = _lib.lib()
     ws = _lib.workspace(L.gda_grl_mlp_ce_workspace_bytes(h, a), dev, "disc_mlp")
-    _lib.check(L.gda_grl_mlp_ce_bwd_f32(
-        _lib.ptr(es), h, ns, _lib.ptr(et), h, nt, h, a, _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
+    _lib.check(L.gda_mlp_head_bwd_f32(
+        ctx.head, _lib.ptr(es), h, ns, _lib.ptr(et), h, nt, h, a, _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
         ctx.p, ctypes.c_uint64(ctx.seed), _lib.ptr(dropout_state.counter(dev)), ctypes.c_uint32(ctx.site),
         _lib.ptr(g), stride, 0.0 if ctx.alpha is None else ctx.alpha, _lib.ptr(alpha_dev),
         _lib.ptr(ges), _lib.ptr(get), _lib.ptr(gW1), _lib.ptr(gb1), _lib.ptr(gW2), _lib.ptr(gb2),
-        _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_grl_mlp_ce_bwd_f32")
+        _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_mlp_head_bwd_f32")
     return ges, get, gW1, gb1, gW2, gb2, None, None
 
 
@@ -1354,6 +1355,31 @@ class _GrlMlpCEPair(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_s, g_t):
         return _grl_mlp_bwd(ctx, torch.stack([g_s.reshape(()).to(torch.float32), g_t.reshape(()).to(torch.float32)]), 1)
+
+
+class _CriticMeans(torch.autograd.Function):
+    """``(mean D(source rows), mean D(target rows))`` for ``D = Linear(h, a) - ReLU - Dropout(p) - Linear(a, 1) - Sigmoid``
+    (AdaGCN's critic inside the ENCODER's loss, adagcn.py:190-193): the row kernels of the two-layer discriminator with
+    the sigmoid-mean head (gda_mlp_head_*_f32, head = 1), no gradient reversal."""
+
+    @staticmethod
+    def forward(ctx, es, et, W1, b1, W2, b2, p):
+        losses = _grl_mlp_fwd(ctx, es, et, W1, b1, W2, b2, -1.0, p, head=1)
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, g_s, g_t):
+        return _grl_mlp_bwd(ctx, torch.stack([g_s.reshape(()).to(torch.float32), g_t.reshape(()).to(torch.float32)]), 1)[:7]
+
+
+def critic_means_ok(es, W1, W2):
+    return (es.is_cuda and es.dtype == torch.float32 and es.dim() == 2 and es.size(1) <= 128
+            and W1.size(0) <= 64 and W2.dim() == 2 and W2.size(0) == 1)
+
+
+def critic_means(source_feat, target_feat, W1, b1, W2, b2, dropout_p=0.0):
+    """The two means ``torch.mean(D(source)), torch.mean(D(target))`` of a sigmoid-headed two-layer critic, fused."""
+    return _CriticMeans.apply(source_feat, target_feat, W1, b1, W2, b2, dropout_p)
 
 
 def grl_mlp_ce_ok(es, W1, W2):

@@ -395,6 +395,42 @@ def test_softmax_entropy_vs_torch(n, c):
     assert torch.equal(ops.softmax_entropy(got_in.detach(), 1e-9), got.detach())      # deterministic
 
 
+@pytest.mark.parametrize("ns,nt,h,a", [(700, 450, 128, 40), (33, 65, 64, 16), (1, 2, 32, 8)])
+def test_critic_means_vs_torch(ns, nt, h, a):
+    """ops.critic_means (gda_mlp_head_*_f32, head = 1): mean D(source), mean D(target) of AdaGCN's critic
+    (Linear - ReLU - Dropout - Linear(a, 1) - Sigmoid) and every gradient of ``|mean_s - mean_t|`` against the composed
+    torch modules, dropout off (the masks are the kernel's own Philox draws); with dropout on: deterministic per step,
+    different between steps, the same mask in forward and backward (a finite-difference check of one input entry)."""
+    gen = torch.Generator().manual_seed(ns + a)
+    es, et = torch.randn(ns, h, generator=gen), torch.randn(nt, h, generator=gen) * 1.2 + 0.1
+    d = torch.nn.Sequential(torch.nn.Linear(h, a), torch.nn.ReLU(), torch.nn.Dropout(0.0), torch.nn.Linear(a, 1), torch.nn.Sigmoid())
+    ref_in = [es.clone().requires_grad_(), et.clone().requires_grad_()]
+    want = torch.abs(torch.mean(d(ref_in[0])) - torch.mean(d(ref_in[1])))
+    (want * 1.3).backward()
+    dd = __import__("copy").deepcopy(d).to(DEV)
+    for p_ in dd.parameters():
+        p_.grad = None
+    got_in = [es.clone().to(DEV).requires_grad_(), et.clone().to(DEV).requires_grad_()]
+    assert ops.critic_means_ok(got_in[0], dd[0].weight, dd[3].weight)
+    ms, mt = ops.critic_means(got_in[0], got_in[1], dd[0].weight, dd[0].bias, dd[3].weight, dd[3].bias, 0.0)
+    got = torch.abs(ms - mt)
+    (got * 1.3).backward()
+    close(got, want, rtol=1e-5)
+    for u, v in zip(got_in, ref_in):
+        close(u.grad, v.grad, rtol=1e-4, atol=1e-8)
+    for pg, pr in zip(dd.parameters(), d.parameters()):
+        close(pg.grad, pr.grad, rtol=1e-4, atol=1e-8)
+    if ns > 100:
+        from pygda_amd.ops import dropout_state
+        vals = []
+        for step in (5, 5, 6):
+            dropout_state.counter(torch.device(DEV)).fill_(step)
+            dropout_state.site = 0
+            a_, b_ = ops.critic_means(got_in[0].detach(), got_in[1].detach(), dd[0].weight, dd[0].bias, dd[3].weight, dd[3].bias, 0.3)
+            vals.append((float(a_), float(b_)))
+        assert vals[0] == vals[1] and vals[0] != vals[2]
+
+
 def test_block_diagonal_pair_of_graphs_aggregates_like_the_two_graphs():
     """graph.block_diag (BaseGDA._stacked_pair, UDAGCN's combined cached operators): rows, order and values of both
     ingested graphs are kept, so one aggregation over the pair is the two aggregations, bit for bit, both ways --
