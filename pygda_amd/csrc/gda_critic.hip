@@ -300,6 +300,25 @@ __device__ __forceinline__ float4 mix4(const float4 t, const float4 s, float al,
 
 __device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// sum over the 32 rows of column `lane` of a wave's tile [32][ldw] (64 columns in use): conflict-free reads, four chains
+__device__ __forceinline__ float tile_column_sum(const float* Ts, int ldw, int lane) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int r = 0; r < RT; r += 4) {
+        s0 += Ts[(size_t)r * ldw + lane]; s1 += Ts[(size_t)(r + 1) * ldw + lane];
+        s2 += Ts[(size_t)(r + 2) * ldw + lane]; s3 += Ts[(size_t)(r + 3) * ldw + lane];
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
+#ifdef GDA_CRITIC_TRACE
+// tracing build (tools/critic_trace.py): clock stamps of every wavefront's first tile at the phase boundaries
+__device__ unsigned long long* gda_critic_trace_buf;
+#define CT_STAMP(i) do { if (lane == 0 && gda_critic_trace_buf) gda_critic_trace_buf[((size_t)blockIdx.x * WAVES + wave) * 16 + (i)] = (i) >= 12 ? wall_clock64() : clock64(); } while (0)
+#else
+#define CT_STAMP(i) do { } while (0)
+#endif
+
 template <int HT>
 __global__ void __launch_bounds__(TB)
 k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restrict__ U, float* __restrict__ Y, int ldy,
@@ -309,7 +328,30 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
     const int h = C.h, a = C.a, ldw = h + 1;
     float* Ts = W1s + (size_t)a * ldw + (size_t)wave * RT * ldw;           // this wave's tile [32][h + 1]
-    load_w1(C, W1s);
+    CT_STAMP(0);
+    CT_STAMP(12);
+#ifdef GDA_CRITIC_TRACE
+    if (lane == 0 && gda_critic_trace_buf)     // where the wavefront runs: HW_ID (cu 11:8, sh 12, se 15:13) | XCC_ID << 32
+        gda_critic_trace_buf[((size_t)blockIdx.x * WAVES + wave) * 16 + 11] =
+            (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#endif
+    {   // W1 -> LDS, row stride h + 1: float4 loads, eight in flight per thread (h = 32 HT: the row / column split is a shift)
+        const int n4 = a * (8 * HT);
+        const float4* w4 = reinterpret_cast<const float4*>(C.W1);
+        for (int e0 = threadIdx.x; e0 < n4; e0 += 8 * TB) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = e0 + k * TB < n4 ? w4[e0 + k * TB] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + k * TB;
+                if (e < n4) {
+                    float* t = W1s + (size_t)(e / (8 * HT)) * ldw + (e % (8 * HT)) * 4;
+                    t[0] = v[k].x; t[1] = v[k].y; t[2] = v[k].z; t[3] = v[k].w;
+                }
+            }
+        }
+    }
     if (threadIdx.x < AMAX) {
         b1s[threadIdx.x] = threadIdx.x < a ? C.b1[threadIdx.x] : 0.f;
         w2s[threadIdx.x] = threadIdx.x < a ? C.w2[threadIdx.x] : 0.f;
@@ -323,10 +365,10 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
     const int64_t g_gap = (n_gap + RT - 1) / RT, g_gp = (m_gp + RT - 1) / RT;
     const float b2 = C.b2[0];
     const int nit = a > 32 ? 2 : 1;                                         // unit tiles that hold real units
-    // w2 gradient terms: after every group the 32 row slots of a half-wave are summed by a butterfly and lane rl keeps
-    // the sum of "its" unit register (tile rl / 16, register rl % 16): two accumulators per lane instead of 64 -- the
-    // kernel has to stay under 256 VGPRs (beyond them values live in AGPRs and every use costs a copy; the first
-    // version ran 1300 cycles per 2-MFMA loop iteration that way)
+    // w2 gradient terms: after every group the per-(unit, row) terms go through the wave's LDS tile and lane i sums unit
+    // i's column over the 32 rows: two accumulators per lane instead of 64 -- the kernel has to stay under 256 VGPRs
+    // (beyond them values live in AGPRs and every use costs a copy; the first version ran 1300 cycles per 2-MFMA loop
+    // iteration that way).  (Until round 6 a shuffle butterfly per unit register: 160 ds_bpermute, 10 k cycles a tile.)
     float w2sum_gap = 0.f, w2sum_gp = 0.f;
     double acc_b2[2] = {0.0, 0.0}, acc_gp = 0.0, acc_ds = 0.0, acc_dt = 0.0;
 
@@ -338,42 +380,73 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
     const float on0 = rl < a ? 1.f : 0.f, on1 = rl + 32 < a ? 1.f : 0.f;
     const float* w1row0c = rl < a ? w1row0 : W1s;
 
-    for (int64_t grp = (int64_t)blockIdx.x * WAVES + wave; grp < g_gap + g_gp; grp += (int64_t)gridDim.x * WAVES) {
-        const bool is_gap = grp < g_gap;
-        const int64_t base = is_gap ? grp * RT : (grp - g_gap) * RT;
-        const int64_t limit = is_gap ? n_gap : m_gp;
-        const int64_t r = base + rl;                                        // this lane pair's row in its space
+    // ONE pass over the tiles of the penalty space cat(e_s, e_t, interpolates): its first n_gap rows ARE the gap rows, so a
+    // tile that holds some also evaluates the gap terms of those rows from the same Z^T = W1 X^T (their own dropout draws:
+    // vector work only) instead of a tile of its own recomputing it.  (Round 6: 974 tiles instead of 1,485 at AdaGCN's
+    // shapes -- the kernel's 372 registers allow one wavefront per SIMD, 1,024 wave slots: one round instead of two.)
+    (void)g_gap;
+    for (int64_t grp = (int64_t)blockIdx.x * WAVES + wave; grp < g_gp; grp += (int64_t)gridDim.x * WAVES) {
+        constexpr bool is_gap = false;
+        const int64_t base = grp * RT;
+        const int64_t limit = m_gp;
+        const int64_t r = base + rl;                                        // this lane pair's row in the penalty space
         const bool live = r < limit;
+        const bool tile_has_gap = base < n_gap;                             // wave-uniform
+        const bool live_g = r < n_gap;
+        CT_STAMP(1);
         lds_settle();                                                       // the previous group's tile reads are done
         // ---- X tile -> LDS (rows past the limit read as zeros)
+        // A wavefront is alone on its SIMD here: every dependent load is a full memory round trip.  So: a tile of source /
+        // target rows only (wave-uniform) reads its rows directly, 8 pieces in flight; a tile with interpolates looks up
+        // all its 4 HT row pieces' (index, index, alpha) first -- one round trip -- and then loads 8 pieces (16 loads) a pass.
+        const bool plain_tile = base + RT <= n_gap;
         {
-            // HT passes of 4 row pieces each: the 8 loads of a pass are issued before the first one is consumed (a
-            // wavefront is alone on its SIMD here: every dependent load is a full memory round trip)
+            constexpr int NP = 4 * HT, PS = HT % 2 == 0 ? 8 : 4;
+            if (plain_tile) {
 #pragma unroll
-            for (int ps = 0; ps < HT; ++ps) {
-                RowSrc src[4];
-                float4 xt[4], xs[4];
+                for (int ps = 0; ps < NP / PS; ++ps) {
+                    float4 xt[PS];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int64_t g = base + (lane + 64 * (4 * ps + q)) / (8 * HT);
+                    for (int q = 0; q < PS; ++q) {
+                        const int idx = lane + 64 * (PS * ps + q), c4 = (idx % (8 * HT)) * 4;
+                        const int64_t g = base + idx / (8 * HT);
+                        xt[q] = *reinterpret_cast<const float4*>((g < R.n_s ? R.es + g * h : R.et + (g - R.n_s) * h) + c4);
+                    }
+#pragma unroll
+                    for (int q = 0; q < PS; ++q) {
+                        const int idx = lane + 64 * (PS * ps + q), row = idx / (8 * HT), c4 = (idx % (8 * HT)) * 4;
+                        float* t = Ts + (size_t)row * ldw + c4;
+                        t[0] = xt[q].x; t[1] = xt[q].y; t[2] = xt[q].z; t[3] = xt[q].w;
+                    }
+                }
+            } else {
+                RowSrc src[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const int64_t g = base + (lane + 64 * q) / (8 * HT);
                     src[q] = row_src(R, h, g, g < limit);
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c4 = ((lane + 64 * (4 * ps + q)) % (8 * HT)) * 4;
-                    xt[q] = *reinterpret_cast<const float4*>(src[q].t + c4);
-                    xs[q] = *reinterpret_cast<const float4*>(src[q].s + c4);
-                }
+                for (int ps = 0; ps < NP / PS; ++ps) {
+                    float4 xt[PS], xs[PS];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {                               // gap space = the first rows of the penalty space
-                    const int idx = lane + 64 * (4 * ps + q), row = idx / (8 * HT), c4 = (idx % (8 * HT)) * 4;
-                    const float4 v = mix4(xt[q], xs[q], src[q].al, base + row < limit);
-                    float* t = Ts + (size_t)row * ldw + c4;
-                    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+                    for (int q = 0; q < PS; ++q) {
+                        const int c4 = ((lane + 64 * (PS * ps + q)) % (8 * HT)) * 4;
+                        xt[q] = *reinterpret_cast<const float4*>(src[PS * ps + q].t + c4);
+                        xs[q] = *reinterpret_cast<const float4*>(src[PS * ps + q].s + c4);
+                    }
+#pragma unroll
+                    for (int q = 0; q < PS; ++q) {                          // gap space = the first rows of the penalty space
+                        const int idx = lane + 64 * (PS * ps + q), row = idx / (8 * HT), c4 = (idx % (8 * HT)) * 4;
+                        const float4 v = mix4(xt[q], xs[q], src[PS * ps + q].al, base + row < limit);
+                        float* t = Ts + (size_t)row * ldw + c4;
+                        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+                    }
                 }
             }
         }
         lds_settle();
+        CT_STAMP(2);
         // ---- Z^T = W1 X^T
         f32x16 accz[2];
 #pragma unroll
@@ -392,11 +465,77 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
             for (int kk = 0; kk < h; kk += 2)
                 accz[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(on0 * w1row0c[kk + half], Ts[(size_t)rl * ldw + kk + half], accz[0], 0, 0, 0);
         }
-        // ---- per unit: a, relu, keep, hid, u; per row: z, s, s'
-        float mr[2][16];                                                    // keep / (1 - p) where the unit is on; accz becomes a = W1 x + b1
+        // accz becomes a = W1 x + b1
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) accz[it][q] += b1s[32 * it + (q & 3) + 8 * (q >> 2) + 4 * half];
+        CT_STAMP(3);
+        // ---- the GAP terms of the rows that are source / target rows (their own keep-bits: sites 0 | 1, row numbered in its
+        // domain): z, s, d gap / d z, the w2 / b2 terms, and the rows' U | Y entries in the gap space
+        if (tile_has_gap) {
+            float mg[2][16];
+            float zg = 0.f;
+            const uint32_t site_g = dr.site + (r < R.n_s ? 0u : 1u);
+            const int64_t rowkey_g = r < R.n_s ? r : r - R.n_s;
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int i0 = 32 * it + 8 * g4 + 4 * half;
+                    uint32_t rn[4] = {~0u, ~0u, ~0u, ~0u};
+                    if (dr.p > 0.f && i0 < a) GdaPhilox::gen(dr.seed, (st << 20) ^ site_g, ((uint64_t)rowkey_g * (uint64_t)a + (uint64_t)i0) >> 2, rn);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = i0 + e, q = 4 * g4 + e;
+                        const float av = accz[it][q];
+                        const float kf = dr.p > 0.f ? (rn[e] >= thresh ? keep_on : 0.f) : 1.f;
+                        const float m = (live_g && i < a && av > 0.f) ? kf : 0.f;
+                        mg[it][q] = m;
+                        zg = fmaf(w2s[i], m * av, zg);
+                    }
+                }
+            const float z_g = zg + __shfl_xor(zg, 32, 64) + b2;
+            const float sg_g = 1.f / (1.f + __expf(-z_g)), sp_g = sg_g * (1.f - sg_g);
+            const float cAg = live_g ? (r < R.n_s ? sp_g / (float)R.n_s : -sp_g / (float)R.n_t) : 0.f;      // d gap / d z_i
+            if (live_g && half == 0) { if (r < R.n_s) acc_ds += (double)sg_g; else acc_dt += (double)sg_g; }
+            if (live_g) {
+                float* yrow = Y + r * (int64_t)ldy;                         // gap rows: the first n_gap rows of U | Y
+                const float* xrow = Ts + (size_t)rl * ldw;                  // the row is still in this wave's X tile
+#pragma unroll
+                for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int j = 32 * jt + 8 * g4 + 4 * half;
+                        *reinterpret_cast<float4*>(yrow + j) = make_float4(cAg * xrow[j], cAg * xrow[j + 1], cAg * xrow[j + 2], cAg * xrow[j + 3]);
+                    }
+                if (half == 0) { yrow[h] = cAg; acc_b2[0] += (double)cAg; }
+                float* urow = U + r * (int64_t)a;
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int i0 = 32 * it + 8 * g4 + 4 * half;
+                        if (i0 < a) *reinterpret_cast<float4*>(urow + i0) = make_float4(
+                            mg[it][4 * g4] * w2s[i0], mg[it][4 * g4 + 1] * w2s[i0 + 1], mg[it][4 * g4 + 2] * w2s[i0 + 2], mg[it][4 * g4 + 3] * w2s[i0 + 3]);
+                    }
+            }
+            // w2 terms: [row][unit] through the tile (X is consumed), lane = unit sums its column over the 32 rows
+            lds_settle();
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    Ts[(size_t)rl * ldw + 32 * it + (q & 3) + 8 * (q >> 2) + 4 * half] = mg[it][q] * (cAg * accz[it][q]);
+            lds_settle();
+            w2sum_gap += tile_column_sum(Ts, ldw, lane);
+        }
+        CT_STAMP(4);
+        // ---- per unit: relu, keep, hid, u; per row: z, s, s'  (the penalty evaluation: site 2, row numbered in the penalty space)
+        float mr[2][16];                                                    // keep / (1 - p) where the unit is on
         float zpart = 0.f;
-        const uint32_t site = is_gap ? dr.site + (r < R.n_s ? 0u : 1u) : dr.site + 2u;
-        const int64_t rowkey = is_gap ? (r < R.n_s ? r : r - R.n_s) : r;
+        const uint32_t site = dr.site + 2u;
+        const int64_t rowkey = r;
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
@@ -407,10 +546,9 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = i0 + e, q = 4 * g4 + e;
-                    const float av = accz[it][q] + b1s[i];
+                    const float av = accz[it][q];
                     const float kf = dr.p > 0.f ? (rn[e] >= thresh ? keep_on : 0.f) : 1.f;
                     const float m = (live && i < a && av > 0.f) ? kf : 0.f;
-                    accz[it][q] = av;
                     mr[it][q] = m;
                     zpart = fmaf(w2s[i], m * av, zpart);                    // hid = m a, u = m w2
                 }
@@ -428,11 +566,9 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
         for (int it = 0; it < 2; ++it)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acct[it][q] = 0.f;
-        if (is_gap) {
-            cA = live ? (r < R.n_s ? sp / (float)R.n_s : -sp / (float)R.n_t) : 0.f;      // d gap / d z_i
-            if (live && half == 0) { if (r < R.n_s) acc_ds += (double)sg; else acc_dt += (double)sg; }
-        } else {
+        {
             // ---- U tile -> LDS (over the X tile), V^T = W1^T U^T
+            CT_STAMP(5);
             lds_settle();
 #pragma unroll
             for (int it = 0; it < 2; ++it)
@@ -458,6 +594,7 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
             n2 += __shfl_xor(n2, 32, 64);
             const float nv = sqrtf(n2), inv = nv > 0.f ? 1.f / nv : 0.f;
             // ---- Vhat tile -> LDS, T^T = W1 Vhat^T
+            CT_STAMP(6);
             lds_settle();
 #pragma unroll
             for (int jt = 0; jt < HT; ++jt)
@@ -486,21 +623,18 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
             if (live && half == 0) acc_gp += (double)((nrm - 1.f) * (nrm - 1.f));
         }
         // ---- outputs of this row
-        {
-            float mine = 0.f;
+        CT_STAMP(7);
+        lds_settle();                                                       // the T product has read the Vhat tile
 #pragma unroll
-            for (int it = 0; it < 2; ++it)
+        for (int it = 0; it < 2; ++it)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    float v = mr[it][q] * (cA * accz[it][q] + cB * acct[it][q]);          // cA hid + cB m (W1 vhat)
-#pragma unroll
-                    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);   // over the 32 rows of this half
-                    mine = rl == 16 * it + q ? v : mine;
-                }
-            if (is_gap) w2sum_gap += mine; else w2sum_gp += mine;
-        }
+            for (int q = 0; q < 16; ++q)                                    // cA hid + cB m (W1 vhat)
+                Ts[(size_t)rl * ldw + 32 * it + (q & 3) + 8 * (q >> 2) + 4 * half] = mr[it][q] * (cA * accz[it][q] + cB * acct[it][q]);
+        lds_settle();
+        w2sum_gp += tile_column_sum(Ts, ldw, lane);
+        CT_STAMP(8);
         if (live) {
-            const int64_t ro = (is_gap ? 0 : n_gap) + r;
+            const int64_t ro = n_gap + r;
             float* yrow = Y + ro * (int64_t)ldy;
             const RowSrc me = row_src(R, h, r, true);                        // gap rows = the first penalty rows
 #pragma unroll
@@ -523,7 +657,7 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
             }
             if (half == 0) {
                 yrow[h] = cA;
-                if (is_gap) acc_b2[0] += (double)cA; else acc_b2[1] += (double)cA;
+                acc_b2[1] += (double)cA;
             }
             float* urow = U + ro * (int64_t)a;
 #pragma unroll
@@ -537,12 +671,9 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
         }
     }
     // ---- block partials: the w2 terms are summed over the 32 row slots of a half-wave first
+    CT_STAMP(9);
     __shared__ double red[WAVES][2 * AMAX + 5];
-    {   // lane rl of a half holds the sums of unit register (tile rl / 16, register rl % 16) of that half
-        const int it = rl >> 4, q = rl & 15;
-        const int i = 32 * it + (q & 3) + 8 * (q >> 2) + 4 * half;
-        if (i < a) { red[wave][i] = (double)w2sum_gap; red[wave][AMAX + i] = (double)w2sum_gp; }
-    }
+    if (lane < a) { red[wave][lane] = (double)w2sum_gap; red[wave][AMAX + lane] = (double)w2sum_gp; }      // lane = unit
     const double b20 = wave_sum_d_fwd(acc_b2[0]), b21 = wave_sum_d_fwd(acc_b2[1]), gps = wave_sum_d_fwd(acc_gp);
     const double dss = wave_sum_d_fwd(acc_ds), dts = wave_sum_d_fwd(acc_dt);
     if (lane == 0) {
@@ -561,6 +692,8 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
         for (int w = 0; w < WAVES; ++w) v += red[w][slot];
         part_rows[(int64_t)t * gridDim.x + blockIdx.x] = v;
     }
+    CT_STAMP(10);
+    CT_STAMP(13);
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -636,6 +769,13 @@ Ws carve(void* base, int64_t n_s, int64_t n_t, int64_t n_i, int h, int a) {
 
 }  // namespace
 
+#ifdef GDA_CRITIC_TRACE
+extern "C" int gda_dbg_critic_trace(unsigned long long* buf) {
+    GDA_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gda_critic_trace_buf), &buf, sizeof(buf)));
+    return GDA_OK;
+}
+#endif
+
 extern "C" size_t gda_wgan_critic_workspace_bytes(int64_t n_s, int64_t n_t, int64_t n_i, int h, int a) {
     if (n_s <= 0 || n_t <= 0 || n_i < 0 || h <= 0 || a <= 0) return 0;
     return carve(nullptr, n_s, n_t, n_i, h, a).total;
@@ -661,11 +801,11 @@ extern "C" int gda_wgan_critic_f32(const float* es, int64_t n_s, const float* et
     const Drop dr{dropout_p, seed, step, site};
     const int64_t n_gap = n_s + n_t, m_gp = n_s + n_t + n_i;
     const int ldy = h + 4;
-    const bool mfma = h % 32 == 0 && h >= 64 && a % 4 == 0 && ((uintptr_t)es | (uintptr_t)et) % 16 == 0;   // h >= 64: the U tile (64 units) shares the X tile's rows
+    const bool mfma = h % 32 == 0 && h >= 64 && a % 4 == 0 && ((uintptr_t)es | (uintptr_t)et | (uintptr_t)W1) % 16 == 0;   // h >= 64: the U tile (64 units) shares the X tile's rows
     int row_blocks = ROW_BLOCKS;
     if (mfma) {
         // 32 rows per wavefront: as many workgroups as there are groups of 4 row tiles (at most ROW_BLOCKS)
-        const int64_t tiles = gda_cdiv(n_gap, RT) + gda_cdiv(m_gp, RT);
+        const int64_t tiles = gda_cdiv(m_gp, RT);             // the gap rows ride in the penalty space's first tiles
         const int64_t want = gda_cdiv(tiles, WAVES);
         row_blocks = (int)(want < ROW_BLOCKS ? want : ROW_BLOCKS);
         const size_t lds = lds_floats_mfma(h, a) * sizeof(float);
