@@ -272,7 +272,9 @@ k_critic_rows(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restrict__ 
 // Same keep-bits as the readlane kernel (keyed on row and unit; one Philox call covers a lane's four adjacent units).
 constexpr int RT = 32;
 
-__host__ __device__ inline size_t lds_floats_mfma(int h, int a) { return (size_t)a * (h + 1) + (size_t)WAVES * RT * (h + 1); }
+__host__ __device__ inline size_t lds_floats_mfma(int h, int a) {      // W1, four X | Y tiles, four U tiles
+    return (size_t)a * (h + 1) + (size_t)WAVES * RT * (h + 1) + (size_t)WAVES * RT * (AMAX + 1);
+}
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -319,15 +321,48 @@ __device__ unsigned long long* gda_critic_trace_buf;
 #define CT_STAMP(i) do { } while (0)
 #endif
 
+constexpr int LDU = AMAX + 1;      // row stride of a wavefront's U tile [32][AMAX + 1]
+
+// Sum of the four wavefronts' 32 x 32 accumulator blocks acc[NB rd + k] (k < NB; block bi = unit tile bi / HT, column tile
+// bi % HT of the [a][h] product) into the workgroup's partial: every wavefront stages its NB blocks in LDS
+// (stage[wave][k][32][32]), then the 256 threads add the four copies in wave order and write (or add to) the partial's
+// entries.  Barriers inside: called by every wavefront of the workgroup, the staging area must be free on entry.
+template <int NB, int HT, int NTOT>
+__device__ __forceinline__ void quad_sum_round(const f32x16 (&acc)[NTOT], int rd, float* stage, int wave, int rl, int half, int a, int h,
+                                               float* __restrict__ out, bool add) {
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            stage[((size_t)(wave * NB + k) * 32 + (q & 3) + 8 * (q >> 2) + 4 * half) * 32 + rl] = acc[NB * rd + k][q];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NB * 4; ++j) {
+        const int idx = threadIdx.x + TB * j, k = idx >> 10, rowl = (idx >> 5) & 31, coll = idx & 31;
+        const int bi = NB * rd + k, row = 32 * (bi / HT) + rowl;
+        float v = stage[idx];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) v += stage[(size_t)w * NB * 1024 + idx];
+        if (row < a) {
+            float* o = out + (size_t)row * h + 32 * (bi % HT) + coll;
+            *o = add ? *o + v : v;
+        }
+    }
+    __syncthreads();
+}
+
 template <int HT>
 __global__ void __launch_bounds__(TB)
-k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restrict__ U, float* __restrict__ Y, int ldy,
+k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restrict__ P_gap, float* __restrict__ P_gp,
                    double* __restrict__ part_rows) {
     extern __shared__ __attribute__((aligned(16))) float W1s[];
     __shared__ float b1s[AMAX], w2s[AMAX];
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
     const int h = C.h, a = C.a, ldw = h + 1;
-    float* Ts = W1s + (size_t)a * ldw + (size_t)wave * RT * ldw;           // this wave's tile [32][h + 1]
+    float* Tall = W1s + (size_t)a * ldw;                                    // the four waves' tiles [32][h + 1]; at the end of a trip
+    float* Ts = Tall + (size_t)wave * RT * ldw;                             //   the staging area of the U^T Y sum (4 x HT blocks)
+    float* Uall = Tall + (size_t)WAVES * RT * ldw;                          // the four waves' U tiles [32][65]; the staging area of
+    float* Us = Uall + (size_t)wave * RT * LDU;                             //   the gap rows' sum (4 x 2 blocks)
     CT_STAMP(0);
     CT_STAMP(12);
 #ifdef GDA_CRITIC_TRACE
@@ -362,14 +397,15 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
     const float keep_on = 1.f / (1.f - dr.p);
     const int rl = lane & 31, half = lane >> 5;
     const int64_t n_gap = R.n_s + R.n_t, m_gp = R.n_s + R.n_t + R.n_i;
-    const int64_t g_gap = (n_gap + RT - 1) / RT, g_gp = (m_gp + RT - 1) / RT;
+    const int64_t g_gp = (m_gp + RT - 1) / RT, nquad = (g_gp + WAVES - 1) / WAVES;
     const float b2 = C.b2[0];
     const int nit = a > 32 ? 2 : 1;                                         // unit tiles that hold real units
-    // w2 gradient terms: after every group the per-(unit, row) terms go through the wave's LDS tile and lane i sums unit
-    // i's column over the 32 rows: two accumulators per lane instead of 64 -- the kernel has to stay under 256 VGPRs
-    // (beyond them values live in AGPRs and every use costs a copy; the first version ran 1300 cycles per 2-MFMA loop
-    // iteration that way).  (Until round 6 a shuffle butterfly per unit register: 160 ds_bpermute, 10 k cycles a tile.)
-    float w2sum_gap = 0.f, w2sum_gp = 0.f;
+    const int64_t pe = (int64_t)a * h;                                      // entries of one U^T Y partial
+    // Per-unit sums over the rows (the w2 terms; u . cA = the b1 terms): the per-(row, unit) values go through the wave's
+    // U tile and lane i sums unit i's column over the 32 rows -- one accumulator per lane and sum instead of one per
+    // unit register (the kernel has to stay under 256 VGPRs: beyond them values live in AGPRs and every use is a copy).
+    // (Until round 6 a shuffle butterfly per unit register: 160 ds_bpermute, 10 k cycles a tile.)
+    float w2sum_gap = 0.f, w2sum_gp = 0.f, b1sum_gap = 0.f, b1sum_gp = 0.f;
     double acc_b2[2] = {0.0, 0.0}, acc_gp = 0.0, acc_ds = 0.0, acc_dt = 0.0;
 
     // W1 as the MFMA's row operand: unit i = rl + 32 it, column k   (zero rows past a)
@@ -381,20 +417,21 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
     const float* w1row0c = rl < a ? w1row0 : W1s;
 
     // ONE pass over the tiles of the penalty space cat(e_s, e_t, interpolates): its first n_gap rows ARE the gap rows, so a
-    // tile that holds some also evaluates the gap terms of those rows from the same Z^T = W1 X^T (their own dropout draws:
-    // vector work only) instead of a tile of its own recomputing it.  (Round 6: 974 tiles instead of 1,485 at AdaGCN's
-    // shapes -- the kernel's 372 registers allow one wavefront per SIMD, 1,024 wave slots: one round instead of two.)
-    (void)g_gap;
-    for (int64_t grp = (int64_t)blockIdx.x * WAVES + wave; grp < g_gp; grp += (int64_t)gridDim.x * WAVES) {
-        constexpr bool is_gap = false;
+    // tile that holds some also evaluates the gap terms of those rows from the same Z^T = W1 X^T (their own dropout draws)
+    // instead of a tile of its own recomputing it.  A workgroup takes four consecutive tiles (a "quad") per trip so that
+    // the U^T Y products of its wavefronts can be summed through LDS: every wavefront runs every trip (rows past the
+    // end are dead: zero contributions), the barriers below are uniform.
+    int64_t trip = 0;
+    for (int64_t quad = blockIdx.x; quad < nquad; quad += gridDim.x, ++trip) {
+        const int64_t grp = quad * WAVES + wave;
         const int64_t base = grp * RT;
         const int64_t limit = m_gp;
         const int64_t r = base + rl;                                        // this lane pair's row in the penalty space
         const bool live = r < limit;
+        const bool quad_has_gap = quad * (WAVES * RT) < n_gap;              // workgroup-uniform
         const bool tile_has_gap = base < n_gap;                             // wave-uniform
         const bool live_g = r < n_gap;
         CT_STAMP(1);
-        lds_settle();                                                       // the previous group's tile reads are done
         // ---- X tile -> LDS (rows past the limit read as zeros)
         // A wavefront is alone on its SIMD here: every dependent load is a full memory round trip.  So: a tile of source /
         // target rows only (wave-uniform) reads its rows directly, 8 pieces in flight; a tile with interpolates looks up
@@ -472,63 +509,80 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
             for (int q = 0; q < 16; ++q) accz[it][q] += b1s[32 * it + (q & 3) + 8 * (q >> 2) + 4 * half];
         CT_STAMP(3);
         // ---- the GAP terms of the rows that are source / target rows (their own keep-bits: sites 0 | 1, row numbered in its
-        // domain): z, s, d gap / d z, the w2 / b2 terms, and the rows' U | Y entries in the gap space
-        if (tile_has_gap) {
-            float mg[2][16];
-            float zg = 0.f;
-            const uint32_t site_g = dr.site + (r < R.n_s ? 0u : 1u);
-            const int64_t rowkey_g = r < R.n_s ? r : r - R.n_s;
+        // domain): z, s, d gap / d z = cAg; the rows' part of gW1 = sum_r (cAg u_r) x_r^T on the matrix cores, summed over
+        // the workgroup's four tiles through LDS
+        if (quad_has_gap) {
+            f32x16 accg[2 * HT];                                            // block it HT + jt
 #pragma unroll
-            for (int it = 0; it < 2; ++it)
+            for (int bi = 0; bi < 2 * HT; ++bi)
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int i0 = 32 * it + 8 * g4 + 4 * half;
-                    uint32_t rn[4] = {~0u, ~0u, ~0u, ~0u};
-                    if (dr.p > 0.f && i0 < a) GdaPhilox::gen(dr.seed, (st << 20) ^ site_g, ((uint64_t)rowkey_g * (uint64_t)a + (uint64_t)i0) >> 2, rn);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = i0 + e, q = 4 * g4 + e;
-                        const float av = accz[it][q];
-                        const float kf = dr.p > 0.f ? (rn[e] >= thresh ? keep_on : 0.f) : 1.f;
-                        const float m = (live_g && i < a && av > 0.f) ? kf : 0.f;
-                        mg[it][q] = m;
-                        zg = fmaf(w2s[i], m * av, zg);
-                    }
-                }
-            const float z_g = zg + __shfl_xor(zg, 32, 64) + b2;
-            const float sg_g = 1.f / (1.f + __expf(-z_g)), sp_g = sg_g * (1.f - sg_g);
-            const float cAg = live_g ? (r < R.n_s ? sp_g / (float)R.n_s : -sp_g / (float)R.n_t) : 0.f;      // d gap / d z_i
-            if (live_g && half == 0) { if (r < R.n_s) acc_ds += (double)sg_g; else acc_dt += (double)sg_g; }
-            if (live_g) {
-                float* yrow = Y + r * (int64_t)ldy;                         // gap rows: the first n_gap rows of U | Y
-                const float* xrow = Ts + (size_t)rl * ldw;                  // the row is still in this wave's X tile
-#pragma unroll
-                for (int jt = 0; jt < HT; ++jt)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int j = 32 * jt + 8 * g4 + 4 * half;
-                        *reinterpret_cast<float4*>(yrow + j) = make_float4(cAg * xrow[j], cAg * xrow[j + 1], cAg * xrow[j + 2], cAg * xrow[j + 3]);
-                    }
-                if (half == 0) { yrow[h] = cAg; acc_b2[0] += (double)cAg; }
-                float* urow = U + r * (int64_t)a;
+                for (int q = 0; q < 16; ++q) accg[bi][q] = 0.f;
+            if (tile_has_gap) {
+                float mg[2][16];
+                float zg = 0.f;
+                const uint32_t site_g = dr.site + (r < R.n_s ? 0u : 1u);
+                const int64_t rowkey_g = r < R.n_s ? r : r - R.n_s;
 #pragma unroll
                 for (int it = 0; it < 2; ++it)
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int i0 = 32 * it + 8 * g4 + 4 * half;
-                        if (i0 < a) *reinterpret_cast<float4*>(urow + i0) = make_float4(
-                            mg[it][4 * g4] * w2s[i0], mg[it][4 * g4 + 1] * w2s[i0 + 1], mg[it][4 * g4 + 2] * w2s[i0 + 2], mg[it][4 * g4 + 3] * w2s[i0 + 3]);
+                        uint32_t rn[4] = {~0u, ~0u, ~0u, ~0u};
+                        if (dr.p > 0.f && i0 < a) GdaPhilox::gen(dr.seed, (st << 20) ^ site_g, ((uint64_t)rowkey_g * (uint64_t)a + (uint64_t)i0) >> 2, rn);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = i0 + e, q = 4 * g4 + e;
+                            const float av = accz[it][q];
+                            const float kf = dr.p > 0.f ? (rn[e] >= thresh ? keep_on : 0.f) : 1.f;
+                            const float m = (live_g && i < a && av > 0.f) ? kf : 0.f;
+                            mg[it][q] = m;
+                            zg = fmaf(w2s[i], m * av, zg);
+                        }
                     }
+                const float z_g = zg + __shfl_xor(zg, 32, 64) + b2;
+                const float sg_g = 1.f / (1.f + __expf(-z_g)), sp_g = sg_g * (1.f - sg_g);
+                const float cAg = live_g ? (r < R.n_s ? sp_g / (float)R.n_s : -sp_g / (float)R.n_t) : 0.f;      // d gap / d z_i
+                if (live_g && half == 0) {
+                    if (r < R.n_s) acc_ds += (double)sg_g; else acc_dt += (double)sg_g;
+                    acc_b2[0] += (double)cAg;
+                }
+                // U tile of the gap rows, scaled by the row's cAg: [row][unit]
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int i = 32 * it + (q & 3) + 8 * (q >> 2) + 4 * half;
+                        Us[(size_t)rl * LDU + i] = (mg[it][q] * w2s[i]) * cAg;
+                    }
+                lds_settle();
+                b1sum_gap += tile_column_sum(Us, LDU, lane);
+                // (cAg U)^T X: units x columns, the 32 rows are the MFMA's k
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+                    if (it < nit) {
+#pragma unroll 4
+                        for (int k2 = 0; k2 < RT; k2 += 2) {
+                            const float ua = Us[(size_t)(k2 + half) * LDU + 32 * it + rl];
+                            const float* xr = Ts + (size_t)(k2 + half) * ldw + rl;
+#pragma unroll
+                            for (int jt = 0; jt < HT; ++jt) accg[it * HT + jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua, xr[32 * jt], accg[it * HT + jt], 0, 0, 0);
+                        }
+                    }
+                // w2 terms of the gap rows
+                lds_settle();
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        Us[(size_t)rl * LDU + 32 * it + (q & 3) + 8 * (q >> 2) + 4 * half] = mg[it][q] * (cAg * accz[it][q]);
+                lds_settle();
+                w2sum_gap += tile_column_sum(Us, LDU, lane);
             }
-            // w2 terms: [row][unit] through the tile (X is consumed), lane = unit sums its column over the 32 rows
-            lds_settle();
+            // the four tiles' products summed through the U tiles' LDS, two blocks a round, into the block's partial
+            __syncthreads();
 #pragma unroll
-            for (int it = 0; it < 2; ++it)
-#pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    Ts[(size_t)rl * ldw + 32 * it + (q & 3) + 8 * (q >> 2) + 4 * half] = mg[it][q] * (cAg * accz[it][q]);
-            lds_settle();
-            w2sum_gap += tile_column_sum(Ts, ldw, lane);
+            for (int rd = 0; rd < HT; ++rd)
+                quad_sum_round<2, HT>(accg, rd, Uall, wave, rl, half, a, h, P_gap + (int64_t)blockIdx.x * pe, trip > 0);
         }
         CT_STAMP(4);
         // ---- per unit: relu, keep, hid, u; per row: z, s, s'  (the penalty evaluation: site 2, row numbered in the penalty space)
@@ -556,18 +610,14 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
         const float z = zpart + __shfl_xor(zpart, 32, 64) + b2;
         const float sg = 1.f / (1.f + __expf(-z)), sp = sg * (1.f - sg);
         float cA = 0.f, cB = 0.f;
-        f32x16 accv[HT];                                                    // V^T, then Vhat^T: this row's columns
-#pragma unroll
-        for (int jt = 0; jt < HT; ++jt)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) accv[jt][q] = 0.f;
-        f32x16 acct[2];                                                     // T^T = W1 Vhat^T (zero for the gap rows)
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acct[it][q] = 0.f;
+        f32x16 accp[2 * HT];                                                // this tile's U^T Y: block it HT + jt
         {
-            // ---- U tile -> LDS (over the X tile), V^T = W1^T U^T
+            f32x16 accv[HT];                                                // V^T, then Vhat^T: this row's columns
+#pragma unroll
+            for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) accv[jt][q] = 0.f;
+            // ---- U tile -> LDS, V^T = W1^T U^T
             CT_STAMP(5);
             lds_settle();
 #pragma unroll
@@ -575,13 +625,13 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int i = 32 * it + (q & 3) + 8 * (q >> 2) + 4 * half;
-                    Ts[(size_t)rl * ldw + i] = mr[it][q] * w2s[i];          // u: columns 0..63 of the tile row
+                    Us[(size_t)rl * LDU + i] = mr[it][q] * w2s[i];          // u
                 }
             lds_settle();
 #pragma unroll 4
             for (int kk = 0; kk < a; kk += 2) {                             // a is a multiple of 4
                 const int i = kk + half;
-                const float ub = Ts[(size_t)rl * ldw + i];
+                const float ub = Us[(size_t)rl * LDU + i];
                 const float* wrow = W1s + (size_t)i * ldw + rl;
 #pragma unroll
                 for (int jt = 0; jt < HT; ++jt) accv[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[32 * jt], ub, accv[jt], 0, 0, 0);
@@ -593,87 +643,93 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
                 for (int q = 0; q < 16; ++q) n2 = fmaf(accv[jt][q], accv[jt][q], n2);
             n2 += __shfl_xor(n2, 32, 64);
             const float nv = sqrtf(n2), inv = nv > 0.f ? 1.f / nv : 0.f;
-            // ---- Vhat tile -> LDS, T^T = W1 Vhat^T
-            CT_STAMP(6);
-            lds_settle();
-#pragma unroll
-            for (int jt = 0; jt < HT; ++jt)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    accv[jt][q] *= inv;
-                    Ts[(size_t)rl * ldw + 32 * jt + (q & 3) + 8 * (q >> 2) + 4 * half] = accv[jt][q];
-                }
-            lds_settle();
-            if (nit > 1) {
-#pragma unroll 8
-                for (int kk = 0; kk < h; kk += 2) {
-                    const float vb = Ts[(size_t)rl * ldw + kk + half];
-                    acct[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(on0 * w1row0c[kk + half], vb, acct[0], 0, 0, 0);
-                    acct[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(on1 * w1row1[kk + half], vb, acct[1], 0, 0, 0);
-                }
-            } else {
-#pragma unroll 8
-                for (int kk = 0; kk < h; kk += 2)
-                    acct[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(on0 * w1row0c[kk + half], Ts[(size_t)rl * ldw + kk + half], acct[0], 0, 0, 0);
-            }
             const float nrm = sp * nv;
             const float e = live ? gp_weight / (float)m_gp * 2.f * (nrm - 1.f) : 0.f;
             cA = e * nv * sp * (1.f - 2.f * sg);
             cB = e * sp;
-            if (live && half == 0) acc_gp += (double)((nrm - 1.f) * (nrm - 1.f));
+            if (live && half == 0) { acc_gp += (double)((nrm - 1.f) * (nrm - 1.f)); acc_b2[1] += (double)cA; }
+            // ---- the row's Y = cA x + cB vhat, in place over its x in the tile (a lane pair owns its row)
+            CT_STAMP(6);
+#pragma unroll
+            for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float* y = Ts + (size_t)rl * ldw + 32 * jt + (q & 3) + 8 * (q >> 2) + 4 * half;
+                    *y = cA * *y + cB * (accv[jt][q] * inv);
+                }
+            lds_settle();
         }
-        // ---- outputs of this row
-        CT_STAMP(7);
-        lds_settle();                                                       // the T product has read the Vhat tile
+        // ---- T'^T = W1 Y^T = cA (a - b1) + cB W1 vhat: the w2 terms are m (T' + cA b1)
+        f32x16 acct[2];
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
-            for (int q = 0; q < 16; ++q)                                    // cA hid + cB m (W1 vhat)
-                Ts[(size_t)rl * ldw + 32 * it + (q & 3) + 8 * (q >> 2) + 4 * half] = mr[it][q] * (cA * accz[it][q] + cB * acct[it][q]);
-        lds_settle();
-        w2sum_gp += tile_column_sum(Ts, ldw, lane);
-        CT_STAMP(8);
-        if (live) {
-            const int64_t ro = n_gap + r;
-            float* yrow = Y + ro * (int64_t)ldy;
-            const RowSrc me = row_src(R, h, r, true);                        // gap rows = the first penalty rows
-#pragma unroll
-            for (int jt = 0; jt < HT; ++jt) {                                // one column tile at a time: 8 loads in flight
-                float4 xt[4], xs[4];
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int j = 32 * jt + 8 * g4 + 4 * half;
-                    xt[g4] = *reinterpret_cast<const float4*>(me.t + j);
-                    xs[g4] = *reinterpret_cast<const float4*>(me.s + j);
-                }
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int j = 32 * jt + 8 * g4 + 4 * half;
-                    const float4 xv = mix4(xt[g4], xs[g4], me.al, true);
-                    *reinterpret_cast<float4*>(yrow + j) = make_float4(
-                        cA * xv.x + cB * accv[jt][4 * g4], cA * xv.y + cB * accv[jt][4 * g4 + 1],
-                        cA * xv.z + cB * accv[jt][4 * g4 + 2], cA * xv.w + cB * accv[jt][4 * g4 + 3]);
-                }
+            for (int q = 0; q < 16; ++q) acct[it][q] = 0.f;
+        if (nit > 1) {
+#pragma unroll 8
+            for (int kk = 0; kk < h; kk += 2) {
+                const float vb = Ts[(size_t)rl * ldw + kk + half];
+                acct[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(on0 * w1row0c[kk + half], vb, acct[0], 0, 0, 0);
+                acct[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(on1 * w1row1[kk + half], vb, acct[1], 0, 0, 0);
             }
-            if (half == 0) {
-                yrow[h] = cA;
-                acc_b2[1] += (double)cA;
-            }
-            float* urow = U + ro * (int64_t)a;
-#pragma unroll
-            for (int it = 0; it < 2; ++it)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int i0 = 32 * it + 8 * g4 + 4 * half;
-                    if (i0 < a) *reinterpret_cast<float4*>(urow + i0) = make_float4(
-                        mr[it][4 * g4] * w2s[i0], mr[it][4 * g4 + 1] * w2s[i0 + 1], mr[it][4 * g4 + 2] * w2s[i0 + 2], mr[it][4 * g4 + 3] * w2s[i0 + 3]);
-                }
+        } else {
+#pragma unroll 8
+            for (int kk = 0; kk < h; kk += 2)
+                acct[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(on0 * w1row0c[kk + half], Ts[(size_t)rl * ldw + kk + half], acct[0], 0, 0, 0);
         }
+        CT_STAMP(7);
+        // ---- U^T Y: units x columns, the 32 rows are the MFMA's k
+#pragma unroll
+        for (int bi = 0; bi < 2 * HT; ++bi)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) accp[bi][q] = 0.f;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+            if (it < nit) {
+#pragma unroll 4
+                for (int k2 = 0; k2 < RT; k2 += 2) {
+                    const float ua = Us[(size_t)(k2 + half) * LDU + 32 * it + rl];
+                    const float* yr = Ts + (size_t)(k2 + half) * ldw + rl;
+#pragma unroll
+                    for (int jt = 0; jt < HT; ++jt) accp[it * HT + jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua, yr[32 * jt], accp[it * HT + jt], 0, 0, 0);
+                }
+            }
+        // ---- the w2 terms m (T' + cA b1) and the b1 terms cA u: column sums over the tile's rows
+        lds_settle();
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = 32 * it + (q & 3) + 8 * (q >> 2) + 4 * half;
+                Us[(size_t)rl * LDU + i] = mr[it][q] * (acct[it][q] + cA * b1s[i]);
+            }
+        lds_settle();
+        w2sum_gp += tile_column_sum(Us, LDU, lane);
+        lds_settle();
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = 32 * it + (q & 3) + 8 * (q >> 2) + 4 * half;
+                Us[(size_t)rl * LDU + i] = (mr[it][q] * w2s[i]) * cA;
+            }
+        lds_settle();
+        b1sum_gp += tile_column_sum(Us, LDU, lane);
+        CT_STAMP(8);
+        // ---- the four tiles' U^T Y summed through LDS (over the X | Y tiles), one unit tile a round, into the block's partial
+        __syncthreads();
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd)
+            quad_sum_round<HT, HT>(accp, rd, Tall, wave, rl, half, a, h, P_gp + (int64_t)blockIdx.x * pe, trip > 0);
+        // (the last barrier of the round: the tiles are free for the next trip)
     }
-    // ---- block partials: the w2 terms are summed over the 32 row slots of a half-wave first
+    // ---- block partials of the per-unit and per-row sums
     CT_STAMP(9);
-    __shared__ double red[WAVES][2 * AMAX + 5];
-    if (lane < a) { red[wave][lane] = (double)w2sum_gap; red[wave][AMAX + lane] = (double)w2sum_gp; }      // lane = unit
+    __shared__ double red[WAVES][4 * AMAX + 5];
+    if (lane < a) {                                                         // lane = unit
+        red[wave][lane] = (double)w2sum_gap; red[wave][AMAX + lane] = (double)w2sum_gp;
+        red[wave][2 * AMAX + 5 + lane] = (double)b1sum_gap; red[wave][3 * AMAX + 5 + lane] = (double)b1sum_gp;
+    }
     const double b20 = wave_sum_d_fwd(acc_b2[0]), b21 = wave_sum_d_fwd(acc_b2[1]), gps = wave_sum_d_fwd(acc_gp);
     const double dss = wave_sum_d_fwd(acc_ds), dts = wave_sum_d_fwd(acc_dt);
     if (lane == 0) {
@@ -681,13 +737,16 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
         red[wave][2 * AMAX + 3] = dss; red[wave][2 * AMAX + 4] = dts;
     }
     __syncthreads();
-    const int t = threadIdx.x;
-    if (t < 2 * a + 5) {
+    // columns of part_rows: [0, a) w2 gap | a: b2 gap | [a + 1, 2a + 1) w2 penalty | 2a + 1: b2 penalty | 2a + 2: penalty
+    // | 2a + 3, 2a + 4: sum D over source / target | [2a + 5, 3a + 5) b1 gap | [3a + 5, 4a + 5) b1 penalty
+    for (int t = threadIdx.x; t < 4 * a + 5; t += TB) {
         int slot;
         if (t < a) slot = t;
         else if (t == a) slot = 2 * AMAX + 0;
         else if (t < 2 * a + 1) slot = AMAX + (t - a - 1);
-        else slot = 2 * AMAX + 1 + (t - (2 * a + 1));
+        else if (t < 2 * a + 5) slot = 2 * AMAX + 1 + (t - (2 * a + 1));
+        else if (t < 3 * a + 5) slot = 2 * AMAX + 5 + (t - (2 * a + 5));
+        else slot = 3 * AMAX + 5 + (t - (3 * a + 5));
         double v = 0.0;
         for (int w = 0; w < WAVES; ++w) v += red[w][slot];
         part_rows[(int64_t)t * gridDim.x + blockIdx.x] = v;
@@ -741,7 +800,69 @@ k_critic_final(Critic C, RowsIn R, float gp_weight, const double* __restrict__ p
     }
 }
 
-struct Ws { double* part_rows; float* U; float* Y; float* UtY_gap; float* UtY_gp; void* gemm_ws; size_t gemm_bytes; size_t total; };
+// The matrix-core path's last launch: the blocks' U^T Y partials [block][a h] folded in a fixed order (16 wavefronts of a
+// workgroup = 16 chains over the blocks for 64 adjacent entries, eight loads in flight each, combined in chain order
+// through LDS), gW1 = -sign(gap) * gap part + penalty part; gb1, gw2, gb2 and the loss from the blocks' column sums.
+constexpr int FIN_TB = 1024, FIN_CH = FIN_TB / 64;
+
+__device__ __forceinline__ float chain_sum(const float* __restrict__ P, int64_t pe, int64_t e, int blocks, int chain) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b0 = chain; b0 < blocks; b0 += 8 * FIN_CH) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = b0 + k * FIN_CH < blocks ? P[(int64_t)(b0 + k * FIN_CH) * pe + e] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += v[k];
+    }
+    return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+__global__ void __launch_bounds__(FIN_TB)
+k_critic_final_fused(Critic C, RowsIn R, float gp_weight, const double* __restrict__ part_rows, int row_blocks, int gap_blocks,
+                     const float* __restrict__ P_gap, const float* __restrict__ P_gp, float* __restrict__ loss,
+                     float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2) {
+    __shared__ float cg[FIN_CH][64], cp[FIN_CH][64];
+    const int t = threadIdx.x, a = C.a, lane = t % 64, chain = t / 64;
+    const int64_t pe = (int64_t)a * C.h, e = (int64_t)blockIdx.x * 64 + lane;
+    if (e < pe) {
+        cg[chain][lane] = chain_sum(P_gap, pe, e, gap_blocks, chain);
+        cp[chain][lane] = chain_sum(P_gp, pe, e, row_blocks, chain);
+    }
+    const int gw = blockIdx.x * FIN_CH + chain, nw = gridDim.x * FIN_CH;
+    const double gap = column_sum(part_rows, 2 * a + 3, row_blocks, lane) / (double)R.n_s
+                     - column_sum(part_rows, 2 * a + 4, row_blocks, lane) / (double)R.n_t;
+    const float sgn = gap > 0.0 ? 1.f : (gap < 0.0 ? -1.f : 0.f);
+    for (int k = gw; k <= 2 * a + 1; k += nw) {
+        if (k <= a) {          // hidden unit k (k < a) or the output bias (k == a): gap part and penalty part
+            const double g0 = column_sum(part_rows, k, row_blocks, lane), g1 = column_sum(part_rows, a + 1 + k, row_blocks, lane);
+            if (lane == 0) {
+                const float v = (float)(-(double)sgn * g0 + g1);
+                if (k < a) gw2[k] = v; else gb2[0] = v;
+            }
+        } else if (k == a + 1) {
+            const double gp = column_sum(part_rows, 2 * a + 2, row_blocks, lane);
+            const double m_gp = (double)(R.n_s + R.n_t + R.n_i);
+            if (lane == 0) loss[0] = (float)(-(gap < 0 ? -gap : gap) + (double)gp_weight * gp / m_gp);     // adagcn.py:177
+        } else {               // first-layer bias of unit k - a - 2
+            const int u = k - a - 2;
+            const double g0 = column_sum(part_rows, 2 * a + 5 + u, row_blocks, lane), g1 = column_sum(part_rows, 3 * a + 5 + u, row_blocks, lane);
+            if (lane == 0) gb1[u] = (float)(-(double)sgn * g0 + g1);
+        }
+    }
+    __syncthreads();
+    if (chain == 0 && e < pe) {
+        float g = 0.f, p = 0.f;
+#pragma unroll
+        for (int c = 0; c < FIN_CH; ++c) { g += cg[c][lane]; p += cp[c][lane]; }
+        gW1[e] = -sgn * g + p;
+    }
+}
+
+struct Ws {
+    double* part_rows; float* U; float* Y; float* UtY_gap; float* UtY_gp; void* gemm_ws; size_t gemm_bytes;
+    float* P_gap; float* P_gp;                      // the matrix-core path's block partials (they share the bytes of U | Y ...)
+    size_t total;
+};
 
 constexpr int ROW_BLOCKS = 512;
 
@@ -755,7 +876,8 @@ Ws carve(void* base, int64_t n_s, int64_t n_t, int64_t n_i, int h, int a) {
         off += gda_align_up(bytes, 256);
         return p;
     };
-    w.part_rows = (double*)take(sizeof(double) * ROW_BLOCKS * (2 * a + 5));
+    w.part_rows = (double*)take(sizeof(double) * ROW_BLOCKS * (4 * a + 5));
+    const size_t shared_from = off;
     w.U = (float*)take(sizeof(float) * rows * a);
     w.Y = (float*)take(sizeof(float) * rows * ldy);
     w.UtY_gap = (float*)take(sizeof(float) * a * ldy);
@@ -763,7 +885,11 @@ Ws carve(void* base, int64_t n_s, int64_t n_t, int64_t n_i, int h, int a) {
     const size_t g1 = gda_gemm_workspace_bytes(GDA_GEMM_TN, a, ldy, n_gap), g2 = gda_gemm_workspace_bytes(GDA_GEMM_TN, a, ldy, m_gp);
     w.gemm_bytes = g1 > g2 ? g1 : g2;
     w.gemm_ws = take(w.gemm_bytes);
-    w.total = off;
+    const size_t end_rows = off;
+    off = shared_from;                              // the other path's layout over the same bytes
+    w.P_gap = (float*)take(sizeof(float) * ROW_BLOCKS * (size_t)a * h);
+    w.P_gp = (float*)take(sizeof(float) * ROW_BLOCKS * (size_t)a * h);
+    w.total = off > end_rows ? off : end_rows;
     return w;
 }
 
@@ -801,31 +927,34 @@ extern "C" int gda_wgan_critic_f32(const float* es, int64_t n_s, const float* et
     const Drop dr{dropout_p, seed, step, site};
     const int64_t n_gap = n_s + n_t, m_gp = n_s + n_t + n_i;
     const int ldy = h + 4;
-    const bool mfma = h % 32 == 0 && h >= 64 && a % 4 == 0 && ((uintptr_t)es | (uintptr_t)et | (uintptr_t)W1) % 16 == 0;   // h >= 64: the U tile (64 units) shares the X tile's rows
+    // the matrix-core path: h = 64, 96, 128 (LDS: W1, four X | Y tiles, four U tiles)
+    const bool mfma = h % 32 == 0 && h >= 64 && h <= 128 && a % 4 == 0 && ((uintptr_t)es | (uintptr_t)et | (uintptr_t)W1) % 16 == 0;
     int row_blocks = ROW_BLOCKS;
     if (mfma) {
-        // 32 rows per wavefront: as many workgroups as there are groups of 4 row tiles (at most ROW_BLOCKS)
+        // 32 rows per wavefront, four tiles per workgroup and trip: as many workgroups as there are quads (at most ROW_BLOCKS)
         const int64_t tiles = gda_cdiv(m_gp, RT);             // the gap rows ride in the penalty space's first tiles
         const int64_t want = gda_cdiv(tiles, WAVES);
         row_blocks = (int)(want < ROW_BLOCKS ? want : ROW_BLOCKS);
+        const int64_t gap_quads = gda_cdiv(n_gap, WAVES * RT);
+        const int gap_blocks = (int)(gap_quads < row_blocks ? gap_quads : row_blocks);
         const size_t lds = lds_floats_mfma(h, a) * sizeof(float);
 #define GDA_CRITIC_MFMA(HT)                                                                                          \
         {                                                                                                            \
             GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_critic_rows_mfma<HT>),                   \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-            k_critic_rows_mfma<HT><<<row_blocks, TB, lds, stream>>>(C, R, dr, gp_weight, ws.U, ws.Y, ldy, ws.part_rows); \
+            k_critic_rows_mfma<HT><<<row_blocks, TB, lds, stream>>>(C, R, dr, gp_weight, ws.P_gap, ws.P_gp, ws.part_rows); \
         }
         switch (h / 32) {
-            case 1: GDA_CRITIC_MFMA(1) break;
             case 2: GDA_CRITIC_MFMA(2) break;
             case 3: GDA_CRITIC_MFMA(3) break;
-            case 4: GDA_CRITIC_MFMA(4) break;
-            case 5: GDA_CRITIC_MFMA(5) break;
-            case 6: GDA_CRITIC_MFMA(6) break;
-            case 7: GDA_CRITIC_MFMA(7) break;
-            default: GDA_CRITIC_MFMA(8) break;
+            default: GDA_CRITIC_MFMA(4) break;
         }
 #undef GDA_CRITIC_MFMA
+        GDA_LAUNCH_CHECK();
+        k_critic_final_fused<<<(unsigned)gda_cdiv((int64_t)a * h, 64), FIN_TB, 0, stream>>>(
+            C, R, gp_weight, ws.part_rows, row_blocks, gap_blocks, ws.P_gap, ws.P_gp, loss, gW1, gb1, gw2, gb2);
+        GDA_LAUNCH_CHECK();
+        return GDA_OK;
     } else {
         const size_t lds = lds_floats(h, a) * sizeof(float);
         const bool wide = h > 128;

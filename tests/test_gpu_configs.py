@@ -592,11 +592,14 @@ def test_wgan_critic_fused_vs_autograd(ns, nt):
     assert bool((outs[0][1] != out[1]).any()) and bool(torch.isfinite(outs[0][1]).all())
 
 
-@pytest.mark.parametrize("h,a,ns,nt", [(128, 40, 9360, 5484), (64, 64, 300, 420), (256, 24, 500, 260), (96, 40, 257, 33)])
+@pytest.mark.parametrize("h,a,ns,nt", [(128, 40, 9360, 5484), (64, 64, 300, 420), (256, 24, 500, 260), (96, 40, 257, 33),
+                                       (128, 64, 40000, 30000)])
 def test_wgan_critic_mfma_rows_equal_readlane_rows(h, a, ns, nt):
-    """The matrix-core row kernel (32 rows per wavefront, h % 32 == 0) against the readlane row kernel (taken when the
-    encodings are not 16-byte aligned) on the same values WITH dropout: same keep-bits by construction, so loss and
-    all four gradients agree to rounding."""
+    """The matrix-core path (32 rows per wavefront, h in {64, 96, 128}; U^T Y inside the row kernel, block partials
+    folded by the final launch) against the readlane row kernel + U^T Y by the GEMM (taken when the encodings are not
+    16-byte aligned, and for other widths) on the same values WITH dropout: same keep-bits by construction, so loss
+    and all four gradients agree to rounding.  The last case has more row tiles than the grid takes in one trip (a
+    workgroup adds to its partial) and gap rows in the second trip."""
     from pygda_amd.ops import dropout_state, wgan_critic_grads
     gen = torch.Generator().manual_seed(h + a)
     es = torch.randn(ns, h, generator=gen).relu().to(DEV)

@@ -74,8 +74,8 @@ def main():
         print(f"    CU {k}: " + ", ".join(f"[{a - v[0][0]}, {b - v[0][0]}]" for a, b in v))
     tr = tr[tr[:, 10] > 0].double()
     print(f"{len(tr)} wavefronts stamped; loss {float(loss):.6f}")
-    names = ["W1 -> LDS + sync", "X tile -> LDS", "Z = W1 X^T", "gap terms", "penalty masks", "U tile, V^T = W1^T U^T",
-             "Vhat tile, T^T = W1 Vhat^T", "w2 butterfly", "Y | U rows out", "block partials"]
+    names = ["W1 -> LDS + sync", "X tile -> LDS", "Z = W1 X^T", "gap terms, (cAg U)^T X, reduce", "penalty masks",
+             "U tile, V^T = W1^T U^T, Y", "T' = W1 Y^T", "U^T Y, column sums", "block reduce, partial out", "block partials"]
     for i, nm in enumerate(names):
         dt = tr[:, i + 1] - tr[:, i]
         print(f"  {nm:28s} mean {dt.mean():9.0f}  min {dt.min():9.0f}  max {dt.max():9.0f}")
