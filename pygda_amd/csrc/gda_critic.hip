@@ -11,16 +11,24 @@
 //     a = W1 x + b1, r = [a > 0], m = dropout mask / (1 - p), hid = m r a, z = w2.hid + b2, s = sigmoid(z),
 //     s' = s (1 - s), u = m r w2, v = W1^T u, grad_x D = s' v, nrm = s' |v|
 //     d nrm = nv s'(1 - 2 s) dz + s' d|v|,   dz = hid.dw2 + db2 + u.(dW1 x + db1),   d|v| = vhat.(dW1^T u) + (m r (W1 vhat)).dw2
-// so a row contributes  u (cA x + cB vhat)^T  to gW1 and  cA u  to gb1 (cA, cB scalars): the kernel writes
-// U [R, a] and Y [R, h + 4] (column h = cA) and ONE matrix-core product gW1|gb1 = U^T Y (gda_gemm_f32, TN,
-// deterministic row-slab split) finishes them; gw2, gb2 and the loss are fixed-order block sums.
-//   k_critic_rows   every row (gap rows with their own masks, carrying the UNSIGNED derivative of the gap, then
-//                   the penalty rows): U, Y, fixed-order block sums (w2 / b2 terms, penalty, D per domain)
-//   gda_gemm_f32    U^T Y for the gap rows and for the penalty rows
-//   k_critic_final  sign(gap) from the block sums; gW1, gb1, gw2, gb2 = -sign * gap part + penalty part; loss
-// One wavefront takes RB = 4 rows: lane k owns hidden unit k (a <= 64) for the W1 x and W1 vhat products, lanes
-// own columns j, j + 64, ... for v = W1^T u; W1 sits in LDS with a padded leading dimension (conflict free both
-// ways), every W1 word read feeds the four rows, the rows' values are broadcast with v_readlane.
+// so a row contributes  u (cA x + cB vhat)^T = u y^T  to gW1 and  cA u  to gb1 (cA, cB scalars); gw2, gb2 and the
+// loss are fixed-order block sums.  Two paths:
+//  * h in {64, 96, 128}, 16-byte aligned encodings -- the matrix-core path, TWO launches (round 6):
+//      k_critic_rows_mfma    32 rows per wavefront; Z^T = W1 X^T, V^T = W1^T U^T, T'^T = W1 Y^T and the tile's U^T Y on
+//                            the fp32 MFMAs; the four tiles of a workgroup summed through LDS into ONE partial
+//                            [a][h] per workgroup (gap rows and penalty rows separately); per-unit / per-row sums
+//                            (w2, b1, b2 terms, penalty, D per domain) as fixed-order block sums.  U and Y never
+//                            reach memory (until round 6: 37 MB written, read back by two GEMM launches).
+//      k_critic_final_fused  the partials folded in a fixed order; sign(gap); gW1, gb1, gw2, gb2 = -sign * gap part
+//                            + penalty part; loss
+//  * any other shape -- the readlane path:
+//      k_critic_rows   every row (gap rows with their own masks, carrying the UNSIGNED derivative of the gap, then
+//                      the penalty rows): U [R, a], Y [R, h + 4] (column h = cA), block sums
+//      gda_gemm_f32    U^T Y for the gap rows and for the penalty rows (TN, deterministic row-slab split)
+//      k_critic_final  sign(gap) from the block sums; the four gradients and the loss
+//    One wavefront takes RB = 4 rows: lane k owns hidden unit k (a <= 64) for the W1 x and W1 vhat products, lanes
+//    own columns j, j + 64, ... for v = W1^T u; W1 sits in LDS with a padded leading dimension (conflict free both
+//    ways), every W1 word read feeds the four rows, the rows' values are broadcast with v_readlane.
 #include "gda_common.h"
 #include "gda_philox.h"
 
@@ -261,14 +269,18 @@ k_critic_rows(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The same rows on the fp32 MATRIX CORES (h % 32 == 0, a % 4 == 0): a wavefront takes 32 rows; the three per-row
+// The same rows on the fp32 MATRIX CORES (h in {64, 96, 128}, a % 4 == 0): a wavefront takes 32 rows; the per-row
 // matrix-vector products become 32-row tile products with the rows as the MFMA's column index,
-//     Z^T [unit, row] = W1 X^T,      V^T [column, row] = W1^T U^T,      T^T [unit, row] = W1 Vhat^T,
+//     Z^T [unit, row] = W1 X^T,      V^T [column, row] = W1^T U^T,      T'^T [unit, row] = W1 Y^T,
 // so that a lane pair (l, l + 32) owns ONE row and holds 32 of its 64 (padded) hidden units / half of its columns in
-// accumulator registers: every per-row scalar (z, s, |v|, cA, cB) is lane-local plus one cross-half shuffle.  The B
-// operands (X, then U, then Vhat) go through one per-wave LDS tile [32][h + 1] (row stride odd: conflict-free operand
-// reads), W1 sits in LDS as before.  The readlane version above spends two VALU instructions per (row, weight): 119 us
-// for the 35 k rows of an AdaGCN critic step; this one 336 MFMAs per 32 penalty rows.
+// accumulator registers: every per-row scalar (z, s, |v|, cA, cB) is lane-local plus one cross-half shuffle.  With
+// y = cA x + cB vhat formed in place over the row's x in LDS, W1 y = cA (a - b1) + cB W1 vhat: the w2 terms
+// m (cA a + cB W1 vhat) are m (T' + cA b1), and the SAME tile is the B operand of the tile's gradient product
+//     (U^T Y) [unit, column] = sum over the 32 rows  u[row, unit] y[row, column]            (rows = the MFMA's k).
+// LDS per workgroup: W1 [a][h + 1], four X | Y tiles [32][h + 1], four U tiles [32][65] (row strides odd:
+// conflict-free operand reads) = 132 KB at h = 128, a = 64.  The readlane version above spends two VALU
+// instructions per (row, weight): 119 us for the 35 k rows of an AdaGCN critic step; this one 464 MFMAs per 32
+// penalty rows (+ 128 for a tile with gap rows) including the gradient product.
 // Same keep-bits as the readlane kernel (keyed on row and unit; one Philox call covers a lane's four adjacent units).
 constexpr int RT = 32;
 

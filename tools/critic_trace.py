@@ -3,9 +3,10 @@
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DGDA_CRITIC_TRACE -c pygda_amd/csrc/gda_critic.hip -o /tmp/critic_trace.o
     hipcc --offload-arch=gfx950 -shared -fPIC /tmp/critic_trace.o <the other objects of pygda_amd/csrc/build/ except gda_critic.o> -ldl -o <lib.so>
-    python tools/critic_trace.py <lib.so> [n_s 8935] [n_t 7410] [h 128] [a 64]
+    python tools/critic_trace.py <lib.so> [n_s 9360] [n_t 8935] [h 128] [a 40] [dropout 0.4]
 
-Calls gda_wgan_critic_f32 at AdaGCN's shapes (interpolates = twice the smaller domain, dropout 0.5) a few times and prints, from
+Calls gda_wgan_critic_f32 at bench.py's AdaGCN shapes (ACMv9 -> Citationv1 stand-ins; interpolates = twice the smaller
+domain) a few times and prints, from
 the clock stamps of every wavefront's first tile (lane 0), the mean / max cycles between the phase boundaries and when
 the wavefronts started and ended."""
 import ctypes
@@ -18,10 +19,11 @@ P = ctypes.c_void_p
 
 def main():
     lib = ctypes.CDLL(sys.argv[1])
-    n_s = int(sys.argv[2]) if len(sys.argv) > 2 else 8935
-    n_t = int(sys.argv[3]) if len(sys.argv) > 3 else 7410
+    n_s = int(sys.argv[2]) if len(sys.argv) > 2 else 9360
+    n_t = int(sys.argv[3]) if len(sys.argv) > 3 else 8935
     h = int(sys.argv[4]) if len(sys.argv) > 4 else 128
-    a = int(sys.argv[5]) if len(sys.argv) > 5 else 64
+    a = int(sys.argv[5]) if len(sys.argv) > 5 else 40
+    p_drop = float(sys.argv[6]) if len(sys.argv) > 6 else 0.4
     n_i = n_t if n_s == n_t else 2 * min(n_s, n_t)          # adagcn.py:423-434: the smaller domain twice
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(3)
@@ -47,7 +49,7 @@ def main():
         st = lib.gda_wgan_critic_f32(
             P(es.data_ptr()), I64(n_s), P(et.data_ptr()), I64(n_t), h, P(isrc.data_ptr()), P(itgt.data_ptr()),
             P(alpha.data_ptr()), I64(n_i), P(W1.data_ptr()), P(b1.data_ptr()), P(w2.data_ptr()), P(b2.data_ptr()), a,
-            ctypes.c_float(0.5), ctypes.c_uint64(1234), P(step.data_ptr()), ctypes.c_uint32(0), ctypes.c_float(10.0),
+            ctypes.c_float(p_drop), ctypes.c_uint64(1234), P(step.data_ptr()), ctypes.c_uint32(0), ctypes.c_float(10.0),
             P(loss.data_ptr()), P(gW1.data_ptr()), P(gb1.data_ptr()), P(gw2.data_ptr()), P(gb2.data_ptr()),
             P(ws.data_ptr()), ctypes.c_size_t(wsb), P(stream))
         assert st == 0, st
