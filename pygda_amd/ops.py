@@ -1302,10 +1302,11 @@ def _grl_mlp_fwd(ctx, es, et, W1, b1, W2, b2, alpha, p, head=0):
     losses = torch.empty(3, dtype=torch.float32, device=dev)
     L = _lib.lib()
     ws = _lib.workspace(L.gda_grl_mlp_ce_workspace_bytes(h, a), dev, "disc_mlp")
-    _lib.check(L.gda_mlp_head_fwd_f32(
-        head, _lib.ptr(es), h, ns, _lib.ptr(et), h, nt, h, a, _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
-        float(p), ctypes.c_uint64(st.seed), _lib.ptr(st.counter(dev)), ctypes.c_uint32(site),
-        _lib.ptr(losses), _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_mlp_head_fwd_f32")
+    with profiler.region(f"disc_mlp_fwd[{h}x{a}]", 2, 4 * (ns + nt) * h, 2 * (ns + nt) * a * (h + W2.size(0))):
+        _lib.check(L.gda_mlp_head_fwd_f32(
+            head, _lib.ptr(es), h, ns, _lib.ptr(et), h, nt, h, a, _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
+            float(p), ctypes.c_uint64(st.seed), _lib.ptr(st.counter(dev)), ctypes.c_uint32(site),
+            _lib.ptr(losses), _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_mlp_head_fwd_f32")
     ctx.save_for_backward(es, et, W1, b1, W2, b2, alpha if torch.is_tensor(alpha) else None)
     ctx.alpha = None if torch.is_tensor(alpha) else float(alpha)
     ctx.p, ctx.seed, ctx.site = float(p), st.seed, site
@@ -1323,12 +1324,14 @@ def _grl_mlp_bwd(ctx, g, stride):
         alpha_dev = alpha_dev.detach().reshape(1).to(torch.float32)
     L = _lib.lib()
     ws = _lib.workspace(L.gda_grl_mlp_ce_workspace_bytes(h, a), dev, "disc_mlp")
-    _lib.check(L.gda_mlp_head_bwd_f32(
-        ctx.head, _lib.ptr(es), h, ns, _lib.ptr(et), h, nt, h, a, _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
-        ctx.p, ctypes.c_uint64(ctx.seed), _lib.ptr(dropout_state.counter(dev)), ctypes.c_uint32(ctx.site),
-        _lib.ptr(g), stride, 0.0 if ctx.alpha is None else ctx.alpha, _lib.ptr(alpha_dev),
-        _lib.ptr(ges), _lib.ptr(get), _lib.ptr(gW1), _lib.ptr(gb1), _lib.ptr(gW2), _lib.ptr(gb2),
-        _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_mlp_head_bwd_f32")
+    # recomputed first layer, d hidden . W1 (input gradients), d hidden^T x (weight gradient): 3 products of rows x a x h
+    with profiler.region(f"disc_mlp_bwd[{h}x{a}]", 2, 4 * (ns + nt) * h * (2 if ges is not None else 1), 6 * (ns + nt) * a * h):
+        _lib.check(L.gda_mlp_head_bwd_f32(
+            ctx.head, _lib.ptr(es), h, ns, _lib.ptr(et), h, nt, h, a, _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
+            ctx.p, ctypes.c_uint64(ctx.seed), _lib.ptr(dropout_state.counter(dev)), ctypes.c_uint32(ctx.site),
+            _lib.ptr(g), stride, 0.0 if ctx.alpha is None else ctx.alpha, _lib.ptr(alpha_dev),
+            _lib.ptr(ges), _lib.ptr(get), _lib.ptr(gW1), _lib.ptr(gb1), _lib.ptr(gW2), _lib.ptr(gb2),
+            _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_mlp_head_bwd_f32")
     return ges, get, gW1, gb1, gW2, gb2, None, None
 
 
@@ -1468,13 +1471,18 @@ def wgan_critic_grads(es, et, idx_s, idx_t, alpha, W1, b1, W2, b2, dropout_p, gp
     site = st.next_site()
     st.next_site(); st.next_site()                          # three mask sets: D(es), D(et), penalty rows
     loss, gW1, gb1, gW2, gb2 = out
-    _lib.check(L.gda_wgan_critic_f32(
-        _lib.ptr(es), n_s, _lib.ptr(et), n_t, h, _lib.ptr(idx_s), _lib.ptr(idx_t),
-        _lib.ptr(None if alpha is None else _f32c(alpha, "alpha")), n_i,
-        _lib.ptr(_f32c(W1, "W1")), _lib.ptr(_f32c(b1, "b1")), _lib.ptr(_f32c(W2, "W2")), _lib.ptr(_f32c(b2, "b2")), a,
-        float(dropout_p), ctypes.c_uint64(st.seed), _lib.ptr(st.counter(es.device)), ctypes.c_uint32(site),
-        float(gp_weight), _lib.ptr(loss), _lib.ptr(gW1), _lib.ptr(gb1), _lib.ptr(gW2), _lib.ptr(gb2),
-        _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_wgan_critic_f32")
+    # algorithmic work of one update: per penalty row the products W1 x, W1^T u, W1 y and the row's u y^T (2 a h flops
+    # each), per gap row its u x^T; the encodings read once, two rows gathered per interpolate
+    rows_gp = n_s + n_t + n_i
+    with profiler.region(f"wgan_critic[{h}x{a}]", 2 if h in (64, 96, 128) and a % 4 == 0 else 7,
+                         4 * h * (n_s + n_t + 2 * n_i), 2 * a * h * (4 * rows_gp + n_s + n_t)):
+        _lib.check(L.gda_wgan_critic_f32(
+            _lib.ptr(es), n_s, _lib.ptr(et), n_t, h, _lib.ptr(idx_s), _lib.ptr(idx_t),
+            _lib.ptr(None if alpha is None else _f32c(alpha, "alpha")), n_i,
+            _lib.ptr(_f32c(W1, "W1")), _lib.ptr(_f32c(b1, "b1")), _lib.ptr(_f32c(W2, "W2")), _lib.ptr(_f32c(b2, "b2")), a,
+            float(dropout_p), ctypes.c_uint64(st.seed), _lib.ptr(st.counter(es.device)), ctypes.c_uint32(site),
+            float(gp_weight), _lib.ptr(loss), _lib.ptr(gW1), _lib.ptr(gb1), _lib.ptr(gW2), _lib.ptr(gb2),
+            _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_wgan_critic_f32")
     return loss
 
 
