@@ -525,6 +525,13 @@ int gda_relu_dropout_fwd_f32(const float* x, float* y, int64_t n, float p, uint6
                              const int64_t* step, uint32_t site, gda_stream_t stream);
 int gda_relu_dropout_bwd_f32(const float* gy, const float* y, float* gx, int64_t n, float p,
                              gda_stream_t stream);
+/* gda_relu_dropout_fwd_f32 of `copies` stacked copies of x [period] (period % 4 == 0) without materialising them:
+ * y [copies * period], element i = the activation of x[i % period] with element i's keep-bit -- what
+ * `F.dropout(F.relu(x.repeat(copies, 1)), p)` draws.  AdaGCN's critic loop re-encodes both domains `critic_steps` times
+ * with an encoder that does not change inside the loop (pygda/models/adagcn.py:169-171): the passes differ by their
+ * dropout draws only and run as one stacked pass.  Forward only (the loop runs under no_grad). */
+int gda_relu_dropout_tiled_fwd_f32(const float* x, int64_t period, int64_t copies, float* y, float p, uint64_t seed,
+                                   const int64_t* step, uint32_t site, gda_stream_t stream);
 /* The same activation across a layout change, next to the LDS-resident K-step kernel (which works on
  * column-major activations): forward reads xT [d, ldT] column-major and writes y [n, d] row-major, backward
  * reads gy, y [n, d] row-major and writes gxT [d, ldT] column-major (rows n..ldT-1 of a column untouched) --
@@ -868,6 +875,19 @@ int gda_adam_multi_ex_f32(const gda_adam_tensor* tensors /* HOST array */, int n
 int gda_adam_multi_sum_f32(const gda_adam_tensor* tensors /* HOST array */, const float* const* grad2 /* HOST array */,
                            int n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay, int flags,
                            gda_stream_t stream);
+/* gda_wgan_critic_f32 (above) AND the critic optimiser's step in the same two launches: the body of one iteration of
+ * AdaGCN's critic loop, pygda/models/adagcn.py:169-183 (`loss.backward(); self.c_optimizer.step()`, the optimiser built
+ * at :271-275).  params[0..3] (HOST array) = W1 [a, h], b1 [a], w2 [a], b2 [1] with their torch.optim.Adam state; the
+ * gradients are written to params[k].grad (as gda_wgan_critic_f32 writes gW1 ...), every step counter is incremented
+ * and the parameters are updated by the thread that formed the gradient -- same arithmetic as gda_adam_multi_f32, same
+ * bits.  Only where gda_wgan_critic_f32 takes its two-launch matrix-core path (h in {64, 96, 128}, a % 4 == 0, 16-byte
+ * aligned es / et / W1): GDA_E_UNSUPPORTED otherwise, nothing launched. */
+int gda_wgan_critic_adam_f32(const float* es, int64_t n_s, const float* et, int64_t n_t, int h,
+                             const int32_t* idx_s, const int32_t* idx_t, const float* alpha, int64_t n_i,
+                             int a, float dropout_p, uint64_t seed, const int64_t* step, uint32_t site,
+                             float gp_weight, float* loss, const gda_adam_tensor* params /* HOST array of 4 */,
+                             float lr, float beta1, float beta2, float eps, float weight_decay,
+                             void* workspace, size_t workspace_bytes, gda_stream_t stream);
 
 /* ------------------------------------------------------------------------------
  * Tall-skinny fp32 GEMMs on the matrix cores: the dense projection of the hidden / classifier

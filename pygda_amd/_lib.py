@@ -100,6 +100,7 @@ _SIGNATURES = {
                                         _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gda_relu_dropout_fwd_f32": (c_int, [_P, _P, c_int64, c_float, ctypes.c_uint64, _P, ctypes.c_uint32, _P]),
     "gda_relu_dropout_bwd_f32": (c_int, [_P, _P, _P, c_int64, c_float, _P]),
+    "gda_relu_dropout_tiled_fwd_f32": (c_int, [_P, c_int64, c_int64, _P, c_float, ctypes.c_uint64, _P, ctypes.c_uint32, _P]),
     "gda_gather_rows_f32": (c_int, [_P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P]),
     "gda_segment_mean_fwd_f32": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, c_int64, _P]),
     "gda_segment_mean_bwd_f32": (c_int, [_P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, _P]),
@@ -166,6 +167,9 @@ _SIGNATURES = {
     "gda_wgan_critic_f32": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int,
                                     c_float, ctypes.c_uint64, _P, ctypes.c_uint32, c_float, _P, _P, _P, _P, _P,
                                     _P, c_size_t, _P]),
+    "gda_wgan_critic_adam_f32": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, _P, c_int64, c_int,
+                                         c_float, ctypes.c_uint64, _P, ctypes.c_uint32, c_float, _P, _P,
+                                         c_float, c_float, c_float, c_float, c_float, _P, c_size_t, _P]),
     "gda_laplacian_workspace_bytes": (c_size_t, [c_int64]),
     "gda_laplacian_fwd_f32": (c_int, [_P, _P, c_int64, c_int, _P, c_int64, _P, _P, _P, c_size_t, _P]),
     "gda_laplacian_bwd_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, c_int64, _P, _P, _P, c_int64, _P]),

@@ -19,7 +19,7 @@ using Philox = GdaPhilox;
 
 __global__ void __launch_bounds__(TB)
 k_relu_dropout_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p, float scale,
-                   uint64_t seed, const int64_t* __restrict__ step, uint32_t site) {
+                   uint64_t seed, const int64_t* __restrict__ step, uint32_t site, int64_t period) {
     const uint64_t st = (uint64_t)step[0];
     const uint32_t thresh = (uint32_t)((double)p * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (double)p * 4294967296.0);
     const int64_t quads = (n + 3) / 4;
@@ -27,7 +27,15 @@ k_relu_dropout_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t n
         uint32_t r[4];
         Philox::gen(seed, (st << 20) ^ site, (uint64_t)q, r);
         const int64_t i = q * 4;
-        if (i + 3 < n) {
+        if (period) {              // y = the activation of `n / period` stacked copies of x: element i reads x[i % period] (period % 4 == 0)
+            const float4 v = *reinterpret_cast<const float4*>(x + i % period);
+            float4 o;
+            o.x = (v.x > 0.f && r[0] >= thresh) ? v.x * scale : 0.f;
+            o.y = (v.y > 0.f && r[1] >= thresh) ? v.y * scale : 0.f;
+            o.z = (v.z > 0.f && r[2] >= thresh) ? v.z * scale : 0.f;
+            o.w = (v.w > 0.f && r[3] >= thresh) ? v.w * scale : 0.f;
+            *reinterpret_cast<float4*>(y + i) = o;
+        } else if (i + 3 < n) {
             const float4 v = *reinterpret_cast<const float4*>(x + i);
             float4 o;
             o.x = (v.x > 0.f && r[0] >= thresh) ? v.x * scale : 0.f;
@@ -371,7 +379,19 @@ extern "C" int gda_relu_dropout_fwd_f32(const float* x, float* y, int64_t n, flo
     if (n == 0) return GDA_OK;
     if (!x || !y || !step) return GDA_E_NULL;
     if (((uintptr_t)x | (uintptr_t)y) % 16 != 0) return GDA_E_UNSUPPORTED;
-    k_relu_dropout_fwd<<<grid_for(n), TB, 0, (hipStream_t)stream>>>(x, y, n, p, 1.f / (1.f - p), seed, step, site);
+    k_relu_dropout_fwd<<<grid_for(n), TB, 0, (hipStream_t)stream>>>(x, y, n, p, 1.f / (1.f - p), seed, step, site, 0);
+    GDA_LAUNCH_CHECK();
+    return GDA_OK;
+}
+
+extern "C" int gda_relu_dropout_tiled_fwd_f32(const float* x, int64_t period, int64_t copies, float* y, float p, uint64_t seed,
+                                              const int64_t* step, uint32_t site, gda_stream_t stream) {
+    if (period < 0 || copies < 0 || !(p >= 0.f && p < 1.f) || period % 4 != 0) return GDA_E_SIZE;
+    if (period == 0 || copies == 0) return GDA_OK;
+    if (!x || !y || !step) return GDA_E_NULL;
+    if (((uintptr_t)x | (uintptr_t)y) % 16 != 0) return GDA_E_UNSUPPORTED;
+    const int64_t n = period * copies;
+    k_relu_dropout_fwd<<<grid_for(n), TB, 0, (hipStream_t)stream>>>(x, y, n, p, 1.f / (1.f - p), seed, step, site, period);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
 }

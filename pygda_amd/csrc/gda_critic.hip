@@ -31,6 +31,7 @@
 //    ways), every W1 word read feeds the four rows, the rows' values are broadcast with v_readlane.
 #include "gda_common.h"
 #include "gda_philox.h"
+#include "gda_adam_rule.h"
 
 namespace {
 
@@ -333,6 +334,14 @@ __device__ unsigned long long* gda_critic_trace_buf;
 #define CT_STAMP(i) do { } while (0)
 #endif
 
+// The critic's own optimiser step applied where the gradients are formed (gda_wgan_critic_adam_f32): torch.optim.Adam
+// state of W1, b1, w2, b2 (in this order); on = 0: gradients only.
+struct CriticAdam {
+    float* p[4]; float* m[4]; float* v[4]; float* step[4];
+    float lr, beta1, beta2, eps, weight_decay;
+    int on;
+};
+
 constexpr int LDU = AMAX + 1;      // row stride of a wavefront's U tile [32][AMAX + 1]
 
 // Sum of the four wavefronts' 32 x 32 accumulator blocks acc[NB rd + k] (k < NB; block bi = unit tile bi / HT, column tile
@@ -366,7 +375,7 @@ __device__ __forceinline__ void quad_sum_round(const f32x16 (&acc)[NTOT], int rd
 template <int HT>
 __global__ void __launch_bounds__(TB)
 k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restrict__ P_gap, float* __restrict__ P_gp,
-                   double* __restrict__ part_rows) {
+                   double* __restrict__ part_rows, CriticAdam ad) {
     extern __shared__ __attribute__((aligned(16))) float W1s[];
     __shared__ float b1s[AMAX], w2s[AMAX];
     const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
@@ -375,6 +384,7 @@ k_critic_rows_mfma(Critic C, RowsIn R, Drop dr, float gp_weight, float* __restri
     float* Ts = Tall + (size_t)wave * RT * ldw;                             //   the staging area of the U^T Y sum (4 x HT blocks)
     float* Uall = Tall + (size_t)WAVES * RT * ldw;                          // the four waves' U tiles [32][65]; the staging area of
     float* Us = Uall + (size_t)wave * RT * LDU;                             //   the gap rows' sum (4 x 2 blocks)
+    if (ad.on && blockIdx.x == 0 && threadIdx.x < 4) *ad.step[threadIdx.x] += 1.0f;      // read by the final launch
     CT_STAMP(0);
     CT_STAMP(12);
 #ifdef GDA_CRITIC_TRACE
@@ -832,10 +842,25 @@ __device__ __forceinline__ float chain_sum(const float* __restrict__ P, int64_t 
 __global__ void __launch_bounds__(FIN_TB)
 k_critic_final_fused(Critic C, RowsIn R, float gp_weight, const double* __restrict__ part_rows, int row_blocks, int gap_blocks,
                      const float* __restrict__ P_gap, const float* __restrict__ P_gp, float* __restrict__ loss,
-                     float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2) {
+                     float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2,
+                     CriticAdam ad) {
     __shared__ float cg[FIN_CH][64], cp[FIN_CH][64];
+    // the update of element i of tensor k (0 W1, 1 b1, 2 w2, 3 b2) by the thread that formed its gradient; the step
+    // counters were incremented by the row kernel
+    auto update = [&](int k, int64_t i, float g) {
+        if (ad.on)
+            gda_adam_element(ad.p[k] + i, g, ad.m[k] + i, ad.v[k] + i, gda_adam_coef(*ad.step[k], ad.lr, ad.beta1, ad.beta2),
+                             ad.beta1, ad.beta2, ad.eps, ad.weight_decay);
+    };
     const int t = threadIdx.x, a = C.a, lane = t % 64, chain = t / 64;
     const int64_t pe = (int64_t)a * C.h, e = (int64_t)blockIdx.x * 64 + lane;
+    // the W1 entry this thread will update, its moments and the bias corrections: fetched beside the partials
+    float w_p = 0.f, w_m = 0.f, w_v = 0.f;
+    GdaAdamCoef w_c{0.f, 1.f};
+    if (ad.on && chain == 0 && e < pe) {
+        w_p = ad.p[0][e]; w_m = ad.m[0][e]; w_v = ad.v[0][e];
+        w_c = gda_adam_coef(*ad.step[0], ad.lr, ad.beta1, ad.beta2);
+    }
     if (e < pe) {
         cg[chain][lane] = chain_sum(P_gap, pe, e, gap_blocks, chain);
         cp[chain][lane] = chain_sum(P_gp, pe, e, row_blocks, chain);
@@ -849,7 +874,7 @@ k_critic_final_fused(Critic C, RowsIn R, float gp_weight, const double* __restri
             const double g0 = column_sum(part_rows, k, row_blocks, lane), g1 = column_sum(part_rows, a + 1 + k, row_blocks, lane);
             if (lane == 0) {
                 const float v = (float)(-(double)sgn * g0 + g1);
-                if (k < a) gw2[k] = v; else gb2[0] = v;
+                if (k < a) { gw2[k] = v; update(2, k, v); } else { gb2[0] = v; update(3, 0, v); }
             }
         } else if (k == a + 1) {
             const double gp = column_sum(part_rows, 2 * a + 2, row_blocks, lane);
@@ -858,7 +883,7 @@ k_critic_final_fused(Critic C, RowsIn R, float gp_weight, const double* __restri
         } else {               // first-layer bias of unit k - a - 2
             const int u = k - a - 2;
             const double g0 = column_sum(part_rows, 2 * a + 5 + u, row_blocks, lane), g1 = column_sum(part_rows, 3 * a + 5 + u, row_blocks, lane);
-            if (lane == 0) gb1[u] = (float)(-(double)sgn * g0 + g1);
+            if (lane == 0) { const float v = (float)(-(double)sgn * g0 + g1); gb1[u] = v; update(1, u, v); }
         }
     }
     __syncthreads();
@@ -866,7 +891,12 @@ k_critic_final_fused(Critic C, RowsIn R, float gp_weight, const double* __restri
         float g = 0.f, p = 0.f;
 #pragma unroll
         for (int c = 0; c < FIN_CH; ++c) { g += cg[c][lane]; p += cp[c][lane]; }
-        gW1[e] = -sgn * g + p;
+        const float v = -sgn * g + p;
+        gW1[e] = v;
+        if (ad.on) {
+            ad.p[0][e] = gda_adam_value(w_p, v, w_m, w_v, w_c, ad.beta1, ad.beta2, ad.eps, ad.weight_decay);
+            ad.m[0][e] = w_m; ad.v[0][e] = w_v;
+        }
     }
 }
 
@@ -919,12 +949,12 @@ extern "C" size_t gda_wgan_critic_workspace_bytes(int64_t n_s, int64_t n_t, int6
     return carve(nullptr, n_s, n_t, n_i, h, a).total;
 }
 
-extern "C" int gda_wgan_critic_f32(const float* es, int64_t n_s, const float* et, int64_t n_t, int h,
-                                   const int32_t* idx_s, const int32_t* idx_t, const float* alpha, int64_t n_i,
-                                   const float* W1, const float* b1, const float* w2, const float* b2, int a,
-                                   float dropout_p, uint64_t seed, const int64_t* step, uint32_t site,
-                                   float gp_weight, float* loss, float* gW1, float* gb1, float* gw2, float* gb2,
-                                   void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+static int critic_update(const float* es, int64_t n_s, const float* et, int64_t n_t, int h,
+                         const int32_t* idx_s, const int32_t* idx_t, const float* alpha, int64_t n_i,
+                         const float* W1, const float* b1, const float* w2, const float* b2, int a,
+                         float dropout_p, uint64_t seed, const int64_t* step, uint32_t site,
+                         float gp_weight, float* loss, float* gW1, float* gb1, float* gw2, float* gb2,
+                         const CriticAdam& ad, void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
     if (n_s <= 0 || n_t <= 0 || n_i < 0 || h <= 0 || a <= 0 || h > HMAX || a > AMAX || h % 4 != 0) return GDA_E_SIZE;
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) return GDA_E_SIZE;
     if (2 * (n_s + n_t) + n_i >= INT32_MAX / 2) return GDA_E_SIZE;
@@ -941,6 +971,7 @@ extern "C" int gda_wgan_critic_f32(const float* es, int64_t n_s, const float* et
     const int ldy = h + 4;
     // the matrix-core path: h = 64, 96, 128 (LDS: W1, four X | Y tiles, four U tiles)
     const bool mfma = h % 32 == 0 && h >= 64 && h <= 128 && a % 4 == 0 && ((uintptr_t)es | (uintptr_t)et | (uintptr_t)W1) % 16 == 0;
+    if (ad.on && !mfma) return GDA_E_UNSUPPORTED;         // the update rides in the matrix-core path's final launch only
     int row_blocks = ROW_BLOCKS;
     if (mfma) {
         // 32 rows per wavefront, four tiles per workgroup and trip: as many workgroups as there are quads (at most ROW_BLOCKS)
@@ -954,7 +985,7 @@ extern "C" int gda_wgan_critic_f32(const float* es, int64_t n_s, const float* et
         {                                                                                                            \
             GDA_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_critic_rows_mfma<HT>),                   \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-            k_critic_rows_mfma<HT><<<row_blocks, TB, lds, stream>>>(C, R, dr, gp_weight, ws.P_gap, ws.P_gp, ws.part_rows); \
+            k_critic_rows_mfma<HT><<<row_blocks, TB, lds, stream>>>(C, R, dr, gp_weight, ws.P_gap, ws.P_gp, ws.part_rows, ad); \
         }
         switch (h / 32) {
             case 2: GDA_CRITIC_MFMA(2) break;
@@ -964,7 +995,7 @@ extern "C" int gda_wgan_critic_f32(const float* es, int64_t n_s, const float* et
 #undef GDA_CRITIC_MFMA
         GDA_LAUNCH_CHECK();
         k_critic_final_fused<<<(unsigned)gda_cdiv((int64_t)a * h, 64), FIN_TB, 0, stream>>>(
-            C, R, gp_weight, ws.part_rows, row_blocks, gap_blocks, ws.P_gap, ws.P_gp, loss, gW1, gb1, gw2, gb2);
+            C, R, gp_weight, ws.part_rows, row_blocks, gap_blocks, ws.P_gap, ws.P_gp, loss, gW1, gb1, gw2, gb2, ad);
         GDA_LAUNCH_CHECK();
         return GDA_OK;
     } else {
@@ -989,4 +1020,37 @@ extern "C" int gda_wgan_critic_f32(const float* es, int64_t n_s, const float* et
                                          loss, gW1, gb1, gw2, gb2);
     GDA_LAUNCH_CHECK();
     return GDA_OK;
+}
+
+extern "C" int gda_wgan_critic_f32(const float* es, int64_t n_s, const float* et, int64_t n_t, int h,
+                                   const int32_t* idx_s, const int32_t* idx_t, const float* alpha, int64_t n_i,
+                                   const float* W1, const float* b1, const float* w2, const float* b2, int a,
+                                   float dropout_p, uint64_t seed, const int64_t* step, uint32_t site,
+                                   float gp_weight, float* loss, float* gW1, float* gb1, float* gw2, float* gb2,
+                                   void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    CriticAdam ad{};
+    return critic_update(es, n_s, et, n_t, h, idx_s, idx_t, alpha, n_i, W1, b1, w2, b2, a, dropout_p, seed, step, site,
+                         gp_weight, loss, gW1, gb1, gw2, gb2, ad, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int gda_wgan_critic_adam_f32(const float* es, int64_t n_s, const float* et, int64_t n_t, int h,
+                                        const int32_t* idx_s, const int32_t* idx_t, const float* alpha, int64_t n_i,
+                                        int a, float dropout_p, uint64_t seed, const int64_t* step, uint32_t site,
+                                        float gp_weight, float* loss, const gda_adam_tensor* params, float lr, float beta1,
+                                        float beta2, float eps, float weight_decay,
+                                        void* workspace, size_t workspace_bytes, gda_stream_t stream_) {
+    if (!params) return GDA_E_NULL;
+    CriticAdam ad{};
+    const int64_t want[4] = {(int64_t)a * h, a, a, 1};
+    for (int k = 0; k < 4; ++k) {
+        const gda_adam_tensor& t = params[k];
+        if (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq || !t.step) return GDA_E_NULL;
+        if (t.numel != want[k]) return GDA_E_SIZE;
+        ad.p[k] = t.param; ad.m[k] = t.exp_avg; ad.v[k] = t.exp_avg_sq; ad.step[k] = t.step;
+    }
+    ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps; ad.weight_decay = weight_decay; ad.on = 1;
+    return critic_update(es, n_s, et, n_t, h, idx_s, idx_t, alpha, n_i, params[0].param, params[1].param, params[2].param,
+                         params[3].param, a, dropout_p, seed, step, site, gp_weight, loss, const_cast<float*>(params[0].grad),
+                         const_cast<float*>(params[1].grad), const_cast<float*>(params[2].grad), const_cast<float*>(params[3].grad),
+                         ad, workspace, workspace_bytes, stream_);
 }

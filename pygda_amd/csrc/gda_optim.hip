@@ -12,6 +12,7 @@
 // finish -- was measured and dropped: the device-scope release it needs writes back the XCD's whole
 // dirty L2 on gfx950, 64-77 us per call against 5-9 us for the generic two-kernel reduction.)
 #include "gda_common.h"
+#include "gda_adam_rule.h"
 
 namespace {
 
@@ -35,11 +36,7 @@ k_adam(AdamTable t, float lr, float beta1, float beta2, float eps, float weight_
     int k = 0;
     while (k + 1 < t.n && item >= t.first_item[k + 1]) ++k;
     const int64_t base = (item - t.first_item[k]) * ITEM;
-    const float step = *t.step[k];                            // already incremented for this update
-    const float bc1 = 1.0f - powf(beta1, step);
-    const float bc2 = 1.0f - powf(beta2, step);
-    const float step_size = lr / bc1;
-    const float bc2_sqrt = sqrtf(bc2);
+    const GdaAdamCoef coef = gda_adam_coef(*t.step[k], lr, beta1, beta2);      // the counter is already incremented for this update
     float* __restrict__ p = t.p[k];
     const float* __restrict__ g = t.g[k];
     const float* __restrict__ g2 = t.g2[k];
@@ -50,17 +47,9 @@ k_adam(AdamTable t, float lr, float beta1, float beta2, float eps, float weight_
     for (int u = 0; u < ITEM / TB; ++u) {
         const int64_t i = base + u * TB + threadIdx.x;
         if (i >= n) break;
-        const float pi = p[i];
         float gi = g[i];
         if (g2) gi = gi + g2[i];                               // what autograd's accumulation would have stored (one rounding)
-        if (weight_decay != 0.f) gi = gi + weight_decay * pi;
-        float mi = m[i], vi = v[i];
-        mi = mi + (gi - mi) * (1.0f - beta1);                // torch: exp_avg.lerp_(grad, 1 - beta1)
-        vi = vi * beta2 + (1.0f - beta2) * gi * gi;          // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = pi - step_size * (mi / denom);                // param.addcdiv_(exp_avg, denom, -step_size)
-        m[i] = mi;
-        v[i] = vi;
+        gda_adam_element(p + i, gi, m + i, v + i, coef, beta1, beta2, eps, weight_decay);      // gda_adam_rule.h
     }
 }
 

@@ -53,6 +53,18 @@ class AdaGCN(BaseGDA):
         return self._gmean(torch.mean(self.discriminator(es).reshape(-1)), es.size(0)) \
             - self._gmean(torch.mean(self.discriminator(et).reshape(-1)), et.size(0))
 
+    def _encoder_loss(self, cls_loss, es, et):
+        """``cls_loss + domain_weight * |E D(e_s) - E D(e_t)|`` (:186-196)."""
+        d = self.discriminator
+        from ..distributed import active
+        if (torch.is_grad_enabled() and not active() and self._fused_critic(es) and d[0].in_features <= 128
+                and cls_loss.dim() == 0 and os.environ.get("PYGDA_AMD_FUSED_GAP_LOSS", "1") == "1"):
+            from ..ops import critic_abs_gap_loss, critic_means_ok
+            if critic_means_ok(es, d[0].weight, d[3].weight):
+                return critic_abs_gap_loss(cls_loss, es, et, d[0].weight, d[0].bias, d[3].weight, d[3].bias,
+                                           d[2].p if d.training else 0.0, self.domain_weight)
+        return cls_loss + torch.abs(self._critic_gap(es, et)) * self.domain_weight
+
     def _fused_critic(self, es):
         """The closed-form critic update (csrc/gda_critic.hip) applies: the reference's critic
         (Linear -> ReLU -> Dropout -> Linear(., 1) -> Sigmoid) on the GPU, means taken over this process's rows."""
@@ -103,11 +115,11 @@ class AdaGCN(BaseGDA):
             off = (torch.arange(S, device=ei.device) * n).repeat_interleave(ei.size(1))
             rep = cache[key] = (ei, Data(x=None, edge_index=ei.repeat(1, S) + off, y=None))   # the entry keeps `ei` alive
             rep[1].edge_index._gda_static = True
-        return self.adagcn.forward_from(h0.repeat(S, 1), rep[1]).view(S, n, -1)
+        return self.adagcn.forward_from(h0, rep[1], copies=S).view(S, n, -1)
 
     def _critic_update_fused(self, es, et):
         from ..hipgraph import host_rand
-        from ..ops import wgan_critic_grads
+        from ..ops import wgan_critic_adam, wgan_critic_grads
         d = self.discriminator
         idx_s, idx_t = self._interp_indices(es.size(0), et.size(0), es.device)
         alpha = host_rand((idx_s.numel(), 1), es.device)                            # the reference's CPU draw
@@ -118,6 +130,11 @@ class AdaGCN(BaseGDA):
         if getattr(self, "_critic_loss", None) is None or self._critic_loss.device != es.device:
             self._critic_loss = torch.zeros(1, dtype=torch.float32, device=es.device)
         p_drop = d[2].p if d.training else 0.0
+        from ..distributed import active
+        if (not active() and os.environ.get("PYGDA_AMD_CRITIC_FUSED_ADAM", "1") == "1"
+                and wgan_critic_adam(es, et, idx_s, idx_t, alpha, params, self.c_optimizer, p_drop, self.gp_weight,
+                                     self._critic_loss)):
+            return                               # gradients AND the optimiser's step in the update's two launches
         wgan_critic_grads(es, et, idx_s, idx_t, alpha, *params, p_drop, self.gp_weight,
                           (self._critic_loss, *(p.grad for p in params)))
         _allreduce_grads(self.c_optimizer)       # data-parallel: replica critics stay identical
@@ -160,9 +177,9 @@ class AdaGCN(BaseGDA):
         encoded_target = net.forward_from(h0_t, target_data)
         source_logits = self.adagcn.cls_model(encoded_source)
         cls_loss = self._gmean(self._source_loss(source_logits, source_data.y), source_logits.size(0))
-        dis_loss = torch.abs(self._critic_gap(encoded_source, encoded_target))
+        loss = self._encoder_loss(cls_loss, encoded_source, encoded_target)
         target_logits = self.adagcn.cls_model(encoded_target)
-        return cls_loss + dis_loss * self.domain_weight, source_logits, target_logits
+        return loss, source_logits, target_logits
 
     def _source_loss(self, logits, labels):
         """``loss_func(source_logits, y)`` (adagcn.py:189) -- the fused loss kernels for the CrossEntropyLoss the trainer builds."""
@@ -203,9 +220,9 @@ class AdaGCN(BaseGDA):
         encoded_source, encoded_target = split_rows(net.forward_from(h0, both), ns)  # :186-196
         source_logits = net.cls_model(encoded_source)
         cls_loss = self._gmean(self._source_loss(source_logits, source_data.y), source_logits.size(0))
-        dis_loss = torch.abs(self._critic_gap(encoded_source, encoded_target))
+        loss = self._encoder_loss(cls_loss, encoded_source, encoded_target)
         target_logits = net.cls_model(encoded_target)
-        return cls_loss + dis_loss * self.domain_weight, source_logits, target_logits
+        return loss, source_logits, target_logits
 
     def _prepare(self, source_data, target_data):
         # mode='graph' (adagcn.py:244-252, adagcn_base.py:93-94): shuffled DataLoader batches, the encoder's output

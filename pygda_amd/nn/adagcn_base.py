@@ -24,7 +24,7 @@ class GNN(nn.Module):
     def forward(self, x, edge_index, batch, mode='node'):
         return self.forward_from(self.conv_layers[0](x, edge_index), edge_index, batch, mode)
 
-    def forward_from(self, h0, edge_index, batch, mode='node'):
+    def forward_from(self, h0, edge_index, batch, mode='node', copies=1):
         """The stack continued from the output of its first conv (before activation / dropout).  That output
         is a deterministic function of the inputs and the weights, so the trainer evaluates it once per domain
         and step and shares it between the 11 encoder passes the reference makes per step (10 inside the critic
@@ -34,6 +34,14 @@ class GNN(nn.Module):
         for i, conv in enumerate(self.conv_layers):
             if i > 0:
                 x = conv(x, edge_index)
+            if i == 0 and copies > 1:
+                # `copies` passes over the same h0 (the critic loop's re-encodings, under no_grad) as ONE stacked pass:
+                # `edge_index` is the block-diagonal graph of the copies; the first activation reads h0 for every copy
+                if i < last and self.act is F.relu and x.is_cuda and x.dtype == torch.float32:
+                    from ..ops import relu_dropout_copies
+                    x = relu_dropout_copies(x, copies, self.dropout.p, self.dropout.training)
+                    continue
+                x = x.repeat(copies, 1)
             if i < last:
                 if self.act is F.relu and x.is_cuda and x.dtype == torch.float32:
                     from ..ops import relu_dropout                  # one kernel each way, no mask tensor
@@ -59,6 +67,6 @@ class AdaGCNBase(nn.Module):
     def first_conv(self, data):
         return self.encoder.conv_layers[0](data.x, data.edge_index)
 
-    def forward_from(self, h0, data):
+    def forward_from(self, h0, data, copies=1):
         batch = None if self.mode == 'node' else data.batch
-        return self.encoder.forward_from(h0, data.edge_index, batch, mode=self.mode)
+        return self.encoder.forward_from(h0, data.edge_index, batch, mode=self.mode, copies=copies)

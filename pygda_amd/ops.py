@@ -1375,6 +1375,48 @@ class _CriticMeans(torch.autograd.Function):
         return _grl_mlp_bwd(ctx, torch.stack([g_s.reshape(()).to(torch.float32), g_t.reshape(()).to(torch.float32)]), 1)[:7]
 
 
+class _CriticMeansVec(torch.autograd.Function):
+    """:class:`_CriticMeans` with the kernel's result block ``[mean D(source), mean D(target), unused]`` handed on as ONE
+    tensor: its gradient arrives as one tensor too (no stack in front of the backward kernels)."""
+
+    @staticmethod
+    def forward(ctx, es, et, W1, b1, W2, b2, p):
+        return _grl_mlp_fwd(ctx, es, et, W1, b1, W2, b2, -1.0, p, head=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _grl_mlp_bwd(ctx, g.to(torch.float32).contiguous(), 1)[:7]
+
+
+class _AddAbsGap(torch.autograd.Function):
+    """``base + weight * |v[0] - v[1]|`` for a scalar ``base`` and a device vector ``v`` in four small launches forward and
+    one backward (the composed expression and its autograd graph: seventeen)."""
+    _wvec = {}
+
+    @staticmethod
+    def forward(ctx, base, v, weight):
+        key = (float(weight), v.device, v.numel())
+        wv = _AddAbsGap._wvec.get(key)
+        if wv is None:
+            wv = _AddAbsGap._wvec[key] = torch.tensor([weight, -weight] + [0.0] * (v.numel() - 2), dtype=torch.float32, device=v.device)
+        d = v[0] - v[1]
+        svec = torch.sign(d) * wv                         # d |gap| / d v, times the weight
+        ctx.save_for_backward(svec)
+        return torch.addcmul(base, d, svec[0])            # d * sign(d) * weight = weight * |d|
+
+    @staticmethod
+    def backward(ctx, g):
+        (svec,) = ctx.saved_tensors
+        return g, g * svec, None
+
+
+def critic_abs_gap_loss(base, source_feat, target_feat, W1, b1, W2, b2, dropout_p, weight):
+    """``base + weight * |mean D(source) - mean D(target)|`` (AdaGCN's encoder loss, adagcn.py:186-193) for the
+    sigmoid-headed two-layer critic: the fused means (:func:`critic_means`) and the scalar tail in a handful of launches."""
+    v = _CriticMeansVec.apply(source_feat, target_feat, W1, b1, W2, b2, dropout_p)
+    return _AddAbsGap.apply(base, v, float(weight))
+
+
 def critic_means_ok(es, W1, W2):
     return (es.is_cuda and es.dtype == torch.float32 and es.dim() == 2 and es.size(1) <= 128
             and W1.size(0) <= 64 and W2.dim() == 2 and W2.size(0) == 1)
@@ -1484,6 +1526,52 @@ def wgan_critic_grads(es, et, idx_s, idx_t, alpha, W1, b1, W2, b2, dropout_p, gp
             float(gp_weight), _lib.ptr(loss), _lib.ptr(gW1), _lib.ptr(gb1), _lib.ptr(gW2), _lib.ptr(gb2),
             _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_wgan_critic_f32")
     return loss
+
+
+def wgan_critic_adam(es, et, idx_s, idx_t, alpha, params, optimizer, dropout_p, gp_weight, loss):
+    """One iteration of AdaGCN's critic loop INCLUDING ``c_optimizer.step()`` (pygda/models/adagcn.py:169-183) in the two
+    launches of :func:`wgan_critic_grads` (include/gda_hip.h: gda_wgan_critic_adam_f32): ``params = (W1, b1, W2, b2)`` with
+    preallocated ``.grad``, ``optimizer`` the :class:`pygda_amd.optim.Adam` that holds exactly them in one group.  Returns
+    False -- nothing launched, nothing changed -- when the shapes are not the matrix-core path's or the optimiser is not
+    of that form; the caller then runs :func:`wgan_critic_grads` + ``optimizer.step()``: the same bits."""
+    from .optim import Adam
+    if not isinstance(optimizer, Adam) or len(optimizer.param_groups) != 1 or optimizer.grad_aliases:
+        return False
+    group = optimizer.param_groups[0]
+    if len(group["params"]) != 4 or any(a is not b for a, b in zip(group["params"], params)):
+        return False
+    es, et = _f32c(es, "encoded_source"), _f32c(et, "encoded_target")
+    n_s, h = es.shape
+    n_t, a = et.size(0), params[0].size(0)
+    W1 = params[0]
+    if not (h in (64, 96, 128) and a % 4 == 0 and all(p.is_contiguous() and p.dtype == torch.float32 for p in params)
+            and (es.data_ptr() | et.data_ptr() | W1.data_ptr()) % 16 == 0):
+        return False
+    n_i = 0 if idx_s is None else idx_s.numel()
+    L = _lib.lib()
+    ws = _lib.workspace(L.gda_wgan_critic_workspace_bytes(n_s, n_t, n_i, h, a), es.device, "critic")
+    table = (_lib.AdamTensorStruct * 4)()
+    for k, p in enumerate(params):
+        stt = optimizer._state(p)
+        if p.grad is None or not p.grad.is_contiguous() or any(stt[n].stride() != p.stride() for n in ("exp_avg", "exp_avg_sq")):
+            return False
+        table[k] = _lib.AdamTensorStruct(p.data_ptr(), p.grad.data_ptr(), stt["exp_avg"].data_ptr(),
+                                         stt["exp_avg_sq"].data_ptr(), stt["step"].data_ptr(), p.numel())
+    st = dropout_state
+    if st.seed is None:
+        st.seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+    site = st.next_site()
+    st.next_site(); st.next_site()                          # three mask sets: D(es), D(et), penalty rows
+    b1_, b2_ = group["betas"]
+    rows_gp = n_s + n_t + n_i
+    with profiler.region(f"wgan_critic[{h}x{a}]", 2, 4 * h * (n_s + n_t + 2 * n_i), 2 * a * h * (4 * rows_gp + n_s + n_t)):
+        _lib.check(L.gda_wgan_critic_adam_f32(
+            _lib.ptr(es), n_s, _lib.ptr(et), n_t, h, _lib.ptr(idx_s), _lib.ptr(idx_t),
+            _lib.ptr(None if alpha is None else _f32c(alpha, "alpha")), n_i, a,
+            float(dropout_p), ctypes.c_uint64(st.seed), _lib.ptr(st.counter(es.device)), ctypes.c_uint32(site),
+            float(gp_weight), _lib.ptr(loss), table, float(group["lr"]), float(b1_), float(b2_), float(group["eps"]),
+            float(group["weight_decay"]), _lib.ptr(ws), ws.numel(), _lib.stream()), "gda_wgan_critic_adam_f32")
+    return True
 
 
 # -------------------------------------------------------------------------- gather --
@@ -1981,6 +2069,24 @@ def relu_dropout_split(x, p, training=True):
             and x.size(0) % 2 == 0 and (x.size(0) // 2 * x.size(1)) % 4 == 0):
         return _ReluDropoutSplit.apply(x, float(p))
     return split_halves(relu_dropout(x, p, training))
+
+
+def relu_dropout_copies(x, copies, p, training=True):
+    """``F.dropout(F.relu(x.repeat(copies, 1)), p, training)`` for ``x [n, d]`` without materialising the copies
+    (include/gda_hip.h: gda_relu_dropout_tiled_fwd_f32); forward only."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        raise _lib.GdaError("relu_dropout_copies is forward-only: call it under torch.no_grad()")
+    if (not training or p <= 0.0 or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.numel() % 4 != 0
+            or not x.is_contiguous() or x.data_ptr() % 16 != 0):
+        return relu_dropout(x.repeat(copies, 1), p, training)
+    y = torch.empty(copies * x.size(0), x.size(1), dtype=torch.float32, device=x.device)
+    st = dropout_state
+    if st.seed is None:
+        st.seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+    _lib.check(_lib.lib().gda_relu_dropout_tiled_fwd_f32(
+        _lib.ptr(x), x.numel(), int(copies), _lib.ptr(y), float(p), ctypes.c_uint64(st.seed), _lib.ptr(st.counter(x.device)),
+        ctypes.c_uint32(st.next_site()), _lib.stream()), "gda_relu_dropout_tiled_fwd_f32")
+    return y
 
 
 def relu_dropout(x, p, training=True):

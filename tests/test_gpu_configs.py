@@ -632,6 +632,51 @@ def test_wgan_critic_mfma_rows_equal_readlane_rows(h, a, ns, nt):
     assert bool((run(es, et, 0.3)[1] != run(es, et, 0.0)[1]).any())
 
 
+@pytest.mark.parametrize("h,a,ns,nt,wd", [(128, 40, 2100, 1700, 0.01), (64, 64, 300, 420, 0.0)])
+def test_wgan_critic_update_with_adam_inside_equals_grads_then_step(h, a, ns, nt, wd):
+    """gda_wgan_critic_adam_f32 (gradients + the critic optimiser's step in the update's two launches) against
+    gda_wgan_critic_f32 followed by optim.Adam.step(): three iterations with dropout from the same state -- parameters,
+    both moments, step counters, gradients and loss bit for bit (one statement of the rule: csrc/gda_adam_rule.h)."""
+    import torch.nn as nn
+    from pygda_amd.ops import dropout_state, wgan_critic_adam, wgan_critic_grads
+    from pygda_amd.optim import Adam
+    gen = torch.Generator().manual_seed(h * a)
+    es = torch.randn(ns, h, generator=gen).relu().to(DEV)
+    et = (torch.randn(nt, h, generator=gen) * 1.2 + 0.1).relu().to(DEV)
+    n_i = 2 * min(ns, nt)
+    idx_s = torch.randint(0, ns, (n_i,), generator=gen, dtype=torch.int32).to(DEV)
+    idx_t = torch.randint(0, nt, (n_i,), generator=gen, dtype=torch.int32).to(DEV)
+    alphas = [torch.rand(n_i, 1, generator=gen).to(DEV) for _ in range(3)]
+    torch.manual_seed(11)
+    proto = nn.Sequential(nn.Linear(h, a), nn.ReLU(), nn.Dropout(0.3), nn.Linear(a, 1), nn.Sigmoid()).to(DEV)
+
+    def run(fused):
+        import copy
+        d = copy.deepcopy(proto)
+        params = (d[0].weight, d[0].bias, d[3].weight, d[3].bias)
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        opt = Adam(d.parameters(), lr=0.01, weight_decay=wd)
+        loss = torch.zeros(1, device=DEV)
+        dropout_state.counter(es.device).fill_(3); dropout_state.site = 0
+        for al in alphas:
+            if fused:
+                assert wgan_critic_adam(es, et, idx_s, idx_t, al, params, opt, 0.3, 10.0, loss)
+            else:
+                wgan_critic_grads(es, et, idx_s, idx_t, al, *params, 0.3, 10.0, (loss, *(p.grad for p in params)))
+                opt.step()
+        return loss, params, [opt.state[p] for p in params]
+
+    (l0, p0, s0), (l1, p1, s1) = run(False), run(True)
+    exact(l0, l1)
+    for x, y, sx, sy in zip(p0, p1, s0, s1):
+        exact(x, y); exact(x.grad, y.grad)
+        for k in ("step", "exp_avg", "exp_avg_sq"):
+            exact(sx[k], sy[k])
+        assert float(sx["step"]) == 3.0
+    assert not torch.equal(p0[0], proto[0].weight)
+
+
 def test_adagcn_fused_critic_trajectory_equals_composed(monkeypatch):
     """AdaGCN.fit for three epochs with the fused critic update against the composed (torch autograd) one: same
     host draws, dropout off -> same losses, accuracies and critic weights."""

@@ -431,6 +431,54 @@ def test_critic_means_vs_torch(ns, nt, h, a):
         assert vals[0] == vals[1] and vals[0] != vals[2]
 
 
+def test_relu_dropout_copies_is_relu_dropout_of_the_repeated_rows():
+    """ops.relu_dropout_copies (gda_relu_dropout_tiled_fwd_f32: element i reads x[i % period], keep-bit of element i)
+    against relu_dropout(x.repeat(copies, 1)): the same draws, bit for bit; the copies differ from one another."""
+    from pygda_amd.ops import dropout_state
+    x = torch.randn(1237, 128, generator=torch.Generator().manual_seed(2)).to(DEV)
+    outs = []
+    for tiled in (False, True):
+        dropout_state.counter(torch.device(DEV)).fill_(4); dropout_state.site = 0
+        with torch.no_grad():
+            outs.append(ops.relu_dropout_copies(x, 10, 0.4) if tiled else ops.relu_dropout(x.repeat(10, 1), 0.4))
+    exact(outs[1], outs[0])
+    y = outs[1].view(10, 1237, 128)
+    assert not torch.equal(y[0], y[1]) and abs(float((y[3] > 0).float().mean()) - 0.3) < 0.02
+    with pytest.raises(Exception):
+        ops.relu_dropout_copies(x.clone().requires_grad_(), 2, 0.4)
+
+
+@pytest.mark.parametrize("swap", [False, True])
+def test_critic_abs_gap_loss_equals_composed_tail(swap):
+    """ops.critic_abs_gap_loss (the fused means handed on as one block + a five-launch scalar tail) against
+    ``base + w * |ms - mt|`` composed from ops.critic_means: the same kernels underneath, so the loss agrees to one
+    rounding and every gradient (inputs, critic parameters, base) bit for bit -- for both signs of the gap."""
+    gen = torch.Generator().manual_seed(4)
+    ns, nt, h, a = 700, 520, 128, 40
+    es, et = torch.randn(ns, h, generator=gen), torch.randn(nt, h, generator=gen) * 1.2 + 0.4
+    if swap:
+        es, et = et, es
+    d = torch.nn.Sequential(torch.nn.Linear(h, a), torch.nn.ReLU(), torch.nn.Dropout(0.0), torch.nn.Linear(a, 1), torch.nn.Sigmoid()).to(DEV)
+    outs = []
+    for fused in (False, True):
+        for p_ in d.parameters():
+            p_.grad = None
+        xs = [es.clone().to(DEV).requires_grad_(), et.clone().to(DEV).requires_grad_()]
+        base = torch.tensor(0.37, device=DEV, requires_grad=True)
+        args = (xs[0], xs[1], d[0].weight, d[0].bias, d[3].weight, d[3].bias, 0.0)
+        if fused:
+            loss = ops.critic_abs_gap_loss(base * 2.0, *args, 1.7)
+        else:
+            ms, mt = ops.critic_means(*args)
+            loss = base * 2.0 + torch.abs(ms - mt) * 1.7
+        (loss * 0.9).backward()
+        outs.append((loss.detach(), [x.grad for x in xs] + [p_.grad.clone() for p_ in d.parameters()] + [base.grad]))
+    close(outs[1][0], outs[0][0], rtol=1e-6)
+    assert float(outs[0][1][0].abs().max()) > 0
+    for g1, g0 in zip(outs[1][1], outs[0][1]):
+        exact(g1, g0)
+
+
 def test_block_diagonal_pair_of_graphs_aggregates_like_the_two_graphs():
     """graph.block_diag (BaseGDA._stacked_pair, UDAGCN's combined cached operators): rows, order and values of both
     ingested graphs are kept, so one aggregation over the pair is the two aggregations, bit for bit, both ways --
