@@ -39,6 +39,33 @@ __device__ __forceinline__ void vload(float (&r)[VEC], const float* __restrict__
     if constexpr (VEC == 4) { r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
 }
 
+// the same with the non-temporal hint (streamed once: do not keep the line in L2); the builtins take native vectors
+template <int VEC> struct NatT { using type = float __attribute__((ext_vector_type(VEC))); };
+template <> struct NatT<1> { using type = float; };
+
+template <int VEC>
+__device__ __forceinline__ void vload_nt(float (&r)[VEC], const float* __restrict__ p) {
+    using V = typename NatT<VEC>::type;
+    const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+    if constexpr (VEC == 1) { r[0] = v; }
+    else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) r[k] = v[k];
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void vstore_nt(float* __restrict__ p, const float (&r)[VEC]) {
+    using V = typename NatT<VEC>::type;
+    V v;
+    if constexpr (VEC == 1) { v = r[0]; }
+    else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[k] = r[k];
+    }
+    __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
+}
+
 template <int VEC>
 __device__ __forceinline__ void vstore(float* __restrict__ p, const float (&r)[VEC]) {
     using V = typename VecT<VEC>::type;
@@ -77,6 +104,7 @@ struct Epilogue {
     const float* gamma_dev;         // device scalar (a learnable filter coefficient) or NULL
     const float* z;                 // [n_rows, d] (ld = ldz) or NULL
     int64_t ldz;
+    int32_t hub_rows;               // HUB kernels: source rows below it are kept in L2, everything else is streamed
 };
 
 template <int VEC>
@@ -101,7 +129,12 @@ __device__ __forceinline__ void apply_epilogue(float (&acc)[VEC], const Epilogue
 // Measured against the shuffle form (tools/spmm_sweep.py with PYGDA_AMD_SPMM_LDS=1, profiles/r3_spmm_lds_vs_shuffle.jsonl).
 // TOUT: y is written TRANSPOSED, yT[c * ldy + row] (ldy >= n_rows) -- the column-major hand-over to the LDS-resident
 // K-step kernel (gda_kstep.hip) for a projection of sparse input features: no transpose launch between the two.
-template <int G, int VEC, bool EPI, bool STG = false, bool TOUT = false>
+// HUB (opt-in measurement variant; degree-ordered graphs: data.auto_reorder): the hub rows'
+// gathers -- source row below ep.hub_rows, a prefix that fits one XCD's L2 -- are ordinary loads, every other byte the
+// kernel touches (the neighbour lists, the tail rows' gathers, the result) carries the non-temporal hint, so that the
+// once-used tail does not push the hubs out of the L2 (R-MAT 2^22: a third of all edge endpoints lie in the first 8,192
+// rows).  What it buys is in the comment at hub_rows() below: not enough to be the default.
+template <int G, int VEC, bool EPI, bool STG = false, bool TOUT = false, bool HUB = false>
 __global__ void __launch_bounds__(TB)
 k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
        const float* __restrict__ val, int64_t n_rows, int d,
@@ -148,8 +181,8 @@ k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
         for (int32_t base = start; base < end; base += G) {
             // one (col, val) pair per lane: a coalesced G*8-byte tile of the neighbour list
             const int32_t k = base + lane_in_group;
-            const int32_t my_col = k < end ? colidx[k] : 0;
-            const float my_val = k < end ? val[k] : 0.0f;
+            const int32_t my_col = k < end ? (HUB ? __builtin_nontemporal_load(colidx + k) : colidx[k]) : 0;
+            const float my_val = k < end ? (HUB ? __builtin_nontemporal_load(val + k) : val[k]) : 0.0f;
             const int cnt = min((int32_t)G, end - base);
             if constexpr (STG) stg_tile[threadIdx.x] = make_int2(my_col, __float_as_int(my_val));   // same wave reads it back
             int e = 0;
@@ -161,7 +194,11 @@ k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                     int32_t cu;
                     if constexpr (STG) { const int2 p = stg_tile[stg_base + e + u]; cu = p.x; w[u] = __int_as_float(p.y); }
                     else { cu = __shfl(my_col, e + u, G); w[u] = __shfl(my_val, e + u, G); }
-                    if (col_ok) vload<VEC>(xv[u], x + (int64_t)cu * ldx + c);
+                    if constexpr (HUB) {
+                        if (col_ok) { if (cu < ep.hub_rows) vload<VEC>(xv[u], x + (int64_t)cu * ldx + c); else vload_nt<VEC>(xv[u], x + (int64_t)cu * ldx + c); }
+                    } else {
+                        if (col_ok) vload<VEC>(xv[u], x + (int64_t)cu * ldx + c);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u)
@@ -175,7 +212,8 @@ k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                 else { cu = __shfl(my_col, e, G); w = __shfl(my_val, e, G); }
                 float xv[VEC];
                 if (col_ok) {
-                    vload<VEC>(xv, x + (int64_t)cu * ldx + c);
+                    if (HUB && cu >= ep.hub_rows) vload_nt<VEC>(xv, x + (int64_t)cu * ldx + c);
+                    else vload<VEC>(xv, x + (int64_t)cu * ldx + c);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) acc[v] = __fadd_rn(acc[v], __fmul_rn(w, xv[v]));
                 }
@@ -192,6 +230,8 @@ k_spmm(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
             if constexpr (TOUT) {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) y[(int64_t)(c + v) * ldy + row] = acc[v];
+            } else if constexpr (HUB) {
+                vstore_nt<VEC>(y + row * ldy + c, acc);
             } else {
                 vstore<VEC>(y + row * ldy + c, acc);
             }
@@ -374,6 +414,14 @@ int dispatch_range(const int32_t* rowptr, const int32_t* colidx, const float* va
 #undef GO
 }
 
+// PYGDA_AMD_SPMM_HUB_ROWS = H > 0: the HUB kernel with source rows below H as the hubs (d = 128 launches).  OFF by default
+// -- measured on R-MAT 2^22, degree-ordered, d = 128 (profiles/r6_experiments.txt 19): L2-side traffic 32.9 -> 28.9 GB at
+// H = 6,144 (launch 4.52 -> 4.84 ms), 29.4 GB at H = 16,384 (4.55 ms): the hint steers a tenth of the bytes and no time.
+static int32_t hub_rows() {
+    static const int32_t v = getenv("PYGDA_AMD_SPMM_HUB_ROWS") ? (int32_t)atoi(getenv("PYGDA_AMD_SPMM_HUB_ROWS")) : 0;
+    return v > 0 ? v : 0;
+}
+
 template <int G, int VEC>
 int launch(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n_rows, int d,
            const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias, const RowSplit& sp,
@@ -389,7 +437,13 @@ int launch(const int32_t* rowptr, const int32_t* colidx, const float* val, int64
     else if (staged)
         k_spmm<G, VEC, false, true><<<(unsigned)(row_blocks + chunk_blocks), TB, 0, s>>>(
             rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, bias, sp, (unsigned)row_blocks, Epilogue{});
-    else
+    else if (const int32_t hub = (G == 32 && VEC == 4) ? hub_rows() : 0) {
+        Epilogue e{};
+        e.hub_rows = hub;
+        if constexpr (G == 32 && VEC == 4)
+            k_spmm<G, VEC, false, false, false, true><<<(unsigned)(row_blocks + chunk_blocks), TB, 0, s>>>(
+                rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, bias, sp, (unsigned)row_blocks, e);
+    } else
         k_spmm<G, VEC, false><<<(unsigned)(row_blocks + chunk_blocks), TB, 0, s>>>(
             rowptr, colidx, val, n_rows, d, x, ldx, y, ldy, bias, sp, (unsigned)row_blocks, Epilogue{});
     GDA_LAUNCH_CHECK();

@@ -431,6 +431,33 @@ def test_critic_means_vs_torch(ns, nt, h, a):
         assert vals[0] == vals[1] and vals[0] != vals[2]
 
 
+def test_spmm_hub_variant_is_bit_identical(tmp_path):
+    """The opt-in HUB variant of the d = 128 aggregation kernel (PYGDA_AMD_SPMM_HUB_ROWS: hub rows loaded normally,
+    everything else with the non-temporal hint) changes cache policy only: same bits as the default kernel (a child
+    process, the switch is read once per process)."""
+    import subprocess, sys, os
+    code = (
+        "import torch, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from pygda_amd import ops\n"
+        "from pygda_amd.graph import build_csr\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "n = 20000\n"
+        "ei = torch.randint(0, n, (2, 300000), generator=g)\n"
+        "ei[0, :60000] = torch.randint(0, 50, (60000,), generator=g)\n"
+        "G = build_csr(ei.cuda(), n, validate=False)\n"
+        "x = torch.randn(n, 128, generator=g).cuda()\n"
+        "y = ops.spmm_kstep(G, x, 2)\n"
+        "torch.save(y.cpu(), sys.argv[1])\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for hub in ("0", "37"):
+        f = str(tmp_path / f"y{hub}.pt")
+        env = dict(os.environ, PYGDA_AMD_SPMM_HUB_ROWS=hub)
+        subprocess.run([sys.executable, "-c", code, f], check=True, env=env, timeout=300)
+        outs.append(torch.load(f))
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().sum()) > 0
+
+
 def test_relu_dropout_copies_is_relu_dropout_of_the_repeated_rows():
     """ops.relu_dropout_copies (gda_relu_dropout_tiled_fwd_f32: element i reads x[i % period], keep-bit of element i)
     against relu_dropout(x.repeat(copies, 1)): the same draws, bit for bit; the copies differ from one another."""

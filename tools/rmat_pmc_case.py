@@ -36,4 +36,4 @@ x = torch.randn(n, d, device="cuda", generator=gen)
 for _ in range(6):
     y = ops.spmm_kstep(G, x, 1)
 torch.cuda.synchronize()
-print(mode, G.nnz, float(y[0, 0]))
+print(mode, G.nnz, float(y[0, 0]), float(y.double().sum()), float(y.double().abs().sum()))
