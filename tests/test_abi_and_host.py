@@ -1236,3 +1236,22 @@ def test_host_thread_pools_of_a_nodes_ranks_fit_the_cpu_quota():
         assert per >= 1 and ranks * per <= 16 - 4, (ranks, per)
     assert _cpu.pool_size_for(16.0, 128) == 12 and _cpu.pool_size_for(2.0, 128) == 1
     assert _cpu.pool_size_for(None, 128) == 128 and _cpu.pool_size_for(16.0, 8) == 8
+
+
+def test_add_abs_gap_function_equals_composed_expression_cpu():
+    """ops._AddAbsGap (the scalar tail of AdaGCN's encoder loss, pygda/models/adagcn.py:186-196): value and both
+    gradients of ``base + w * |v[0] - v[1]|`` against the composed expression, both signs of the gap (plain torch ops:
+    runs on the CPU)."""
+    import torch
+    from pygda_amd.ops import _AddAbsGap
+    for v0, v1 in ((0.7, 0.2), (0.1, 0.9)):
+        outs = []
+        for fused in (False, True):
+            base = torch.tensor(1.25, requires_grad=True)
+            v = torch.tensor([v0, v1, 0.0], requires_grad=True)
+            loss = _AddAbsGap.apply(base * 3.0, v, 2.5) if fused else base * 3.0 + torch.abs(v[0] - v[1]) * 2.5
+            (loss * 0.5).backward()
+            outs.append((loss.detach(), base.grad, v.grad))
+        assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-6)
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.allclose(outs[0][2], outs[1][2], rtol=0, atol=0)
+
